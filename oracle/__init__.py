@@ -1,0 +1,26 @@
+"""CPU oracle for the part-discovery training path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is shipped or measured as
+the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it, and there only as the
+checker / the reported CPU baseline.
+
+What it is: a line-by-line CPU restatement (torch-CPU, fp32 or fp64, plus
+independent NumPy versions of every non-convolution op) of the reference's
+TensorFlow-1.14 graph
+    cub/code/SB_model48i/model.py   (graph M:313-521, losses M:604-932)
+    cub/code/nn.py                  (ops)
+    cub/code/util.py:878-995        (fill_triangular)
+The reference cannot be imported here (TensorFlow 1.14, edflow, eddata,
+tfutils are absent and there is no network), so:
+
+    PARITY UNPINNED except ``fill_triangular`` -- the single op the
+    reference's own test-suite pins (cub/code/test_pytest.py:4-28, known answer
+    cub/code/util.py:894-897).  Everything else is pinned to this restatement,
+    its NumPy cross-checks, the docstring known-answers of nn.py and the
+    closed-form step-0 log values of cub/train/log.txt:204-260.
+
+Three externals are restated from their published behaviour and flagged
+UNVERIFIED where used: edflow ``VGG19Features`` (perceptual loss),
+``tfutils.draw_rect`` and the edflow per-key Adam wiring.
+"""
