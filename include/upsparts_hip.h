@@ -1,0 +1,239 @@
+/* upsparts_hip.h -- C ABI of libupsparts_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the part-discovery training hot path of
+ * CompVis/unsupervised-part-segmentation.  The reference has NO FFI of its own
+ * (it is TensorFlow-1.14 graph code); every entry point below replaces the stock
+ * TF op(s) that the cited reference lines execute.  Citations are relative to
+ * /root/reference:  M = cub/code/SB_model48i/model.py,  N = cub/code/nn.py.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *     (caller-owned, no hidden allocation) unless a parameter says "host";
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return value: 0 = ok, negative = UPS_E_* (no exceptions cross the ABI);
+ *   - activations are NHWC, element type UPS_F32 or UPS_BF16, with a physical
+ *     channel count that is a multiple of 8 (16-byte rows); accumulation is fp32;
+ *   - thread-compatible: one stream per concurrent caller.
+ */
+#ifndef UPSPARTS_HIP_H
+#define UPSPARTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UPS_ABI_VERSION 1
+
+enum { UPS_F32 = 0, UPS_BF16 = 1 };
+enum { UPS_ACT_NONE = 0, UPS_ACT_LRELU = 1, UPS_ACT_RELU = 2 };
+enum { UPS_OK = 0, UPS_E_ARG = -1, UPS_E_UNSUPPORTED = -2, UPS_E_LAUNCH = -3 };
+
+int ups_abi_version(void);
+/* human readable description of the last error on this thread (host string) */
+const char* ups_last_error(void);
+
+/* ---------------------------------------------------------------- convolution engine
+ * Implicit-GEMM gather convolution on MFMA (bf16 32x32x16 / exact-f32 32x32x2).
+ * One kernel serves tf.nn.conv2d forward (N:617-664, nin N:811-813, downsample
+ * N:816-817) and its input gradient (dgrad), for stride 1 and 2 with TF 'SAME'
+ * padding, by describing the op as
+ *     out[img, i*out_sy+out_oy, j*out_sx+out_ox, c] =
+ *         epi( sum_t sum_k in[img, i*in_sy+tap_dy[t], j*in_sx+tap_dx[t], k] * w[tap_w[t]][c][k] )
+ * over the lattice i<ho, j<wo.  Out-of-range source pixels read as zero.
+ * epi:  v = acc + bias[c] + coord_affine(c) ; v *= act'(dact[pix][c]) ; v += res[pix][c].
+ */
+typedef struct {
+    int32_t dtype;            /* UPS_F32 / UPS_BF16: element type of in, w, res, dact and (unless out_f32) out */
+    int32_t n, hi, wi;        /* input tensor [n, hi, wi, ldi] */
+    int32_t ci;               /* reduction channels per tap (multiple of 8, <= ldi) */
+    int32_t ldi;              /* physical input channels */
+    int32_t ho, wo;           /* lattice points per image */
+    int32_t co;               /* logical output channels = rows of each weight slice */
+    int32_t co_fill;          /* channels [co, co_fill) of out are written as zero (>= co) */
+    int32_t ldo;              /* physical channels of out */
+    int32_t out_h, out_w;     /* physical output spatial size */
+    int32_t out_sy, out_sx, out_oy, out_ox;
+    int32_t in_sy, in_sx;
+    int32_t ntaps, kh, kw;    /* taps are r-major (t = r*kw + s) when coord_tab is used */
+    int32_t tap_dy[9], tap_dx[9], tap_w[9];
+    int32_t act_in;           /* UPS_ACT_* applied to `in` while it is staged (fused lrelu/relu-on-load) */
+    float   act_slope;        /* leaky slope (0.2: N:755-756) */
+    int32_t out_f32;          /* 1: out is float regardless of dtype */
+    int32_t dact_kind;        /* UPS_ACT_* of the activation whose derivative multiplies the result (dgrad) */
+    int32_t ldr, ldd;         /* physical channels of res / dact */
+    const void*  in;
+    const void*  w;           /* [n_slices][co][ci], k contiguous, dtype */
+    void*        out;
+    const float* bias;        /* [co] or NULL */
+    const float* coord_tab;   /* [64][3][co] affine CoordConv table (ups_coord_table) or NULL */
+    const void*  res;         /* residual, same pixel lattice as out, or NULL */
+    const void*  dact;        /* pre-activation tensor for dact_kind, same lattice as out, or NULL */
+} ups_conv_desc;
+
+int ups_conv_igemm(const ups_conv_desc* d, void* stream);
+
+/* Weight gradient  dV[tap][ci][co] = sum_pix act(in)[src(pix,tap)][ci] * dout[pix][co]
+ * (gradient of N:661-663 w.r.t. V), split-K over pixels into fp32 slabs + deterministic reduce.
+ * grad layout is the TF variable layout HWIO with `cin_v` input channels (cin_v = ci_log (+2 CoordConv)). */
+typedef struct {
+    int32_t dtype;
+    int32_t n, hi, wi, ci, ldi;       /* forward input, ci = channels to differentiate (multiple of 8) */
+    int32_t ci_log;                   /* rows actually stored (logical input channels) */
+    int32_t cin_v;                    /* input-channel extent of grad (>= ci_log) */
+    int32_t ho, wo, co, ldo;          /* dout tensor [n, ho, wo, ldo], co logical */
+    int32_t in_sy, in_sx;
+    int32_t ntaps;
+    int32_t tap_dy[9], tap_dx[9], tap_w[9];
+    int32_t act_in; float act_slope;
+    int32_t splitk;                   /* from ups_conv_wgrad_plan */
+    const void* in; const void* dout;
+    float* grad;                      /* [kh*kw][cin_v][co] fp32 */
+    float* workspace;                 /* splitk * ntaps*cin_v*co floats */
+} ups_wgrad_desc;
+
+int ups_conv_wgrad_plan(const ups_wgrad_desc* d, int32_t* splitk, size_t* workspace_bytes);
+int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream);
+
+/* fp32 HWIO master weights -> dtype copies: w_fwd [tap][co][ci_pad] and w_dgrad [tap][ci_pad_rows][co_pad_k].
+ * src [ntaps][cin_v][co]; only input channels < ci_log are copied (CoordConv rows are handled by
+ * ups_coord_table); rows/cols beyond the logical extent are zero.  Either dst may be NULL. */
+int ups_weight_prep(const float* src, int32_t ntaps, int32_t cin_v, int32_t ci_log, int32_t co,
+                    int32_t dtype, void* w_fwd, int32_t ci_pad,
+                    void* w_dgrad, int32_t dgrad_rows, int32_t dgrad_k, void* stream);
+
+/* CoordConv (N:2123-2154) folded into an affine epilogue: tab[cls][0..2][c] with
+ * cls = ymask*8 + xmask (valid-tap bitmasks of the output pixel);
+ * contribution = tab[cls][0][c] + j*tab[cls][1][c] + i*tab[cls][2][c].
+ * V is the fp32 HWIO variable with ci_log+2 input channels; ax = 2/max(1,H-1), ay = 2/max(1,W-1). */
+int ups_coord_table(const float* V, int32_t kh, int32_t kw, int32_t ci_log, int32_t co,
+                    const int32_t* tap_dy, const int32_t* tap_dx, int32_t in_sy, int32_t in_sx,
+                    float ax, float ay, float* tab, void* stream);
+/* gsum[pix][c] = sum_n dout[n][pix][c] (fp32) */
+int ups_batch_sum(const void* dout, int32_t dtype, int32_t n, int64_t pix, int32_t co, int32_t ldo,
+                  float* gsum, void* stream);
+/* gradient of the two CoordConv rows of V and (optionally) the bias from gsum [ho*wo][co] */
+int ups_coord_wgrad(const float* gsum, int32_t hi, int32_t wi, int32_t ho, int32_t wo, int32_t co,
+                    int32_t kh, int32_t kw, const int32_t* tap_dy, const int32_t* tap_dx,
+                    int32_t in_sy, int32_t in_sx, float ax, float ay,
+                    int32_t ci_log, float* gradV, float* grad_bias, void* stream);
+/* grad_bias[c] = sum_rows dout[row][c]; workspace >= 1024*co floats */
+int ups_col_sum(const void* dout, int32_t dtype, int64_t rows, int32_t co, int32_t ldo,
+                float* out, float* workspace, void* stream);
+
+/* ---------------------------------------------------------------- resampling / pooling
+ * Legacy TF-1 bilinear x2 (N:834-847, tf.image.resize_images BILINEAR, no half-pixel centres). */
+int ups_bilinear2x_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+int ups_bilinear2x_bwd(const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+/* activate + global spatial mean (M:50-51): y[n][c] = mean_hw act(x) */
+int ups_act_mean_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t hw, int32_t c, int32_t act, float slope, void* stream);
+int ups_act_mean_bwd(const void* x, const void* gy, void* gx, int32_t dtype, int32_t n, int32_t hw, int32_t c, int32_t act, float slope, void* stream);
+/* 2x2/2 max pool on pre-activations (Keras VGG19 block*_pool); bwd routes to the first maximal element */
+int ups_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+int ups_maxpool2_bwd(const void* x, const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+/* copy `c` channels between tensors with different physical widths / offsets (concat for N:1049-1051) */
+int ups_copy_channels(const void* src, int32_t lds, void* dst, int32_t ldd, int32_t dtype, int64_t rows, int32_t c, void* stream);
+/* dst[row][0..c) += src[row][0..c) */
+int ups_add_channels(const void* src, int32_t lds, void* dst, int32_t ldd, int32_t dtype, int64_t rows, int32_t c, void* stream);
+
+/* ---------------------------------------------------------------- perceptual loss pieces (M:607-619, edflow VGG19Features)
+ * [-1,1] RGB fp32 [n,h,w,3] or dtype [n,h,w,ldx] -> BGR*255 - mean, dtype [n,h,w,8] (channels 3..7 zero) */
+int ups_vgg_preprocess_fwd(const void* x, int32_t x_is_f32, int32_t ldx, void* y, int32_t dtype, int64_t pixels, void* stream);
+int ups_vgg_preprocess_bwd(const void* gy, void* gx, int32_t dtype, int32_t ldgx, int64_t pixels, void* stream);
+/* partial[block] = sum |act(a) - act(b)| ; loss = scale * sum(partial) is finished by ups_sum_scale */
+int ups_l1_fwd(const void* a, const void* b, int32_t dtype, int64_t rows, int32_t c, int32_t ld, int32_t act,
+               float* partial, int32_t nblocks, void* stream);
+/* gb[row][c] = -scale * sign(act(a)-act(b)) * act'(b), pad channels zero (gradient w.r.t. the 2nd operand) */
+int ups_l1_bwd(const void* a, const void* b, void* gb, int32_t dtype, int64_t rows, int32_t c, int32_t ld, int32_t act,
+               const float* scale_dev, float scale, void* stream);
+/* out[0] (+)= scale * sum(partial[0..n)) */
+int ups_sum_scale(const float* partial, int32_t n, float scale, float* out, int32_t accumulate, void* stream);
+
+/* ---------------------------------------------------------------- part path
+ * l = mean + eps (N:1427-1433); m = softmax_P(l) (N:58-62); hard = (m == max_P m) (N:134-136);
+ * argmax = first maximal index (M:447,470).  eps, hard, argmax may be NULL.  All fp32, [pixels][P]. */
+int ups_part_softmax_fwd(const float* mean, const float* eps, float* l, float* m, float* hard, int64_t* argmax,
+                         int64_t pixels, int32_t P, void* stream);
+/* spatial soft-max moments (N:65-71, N:1541-1587) of gamma*x per (n,p) over H*W, optionally masked by
+ * (1 - rect) with integer rectangle centres `rect_c` [n*P][2] (y,x) and half sizes:
+ * stats[n][p] = {max, Z, sum e*k, sum e*k*gy, sum e*k*gx, sum e*k*(gy^2+gx^2), 0, 0},  e = exp(gamma*x - max) */
+int ups_spatial_moments(const float* x, int32_t n, int32_t h, int32_t w, int32_t P, float gamma,
+                        const int32_t* rect_c, int32_t half_h, int32_t half_w, float* stats, void* stream);
+/* `stats` must hold n*P*8 floats of result followed by n*8*P*6 floats of scratch (ups_spatial_moments_floats). */
+size_t ups_spatial_moments_floats(int32_t n, int32_t P);
+/* px[n*P][2] = int32(mu*h/2 + h/2) (M:441,459; truncation) from the un-masked stats */
+int ups_moments_to_px(const float* stats, int32_t count, int32_t h, int32_t* px, void* stream);
+/* tfutils.draw_rect (external; semantics inferred): out [n,h,w,P] fp32 */
+int ups_draw_rect(const int32_t* px, int32_t n, int32_t h, int32_t w, int32_t P, int32_t half_h, int32_t half_w,
+                  float* out, void* stream);
+/* mask_parts + apply_partwise transpose (M:176-187, N:97-103): out[(p*B+b)][y][x][0..8) = view[b][y][x][c]*hard[b][y][x][p] */
+int ups_mask_parts_fwd(const float* view, const float* hard, void* out, int32_t dtype, int32_t B, int64_t hw, int32_t P, void* stream);
+/* g_hard[b][pix][p] = sum_c g_out[(p*B+b)][pix][c] * view[b][pix][c] */
+int ups_mask_parts_bwd(const float* view, const void* g_out, float* g_hard, int32_t dtype, int32_t B, int64_t hw, int32_t P, void* stream);
+/* unpool_features + concat (M:225-249, 482-484): out[b][pix][f] = sum_p hard*feat[b][p][f]; out[..][F+p] = hard; pad zero */
+int ups_unpool_fwd(const float* hard, const float* feat, void* out, int32_t dtype, int32_t B, int64_t hw, int32_t P, int32_t F, int32_t ldo, void* stream);
+/* g_hard[b][pix][p] = sum_f g[..f]*feat[b][p][f] + g[..F+p];  g_feat_partial[blk][b][p][f] partial sums (blocks_per_image each) */
+int ups_unpool_bwd(const float* hard, const float* feat, const void* g, float* g_hard, float* g_feat,
+                   int32_t dtype, int32_t B, int64_t hw, int32_t P, int32_t F, int32_t ldo, void* stream);
+/* `g_feat` must hold B*P*F floats of result followed by scratch; total = ups_unpool_bwd_floats(B,P,F). */
+size_t ups_unpool_bwd_floats(int32_t B, int32_t P, int32_t F);
+
+/* ---------------------------------------------------------------- mask priors (M:652-797), fused
+ * One pass over l/m per view producing the partial sums, one fused backward producing dl.
+ * See csrc/priors.hip for the slot layout of `sums`. */
+typedef struct {
+    int32_t n, h, w, P;
+    int32_t view;                 /* 0: KL + entropy + mumford-shah + area + patch + gmrf ; 1: KL + variance */
+    int32_t entropy_ce;           /* 0: entropy_func "entropy", 1: "cross_entropy" (M:671-680) */
+    float gamma;
+    int32_t half_h, half_w;
+    float ms_alpha, ms_lambda;    /* 1.0, 1e-2 hard-coded at M:744-746 */
+    float w_kl, w_entropy, w_ms, w_area, w_patch, w_gmrf, w_var;  /* schedule weights at this step */
+    const float* l;               /* mean + eps */
+    const float* l_mean;          /* view 0 only (gmrf) */
+    const float* m;               /* softmax(l) */
+    const float* hard;
+    const int32_t* px;            /* rectangle centres [n*P][2] */
+    float* per_np;                /* [n][P][8] per-(image,part) sums */
+    float* sums;                  /* [16] global sums (zeroed by the call) */
+    const float* g_hard;          /* upstream gradient w.r.t. the STE hard mask or NULL (bwd) */
+    float* dl;                    /* d total / d l_mean (bwd); l = l_mean + eps, so the gmrf term is fused in */
+} ups_prior_desc;
+/* `sums` must hold 16 floats of result followed by scratch; total = ups_prior_sums_floats(n, P). */
+size_t ups_prior_sums_floats(int32_t n, int32_t P);
+int ups_prior_fwd(const ups_prior_desc* d, void* stream);
+int ups_prior_bwd(const ups_prior_desc* d, void* stream);
+
+/* ---------------------------------------------------------------- full-covariance latent (N:1134-1208, util.py:878-995)
+ * params [B][dim + dim(dim+1)/2] fp32.  samples[s][b][i] = mean + L (level[s]*eps[s][b]) ; kl_rows[b][i]. */
+/* `level` is a HOST array of S noise levels (S <= 8).  kl_rows may be NULL. */
+int ups_latent_fwd(const float* params, const float* eps, const float* level, int32_t S, int32_t B, int32_t dim,
+                   float* samples, float* kl_rows, void* stream);
+/* g_params = J^T g_samples + gk * d(sum_i kl_rows[b][i])/d params, gk = g_kl_scale * (g_kl_dev ? *g_kl_dev : 1) */
+int ups_latent_bwd(const float* params, const float* eps, const float* level, const float* g_samples,
+                   const float* g_kl_dev, float g_kl_scale,
+                   int32_t S, int32_t B, int32_t dim, float* g_params, void* stream);
+
+/* ---------------------------------------------------------------- optimizer (tf.train.AdamOptimizer, Appendix A.12)
+ * p -= lr_t * m / (sqrt(v) + eps) over a flat fp32 buffer; lr_t computed by the caller. */
+int ups_adam(float* p, const float* g, float* m, float* v, int64_t count, float lr_t, float beta1, float beta2, float eps,
+             float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------- Gaussian renderers (N:1639-1702, N:1976-2021)
+ * tf_hm: P_xy [B][K][2], stddev [B][K][2] on the integer pixel grid (x,y order) -> heat [B,h,w,K] */
+int ups_gauss_hm(const float* pts, const float* stddev, float* out, int32_t B, int32_t h, int32_t w, int32_t K, void* stream);
+/* tf_hm3: mu [B][K][2] (y,x in [-1,1]), L [B][K][2][2] -> density [B,h,w,K] */
+int ups_gauss_hm3(const float* mu, const float* L, float* out, int32_t B, int32_t h, int32_t w, int32_t K, void* stream);
+
+/* ---------------------------------------------------------------- misc
+ * dtype conversion of a flat buffer (fp32 <-> bf16) */
+int ups_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t count, void* stream);
+/* dst[row][0..c) = src[row][0..c) (fp32 -> dtype), dst[row][c..ldd) = 0 */
+int ups_pad_convert(const float* src, int32_t c, void* dst, int32_t dtype, int32_t ldd, int64_t rows, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UPSPARTS_HIP_H */

@@ -1,0 +1,321 @@
+"""GPU parity tests: every HIP kernel family (through the C ABI) against the CPU oracle on identical
+seeded inputs.  fp32 mode must meet north_star's 1e-3 relative tolerance (the kernel-level bars below
+are tighter); bf16 mode is compared with the oracle evaluated on bf16-rounded inputs at 2e-2."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from util import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 2e-4      # kernel-level bar for the fp32 (exact MFMA f32) path; north_star end-to-end bar is 1e-3
+BF16_TOL = 2e-2
+
+
+def _mods():
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import lib, ops
+    from oracle import ref_model as R
+    return lib, ops, R
+
+
+def _layer(ops, lib, V, b, k, stride, coords, act, dev):
+    return ops.ConvLayer("t/conv2d_0", V.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True), k, stride, coords,
+                         act)
+
+
+def _oracle_conv(R, x, V, b, stride, coords, act, res_self, res):
+    xa = x
+    if act == "leaky_relu":
+        xa = torch.nn.functional.leaky_relu(x, 0.2)
+    elif act == "relu":
+        xa = torch.relu(x)
+    if coords:
+        xa = R.Scope.add_coordinates(xa)
+    y = R.conv2d_same(xa, V, b, stride)
+    if res_self:
+        y = y + x
+    if res is not None:
+        y = y + res
+    return y
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, coords, act, res_self
+    (2, 16, 16, 8, 16, 3, 1, False, None, False),
+    (2, 16, 16, 16, 16, 3, 1, True, "leaky_relu", True),
+    (3, 16, 16, 16, 24, 3, 2, True, None, False),
+    (2, 12, 20, 32, 40, 3, 2, False, "leaky_relu", False),
+    (2, 8, 8, 64, 130, 3, 1, True, "leaky_relu", False),
+    (4, 1, 1, 16, 72, 1, 1, True, None, False),
+    (5, 4, 4, 16, 16, 1, 1, False, "leaky_relu", True),
+    (1, 32, 32, 8, 3, 3, 1, False, "relu", False),
+    (2, 9, 7, 8, 8, 3, 2, True, None, False),       # odd sizes: pad_before = 1 for stride 2
+    (1, 40, 40, 256, 256, 3, 1, True, "leaky_relu", True),
+]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case, dtype, dev):
+    lib, ops, R = _mods()
+    n, h, w, cin, cout, k, stride, coords, act, res_self = case
+    g = torch.Generator().manual_seed(100 + CONV_CASES.index(case))
+    cin_v = cin + (2 if coords else 0)
+    x = torch.randn(n, h, w, cin, generator=g)
+    V = torch.randn(k, k, cin_v, cout, generator=g) / math.sqrt(cin_v * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    T = torch.float32 if dtype == "fp32" else torch.bfloat16
+    tol = F32_TOL if dtype == "fp32" else BF16_TOL
+    if dtype == "bf16":     # the oracle sees the same rounded operands
+        x = x.to(T).float()
+    Vq = V.to(T).float() if dtype == "bf16" else V
+    # oracle (fp64) with autograd
+    xo = x.double().requires_grad_(True)
+    Vo = V.double().clone()
+    if dtype == "bf16":     # main channels are rounded by weight_prep, CoordConv rows stay fp32
+        Vo[:, :, :cin] = Vq[:, :, :cin].double()
+    Vo.requires_grad_(True)
+    bo = b.double().requires_grad_(True)
+    yo = _oracle_conv(R, xo, Vo, bo, stride, coords, act, res_self, None)
+    go = torch.randn(yo.shape, generator=g)
+    if dtype == "bf16":
+        go = go.to(T).float()
+    yo.backward(go.double())
+    # HIP
+    lay = _layer(ops, lib, V, b, k, stride, coords, act, dev)
+    xd = x.to(dev, T).requires_grad_(True)
+    y = ops.conv(xd, lay, res_self=res_self)
+    assert y.shape[-1] == ops.round8(cout)
+    assert_close(y[..., :cout].float(), yo.float(), tol, "conv fwd {}".format(case))
+    if y.shape[-1] > cout:
+        assert float(y[..., cout:].float().abs().max()) == 0.0
+    gd = torch.zeros(y.shape, dtype=T, device=dev)
+    gd[..., :cout] = go.to(dev, T)
+    gx, gV, gb = torch.autograd.grad([y], [xd, lay.V, lay.b], grad_outputs=[gd])
+    assert_close(gx.float(), xo.grad.float(), tol, "conv dgrad {}".format(case))
+    assert_close(gV.float(), Vo.grad.float(), tol * (4 if dtype == "bf16" else 1), "conv wgrad {}".format(case))
+    assert_close(gb.float(), bo.grad.float(), tol, "conv bias grad {}".format(case))
+
+
+def test_conv_f32_out_and_padded_input(dev):
+    """fp32 output with ldo == co (logits / latent head) and an input whose physical width exceeds Cin."""
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(3)
+    n, h, w, cin, cout = 2, 8, 8, 11, 10
+    x = torch.randn(n, h, w, cin, generator=g)
+    V = torch.randn(3, 3, cin, cout, generator=g) / 10
+    b = torch.randn(cout, generator=g)
+    yo = R.conv2d_same(x.double(), V.double(), b.double(), 1)
+    lay = _layer(ops, lib, V, b, 3, 1, False, None, dev)
+    xp = torch.zeros(n, h, w, 16)
+    xp[..., :cin] = x
+    xd = xp.to(dev).requires_grad_(True)
+    y = ops.conv(xd, lay, out_f32=True)
+    assert y.dtype == torch.float32 and y.shape[-1] == cout
+    assert_close(y, yo.float(), F32_TOL, "conv f32-out")
+    go = torch.randn(yo.shape, generator=g)
+    xo = x.double().requires_grad_(True)
+    Vo = V.double().requires_grad_(True)
+    R.conv2d_same(xo, Vo, b.double(), 1).backward(go.double())
+    gx, gV = torch.autograd.grad([y], [xd, lay.V], grad_outputs=[go.to(dev)])
+    assert_close(gx[..., :cin], xo.grad.float(), F32_TOL, "dgrad padded")
+    assert float(gx[..., cin:].abs().max()) == 0.0
+    assert_close(gV, Vo.grad.float(), F32_TOL, "wgrad padded")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bilinear_actmean_maxpool(dtype, dev):
+    lib, ops, R = _mods()
+    from oracle import np_ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 6, 5, 16, generator=g).to(dtype).float()
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    xo = x.double().requires_grad_(True)
+    yo = R.bilinear_up2(xo)
+    assert np.allclose(yo.detach().numpy(), np_ops.bilinear_up2(x.double().numpy()), atol=1e-12)
+    go = torch.randn(yo.shape, generator=g).to(dtype).float()
+    yo.backward(go.double())
+    xd = x.to(dev, dtype).requires_grad_(True)
+    y = ops.BilinearFn.apply(xd)
+    assert_close(y.float(), yo.float(), tol, "bilinear fwd")
+    (gx,) = torch.autograd.grad([y], [xd], grad_outputs=[go.to(dev, dtype)])
+    assert_close(gx.float(), xo.grad.float(), tol, "bilinear bwd")
+    # activate + mean
+    xo = x.double().requires_grad_(True)
+    yo = torch.nn.functional.leaky_relu(xo, 0.2).mean(dim=(1, 2), keepdim=True)
+    go = torch.randn(yo.shape, generator=g)
+    yo.backward(go.double())
+    xd = x.to(dev, dtype).requires_grad_(True)
+    y = ops.ActMeanFn.apply(xd, lib.ACT_LRELU, 0.2)
+    assert_close(y.float(), yo.float(), tol, "act_mean fwd")
+    (gx,) = torch.autograd.grad([y], [xd], grad_outputs=[go.to(dev, dtype)])
+    assert_close(gx.float(), xo.grad.float(), 2 * tol if tol > 1e-5 else 1e-5, "act_mean bwd")
+    # max pool
+    x2 = torch.randn(2, 6, 4, 16, generator=g).to(dtype).float()
+    xo = x2.double().requires_grad_(True)
+    yo = torch.nn.functional.max_pool2d(xo.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    go = torch.randn(yo.shape, generator=g).to(dtype).float()
+    yo.backward(go.double())
+    xd = x2.to(dev, dtype).requires_grad_(True)
+    y = ops.MaxPoolFn.apply(xd)
+    assert_close(y.float(), yo.float(), 1e-6, "maxpool fwd")
+    (gx,) = torch.autograd.grad([y], [xd], grad_outputs=[go.to(dev, dtype)])
+    assert_close(gx.float(), xo.grad.float(), 1e-6, "maxpool bwd")
+
+
+def test_l1_and_vgg_preprocess(dev):
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(3, 5, 5, 8, generator=g)
+    b = torch.randn(3, 5, 5, 8, generator=g)
+    bo = b.double().requires_grad_(True)
+    lo = (torch.relu(a.double()[..., :6]) - torch.relu(bo[..., :6])).abs().mean()
+    (3.0 * lo).backward()
+    bd = b.to(dev).requires_grad_(True)
+    l = ops.L1MeanFn.apply(a.to(dev), bd, 6, lib.ACT_RELU)
+    assert abs(float(l) - float(lo)) < 1e-6 * max(1.0, abs(float(lo)))
+    (gb,) = torch.autograd.grad([3.0 * l], [bd])
+    assert_close(gb[..., :6], bo.grad.float()[..., :6], 1e-5, "l1 bwd")
+    assert float(gb[..., 6:].abs().max()) == 0.0
+    img = torch.rand(2, 4, 4, 3, generator=g) * 2 - 1
+    y = ops.VggPreFn.apply(img.to(dev), torch.float32)
+    ref = torch.flip((img + 1) * 127.5, dims=[-1]) - torch.tensor(R.VGG_BGR_MEAN)
+    assert_close(y[..., :3], ref, 1e-6, "vgg preprocess")
+    assert float(y[..., 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("P", [3, 10, 25])
+def test_part_path(P, dev):
+    lib, ops, R = _mods()
+    from oracle import np_ops
+    g = torch.Generator().manual_seed(7 + P)
+    N, S, gamma, patch = 3, 16, 10.0, 6
+    mean = torch.randn(N, S, S, P, generator=g)
+    eps = torch.randn(N, S, S, P, generator=g)
+    l, m, hard, _ = ops.part_softmax(mean.to(dev), eps.to(dev))
+    lo = (mean + eps).double()
+    mo = torch.softmax(lo, dim=-1)
+    assert_close(l, lo.float(), 1e-6, "l")
+    assert_close(m, mo.float(), 1e-5, "softmax")
+    assert torch.equal(hard.cpu().argmax(-1), mo.argmax(-1))
+    assert float(hard.sum(-1).min()) >= 1.0
+    _, soft, _, am = ops.part_softmax(mean.to(dev), None, want_hard=False, want_argmax=True)
+    assert torch.equal(am.cpu(), torch.softmax(mean.double(), -1).argmax(-1))
+    # rectangle centres
+    ho = R.hard_max(mo)
+    rect_o, px_o = R.patch_mask(ho, gamma, patch)
+    stats = ops.spatial_moments(hard, gamma)
+    px = ops.moments_to_px(stats, S)
+    mu_o, _ = R.probs_to_mu_sigma(R.spatial_softmax(ho * gamma))
+    mu = torch.stack([stats[..., 3] / stats[..., 1], stats[..., 4] / stats[..., 1]], -1)
+    assert_close(mu, mu_o.float(), 1e-4, "mu")
+    frac = (mu_o * S / 2.0 + S / 2.0)
+    stable = ((frac - frac.round()).abs() > 1e-3).all(-1)      # truncation is only compared away from integer boundaries
+    assert torch.equal(px.cpu()[stable].long(), px_o[stable])
+    rect = ops.draw_rect(px, S, S, patch // 2)
+    rect_np = np_ops.draw_rect(px.cpu().numpy().reshape(-1, 2), patch, patch, S, S).reshape(N, P, S, S).transpose(0, 2, 3, 1)
+    assert np.array_equal(rect.cpu().numpy(), rect_np)
+    # masked moments (variance-loss statistics)
+    st2 = ops.spatial_moments(m, gamma, rect_px=px, half=patch // 2)
+    c1 = R.spatial_softmax(mo * gamma) * (1 - torch.from_numpy(rect_np).double())
+    mu2, sig2 = R.probs_to_mu_sigma(c1)
+    v_o = sig2[:, :, 0, 0] + sig2[:, :, 1, 1]
+    Z = st2[..., 1]
+    v = st2[..., 5] / Z - (st2[..., 3] / Z) ** 2 - (st2[..., 4] / Z) ** 2
+    assert_close(v, v_o.float(), 1e-4, "variance per part")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mask_parts_unpool(dtype, dev):
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(11)
+    B, S, P, F = 2, 8, 5, 16
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    view = torch.rand(B, S, S, 3, generator=g) * 2 - 1
+    hard = torch.nn.functional.one_hot(torch.randint(0, P, (B, S, S), generator=g), P).float()
+    hard[0, 0, 0] = torch.tensor([1.0, 1.0, 0, 0, 0])           # a tie
+    feat = torch.randn(B, P, F, generator=g)
+    ho = hard.double().requires_grad_(True)
+    parts = (view.double().unsqueeze(3) * ho.unsqueeze(4)).permute(3, 0, 1, 2, 4).reshape(P * B, S, S, 3)
+    gp = torch.randn(parts.shape, generator=g).to(dtype).float()
+    parts.backward(gp.double())
+    hd = hard.to(dev).requires_grad_(True)
+    out = ops.MaskPartsFn.apply(view.to(dev), hd, dtype)
+    assert_close(out[..., :3].float(), parts.float(), tol, "mask_parts fwd")
+    assert float(out[..., 3:].float().abs().max()) == 0.0
+    gd = torch.zeros(out.shape, dtype=dtype, device=dev)
+    gd[..., :3] = gp.to(dev, dtype)
+    (gh,) = torch.autograd.grad([out], [hd], grad_outputs=[gd])
+    assert_close(gh, ho.grad.float(), tol, "mask_parts bwd")
+    # unpool
+    ho = hard.double().requires_grad_(True)
+    fo = feat.double().requires_grad_(True)
+    inj = torch.cat([torch.einsum("bhwp,bpf->bhwf", ho, fo), ho], dim=3)
+    gi = torch.randn(inj.shape, generator=g).to(dtype).float()
+    inj.backward(gi.double())
+    hd = hard.to(dev).requires_grad_(True)
+    fd = feat.to(dev).requires_grad_(True)
+    out = ops.UnpoolFn.apply(hd, fd, dtype)
+    ld = ops.round8(F + P)
+    assert out.shape[-1] == ld
+    assert_close(out[..., :F + P].float(), inj.float(), tol, "unpool fwd")
+    gd = torch.zeros(out.shape, dtype=dtype, device=dev)
+    gd[..., :F + P] = gi.to(dev, dtype)
+    gh, gf = torch.autograd.grad([out], [hd, fd], grad_outputs=[gd])
+    assert_close(gh, ho.grad.float(), tol, "unpool d hard")
+    assert_close(gf, fo.grad.float(), tol, "unpool d feat")
+
+
+def test_latent(dev):
+    lib, ops, R = _mods()
+    from oracle import np_ops
+    g = torch.Generator().manual_seed(13)
+    for Z, B, S in ((8, 3, 7), (256, 2, 7), (40, 2, 1)):
+        NP = Z + Z * (Z + 1) // 2
+        params = torch.randn(B, NP, generator=g) * 0.3
+        eps = torch.randn(S, B, Z, generator=g)
+        levels = [1.0, 0.7, 0.7, 1.0, 1.0, 1.0, 1.0][:S]
+        po = params.double().requires_grad_(True)
+        d = R.FullLatent(po, Z)
+        so = torch.stack([d.sample(eps[s].double(), noise_level=levels[s]).reshape(B, Z) for s in range(S)])
+        klo = d.kl()
+        mean_np, L_np, ld_np = np_ops.full_latent(params.double().numpy(), Z)
+        assert abs(np_ops.full_latent_kl(mean_np, L_np, ld_np) - float(klo)) < 1e-9 * max(1, abs(float(klo)))
+        gs = torch.randn(S, B, Z, generator=g)
+        w_kl = 1.7
+        ((so * gs.double()).sum() + w_kl * klo).backward()
+        samples, kl_rows = ops.latent_fwd(params.to(dev), eps.to(dev), levels, True)
+        assert_close(samples, so.float(), 2e-5, "latent samples Z={}".format(Z))
+        assert abs(float(kl_rows.sum(1).mean()) - float(klo)) < 1e-4 * max(1.0, abs(float(klo)))
+        scale = torch.tensor([w_kl], device=dev)
+        gp = ops.latent_bwd(params.to(dev), eps.to(dev), levels, gs.to(dev), scale, 1.0 / B)
+        assert_close(gp, po.grad.float(), 5e-5, "latent bwd Z={}".format(Z))
+
+
+def test_adam_and_gauss(dev):
+    lib, ops, R = _mods()
+    from oracle import np_ops
+    g = torch.Generator().manual_seed(17)
+    p = torch.randn(1000, generator=g); gr = torch.randn(1000, generator=g)
+    m = torch.randn(1000, generator=g) * 0.1; v = torch.rand(1000, generator=g) * 0.1
+    t, lr, b1, b2 = 3, 2e-4, 0.5, 0.9
+    pn, mn, vn = np_ops.tf_adam_step(p.double().numpy(), gr.double().numpy(), m.double().numpy(), v.double().numpy(), t, lr, b1, b2)
+    pd, md, vd = p.to(dev), m.to(dev), v.to(dev)
+    ops.adam_step(pd, gr.to(dev), md, vd, lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t), b1, b2, 1e-8)
+    assert np.allclose(pd.cpu().numpy(), pn, rtol=1e-5, atol=1e-7)
+    assert np.allclose(md.cpu().numpy(), mn, rtol=1e-5, atol=1e-7)
+    assert np.allclose(vd.cpu().numpy(), vn, rtol=1e-5, atol=1e-7)
+    pts = torch.rand(2, 3, 2, generator=g) * 10
+    sd = torch.rand(2, 3, 2, generator=g) * 2 + 1
+    hm = ops.gauss_hm(pts.to(dev), sd.to(dev), 12, 10)
+    assert np.allclose(hm.cpu().numpy(), np_ops.tf_hm(pts.numpy(), 12, 10, sd.numpy()), rtol=1e-4, atol=1e-6)
+    mu = torch.rand(2, 3, 2, generator=g) - 0.5
+    Lt = torch.zeros(2, 3, 2, 2)
+    Lt[..., 0, 0] = 0.3 + torch.rand(2, 3, generator=g); Lt[..., 1, 1] = 0.3 + torch.rand(2, 3, generator=g)
+    Lt[..., 1, 0] = torch.randn(2, 3, generator=g) * 0.2
+    hm3 = ops.gauss_hm3(mu.to(dev), Lt.to(dev), 9, 11)
+    assert np.allclose(hm3.cpu().numpy(), np_ops.tf_hm3(9, 11, mu.numpy(), Lt.numpy()), rtol=1e-4, atol=1e-6)

@@ -1,0 +1,102 @@
+// Shared device helpers for libupsparts_hip (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/upsparts_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+void ups_set_error(const char* fmt, ...);
+
+#define UPS_CHECK_ARG(cond)                                                        \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            ups_set_error("%s:%d: argument check failed: %s", __FILE__, __LINE__, #cond); \
+            return UPS_E_ARG;                                                      \
+        }                                                                          \
+    } while (0)
+
+#define UPS_LAUNCH_CHECK()                                                         \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            ups_set_error("%s:%d: launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return UPS_E_LAUNCH;                                                   \
+        }                                                                          \
+    } while (0)
+
+// 16-byte chunk of T
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+    static constexpr int N = 4;
+    __device__ static inline void unpack(const uint4& u, float* f) {
+        f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct Chunk<bf16> {
+    static constexpr int N = 8;
+    __device__ static inline void unpack(const uint4& u, float* f) {
+        f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+        f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+        f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+        f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+    __device__ static inline unsigned pk(float a, float b) {
+        union { bf16 h[2]; unsigned u; } x;
+        x.h[0] = (bf16)a; x.h[1] = (bf16)b;   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+        return x.u;
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(pk(f[0], f[1]), pk(f[2], f[3]), pk(f[4], f[5]), pk(f[6], f[7]));
+    }
+};
+
+__device__ inline float ups_act(float x, int act, float slope) {
+    if (act == UPS_ACT_LRELU) return x > 0.f ? x : slope * x;
+    if (act == UPS_ACT_RELU) return x > 0.f ? x : 0.f;
+    return x;
+}
+__device__ inline float ups_dact(float x, int act, float slope) {
+    if (act == UPS_ACT_LRELU) return x > 0.f ? 1.f : slope;
+    if (act == UPS_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+template <typename T> __device__ inline float ld_as_float(const T* p);
+template <> __device__ inline float ld_as_float<float>(const float* p) { return *p; }
+template <> __device__ inline float ld_as_float<bf16>(const bf16* p) { return (float)*p; }
+template <typename T> __device__ inline void st_from_float(T* p, float v);
+template <> __device__ inline void st_from_float<float>(float* p, float v) { *p = v; }
+template <> __device__ inline void st_from_float<bf16>(bf16* p, float v) { *p = (bf16)v; }
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for 256-thread blocks; result valid in thread 0 (and broadcast via smem[0])
+__device__ inline float block_sum_256(float v, float* smem4) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem4[wid] = v;
+    __syncthreads();
+    return smem4[0] + smem4[1] + smem4[2] + smem4[3];
+}
+
+static inline int ups_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

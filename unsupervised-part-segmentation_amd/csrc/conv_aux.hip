@@ -1,0 +1,226 @@
+// Helpers around the convolution engine: weight layout/dtype preparation, the CoordConv affine table and its
+// gradient, bias gradients.  (cub/code/nn.py:617-664 conv variables V [kh,kw,Cin(+2),Cout] + b; CoordConv
+// channels nn.py:2123-2154.)
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ void weight_prep_kernel(const float* __restrict__ src, int ntaps, int cin_v, int ci_log, int co,
+                                   T* __restrict__ wf, int ci_pad, T* __restrict__ wd, int drows, int dk) {
+    const long long nf = wf ? (long long)ntaps * co * ci_pad : 0;
+    const long long nd = wd ? (long long)ntaps * drows * dk : 0;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd;
+         idx += (long long)gridDim.x * blockDim.x) {
+        if (idx < nf) {
+            const int k = (int)(idx % ci_pad);
+            const long long tc = idx / ci_pad;
+            const int c = (int)(tc % co), t = (int)(tc / co);
+            const float v = k < ci_log ? src[((long long)t * cin_v + k) * co + c] : 0.f;
+            st_from_float<T>(wf + idx, v);
+        } else {
+            const long long j = idx - nf;
+            const int k = (int)(j % dk);
+            const long long tr = j / dk;
+            const int r = (int)(tr % drows), t = (int)(tr / drows);
+            const float v = (k < co && r < ci_log) ? src[((long long)t * cin_v + r) * co + k] : 0.f;
+            st_from_float<T>(wd + j, v);
+        }
+    }
+}
+
+struct Taps3 { int dy[3], dx[3]; };
+
+__global__ void coord_table_kernel(const float* __restrict__ V, int kh, int kw, int ci_log, int co, Taps3 tp, int in_sy,
+                                   int in_sx, float ax, float ay, float* __restrict__ tab) {
+    const int cls = blockIdx.y;
+    const int ym = cls >> 3, xm = cls & 7;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= co) return;
+    float k0 = 0.f, kj = 0.f, ki = 0.f;
+    const int cin_v = ci_log + 2;
+    for (int r = 0; r < kh; ++r) {
+        if (!((ym >> r) & 1)) continue;
+        for (int s = 0; s < kw; ++s) {
+            if (!((xm >> s) & 1)) continue;
+            const float vx = V[((long long)(r * kw + s) * cin_v + ci_log) * co + c];
+            const float vy = V[((long long)(r * kw + s) * cin_v + ci_log + 1) * co + c];
+            const int dys = r == 0 ? tp.dy[0] : (r == 1 ? tp.dy[1] : tp.dy[2]);
+            const int dxs = s == 0 ? tp.dx[0] : (s == 1 ? tp.dx[1] : tp.dx[2]);
+            k0 += (ax * (float)dxs - 1.f) * vx + (ay * (float)dys - 1.f) * vy;
+            kj += ax * (float)in_sx * vx;
+            ki += ay * (float)in_sy * vy;
+        }
+    }
+    tab[((long long)cls * 3 + 0) * co + c] = k0;
+    tab[((long long)cls * 3 + 1) * co + c] = kj;
+    tab[((long long)cls * 3 + 2) * co + c] = ki;
+}
+
+template <typename T>
+__global__ void batch_sum_kernel(const T* __restrict__ d, int n, long long pix, int co, int ldo, float* __restrict__ g) {
+    const long long total = pix * co;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % co);
+        const long long px = idx / co;
+        float s = 0.f;
+        for (int b = 0; b < n; ++b) s += ld_as_float<T>(d + ((long long)b * pix + px) * ldo + c);
+        g[idx] = s;
+    }
+}
+
+// blockIdx.y = tap (== ntaps: bias), 64 channels x 4 pixel lanes per block
+__global__ __launch_bounds__(256) void coord_wgrad_kernel(const float* __restrict__ g, int hi, int wi, int ho, int wo,
+                                                          int co, int kh, int kw, Taps3 tp, int in_sy, int in_sx,
+                                                          float ax, float ay, int ci_log, float* __restrict__ gV,
+                                                          float* __restrict__ gb) {
+    __shared__ float red[2][4][64];
+    const int tap = blockIdx.y, ntaps = kh * kw;
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool is_bias = tap == ntaps;
+    const int r = is_bias ? 0 : tap / kw, s = is_bias ? 0 : tap % kw;
+    const int dys = r == 0 ? tp.dy[0] : (r == 1 ? tp.dy[1] : tp.dy[2]);
+    const int dxs = s == 0 ? tp.dx[0] : (s == 1 ? tp.dx[1] : tp.dx[2]);
+    float sx = 0.f, sy = 0.f;
+    if (c < co) {
+        for (int px = pl; px < ho * wo; px += 4) {
+            const int i = px / wo, j = px - i * wo;
+            const float v = g[(long long)px * co + c];
+            if (is_bias) { sx += v; continue; }
+            const int y = i * in_sy + dys, x = j * in_sx + dxs;
+            if ((unsigned)y < (unsigned)hi && (unsigned)x < (unsigned)wi) {
+                sx += (ax * (float)x - 1.f) * v;
+                sy += (ay * (float)y - 1.f) * v;
+            }
+        }
+    }
+    red[0][pl][cl] = sx; red[1][pl][cl] = sy;
+    __syncthreads();
+    if (pl == 0 && c < co) {
+        sx = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        sy = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        if (is_bias) { if (gb) gb[c] = sx; }
+        else {
+            const int cin_v = ci_log + 2;
+            gV[((long long)tap * cin_v + ci_log) * co + c] = sx;
+            gV[((long long)tap * cin_v + ci_log + 1) * co + c] = sy;
+        }
+    }
+}
+
+// partial[blockIdx.y][c] = sum over this block's row range
+template <typename T>
+__global__ __launch_bounds__(256) void col_sum_kernel(const T* __restrict__ d, long long rows, int co, int ldo, int tx_n,
+                                                      float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n, ty_n = 256 / tx_n;
+    const int c = blockIdx.x * tx_n + tx;
+    const long long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long long r0 = (long long)blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    float s = 0.f;
+    if (c < co)
+        for (long long r = r0 + ty; r < r1; r += ty_n) s += ld_as_float<T>(d + r * ldo + c);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && c < co) {
+        for (int k = 1; k < ty_n; ++k) s += red[k * tx_n + tx];
+        partial[(long long)blockIdx.y * co + c] = s;
+    }
+}
+
+__global__ void col_sum_final_kernel(const float* __restrict__ partial, int nb, int co, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= co) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[(long long)b * co + c];
+    out[c] = s;
+}
+
+}  // namespace
+
+extern "C" int ups_weight_prep(const float* src, int32_t ntaps, int32_t cin_v, int32_t ci_log, int32_t co, int32_t dtype,
+                               void* w_fwd, int32_t ci_pad, void* w_dgrad, int32_t dgrad_rows, int32_t dgrad_k,
+                               void* stream) {
+    UPS_CHECK_ARG(src && (w_fwd || w_dgrad));
+    UPS_CHECK_ARG(ci_log <= cin_v && (!w_fwd || ci_pad >= ci_log) && (!w_dgrad || dgrad_k >= co));
+    const long long total = (w_fwd ? (long long)ntaps * co * ci_pad : 0) + (w_dgrad ? (long long)ntaps * dgrad_rows * dgrad_k : 0);
+    int grid = ups_cdiv(total, 256);
+    if (grid > 8192) grid = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32)
+        hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(grid), dim3(256), 0, s, src, ntaps, cin_v, ci_log, co,
+                           (float*)w_fwd, ci_pad, (float*)w_dgrad, dgrad_rows, dgrad_k);
+    else
+        hipLaunchKernelGGL(weight_prep_kernel<bf16>, dim3(grid), dim3(256), 0, s, src, ntaps, cin_v, ci_log, co,
+                           (bf16*)w_fwd, ci_pad, (bf16*)w_dgrad, dgrad_rows, dgrad_k);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+static Taps3 make_taps3(int kh, int kw, const int32_t* dy, const int32_t* dx) {
+    Taps3 t;
+    for (int i = 0; i < 3; ++i) { t.dy[i] = 0; t.dx[i] = 0; }
+    for (int r = 0; r < kh; ++r) t.dy[r] = dy[r * kw];
+    for (int s = 0; s < kw; ++s) t.dx[s] = dx[s];
+    return t;
+}
+
+extern "C" int ups_coord_table(const float* V, int32_t kh, int32_t kw, int32_t ci_log, int32_t co, const int32_t* tap_dy,
+                               const int32_t* tap_dx, int32_t in_sy, int32_t in_sx, float ax, float ay, float* tab,
+                               void* stream) {
+    UPS_CHECK_ARG(V && tab && tap_dy && tap_dx && kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3);
+    hipLaunchKernelGGL(coord_table_kernel, dim3(ups_cdiv(co, 128), 64), dim3(128), 0, (hipStream_t)stream, V, kh, kw,
+                       ci_log, co, make_taps3(kh, kw, tap_dy, tap_dx), in_sy, in_sx, ax, ay, tab);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_batch_sum(const void* dout, int32_t dtype, int32_t n, int64_t pix, int32_t co, int32_t ldo, float* gsum,
+                             void* stream) {
+    UPS_CHECK_ARG(dout && gsum && n > 0 && pix > 0);
+    int grid = ups_cdiv(pix * co, 256);
+    if (grid > 16384) grid = 16384;
+    if (dtype == UPS_F32)
+        hipLaunchKernelGGL(batch_sum_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dout, n,
+                           (long long)pix, co, ldo, gsum);
+    else
+        hipLaunchKernelGGL(batch_sum_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, n,
+                           (long long)pix, co, ldo, gsum);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_coord_wgrad(const float* gsum, int32_t hi, int32_t wi, int32_t ho, int32_t wo, int32_t co, int32_t kh,
+                               int32_t kw, const int32_t* tap_dy, const int32_t* tap_dx, int32_t in_sy, int32_t in_sx,
+                               float ax, float ay, int32_t ci_log, float* gradV, float* grad_bias, void* stream) {
+    UPS_CHECK_ARG(gsum && gradV && kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3);
+    hipLaunchKernelGGL(coord_wgrad_kernel, dim3(ups_cdiv(co, 64), kh * kw + 1), dim3(256), 0, (hipStream_t)stream, gsum,
+                       hi, wi, ho, wo, co, kh, kw, make_taps3(kh, kw, tap_dy, tap_dx), in_sy, in_sx, ax, ay, ci_log,
+                       gradV, grad_bias);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_col_sum(const void* dout, int32_t dtype, int64_t rows, int32_t co, int32_t ldo, float* out,
+                           float* workspace, void* stream) {
+    UPS_CHECK_ARG(dout && out && workspace && rows > 0 && co > 0);
+    int tx = 32;
+    while (tx < co && tx < 256) tx *= 2;
+    const int ty = 256 / tx;
+    int nb = (int)((rows + (long long)ty * 16 - 1) / ((long long)ty * 16));
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32)
+        hipLaunchKernelGGL(col_sum_kernel<float>, dim3(ups_cdiv(co, tx), nb), dim3(256), 0, s, (const float*)dout,
+                           (long long)rows, co, ldo, tx, workspace);
+    else
+        hipLaunchKernelGGL(col_sum_kernel<bf16>, dim3(ups_cdiv(co, tx), nb), dim3(256), 0, s, (const bf16*)dout,
+                           (long long)rows, co, ldo, tx, workspace);
+    UPS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_sum_final_kernel, dim3(ups_cdiv(co, 256)), dim3(256), 0, s, workspace, nb, co, out);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}

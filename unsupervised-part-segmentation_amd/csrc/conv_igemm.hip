@@ -1,0 +1,309 @@
+// Implicit-GEMM gather convolution on the CDNA4 matrix cores (forward + dgrad).
+//
+// Replaces tf.nn.conv2d / its input gradient as used by nn.conv2d (cub/code/nn.py:617-711),
+// nin (nn.py:811-813), downsample (nn.py:816-817) and residual_block (nn.py:1042-1056).
+//
+// GEMM view: M = n*ho*wo lattice points (rows), N = output channels, K = taps x ci.
+//   A[m][k] = act(in[src(m, tap)][k])   gathered on the fly (never materialised: no im2col buffer)
+//   B[k][c] = w[tap][c][k]               (k contiguous per output channel)
+// Block = 256 threads = 4 waves, tile 128 x BN, K-chunk = 64 bytes per row (32 bf16 / 16 f32).
+// Staging is through registers (global_load_dwordx4 -> fused activation -> ds_write_b128) because the
+// activation-on-load and the zero padding of out-of-image taps need the data in VGPRs; the next chunk's
+// global loads are issued before the MFMAs of the current one (issue-early / write-late).
+// LDS rows are padded 64 -> 80 bytes so the 16-lane groups of ds_read_b128 fall on distinct 16-B slots.
+// MFMA: v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 (exact fp32) for the parity mode.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int RS = 80;  // LDS row stride in bytes (64 data + 16 pad)
+
+template <typename T> struct Mma;
+
+template <> struct Mma<bf16> {
+    // one 64-byte K-chunk = 32 bf16 = two 32x32x16 steps
+    template <int TM, int TN>
+    __device__ static inline void chunk(const unsigned char* a_base, const unsigned char* b_base, int lane,
+                                        f32x16 (&acc)[TM][TN]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(a_base + (i * 32 + r) * RS + ks * 32 + h * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(b_base + (j * 32 + r) * RS + ks * 32 + h * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+template <> struct Mma<float> {
+    // one 64-byte K-chunk = 16 floats; lane half h owns k in [8h, 8h+8): 8 x (32x32x2) steps
+    template <int TM, int TN>
+    __device__ static inline void chunk(const unsigned char* a_base, const unsigned char* b_base, int lane,
+                                        f32x16 (&acc)[TM][TN]) {
+        const int r = lane & 31, h = lane >> 5;
+        f32x4 a[TM][2], b[TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            a[i][0] = *(const f32x4*)(a_base + (i * 32 + r) * RS + h * 32);
+            a[i][1] = *(const f32x4*)(a_base + (i * 32 + r) * RS + h * 32 + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            b[j][0] = *(const f32x4*)(b_base + (j * 32 + r) * RS + h * 32);
+            b[j][1] = *(const f32x4*)(b_base + (j * 32 + r) * RS + h * 32 + 16);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk >> 2][kk & 3],
+                                                                     acc[i][j], 0, 0, 0);
+    }
+};
+
+// taps packed 4 bits each (no dynamically indexed kernarg arrays -> no scratch):
+//   tap_off: (dy+1)<<2 | (dx+1), dy,dx in [-1,2];   tap_wi: weight slice index
+__device__ inline int tap_dy_of(unsigned long long off, int t) { return (int)((off >> (4 * t + 2)) & 3) - 1; }
+__device__ inline int tap_dx_of(unsigned long long off, int t) { return (int)((off >> (4 * t)) & 3) - 1; }
+__device__ inline int tap_w_of(unsigned long long wi, int t) { return (int)((wi >> (4 * t)) & 15); }
+
+// ups_conv_desc without the tap arrays
+struct ConvK {
+    int n, hi, wi, ci, ldi, ho, wo, co, co_fill, ldo, out_h, out_w, out_sy, out_sx, out_oy, out_ox, in_sy, in_sx;
+    int ntaps, kh, kw, act_in, out_f32, dact_kind, ldr, ldd;
+    float act_slope;
+    unsigned long long tap_off, tap_wi;
+    const void* in; const void* w; void* out;
+    const float* bias; const float* coord_tab; const void* res; const void* dact;
+};
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const int M, const int ntn,
+                                                         const int kchunks) {
+    constexpr int EPC = Chunk<T>::N;
+    constexpr int BK = 4 * EPC;
+    constexpr int WN = (BN == 32) ? 1 : 2;
+    constexpr int WM = 4 / WN;
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int BROWS = (BN + 63) / 64;  // B rows staged per thread (BN=32: only threads < 128)
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * RS + BM * 8 + BM * 12];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + BM * RS;
+    long long* rowpix = (long long*)(smem + (BM + BN) * RS);
+    int* rowaux = (int*)(rowpix + BM);  // [BM][3] = cls, j, i
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nt = blockIdx.x % ntn, mt = blockIdx.x / ntn;
+    const int wm = wid / WN, wn = wid % WN;
+
+    const T* __restrict__ in = (const T*)p.in;
+    const T* __restrict__ w = (const T*)p.w;
+    const int hw_o = p.ho * p.wo;
+
+    // ---- per-thread staging coordinates: rows r0 and r0+64, 16-byte chunk `chunk` of each row
+    const int chunk = tid & 3, r0 = tid >> 2;
+    int iy0[2], ix0[2];
+    long long ibase[2];
+    bool rv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int m = mt * BM + r0 + 64 * q;
+        rv[q] = m < M;
+        const int mm = rv[q] ? m : 0;
+        const int img = mm / hw_o, rem = mm - img * hw_o;
+        const int i = rem / p.wo, j = rem - i * p.wo;
+        iy0[q] = i * p.in_sy;
+        ix0[q] = j * p.in_sx;
+        ibase[q] = (long long)img * p.hi * p.wi;
+    }
+    const bool b_thread = (BN >= 64) || (tid < 128);
+
+    // NOTE: named registers, not arrays: uint4 arrays captured by the lambdas are demoted to scratch by hipcc.
+    uint4 ra0, ra1, rb0, rb1;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    const int iy00 = iy0[0], iy01 = iy0[1], ix00 = ix0[0], ix01 = ix0[1];
+    const long long ib0 = ibase[0], ib1 = ibase[1];
+    const bool rv0 = rv[0], rv1 = rv[1];
+
+    auto load_a = [&](bool rvq, int iy, int ix, long long ib, int dy, int dx, int koff, bool kok) -> uint4 {
+        const int y = iy + dy, x = ix + dx;
+        const bool ok = rvq && kok && (unsigned)y < (unsigned)p.hi && (unsigned)x < (unsigned)p.wi;
+        uint4 v = zero4;
+        if (ok) v = *(const uint4*)(in + ((ib + (long long)y * p.wi + x) * p.ldi + koff));
+        return v;
+    };
+    auto load_b = [&](const T* wt, int c, int koff, bool kok) -> uint4 {
+        uint4 v = zero4;
+        if (b_thread && kok && c < p.co) v = *(const uint4*)(wt + (long long)c * p.ci + koff);
+        return v;
+    };
+    auto load_chunk = [&](int t, int kc) {
+        const int koff = kc * BK + chunk * EPC;
+        const bool kok = koff < p.ci;
+        const int dy = tap_dy_of(p.tap_off, t), dx = tap_dx_of(p.tap_off, t);
+        ra0 = load_a(rv0, iy00, ix00, ib0, dy, dx, koff, kok);
+        ra1 = load_a(rv1, iy01, ix01, ib1, dy, dx, koff, kok);
+        const T* wt = w + (long long)tap_w_of(p.tap_wi, t) * p.co * p.ci;
+        rb0 = load_b(wt, nt * BN + r0, koff, kok);
+        if (BROWS > 1) rb1 = load_b(wt, nt * BN + r0 + 64, koff, kok);
+    };
+    auto act_u4 = [&](uint4 u) -> uint4 {
+        if (p.act_in != UPS_ACT_NONE) {
+            float f[EPC];
+            Chunk<T>::unpack(u, f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] = ups_act(f[e], p.act_in, p.act_slope);
+            u = Chunk<T>::pack(f);
+        }
+        return u;
+    };
+    auto stage_chunk = [&]() {
+        *(uint4*)(As + r0 * RS + chunk * 16) = act_u4(ra0);
+        *(uint4*)(As + (r0 + 64) * RS + chunk * 16) = act_u4(ra1);
+        if (b_thread) {
+            *(uint4*)(Bs + r0 * RS + chunk * 16) = rb0;
+            if (BROWS > 1) *(uint4*)(Bs + (r0 + 64) * RS + chunk * 16) = rb1;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const unsigned char* a_base = As + (wm * TM * 32) * RS;
+    const unsigned char* b_base = Bs + (wn * TN * 32) * RS;
+
+    const int total = p.ntaps * kchunks;
+    int t_next = 0, kc_next = 0;
+    load_chunk(0, 0);
+    for (int c = 0; c < total; ++c) {
+        stage_chunk();
+        __syncthreads();
+        if (++kc_next == kchunks) { kc_next = 0; ++t_next; }
+        if (c + 1 < total) load_chunk(t_next, kc_next);  // in flight while the MFMAs below run
+        Mma<T>::template chunk<TM, TN>(a_base, b_base, lane, acc);
+        __syncthreads();
+    }
+
+    // ---- epilogue: row table in LDS (pixel index, CoordConv class, j, i)
+    if (tid < BM) {
+        const int m = mt * BM + tid;
+        long long pix = -1;
+        int cls = 0, i = 0, j = 0;
+        if (m < M) {
+            const int img = m / hw_o, rem = m - img * hw_o;
+            i = rem / p.wo; j = rem - i * p.wo;
+            pix = ((long long)img * p.out_h + (i * p.out_sy + p.out_oy)) * p.out_w + (j * p.out_sx + p.out_ox);
+            if (p.coord_tab) {
+                int ym = 0, xm = 0;
+                for (int r = 0; r < p.kh; ++r) ym |= ((unsigned)(i * p.in_sy + tap_dy_of(p.tap_off, r * p.kw)) < (unsigned)p.hi) << r;
+                for (int s = 0; s < p.kw; ++s) xm |= ((unsigned)(j * p.in_sx + tap_dx_of(p.tap_off, s)) < (unsigned)p.wi) << s;
+                cls = ym * 8 + xm;
+            }
+        }
+        rowpix[tid] = pix;
+        rowaux[tid * 3 + 0] = cls; rowaux[tid * 3 + 1] = j; rowaux[tid * 3 + 2] = i;
+    }
+    __syncthreads();
+
+    T* __restrict__ outT = (T*)p.out;
+    float* __restrict__ outF = (float*)p.out;
+    const T* __restrict__ res = (const T*)p.res;
+    const T* __restrict__ dact = (const T*)p.dact;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = nt * BN + (wn * TN + tn) * 32 + (lane & 31);
+        const bool cvalid = col < p.co;
+        const bool cfill = col < p.co_fill;
+        const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rl = (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const long long pix = rowpix[rl];
+                if (pix < 0 || !cfill) continue;
+                float v = 0.f;
+                if (cvalid) {
+                    v = acc[tm][tn][e] + bias;
+                    if (p.coord_tab) {
+                        const float* tb = p.coord_tab + (long long)rowaux[rl * 3] * 3 * p.co + col;
+                        v += tb[0] + (float)rowaux[rl * 3 + 1] * tb[p.co] + (float)rowaux[rl * 3 + 2] * tb[2 * p.co];
+                    }
+                    if (dact) v *= ups_dact(ld_as_float<T>(dact + pix * p.ldd + col), p.dact_kind, p.act_slope);
+                    if (res) v += ld_as_float<T>(res + pix * p.ldr + col);
+                }
+                if (p.out_f32) outF[pix * p.ldo + col] = v;
+                else st_from_float<T>(outT + pix * p.ldo + col, v);
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch(const ups_conv_desc& dd, hipStream_t s) {
+    constexpr int EPC = Chunk<T>::N;
+    ConvK d;
+    d.n = dd.n; d.hi = dd.hi; d.wi = dd.wi; d.ci = dd.ci; d.ldi = dd.ldi; d.ho = dd.ho; d.wo = dd.wo; d.co = dd.co;
+    d.co_fill = dd.co_fill; d.ldo = dd.ldo; d.out_h = dd.out_h; d.out_w = dd.out_w; d.out_sy = dd.out_sy;
+    d.out_sx = dd.out_sx; d.out_oy = dd.out_oy; d.out_ox = dd.out_ox; d.in_sy = dd.in_sy; d.in_sx = dd.in_sx;
+    d.ntaps = dd.ntaps; d.kh = dd.kh; d.kw = dd.kw; d.act_in = dd.act_in; d.out_f32 = dd.out_f32;
+    d.dact_kind = dd.dact_kind; d.ldr = dd.ldr; d.ldd = dd.ldd; d.act_slope = dd.act_slope;
+    d.in = dd.in; d.w = dd.w; d.out = dd.out; d.bias = dd.bias; d.coord_tab = dd.coord_tab; d.res = dd.res; d.dact = dd.dact;
+    d.tap_off = 0; d.tap_wi = 0;
+    for (int t = 0; t < dd.ntaps; ++t) {
+        if (dd.tap_dy[t] < -1 || dd.tap_dy[t] > 2 || dd.tap_dx[t] < -1 || dd.tap_dx[t] > 2 || dd.tap_w[t] < 0 || dd.tap_w[t] > 15)
+            return UPS_E_ARG;
+        d.tap_off |= (unsigned long long)(((dd.tap_dy[t] + 1) << 2) | (dd.tap_dx[t] + 1)) << (4 * t);
+        d.tap_wi |= (unsigned long long)dd.tap_w[t] << (4 * t);
+    }
+    const long long M = (long long)d.n * d.ho * d.wo;
+    if (M <= 0 || M > 0x7fffffffLL) return UPS_E_ARG;
+    const int kchunks = ups_cdiv(d.ci, 4 * EPC);
+    const int ctot = d.co_fill;
+    const int mtiles = ups_cdiv(M, BM);
+    if (ctot > 64) {
+        const int ntn = ups_cdiv(ctot, 128);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3(mtiles * ntn), dim3(256), 0, s, d, (int)M, ntn, kchunks);
+    } else if (ctot > 32) {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3(mtiles), dim3(256), 0, s, d, (int)M, 1, kchunks);
+    } else {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 32>), dim3(mtiles), dim3(256), 0, s, d, (int)M, 1, kchunks);
+    }
+    return UPS_OK;
+}
+
+}  // namespace
+
+extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
+    UPS_CHECK_ARG(d != nullptr);
+    UPS_CHECK_ARG(d->dtype == UPS_F32 || d->dtype == UPS_BF16);
+    UPS_CHECK_ARG(d->in && d->w && d->out);
+    UPS_CHECK_ARG(d->ci > 0 && d->ci % 8 == 0 && d->ldi % 8 == 0 && d->ci <= d->ldi);
+    UPS_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= 9);
+    UPS_CHECK_ARG(d->co >= 1 && d->co_fill >= d->co && d->co_fill <= d->ldo);
+    UPS_CHECK_ARG(d->n > 0 && d->ho > 0 && d->wo > 0 && d->hi > 0 && d->wi > 0);
+    UPS_CHECK_ARG(!d->coord_tab || (d->kh * d->kw == d->ntaps && d->kh <= 3 && d->kw <= 3));
+    UPS_CHECK_ARG(((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->w & 15) == 0);
+    UPS_CHECK_ARG((d->out_sy * (d->ho - 1) + d->out_oy) < d->out_h && (d->out_sx * (d->wo - 1) + d->out_ox) < d->out_w);
+    int rc = (d->dtype == UPS_F32) ? launch<float>(*d, (hipStream_t)stream) : launch<bf16>(*d, (hipStream_t)stream);
+    if (rc != UPS_OK) { ups_set_error("ups_conv_igemm: bad problem size"); return rc; }
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}

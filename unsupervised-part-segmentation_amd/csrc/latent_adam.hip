@@ -1,0 +1,198 @@
+// Full-covariance latent (cub/code/nn.py:1134-1208 + the spiral fill of cub/code/util.py:878-995),
+// TF-style Adam (tf.train.AdamOptimizer), the Gaussian renderers of nn.py:1639-1702
+// and nn.py:1976-2021, and the error plumbing of the C ABI.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+void ups_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* ups_last_error(void) { return g_err; }
+extern "C" int ups_abi_version(void) { return UPS_ABI_VERSION; }
+
+namespace {
+
+constexpr int MAXS = 8;
+
+// index into the triangular parameter vector x (length m = n(n+1)/2) of element (i, j<=i) of
+// fill_triangular(x) (util.py:981-993): row-major position q of concat(x[n:], reverse(x))
+__device__ inline int tri_index(int i, int j, int n, int m) {
+    const int q = i * n + j;
+    return q < m - n ? n + q : m - 1 - (q - (m - n));
+}
+
+struct Levels { float v[MAXS]; };
+
+// one wave per matrix row; lanes stride over the columns (contiguous parameter reads)
+__global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict__ params, const float* __restrict__ eps,
+                                                         Levels lv, int S, int B, int n, float* __restrict__ samples,
+                                                         float* __restrict__ kl_rows) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int m = n * (n + 1) / 2, np = n + m;
+    const float* pb = params + (long long)b * np;
+    for (int i = blockIdx.y * 4 + wid; i < n; i += gridDim.y * 4) {
+        const float rs = 1.f / sqrtf((float)(i + 1));
+        float dot[MAXS];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) dot[s] = 0.f;
+        float sumsq = 0.f;
+        for (int j = lane; j <= i; j += 64) {
+            const float raw = pb[n + tri_index(i, j, n, m)];
+            const float L = (j == i) ? expf(raw) : raw * rs;
+            sumsq += L * L;
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (s < S) dot[s] += L * lv.v[s] * eps[((long long)s * B + b) * n + j];
+        }
+        sumsq = wave_sum(sumsq);
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s < S) dot[s] = wave_sum(dot[s]);
+        if (lane == 0) {
+            const float mean = pb[i];
+            const float raw_ii = pb[n + tri_index(i, i, n, m)];
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (s < S) samples[((long long)s * B + b) * n + i] = mean + dot[s];
+            if (kl_rows) kl_rows[(long long)b * n + i] = 0.5f * (sumsq - 1.f + mean * mean - 2.f * raw_ii);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ params, const float* __restrict__ eps,
+                                                         Levels lv, const float* __restrict__ gs,
+                                                         const float* __restrict__ gk_dev, float gk_scale, int S, int B,
+                                                         int n, float* __restrict__ gp) {
+    const float gk = gk_scale * (gk_dev ? gk_dev[0] : 1.f);
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int m = n * (n + 1) / 2, np = n + m;
+    const float* pb = params + (long long)b * np;
+    float* gb = gp + (long long)b * np;
+    for (int i = blockIdx.y * 4 + wid; i < n; i += gridDim.y * 4) {
+        const float rs = 1.f / sqrtf((float)(i + 1));
+        float gi[MAXS];
+        float gsum = 0.f;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            gi[s] = (s < S) ? gs[((long long)s * B + b) * n + i] : 0.f;
+            gsum += gi[s];
+            gi[s] *= lv.v[s < S ? s : 0];
+        }
+        for (int j = lane; j <= i; j += 64) {
+            const int idx = n + tri_index(i, j, n, m);
+            const float raw = pb[idx];
+            const float L = (j == i) ? expf(raw) : raw * rs;
+            float dL = gk * L;
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (s < S) dL += gi[s] * eps[((long long)s * B + b) * n + j];
+            gb[idx] = (j == i) ? dL * L - gk : dL * rs;
+        }
+        if (lane == 0) gb[i] = gsum + gk * pb[i];
+    }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long long count, float lr_t, float b1, float b2, float eps, float gscale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        const float gg = g[i] * gscale;
+        const float mm = b1 * m[i] + (1.f - b1) * gg;
+        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm; v[i] = vv;
+        p[i] = p[i] - lr_t * mm / (sqrtf(vv) + eps);
+    }
+}
+
+__global__ void gauss_hm_kernel(const float* __restrict__ pts, const float* __restrict__ sd, float* __restrict__ out, int B,
+                                int h, int w, int K) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * h * w * K) return;
+    const int k = (int)(idx % K);
+    long long t = idx / K;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h);
+    const int b = (int)(t / h);
+    const float* pp = pts + ((long long)b * K + k) * 2;
+    const float* ss = sd + ((long long)b * K + k) * 2;
+    const float dx = (float)x - pp[0], dy = (float)y - pp[1];
+    out[idx] = expf(-(dx * dx) / (2.f * ss[0] * ss[0]) - (dy * dy) / (2.f * ss[1] * ss[1]));
+}
+
+__global__ void gauss_hm3_kernel(const float* __restrict__ mu, const float* __restrict__ L, float* __restrict__ out, int B,
+                                 int h, int w, int K) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * h * w * K) return;
+    const int k = (int)(idx % K);
+    long long t = idx / K;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h);
+    const int b = (int)(t / h);
+    const float* m2 = mu + ((long long)b * K + k) * 2;
+    const float* l4 = L + ((long long)b * K + k) * 4;
+    const float gy = h > 1 ? -1.f + 2.f * (float)y / (float)(h - 1) : -1.f;
+    const float gx = w > 1 ? -1.f + 2.f * (float)x / (float)(w - 1) : -1.f;
+    const float d0 = gy - m2[0], d1 = gx - m2[1];
+    const float z0 = d0 / l4[0];
+    const float z1 = (d1 - l4[2] * z0) / l4[3];
+    out[idx] = expf(-0.5f * (z0 * z0 + z1 * z1)) / (6.283185307179586f * fabsf(l4[0] * l4[3]));
+}
+
+}  // namespace
+
+extern "C" int ups_latent_fwd(const float* params, const float* eps, const float* level, int32_t S, int32_t B, int32_t dim,
+                              float* samples, float* kl_rows, void* stream) {
+    UPS_CHECK_ARG(params && eps && level && samples && S >= 1 && S <= MAXS && B > 0 && dim > 0);
+    Levels lv;
+    for (int s = 0; s < MAXS; ++s) lv.v[s] = s < S ? level[s] : 0.f;   // `level` is a HOST array
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(B, ups_cdiv(dim, 32)), dim3(256), 0, (hipStream_t)stream, params, eps, lv, S,
+                       B, dim, samples, kl_rows);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_latent_bwd(const float* params, const float* eps, const float* level, const float* g_samples,
+                              const float* g_kl_dev, float g_kl_scale, int32_t S, int32_t B, int32_t dim, float* g_params,
+                              void* stream) {
+    UPS_CHECK_ARG(params && eps && level && g_samples && g_params && S >= 1 && S <= MAXS);
+    Levels lv;
+    for (int s = 0; s < MAXS; ++s) lv.v[s] = s < S ? level[s] : 0.f;
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(B, ups_cdiv(dim, 32)), dim3(256), 0, (hipStream_t)stream, params, eps, lv,
+                       g_samples, g_kl_dev, g_kl_scale, S, B, dim, g_params);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_adam(float* p, const float* g, float* m, float* v, int64_t count, float lr_t, float beta1, float beta2,
+                        float eps, float grad_scale, void* stream) {
+    UPS_CHECK_ARG(p && g && m && v && count >= 0);
+    if (count == 0) return UPS_OK;
+    long long grid = (count + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)count, lr_t,
+                       beta1, beta2, eps, grad_scale);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_gauss_hm(const float* pts, const float* stddev, float* out, int32_t B, int32_t h, int32_t w, int32_t K,
+                            void* stream) {
+    UPS_CHECK_ARG(pts && stddev && out);
+    hipLaunchKernelGGL(gauss_hm_kernel, dim3(ups_cdiv((long long)B * h * w * K, 256)), dim3(256), 0, (hipStream_t)stream, pts,
+                       stddev, out, B, h, w, K);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_gauss_hm3(const float* mu, const float* L, float* out, int32_t B, int32_t h, int32_t w, int32_t K,
+                             void* stream) {
+    UPS_CHECK_ARG(mu && L && out);
+    hipLaunchKernelGGL(gauss_hm3_kernel, dim3(ups_cdiv((long long)B * h * w * K, 256)), dim3(256), 0, (hipStream_t)stream, mu, L,
+                       out, B, h, w, K);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}

@@ -1,0 +1,355 @@
+// The part path between the mask decoder and the image decoder (cub/code/SB_model48i/model.py:414-484):
+// per-pixel soft-max over parts + hard max, spatial soft-max moments -> rectangle centres, part-masked
+// appearance images, part-feature un-pooling.  All HBM-bound; lanes run along the part / feature axis so
+// every global access is coalesced and the part reductions are wavefront shuffles.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ softmax_P + hard_max (nn.py:58-62, 134-136)
+template <int GP>
+__global__ void part_softmax_kernel(const float* __restrict__ mean, const float* __restrict__ eps, float* __restrict__ l,
+                                    float* __restrict__ m, float* __restrict__ hard, long long* __restrict__ amax,
+                                    long long pixels, int P) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long pix = gid / GP;
+    const int c = (int)(gid % GP);
+    const bool ok = pix < pixels && c < P;
+    float v = -INFINITY;
+    if (ok) {
+        v = mean[pix * P + c];
+        if (eps) v += eps[pix * P + c];
+        if (l) l[pix * P + c] = v;
+    }
+    float mx = v;
+#pragma unroll
+    for (int o = GP / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, GP));
+    const float e = ok ? expf(v - mx) : 0.f;
+    float s = e;
+#pragma unroll
+    for (int o = GP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, GP);
+    const float pm = e / s;
+    float mm = ok ? pm : -1.f;
+#pragma unroll
+    for (int o = GP / 2; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, GP));
+    const bool is_max = ok && pm == mm;
+    int first = is_max ? c : GP;
+#pragma unroll
+    for (int o = GP / 2; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, GP));
+    if (ok) {
+        m[pix * P + c] = pm;
+        if (hard) hard[pix * P + c] = is_max ? 1.f : 0.f;
+        if (amax && c == 0) amax[pix] = first;
+    }
+}
+
+// ------------------------------------------------------------------ spatial soft-max moments (nn.py:65-71, 1541-1587)
+// partial[n][slab][p][6] = {max, Z, S0, Sy, Sx, Q} relative to the slab max
+template <int GP>
+__global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ x, int h, int w, int P, float gamma,
+                                                              const int* __restrict__ rc, int hh, int hw_half,
+                                                              int rows_per_slab, float* __restrict__ partial) {
+    constexpr int PL = 256 / GP;
+    __shared__ float red[PL][GP][6];
+    const int n = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
+    const int c = threadIdx.x % GP, pl = threadIdx.x / GP;
+    const int y0 = slab * rows_per_slab, y1 = min(h, y0 + rows_per_slab);
+    float mx = -INFINITY, Z = 0.f, S0 = 0.f, Sy = 0.f, Sx = 0.f, Q = 0.f;
+    int cy = 0, cx = 0;
+    if (rc && c < P) { cy = rc[((long long)n * P + c) * 2]; cx = rc[((long long)n * P + c) * 2 + 1]; }
+    if (c < P) {
+        const float sy = h > 1 ? 2.f / (float)(h - 1) : 0.f, sx = w > 1 ? 2.f / (float)(w - 1) : 0.f;
+        for (int px = y0 * w + pl; px < y1 * w; px += PL) {
+            const int yy = px / w, xx = px - yy * w;
+            const float v = gamma * x[((long long)n * h * w + px) * P + c];
+            if (v > mx) {
+                const float sc = expf(mx - v);  // exp(-inf) = 0 on the first element
+                Z *= sc; S0 *= sc; Sy *= sc; Sx *= sc; Q *= sc;
+                mx = v;
+            }
+            const float e = expf(v - mx);
+            Z += e;
+            float k = 1.f;
+            if (rc && abs(yy - cy) <= hh && abs(xx - cx) <= hw_half) k = 0.f;
+            const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
+            const float ek = e * k;
+            S0 += ek; Sy += ek * gy; Sx += ek * gx; Q += ek * (gy * gy + gx * gx);
+        }
+    }
+    red[pl][c][0] = mx; red[pl][c][1] = Z; red[pl][c][2] = S0; red[pl][c][3] = Sy; red[pl][c][4] = Sx; red[pl][c][5] = Q;
+    __syncthreads();
+    if (pl == 0 && c < P) {
+        float M = mx;
+        for (int q = 1; q < PL; ++q) M = fmaxf(M, red[q][c][0]);
+        float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < PL; ++q) {
+            const float mq = red[q][c][0];
+            const float sc = (mq == -INFINITY) ? 0.f : expf(mq - M);
+            for (int k = 0; k < 5; ++k) o[k] += sc * red[q][c][1 + k];
+        }
+        float* dst = partial + (((long long)n * nslab + slab) * P + c) * 6;
+        dst[0] = M;
+        for (int k = 0; k < 5; ++k) dst[1 + k] = o[k];
+    }
+}
+
+__global__ void moments_combine_kernel(const float* __restrict__ partial, int count_n, int nslab, int P, float* __restrict__ stats) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count_n * P) return;
+    const int n = idx / P, c = idx - n * P;
+    float M = -INFINITY;
+    for (int s = 0; s < nslab; ++s) M = fmaxf(M, partial[(((long long)n * nslab + s) * P + c) * 6]);
+    float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nslab; ++s) {
+        const float* src = partial + (((long long)n * nslab + s) * P + c) * 6;
+        const float sc = (src[0] == -INFINITY) ? 0.f : expf(src[0] - M);
+        for (int k = 0; k < 5; ++k) o[k] += sc * src[1 + k];
+    }
+    float* d = stats + (long long)idx * 8;
+    d[0] = M; d[1] = o[0]; d[2] = o[1]; d[3] = o[2]; d[4] = o[3]; d[5] = o[4]; d[6] = 0.f; d[7] = 0.f;
+}
+
+__global__ void moments_to_px_kernel(const float* __restrict__ stats, int count, int h, int* __restrict__ px) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const float* s = stats + (long long)idx * 8;
+    const float muy = s[3] / s[1], mux = s[4] / s[1];
+    px[idx * 2 + 0] = (int)(muy * (float)h / 2.0f + (float)h / 2.0f);   // tf.cast(float->int32): truncation
+    px[idx * 2 + 1] = (int)(mux * (float)h / 2.0f + (float)h / 2.0f);
+}
+
+__global__ void draw_rect_kernel(const int* __restrict__ px, int n, int h, int w, int P, int hh, int hwid, float* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * h * w * P) return;
+    const int c = (int)(idx % P);
+    long long t = idx / P;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h);
+    const int b = (int)(t / h);
+    const int cy = px[((long long)b * P + c) * 2], cx = px[((long long)b * P + c) * 2 + 1];
+    out[idx] = (abs(y - cy) <= hh && abs(x - cx) <= hwid) ? 1.f : 0.f;
+}
+
+// ------------------------------------------------------------------ mask_parts (model.py:176-187) + part-major transpose (nn.py:97-103)
+template <typename T>
+__global__ void mask_parts_fwd_kernel(const float* __restrict__ view, const float* __restrict__ hard, T* __restrict__ out,
+                                      int B, long long hw, int P) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * hw) return;
+    const int b = (int)(idx / hw);
+    const long long px = idx - (long long)b * hw;
+    const float v0 = view[idx * 3], v1 = view[idx * 3 + 1], v2 = view[idx * 3 + 2];
+    for (int p = 0; p < P; ++p) {
+        const float hm = hard[idx * P + p];
+        float f[8] = {v0 * hm, v1 * hm, v2 * hm, 0.f, 0.f, 0.f, 0.f, 0.f};
+        T* o = out + (((long long)p * B + b) * hw + px) * 8;
+        if (sizeof(T) == 2) *(uint4*)o = Chunk<bf16>::pack(f);
+        else { *(uint4*)o = Chunk<float>::pack(f); *(uint4*)((float*)o + 4) = Chunk<float>::pack(f + 4); }
+    }
+}
+template <typename T>
+__global__ void mask_parts_bwd_kernel(const float* __restrict__ view, const T* __restrict__ g, float* __restrict__ gh,
+                                      int B, long long hw, int P) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * hw) return;
+    const int b = (int)(idx / hw);
+    const long long px = idx - (long long)b * hw;
+    const float v0 = view[idx * 3], v1 = view[idx * 3 + 1], v2 = view[idx * 3 + 2];
+    for (int p = 0; p < P; ++p) {
+        const T* gp = g + (((long long)p * B + b) * hw + px) * 8;
+        gh[idx * P + p] = ld_as_float<T>(gp) * v0 + ld_as_float<T>(gp + 1) * v1 + ld_as_float<T>(gp + 2) * v2;
+    }
+}
+
+// ------------------------------------------------------------------ unpool_features + concat (model.py:225-249, 482-484)
+// one thread per (pixel, 8-channel chunk); chunks >= F/8 carry the hard mask itself, then zero padding
+template <typename T>
+__global__ void unpool_fwd_kernel(const float* __restrict__ hard, const float* __restrict__ feat, T* __restrict__ out, int B,
+                                  long long hw, int P, int F, int ldo) {
+    const int cpp = ldo / 8;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * hw * cpp) return;
+    const int k = (int)(idx % cpp);
+    const long long bp = idx / cpp;
+    const int b = (int)(bp / hw);
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* hrow = hard + bp * P;
+    if (k * 8 < F) {
+        for (int p = 0; p < P; ++p) {
+            const float hm = hrow[p];
+            if (hm != 0.f) {
+                const float* fr = feat + ((long long)b * P + p) * F + k * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += hm * fr[e];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = k * 8 + e - F;
+            if (ch < P) f[e] = hrow[ch];
+        }
+    }
+    T* o = out + bp * ldo + k * 8;
+    if (sizeof(T) == 2) *(uint4*)o = Chunk<bf16>::pack(f);
+    else { *(uint4*)o = Chunk<float>::pack(f); *(uint4*)((float*)o + 4) = Chunk<float>::pack(f + 4); }
+}
+
+// block = (image b, slab of pixels); wave pl walks pixels, lane f owns feature f.
+// g_hard via wavefront dot products, g_feat via private LDS columns (one-hot -> one RMW per pixel).
+template <typename T>
+__global__ __launch_bounds__(256) void unpool_bwd_kernel(const float* __restrict__ hard, const float* __restrict__ feat,
+                                                         const T* __restrict__ g, float* __restrict__ gh,
+                                                         float* __restrict__ gfeat_partial, int B, long long hw, int P,
+                                                         int F, int ldo, int slab_px) {
+    extern __shared__ float acc[];  // [4][P][64]
+    const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
+    const int f = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * P * 64; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const long long p0 = (long long)slab * slab_px, p1 = min(hw, p0 + slab_px);
+    float* my = acc + (long long)pl * P * 64;
+    for (long long px = p0 + pl; px < p1; px += 4) {
+        const long long bp = (long long)b * hw + px;
+        const float gf = (f < F) ? ld_as_float<T>(g + bp * ldo + f) : 0.f;
+        for (int p = 0; p < P; ++p) {
+            const float hm = hard[bp * P + p];
+            if (hm != 0.f) my[p * 64 + f] += hm * gf;
+            float d = (f < F) ? gf * feat[((long long)b * P + p) * F + f] : 0.f;
+            d = wave_sum(d);
+            if (f == 0) gh[bp * P + p] = d + ld_as_float<T>(g + bp * ldo + F + p);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P * 64; i += 256) {
+        const int p = i / 64, ff = i % 64;
+        if (ff < F)
+            gfeat_partial[(((long long)b * nslab + slab) * P + p) * F + ff] =
+                acc[i] + acc[P * 64 + i] + acc[2 * P * 64 + i] + acc[3 * P * 64 + i];
+    }
+}
+
+__global__ void unpool_feat_reduce_kernel(const float* __restrict__ partial, int B, int nslab, int PF, float* __restrict__ gfeat) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * PF) return;
+    const int b = idx / PF, r = idx - b * PF;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += partial[((long long)b * nslab + k) * PF + r];
+    gfeat[idx] = s;
+}
+
+constexpr int UNPOOL_SLABS = 16;
+
+}  // namespace
+
+extern "C" int ups_part_softmax_fwd(const float* mean, const float* eps, float* l, float* m, float* hard, int64_t* argmax,
+                                    int64_t pixels, int32_t P, void* stream) {
+    UPS_CHECK_ARG(mean && m && pixels > 0 && P >= 1 && P <= 64);
+    hipStream_t s = (hipStream_t)stream;
+    int gp = 2;
+    while (gp < P) gp *= 2;
+    const int grid = ups_cdiv(pixels * gp, 256);
+#define UPS_PS(G) hipLaunchKernelGGL(part_softmax_kernel<G>, dim3(grid), dim3(256), 0, s, mean, eps, l, m, hard, (long long*)argmax, (long long)pixels, P)
+    switch (gp) {
+        case 2: UPS_PS(2); break;
+        case 4: UPS_PS(4); break;
+        case 8: UPS_PS(8); break;
+        case 16: UPS_PS(16); break;
+        case 32: UPS_PS(32); break;
+        default: UPS_PS(64); break;
+    }
+#undef UPS_PS
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_spatial_moments(const float* x, int32_t n, int32_t h, int32_t w, int32_t P, float gamma,
+                                   const int32_t* rect_c, int32_t half_h, int32_t half_w, float* stats, void* stream) {
+    UPS_CHECK_ARG(x && stats && n > 0 && P >= 1 && P <= 64);
+    hipStream_t s = (hipStream_t)stream;
+    // stats buffer doubles as the partial buffer: caller provides n*P*8 floats for stats followed by workspace
+    // n*NSLAB*P*6 floats (documented in the Python wrapper) -> keep it simple: workspace sits right after stats.
+    const int nslab = 8;
+    float* partial = stats + (long long)n * P * 8;
+    const int rows = ups_cdiv(h, nslab);
+    int gp = 2;
+    while (gp < P) gp *= 2;
+#define UPS_MP(G) hipLaunchKernelGGL(moments_partial_kernel<G>, dim3(n, nslab), dim3(256), 0, s, x, h, w, P, gamma, rect_c, half_h, half_w, rows, partial)
+    switch (gp) {
+        case 2: UPS_MP(2); break;
+        case 4: UPS_MP(4); break;
+        case 8: UPS_MP(8); break;
+        case 16: UPS_MP(16); break;
+        case 32: UPS_MP(32); break;
+        default: UPS_MP(64); break;
+    }
+#undef UPS_MP
+    UPS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(moments_combine_kernel, dim3(ups_cdiv(n * P, 256)), dim3(256), 0, s, partial, n, nslab, P, stats);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" size_t ups_spatial_moments_floats(int32_t n, int32_t P) { return (size_t)n * P * 8 + (size_t)n * 8 * P * 6; }
+extern "C" size_t ups_unpool_bwd_floats(int32_t B, int32_t P, int32_t F) { return (size_t)B * P * F * (1 + UNPOOL_SLABS); }
+
+extern "C" int ups_moments_to_px(const float* stats, int32_t count, int32_t h, int32_t* px, void* stream) {
+    UPS_CHECK_ARG(stats && px && count > 0);
+    hipLaunchKernelGGL(moments_to_px_kernel, dim3(ups_cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, stats, count, h, px);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_draw_rect(const int32_t* px, int32_t n, int32_t h, int32_t w, int32_t P, int32_t half_h, int32_t half_w,
+                             float* out, void* stream) {
+    UPS_CHECK_ARG(px && out);
+    hipLaunchKernelGGL(draw_rect_kernel, dim3(ups_cdiv((long long)n * h * w * P, 256)), dim3(256), 0, (hipStream_t)stream,
+                       px, n, h, w, P, half_h, half_w, out);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_mask_parts_fwd(const float* view, const float* hard, void* out, int32_t dtype, int32_t B, int64_t hw,
+                                  int32_t P, void* stream) {
+    UPS_CHECK_ARG(view && hard && out);
+    const int grid = ups_cdiv((long long)B * hw, 256);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(mask_parts_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, view, hard, (float*)out, B, (long long)hw, P);
+    else hipLaunchKernelGGL(mask_parts_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, view, hard, (bf16*)out, B, (long long)hw, P);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_mask_parts_bwd(const float* view, const void* g_out, float* g_hard, int32_t dtype, int32_t B, int64_t hw,
+                                  int32_t P, void* stream) {
+    UPS_CHECK_ARG(view && g_out && g_hard);
+    const int grid = ups_cdiv((long long)B * hw, 256);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(mask_parts_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, view, (const float*)g_out, g_hard, B, (long long)hw, P);
+    else hipLaunchKernelGGL(mask_parts_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, view, (const bf16*)g_out, g_hard, B, (long long)hw, P);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_unpool_fwd(const float* hard, const float* feat, void* out, int32_t dtype, int32_t B, int64_t hw, int32_t P,
+                              int32_t F, int32_t ldo, void* stream) {
+    UPS_CHECK_ARG(hard && feat && out && F % 8 == 0 && ldo % 8 == 0 && ldo >= F + P);
+    const int grid = ups_cdiv((long long)B * hw * (ldo / 8), 256);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(unpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, hard, feat, (float*)out, B, (long long)hw, P, F, ldo);
+    else hipLaunchKernelGGL(unpool_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, hard, feat, (bf16*)out, B, (long long)hw, P, F, ldo);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+// g_feat: caller provides B*P*F floats followed by B*UNPOOL_SLABS*P*F floats of workspace.
+extern "C" int ups_unpool_bwd(const float* hard, const float* feat, const void* g, float* g_hard, float* g_feat, int32_t dtype,
+                              int32_t B, int64_t hw, int32_t P, int32_t F, int32_t ldo, void* stream) {
+    UPS_CHECK_ARG(hard && feat && g && g_hard && g_feat && F <= 64 && P <= 64 && ldo >= F + P);
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = g_feat + (long long)B * P * F;
+    const int slab_px = ups_cdiv(hw, UNPOOL_SLABS);
+    const size_t shmem = (size_t)4 * P * 64 * sizeof(float);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(unpool_bwd_kernel<float>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, feat, (const float*)g, g_hard, partial, B, (long long)hw, P, F, ldo, slab_px);
+    else hipLaunchKernelGGL(unpool_bwd_kernel<bf16>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, feat, (const bf16*)g, g_hard, partial, B, (long long)hw, P, F, ldo, slab_px);
+    UPS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(unpool_feat_reduce_kernel, dim3(ups_cdiv(B * P * F, 256)), dim3(256), 0, s, partial, B, UNPOOL_SLABS, P * F, g_feat);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}

@@ -1,0 +1,448 @@
+// HBM-bound NHWC streaming kernels: legacy-TF bilinear x2, activation + global mean, 2x2 max pool,
+// channel copies, the perceptual-loss pre-processing and L1 reductions, dtype conversion.
+// All of them move 16 bytes per lane (8 bf16 / 4 f32) with lanes along the channel axis -> fully coalesced.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct V16 {
+    static constexpr int N = Chunk<T>::N;
+    __device__ static inline void ld(const T* p, float* f) { uint4 u = *(const uint4*)p; Chunk<T>::unpack(u, f); }
+    __device__ static inline void st(T* p, const float* f) { *(uint4*)p = Chunk<T>::pack(f); }
+};
+
+// ------------------------------------------------------------------ bilinear x2 (cub/code/nn.py:834-847; Appendix A.2)
+// out[2i] = in[i]; out[2i+1] = 0.5*(in[i] + in[min(i+1, n-1)])  (rows first, then columns, like the oracle)
+template <typename T>
+__global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c) {
+    constexpr int E = V16<T>::N;
+    const int cc = c / E;
+    const long long total = (long long)n * 2 * h * 2 * w * cc;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % cc);
+        long long t = idx / cc;
+        const int ox = (int)(t % (2 * w)); t /= 2 * w;
+        const int oy = (int)(t % (2 * h));
+        const int b = (int)(t / (2 * h));
+        const int y0 = oy >> 1, y1 = min(y0 + 1, h - 1), x0 = ox >> 1, x1 = min(x0 + 1, w - 1);
+        const T* base = x + (long long)b * h * w * c + k * E;
+        float a[E], r[E];
+        V16<T>::ld(base + ((long long)y0 * w + x0) * c, a);
+        if (oy & 1) {
+            V16<T>::ld(base + ((long long)y1 * w + x0) * c, r);
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] = 0.5f * (a[e] + r[e]);
+        }
+        if (ox & 1) {
+            float q[E];
+            V16<T>::ld(base + ((long long)y0 * w + x1) * c, q);
+            if (oy & 1) {
+                V16<T>::ld(base + ((long long)y1 * w + x1) * c, r);
+#pragma unroll
+                for (int e = 0; e < E; ++e) q[e] = 0.5f * (q[e] + r[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] = 0.5f * (a[e] + q[e]);
+        }
+        V16<T>::st(y + idx * E, a);
+    }
+}
+
+// gather form of the transpose: 1-D weights of output o on input i: o=2i ->1, o=2i+1 ->.5 (+.5 if i==n-1), o=2i-1 ->.5
+__device__ inline float up_w(int o, int i, int n) {
+    if (o == 2 * i) return 1.f;
+    if (o == 2 * i + 1) return (i == n - 1) ? 1.f : 0.5f;
+    return 0.5f;  // o == 2i-1
+}
+
+template <typename T>
+__global__ void bilinear2x_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int n, int h, int w, int c) {
+    constexpr int E = V16<T>::N;
+    const int cc = c / E;
+    const long long total = (long long)n * h * w * cc;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % cc);
+        long long t = idx / cc;
+        const int ix = (int)(t % w); t /= w;
+        const int iy = (int)(t % h);
+        const int b = (int)(t / h);
+        const T* base = gy + (long long)b * 4 * h * w * c + k * E;
+        float acc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.f;
+        for (int oy = max(2 * iy - 1, 0); oy <= 2 * iy + 1; ++oy) {
+            const float wy = up_w(oy, iy, h);
+            for (int ox = max(2 * ix - 1, 0); ox <= 2 * ix + 1; ++ox) {
+                const float ww = wy * up_w(ox, ix, w);
+                float g[E];
+                V16<T>::ld(base + ((long long)oy * 2 * w + ox) * c, g);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] += ww * g[e];
+            }
+        }
+        V16<T>::st(gx + idx * E, acc);
+    }
+}
+
+// ------------------------------------------------------------------ activate + global mean (model.py:50-51)
+template <typename T>
+__global__ void act_mean_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int hw, int c, int act, float slope) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * c) return;
+    const int b = idx / c, ch = idx - b * c;
+    float s = 0.f;
+    for (int p = 0; p < hw; ++p) s += ups_act(ld_as_float<T>(x + ((long long)b * hw + p) * c + ch), act, slope);
+    st_from_float<T>(y + idx, s / (float)hw);
+}
+template <typename T>
+__global__ void act_mean_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx, int n, int hw,
+                                    int c, int act, float slope) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * hw * c) return;
+    const int ch = (int)(idx % c);
+    const int b = (int)(idx / ((long long)hw * c));
+    const float g = ld_as_float<T>(gy + (long long)b * c + ch) / (float)hw;
+    st_from_float<T>(gx + idx, g * ups_dact(ld_as_float<T>(x + idx), act, slope));
+}
+
+// ------------------------------------------------------------------ 2x2 max pool
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c) {
+    constexpr int E = V16<T>::N;
+    const int cc = c / E, ho = h / 2, wo = w / 2;
+    const long long total = (long long)n * ho * wo * cc;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % cc);
+        long long t = idx / cc;
+        const int ox = (int)(t % wo); t /= wo;
+        const int oy = (int)(t % ho);
+        const int b = (int)(t / ho);
+        const T* base = x + (((long long)b * h + 2 * oy) * w + 2 * ox) * c + k * E;
+        float a[E], q[E];
+        V16<T>::ld(base, a);
+        V16<T>::ld(base + c, q);
+#pragma unroll
+        for (int e = 0; e < E; ++e) a[e] = fmaxf(a[e], q[e]);
+        V16<T>::ld(base + (long long)w * c, q);
+#pragma unroll
+        for (int e = 0; e < E; ++e) a[e] = fmaxf(a[e], q[e]);
+        V16<T>::ld(base + (long long)w * c + c, q);
+#pragma unroll
+        for (int e = 0; e < E; ++e) a[e] = fmaxf(a[e], q[e]);
+        V16<T>::st(y + idx * E, a);
+    }
+}
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx, int n, int h,
+                                    int w, int c) {
+    constexpr int E = V16<T>::N;
+    const int cc = c / E, ho = h / 2, wo = w / 2;
+    const long long total = (long long)n * ho * wo * cc;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % cc);
+        long long t = idx / cc;
+        const int ox = (int)(t % wo); t /= wo;
+        const int oy = (int)(t % ho);
+        const int b = (int)(t / ho);
+        const long long o00 = (((long long)b * h + 2 * oy) * w + 2 * ox) * c + k * E;
+        const long long offs[4] = {o00, o00 + c, o00 + (long long)w * c, o00 + (long long)w * c + c};
+        float v[4][E], g[E], m[E];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) V16<T>::ld(x + offs[q], v[q]);
+        V16<T>::ld(gy + idx * E, g);
+#pragma unroll
+        for (int e = 0; e < E; ++e) m[e] = fmaxf(fmaxf(v[0][e], v[1][e]), fmaxf(v[2][e], v[3][e]));
+        bool taken[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) taken[e] = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float o[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool hit = !taken[e] && v[q][e] == m[e];
+                o[e] = hit ? g[e] : 0.f;
+                taken[e] = taken[e] || hit;
+            }
+            V16<T>::st(gx + offs[q], o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ channel copy / add between tensors of different widths
+template <typename T, bool ADD>
+__global__ void copy_channels_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd, long long rows, int c) {
+    constexpr int E = V16<T>::N;
+    const int cc = c / E;
+    const long long total = rows * cc;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % cc);
+        const long long r = idx / cc;
+        float a[E];
+        V16<T>::ld(src + r * lds + k * E, a);
+        if (ADD) {
+            float d[E];
+            V16<T>::ld(dst + r * ldd + k * E, d);
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] += d[e];
+        }
+        V16<T>::st(dst + r * ldd + k * E, a);
+    }
+}
+
+// ------------------------------------------------------------------ VGG pre-processing (edflow VGG19Features, UNVERIFIED)
+// y[pix] = {b*127.5+127.5-103.939, g*..-116.779, r*..-123.68, 0,0,0,0,0}
+template <typename T, typename TX>
+__global__ void vgg_pre_fwd_kernel(const TX* __restrict__ x, int ldx, T* __restrict__ y, long long pixels) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pixels) return;
+    const float r = ld_as_float<TX>(x + p * ldx), g = ld_as_float<TX>(x + p * ldx + 1), b = ld_as_float<TX>(x + p * ldx + 2);
+    T* o = y + p * 8;
+    st_from_float<T>(o + 0, (b + 1.f) * 127.5f - 103.939f);
+    st_from_float<T>(o + 1, (g + 1.f) * 127.5f - 116.779f);
+    st_from_float<T>(o + 2, (r + 1.f) * 127.5f - 123.68f);
+#pragma unroll
+    for (int e = 3; e < 8; ++e) st_from_float<T>(o + e, 0.f);
+}
+template <typename T>
+__global__ void vgg_pre_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int ldgx, long long pixels) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pixels) return;
+    const T* g = gy + p * 8;
+    T* o = gx + p * ldgx;
+    st_from_float<T>(o + 0, 127.5f * ld_as_float<T>(g + 2));
+    st_from_float<T>(o + 1, 127.5f * ld_as_float<T>(g + 1));
+    st_from_float<T>(o + 2, 127.5f * ld_as_float<T>(g + 0));
+    for (int e = 3; e < ldgx; ++e) st_from_float<T>(o + e, 0.f);
+}
+
+// ------------------------------------------------------------------ L1 feature distance (sum |act(a)-act(b)|)
+template <typename T>
+__global__ __launch_bounds__(256) void l1_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, long long rows,
+                                                     int c, int ld, int act, float* __restrict__ partial) {
+    __shared__ float red[4];
+    constexpr int E = V16<T>::N;
+    const int cc = ld / E;
+    const long long total = rows * cc;
+    float s = 0.f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % cc);
+        float x[E], y[E];
+        V16<T>::ld(a + idx * E, x);
+        V16<T>::ld(b + idx * E, y);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (k * E + e < c) s += fabsf(ups_act(x[e], act, 0.f) - ups_act(y[e], act, 0.f));
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+template <typename T>
+__global__ void l1_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ gb, long long rows, int c,
+                              int ld, int act, const float* __restrict__ scale_dev, float scale) {
+    constexpr int E = V16<T>::N;
+    const int cc = ld / E;
+    const long long total = rows * cc;
+    const float sc = scale * (scale_dev ? scale_dev[0] : 1.f);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % cc);
+        float x[E], y[E], g[E];
+        V16<T>::ld(a + idx * E, x);
+        V16<T>::ld(b + idx * E, y);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float d = ups_act(x[e], act, 0.f) - ups_act(y[e], act, 0.f);
+            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            g[e] = (k * E + e < c) ? -sc * sg * ups_dact(y[e], act, 0.f) : 0.f;
+        }
+        V16<T>::st(gb + idx * E, g);
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ partial, int n, float scale,
+                                                        float* __restrict__ out, int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + scale * s;
+}
+
+template <typename TS, typename TD>
+__global__ void convert_kernel(const TS* __restrict__ s, TD* __restrict__ d, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        st_from_float<TD>(d + i, ld_as_float<TS>(s + i));
+}
+
+template <typename T>
+__global__ void pad_convert_kernel(const float* __restrict__ s, int c, T* __restrict__ d, int ldd, long long rows) {
+    const long long total = rows * ldd;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % ldd);
+        const long long r = i / ldd;
+        st_from_float<T>(d + i, k < c ? s[r * c + k] : 0.f);
+    }
+}
+
+inline int grid_for(long long work, int cap = 16384) {
+    long long g = (work + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+#define UPS_DISPATCH(dtype, KERNEL, grid, s, ...)                                                         \
+    do {                                                                                                  \
+        if ((dtype) == UPS_F32) hipLaunchKernelGGL(KERNEL<float>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else if ((dtype) == UPS_BF16) hipLaunchKernelGGL(KERNEL<bf16>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else { ups_set_error("bad dtype %d", (int)(dtype)); return UPS_E_ARG; }                           \
+        UPS_LAUNCH_CHECK();                                                                               \
+    } while (0)
+
+extern "C" int ups_bilinear2x_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+    UPS_CHECK_ARG(x && y && c % 8 == 0);
+    const long long work = (long long)n * 4 * h * w * (c / (dtype == UPS_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(bilinear2x_fwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)x, (float*)y, n, h, w, c);
+    else hipLaunchKernelGGL(bilinear2x_fwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w, c);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_bilinear2x_bwd(const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+    UPS_CHECK_ARG(gy && gx && c % 8 == 0);
+    const long long work = (long long)n * h * w * (c / (dtype == UPS_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(bilinear2x_bwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)gy, (float*)gx, n, h, w, c);
+    else hipLaunchKernelGGL(bilinear2x_bwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)gy, (bf16*)gx, n, h, w, c);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_act_mean_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t hw, int32_t c, int32_t act, float slope, void* stream) {
+    UPS_CHECK_ARG(x && y);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = ups_cdiv((long long)n * c, 256);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(act_mean_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, n, hw, c, act, slope);
+    else hipLaunchKernelGGL(act_mean_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, hw, c, act, slope);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_act_mean_bwd(const void* x, const void* gy, void* gx, int32_t dtype, int32_t n, int32_t hw, int32_t c, int32_t act, float slope, void* stream) {
+    UPS_CHECK_ARG(x && gy && gx);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = ups_cdiv((long long)n * hw * c, 256);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(act_mean_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)gy, (float*)gx, n, hw, c, act, slope);
+    else hipLaunchKernelGGL(act_mean_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, (const bf16*)gy, (bf16*)gx, n, hw, c, act, slope);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+    UPS_CHECK_ARG(x && y && c % 8 == 0 && h % 2 == 0 && w % 2 == 0);
+    const long long work = (long long)n * (h / 2) * (w / 2) * (c / (dtype == UPS_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)x, (float*)y, n, h, w, c);
+    else hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w, c);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_maxpool2_bwd(const void* x, const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+    UPS_CHECK_ARG(x && gy && gx && c % 8 == 0 && h % 2 == 0 && w % 2 == 0);
+    const long long work = (long long)n * (h / 2) * (w / 2) * (c / (dtype == UPS_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)x, (const float*)gy, (float*)gx, n, h, w, c);
+    else hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)x, (const bf16*)gy, (bf16*)gx, n, h, w, c);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_copy_channels(const void* src, int32_t lds, void* dst, int32_t ldd, int32_t dtype, int64_t rows, int32_t c, void* stream) {
+    UPS_CHECK_ARG(src && dst && c % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0);
+    const long long work = (long long)rows * (c / (dtype == UPS_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL((copy_channels_kernel<float, false>), dim3(grid_for(work)), dim3(256), 0, s, (const float*)src, lds, (float*)dst, ldd, (long long)rows, c);
+    else hipLaunchKernelGGL((copy_channels_kernel<bf16, false>), dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)src, lds, (bf16*)dst, ldd, (long long)rows, c);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_add_channels(const void* src, int32_t lds, void* dst, int32_t ldd, int32_t dtype, int64_t rows, int32_t c, void* stream) {
+    UPS_CHECK_ARG(src && dst && c % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0);
+    const long long work = (long long)rows * (c / (dtype == UPS_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL((copy_channels_kernel<float, true>), dim3(grid_for(work)), dim3(256), 0, s, (const float*)src, lds, (float*)dst, ldd, (long long)rows, c);
+    else hipLaunchKernelGGL((copy_channels_kernel<bf16, true>), dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)src, lds, (bf16*)dst, ldd, (long long)rows, c);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_vgg_preprocess_fwd(const void* x, int32_t x_is_f32, int32_t ldx, void* y, int32_t dtype, int64_t pixels, void* stream) {
+    UPS_CHECK_ARG(x && y && ldx >= 3);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = ups_cdiv(pixels, 256);
+    if (dtype == UPS_F32) hipLaunchKernelGGL((vgg_pre_fwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)x, ldx, (float*)y, (long long)pixels);
+    else if (x_is_f32) hipLaunchKernelGGL((vgg_pre_fwd_kernel<bf16, float>), dim3(grid), dim3(256), 0, s, (const float*)x, ldx, (bf16*)y, (long long)pixels);
+    else hipLaunchKernelGGL((vgg_pre_fwd_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)x, ldx, (bf16*)y, (long long)pixels);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_vgg_preprocess_bwd(const void* gy, void* gx, int32_t dtype, int32_t ldgx, int64_t pixels, void* stream) {
+    UPS_CHECK_ARG(gy && gx && ldgx >= 3);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = ups_cdiv(pixels, 256);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(vgg_pre_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)gy, (float*)gx, ldgx, (long long)pixels);
+    else hipLaunchKernelGGL(vgg_pre_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)gy, (bf16*)gx, ldgx, (long long)pixels);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_l1_fwd(const void* a, const void* b, int32_t dtype, int64_t rows, int32_t c, int32_t ld, int32_t act, float* partial, int32_t nblocks, void* stream) {
+    UPS_CHECK_ARG(a && b && partial && ld % 8 == 0 && c <= ld && nblocks >= 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(l1_fwd_kernel<float>, dim3(nblocks), dim3(256), 0, s, (const float*)a, (const float*)b, (long long)rows, c, ld, act, partial);
+    else hipLaunchKernelGGL(l1_fwd_kernel<bf16>, dim3(nblocks), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (long long)rows, c, ld, act, partial);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_l1_bwd(const void* a, const void* b, void* gb, int32_t dtype, int64_t rows, int32_t c, int32_t ld, int32_t act, const float* scale_dev, float scale, void* stream) {
+    UPS_CHECK_ARG(a && b && gb && ld % 8 == 0 && c <= ld);
+    const long long work = (long long)rows * (ld / (dtype == UPS_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(l1_bwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)gb, (long long)rows, c, ld, act, scale_dev, scale);
+    else hipLaunchKernelGGL(l1_bwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (bf16*)gb, (long long)rows, c, ld, act, scale_dev, scale);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_sum_scale(const float* partial, int32_t n, float scale, float* out, int32_t accumulate, void* stream) {
+    UPS_CHECK_ARG(partial && out && n >= 1);
+    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, scale, out, accumulate);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_convert(const void* src, int32_t sd, void* dst, int32_t dd, int64_t count, void* stream) {
+    UPS_CHECK_ARG(src && dst && count >= 0);
+    if (count == 0) return UPS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(count);
+    if (sd == UPS_F32 && dd == UPS_BF16) hipLaunchKernelGGL((convert_kernel<float, bf16>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16*)dst, (long long)count);
+    else if (sd == UPS_BF16 && dd == UPS_F32) hipLaunchKernelGGL((convert_kernel<bf16, float>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (float*)dst, (long long)count);
+    else if (sd == UPS_F32 && dd == UPS_F32) hipLaunchKernelGGL((convert_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, (long long)count);
+    else if (sd == UPS_BF16 && dd == UPS_BF16) hipLaunchKernelGGL((convert_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, (long long)count);
+    else { ups_set_error("ups_convert: bad dtypes"); return UPS_E_ARG; }
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_pad_convert(const float* src, int32_t c, void* dst, int32_t dtype, int32_t ldd, int64_t rows, void* stream) {
+    UPS_CHECK_ARG(src && dst && ldd >= c && rows >= 0);
+    if (rows == 0) return UPS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for((long long)rows * ldd);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(pad_convert_kernel<float>, dim3(grid), dim3(256), 0, s, src, c, (float*)dst, ldd, (long long)rows);
+    else hipLaunchKernelGGL(pad_convert_kernel<bf16>, dim3(grid), dim3(256), 0, s, src, c, (bf16*)dst, ldd, (long long)rows);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}

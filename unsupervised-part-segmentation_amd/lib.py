@@ -1,0 +1,156 @@
+"""ctypes binding of libupsparts_hip.so (the C ABI declared in include/upsparts_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/build.sh``.  There is NO CPU or
+PyTorch fallback: if the shared object is missing or a call returns non-zero this module raises.
+torch is used only to own device memory and streams; every entry point receives raw device pointers.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libupsparts_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+ACT = {None: ACT_NONE, "leaky_relu": ACT_LRELU, "relu": ACT_RELU}
+
+
+class UpsError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("hi", C.c_int32), ("wi", C.c_int32), ("ci", C.c_int32),
+                ("ldi", C.c_int32), ("ho", C.c_int32), ("wo", C.c_int32), ("co", C.c_int32), ("co_fill", C.c_int32),
+                ("ldo", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_sy", C.c_int32),
+                ("out_sx", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32), ("in_sy", C.c_int32),
+                ("in_sx", C.c_int32), ("ntaps", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9), ("tap_w", C.c_int32 * 9),
+                ("act_in", C.c_int32), ("act_slope", C.c_float), ("out_f32", C.c_int32), ("dact_kind", C.c_int32),
+                ("ldr", C.c_int32), ("ldd", C.c_int32),
+                ("in_", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p), ("bias", C.c_void_p),
+                ("coord_tab", C.c_void_p), ("res", C.c_void_p), ("dact", C.c_void_p)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("hi", C.c_int32), ("wi", C.c_int32), ("ci", C.c_int32),
+                ("ldi", C.c_int32), ("ci_log", C.c_int32), ("cin_v", C.c_int32), ("ho", C.c_int32), ("wo", C.c_int32),
+                ("co", C.c_int32), ("ldo", C.c_int32), ("in_sy", C.c_int32), ("in_sx", C.c_int32), ("ntaps", C.c_int32),
+                ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9), ("tap_w", C.c_int32 * 9),
+                ("act_in", C.c_int32), ("act_slope", C.c_float), ("splitk", C.c_int32),
+                ("in_", C.c_void_p), ("dout", C.c_void_p), ("grad", C.c_void_p), ("workspace", C.c_void_p)]
+
+
+class PriorDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("P", C.c_int32), ("view", C.c_int32),
+                ("entropy_ce", C.c_int32), ("gamma", C.c_float), ("half_h", C.c_int32), ("half_w", C.c_int32),
+                ("ms_alpha", C.c_float), ("ms_lambda", C.c_float),
+                ("w_kl", C.c_float), ("w_entropy", C.c_float), ("w_ms", C.c_float), ("w_area", C.c_float),
+                ("w_patch", C.c_float), ("w_gmrf", C.c_float), ("w_var", C.c_float),
+                ("l", C.c_void_p), ("l_mean", C.c_void_p), ("m", C.c_void_p), ("hard", C.c_void_p), ("px", C.c_void_p),
+                ("per_np", C.c_void_p), ("sums", C.c_void_p), ("g_hard", C.c_void_p), ("dl", C.c_void_p)]
+
+
+_lib = None
+
+_I, _L, _F, _P, _Z = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+_SIGS = {
+    "ups_abi_version": ([], C.c_int),
+    "ups_conv_igemm": ([C.POINTER(ConvDesc), _P], C.c_int),
+    "ups_conv_wgrad_plan": ([C.POINTER(WgradDesc), C.POINTER(_I), C.POINTER(_Z)], C.c_int),
+    "ups_conv_wgrad": ([C.POINTER(WgradDesc), _P], C.c_int),
+    "ups_weight_prep": ([_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P], C.c_int),
+    "ups_coord_table": ([_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _I, _I, _F, _F, _P, _P], C.c_int),
+    "ups_batch_sum": ([_P, _I, _I, _L, _I, _I, _P, _P], C.c_int),
+    "ups_coord_wgrad": ([_P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _I, _I, _F, _F, _I, _P, _P, _P], C.c_int),
+    "ups_col_sum": ([_P, _I, _L, _I, _I, _P, _P, _P], C.c_int),
+    "ups_bilinear2x_fwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "ups_bilinear2x_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "ups_act_mean_fwd": ([_P, _P, _I, _I, _I, _I, _I, _F, _P], C.c_int),
+    "ups_act_mean_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _F, _P], C.c_int),
+    "ups_maxpool2_fwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "ups_maxpool2_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "ups_copy_channels": ([_P, _I, _P, _I, _I, _L, _I, _P], C.c_int),
+    "ups_add_channels": ([_P, _I, _P, _I, _I, _L, _I, _P], C.c_int),
+    "ups_vgg_preprocess_fwd": ([_P, _I, _I, _P, _I, _L, _P], C.c_int),
+    "ups_vgg_preprocess_bwd": ([_P, _P, _I, _I, _L, _P], C.c_int),
+    "ups_l1_fwd": ([_P, _P, _I, _L, _I, _I, _I, _P, _I, _P], C.c_int),
+    "ups_l1_bwd": ([_P, _P, _P, _I, _L, _I, _I, _I, _P, _F, _P], C.c_int),
+    "ups_sum_scale": ([_P, _I, _F, _P, _I, _P], C.c_int),
+    "ups_part_softmax_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _P], C.c_int),
+    "ups_spatial_moments": ([_P, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P], C.c_int),
+    "ups_spatial_moments_floats": ([_I, _I], _Z),
+    "ups_moments_to_px": ([_P, _I, _I, _P, _P], C.c_int),
+    "ups_draw_rect": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
+    "ups_mask_parts_fwd": ([_P, _P, _P, _I, _I, _L, _I, _P], C.c_int),
+    "ups_mask_parts_bwd": ([_P, _P, _P, _I, _I, _L, _I, _P], C.c_int),
+    "ups_unpool_fwd": ([_P, _P, _P, _I, _I, _L, _I, _I, _I, _P], C.c_int),
+    "ups_unpool_bwd": ([_P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _P], C.c_int),
+    "ups_unpool_bwd_floats": ([_I, _I, _I], _Z),
+    "ups_prior_sums_floats": ([_I, _I], _Z),
+    "ups_prior_fwd": ([C.POINTER(PriorDesc), _P], C.c_int),
+    "ups_prior_bwd": ([C.POINTER(PriorDesc), _P], C.c_int),
+    "ups_latent_fwd": ([_P, _P, C.POINTER(_F), _I, _I, _I, _P, _P, _P], C.c_int),
+    "ups_latent_bwd": ([_P, _P, C.POINTER(_F), _P, _P, _F, _I, _I, _I, _P, _P], C.c_int),
+    "ups_adam": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P], C.c_int),
+    "ups_gauss_hm": ([_P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
+    "ups_gauss_hm3": ([_P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
+    "ups_convert": ([_P, _I, _P, _I, _L, _P], C.c_int),
+    "ups_pad_convert": ([_P, _I, _P, _I, _I, _L, _P], C.c_int),
+}
+EXPORTS = sorted(list(_SIGS) + ["ups_last_error"])
+
+
+def load():
+    """Load the HIP library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UpsError("libupsparts_hip.so not found at {} -- run __graft_entry__.build() "
+                       "(there is no CPU fallback for the product path)".format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH)
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    lib.ups_last_error.argtypes = []
+    lib.ups_last_error.restype = C.c_char_p
+    if lib.ups_abi_version() != 1:
+        raise UpsError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise UpsError("{} failed ({}): {}".format(what, rc, load().ups_last_error().decode()))
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    return C.c_void_p(t.data_ptr())
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise UpsError("unsupported dtype {}".format(t.dtype))
+
+
+def torch_dtype(code):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

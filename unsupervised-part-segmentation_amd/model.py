@@ -1,0 +1,514 @@
+"""``TrainModel`` / ``Trainer``: the edflow-facing surface of the reference
+(cub/code/SB_model48i/model.py: TrainModel 251-521, Trainer 570-1068) on the MI355X-native path.
+
+The reference builds a static TF graph and lets ``session.run`` execute it; here ``Trainer.train_step``
+plays the role of one ``session.run(train_op)``: forward, the seven per-sub-network losses, the
+per-key gradients (each sub-network is updated with the gradient of ITS OWN loss only, model.py:739-742,
+786-815), TF-style Adam and the Lagrangian / EMA state updates -- all on device, no host sync.
+
+Tape layout (cuts where the per-key semantics need different upstream gradients):
+  A  encoder_0 -> latent parameters            (gets d rec, d adversarial, d bottleneck)
+  B  decoder_visualize: z -> logits            (weights: d(rec + priors); input z: d rec only)
+  C  hard masks -> parts -> encoder_1 -> unpool -> decoder_delta -> perceptual loss
+  D  the three critics
+The part path between B and C (soft-max, hard max, moments, rectangles, priors) is not taped at all:
+its forward and its fused backward are single HIP kernels.
+"""
+import ctypes as C
+import math
+import os
+from collections import OrderedDict
+
+import torch
+
+from . import lib as L
+from . import nets as N
+from . import ops
+from .nets import Act
+from .schedules import make_var, make_linear_var
+
+
+def _scalar(v, device):
+    return torch.tensor(float(v), dtype=torch.float32, device=device)
+
+
+class TrainModel(object):
+    """Mirror of model.py:251-280: ``inputs``, ``outputs``, ``variables``, ``n_parts``."""
+
+    def __init__(self, config, device=None, seed=None):
+        self.config = config
+        if not torch.cuda.is_available():
+            raise L.UpsError("TrainModel needs a HIP device: the product path has no CPU fallback")
+        L.load()
+        self.device = torch.device(device if device is not None else "cuda:{}".format(torch.cuda.current_device()))
+        self.pretty = config.get("use_pretty", False)
+        self.n_parts = config.get("n_parts")
+        self.use_tps = config.get("use_tps", False)
+        if self.use_tps:
+            raise NotImplementedError("in-graph TPS (eddata.utils.tps) is a 'next' row: feed pre-warped views "
+                                      "or set use_tps: False")
+        prec = str(config.get("precision", "bf16")).lower()
+        self.act_dtype = torch.float32 if prec in ("fp32", "f32", "float32") else torch.bfloat16
+        self.patch_size = config.get("patch_size", 32)
+        self.nets = N.Nets(config, self.device, seed if seed is not None else config.get("seed", 0))
+        self.bank = self.nets.bank
+        self._last = {}
+
+    # model.py:260-263
+    @property
+    def inputs(self):
+        B, S = self.config["batch_size"], self.config["spatial_size"]
+        return {k: (B, S, S, 3) for k in ("view0", "view1", "view0_target")}
+
+    @property
+    def variables(self):
+        return self.bank.params
+
+    # model.py:265-280 -- evaluated for the most recent batch given to ``forward``
+    @property
+    def outputs(self):
+        return self._last
+
+    def to_act(self, x_f32):
+        """fp32 [n,H,W,c] -> activation dtype, 8-padded channels."""
+        x_f32 = x_f32.contiguous()
+        out = torch.empty(x_f32.shape[:-1] + (ops.round8(x_f32.shape[-1]),), dtype=self.act_dtype, device=x_f32.device)
+        rows = x_f32.numel() // x_f32.shape[-1]
+        L.call("ups_pad_convert", L.ptr(x_f32), x_f32.shape[-1], L.ptr(out), L.dt(out), out.shape[-1], rows, L.stream())
+        return out
+
+    @torch.no_grad()
+    def forward(self, batch, noise=None):
+        """Inference graph (test_mode semantics when ``noise`` is None): fills ``outputs``."""
+        cfg = self.config
+        v0 = batch["view0"].to(self.device, torch.float32)
+        v1 = batch["view1"].to(self.device, torch.float32)
+        B, S = v0.shape[0], v0.shape[1]
+        Z, A, P = cfg.get("z0_size", 256), cfg.get("local_app_size", 64), self.n_parts
+        img01 = self.to_act(torch.cat([v0, v1], 0))
+        pe = self.nets.e_pi(Act(img01, 2 * B, S, S, 3)).t.view(2 * B, -1)
+        if noise is None:
+            z = pe[:, :Z].contiguous()
+        else:
+            s0, _ = ops.latent_fwd(pe[:B].contiguous(), noise["eps_pi0"][:1].to(self.device), [1.0], False)
+            s1, _ = ops.latent_fwd(pe[B:].contiguous(), noise["eps_pi1"][None].to(self.device), [1.0], False)
+            z = torch.cat([s0[0], s1[0]], 0)
+        lm = self.nets.dv(Act(self.to_act(z.view(2 * B, 1, 1, Z)), 2 * B, 1, 1, Z)).t
+        eps = None if noise is None else torch.cat([noise["eps_l0"], noise["eps_l1"]], 0).to(self.device)
+        _, m, hard, _ = ops.part_softmax(lm, eps)
+        _, soft, _, amax = ops.part_softmax(lm[:B].contiguous(), None, want_hard=False, want_argmax=True)
+        parts = ops.MaskPartsFn.apply(v1.contiguous(), hard[B:].contiguous(), self.act_dtype)
+        yp = self.nets.e_alpha(Act(parts, P * B, S, S, 3)).t
+        feat = yp.float().view(P, B, A).permute(1, 0, 2).contiguous()
+        inj = ops.UnpoolFn.apply(hard[:B].contiguous(), feat, self.act_dtype)
+        gen = self.nets.dd(Act(inj, B, S, S, A + P)).t
+        self._last = {"generated": gen[..., :3].float(), "m0_sample": m[:B], "out_parts_hard": amax,
+                      "out_parts_soft": soft, "view0_mask00_rgb": mask2rgb(m[:B])}
+        return self._last
+
+
+def mask_colors(n_parts):
+    """nn.py:2118-2120 (inferno colour table); needs matplotlib, falls back to a grey ramp."""
+    try:
+        from matplotlib import pyplot as plt
+        import numpy as np
+        return torch.tensor(plt.cm.inferno(np.linspace(0, 1, n_parts))[:, :3], dtype=torch.float32)
+    except Exception:  # pragma: no cover
+        return torch.linspace(0, 1, n_parts).view(-1, 1).repeat(1, 3)
+
+
+def mask2rgb(mask):
+    """nn.py:2067-2089: one-hot(argmax) x colours in [-1,1] (visualisation output only)."""
+    P = mask.shape[3]
+    col = ((mask_colors(P) - 0.5) * 2).to(mask.device)
+    return col[mask.argmax(dim=3)]
+
+
+class Trainer(object):
+    """Mirror of model.py:570-1068 plus the pieces edflow's TFBaseTrainer supplied (session loop,
+    one Adam per loss key over the variables whose name contains the key, logging cadence)."""
+
+    def __init__(self, config, root=None, model=None, **kwargs):
+        self.config, self.root, self.model = config, root, model
+        self.device = model.device
+        self.logger = kwargs.get("logger")
+        self.global_step = 0
+        self.log_ops, self.img_ops, self.update_ops = OrderedDict(), OrderedDict(), []
+        self.world_size = kwargs.get("world_size", 1)
+        self.process_group = kwargs.get("process_group")
+        self.beta1 = config.get("beta1", 0.5)        # edflow TFBaseTrainer defaults (UNVERIFIED)
+        self.beta2 = config.get("beta2", 0.9)
+        self.adam_eps = 1e-8
+        self.perceptual_input = config.get("perceptual_input", "native")
+        vw = config.get("vgg_widths", N.VGG_WIDTHS)
+        self.vgg = N.VggTrunk(self.device, seed=config.get("vgg_seed", 7), widths=tuple(vw))
+        mi = config["MI"]
+        d = self.device
+        # non-trainable state (model.py:503, 829-834, 861-866, 890, 921) -- device scalars
+        self.state = {"lon": _scalar(1.0, d), "loa": _scalar(mi.get("loa_init", 0.0), d),
+                      "lor": _scalar(mi.get("lor_init", 7.5), d),
+                      "avg_acc0": _scalar(0.5, d), "avg_acc1": _scalar(0.5, d), "avg_acc_error": _scalar(0.0, d),
+                      "avg_loss_dis0": _scalar(1.0, d), "avg_loss_dis1": _scalar(1.0, d),
+                      "avg_mim": _scalar(0.0, d), "avg_independent_mim": _scalar(0.0, d)}
+        self._gen = torch.Generator(device=d)
+        self._gen.manual_seed(int(config.get("noise_seed", 4321)) + 7919 * int(kwargs.get("rank", 0)))
+        self.losses = OrderedDict((k, None) for k in self.loss_keys())
+
+    # ------------------------------------------------------------------ edflow hook surface
+    def loss_keys(self):
+        keys = list(N.SUBMODULES)
+        for k in self.config.get("fix_weights", []):      # model.py:1062-1067
+            if k in keys:
+                keys.remove(k)
+        return keys
+
+    def make_loss_ops(self):
+        """model.py:604: returns {optimizer key: loss}.  In this eager design the values are the
+        device scalars of the most recent step (None before the first step)."""
+        return self.losses
+
+    def get_restore_variables(self):
+        """model.py:571-590: name-substring exclude list."""
+        vs = list(self.model.variables.keys())
+        default_exclude = ["pretty_discriminator", "beta1_power_7", "beta2_power_7", "phase_weight", "grad_weight",
+                           "phase_gamma"]
+        for name in self.config.get("restore_exclude", default_exclude):
+            vs = [v for v in vs if name not in v]
+        return vs
+
+    def set_global_step(self, step):
+        self.global_step = int(step)
+
+    def initialize(self, checkpoint_path=None):
+        """model.py:592-602: lazy restore, missing variables ignored, step parsed from the file name."""
+        if checkpoint_path is None:
+            return
+        ck = torch.load(checkpoint_path, map_location="cpu")
+        keep = set(self.get_restore_variables())
+        self.model.bank.load({n: t for n, t in ck["params"].items() if n in keep})
+        for key, grp in self.model.bank.groups.items():
+            st = ck.get("adam", {}).get(key)
+            if st is not None and st["m"].numel() == grp["flat"]["m"].numel():
+                grp["flat"]["m"].copy_(st["m"]); grp["flat"]["v"].copy_(st["v"]); grp["t"] = st["t"]
+        for k, v in ck.get("state", {}).items():
+            if k in self.state:
+                self.state[k].fill_(float(v))
+        base = os.path.basename(checkpoint_path)
+        digits = "".join(ch for ch in base.split("-")[-1] if ch.isdigit())
+        self.set_global_step(int(digits) if digits else ck.get("global_step", 0))
+        if self.logger:
+            self.logger.info("Lazily restored from {}".format(checkpoint_path))
+
+    def save_checkpoint(self, path):
+        bank = self.model.bank
+        torch.save({"params": bank.state(), "global_step": self.global_step,
+                    "adam": {k: {"m": g["flat"]["m"].cpu(), "v": g["flat"]["v"].cpu(), "t": g["t"]}
+                             for k, g in bank.groups.items()},
+                    "state": {k: float(v) for k, v in self.state.items()}}, path)
+
+    # ------------------------------------------------------------------ helpers
+    def draw_noise(self, B):
+        cfg = self.config
+        S, P, Z = cfg["spatial_size"], self.model.n_parts, cfg.get("z0_size", 256)
+        r = lambda *s: torch.randn(*s, generator=self._gen, device=self.device, dtype=torch.float32)
+        return {"eps_pi0": r(7, B, Z), "eps_pi1": r(B, Z), "eps_l0": r(B, S, S, P), "eps_l1": r(B, S, S, P)}
+
+    def learning_rate(self):
+        cfg = self.config
+        lr = cfg.get("lr", 1e-4)
+        return make_linear_var(self.global_step, cfg.get("lr_decay_begin", 1000), cfg.get("lr_decay_end", 1001), lr, 0.0,
+                               0.0, lr)
+
+    def _prior(self, view, n, S, P, l, lm, m, hard, px, per_np, sums, w, g_hard=None, dl=None, bwd=False):
+        d = L.PriorDesc()
+        d.n, d.h, d.w, d.P, d.view = n, S, S, P, view
+        d.entropy_ce = int(self.config.get("entropy_func", "cross_entropy") == "cross_entropy")
+        d.gamma = float(self.config.get("gamma", 3.0))
+        d.half_h = d.half_w = self.model.patch_size // 2
+        d.ms_alpha, d.ms_lambda = 1.0, 1.0e-2                      # hard-coded at model.py:744-746
+        d.w_kl, d.w_entropy, d.w_ms, d.w_area = w["kl"], w["entropy"], w["ms"], w["area"]
+        d.w_patch, d.w_gmrf, d.w_var = w["patch"], w["gmrf"], w["var"]
+        g = lambda t: t.data_ptr() if t is not None else None
+        d.l, d.l_mean, d.m, d.hard, d.px = g(l), g(lm), g(m), g(hard), g(px)
+        d.per_np, d.sums, d.g_hard, d.dl = g(per_np), g(sums), g(g_hard), g(dl)
+        L.call("ups_prior_bwd" if bwd else "ups_prior_fwd", C.byref(d), L.stream())
+
+    # ------------------------------------------------------------------ one session.run(train_op)
+    def train_step(self, batch, noise=None):
+        cfg, model, nets, bank = self.config, self.model, self.model.nets, self.model.bank
+        dev, T = self.device, model.act_dtype
+        step = self.global_step
+        keys = self.loss_keys()
+        v0 = batch["view0"].to(dev, torch.float32).contiguous()
+        v1 = batch["view1"].to(dev, torch.float32).contiguous()
+        vt = batch["view0_target"].to(dev, torch.float32).contiguous()
+        B, S = v0.shape[0], v0.shape[1]
+        Z, A, P = cfg.get("z0_size", 256), cfg.get("local_app_size", 64), model.n_parts
+        gamma = float(cfg.get("gamma", 3.0))
+        half = model.patch_size // 2
+        if noise is None:
+            noise = self.draw_noise(B)
+        noise = {k: v.to(dev, torch.float32).contiguous() for k, v in noise.items()}
+        st = self.state
+        log = OrderedDict()
+
+        # ---- schedule constants of this step (model.py:621-646, 709-726, 774-779)
+        w_gmrf = make_var(step, cfg["prior_gmrf_weight"])
+        w_ms = make_var(step, cfg["prior_mumford_sha_weight"])
+        w_kl = make_linear_var(step, **cfg["kl_weight"])
+        w_var = make_var(step, cfg["variance_weight"])
+        w_weak = make_var(step, cfg["weakly_superv_loss_weight_p"])
+        w_patch = make_var(step, cfg["patch_loss_weight"])
+        pretrain = bool(cfg.get("pretrain", False))
+
+        # ================= A: pose encoder + latent (model.py:382-409)
+        img01 = model.to_act(torch.cat([v0, v1], 0))
+        pe = nets.e_pi(Act(img01, 2 * B, S, S, 3)).t                    # fp32 [2B,1,1,NP], taped
+        pe2 = pe.detach().view(2 * B, -1)
+        pe_v0, pe_v1 = pe2[:B].contiguous(), pe2[B:].contiguous()
+        lon = 1.0                                                         # LON_ADAPTIVE = False (model.py:842): lon stays 1
+        levels0 = [1.0, lon, lon, 1.0, 1.0, 1.0, 1.0]                     # draw order model.py:406,506,509,512,514,518,520
+        samples0, kl_rows = ops.latent_fwd(pe_v0, noise["eps_pi0"], levels0, True)
+        samples1, _ = ops.latent_fwd(pe_v1, noise["eps_pi1"][None], [1.0], False)
+        bottleneck = kl_rows.sum(dim=1).mean()                            # nn.py:1196-1208
+
+        # appearance of the whole views feeds the critics only -> forward only (model.py:394-397)
+        with torch.no_grad():
+            alpha = nets.e_alpha(Act(img01, 2 * B, S, S, 3)).t            # [2B,1,1,A]
+            alpha_in = torch.cat([alpha[B:], torch.flip(alpha[:B], dims=[0])], 0).contiguous()
+
+        # ================= B: mask decoder (model.py:411-412)
+        z_leaf = model.to_act(torch.cat([samples0[0], samples1[0]], 0).view(2 * B, 1, 1, Z)).requires_grad_(True)
+        l_mean = nets.dv(Act(z_leaf, 2 * B, 1, 1, Z)).t                   # fp32 [2B,S,S,P], taped
+        lm = l_mean.detach()
+
+        # ================= part path, untaped (model.py:414-473)
+        eps_l = torch.cat([noise["eps_l0"], noise["eps_l1"]], 0)
+        l, m, hard, _ = ops.part_softmax(lm, eps_l)
+        px = ops.moments_to_px(ops.spatial_moments(hard, gamma), S)       # [2B,P,2] rectangle centres (stop-gradient)
+        hard0 = hard[:B].detach().requires_grad_(True)
+        hard1 = hard[B:].detach().requires_grad_(True)
+
+        # ================= C: part-wise appearance -> unpool -> image decoder -> perceptual loss (model.py:478-485, 607-619)
+        parts = ops.MaskPartsFn.apply(v1, hard1, T)                        # [P*B,S,S,8]
+        yp = nets.e_alpha(Act(parts, P * B, S, S, 3)).t                    # [P*B,1,1,A]
+        feat = yp.float().view(P, B, A).permute(1, 0, 2).contiguous()      # [B,P,A]
+        inj = ops.UnpoolFn.apply(hard0, feat, T)
+        gen = nets.dd(Act(inj, B, S, S, A + P)).t                          # [B,S,S,8]
+        if self.perceptual_input == "resize256":
+            assert S == 128
+            tgt_in = ops.BilinearFn.apply(model.to_act(vt)); gen_in = ops.BilinearFn.apply(gen)
+        else:
+            tgt_in, gen_in = vt, gen
+        rec = self.vgg.loss(tgt_in, gen_in, T)
+        auto_rec = (1e-3 * 0.5 * (S * S * 3)) * rec                        # model.py:613-619
+
+        rec_params = []
+        for k in ("encoder_1", "decoder_delta"):
+            if k in keys:
+                rec_params += [bank.params[n] for n in bank.groups[k]["names"]]
+        gr = torch.autograd.grad([auto_rec], [hard0, hard1] + rec_params)  # conv wgrads land in bank.grads
+        g_hard0, g_hard1 = gr[0].contiguous(), gr[1].contiguous()
+
+        # ================= mask priors: fused forward sums + fused backward (model.py:652-797)
+        nfl = L.load().ups_prior_sums_floats(B, P)
+        sums0 = torch.empty(nfl, dtype=torch.float32, device=dev)
+        sums1 = torch.empty(nfl, dtype=torch.float32, device=dev)
+        per_np0 = torch.empty((B, P, 8), dtype=torch.float32, device=dev)
+        l0, l1, m0, m1 = l[:B], l[B:], m[:B], m[B:]
+        px0, px1 = px[:B].contiguous(), px[B:].contiguous()
+        wz = {"kl": 0.0, "entropy": 0.0, "ms": 0.0, "area": 0.0, "patch": 0.0, "gmrf": 0.0, "var": 0.0}
+        wp = dict(wz) if pretrain else {"kl": w_kl, "entropy": w_weak, "ms": w_ms, "area": 1.0e-12, "patch": w_patch,
+                                        "gmrf": w_gmrf, "var": w_var}
+        self._prior(0, B, S, P, l0, lm[:B], m0, hard[:B], px0, per_np0, sums0, wp)
+        self._prior(1, B, S, P, l1, None, m1, None, px1, None, sums1, wp)
+        stats_v = ops.spatial_moments(m1.contiguous(), gamma, rect_px=px1, half=half)     # variance moments (model.py:683-707)
+        npx = float(B * S * S)
+        prior_gmrf = sums0[3] / B
+        mask0_kl = (sums0[0] + sums1[0]) / npx
+        weakly = sums0[1] / npx
+        patch_loss = sums0[2] / B
+        p_ms = w_ms * sums0[4] / B
+        area_cost = 1.0e-12 * sums0[5] / B
+        Zs = stats_v[..., 1]
+        variances = (stats_v[..., 5] / Zs - (stats_v[..., 3] / Zs) ** 2 - (stats_v[..., 4] / Zs) ** 2).sum(dim=1).mean()
+        prior_total = (w_gmrf * prior_gmrf + w_kl * mask0_kl + weakly * w_weak + w_var * variances + p_ms + area_cost
+                       + patch_loss * w_patch)
+
+        dl_tot = torch.empty_like(lm)
+        dl_rec = torch.empty_like(lm)
+        self._prior(0, B, S, P, l0, lm[:B], m0, hard[:B], px0, per_np0, sums0, wp, g_hard0, dl_tot[:B], bwd=True)
+        self._prior(1, B, S, P, l1, None, m1, None, px1, stats_v, sums1, wp, g_hard1, dl_tot[B:], bwd=True)
+        self._prior(0, B, S, P, l0, lm[:B], m0, hard[:B], px0, per_np0, sums0, wz, g_hard0, dl_rec[:B], bwd=True)
+        self._prior(1, B, S, P, l1, None, m1, None, px1, stats_v, sums1, wz, g_hard1, dl_rec[B:], bwd=True)
+
+        # ---- B backward: weights see rec + priors, the latent sees rec only
+        if "decoder_visualize" in keys:
+            dv_params = [bank.params[n] for n in bank.groups["decoder_visualize"]["names"]]
+            torch.autograd.grad([l_mean], dv_params, grad_outputs=[dl_tot], retain_graph=True)
+        gz = torch.autograd.grad([l_mean], [z_leaf], grad_outputs=[dl_rec])[0].float().view(2 * B, Z)
+
+        # ================= D: critics (model.py:502-521, 800-866)
+        mi = cfg["MI"]
+        MI_TARGET, MI_SLACK = mi.get("mi_target", 0.125), mi.get("mi_slack", 0.05)
+        crit = {}
+        for ci, name in enumerate(("mi0_discriminator", "mi1_discriminator", "mi_estimator")):
+            pi_in = model.to_act(torch.cat([samples0[1 + 2 * ci], samples0[2 + 2 * ci]], 0).view(2 * B, 1, 1, Z))
+            pi_in.requires_grad_(name == "mi0_discriminator")
+            h_pi, h_al = nets.critic(name, (Act(pi_in, 2 * B, 1, 1, Z), Act(alpha_in, 2 * B, 1, 1, A)))
+            logits = (h_pi.t.float() * h_al.t.float()).sum(dim=(1, 2, 3))
+            joint, marg = logits[:B], logits[B:]
+            loss = 0.5 * (torch.nn.functional.softplus(-joint).mean() + torch.nn.functional.softplus(marg).mean())
+            acc = ((joint > 0).sum() + (marg < 0).sum()).float() / (2 * B)
+            crit[name] = (loss, joint, acc, pi_in)
+        loss_dis0, joint0, acc0, pi_leaf0 = crit["mi0_discriminator"]
+        loss_dis1, joint1, acc1, _ = crit["mi1_discriminator"]
+        loss_est, _, acc_est, _ = crit["mi_estimator"]
+        mim = joint0.mean()                                                # logit_constraint(real=False), model.py:855
+        ind_mim = joint1.mean()
+
+        adv = None
+        g_adv = None
+        if cfg.get("adversarial_regularization", True):                   # model.py:886-909
+            loa, loa_lr = st["loa"], mi.get("loa_lr", 4.0)
+            loa_gain = mim - (1.0 - MI_SLACK) * MI_TARGET
+            if mi.get("loa_adaptive", True):
+                active = (loa_lr * loa_gain.detach() >= -loa).float()
+                adv = active * (loa * loa_gain + loa_lr / 2.0 * loa_gain ** 2)
+            else:
+                adv = loa * loa_gain
+            if "encoder_0" in keys:
+                g_adv = torch.autograd.grad([adv], [pi_leaf0], retain_graph=True)[0].float().view(2 * B, Z)[:B]
+        for name in ("mi0_discriminator", "mi1_discriminator", "mi_estimator"):
+            if name in keys:
+                ps = [bank.params[n] for n in bank.groups[name]["names"]]
+                torch.autograd.grad([crit[name][0]], ps)
+
+        # ================= A backward (model.py:739, 909, 930)
+        bw = None
+        beta_0 = cfg.get("beta_0", 1.0)
+        var_reg = cfg.get("variational_regularization", True)
+        if var_reg:
+            assert not cfg.get("test_mode", False)
+            explor = torch.exp(st["lor"])
+            bw = beta_0 * explor * bottleneck
+        if "encoder_0" in keys:
+            g_s0 = torch.zeros((7, B, Z), dtype=torch.float32, device=dev)
+            g_s0[0] = gz[:B]
+            if g_adv is not None:
+                g_s0[1] = g_adv
+            gp0 = ops.latent_bwd(pe_v0, noise["eps_pi0"], levels0, g_s0, explor.reshape(1) if var_reg else None,
+                                 beta_0 / B if var_reg else 0.0)
+            gp1 = ops.latent_bwd(pe_v1, noise["eps_pi1"][None], [1.0], gz[B:].contiguous()[None], None, 0.0)
+            g_pe = torch.cat([gp0, gp1], 0).view_as(pe)
+            e0_params = [bank.params[n] for n in bank.groups["encoder_0"]["names"]]
+            torch.autograd.grad([pe], e0_params, grad_outputs=[g_pe])
+
+        # ================= gradient all-reduce (data parallel) + TF Adam per key
+        self._reduce_and_step(keys)
+
+        # ================= state updates (update_ops; Appendix A.15: losses above used the pre-update state)
+        stats = torch.stack([mim.detach(), ind_mim.detach(), acc0, acc1, loss_dis0.detach(), loss_dis1.detach()])
+        if self.world_size > 1:
+            torch.distributed.all_reduce(stats, group=self.process_group)
+            stats /= self.world_size
+        g_mim, g_ind, g_acc0, g_acc1, g_l0, g_l1 = stats.unbind(0)
+        ema = lambda old, val: 0.99 * old + (1.0 - 0.99) * val            # model.py:28-35
+        new = dict(st)
+        new["avg_acc0"] = ema(st["avg_acc0"], g_acc0); new["avg_acc1"] = ema(st["avg_acc1"], g_acc1)
+        new["avg_acc_error"] = ema(st["avg_acc_error"], g_acc1 - g_acc0)
+        new["avg_loss_dis0"] = ema(st["avg_loss_dis0"], g_l0); new["avg_loss_dis1"] = ema(st["avg_loss_dis1"], g_l1)
+        new["avg_mim"] = ema(st["avg_mim"], g_mim); new["avg_independent_mim"] = ema(st["avg_independent_mim"], g_ind)
+        if cfg.get("adversarial_regularization", True) and mi.get("loa_adaptive", True):
+            new["loa"] = torch.clamp(st["loa"] + mi.get("loa_lr", 4.0) * (g_mim - (1.0 - MI_SLACK) * MI_TARGET), min=0.0)
+        if var_reg and mi.get("lor_adaptive", True):
+            new["lor"] = torch.clamp(st["lor"] + mi.get("lor_lr", 0.05) * (g_ind - MI_TARGET), mi.get("lor_min", 1.0),
+                                     mi.get("lor_max", 7.5))
+
+        # ================= losses per key + log ops (model.py:648-966; same names as the reference)
+        Ls = OrderedDict()
+        Ls["encoder_0"] = auto_rec + (adv if adv is not None else 0.0) + (bw if bw is not None else 0.0)
+        Ls["encoder_1"] = auto_rec
+        Ls["decoder_delta"] = auto_rec
+        Ls["decoder_visualize"] = auto_rec if pretrain else auto_rec + prior_total
+        Ls["mi0_discriminator"], Ls["mi1_discriminator"], Ls["mi_estimator"] = loss_dis0, loss_dis1, loss_est
+        self.losses = OrderedDict((k, Ls[k].detach()) for k in keys)
+        avg_mim = torch.clamp(st["avg_mim"], min=0.0); avg_ind = torch.clamp(st["avg_independent_mim"], min=0.0)
+        loo = torch.clamp((avg_ind - avg_mim) / (avg_ind + 1e-6), 0.0, 1.0)
+        log.update({"prior_gmrf": prior_gmrf, "prior_gmrf_weight": w_gmrf, "prior_gmrf_weighted": w_gmrf * prior_gmrf,
+                    "mask0_kl_weight": w_kl, "mask0_kl": mask0_kl, "mask0_kl_weighted": w_kl * mask0_kl,
+                    "variance_loss_weighted": w_var * variances, "variance_loss": variances, "variance_weight": w_var,
+                    "weakly_superv_loss_weight_p": w_weak, "weakly_superv_loss_p": weakly,
+                    "weakly_superv_loss_p_weighted": weakly * w_weak,
+                    "patch_loss": patch_loss, "patch_loss_weight": w_patch, "patch_loss_weighted": patch_loss * w_patch,
+                    "mumford_sha_lambda": make_var(step, cfg["mumford_sha_lambda"]),
+                    "mumford_sha_alpha": make_var(step, cfg["mumford_sha_alpha"]),
+                    "avg_acc_error": st["avg_acc_error"], "avg_mim": avg_mim, "avg_independent_mim": avg_ind,
+                    "loo": loo, "lon_gain": -loo + 0.025, "model_lon": st["lon"]})
+        for k in Ls:
+            log["loss_" + k] = Ls[k].detach()
+        log.update({"dis0_accuracy": acc0, "dis1_accuracy": acc1, "avg_dis0_accuracy": st["avg_acc0"],
+                    "avg_dis1_accuracy": st["avg_acc1"], "avg_loss_dis0": st["avg_loss_dis0"],
+                    "avg_loss_dis1": st["avg_loss_dis1"], "est_accuracy": acc_est,
+                    "mi_constraint": mim.detach(), "independent_mi_constraint": ind_mim.detach()})
+        if adv is not None:
+            log.update({"adversarial_weight": st["loa"], "adversarial_constraint": mim.detach(),
+                        "adversarial_weighted_loss": adv.detach(), "loa": st["loa"],
+                        "loa_gain": (mim - (1.0 - MI_SLACK) * MI_TARGET).detach()})
+        if bw is not None:
+            log.update({"bottleneck_weight": st["lor"], "bottleneck_loss": bottleneck, "bottleneck_weighted_loss": bw,
+                        "lor": st["lor"], "explor": beta_0 * torch.exp(st["lor"]), "lor_gain": (ind_mim - MI_TARGET).detach()})
+        log.update({"zr_mumford_sha": p_ms, "z_mumford_sha_smoothness_cost": sums0[6] / B,
+                    "z_mumford_sha_contour_cost": sums0[7] / B, "z_area_cost": area_cost,
+                    "prior_mumford_sha_weight": w_ms, "perceptual": rec.detach(), "lr": self.learning_rate()})
+        self.log_ops = log
+        self.state = new
+        self.global_step += 1
+        self._debug = {"l_mean": lm, "l": l, "m": m, "hard": hard, "px": px, "generated": gen, "feat": feat.detach(),
+                       "dl_tot": dl_tot, "dl_rec": dl_rec, "g_hard0": g_hard0, "g_hard1": g_hard1, "pe": pe2}
+        return self.losses
+
+    def _reduce_and_step(self, keys):
+        """RCCL all-reduce (sum, scaled by 1/world in the Adam kernel) of each key's flat gradient,
+        then one fused Adam launch per key (tf.train.AdamOptimizer semantics, Appendix A.12)."""
+        bank = self.model.bank
+        handles = []
+        if self.world_size > 1:
+            for k in keys:
+                handles.append(torch.distributed.all_reduce(bank.groups[k]["flat"]["g"], group=self.process_group,
+                                                            async_op=True))
+            for h in handles:
+                h.wait()
+        lr = self.learning_rate()
+        for k in keys:
+            grp = bank.groups[k]
+            grp["t"] += 1
+            t = grp["t"]
+            lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+            f = grp["flat"]
+            ops.adam_step(f["p"], f["g"], f["m"], f["v"], lr_t, self.beta1, self.beta2, self.adam_eps, 1.0 / self.world_size)
+        ops.WeightVersion.value += 1
+
+    # ------------------------------------------------------------------ edflow iterate(): log cadence of LoggingHook
+    def fetch_logs(self):
+        out = OrderedDict()
+        for k, v in self.log_ops.items():
+            out[k] = float(v) if torch.is_tensor(v) else float(v)
+        return out
+
+    def iterate(self, batch_iterator, num_steps=None, log_fn=print):
+        cfg = self.config
+        num_steps = num_steps if num_steps is not None else cfg.get("num_steps", 1000000)
+        log_freq, ckpt_freq = cfg.get("log_freq", 250), cfg.get("ckpt_freq", 10000)
+        for batch in batch_iterator:
+            if self.global_step >= num_steps:
+                break
+            s = self.global_step
+            self.train_step(batch)
+            if s % log_freq == 0 or (s & (s - 1)) == 0:      # edflow LoggingHook: steps 0,1,2,4,8,... and every log_freq
+                log_fn("[INFO] [LoggingHook]: global_step: {}".format(s))
+                for k, v in self.fetch_logs().items():
+                    log_fn("[INFO] [LoggingHook]: {}: {}".format(k, v))
+            if self.root and ckpt_freq and s > 0 and s % ckpt_freq == 0:
+                os.makedirs(os.path.join(self.root, "train", "checkpoints"), exist_ok=True)
+                self.save_checkpoint(os.path.join(self.root, "train", "checkpoints", "model.ckpt-{}".format(s)))

@@ -1,0 +1,315 @@
+"""Sub-network builders of the part-discovery model on top of the HIP operators.
+
+Same structure, variable names and creation order as the reference builders
+(cub/code/SB_model48i/model.py: encoder_model 38-54, hourglass_model 80-131, single_decoder_model
+134-156, discriminator_model 159-173; arg-scope / naming / weight sharing cub/code/nn.py:17-46), but
+every ``activate`` is folded into the load of the consuming convolution and CoordConv channels are an
+affine epilogue, so no activated / coordinate-augmented tensor is ever written to HBM.
+"""
+import math
+import zlib
+from collections import OrderedDict
+
+import torch
+
+from . import lib as L
+from . import ops
+from .ops import ConvLayer, round8
+
+SUBMODULES = ("encoder_0", "encoder_1", "decoder_delta", "decoder_visualize",
+              "mi0_discriminator", "mi1_discriminator", "mi_estimator")
+DSIZE = 512                     # model.py:10
+VGG_WIDTHS = (64, 128, 256, 512, 512)
+VGG_DEPTHS = (2, 2, 4, 4, 2)
+
+
+def _rng(seed, name):
+    g = torch.Generator()
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2 ** 63 - 1))
+    return g
+
+
+def uniform_init(seed, name, shape, bound):
+    """nn.py:634-652: V and b ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)); deterministic per variable name."""
+    u = torch.rand(shape, generator=_rng(seed, name), dtype=torch.float64)
+    return ((2.0 * u - 1.0) * bound).to(torch.float32)
+
+
+class ParamBank(object):
+    """All trainable variables, grouped per optimizer key into flat fp32 buffers
+    (params / grads / Adam m / Adam v) so that the optimizer and the DP all-reduce touch one
+    contiguous range per sub-network.  ``specs``: name -> (shape, bound)."""
+
+    def __init__(self, specs, device, seed=0):
+        self.specs = specs
+        self.device = device
+        self.groups = OrderedDict()
+        self.params, self.grads = OrderedDict(), OrderedDict()
+        for key in SUBMODULES:
+            names = [n for n in specs if key in n]      # edflow: var_list = [v for v in variables if key in v.name]
+            total = sum(int(torch.Size(specs[n][0]).numel()) for n in names)
+            flat = {k: torch.zeros(total, dtype=torch.float32, device=device) for k in ("p", "g", "m", "v")}
+            off = 0
+            for n in names:
+                shape = specs[n][0]
+                cnt = int(torch.Size(shape).numel())
+                self.params[n] = flat["p"][off:off + cnt].view(shape).requires_grad_(True)
+                self.grads[n] = flat["g"][off:off + cnt].view(shape)
+                off += cnt
+            self.groups[key] = {"names": names, "flat": flat, "t": 0}
+        self.initialize(seed)
+
+    @torch.no_grad()
+    def initialize(self, seed):
+        for n, (shape, bound) in self.specs.items():
+            self.params[n].copy_(uniform_init(seed, n, shape, bound))
+        ops.WeightVersion.value += 1
+
+    @torch.no_grad()
+    def load(self, state):
+        """state: name -> tensor (the oracle / checkpoint format)."""
+        for n, t in state.items():
+            if n in self.params:
+                self.params[n].copy_(t.to(torch.float32))
+        ops.WeightVersion.value += 1
+
+    def state(self):
+        return OrderedDict((n, p.detach().cpu().clone()) for n, p in self.params.items())
+
+
+class Act(object):
+    """Activation handle: tensor (None in the shape-only dry run) + logical channel count."""
+    __slots__ = ("t", "n", "h", "w", "c")
+
+    def __init__(self, t, n, h, w, c):
+        self.t, self.n, self.h, self.w, self.c = t, n, h, w, c
+
+
+class Scope(object):
+    """One nn.model_arg_scope: fresh counter per template call, variables shared by name."""
+
+    def __init__(self, owner, prefix, activation, coords):
+        self.owner, self.prefix, self.coords = owner, prefix, coords
+        self.act = L.ACT[activation]
+        self.counter = 0
+
+    def _layer(self, cin, cout, k, stride, act_in):
+        name = "{}/conv2d_{}".format(self.prefix, self.counter)
+        self.counter += 1
+        own = self.owner
+        if own.dry:
+            cin_v = cin + (2 if self.coords else 0)
+            bound = math.sqrt(1.0 / (cin_v * k * k))
+            own.specs[name + "/V"] = ((k, k, cin_v, cout), bound)
+            own.specs[name + "/b"] = ((cout,), bound)
+            return None
+        key = (name, act_in)
+        lay = own.layers.get(key)
+        if lay is None:
+            lay = ConvLayer(name, own.bank.params[name + "/V"], own.bank.params[name + "/b"], k, stride, self.coords, act_in)
+            lay.grad_V, lay.grad_b = own.bank.grads[name + "/V"], own.bank.grads[name + "/b"]
+            own.layers[key] = lay
+        return lay
+
+    def conv2d(self, x, cout, k=3, stride=1, act_in=L.ACT_NONE, res=None, res_self=False, out_f32=False):
+        lay = self._layer(x.c, cout, k, stride, act_in)
+        ho, wo = ops.same_geometry(x.h, k, stride)[0], ops.same_geometry(x.w, k, stride)[0]
+        if lay is None:
+            return Act(None, x.n, ho, wo, cout)
+        t = ops.conv(x.t, lay, res=None if res is None else res.t, res_self=res_self, out_f32=out_f32)
+        return Act(t, x.n, ho, wo, cout)
+
+    def nin(self, x, cout, **kw):
+        return self.conv2d(x, cout, k=1, **kw)
+
+    def downsample(self, x, cout):
+        return self.conv2d(x, cout, k=3, stride=2)
+
+    def residual_block(self, x, skipin=None, k=3):
+        """x + conv(act(x [++ nin(act(skip))]))  (nn.py:1042-1056, dropout keep_prob = 1)."""
+        if skipin is None:
+            return self.conv2d(x, x.c, k=k, act_in=self.act, res_self=True)
+        s = self.nin(skipin, x.c, act_in=self.act)
+        if x.t is None:
+            cat = Act(None, x.n, x.h, x.w, 2 * x.c)
+        else:
+            assert x.c % 8 == 0
+            cat = Act(torch.cat([x.t, s.t], dim=-1), x.n, x.h, x.w, 2 * x.c)
+        return self.conv2d(cat, x.c, act_in=self.act, res=x)
+
+    def upsample_linear(self, x):
+        if x.t is None:
+            return Act(None, x.n, 2 * x.h, 2 * x.w, x.c)
+        return Act(ops.BilinearFn.apply(x.t), x.n, 2 * x.h, 2 * x.w, x.c)
+
+    def act_mean(self, x):
+        if x.t is None:
+            return Act(None, x.n, 1, 1, x.c)
+        return Act(ops.ActMeanFn.apply(x.t, self.act, 0.2), x.n, 1, 1, x.c)
+
+
+def encoder_model(sc, x, out_size, config, extra_resnets, out_f32=False):
+    """model.py:38-54."""
+    h = sc.conv2d(x, config[0])
+    h = sc.residual_block(h)
+    for nf in config[1:]:
+        h = sc.downsample(h, nf)
+        h = sc.residual_block(h)
+    for _ in range(extra_resnets):
+        h = sc.residual_block(h)
+    h = sc.act_mean(h)
+    return sc.nin(h, out_size, out_f32=out_f32)
+
+
+def single_decoder_model(sc, z, n_out, config, upsample_config):
+    """model.py:134-156 (upsample 'linear' ignores num_units: nn.py:834-847)."""
+    if isinstance(upsample_config, str):
+        upsample_config = [upsample_config] * (len(config) - 1)
+    assert len(upsample_config) == len(config) - 1
+    if any(u != "linear" for u in upsample_config):
+        raise NotImplementedError("only upsample method 'linear' is on the shipped path")
+    c = config[-1]
+    h = sc.nin(z, 4 * 4 * c)
+    if h.t is not None:
+        assert h.t.shape[-1] == 16 * c
+        h = Act(h.t.view(h.n, 4, 4, c), h.n, 4, 4, c)
+    else:
+        h = Act(None, h.n, 4, 4, c)
+    h = sc.conv2d(h, c)
+    h = sc.residual_block(h)
+    for _nf, _u in zip(config[-2::-1], upsample_config[-1::-1]):
+        h = sc.residual_block(h)
+        h = sc.upsample_linear(h)
+    h = sc.residual_block(h)
+    return sc.conv2d(h, n_out, out_f32=True)
+
+
+def hourglass_model(sc, x, config, extra_resnets, n_out=3, upsample_method="subpixel"):
+    """model.py:80-131 with alpha = pi = None (model.py:91-92)."""
+    if upsample_method != "linear":
+        raise NotImplementedError("only upsample method 'linear' is on the shipped path")
+    hs = []
+    h = sc.conv2d(x, config[0])
+    h = sc.residual_block(h)
+    for nf in config[1:]:
+        h = sc.downsample(h, nf)
+        h = sc.residual_block(h)
+        hs.append(h)
+    for _ in range(extra_resnets):
+        h = sc.residual_block(h)
+    for i, _nf in enumerate(config[-2::-1]):
+        h = sc.residual_block(h, skipin=hs[-(i + 1)])
+        h = sc.upsample_linear(h)
+    h = sc.residual_block(h)
+    return sc.conv2d(h, n_out)
+
+
+def discriminator_towers(sc, pair):
+    """model.py:159-173 up to the two 512-d embeddings (the dot product is done by the caller)."""
+    outs = []
+    for z in pair:
+        h = sc.nin(z, DSIZE)
+        for _ in range(4):
+            h = sc.residual_block(h, k=1)
+        h = sc.nin(h, DSIZE, act_in=sc.act)
+        outs.append(h)
+    return outs
+
+
+class Nets(object):
+    """The seven templates of model.py:349-380 bound to one ParamBank."""
+
+    def __init__(self, config, device, seed=0):
+        self.config = config
+        self.dry, self.specs, self.layers, self.bank = True, OrderedDict(), {}, None
+        S = config["spatial_size"]
+        Z, A, P = config.get("z0_size", 256), config.get("local_app_size", 64), config["n_parts"]
+        img = Act(None, 1, S, S, 3)
+        self.e_pi(img); self.e_alpha(img)
+        self.dv(Act(None, 1, 1, 1, Z))
+        self.dd(Act(None, 1, S, S, A + P))
+        for name in ("mi0_discriminator", "mi1_discriminator", "mi_estimator"):
+            self.critic(name, (Act(None, 1, 1, 1, Z), Act(None, 1, 1, 1, A)))
+        self.dry = False
+        self.bank = ParamBank(self.specs, device, seed)
+
+    def _scope(self, name, kw):
+        return Scope(self, name, kw.get("activation", "relu"), kw.get("coords", False))
+
+    def e_pi(self, x):
+        kw = self.config["encoder0"]
+        z = self.config.get("z0_size", 256)
+        return encoder_model(self._scope("encoder_0", kw), x, z + z * (z + 1) // 2, kw["config"], kw["extra_resnets"],
+                             out_f32=True)
+
+    def e_alpha(self, x):
+        kw = self.config["encoder1"]
+        return encoder_model(self._scope("encoder_1", kw), x, self.config.get("local_app_size", 64), kw["config"],
+                             kw["extra_resnets"])
+
+    def dv(self, z):
+        kw = self.config["dv"]
+        return single_decoder_model(self._scope("decoder_visualize", kw), z, self.config["n_parts"], kw["config"],
+                                    kw.get("upsample_config", "subpixel"))
+
+    def dd(self, x):
+        kw = self.config["final_hour"]
+        return hourglass_model(self._scope("decoder_delta", kw), x, kw["config"], kw["extra_resnets"],
+                               upsample_method=kw.get("upsample_method", "subpixel"))
+
+    def critic(self, name, pair):
+        return discriminator_towers(self._scope(name, self.config["discriminator"]), pair)
+
+
+# --------------------------------------------------------------------------- perceptual trunk (EXTERNAL, stand-in weights)
+class VggTrunk(object):
+    """Keras-VGG19 topology up to block5_conv2 with frozen weights (edflow VGG19Features, UNVERIFIED;
+    the ImageNet weights are not obtainable offline, so He-normal stand-ins are generated per name --
+    ``load`` accepts real Keras kernels in HWIO)."""
+
+    def __init__(self, device, seed=7, widths=VGG_WIDTHS, depths=VGG_DEPTHS):
+        self.depths = depths
+        self.layers = []
+        cin = 3
+        for bi, (wd, dp) in enumerate(zip(widths, depths)):
+            blk = []
+            for ci in range(dp):
+                name = "vgg19/block{}_conv{}".format(bi + 1, ci + 1)
+                std = math.sqrt(2.0 / (9 * cin))
+                V = (torch.randn((3, 3, cin, wd), generator=_rng(seed, name), dtype=torch.float64) * std).float().to(device)
+                b = torch.zeros(wd, device=device)
+                first = bi == 0 and ci == 0
+                blk.append(ConvLayer(name, V, b, 3, 1, False, L.ACT_NONE if first else L.ACT_RELU))
+                cin = wd
+            self.layers.append(blk)
+
+    def load(self, state):
+        for blk in self.layers:
+            for lay in blk:
+                lay.V.copy_(state[lay.name + "/V"]); lay.b.copy_(state[lay.name + "/b"])
+        ops.WeightVersion.value += 1
+
+    def features(self, x_img, act_dtype):
+        """x_img [n,H,W,>=3] in [-1,1] -> list of (pre-activation feature, logical channels, act for L1)."""
+        x = ops.VggPreFn.apply(x_img, act_dtype)
+        feats = [(x, 3, L.ACT_NONE)]
+        h = x
+        for bi, blk in enumerate(self.layers):
+            if bi > 0:
+                h = ops.MaxPoolFn.apply(h)     # max-pool commutes with ReLU: pool the pre-activations
+            for ci, lay in enumerate(blk):
+                h = ops.ConvFn.apply(h, lay.V, lay.b, None, lay, 0, False, None)
+                if ci == 1:
+                    feats.append((h, lay.co, L.ACT_RELU))
+        return feats
+
+    def loss(self, target_img, generated_img, act_dtype):
+        """sum_l mean |f_l(target) - f_l(generated)| (feature weights 1, gram weight 0: model.py:608)."""
+        with torch.no_grad():
+            ft = self.features(target_img, act_dtype)
+        fg = self.features(generated_img, act_dtype)
+        total = None
+        for (a, c, act), (b, _, _) in zip(ft, fg):
+            term = ops.L1MeanFn.apply(a, b, c, act)
+            total = term if total is None else total + term
+        return total

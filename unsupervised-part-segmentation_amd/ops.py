@@ -1,0 +1,506 @@
+"""Host-side operators over the C ABI: tap geometry for TF 'SAME' convolutions and the autograd
+wrappers (forward / dgrad / wgrad) that let PyTorch own the tape while every FLOP runs in
+libupsparts_hip.so.  Reference semantics: cub/code/nn.py (conv2d 617-711, residual_block 1042-1056,
+upsample 834-847), SURVEY.md Appendix A.
+
+Activations are NHWC tensors whose last dimension is the PHYSICAL channel count (multiple of 8);
+weights stay fp32 in the TF variable layout HWIO and are re-laid-out / converted once per optimizer step.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def round8(c):
+    return (c + 7) // 8 * 8
+
+
+def same_geometry(size, k, stride):
+    """TF 'SAME': out = ceil(in/stride); pad_before = pad_total // 2 (Appendix A.1)."""
+    out = -(-size // stride)
+    pad_total = max((out - 1) * stride + k - size, 0)
+    return out, pad_total // 2
+
+
+class _Workspace(object):
+    """Grow-only device scratch (one per process; all launches are on the current stream)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+WORKSPACE = _Workspace()
+COLSUM_WS = _Workspace()
+
+
+class WeightVersion(object):
+    """Bumped by the optimizer; ConvLayer caches of converted weights key on it."""
+    value = 0
+
+
+class ConvLayer(object):
+    """One conv2d variable pair (V [kh,kw,Cin(+2),Cout] HWIO fp32, b [Cout]) + its launch geometry."""
+
+    def __init__(self, name, V, b, k, stride, coords, act_in, slope=0.2):
+        self.name, self.V, self.b = name, V, b
+        self.k, self.stride, self.coords = k, stride, coords
+        self.act_in = L.ACT[act_in] if not isinstance(act_in, int) else act_in
+        self.slope = slope
+        self.cin_v = V.shape[2]
+        self.ci_log = self.cin_v - (2 if coords else 0)
+        self.co = V.shape[3]
+        self.grad_V = None          # optional preallocated views into a flat gradient buffer
+        self.grad_b = None
+        self._cache = {}
+
+    # ---- converted weights (refreshed when the optimizer has stepped)
+    def prepared(self, dtype_code, hi, wi, need_dgrad):
+        key = (dtype_code, hi, wi)
+        ent = self._cache.get(key)
+        if ent is None or ent["version"] != WeightVersion.value:
+            ent = {"version": WeightVersion.value, "w_fwd": None, "w_dgrad": None, "ctab": None}
+            self._cache[key] = ent
+        dev = self.V.device
+        td = L.torch_dtype(dtype_code)
+        ntaps = self.k * self.k
+        ci_pad = round8(self.ci_log)
+        if ent["w_fwd"] is None or (need_dgrad and ent["w_dgrad"] is None):
+            do_f = ent["w_fwd"] is None
+            do_d = need_dgrad and ent["w_dgrad"] is None
+            if do_f:
+                ent["w_fwd"] = torch.empty((ntaps, self.co, ci_pad), dtype=td, device=dev)
+            if do_d:
+                ent["w_dgrad"] = torch.empty((ntaps, self.ci_log, round8(self.co)), dtype=td, device=dev)
+            L.call("ups_weight_prep", L.ptr(self.V), ntaps, self.cin_v, self.ci_log, self.co, dtype_code,
+                   L.ptr(ent["w_fwd"]) if do_f else None, ci_pad,
+                   L.ptr(ent["w_dgrad"]) if do_d else None, self.ci_log, round8(self.co), L.stream())
+        if self.coords and ent["ctab"] is None:
+            ent["ctab"] = torch.empty((64, 3, self.co), dtype=torch.float32, device=dev)
+            dy, dx, _ = self.fwd_taps(hi, wi)
+            ax, ay = 2.0 / max(1, hi - 1), 2.0 / max(1, wi - 1)     # nn.py:2145-2148 (xx / (H-1), yy / (W-1))
+            L.call("ups_coord_table", L.ptr(self.V), self.k, self.k, self.ci_log, self.co,
+                   (C.c_int32 * 9)(*dy), (C.c_int32 * 9)(*dx), self.stride, self.stride, ax, ay,
+                   L.ptr(ent["ctab"]), L.stream())
+        return ent
+
+    def out_hw(self, hi, wi):
+        return same_geometry(hi, self.k, self.stride)[0], same_geometry(wi, self.k, self.stride)[0]
+
+    def fwd_taps(self, hi, wi):
+        _, pby = same_geometry(hi, self.k, self.stride)
+        _, pbx = same_geometry(wi, self.k, self.stride)
+        dy, dx, tw = [0] * 9, [0] * 9, [0] * 9
+        for r in range(self.k):
+            for s in range(self.k):
+                t = r * self.k + s
+                dy[t], dx[t], tw[t] = r - pby, s - pbx, t
+        return dy, dx, tw
+
+
+def _fill_taps(desc, dy, dx, tw, ntaps):
+    for t in range(9):
+        desc.tap_dy[t] = dy[t] if t < ntaps else 0
+        desc.tap_dx[t] = dx[t] if t < ntaps else 0
+        desc.tap_w[t] = tw[t] if t < ntaps else 0
+    desc.ntaps = ntaps
+
+
+def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None):
+    """out = conv(act(x) (+coords), V) + b (+ res);  x [n,hi,wi,ldi]."""
+    n, hi, wi, ldi = x.shape
+    dcode = L.dt(x)
+    ho, wo = layer.out_hw(hi, wi)
+    ent = layer.prepared(dcode, hi, wi, need_dgrad=False)
+    ldo = ldo if ldo is not None else (layer.co if out_f32 else round8(layer.co))
+    co_fill = co_fill if co_fill is not None else ldo
+    out = torch.empty((n, ho, wo, ldo), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    d = L.ConvDesc()
+    d.dtype = dcode
+    d.n, d.hi, d.wi, d.ci, d.ldi = n, hi, wi, round8(layer.ci_log), ldi
+    d.ho, d.wo, d.co, d.co_fill, d.ldo = ho, wo, layer.co, co_fill, ldo
+    d.out_h, d.out_w, d.out_sy, d.out_sx, d.out_oy, d.out_ox = ho, wo, 1, 1, 0, 0
+    d.in_sy = d.in_sx = layer.stride
+    dy, dx, tw = layer.fwd_taps(hi, wi)
+    _fill_taps(d, dy, dx, tw, layer.k * layer.k)
+    d.kh = d.kw = layer.k
+    d.act_in, d.act_slope, d.out_f32, d.dact_kind = layer.act_in, layer.slope, int(out_f32), 0
+    d.ldr = res.shape[-1] if res is not None else 0
+    d.ldd = 0
+    d.in_, d.w, d.out = x.data_ptr(), ent["w_fwd"].data_ptr(), out.data_ptr()
+    d.bias = layer.b.data_ptr()
+    d.coord_tab = ent["ctab"].data_ptr() if layer.coords else None
+    d.res = res.data_ptr() if res is not None else None
+    d.dact = None
+    assert round8(layer.ci_log) <= ldi, (layer.name, layer.ci_log, ldi)
+    L.call("ups_conv_igemm", C.byref(d), L.stream())
+    return out
+
+
+def conv_dgrad(g, x, layer, res=None):
+    """gx = act'(x) * conv^T(g) (+ res);  g [n,ho,wo,ldg] in the activation dtype, x the forward input."""
+    n, hi, wi, ldi = x.shape
+    dcode = L.dt(x)
+    ho, wo = layer.out_hw(hi, wi)
+    ent = layer.prepared(dcode, hi, wi, need_dgrad=True)
+    gx = torch.empty_like(x)
+    k, st = layer.k, layer.stride
+    _, pby = same_geometry(hi, k, st)
+    _, pbx = same_geometry(wi, k, st)
+    classes = [(0, 0)] if st == 1 else [(py, px) for py in range(st) for px in range(st)]
+    for (py, px) in classes:
+        lat_h = (hi - py + st - 1) // st
+        lat_w = (wi - px + st - 1) // st
+        if lat_h <= 0 or lat_w <= 0:
+            continue
+        dy, dx, tw = [], [], []
+        for r in range(k):
+            if (py + pby - r) % st:
+                continue
+            for s in range(k):
+                if (px + pbx - s) % st:
+                    continue
+                dy.append((py + pby - r) // st); dx.append((px + pbx - s) // st); tw.append(r * k + s)
+        d = L.ConvDesc()
+        d.dtype = dcode
+        d.n, d.hi, d.wi, d.ci, d.ldi = n, ho, wo, round8(layer.co), g.shape[-1]
+        d.ho, d.wo, d.co, d.co_fill, d.ldo = lat_h, lat_w, layer.ci_log, ldi, ldi
+        d.out_h, d.out_w, d.out_sy, d.out_sx, d.out_oy, d.out_ox = hi, wi, st, st, py, px
+        d.in_sy = d.in_sx = 1
+        if not dy:      # no tap reaches this parity class: gradient is zero there (still apply res)
+            dy, dx, tw = [0], [0], [0]
+            raise L.UpsError("empty tap class is not expected for k=3/k=1 'SAME' convolutions")
+        _fill_taps(d, dy + [0] * 9, dx + [0] * 9, tw + [0] * 9, len(dy))
+        d.kh, d.kw = 1, len(dy)
+        d.act_in, d.act_slope, d.out_f32 = 0, layer.slope, 0
+        d.dact_kind = layer.act_in
+        d.ldr = res.shape[-1] if res is not None else 0
+        d.ldd = ldi
+        d.in_, d.w, d.out = g.data_ptr(), ent["w_dgrad"].data_ptr(), gx.data_ptr()
+        d.bias, d.coord_tab = None, None
+        d.res = res.data_ptr() if res is not None else None
+        d.dact = x.data_ptr() if layer.act_in != L.ACT_NONE else None
+        assert round8(layer.co) <= g.shape[-1]
+        L.call("ups_conv_igemm", C.byref(d), L.stream())
+    return gx
+
+
+def conv_wgrad(g, x, layer):
+    """(dV [kh,kw,cin_v,co] fp32, db [co] fp32)."""
+    n, hi, wi, ldi = x.shape
+    dcode = L.dt(x)
+    ho, wo = layer.out_hw(hi, wi)
+    dev = x.device
+    gV = layer.grad_V if layer.grad_V is not None else torch.empty_like(layer.V)
+    gb = layer.grad_b if layer.grad_b is not None else torch.empty_like(layer.b)
+    d = L.WgradDesc()
+    d.dtype = dcode
+    d.n, d.hi, d.wi, d.ci, d.ldi = n, hi, wi, round8(layer.ci_log), ldi
+    d.ci_log, d.cin_v = layer.ci_log, layer.cin_v
+    d.ho, d.wo, d.co, d.ldo = ho, wo, layer.co, g.shape[-1]
+    d.in_sy = d.in_sx = layer.stride
+    dy, dx, tw = layer.fwd_taps(hi, wi)
+    _fill_taps(d, dy, dx, tw, layer.k * layer.k)
+    d.act_in, d.act_slope = layer.act_in, layer.slope
+    sk, wsb = C.c_int32(0), C.c_size_t(0)
+    d.in_, d.dout, d.grad = x.data_ptr(), g.data_ptr(), gV.data_ptr()
+    L.call("ups_conv_wgrad_plan", C.byref(d), C.byref(sk), C.byref(wsb))
+    ws = WORKSPACE.get(wsb.value, dev)
+    d.splitk, d.workspace = sk.value, ws.data_ptr()
+    L.call("ups_conv_wgrad", C.byref(d), L.stream())
+    if layer.coords:
+        gsum = torch.empty((ho * wo, layer.co), dtype=torch.float32, device=dev)
+        L.call("ups_batch_sum", L.ptr(g), dcode, n, ho * wo, layer.co, g.shape[-1], L.ptr(gsum), L.stream())
+        ax, ay = 2.0 / max(1, hi - 1), 2.0 / max(1, wi - 1)
+        L.call("ups_coord_wgrad", L.ptr(gsum), hi, wi, ho, wo, layer.co, layer.k, layer.k,
+               (C.c_int32 * 9)(*dy), (C.c_int32 * 9)(*dx), layer.stride, layer.stride, ax, ay,
+               layer.ci_log, L.ptr(gV), L.ptr(gb), L.stream())
+    else:
+        cws = COLSUM_WS.get(1024 * layer.co * 4, dev)
+        L.call("ups_col_sum", L.ptr(g), dcode, n * ho * wo, layer.co, g.shape[-1], L.ptr(gb), L.ptr(cws), L.stream())
+    return gV, gb
+
+
+def to_act_dtype(g, like_dtype, co):
+    """fp32 gradient [.., c] of an fp32-output conv -> activation dtype with 8-padded channels."""
+    ld = round8(co)
+    if g.dtype == like_dtype and g.shape[-1] == ld:
+        return g.contiguous()
+    g = g.contiguous()
+    assert g.dtype == torch.float32
+    out = torch.empty(g.shape[:-1] + (ld,), dtype=like_dtype, device=g.device)
+    rows = g.numel() // g.shape[-1]
+    L.call("ups_pad_convert", L.ptr(g), g.shape[-1], L.ptr(out), L.dt(out), ld, rows, L.stream())
+    return out
+
+
+class ConvFn(torch.autograd.Function):
+    """res_mode 0: plain; 1: out = res + conv(x); 2: out = x + conv(act(x)) (residual_block, nn.py:1042-1056)."""
+
+    @staticmethod
+    def forward(ctx, x, V, b, res, layer, res_mode, out_f32, ldo):
+        x = x.contiguous()
+        r = x if res_mode == 2 else (res.contiguous() if res_mode == 1 else None)
+        out = conv_forward(x, layer, res=r, out_f32=out_f32, ldo=ldo)
+        ctx.save_for_backward(x)
+        ctx.layer, ctx.res_mode = layer, res_mode
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        layer = ctx.layer
+        g = to_act_dtype(g, x.dtype, layer.co)
+        gx = gV = gb = gres = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gV, gb = conv_wgrad(g, x, layer)
+        if ctx.needs_input_grad[0]:
+            gx = conv_dgrad(g, x, layer, res=g if ctx.res_mode == 2 else None)
+        if ctx.res_mode == 1 and ctx.needs_input_grad[3]:
+            gres = g
+        return gx, gV, gb, gres, None, None, None, None
+
+
+def conv(x, layer, res=None, res_self=False, out_f32=False, ldo=None):
+    mode = 2 if res_self else (1 if res is not None else 0)
+    return ConvFn.apply(x, layer.V, layer.b, res, layer, mode, out_f32, ldo)
+
+
+class BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+        L.call("ups_bilinear2x_fwd", L.ptr(x), L.ptr(y), L.dt(x), n, h, w, c, L.stream())
+        ctx.shape = (n, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c = ctx.shape
+        g = g.contiguous()
+        gx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+        L.call("ups_bilinear2x_bwd", L.ptr(g), L.ptr(gx), L.dt(g), n, h, w, c, L.stream())
+        return gx
+
+
+class ActMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        y = torch.empty((n, 1, 1, c), dtype=x.dtype, device=x.device)
+        L.call("ups_act_mean_fwd", L.ptr(x), L.ptr(y), L.dt(x), n, h * w, c, act, slope, L.stream())
+        ctx.save_for_backward(x)
+        ctx.act, ctx.slope = act, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        n, h, w, c = x.shape
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        L.call("ups_act_mean_bwd", L.ptr(x), L.ptr(g), L.ptr(gx), L.dt(x), n, h * w, c, ctx.act, ctx.slope, L.stream())
+        return gx, None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+        L.call("ups_maxpool2_fwd", L.ptr(x), L.ptr(y), L.dt(x), n, h, w, c, L.stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        n, h, w, c = x.shape
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        L.call("ups_maxpool2_bwd", L.ptr(x), L.ptr(g), L.ptr(gx), L.dt(x), n, h, w, c, L.stream())
+        return gx
+
+
+class VggPreFn(torch.autograd.Function):
+    """[-1,1] RGB -> BGR*255 - ImageNet mean, 8-channel padded (edflow VGG19Features, UNVERIFIED)."""
+
+    @staticmethod
+    def forward(ctx, x, act_dtype):
+        x = x.contiguous()
+        pixels = x.numel() // x.shape[-1]
+        y = torch.empty(x.shape[:-1] + (8,), dtype=act_dtype, device=x.device)
+        L.call("ups_vgg_preprocess_fwd", L.ptr(x), int(x.dtype == torch.float32), x.shape[-1], L.ptr(y), L.dt(y),
+               pixels, L.stream())
+        ctx.in_shape, ctx.in_dtype = x.shape, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        assert ctx.in_dtype == g.dtype, "gradient flows back to an activation-dtype image"
+        gx = torch.empty(ctx.in_shape, dtype=g.dtype, device=g.device)
+        L.call("ups_vgg_preprocess_bwd", L.ptr(g), L.ptr(gx), L.dt(g), ctx.in_shape[-1],
+               g.numel() // 8, L.stream())
+        return gx, None
+
+
+L1_BLOCKS = 1024
+
+
+class L1MeanFn(torch.autograd.Function):
+    """mean |act(a) - act(b)| over the logical channels; gradient w.r.t. b only (a is the target)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c_log, act):
+        a, b = a.contiguous(), b.contiguous()
+        rows, ld = b.numel() // b.shape[-1], b.shape[-1]
+        partial = torch.empty(L1_BLOCKS, dtype=torch.float32, device=b.device)
+        out = torch.empty((), dtype=torch.float32, device=b.device)
+        L.call("ups_l1_fwd", L.ptr(a), L.ptr(b), L.dt(b), rows, c_log, ld, act, L.ptr(partial), L1_BLOCKS, L.stream())
+        L.call("ups_sum_scale", L.ptr(partial), L1_BLOCKS, 1.0 / (rows * c_log), L.ptr(out), 0, L.stream())
+        ctx.save_for_backward(a, b)
+        ctx.c_log, ctx.act = c_log, act
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        rows, ld = b.numel() // b.shape[-1], b.shape[-1]
+        gb = torch.empty_like(b)
+        g = g.contiguous().float()
+        L.call("ups_l1_bwd", L.ptr(a), L.ptr(b), L.ptr(gb), L.dt(b), rows, ctx.c_log, ld, ctx.act, L.ptr(g),
+               1.0 / (rows * ctx.c_log), L.stream())
+        return None, gb, None, None
+
+
+class MaskPartsFn(torch.autograd.Function):
+    """mask_parts + part-major transpose (model.py:176-187, nn.py:97-103): -> [P*B,H,W,8]."""
+
+    @staticmethod
+    def forward(ctx, view, hard, act_dtype):
+        B, H, W, P = hard.shape
+        out = torch.empty((P * B, H, W, 8), dtype=act_dtype, device=hard.device)
+        L.call("ups_mask_parts_fwd", L.ptr(view), L.ptr(hard), L.ptr(out), L.dt(out), B, H * W, P, L.stream())
+        ctx.save_for_backward(view)
+        ctx.shape = (B, H, W, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (view,) = ctx.saved_tensors
+        B, H, W, P = ctx.shape
+        g = g.contiguous()
+        gh = torch.empty((B, H, W, P), dtype=torch.float32, device=g.device)
+        L.call("ups_mask_parts_bwd", L.ptr(view), L.ptr(g), L.ptr(gh), L.dt(g), B, H * W, P, L.stream())
+        return None, gh, None
+
+
+class UnpoolFn(torch.autograd.Function):
+    """unpool_features + concat with the hard mask (model.py:225-249, 482-484): -> [B,H,W,round8(F+P)]."""
+
+    @staticmethod
+    def forward(ctx, hard, feat, act_dtype):
+        B, H, W, P = hard.shape
+        F = feat.shape[-1]
+        ldo = round8(F + P)
+        feat = feat.contiguous()
+        out = torch.empty((B, H, W, ldo), dtype=act_dtype, device=hard.device)
+        L.call("ups_unpool_fwd", L.ptr(hard), L.ptr(feat), L.ptr(out), L.dt(out), B, H * W, P, F, ldo, L.stream())
+        ctx.save_for_backward(hard, feat)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        hard, feat = ctx.saved_tensors
+        B, H, W, P = hard.shape
+        F = feat.shape[-1]
+        g = g.contiguous()
+        gh = torch.empty_like(hard)
+        nfl = L.load().ups_unpool_bwd_floats(B, P, F)
+        gf = torch.empty(nfl, dtype=torch.float32, device=g.device)
+        L.call("ups_unpool_bwd", L.ptr(hard), L.ptr(feat), L.ptr(g), L.ptr(gh), L.ptr(gf), L.dt(g), B, H * W, P, F,
+               g.shape[-1], L.stream())
+        return gh, gf[:B * P * F].view(B, P, F), None
+
+
+# --------------------------------------------------------------------------- raw (non-autograd) part-path / latent calls
+def part_softmax(mean, eps=None, want_hard=True, want_argmax=False):
+    mean = mean.contiguous()
+    pixels, P = mean.numel() // mean.shape[-1], mean.shape[-1]
+    l = torch.empty_like(mean) if eps is not None else mean
+    m = torch.empty_like(mean)
+    hard = torch.empty_like(mean) if want_hard else None
+    am = torch.empty(mean.shape[:-1], dtype=torch.int64, device=mean.device) if want_argmax else None
+    L.call("ups_part_softmax_fwd", L.ptr(mean), L.ptr(eps.contiguous()) if eps is not None else None,
+           L.ptr(l) if eps is not None else None, L.ptr(m), L.ptr(hard), L.ptr(am), pixels, P, L.stream())
+    return l, m, hard, am
+
+
+def spatial_moments(x, gamma, rect_px=None, half=0):
+    n, h, w, P = x.shape
+    nfl = L.load().ups_spatial_moments_floats(n, P)
+    buf = torch.empty(nfl, dtype=torch.float32, device=x.device)
+    L.call("ups_spatial_moments", L.ptr(x), n, h, w, P, float(gamma), L.ptr(rect_px), half, half, L.ptr(buf), L.stream())
+    return buf[:n * P * 8].view(n, P, 8)
+
+
+def moments_to_px(stats, h):
+    n, P, _ = stats.shape
+    px = torch.empty((n, P, 2), dtype=torch.int32, device=stats.device)
+    L.call("ups_moments_to_px", L.ptr(stats), n * P, h, L.ptr(px), L.stream())
+    return px
+
+
+def draw_rect(px, h, w, half):
+    n, P, _ = px.shape
+    out = torch.empty((n, h, w, P), dtype=torch.float32, device=px.device)
+    L.call("ups_draw_rect", L.ptr(px), n, h, w, P, half, half, L.ptr(out), L.stream())
+    return out
+
+
+def latent_fwd(params, eps, levels, want_kl):
+    """params [B,NP] fp32, eps [S,B,Z] -> samples [S,B,Z], kl_rows [B,Z] or None."""
+    S, B, Z = eps.shape
+    samples = torch.empty((S, B, Z), dtype=torch.float32, device=params.device)
+    kl = torch.empty((B, Z), dtype=torch.float32, device=params.device) if want_kl else None
+    L.call("ups_latent_fwd", L.ptr(params), L.ptr(eps.contiguous()), (C.c_float * S)(*levels), S, B, Z,
+           L.ptr(samples), L.ptr(kl), L.stream())
+    return samples, kl
+
+
+def latent_bwd(params, eps, levels, g_samples, g_kl_dev, g_kl_scale):
+    S, B, Z = eps.shape
+    gp = torch.empty_like(params)
+    L.call("ups_latent_bwd", L.ptr(params), L.ptr(eps.contiguous()), (C.c_float * S)(*levels),
+           L.ptr(g_samples.contiguous()), L.ptr(g_kl_dev), float(g_kl_scale), S, B, Z, L.ptr(gp), L.stream())
+    return gp
+
+
+def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0):
+    L.call("ups_adam", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), float(lr_t), float(beta1), float(beta2),
+           float(eps), float(grad_scale), L.stream())
+
+
+def gauss_hm(pts, stddev, h, w):
+    B, K, _ = pts.shape
+    out = torch.empty((B, h, w, K), dtype=torch.float32, device=pts.device)
+    L.call("ups_gauss_hm", L.ptr(pts.contiguous()), L.ptr(stddev.contiguous()), L.ptr(out), B, h, w, K, L.stream())
+    return out
+
+
+def gauss_hm3(mu, Lt, h, w):
+    B, K, _ = mu.shape
+    out = torch.empty((B, h, w, K), dtype=torch.float32, device=mu.device)
+    L.call("ups_gauss_hm3", L.ptr(mu.contiguous()), L.ptr(Lt.contiguous()), L.ptr(out), B, h, w, K, L.stream())
+    return out
