@@ -346,7 +346,8 @@ class Trainer(object):
         if "decoder_visualize" in keys:
             dv_params = [bank.params[n] for n in bank.groups["decoder_visualize"]["names"]]
             torch.autograd.grad([l_mean], dv_params, grad_outputs=[dl_tot], retain_graph=True)
-        gz = torch.autograd.grad([l_mean], [z_leaf], grad_outputs=[dl_rec])[0].float().view(2 * B, Z)
+        with ops.skip_wgrad():
+            gz = torch.autograd.grad([l_mean], [z_leaf], grad_outputs=[dl_rec])[0].float().view(2 * B, Z)
 
         # ================= D: critics (model.py:502-521, 800-866)
         mi = cfg["MI"]
@@ -378,7 +379,8 @@ class Trainer(object):
             else:
                 adv = loa * loa_gain
             if "encoder_0" in keys:
-                g_adv = torch.autograd.grad([adv], [pi_leaf0], retain_graph=True)[0].float().view(2 * B, Z)[:B]
+                with ops.skip_wgrad():
+                    g_adv = torch.autograd.grad([adv], [pi_leaf0], retain_graph=True)[0].float().view(2 * B, Z)[:B]
         for name in ("mi0_discriminator", "mi1_discriminator", "mi_estimator"):
             if name in keys:
                 ps = [bank.params[n] for n in bank.groups[name]["names"]]

@@ -240,6 +240,20 @@ def to_act_dtype(g, like_dtype, co):
     return out
 
 
+class GradMode(object):
+    """ctx.needs_input_grad is fixed when the tape is recorded, not per autograd.grad call; a backward pass
+    that only wants input gradients (e.g. d rec / d z through the mask decoder) sets skip_wgrad."""
+    skip_wgrad = False
+
+
+class skip_wgrad(object):
+    def __enter__(self):
+        self.prev, GradMode.skip_wgrad = GradMode.skip_wgrad, True
+
+    def __exit__(self, *a):
+        GradMode.skip_wgrad = self.prev
+
+
 class ConvFn(torch.autograd.Function):
     """res_mode 0: plain; 1: out = res + conv(x); 2: out = x + conv(act(x)) (residual_block, nn.py:1042-1056)."""
 
@@ -258,7 +272,7 @@ class ConvFn(torch.autograd.Function):
         layer = ctx.layer
         g = to_act_dtype(g, x.dtype, layer.co)
         gx = gV = gb = gres = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not GradMode.skip_wgrad:
             gV, gb = conv_wgrad(g, x, layer)
         if ctx.needs_input_grad[0]:
             gx = conv_dgrad(g, x, layer, res=g if ctx.res_mode == 2 else None)
