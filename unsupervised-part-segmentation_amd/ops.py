@@ -40,6 +40,16 @@ WORKSPACE = _Workspace()
 COLSUM_WS = _Workspace()
 
 
+class KernelTimer(object):
+    """bench.py hook: HIP events (recorded on the launch stream) around the forward launch of one named
+    convolution, so the roofline figure is that kernel's own duration, measured live."""
+    layer, enabled, events, flops = None, False, [], 0.0
+
+    @classmethod
+    def mean_ms(cls):
+        return sum(a.elapsed_time(b) for a, b in cls.events) / max(1, len(cls.events))
+
+
 class WeightVersion(object):
     """Bumped by the optimizer; ConvLayer caches of converted weights key on it."""
     value = 0
@@ -139,7 +149,15 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None):
     d.res = res.data_ptr() if res is not None else None
     d.dact = None
     assert round8(layer.ci_log) <= ldi, (layer.name, layer.ci_log, ldi)
-    L.call("ups_conv_igemm", C.byref(d), L.stream())
+    if KernelTimer.layer == layer.name and KernelTimer.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.call("ups_conv_igemm", C.byref(d), L.stream())
+        e1.record()
+        KernelTimer.events.append((e0, e1))
+        KernelTimer.flops = 2.0 * n * ho * wo * layer.k * layer.k * layer.cin_v * layer.co
+    else:
+        L.call("ups_conv_igemm", C.byref(d), L.stream())
     return out
 
 

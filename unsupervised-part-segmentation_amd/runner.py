@@ -1,0 +1,90 @@
+"""``edflow -t <yaml>`` work-alike for the hot path (edflow itself is an un-vendored dependency of the
+reference: requirements.txt:33).  Keeps the surface the shipped configs rely on:
+
+  * ``model:`` / ``iterator:`` are import paths (train_cub_subset_tps.yaml:1-2); the reference's package names
+    ``nips19.*`` / ``src.*`` resolve to this package's TrainModel / Trainer, any other path is imported as is;
+  * ``Model(config)`` then ``Iterator(config, root, model)``, ``iterator.initialize(checkpoint)``,
+    ``iterator.iterate(batches)`` (cub/train/log.txt:1-9, 201-203);
+  * ``[INFO] [LoggingHook]: name: value`` lines at steps 0,1,2,4,8,... and every ``log_freq``; checkpoints every
+    ``ckpt_freq`` under ``<root>/train/checkpoints/model.ckpt-<step>``.
+
+Data: the CSV/albumentations pipeline (cub/code/data/data.py) is out of the hot path; ``dataset:`` values that
+cannot be imported fall back to ``SyntheticPairs`` (U(-1,1) views) unless ``--strict-dataset`` is given.
+"""
+import argparse
+import importlib
+import os
+import time
+
+import torch
+import yaml
+
+from .model import TrainModel, Trainer
+
+ALIASES = {"TrainModel": TrainModel, "Trainer": Trainer}
+
+
+def get_obj_from_str(path):
+    mod, name = path.rsplit(".", 1)
+    if mod.split(".")[0] in ("nips19", "src") and name in ALIASES:
+        return ALIASES[name]
+    return getattr(importlib.import_module(mod), name)
+
+
+class SyntheticPairs(object):
+    """{"view0","view1","view0_target"} of NHWC float32 in [-1,1] (cub/code/data/data.py:157-175 contract)."""
+
+    def __init__(self, config, seed=1234):
+        self.config = config
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def __iter__(self):
+        B, S = self.config["batch_size"], self.config["spatial_size"]
+        while True:
+            yield {k: torch.rand(B, S, S, 3, generator=self.gen) * 2 - 1 for k in ("view0", "view1", "view0_target")}
+
+
+def load_config(paths):
+    cfg = {}
+    for p in paths:
+        with open(p) as f:
+            cfg.update(yaml.safe_load(f))
+    return cfg
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="upsparts-run")
+    ap.add_argument("-t", "--train", nargs="+", required=True, help="training yaml(s)")
+    ap.add_argument("-c", "--checkpoint", default=None)
+    ap.add_argument("-p", "--project", default=None, help="log root (default logs/<timestamp>)")
+    ap.add_argument("--num_steps", type=int, default=None)
+    ap.add_argument("--set", nargs="*", default=[], help="key=value overrides (yaml-parsed)")
+    ap.add_argument("--strict-dataset", action="store_true")
+    args = ap.parse_args(argv)
+    cfg = load_config(args.train)
+    for kv in args.set:
+        k, v = kv.split("=", 1)
+        cfg[k] = yaml.safe_load(v)
+    root = args.project or os.path.join("logs", time.strftime("%Y-%m-%dT%H-%M-%S") + "_" + os.path.basename(args.train[0]).split(".")[0])
+    os.makedirs(os.path.join(root, "train"), exist_ok=True)
+    Model, Iterator = get_obj_from_str(cfg["model"]), get_obj_from_str(cfg["iterator"])
+    try:
+        dataset = get_obj_from_str(cfg["dataset"])(cfg)
+    except Exception:
+        if args.strict_dataset:
+            raise
+        dataset = SyntheticPairs(cfg)
+    model = Model(cfg)
+    it = Iterator(cfg, root, model)
+    it.initialize(args.checkpoint)
+    log_path = os.path.join(root, "train", "log.txt")
+    with open(log_path, "a") as lf:
+        def log_fn(line):
+            print(line)
+            lf.write(line + "\n")
+        it.iterate(iter(dataset), num_steps=args.num_steps, log_fn=log_fn)
+    return it
+
+
+if __name__ == "__main__":
+    main()
