@@ -580,7 +580,7 @@ def losses(o, config, state, step, vp, perceptual_mode="native", vgg_depths=VGG_
     est_acc = acc(o["mi_logit_joint"], o["mi_logit_marginal"])
 
     new = dict(state)
-    ema = lambda k, v: 0.99 * state[k] + (1.0 - 0.99) * float(v)       # M:28-35
+    ema = lambda k, v: 0.99 * state[k] + (1.0 - 0.99) * float(v.detach() if torch.is_tensor(v) else v)     # M:28-35
     new["avg_acc0"] = ema("avg_acc0", dis0_acc)
     new["avg_acc1"] = ema("avg_acc1", dis1_acc)
     new["avg_acc_error"] = ema("avg_acc_error", dis1_acc - dis0_acc)

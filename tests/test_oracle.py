@@ -1,0 +1,176 @@
+"""CPU tests of the oracle itself: the reference's only pinned op (fill_triangular,
+cub/code/test_pytest.py:4-28, known answer cub/code/util.py:894-902), NumPy-vs-torch cross-checks of every
+non-conv op, TF semantics traps and the closed-form step-0 values of
+cub/train/log.txt:204-260."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import configs, np_ops, ref_model as R
+
+
+def test_fill_triangular_known_answer():
+    # util.py:894-902
+    assert np.array_equal(np_ops.fill_triangular(np.arange(1, 7)), [[4, 0, 0], [6, 5, 0], [3, 2, 1]])
+    assert np.array_equal(np_ops.fill_triangular(np.arange(1, 7), upper=True), [[1, 2, 3], [0, 5, 6], [0, 0, 4]])
+    assert np.array_equal(R.fill_triangular(torch.arange(1, 7)).numpy(), [[4, 0, 0], [6, 5, 0], [3, 2, 1]])
+    # the numpy recipe spelled out in util.py:958-971
+    n = 3
+    x = np.arange(n * (n + 1) // 2)
+    m = x.shape[0]
+    x_tail = x[(m - (n ** 2 - m)):]
+    assert np.array_equal(np.tril(np.concatenate([x_tail, x[::-1]], 0).reshape(n, n)), np_ops.fill_triangular(x))
+
+
+def test_fill_triangular_batched_and_index_map():
+    rng = np.random.RandomState(0)
+    for n in (1, 2, 5, 8, 256):
+        m = n * (n + 1) // 2
+        x = rng.randn(2, m)
+        a = np_ops.fill_triangular(x)
+        b = R.fill_triangular(torch.from_numpy(x)).numpy()
+        assert np.array_equal(a, b)
+        idx = np_ops.fill_triangular_index(n)
+        tri = np.tril_indices(n)
+        assert np.array_equal(a[0][tri], x[0][idx[tri]])
+        assert sorted(idx[tri].tolist()) == list(range(m))       # bijection onto the lower triangle
+    try:
+        np_ops.fill_triangular(np.arange(5))
+        assert False
+    except ValueError:
+        pass
+
+
+def test_same_padding_stride2_is_bottom_right():
+    # Appendix A.1: even input, stride 2, k=3 -> pad 0 before, 1 after
+    x = torch.arange(16.0).view(1, 4, 4, 1)
+    V = torch.zeros(3, 3, 1, 1); V[0, 0, 0, 0] = 1.0           # picks the top-left tap
+    y = R.conv2d_same(x, V, torch.zeros(1), 2)
+    assert torch.equal(y.view(2, 2), torch.tensor([[0.0, 2.0], [8.0, 10.0]]))
+    V = torch.zeros(3, 3, 1, 1); V[2, 2, 0, 0] = 1.0           # bottom-right tap reads the zero pad at the border
+    y = R.conv2d_same(x, V, torch.zeros(1), 2)
+    assert torch.equal(y.view(2, 2), torch.tensor([[10.0, 0.0], [0.0, 0.0]]))
+
+
+def test_bilinear_legacy_tf():
+    x = torch.tensor([0.0, 2.0, 6.0]).view(1, 1, 3, 1).repeat(1, 2, 1, 1)
+    y = R.bilinear_up2(x)
+    assert torch.equal(y[0, 0, :, 0], torch.tensor([0.0, 1.0, 2.0, 4.0, 6.0, 6.0]))      # last column clamps
+    xn = np.random.RandomState(1).randn(2, 3, 5, 4)
+    assert np.allclose(np_ops.bilinear_up2(xn), R.bilinear_up2(torch.from_numpy(xn)).numpy())
+
+
+def test_coordinates_channel_order_and_1x1():
+    x = torch.zeros(1, 3, 4, 2)
+    y = R.Scope.add_coordinates(x)
+    assert y.shape == (1, 3, 4, 4)
+    assert np.allclose(y.numpy(), np_ops.add_coordinates(x.numpy()))
+    assert torch.allclose(y[0, 0, :, 2], torch.tensor([0.0, 1.0, 2.0, 3.0]) / 2 * 2 - 1)   # xx = column / (H-1)
+    assert torch.allclose(y[0, :, 0, 3], torch.tensor([0.0, 1.0, 2.0]) / 3 * 2 - 1)        # yy = row / (W-1)
+    one = R.Scope.add_coordinates(torch.zeros(2, 1, 1, 1))
+    assert torch.equal(one[..., 1:], -torch.ones(2, 1, 1, 2))
+
+
+def test_part_ops_numpy_vs_torch():
+    rng = np.random.RandomState(2)
+    x = rng.randn(2, 6, 7, 4)
+    m = np_ops.softmax_lastdim(x)
+    assert np.allclose(m, torch.softmax(torch.from_numpy(x), -1).numpy())
+    assert np.array_equal(np_ops.hard_max(m), R.hard_max(torch.from_numpy(m)).numpy())
+    tie = np.array([[0.5, 0.5, 0.0]])
+    assert np.array_equal(np_ops.hard_max(tie), [[1.0, 1.0, 0.0]])                        # Appendix A.7
+    ss = np_ops.spatial_softmax(3.0 * x)
+    assert np.allclose(ss, R.spatial_softmax(torch.from_numpy(3.0 * x)).numpy())
+    assert np.allclose(ss.sum(axis=(1, 2)), 1.0)
+    mu, sig = np_ops.probs_to_mu_sigma(ss)
+    mu_t, sig_t = R.probs_to_mu_sigma(torch.from_numpy(ss))
+    assert np.allclose(mu, mu_t.numpy()) and np.allclose(sig, sig_t.numpy())
+    assert np.array_equal(np_ops.mu_to_pixel(np.array([[-1.0, 0.999], [0.49, -0.51]]), 128), [[0, 127], [95, 31]])
+    # mumford-shah / gmrf pieces
+    r, s, c = np_ops.mumford_shah(m, 1.0, 1e-2)
+    g = R.squared_grad(torch.from_numpy(m)).numpy()
+    assert np.allclose(r, np.minimum(g, 1e-2)) and np.allclose(s + c, r)
+    dy, dx = np_ops.image_gradients(x)
+    assert np.all(dy[:, -1] == 0) and np.all(dx[:, :, -1] == 0)
+
+
+def test_draw_rect_convention():
+    r = np_ops.draw_rect(np.array([[64, 64], [0, 127]]), 32, 32, 128, 128)
+    assert r[0].sum() == 33 * 33                       # inclusive box: Appendix C (patch_loss 15294.75 ~ 128^2 - 33^2)
+    assert r[1].sum() == 17 * 17                       # clipped at the image border
+    rt = R.draw_rect(torch.tensor([[64, 64], [0, 127]]), 32, 32, 128, 128, torch.float32)
+    assert np.array_equal(r, rt.numpy())
+
+
+def test_step0_closed_forms_of_the_reference_log():
+    """cub/train/log.txt:204-260 with n_parts=25, 128^2, gamma=10, patch 32."""
+    P, S = 25, 128
+    rng = np.random.RandomState(0)
+    m = np_ops.softmax_lastdim(rng.randn(2, S, S, P) * math.sqrt(1.04))
+    kl = np_ops.categorical_kl(m)
+    assert abs(2 * kl - 0.9168) < 0.02                                     # mask0_kl (two maps)
+    ent = float(np.mean(-(m * np.log(m)).sum(-1)))
+    assert abs(ent - 2.7595) < 0.02                                        # weakly_superv_loss_p = ln 25 - kl
+    rect = np_ops.draw_rect(np.array([[64, 64]]), 32, 32, S, S)[0]
+    assert abs((S * S - rect.sum()) - 15294.75) < 1.0                      # patch_loss: one-hot mass outside a centred box
+    c = np.full((1, S, S, 1), 1.0 / (S * S)) * (1 - rect)[None, :, :, None]
+    _, sig = np_ops.probs_to_mu_sigma(c)
+    assert abs(P * (sig[0, 0, 0, 0] + sig[0, 0, 1, 1]) - 16.854) < 0.01    # variance_loss (logged 16.77)
+    assert abs(1e-12 * P * (S * S / P) ** 2 - 1.0737e-5) < 1e-8            # z_area_cost (logged 1.08e-5)
+    assert abs(math.log(2) - 0.693) < 1e-3                                 # critic losses ~ ln 2
+
+
+def test_latent_numpy_vs_torch_and_schedules():
+    rng = np.random.RandomState(3)
+    Z = 6
+    p = rng.randn(3, Z + Z * (Z + 1) // 2) * 0.2
+    mean, L, ld = np_ops.full_latent(p, Z)
+    d = R.FullLatent(torch.from_numpy(p), Z)
+    assert np.allclose(L, d.L.numpy()) and np.allclose(mean, d.mean.numpy())
+    assert np.allclose(np.diagonal(L, axis1=1, axis2=2), np.exp(ld))
+    assert abs(np_ops.full_latent_kl(mean, L, ld) - float(d.kl())) < 1e-12
+    eps = rng.randn(3, Z)
+    s = d.sample(torch.from_numpy(eps), noise_level=0.5).reshape(3, Z).numpy()
+    assert np.allclose(s, mean + 0.5 * np.einsum("bij,bj->bi", L, eps))
+    cfg = configs.cub_config()
+    assert R.make_var(0, cfg["prior_gmrf_weight"]) == 1e-3 and R.make_var(0, cfg["variance_weight"]) == 1
+    assert R.make_var(70000, cfg["weakly_superv_loss_weight_p"]) == 1.0
+    assert np_ops.staircase_var(25, 0, 1.0, 10, 0.5, 0.0, 1.0) == 0.25
+    assert np_ops.linear_var(5, 0, 10, 0.0, 1.0) == 0.5
+    assert abs(R.learning_rate(cfg, 0) - 2e-4) < 1e-12
+
+
+def test_per_key_and_merged_gradient_schemes_agree():
+    cfg = configs.tiny_config()
+    params = R.init_params(cfg, 0)
+    vp = R.vgg_params(7, widths=(8, 8, 16, 16, 16))
+    views, noise = R.synthetic_views(cfg), R.synthetic_noise(cfg)
+    st = R.initial_state(cfg)
+    _, L1, _, _, g1 = R.gradients(params, cfg, views, noise, st, 0, vp, dtype=torch.float64, scheme="per_key")
+    _, L2, _, _, g2 = R.gradients(params, cfg, views, noise, st, 0, vp, dtype=torch.float64, scheme="merged")
+    assert set(L1) == set(R.SUBMODULES)
+    for n in g1:
+        assert torch.allclose(g1[n], g2[n], atol=1e-12), n
+    # priors reach decoder_visualize only; the bottleneck reaches encoder_0 only (model.py:739-742, 786-815, 930)
+    assert float(L1["decoder_visualize"]) > float(L1["encoder_1"])
+    assert float(L1["encoder_0"]) != float(L1["encoder_1"])
+
+
+def test_tf_adam_epsilon_placement():
+    p, g = np.array([1.0]), np.array([1e-9])
+    pn, m, v = np_ops.tf_adam_step(p, g, np.zeros(1), np.zeros(1), 1, 0.1, 0.5, 0.9)
+    lr_t = 0.1 * math.sqrt(1 - 0.9) / (1 - 0.5)
+    assert np.allclose(pn, 1.0 - lr_t * (0.5e-9) / (math.sqrt(0.1e-18) + 1e-8))
+
+
+def test_gaussian_renderers_docstring_example():
+    # nn.py:1658-1674
+    H = W = 20
+    means = (np.array([[10, 10], [10, 15]], np.float32))
+    var = np.array([[3, 1], [1, 3]], np.float32)
+    hm = np_ops.tf_hm(means[None], H, W, var[None])
+    assert hm.shape == (1, H, W, 2) and abs(hm[0, 10, 10, 0] - 1.0) < 1e-6 and abs(hm[0, 15, 10, 1] - 1.0) < 1e-6
+    mu = np.zeros((1, 1, 2)); Lm = np.eye(2)[None, None] * 0.5
+    d = np_ops.tf_hm3(5, 5, mu, Lm)
+    assert abs(d[0, 2, 2, 0] - 1.0 / (2 * math.pi * 0.25)) < 1e-9

@@ -24,6 +24,7 @@ import torch
 from . import lib as L
 from . import nets as N
 from . import ops
+from . import dist as D
 from .nets import Act
 from .schedules import make_var, make_linear_var
 
@@ -151,7 +152,7 @@ class Trainer(object):
                       "avg_loss_dis0": _scalar(1.0, d), "avg_loss_dis1": _scalar(1.0, d),
                       "avg_mim": _scalar(0.0, d), "avg_independent_mim": _scalar(0.0, d)}
         self._gen = torch.Generator(device=d)
-        self._gen.manual_seed(int(config.get("noise_seed", 4321)) + 7919 * int(kwargs.get("rank", 0)))
+        self._gen.manual_seed(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))
         self.losses = OrderedDict((k, None) for k in self.loss_keys())
 
     # ------------------------------------------------------------------ edflow hook surface
@@ -411,9 +412,7 @@ class Trainer(object):
 
         # ================= state updates (update_ops; Appendix A.15: losses above used the pre-update state)
         stats = torch.stack([mim.detach(), ind_mim.detach(), acc0, acc1, loss_dis0.detach(), loss_dis1.detach()])
-        if self.world_size > 1:
-            torch.distributed.all_reduce(stats, group=self.process_group)
-            stats /= self.world_size
+        D.average_scalars(stats, self.world_size, self.process_group)
         g_mim, g_ind, g_acc0, g_acc1, g_l0, g_l1 = stats.unbind(0)
         ema = lambda old, val: 0.99 * old + (1.0 - 0.99) * val            # model.py:28-35
         new = dict(st)
@@ -474,13 +473,8 @@ class Trainer(object):
         """RCCL all-reduce (sum, scaled by 1/world in the Adam kernel) of each key's flat gradient,
         then one fused Adam launch per key (tf.train.AdamOptimizer semantics, Appendix A.12)."""
         bank = self.model.bank
-        handles = []
-        if self.world_size > 1:
-            for k in keys:
-                handles.append(torch.distributed.all_reduce(bank.groups[k]["flat"]["g"], group=self.process_group,
-                                                            async_op=True))
-            for h in handles:
-                h.wait()
+        handles = [D.allreduce_bucket(bank.groups[k]["flat"]["g"], self.world_size, self.process_group) for k in keys]
+        D.wait_all(handles)
         lr = self.learning_rate()
         for k in keys:
             grp = bank.groups[k]
