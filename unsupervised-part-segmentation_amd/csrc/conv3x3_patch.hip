@@ -1,0 +1,314 @@
+// Patch-tiled 3x3 / stride-1 'SAME' convolution (forward and dgrad) for the layers that carry >90 % of the
+// FLOPs of the path (res-blocks of the mask decoder, the encoders and the perceptual trunk;
+// cub/code/nn.py:617-664,1042-1056).
+//
+// Block = 512 threads = 8 waves, output tile = 16x16 pixels of one image x BN output channels.
+// Per 64-byte channel chunk the (16+2)x(16+2) input halo patch is staged ONCE (activation-on-load and zero
+// padding applied once per element instead of once per tap) and reused by all nine taps from LDS; the weights
+// are staged one kernel row (3 taps) at a time.  Both are double-buffered, so the loop runs
+//     issue global loads (next tap-row [+ next patch]) -> 24 MFMAs per wave from LDS -> write LDS -> 1 barrier.
+// LDS pixel / weight rows are padded 64 -> 80 bytes (conflict-free ds_read_b128 for 16 consecutive pixels).
+// MFMA: v_mfma_f32_32x32x16_bf16 or exact-fp32 v_mfma_f32_32x32x2_f32.  Epilogue identical to conv_igemm.
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 16;                 // tile side
+constexpr int PW = TS + 2;             // patch side
+constexpr int PPIX = PW * PW;          // 324 patch pixels
+constexpr int RS = 80;                 // LDS row stride (bytes)
+constexpr int A_BYTES = PPIX * RS;     // 25920
+
+struct PatchK {
+    int n, h, w, ci, ldi, co, co_fill, ldo, ldr, ldd, act_in, out_f32, dact_kind, has_ctab;
+    float act_slope;
+    unsigned long long tap_off, tap_wi;   // 4 bits per tap: (dy+1)<<2|(dx+1) ; weight slice
+    const void* in; const void* wgt; void* out;
+    const float* bias; const float* coord_tab; const void* res; const void* dact;
+};
+
+__device__ inline int p_dy(unsigned long long off, int t) { return (int)((off >> (4 * t + 2)) & 3) - 1; }
+__device__ inline int p_dx(unsigned long long off, int t) { return (int)((off >> (4 * t)) & 3) - 1; }
+__device__ inline int p_w(unsigned long long wi, int t) { return (int)((wi >> (4 * t)) & 15); }
+
+template <typename T> struct PMma;
+template <> struct PMma<bf16> {
+    template <int TM, int TN>
+    __device__ static inline void tap(const unsigned char* a_lane, const unsigned char* b_lane, f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(a_lane + i * (2 * PW * RS) + ks * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(b_lane + j * (32 * RS) + ks * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+template <> struct PMma<float> {
+    template <int TM, int TN>
+    __device__ static inline void tap(const unsigned char* a_lane, const unsigned char* b_lane, f32x16 (&acc)[TM][TN]) {
+        // a_lane / b_lane already include the lane-half offset h*16 (bf16 convention); fp32 halves own 32 bytes
+        f32x4 a[TM][2], b[TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            a[i][0] = *(const f32x4*)(a_lane + i * (2 * PW * RS));
+            a[i][1] = *(const f32x4*)(a_lane + i * (2 * PW * RS) + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            b[j][0] = *(const f32x4*)(b_lane + j * (32 * RS));
+            b[j][1] = *(const f32x4*)(b_lane + j * (32 * RS) + 16);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk >> 2][kk & 3],
+                                                                     acc[i][j], 0, 0, 0);
+    }
+};
+
+template <typename T, int BN>
+__global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, const int tiles_x, const int tiles_y,
+                                                            const int ntn, const int kchunks, const int nblocks) {
+    constexpr int EPC = Chunk<T>::N;
+    constexpr int BK = 4 * EPC;
+    constexpr int WN = (BN == 32) ? 1 : 2;
+    constexpr int WM = 8 / WN;                   // 4 or 8 waves along the pixels
+    constexpr int TM = 256 / WM / 32;            // 2 or 1
+    constexpr int TN = BN / WN / 32;             // 2, 1, 1
+    constexpr int B_BYTES = 3 * BN * RS;         // one tap-row of weights
+    constexpr int NB = (3 * BN * 4 + 511) / 512; // weight chunks per thread per tap-row: 3, 2, 1
+    constexpr int HALF_OFF = (sizeof(T) == 2) ? 16 : 32;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Abuf = smem;                  // 2 x A_BYTES
+    unsigned char* Bbuf = smem + 2 * A_BYTES;    // 2 x B_BYTES
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // XCD-aware order: consecutive logical tiles (which share halos / the same patch for both N-tiles) stay on
+    // one XCD's L2 (blocks are dealt round-robin over the 8 XCDs)
+    int bid = blockIdx.x;
+    if ((nblocks & 7) == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
+    const int nt = bid % ntn;
+    int t = bid / ntn;
+    const int tx0 = (t % tiles_x) * TS; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * TS;
+    const int img = t / tiles_y;
+    const int wm = wid / WN, wn = wid % WN;
+
+    const T* __restrict__ in = (const T*)p.in + (long long)img * p.h * p.w * p.ldi;
+    const T* __restrict__ w = (const T*)p.wgt;
+
+    // ---- patch staging: items tid, tid+512, tid+1024 of the 324x4 16-byte chunks
+    long long pa0 = -1, pa1 = -1, pa2 = -1;      // element offsets (without the channel-chunk offset), -1 = zero fill
+    {
+        auto mk = [&](int item) -> long long {
+            if (item >= PPIX * 4) return -2;      // no item
+            const int pix = item >> 2, ch = item & 3;
+            const int py = pix / PW, px = pix - py * PW;
+            const int y = ty0 - 1 + py, x = tx0 - 1 + px;
+            if ((unsigned)y >= (unsigned)p.h || (unsigned)x >= (unsigned)p.w) return -1;
+            return ((long long)y * p.w + x) * p.ldi + ch * EPC;
+        };
+        pa0 = mk(tid); pa1 = mk(tid + 512); pa2 = mk(tid + 1024);
+    }
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 ra0, ra1, ra2, rb0, rb1, rb2;
+
+    const int cha = (tid & 3) * EPC;            // 512 % 4 == 0: all three items of a thread share the chunk slot
+    auto ld_a = [&](long long off, int koff) -> uint4 {
+        uint4 v = zero4;
+        if (off >= 0 && koff + cha < p.ci) v = *(const uint4*)(in + off + koff);
+        return v;
+    };
+    auto load_patch = [&](int cc) {
+        const int koff = cc * BK;
+        ra0 = ld_a(pa0, koff); ra1 = ld_a(pa1, koff);
+        if (pa2 != -2) ra2 = ld_a(pa2, koff);
+    };
+    auto act_u4 = [&](uint4 u) -> uint4 {
+        if (p.act_in != UPS_ACT_NONE) {
+            float f[EPC];
+            Chunk<T>::unpack(u, f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] = ups_act(f[e], p.act_in, p.act_slope);
+            u = Chunk<T>::pack(f);
+        }
+        return u;
+    };
+    auto store_patch = [&](unsigned char* A) {
+        *(uint4*)(A + (tid >> 2) * RS + (tid & 3) * 16) = act_u4(ra0);
+        *(uint4*)(A + ((tid + 512) >> 2) * RS + (tid & 3) * 16) = act_u4(ra1);
+        if (pa2 != -2) *(uint4*)(A + ((tid + 1024) >> 2) * RS + (tid & 3) * 16) = act_u4(ra2);
+    };
+    // weights of tap-row g (taps 3g..3g+2), chunk cc: item -> (tap_local, row, ch)
+    auto ld_b = [&](int item, int g, int koff) -> uint4 {
+        uint4 v = zero4;
+        if (item < 3 * BN * 4) {
+            const int tl = item / (BN * 4), rem = item - tl * (BN * 4);
+            const int row = rem >> 2, ch = rem & 3;
+            const int c = nt * BN + row, k = koff + ch * EPC;
+            if (c < p.co && k < p.ci)
+                v = *(const uint4*)(w + ((long long)p_w(p.tap_wi, 3 * g + tl) * p.co + c) * p.ci + k);
+        }
+        return v;
+    };
+    auto load_w = [&](int g, int cc) {
+        const int koff = cc * BK;
+        rb0 = ld_b(tid, g, koff);
+        if (NB > 1) rb1 = ld_b(tid + 512, g, koff);
+        if (NB > 2) rb2 = ld_b(tid + 1024, g, koff);
+    };
+    auto store_w = [&](unsigned char* B) {
+        if (tid < 3 * BN * 4) *(uint4*)(B + (tid >> 2) * RS + (tid & 3) * 16) = rb0;
+        if (NB > 1 && tid + 512 < 3 * BN * 4) *(uint4*)(B + ((tid + 512) >> 2) * RS + (tid & 3) * 16) = rb1;
+        if (NB > 2 && tid + 1024 < 3 * BN * 4) *(uint4*)(B + ((tid + 1024) >> 2) * RS + (tid & 3) * 16) = rb2;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // per-lane fragment bases: output row r of MFMA block tm -> tile pixel (ty, tx)
+    const int r = lane & 31, hh = lane >> 5;
+    const int ty_l = (wm * TM * 2) + (r >> 4), tx_l = r & 15;
+    const int a_lane_off = (ty_l * PW + tx_l) * RS + hh * HALF_OFF;        // patch origin is (-1,-1): tap (dy,dx) adds (dy+1, dx+1)
+    const int b_lane_off = (wn * TN * 32 + r) * RS + hh * HALF_OFF;
+
+    const int total = 3 * kchunks;
+    load_patch(0); load_w(0, 0);
+    store_patch(Abuf); store_w(Bbuf);
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const int cc = it / 3, g = it - cc * 3;
+        const int nx = it + 1;
+        const bool more = nx < total;
+        const int ncc = nx / 3, ng = nx - ncc * 3;
+        if (more) {
+            load_w(ng, ncc);
+            if (ng == 0) load_patch(ncc);
+        }
+        const unsigned char* A = Abuf + (cc & 1) * A_BYTES + a_lane_off;
+        const unsigned char* B = Bbuf + (it & 1) * B_BYTES + b_lane_off;
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl) {
+            const int tp = 3 * g + tl;
+            const int po = ((p_dy(p.tap_off, tp) + 1) * PW + (p_dx(p.tap_off, tp) + 1)) * RS;
+            PMma<T>::template tap<TM, TN>(A + po, B + tl * BN * RS, acc);
+        }
+        if (more) {
+            store_w(Bbuf + (nx & 1) * B_BYTES);
+            if (ng == 0) store_patch(Abuf + (ncc & 1) * A_BYTES);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    T* __restrict__ outT = (T*)p.out;
+    float* __restrict__ outF = (float*)p.out;
+    const T* __restrict__ res = (const T*)p.res;
+    const T* __restrict__ dact = (const T*)p.dact;
+    const long long img_pix = (long long)img * p.h * p.w;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = nt * BN + (wn * TN + tn) * 32 + (lane & 31);
+        const bool cvalid = col < p.co;
+        if (col >= p.co_fill) continue;
+        const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int y = ty0 + (wm * TM + tm) * 2 + (rr >> 4), x = tx0 + (rr & 15);
+                const long long pix = img_pix + (long long)y * p.w + x;
+                float v = 0.f;
+                if (cvalid) {
+                    v = acc[tm][tn][e] + bias;
+                    if (p.coord_tab) {
+                        const int ym = (y > 0 ? 1 : 0) | 2 | (y + 1 < p.h ? 4 : 0);
+                        const int xm = (x > 0 ? 1 : 0) | 2 | (x + 1 < p.w ? 4 : 0);
+                        const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
+                        v += tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co];
+                    }
+                    if (dact) v *= ups_dact(ld_as_float<T>(dact + pix * p.ldd + col), p.dact_kind, p.act_slope);
+                    if (res) v += ld_as_float<T>(res + pix * p.ldr + col);
+                }
+                if (p.out_f32) outF[pix * p.ldo + col] = v;
+                else st_from_float<T>(outT + pix * p.ldo + col, v);
+            }
+        }
+    }
+}
+
+template <typename T, int BN>
+int launch_bn(const PatchK& k, hipStream_t s) {
+    constexpr int EPC = Chunk<T>::N;
+    const int tiles_x = k.w / TS, tiles_y = k.h / TS;
+    const int ntn = ups_cdiv(k.co_fill, BN);
+    const int kchunks = ups_cdiv(k.ci, 4 * EPC);
+    const int nblocks = k.n * tiles_x * tiles_y * ntn;
+    const size_t shmem = 2 * A_BYTES + 2 * 3 * BN * RS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return UPS_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN>), dim3(nblocks), dim3(512), shmem, s, k, tiles_x, tiles_y, ntn, kchunks,
+                       nblocks);
+    return UPS_OK;
+}
+
+template <typename T>
+int launch_t(const PatchK& k, hipStream_t s) {
+    if (k.co_fill > 64) return launch_bn<T, 128>(k, s);
+    if (k.co_fill > 32) return launch_bn<T, 64>(k, s);
+    return launch_bn<T, 32>(k, s);
+}
+
+}  // namespace
+
+// Internal entry used by ups_conv_igemm's dispatcher (conv_igemm.hip). Returns 1 if the problem is not eligible.
+int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
+    if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox)
+        return 1;
+    if (d->hi != d->ho || d->wi != d->wo || d->out_h != d->ho || d->out_w != d->wo) return 1;
+    if (d->hi % TS || d->wi % TS) return 1;
+    bool seen[9] = {false, false, false, false, false, false, false, false, false};
+    for (int t = 0; t < 9; ++t) {
+        const int dy = d->tap_dy[t], dx = d->tap_dx[t];
+        if (dy < -1 || dy > 1 || dx < -1 || dx > 1 || d->tap_w[t] < 0 || d->tap_w[t] > 15) return 1;
+        seen[(dy + 1) * 3 + dx + 1] = true;
+    }
+    for (int t = 0; t < 9; ++t) if (!seen[t]) return 1;
+    if (d->coord_tab) {   // the epilogue derives the class from the forward tap order r-major, dy = r-1, dx = s-1
+        for (int t = 0; t < 9; ++t) if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1) return 1;
+    }
+    PatchK k;
+    k.n = d->n; k.h = d->hi; k.w = d->wi; k.ci = d->ci; k.ldi = d->ldi; k.co = d->co; k.co_fill = d->co_fill;
+    k.ldo = d->ldo; k.ldr = d->ldr; k.ldd = d->ldd; k.act_in = d->act_in; k.out_f32 = d->out_f32;
+    k.dact_kind = d->dact_kind; k.has_ctab = d->coord_tab != nullptr; k.act_slope = d->act_slope;
+    k.in = d->in; k.wgt = d->w; k.out = d->out; k.bias = d->bias; k.coord_tab = d->coord_tab; k.res = d->res; k.dact = d->dact;
+    k.tap_off = 0; k.tap_wi = 0;
+    for (int t = 0; t < 9; ++t) {
+        k.tap_off |= (unsigned long long)(((d->tap_dy[t] + 1) << 2) | (d->tap_dx[t] + 1)) << (4 * t);
+        k.tap_wi |= (unsigned long long)d->tap_w[t] << (4 * t);
+    }
+    const int rc = (d->dtype == UPS_F32) ? launch_t<float>(k, s) : launch_t<bf16>(k, s);
+    return rc == UPS_OK ? 0 : rc;
+}

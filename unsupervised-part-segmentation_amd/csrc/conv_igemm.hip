@@ -12,6 +12,8 @@
 // global loads are issued before the MFMAs of the current one (issue-early / write-late).
 // LDS rows are padded 64 -> 80 bytes so the 16-lane groups of ds_read_b128 fall on distinct 16-B slots.
 // MFMA: v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 (exact fp32) for the parity mode.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -291,6 +293,8 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
 
 }  // namespace
 
+int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_patch.hip
+
 extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d != nullptr);
     UPS_CHECK_ARG(d->dtype == UPS_F32 || d->dtype == UPS_BF16);
@@ -302,6 +306,13 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(!d->coord_tab || (d->kh * d->kw == d->ntaps && d->kh <= 3 && d->kw <= 3));
     UPS_CHECK_ARG(((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->w & 15) == 0);
     UPS_CHECK_ARG((d->out_sy * (d->ho - 1) + d->out_oy) < d->out_h && (d->out_sx * (d->wo - 1) + d->out_ox) < d->out_w);
+    // 3x3 / stride-1 problems on 16-aligned images go to the patch-tiled kernel (halo reuse across the 9 taps)
+    const char* force = getenv("UPS_FORCE_GENERIC_CONV");
+    if (!(force && force[0] == '1')) {
+        const int pr = ups_conv3x3_patch_try(d, (hipStream_t)stream);
+        if (pr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
+        if (pr < 0) { ups_set_error("ups_conv_igemm: patch kernel launch setup failed"); return pr; }
+    }
     int rc = (d->dtype == UPS_F32) ? launch<float>(*d, (hipStream_t)stream) : launch<bf16>(*d, (hipStream_t)stream);
     if (rc != UPS_OK) { ups_set_error("ups_conv_igemm: bad problem size"); return rc; }
     UPS_LAUNCH_CHECK();

@@ -465,7 +465,7 @@ class Trainer(object):
         self.log_ops = log
         self.state = new
         self.global_step += 1
-        self._debug = {"l_mean": lm, "l": l, "m": m, "hard": hard, "px": px, "generated": gen, "feat": feat.detach(),
+        self._debug = {"l_mean": lm, "l": l, "m": m, "hard": hard, "px": px, "generated": gen.detach(), "feat": feat.detach(),
                        "dl_tot": dl_tot, "dl_rec": dl_rec, "g_hard0": g_hard0, "g_hard1": g_hard1, "pe": pe2}
         return self.losses
 
