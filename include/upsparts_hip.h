@@ -91,7 +91,8 @@ typedef struct {
     int32_t splitk;                   /* from ups_conv_wgrad_plan */
     const void* in; const void* dout;
     float* grad;                      /* [kh*kw][cin_v][co] fp32 */
-    float* workspace;                 /* splitk * ntaps*cin_v*co floats */
+    float* grad_bias;                 /* [co] fp32 or NULL: sum_pix dout, reduced from the same dout tiles */
+    float* workspace;                 /* bytes from ups_conv_wgrad_plan */
 } ups_wgrad_desc;
 
 int ups_conv_wgrad_plan(const ups_wgrad_desc* d, int32_t* splitk, size_t* workspace_bytes);
@@ -114,11 +115,12 @@ int ups_coord_table(const float* V, int32_t kh, int32_t kw, int32_t ci_log, int3
 /* gsum[pix][c] = sum_n dout[n][pix][c] (fp32) */
 int ups_batch_sum(const void* dout, int32_t dtype, int32_t n, int64_t pix, int32_t co, int32_t ldo,
                   float* gsum, void* stream);
-/* gradient of the two CoordConv rows of V and (optionally) the bias from gsum [ho*wo][co] */
+/* gradient of the two CoordConv rows of V (and optionally the bias) from gsum [ho*wo][co];
+ * `scratch` holds (kh+1)*2*wo*co floats (separable two-stage reduction: rows first, then columns) */
 int ups_coord_wgrad(const float* gsum, int32_t hi, int32_t wi, int32_t ho, int32_t wo, int32_t co,
                     int32_t kh, int32_t kw, const int32_t* tap_dy, const int32_t* tap_dx,
                     int32_t in_sy, int32_t in_sx, float ax, float ay,
-                    int32_t ci_log, float* gradV, float* grad_bias, void* stream);
+                    int32_t ci_log, float* gradV, float* grad_bias, float* scratch, void* stream);
 /* grad_bias[c] = sum_rows dout[row][c]; workspace >= 1024*co floats */
 int ups_col_sum(const void* dout, int32_t dtype, int64_t rows, int32_t co, int32_t ldo,
                 float* out, float* workspace, void* stream);

@@ -70,44 +70,59 @@ __global__ void batch_sum_kernel(const T* __restrict__ d, int n, long long pix, 
     }
 }
 
-// blockIdx.y = tap (== ntaps: bias), 64 channels x 4 pixel lanes per block
-__global__ __launch_bounds__(256) void coord_wgrad_kernel(const float* __restrict__ g, int hi, int wi, int ho, int wo,
-                                                          int co, int kh, int kw, Taps3 tp, int in_sy, int in_sx,
-                                                          float ax, float ay, int ci_log, float* __restrict__ gV,
-                                                          float* __restrict__ gb) {
-    __shared__ float red[2][4][64];
-    const int tap = blockIdx.y, ntaps = kh * kw;
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const bool is_bias = tap == ntaps;
-    const int r = is_bias ? 0 : tap / kw, s = is_bias ? 0 : tap % kw;
-    const int dys = r == 0 ? tp.dy[0] : (r == 1 ? tp.dy[1] : tp.dy[2]);
-    const int dxs = s == 0 ? tp.dx[0] : (s == 1 ? tp.dx[1] : tp.dx[2]);
-    float sx = 0.f, sy = 0.f;
-    if (c < co) {
-        for (int px = pl; px < ho * wo; px += 4) {
-            const int i = px / wo, j = px - i * wo;
-            const float v = g[(long long)px * co + c];
-            if (is_bias) { sx += v; continue; }
-            const int y = i * in_sy + dys, x = j * in_sx + dxs;
-            if ((unsigned)y < (unsigned)hi && (unsigned)x < (unsigned)wi) {
-                sx += (ax * (float)x - 1.f) * v;
-                sy += (ay * (float)y - 1.f) * v;
+// CoordConv weight gradient, separable two-stage reduction over the batch-summed gradient map g[ho][wo][co]:
+//   stage 1 (rows):  A[r][j][c] = sum_i valid_y(i,r) g[i][j][c],  B[r][j][c] = sum_i valid_y(i,r) (ay*y-1) g[i][j][c]
+//                    (r = kh: all rows, used for the bias)
+//   stage 2 (cols):  dVx[r][s][c] = sum_j valid_x(j,s) (ax*x-1) A[r][j][c],  dVy[r][s][c] = sum_j valid_x(j,s) B[r][j][c]
+__global__ void coord_rows_kernel(const float* __restrict__ g, int hi, int ho, int wo, int co, int kh, Taps3 tp, int in_sy,
+                                  float ay, float* __restrict__ scratch) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)wo * co) return;
+    float A[4] = {0.f, 0.f, 0.f, 0.f}, B[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < ho; ++i) {
+        const float v = g[(long long)i * wo * co + idx];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (r < kh) {
+                const int y = i * in_sy + (r == 0 ? tp.dy[0] : (r == 1 ? tp.dy[1] : tp.dy[2]));
+                if ((unsigned)y < (unsigned)hi) { A[r] += v; B[r] += (ay * (float)y - 1.f) * v; }
             }
         }
+        A[3] += v;
     }
-    red[0][pl][cl] = sx; red[1][pl][cl] = sy;
-    __syncthreads();
-    if (pl == 0 && c < co) {
-        sx = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        sy = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-        if (is_bias) { if (gb) gb[c] = sx; }
-        else {
-            const int cin_v = ci_log + 2;
-            gV[((long long)tap * cin_v + ci_log) * co + c] = sx;
-            gV[((long long)tap * cin_v + ci_log + 1) * co + c] = sy;
+    const long long plane = (long long)wo * co;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        if (r < kh) { scratch[(2 * r) * plane + idx] = A[r]; scratch[(2 * r + 1) * plane + idx] = B[r]; }
+    scratch[(2 * kh) * plane + idx] = A[3];
+}
+
+__global__ void coord_cols_kernel(const float* __restrict__ scratch, int wi, int wo, int co, int kh, int kw, Taps3 tp,
+                                  int in_sx, float ax, int ci_log, float* __restrict__ gV, float* __restrict__ gb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tap = blockIdx.y;                  // kh*kw taps, then one extra block row for the bias
+    if (c >= co) return;
+    const long long plane = (long long)wo * co;
+    if (tap == kh * kw) {
+        if (!gb) return;
+        float s = 0.f;
+        for (int j = 0; j < wo; ++j) s += scratch[(2 * kh) * plane + (long long)j * co + c];
+        gb[c] = s;
+        return;
+    }
+    const int r = tap / kw, s_ = tap % kw;
+    const int dxs = s_ == 0 ? tp.dx[0] : (s_ == 1 ? tp.dx[1] : tp.dx[2]);
+    float sx = 0.f, sy = 0.f;
+    for (int j = 0; j < wo; ++j) {
+        const int x = j * in_sx + dxs;
+        if ((unsigned)x < (unsigned)wi) {
+            sx += (ax * (float)x - 1.f) * scratch[(2 * r) * plane + (long long)j * co + c];
+            sy += scratch[(2 * r + 1) * plane + (long long)j * co + c];
         }
     }
+    const int cin_v = ci_log + 2;
+    gV[((long long)tap * cin_v + ci_log) * co + c] = sx;
+    gV[((long long)tap * cin_v + ci_log + 1) * co + c] = sy;
 }
 
 // partial[blockIdx.y][c] = sum over this block's row range
@@ -194,11 +209,16 @@ extern "C" int ups_batch_sum(const void* dout, int32_t dtype, int32_t n, int64_t
 
 extern "C" int ups_coord_wgrad(const float* gsum, int32_t hi, int32_t wi, int32_t ho, int32_t wo, int32_t co, int32_t kh,
                                int32_t kw, const int32_t* tap_dy, const int32_t* tap_dx, int32_t in_sy, int32_t in_sx,
-                               float ax, float ay, int32_t ci_log, float* gradV, float* grad_bias, void* stream) {
-    UPS_CHECK_ARG(gsum && gradV && kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3);
-    hipLaunchKernelGGL(coord_wgrad_kernel, dim3(ups_cdiv(co, 64), kh * kw + 1), dim3(256), 0, (hipStream_t)stream, gsum,
-                       hi, wi, ho, wo, co, kh, kw, make_taps3(kh, kw, tap_dy, tap_dx), in_sy, in_sx, ax, ay, ci_log,
-                       gradV, grad_bias);
+                               float ax, float ay, int32_t ci_log, float* gradV, float* grad_bias, float* scratch,
+                               void* stream) {
+    UPS_CHECK_ARG(gsum && gradV && scratch && kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3);
+    const Taps3 tp = make_taps3(kh, kw, tap_dy, tap_dx);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(coord_rows_kernel, dim3(ups_cdiv((long long)wo * co, 256)), dim3(256), 0, s, gsum, hi, ho, wo, co, kh,
+                       tp, in_sy, ay, scratch);
+    UPS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(coord_cols_kernel, dim3(ups_cdiv(co, 64), kh * kw + 1), dim3(64), 0, s, scratch, wi, wo, co, kh, kw,
+                       tp, in_sx, ax, ci_log, gradV, grad_bias);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

@@ -1,18 +1,22 @@
-// Weight gradient of the gather convolution:  dV[tap][ci][co] = sum_pix act(in)[src(pix,tap)][ci] * dout[pix][co]
-// (gradient of tf.nn.conv2d w.r.t. its filter, cub/code/nn.py:661-663).
+// Weight (and bias) gradient of the gather convolution:
+//     dV[tap][ci][co] = sum_pix act(in)[src(pix,tap)][ci] * dout[pix][co],   db[co] = sum_pix dout[pix][co]
+// (gradient of tf.nn.conv2d + bias w.r.t. V and b, cub/code/nn.py:661-663).
 //
-// GEMM view: rows = input channels, cols = output channels, K = lattice points (pixels) -> split-K over pixels
-// into fp32 slabs, then a deterministic slab reduction (no float atomics: bitwise reproducible).
-// Both operands are pixel-major in HBM (NHWC), i.e. K is the slow dimension of both; the tiles are staged
+// GEMM view: rows = "virtual channels" v = tap*ci + c (taps are packed into the row tile, so a 128-row tile of a
+// thin layer covers several taps and dout is re-read ceil(ntaps*ci/128) times instead of ntaps times),
+// cols = output channels, K = lattice points (pixels) -> split-K over pixels into fp32 slabs + a deterministic
+// slab reduction (no float atomics: bitwise reproducible).
+// Both operands are pixel-major in HBM (NHWC), i.e. K is the slow dimension of both: the tiles are staged
 // row-major [pixel][channel] in LDS and the MFMA fragments are fetched with the gfx950 transposing read
 // ds_read_b64_tr_b16 (bf16) / plain ds_read_b32 (f32 32x32x2 needs one element per lane).
 // LDS row stride == 64 (mod 128) bytes keeps the transposed reads of a 32-lane half on distinct banks.
+// The blocks of row-tile 0 also reduce their dout tiles over pixels -> bias gradient (no extra pass over dout).
 #include "common.h"
 
 namespace {
 
 struct WgK {
-    int n, hi, wi, ci, ldi, ci_log, cin_v, ho, wo, co, ldo, in_sy, in_sx, ntaps, act_in;
+    int n, hi, wi, ci, ldi, ci_log, cin_v, ho, wo, co, ldo, in_sy, in_sx, ntaps, act_in, want_bias;
     float act_slope;
     unsigned long long tap_off, tap_wi;
     const void* in; const void* dout; float* ws;
@@ -41,6 +45,7 @@ __device__ inline bf16x8 tr_frag(const unsigned char* tile, int rs, int k0, int 
     return u.b;
 }
 
+// slab layout per split: [ntaps*cin_v*co weight floats][co bias floats]
 template <typename T, int BMW, int BNW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int M, const int cit, const int cot,
                                                          const int chunks_total, const int chunks_per) {
@@ -55,46 +60,60 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int 
     constexpr int ACTIVE = WM * WN;            // waves that own MFMA blocks (<= 4)
     constexpr int CPA = BMW / EPC;             // 16-byte chunks per X row
     constexpr int CPB = BNW / EPC;
-    constexpr int NA = (PK * CPA + 255) / 256; // X chunks per thread (2, 1, or 1 with half the threads)
+    constexpr int NA = (PK * CPA + 255) / 256; // X chunks per thread
     constexpr int NB = (PK * CPB + 255) / 256;
+    constexpr int BPARTS = 256 / BNW;          // pixel groups for the bias column sums
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[PK * (RSA + RSB)];
     unsigned char* Xs = smem;
     unsigned char* Ds = smem + PK * RSA;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int b = blockIdx.x;
-    const int cot_i = b % cot; b /= cot;
-    const int cit_i = b % cit; b /= cit;
-    const int tap = b;
+    const int cot_i = blockIdx.x % cot, cit_i = blockIdx.x / cot;
     const int split = blockIdx.y;
     const int wm = wid / WN, wn = wid % WN;
 
     const T* __restrict__ in = (const T*)p.in;
     const T* __restrict__ dout = (const T*)p.dout;
     const int hw_o = p.ho * p.wo;
-    const int dy = wtap_dy(p.tap_off, tap), dx = wtap_dx(p.tap_off, tap);
-    const int ci0 = cit_i * BMW, co0 = cot_i * BNW;
+    const int V = p.ntaps * p.ci;
+    const int v0 = cit_i * BMW, co0 = cot_i * BNW;
+    const bool do_bias = p.want_bias && cit_i == 0;
 
     const int c_begin = split * chunks_per;
     const int c_end = min(chunks_total, c_begin + chunks_per);
 
+    // loop-invariant decode of this thread's X items: virtual channel -> (tap offset, channel)
+    int xrow0 = 0, xrow1 = 0, xc0 = -1, xc1 = -1, xdy0 = 0, xdx0 = 0, xdy1 = 0, xdx1 = 0;
+    {
+        auto dec = [&](int idx, int& row, int& c, int& dy, int& dx) {
+            c = -1;
+            if (idx < PK * CPA) {
+                row = idx / CPA;
+                const int v = v0 + (idx - row * CPA) * EPC;
+                if (v < V) {
+                    const int tap = v / p.ci;
+                    c = v - tap * p.ci;
+                    dy = wtap_dy(p.tap_off, tap); dx = wtap_dx(p.tap_off, tap);
+                }
+            }
+        };
+        dec(tid, xrow0, xc0, xdy0, xdx0);
+        if (NA > 1) dec(tid + 256, xrow1, xc1, xdy1, xdx1);
+    }
+
     uint4 xa0, xa1, db0, db1;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 
-    auto load_x = [&](int chunk_idx, int idx) -> uint4 {
+    auto load_x = [&](int chunk_idx, int row, int c, int dy, int dx) -> uint4 {
         uint4 v = zero4;
-        if (idx < PK * CPA) {
-            const int row = idx / CPA, cc = idx - row * CPA;
-            const int m = chunk_idx * PK + row;
-            const int ch = ci0 + cc * EPC;
-            if (m < M && ch < p.ci) {
-                const int img = m / hw_o, rem = m - img * hw_o;
-                const int i = rem / p.wo, j = rem - i * p.wo;
-                const int y = i * p.in_sy + dy, x = j * p.in_sx + dx;
-                if ((unsigned)y < (unsigned)p.hi && (unsigned)x < (unsigned)p.wi)
-                    v = *(const uint4*)(in + (((long long)img * p.hi + y) * p.wi + x) * p.ldi + ch);
-            }
+        const int m = chunk_idx * PK + row;
+        if (c >= 0 && m < M) {
+            const int img = m / hw_o, rem = m - img * hw_o;
+            const int i = rem / p.wo, j = rem - i * p.wo;
+            const int y = i * p.in_sy + dy, x = j * p.in_sx + dx;
+            if ((unsigned)y < (unsigned)p.hi && (unsigned)x < (unsigned)p.wi)
+                v = *(const uint4*)(in + (((long long)img * p.hi + y) * p.wi + x) * p.ldi + c);
         }
         return v;
     };
@@ -119,8 +138,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int 
         return u;
     };
     auto load_chunk = [&](int chunk_idx) {
-        xa0 = load_x(chunk_idx, tid);
-        if (NA > 1) xa1 = load_x(chunk_idx, tid + 256);
+        xa0 = load_x(chunk_idx, xrow0, xc0, xdy0, xdx0);
+        if (NA > 1) xa1 = load_x(chunk_idx, xrow1, xc1, xdy1, xdx1);
         db0 = load_d(chunk_idx, tid);
         if (NB > 1) db1 = load_d(chunk_idx, tid + 256);
     };
@@ -138,12 +157,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float bsum = 0.f;
+    const int bcol = tid % BNW, bpart = tid / BNW;
 
     if (c_begin < c_end) load_chunk(c_begin);
     for (int c = c_begin; c < c_end; ++c) {
         stage_chunk();
         __syncthreads();
         if (c + 1 < c_end) load_chunk(c + 1);
+        if (do_bias) {
+#pragma unroll
+            for (int k = 0; k < PK / BPARTS; ++k)
+                bsum += ld_as_float<T>((const T*)(Ds + (bpart * (PK / BPARTS) + k) * RSB) + bcol);
+        }
         if (wid < ACTIVE) {
             if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -179,9 +205,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int 
         __syncthreads();
     }
 
+    const long long slab_sz = (long long)p.ntaps * p.cin_v * p.co + p.co;
+    float* slab = p.ws + (long long)split * slab_sz;
     if (wid < ACTIVE) {
-        float* slab = p.ws + (long long)split * p.ntaps * p.cin_v * p.co;
-        const int tw = wtap_w(p.tap_wi, tap);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int col = co0 + (wn * TN + tn) * 32 + (lane & 31);
@@ -190,37 +216,61 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int 
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int row = ci0 + (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    if (row < p.ci_log) slab[((long long)tw * p.cin_v + row) * p.co + col] = acc[tm][tn][e];
+                    const int v = v0 + (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (v < V) {
+                        const int tap = v / p.ci, cch = v - tap * p.ci;
+                        if (cch < p.ci_log)
+                            slab[((long long)wtap_w(p.tap_wi, tap) * p.cin_v + cch) * p.co + col] = acc[tm][tn][e];
+                    }
                 }
+        }
+    }
+    if (do_bias) {
+        float* red = (float*)smem;            // safe: every wave passed the loop's final barrier
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < BNW && co0 + tid < p.co) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < BPARTS; ++k) s += red[k * BNW + tid];
+            slab[(long long)p.ntaps * p.cin_v * p.co + co0 + tid] = s;
         }
     }
 }
 
-// grad[tap][row < ci_log][co] = sum_s slab[s][...]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ grad, int splitk, int ntaps_w,
-                                    int cin_v, int ci_log, int co, long long slab) {
-    const long long total = (long long)ntaps_w * ci_log * co;
+// grad[tap][row < ci_log][co] = sum_s slab[s][...] ; grad_bias[co] = sum_s slab[s][bias part]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ grad, float* __restrict__ gbias,
+                                    int splitk, int ntaps_w, int cin_v, int ci_log, int co, long long slab) {
+    const long long nw = (long long)ntaps_w * ci_log * co;
+    const long long total = nw + (gbias ? co : 0);
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % co);
-        const long long tr = idx / co;
-        const int row = (int)(tr % ci_log), tap = (int)(tr / ci_log);
-        const long long off = ((long long)tap * cin_v + row) * co + c;
+        long long off;
+        float* dst;
+        if (idx < nw) {
+            const int c = (int)(idx % co);
+            const long long tr = idx / co;
+            const int row = (int)(tr % ci_log), tap = (int)(tr / ci_log);
+            off = ((long long)tap * cin_v + row) * co + c;
+            dst = grad + off;
+        } else {
+            off = (long long)ntaps_w * cin_v * co + (idx - nw);
+            dst = gbias + (idx - nw);
+        }
         float s = 0.f;
         for (int k = 0; k < splitk; ++k) s += ws[k * slab + off];
-        grad[off] = s;
+        *dst = s;
     }
 }
 
 template <typename T, int BMW, int BNW>
 void launch_tile(const WgK& k, int M, int splitk, hipStream_t s) {
     constexpr int PK = 4 * Chunk<T>::N;
-    const int cit = ups_cdiv(k.ci, BMW), cot = ups_cdiv(k.co, BNW);
+    const int cit = ups_cdiv(k.ntaps * k.ci, BMW), cot = ups_cdiv(k.co, BNW);
     const int chunks_total = ups_cdiv(M, PK);
     const int chunks_per = ups_cdiv(chunks_total, splitk);
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW>), dim3(k.ntaps * cit * cot, splitk), dim3(256), 0, s, k, M, cit,
-                       cot, chunks_total, chunks_per);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW>), dim3(cit * cot, splitk), dim3(256), 0, s, k, M, cit, cot,
+                       chunks_total, chunks_per);
 }
 
 template <typename T, int BMW>
@@ -230,19 +280,21 @@ void launch_n(const WgK& k, int M, int splitk, hipStream_t s) {
     else launch_tile<T, BMW, 32>(k, M, splitk, s);
 }
 
+int tile_of(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
+
 template <typename T>
 void launch_m(const WgK& k, int M, int splitk, hipStream_t s) {
-    if (k.ci > 64) launch_n<T, 128>(k, M, splitk, s);
-    else if (k.ci > 32) launch_n<T, 64>(k, M, splitk, s);
+    const int bm = tile_of(k.ntaps * k.ci);
+    if (bm == 128) launch_n<T, 128>(k, M, splitk, s);
+    else if (bm == 64) launch_n<T, 64>(k, M, splitk, s);
     else launch_n<T, 32>(k, M, splitk, s);
 }
-
-int tile_of(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
 
 int plan_splitk(const ups_wgrad_desc* d) {
     const long long M = (long long)d->n * d->ho * d->wo;
     const int pk = d->dtype == UPS_BF16 ? 32 : 16;
-    const int tiles = d->ntaps * ups_cdiv(d->ci, tile_of(d->ci)) * ups_cdiv(d->co, tile_of(d->co));
+    const int v = d->ntaps * d->ci;
+    const int tiles = ups_cdiv(v, tile_of(v)) * ups_cdiv(d->co, tile_of(d->co));
     const int chunks = ups_cdiv(M, pk);
     int sk = ups_cdiv(2048, tiles);            // ~8 blocks per CU
     const int max_by_work = chunks / 8 > 0 ? chunks / 8 : 1;  // at least 8 chunks per block
@@ -259,7 +311,7 @@ extern "C" int ups_conv_wgrad_plan(const ups_wgrad_desc* d, int32_t* splitk, siz
     UPS_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= 9 && d->ci > 0 && d->co > 0);
     const int sk = plan_splitk(d);
     *splitk = sk;
-    *workspace_bytes = (size_t)sk * d->ntaps * d->cin_v * d->co * sizeof(float);
+    *workspace_bytes = (size_t)sk * ((size_t)d->ntaps * d->cin_v * d->co + d->co) * sizeof(float);
     return UPS_OK;
 }
 
@@ -276,7 +328,7 @@ extern "C" int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream) {
     WgK k;
     k.n = d->n; k.hi = d->hi; k.wi = d->wi; k.ci = d->ci; k.ldi = d->ldi; k.ci_log = d->ci_log; k.cin_v = d->cin_v;
     k.ho = d->ho; k.wo = d->wo; k.co = d->co; k.ldo = d->ldo; k.in_sy = d->in_sy; k.in_sx = d->in_sx;
-    k.ntaps = d->ntaps; k.act_in = d->act_in; k.act_slope = d->act_slope;
+    k.ntaps = d->ntaps; k.act_in = d->act_in; k.act_slope = d->act_slope; k.want_bias = d->grad_bias != nullptr;
     k.in = d->in; k.dout = d->dout; k.ws = d->workspace;
     k.tap_off = 0; k.tap_wi = 0;
     int max_tw = 0;
@@ -292,10 +344,10 @@ extern "C" int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream) {
     if (d->dtype == UPS_F32) launch_m<float>(k, (int)M, d->splitk, s);
     else launch_m<bf16>(k, (int)M, d->splitk, s);
     UPS_LAUNCH_CHECK();
-    const long long slab = (long long)d->ntaps * d->cin_v * d->co;
-    const long long total = (long long)d->ntaps * d->ci_log * d->co;
+    const long long slab = (long long)d->ntaps * d->cin_v * d->co + d->co;
+    const long long total = (long long)d->ntaps * d->ci_log * d->co + d->co;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ups_cdiv(total, 256) > 4096 ? 4096 : ups_cdiv(total, 256)), dim3(256), 0,
-                       s, d->workspace, d->grad, d->splitk, d->ntaps, d->cin_v, d->ci_log, d->co, slab);
+                       s, d->workspace, d->grad, d->grad_bias, d->splitk, d->ntaps, d->cin_v, d->ci_log, d->co, slab);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

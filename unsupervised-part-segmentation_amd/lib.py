@@ -40,7 +40,8 @@ class WgradDesc(C.Structure):
                 ("co", C.c_int32), ("ldo", C.c_int32), ("in_sy", C.c_int32), ("in_sx", C.c_int32), ("ntaps", C.c_int32),
                 ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9), ("tap_w", C.c_int32 * 9),
                 ("act_in", C.c_int32), ("act_slope", C.c_float), ("splitk", C.c_int32),
-                ("in_", C.c_void_p), ("dout", C.c_void_p), ("grad", C.c_void_p), ("workspace", C.c_void_p)]
+                ("in_", C.c_void_p), ("dout", C.c_void_p), ("grad", C.c_void_p), ("grad_bias", C.c_void_p),
+                ("workspace", C.c_void_p)]
 
 
 class PriorDesc(C.Structure):
@@ -64,7 +65,7 @@ _SIGS = {
     "ups_weight_prep": ([_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P], C.c_int),
     "ups_coord_table": ([_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _I, _I, _F, _F, _P, _P], C.c_int),
     "ups_batch_sum": ([_P, _I, _I, _L, _I, _I, _P, _P], C.c_int),
-    "ups_coord_wgrad": ([_P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _I, _I, _F, _F, _I, _P, _P, _P], C.c_int),
+    "ups_coord_wgrad": ([_P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _I, _I, _F, _F, _I, _P, _P, _P, _P], C.c_int),
     "ups_col_sum": ([_P, _I, _L, _I, _I, _P, _P, _P], C.c_int),
     "ups_bilinear2x_fwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "ups_bilinear2x_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),

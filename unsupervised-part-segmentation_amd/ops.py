@@ -227,21 +227,19 @@ def conv_wgrad(g, x, layer):
     _fill_taps(d, dy, dx, tw, layer.k * layer.k)
     d.act_in, d.act_slope = layer.act_in, layer.slope
     sk, wsb = C.c_int32(0), C.c_size_t(0)
-    d.in_, d.dout, d.grad = x.data_ptr(), g.data_ptr(), gV.data_ptr()
+    d.in_, d.dout, d.grad, d.grad_bias = x.data_ptr(), g.data_ptr(), gV.data_ptr(), gb.data_ptr()
     L.call("ups_conv_wgrad_plan", C.byref(d), C.byref(sk), C.byref(wsb))
     ws = WORKSPACE.get(wsb.value, dev)
     d.splitk, d.workspace = sk.value, ws.data_ptr()
-    L.call("ups_conv_wgrad", C.byref(d), L.stream())
+    L.call("ups_conv_wgrad", C.byref(d), L.stream())        # dV (main channels) + db from the same dout tiles
     if layer.coords:
         gsum = torch.empty((ho * wo, layer.co), dtype=torch.float32, device=dev)
         L.call("ups_batch_sum", L.ptr(g), dcode, n, ho * wo, layer.co, g.shape[-1], L.ptr(gsum), L.stream())
         ax, ay = 2.0 / max(1, hi - 1), 2.0 / max(1, wi - 1)
+        scratch = COLSUM_WS.get((layer.k + 1) * 2 * wo * layer.co * 4, dev)
         L.call("ups_coord_wgrad", L.ptr(gsum), hi, wi, ho, wo, layer.co, layer.k, layer.k,
                (C.c_int32 * 9)(*dy), (C.c_int32 * 9)(*dx), layer.stride, layer.stride, ax, ay,
-               layer.ci_log, L.ptr(gV), L.ptr(gb), L.stream())
-    else:
-        cws = COLSUM_WS.get(1024 * layer.co * 4, dev)
-        L.call("ups_col_sum", L.ptr(g), dcode, n * ho * wo, layer.co, g.shape[-1], L.ptr(gb), L.ptr(cws), L.stream())
+               layer.ci_log, L.ptr(gV), None, L.ptr(scratch), L.stream())
     return gV, gb
 
 
