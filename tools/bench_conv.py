@@ -1,0 +1,99 @@
+"""Micro-benchmark of the convolution engine on representative layers of the CUB 128x128 / B=64 step.
+Usage (GPU box): python tools/bench_conv.py [--check] [--only name,...]"""
+import argparse
+import math
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import upsparts_amd  # noqa: E402,F401
+from upsparts_amd import ops, lib  # noqa: E402
+
+CASES = [
+    # name, n, h, cin, cout, k, stride, coords, act
+    ("dv_rb128", 128, 128, 256, 256, 3, 1, True, "leaky_relu"),
+    ("dv_rb64", 128, 64, 256, 256, 3, 1, True, "leaky_relu"),
+    ("dv_rb32", 128, 32, 256, 256, 3, 1, True, "leaky_relu"),
+    ("dv_out", 128, 128, 256, 10, 3, 1, True, None),
+    ("ea_in", 640, 128, 3, 32, 3, 1, False, None),
+    ("ea_rb0", 640, 128, 32, 32, 3, 1, False, "leaky_relu"),
+    ("ea_down0", 640, 128, 32, 64, 3, 2, False, None),
+    ("ea_rb1", 640, 64, 64, 64, 3, 1, False, "leaky_relu"),
+    ("ea_down1", 640, 64, 64, 128, 3, 2, False, None),
+    ("ea_rb2", 640, 32, 128, 128, 3, 1, False, "leaky_relu"),
+    ("ea_rb4", 640, 8, 256, 256, 3, 1, False, "leaky_relu"),
+    ("vgg1_2", 64, 128, 64, 64, 3, 1, False, "relu"),
+    ("vgg3_2", 64, 32, 256, 256, 3, 1, False, "relu"),
+    ("vgg4_2", 64, 16, 512, 512, 3, 1, False, "relu"),
+    ("crit_nin", 128, 1, 512, 512, 1, 1, False, "leaky_relu"),
+]
+
+
+def timeit(fn, iters):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    only = set(args.only.split(",")) if args.only else None
+    print("{:10s} {:>9s} {:>8s} {:>9s} {:>8s} {:>9s} {:>8s}".format("layer", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
+    tot = [0.0, 0.0, 0.0]
+    for name, n, h, cin, cout, k, stride, coords, act in CASES:
+        if only and name not in only:
+            continue
+        g = torch.Generator().manual_seed(1)
+        cin_v = cin + (2 if coords else 0)
+        V = (torch.randn(k, k, cin_v, cout, generator=g) / math.sqrt(cin_v * k * k)).to(dev)
+        b = torch.randn(cout, generator=g).to(dev)
+        lay = ops.ConvLayer(name + "/conv2d_0", V, b, k, stride, coords, act)
+        x = torch.randn(n, h, h, ops.round8(cin), device=dev).to(T)
+        if ops.round8(cin) > cin:
+            x[..., cin:] = 0
+        y = ops.conv_forward(x, lay)
+        gy = torch.randn(y.shape, device=dev).to(T)
+        ho = y.shape[1]
+        flops = 2.0 * n * ho * ho * k * k * cin_v * cout
+        tf = timeit(lambda: ops.conv_forward(x, lay), args.iters)
+        td = timeit(lambda: ops.conv_dgrad(gy, x, lay), args.iters)
+        tw = timeit(lambda: ops.conv_wgrad(gy, x, lay), args.iters)
+        tot[0] += tf; tot[1] += td; tot[2] += tw
+        print("{:10s} {:9.3f} {:8.1f} {:9.3f} {:8.1f} {:9.3f} {:8.1f}".format(
+            name, tf, flops / tf / 1e9, td, flops / td / 1e9, tw, flops / tw / 1e9))
+        if args.check:
+            xa = x.float()[..., :cin]
+            if act == "leaky_relu":
+                xa = torch.nn.functional.leaky_relu(xa, 0.2)
+            elif act == "relu":
+                xa = torch.relu(xa)
+            Vq = V.clone()
+            Vq[:, :, :cin] = V[:, :, :cin].to(T).float()
+            if coords:
+                col = torch.arange(h, device=dev, dtype=torch.float32) / max(1, h - 1) * 2 - 1
+                xx = col.view(1, 1, h, 1).expand(n, h, h, 1); yy = col.view(1, h, 1, 1).expand(n, h, h, 1)
+                xa = torch.cat([xa, xx, yy], -1)
+            oh = -(-h // stride); pt = max((oh - 1) * stride + k - h, 0)
+            xp = torch.nn.functional.pad(xa.permute(0, 3, 1, 2), (pt // 2, pt - pt // 2, pt // 2, pt - pt // 2))
+            ref = torch.nn.functional.conv2d(xp[:8], Vq.permute(3, 2, 0, 1), b, stride=stride).permute(0, 2, 3, 1)
+            err = float((y[:8, ..., :cout].float() - ref).abs().max() / ref.abs().max())
+            print("           fwd max-rel err vs torch fp32 (first 8 images): {:.2e}".format(err))
+    print("{:10s} {:9.3f} {:8s} {:9.3f} {:8s} {:9.3f}".format("sum", tot[0], "", tot[1], "", tot[2]))
+
+
+if __name__ == "__main__":
+    main()

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
         pa0 = mk(tid); pa1 = mk(tid + 512); pa2 = mk(tid + 1024);
     }
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 ra0, ra1, ra2, rb0, rb1, rb2;
+    uint4 ra0, ra1, ra2;
+    struct WSet { uint4 r0, r1, r2; } ws0, ws1;     // two weight stages in flight (prefetch distance 2)
 
     const int cha = (tid & 3) * EPC;            // 512 % 4 == 0: all three items of a thread share the chunk slot
     auto ld_a = [&](long long off, int koff) -> uint4 {
@@ -162,16 +163,16 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
         }
         return v;
     };
-    auto load_w = [&](int g, int cc) {
+    auto load_w = [&](WSet& q, int g, int cc) {
         const int koff = cc * BK;
-        rb0 = ld_b(tid, g, koff);
-        if (NB > 1) rb1 = ld_b(tid + 512, g, koff);
-        if (NB > 2) rb2 = ld_b(tid + 1024, g, koff);
+        q.r0 = ld_b(tid, g, koff);
+        if (NB > 1) q.r1 = ld_b(tid + 512, g, koff);
+        if (NB > 2) q.r2 = ld_b(tid + 1024, g, koff);
     };
-    auto store_w = [&](unsigned char* B) {
-        if (tid < 3 * BN * 4) *(uint4*)(B + (tid >> 2) * RS + (tid & 3) * 16) = rb0;
-        if (NB > 1 && tid + 512 < 3 * BN * 4) *(uint4*)(B + ((tid + 512) >> 2) * RS + (tid & 3) * 16) = rb1;
-        if (NB > 2 && tid + 1024 < 3 * BN * 4) *(uint4*)(B + ((tid + 1024) >> 2) * RS + (tid & 3) * 16) = rb2;
+    auto store_w = [&](const WSet& q, unsigned char* B) {
+        if (tid < 3 * BN * 4) *(uint4*)(B + (tid >> 2) * RS + (tid & 3) * 16) = q.r0;
+        if (NB > 1 && tid + 512 < 3 * BN * 4) *(uint4*)(B + ((tid + 512) >> 2) * RS + (tid & 3) * 16) = q.r1;
+        if (NB > 2 && tid + 1024 < 3 * BN * 4) *(uint4*)(B + ((tid + 1024) >> 2) * RS + (tid & 3) * 16) = q.r2;
     };
 
     f32x16 acc[TM][TN];
@@ -188,18 +189,21 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
     const int a_lane_off = (ty_l * PW + tx_l) * RS + hh * HALF_OFF;        // patch origin is (-1,-1): tap (dy,dx) adds (dy+1, dx+1)
     const int b_lane_off = (wn * TN * 32 + r) * RS + hh * HALF_OFF;
 
+    // Software pipeline, prefetch distance 2: the global loads of tap-row it+2 are issued before the MFMAs of
+    // tap-row it and written to LDS after the MFMAs of tap-row it+1 (their buffer was last read by tap-row it),
+    // so every load has two compute phases to land; one barrier per tap-row.
     const int total = 3 * kchunks;
-    load_patch(0); load_w(0, 0);
-    store_patch(Abuf); store_w(Bbuf);
+    load_patch(0); load_w(ws0, 0, 0);
+    store_patch(Abuf); store_w(ws0, Bbuf);
+    if (total > 1) load_w(ws1, 1, 0);
     __syncthreads();
-    for (int it = 0; it < total; ++it) {
+    auto iter = [&](int it, WSet& ld_set, const WSet& st_set) {
         const int cc = it / 3, g = it - cc * 3;
-        const int nx = it + 1;
-        const bool more = nx < total;
-        const int ncc = nx / 3, ng = nx - ncc * 3;
-        if (more) {
-            load_w(ng, ncc);
-            if (ng == 0) load_patch(ncc);
+        const int n2 = it + 2, n1 = it + 1;
+        if (n2 < total) {
+            const int c2 = n2 / 3, g2 = n2 - c2 * 3;
+            load_w(ld_set, g2, c2);
+            if (g2 == 0) load_patch(c2);
         }
         const unsigned char* A = Abuf + (cc & 1) * A_BYTES + a_lane_off;
         const unsigned char* B = Bbuf + (it & 1) * B_BYTES + b_lane_off;
@@ -209,11 +213,15 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
             const int po = ((p_dy(p.tap_off, tp) + 1) * PW + (p_dx(p.tap_off, tp) + 1)) * RS;
             PMma<T>::template tap<TM, TN>(A + po, B + tl * BN * RS, acc);
         }
-        if (more) {
-            store_w(Bbuf + (nx & 1) * B_BYTES);
-            if (ng == 0) store_patch(Abuf + (ncc & 1) * A_BYTES);
+        if (n1 < total) {
+            store_w(st_set, Bbuf + (n1 & 1) * B_BYTES);
+            if (n1 % 3 == 0) store_patch(Abuf + ((n1 / 3) & 1) * A_BYTES);
         }
         __syncthreads();
+    };
+    for (int it = 0; it < total; it += 2) {
+        iter(it, ws0, ws1);
+        if (it + 1 < total) iter(it + 1, ws1, ws0);
     }
 
     // ---- epilogue

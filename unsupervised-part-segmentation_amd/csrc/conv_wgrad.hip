@@ -306,9 +306,18 @@ int plan_splitk(const ups_wgrad_desc* d) {
 
 }  // namespace
 
+int ups_wgrad3x3_plan(const ups_wgrad_desc* d, int* splitk, int* slabs);   // conv_wgrad3x3.hip
+int ups_wgrad3x3_run(const ups_wgrad_desc* d, hipStream_t s);
+
 extern "C" int ups_conv_wgrad_plan(const ups_wgrad_desc* d, int32_t* splitk, size_t* workspace_bytes) {
     UPS_CHECK_ARG(d && splitk && workspace_bytes);
     UPS_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= 9 && d->ci > 0 && d->co > 0);
+    int sk3 = 0, slabs3 = 0;
+    if (ups_wgrad3x3_plan(d, &sk3, &slabs3) == 0) {      // bf16 3x3/stride-1: patch-tiled kernel
+        *splitk = sk3;
+        *workspace_bytes = (size_t)slabs3 * ((size_t)d->ntaps * d->cin_v * d->co + d->co) * sizeof(float);
+        return UPS_OK;
+    }
     const int sk = plan_splitk(d);
     *splitk = sk;
     *workspace_bytes = (size_t)sk * ((size_t)d->ntaps * d->cin_v * d->co + d->co) * sizeof(float);
@@ -341,13 +350,19 @@ extern "C" int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream) {
     }
     UPS_CHECK_ARG(max_tw < d->ntaps);  // slab holds ntaps slices
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == UPS_F32) launch_m<float>(k, (int)M, d->splitk, s);
+    int nslabs = d->splitk;
+    int sk3 = 0, slabs3 = 0;
+    if (ups_wgrad3x3_plan(d, &sk3, &slabs3) == 0) {
+        UPS_CHECK_ARG(d->splitk == sk3);
+        if (ups_wgrad3x3_run(d, s) != UPS_OK) { ups_set_error("ups_conv_wgrad: patch kernel launch setup failed"); return UPS_E_LAUNCH; }
+        nslabs = slabs3;
+    } else if (d->dtype == UPS_F32) launch_m<float>(k, (int)M, d->splitk, s);
     else launch_m<bf16>(k, (int)M, d->splitk, s);
     UPS_LAUNCH_CHECK();
     const long long slab = (long long)d->ntaps * d->cin_v * d->co + d->co;
     const long long total = (long long)d->ntaps * d->ci_log * d->co + d->co;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ups_cdiv(total, 256) > 4096 ? 4096 : ups_cdiv(total, 256)), dim3(256), 0,
-                       s, d->workspace, d->grad, d->grad_bias, d->splitk, d->ntaps, d->cin_v, d->ci_log, d->co, slab);
+                       s, d->workspace, d->grad, d->grad_bias, nslabs, d->ntaps, d->cin_v, d->ci_log, d->co, slab);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

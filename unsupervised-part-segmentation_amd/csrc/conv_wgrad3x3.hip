@@ -1,0 +1,272 @@
+// Patch-tiled weight gradient for 3x3 / stride-1 'SAME' convolutions, bf16 (the wgrad twin of conv3x3_patch.hip):
+//     dV[tap][ci][co] = sum_{img,y,x} act(in)[img][y+dy][x+dx][ci] * dout[img][y][x][co]      (nn.py:661-663)
+//
+// Block = 512 threads = 8 waves; it owns a (CB input channels x BN output channels) slice of dV for ALL nine taps
+// (9 accumulator blocks of 32x32 per wave = 144 AGPRs) and walks over half-tiles of 8x16 output pixels:
+// per half-tile the (8+2)x(16+2) input halo patch [pixel][CB] and the dout tile [pixel][BN] are staged once in LDS
+// (row-major, double-buffered, activation-on-load applied once) and every tap's operand is a shifted window of the
+// same patch, fetched as an MFMA fragment with the transposing read ds_read_b64_tr_b16 (pixels are the GEMM K).
+// Staging traffic per MFMA is ~6x lower than in the generic split-K kernel (which re-stages X per tap).
+// Waves are arranged WCI x WCO x WK: input-channel half, output-channel block, and K (tile rows) split; each K-part
+// writes its own fp32 slab (deterministic reduce, no atomics).  The bias gradient is summed on the VALU from the dout
+// fragments the channel-slice-0 waves already hold.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 16, TH = 8;           // half-tile: 8 rows x 16 pixels
+constexpr int PWID = TW + 2, PROWS = TH + 2, PPIX = PWID * PROWS;   // 18 x 10 = 180 patch pixels
+
+struct Wg3K {
+    int n, h, w, ci, ldi, ci_log, cin_v, co, ldo, act_in, want_bias, units_total, units_per, tiles_x, tiles_y;
+    float act_slope;
+    unsigned long long tap_off, tap_wi;
+    const void* in; const void* dout; float* ws;
+};
+
+__device__ inline int g_dy(unsigned long long off, int t) { return (int)((off >> (4 * t + 2)) & 3) - 1; }
+__device__ inline int g_dx(unsigned long long off, int t) { return (int)((off >> (4 * t)) & 3) - 1; }
+__device__ inline int g_w(unsigned long long wi, int t) { return (int)((wi >> (4 * t)) & 15); }
+
+constexpr int lds_stride3(int row_bytes) { return ((row_bytes + 63) / 128) * 128 + 64; }
+
+typedef __attribute__((address_space(3))) s16x4 lds3_s16x4;
+
+// element j of lane l = M[row0 + 8*(l>>5) + j][c0 + (l&31)] of a row-major LDS tile (row stride rs bytes)
+__device__ inline bf16x8 tr_frag3(const unsigned char* tile, int rs, int row0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, h = g >> 1;
+    const int cb = c0 + 16 * (g & 1), q = i >> 2, pp = i & 3;
+    const unsigned char* a0 = tile + (row0 + 8 * h + q) * rs + (cb + 4 * pp) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds3_s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds3_s16x4*)(a0 + 4 * rs));
+    union { s16x4 s[2]; bf16x8 b; } u;
+    u.s[0] = lo; u.s[1] = hi;
+    return u.b;
+}
+
+template <int CB, int BN>
+__global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const int cit, const int cot) {
+    constexpr int WCI = CB / 32, WCO = BN / 32, WK = 8 / (WCI * WCO);
+    constexpr int RSX = lds_stride3(CB * 2), RSD = lds_stride3(BN * 2);
+    constexpr int XB = PPIX * RSX, DB = TH * TW * RSD;
+    constexpr int CPX = CB / 8, CPD = BN / 8;                 // 16-byte chunks per row
+    constexpr int NX = (PPIX * CPX + 511) / 512, ND = (TH * TW * CPD + 511) / 512;
+    static_assert(NX <= 3 && ND <= 4, "staging register budget");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Xbuf = smem;                 // 2 x XB
+    unsigned char* Dbuf = smem + 2 * XB;        // 2 x DB
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cot_i = blockIdx.x % cot, cit_i = blockIdx.x / cot;
+    const int split = blockIdx.y;
+    const int w_ci = wid % WCI, w_co = (wid / WCI) % WCO, w_k = wid / (WCI * WCO);
+    const int ci0 = cit_i * CB, co0 = cot_i * BN;
+    const bf16* __restrict__ in = (const bf16*)p.in;
+    const bf16* __restrict__ dout = (const bf16*)p.dout;
+    const bool do_bias = p.want_bias && cit_i == 0 && w_ci == 0;
+
+    const int u_begin = split * p.units_per;
+    const int u_end = min(p.units_total, u_begin + p.units_per);
+
+    uint4 rx0, rx1, rx2, rd0, rd1, rd2, rd3;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+
+    auto unit_origin = [&](int u, int& img, int& y0, int& x0) {
+        const int half = u & 1;
+        int t = u >> 1;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        img = t / p.tiles_y;
+        y0 = ty * 16 + half * TH; x0 = tx * TW;
+    };
+    auto ld_x = [&](int item, int img, int y0, int x0) -> uint4 {
+        uint4 v = zero4;
+        if (item < PPIX * CPX) {
+            const int pix = item / CPX, cc = item - pix * CPX;
+            const int py = pix / PWID, px = pix - py * PWID;
+            const int y = y0 - 1 + py, x = x0 - 1 + px, ch = ci0 + cc * 8;
+            if ((unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w && ch < p.ci)
+                v = *(const uint4*)(in + (((long long)img * p.h + y) * p.w + x) * p.ldi + ch);
+        }
+        return v;
+    };
+    auto ld_d = [&](int item, int img, int y0, int x0) -> uint4 {
+        uint4 v = zero4;
+        if (item < TH * TW * CPD) {
+            const int pix = item / CPD, cc = item - pix * CPD;
+            const int y = y0 + (pix >> 4), x = x0 + (pix & 15), ch = co0 + cc * 8;
+            if (ch < p.ldo) v = *(const uint4*)(dout + (((long long)img * p.h + y) * p.w + x) * p.ldo + ch);
+        }
+        return v;
+    };
+    auto load_unit = [&](int u) {
+        int img, y0, x0;
+        unit_origin(u, img, y0, x0);
+        rx0 = ld_x(tid, img, y0, x0);
+        if (NX > 1) rx1 = ld_x(tid + 512, img, y0, x0);
+        if (NX > 2) rx2 = ld_x(tid + 1024, img, y0, x0);
+        rd0 = ld_d(tid, img, y0, x0);
+        if (ND > 1) rd1 = ld_d(tid + 512, img, y0, x0);
+        if (ND > 2) rd2 = ld_d(tid + 1024, img, y0, x0);
+        if (ND > 3) rd3 = ld_d(tid + 1536, img, y0, x0);
+    };
+    auto act_u4 = [&](uint4 u) -> uint4 {
+        if (p.act_in != UPS_ACT_NONE) {
+            float f[8];
+            Chunk<bf16>::unpack(u, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = ups_act(f[e], p.act_in, p.act_slope);
+            u = Chunk<bf16>::pack(f);
+        }
+        return u;
+    };
+    auto st_x = [&](unsigned char* X, int item, uint4 v) {
+        if (item < PPIX * CPX) { const int pix = item / CPX, cc = item - pix * CPX; *(uint4*)(X + pix * RSX + cc * 16) = act_u4(v); }
+    };
+    auto st_d = [&](unsigned char* D, int item, uint4 v) {
+        if (item < TH * TW * CPD) { const int pix = item / CPD, cc = item - pix * CPD; *(uint4*)(D + pix * RSD + cc * 16) = v; }
+    };
+    auto store_unit = [&](int buf) {
+        unsigned char* X = Xbuf + buf * XB;
+        unsigned char* D = Dbuf + buf * DB;
+        st_x(X, tid, rx0);
+        if (NX > 1) st_x(X, tid + 512, rx1);
+        if (NX > 2) st_x(X, tid + 1024, rx2);
+        st_d(D, tid, rd0);
+        if (ND > 1) st_d(D, tid + 512, rd1);
+        if (ND > 2) st_d(D, tid + 1024, rd2);
+        if (ND > 3) st_d(D, tid + 1536, rd3);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    float bsum = 0.f;        // bias gradient: column sums straight from the dout fragments (k = 8*(lane>>5)+j, col = lane&31)
+
+    if (u_begin < u_end) { load_unit(u_begin); store_unit(0); }
+    __syncthreads();
+    for (int u = u_begin; u < u_end; ++u) {
+        const int buf = (u - u_begin) & 1;
+        if (u + 1 < u_end) load_unit(u + 1);
+        const unsigned char* X = Xbuf + buf * XB;
+        const unsigned char* D = Dbuf + buf * DB;
+#pragma unroll 1
+        for (int kk = 0; kk < TH / WK; ++kk) {
+            const int ks = w_k + kk * WK;                               // tile row handled by this wave
+            const bf16x8 b = tr_frag3(D, RSD, ks * TW, w_co * 32, lane);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int row0 = (ks + g_dy(p.tap_off, t) + 1) * PWID + g_dx(p.tap_off, t) + 1;
+                const bf16x8 a = tr_frag3(X, RSX, row0, w_ci * 32, lane);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += (float)b[j];
+            }
+        }
+        if (u + 1 < u_end) store_unit(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- write this wave's slab: slab index = split * WK + w_k
+    const long long slab_sz = (long long)9 * p.cin_v * p.co + p.co;
+    float* slab = p.ws + ((long long)split * WK + w_k) * slab_sz;
+    const int col = co0 + w_co * 32 + (lane & 31);
+    if (col < p.co) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int tw = g_w(p.tap_wi, t);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = ci0 + w_ci * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < p.ci_log) slab[((long long)tw * p.cin_v + row) * p.co + col] = acc[t][e];
+            }
+        }
+        // bias part of the slab: written by the channel-slice-0 waves, zero-filled by nobody else (cit_i == 0 only)
+        bsum += __shfl_xor(bsum, 32, 64);                              // the two lane halves own k = 0..7 / 8..15
+        if (do_bias && (lane >> 5) == 0) slab[(long long)9 * p.cin_v * p.co + col] = bsum;
+    }
+}
+
+struct Variant { int cb, bn, wk; };
+
+Variant pick(const ups_wgrad_desc* d) {
+    Variant v;
+    v.cb = d->ci > 32 ? 64 : 32;
+    v.bn = d->co > 64 ? 128 : (d->co > 32 ? 64 : 32);
+    v.wk = 8 / ((v.cb / 32) * (v.bn / 32));
+    return v;
+}
+
+bool eligible(const ups_wgrad_desc* d) {
+    if (d->dtype != UPS_BF16 || d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1) return false;
+    if (d->hi != d->ho || d->wi != d->wo || d->hi % 16 || d->wi % 16) return false;
+    bool seen[9] = {false, false, false, false, false, false, false, false, false};
+    for (int t = 0; t < 9; ++t) {
+        const int dy = d->tap_dy[t], dx = d->tap_dx[t];
+        if (dy < -1 || dy > 1 || dx < -1 || dx > 1 || d->tap_w[t] < 0 || d->tap_w[t] > 8) return false;
+        seen[(dy + 1) * 3 + dx + 1] = true;
+    }
+    for (int t = 0; t < 9; ++t) if (!seen[t]) return false;
+    const char* force = getenv("UPS_FORCE_GENERIC_CONV");
+    return !(force && force[0] == '1');
+}
+
+template <int CB, int BN>
+int launch3(const Wg3K& k, int cit, int cot, int splitk, hipStream_t s) {
+    constexpr int RSX = lds_stride3(CB * 2), RSD = lds_stride3(BN * 2);
+    const size_t shmem = 2 * (size_t)(PPIX * RSX + TH * TW * RSD);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<CB, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shmem) != hipSuccess) return UPS_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad3x3_kernel<CB, BN>), dim3(cit * cot, splitk), dim3(512), shmem, s, k, cit, cot);
+    return UPS_OK;
+}
+
+}  // namespace
+
+// Returns 1 when the problem is not eligible; otherwise fills block split count and slabs (= splitk * WK).
+int ups_wgrad3x3_plan(const ups_wgrad_desc* d, int* splitk, int* slabs) {
+    if (!eligible(d)) return 1;
+    const Variant v = pick(d);
+    const int pairs = ups_cdiv(d->ci, v.cb) * ups_cdiv(d->co, v.bn);
+    const int units = d->n * (d->hi / 16) * (d->wi / 16) * 2;
+    int sk = ups_cdiv(512, pairs);                 // ~2 blocks per CU in flight over the launch
+    if (sk > units / 4) sk = units / 4 > 0 ? units / 4 : 1;
+    if (sk > 256) sk = 256;
+    *splitk = sk;
+    *slabs = sk * v.wk;
+    return 0;
+}
+
+int ups_wgrad3x3_run(const ups_wgrad_desc* d, hipStream_t s) {
+    const Variant v = pick(d);
+    Wg3K k;
+    k.n = d->n; k.h = d->hi; k.w = d->wi; k.ci = d->ci; k.ldi = d->ldi; k.ci_log = d->ci_log; k.cin_v = d->cin_v;
+    k.co = d->co; k.ldo = d->ldo; k.act_in = d->act_in; k.act_slope = d->act_slope; k.want_bias = d->grad_bias != nullptr;
+    k.tiles_x = d->wi / 16; k.tiles_y = d->hi / 16;
+    k.units_total = d->n * k.tiles_x * k.tiles_y * 2;
+    k.units_per = ups_cdiv(k.units_total, d->splitk);
+    k.in = d->in; k.dout = d->dout; k.ws = d->workspace;
+    k.tap_off = 0; k.tap_wi = 0;
+    for (int t = 0; t < 9; ++t) {
+        k.tap_off |= (unsigned long long)(((d->tap_dy[t] + 1) << 2) | (d->tap_dx[t] + 1)) << (4 * t);
+        k.tap_wi |= (unsigned long long)d->tap_w[t] << (4 * t);
+    }
+    const int cit = ups_cdiv(d->ci, v.cb), cot = ups_cdiv(d->co, v.bn);
+    if (v.cb == 64 && v.bn == 128) return launch3<64, 128>(k, cit, cot, d->splitk, s);
+    if (v.cb == 64 && v.bn == 64) return launch3<64, 64>(k, cit, cot, d->splitk, s);
+    if (v.cb == 64 && v.bn == 32) return launch3<64, 32>(k, cit, cot, d->splitk, s);
+    if (v.cb == 32 && v.bn == 128) return launch3<32, 128>(k, cit, cot, d->splitk, s);
+    if (v.cb == 32 && v.bn == 64) return launch3<32, 64>(k, cit, cot, d->splitk, s);
+    return launch3<32, 32>(k, cit, cot, d->splitk, s);
+}
