@@ -100,10 +100,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = (BN + 63) / 64;  // B rows staged per thread (BN=32: only threads < 128)
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * RS + BM * 8 + BM * 12];
-    unsigned char* As = smem;
-    unsigned char* Bs = smem + BM * RS;
-    long long* rowpix = (long long*)(smem + (BM + BN) * RS);
+    constexpr int STAGE = (BM + BN) * RS;       // one LDS stage: A tile + B tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + BM * 8 + BM * 12];
+    long long* rowpix = (long long*)(smem + 2 * STAGE);
     int* rowaux = (int*)(rowpix + BM);  // [BM][3] = cls, j, i
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -132,8 +131,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
     }
     const bool b_thread = (BN >= 64) || (tid < 128);
 
-    // NOTE: named registers, not arrays: uint4 arrays captured by the lambdas are demoted to scratch by hipcc.
-    uint4 ra0, ra1, rb0, rb1;
+    // NOTE: named registers / plain structs, not arrays: uint4 arrays captured by the lambdas are demoted to scratch.
+    struct RSet { uint4 a0, a1, b0, b1; } s0, s1;     // two chunks in flight (prefetch distance 2)
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     const int iy00 = iy0[0], iy01 = iy0[1], ix00 = ix0[0], ix01 = ix0[1];
     const long long ib0 = ibase[0], ib1 = ibase[1];
@@ -151,15 +150,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
         if (b_thread && kok && c < p.co) v = *(const uint4*)(wt + (long long)c * p.ci + koff);
         return v;
     };
-    auto load_chunk = [&](int t, int kc) {
+    auto load_chunk = [&](RSet& q, int c) {
+        const int t = c / kchunks, kc = c - t * kchunks;
         const int koff = kc * BK + chunk * EPC;
         const bool kok = koff < p.ci;
         const int dy = tap_dy_of(p.tap_off, t), dx = tap_dx_of(p.tap_off, t);
-        ra0 = load_a(rv0, iy00, ix00, ib0, dy, dx, koff, kok);
-        ra1 = load_a(rv1, iy01, ix01, ib1, dy, dx, koff, kok);
+        q.a0 = load_a(rv0, iy00, ix00, ib0, dy, dx, koff, kok);
+        q.a1 = load_a(rv1, iy01, ix01, ib1, dy, dx, koff, kok);
         const T* wt = w + (long long)tap_w_of(p.tap_wi, t) * p.co * p.ci;
-        rb0 = load_b(wt, nt * BN + r0, koff, kok);
-        if (BROWS > 1) rb1 = load_b(wt, nt * BN + r0 + 64, koff, kok);
+        q.b0 = load_b(wt, nt * BN + r0, koff, kok);
+        if (BROWS > 1) q.b1 = load_b(wt, nt * BN + r0 + 64, koff, kok);
     };
     auto act_u4 = [&](uint4 u) -> uint4 {
         if (p.act_in != UPS_ACT_NONE) {
@@ -171,12 +171,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
         }
         return u;
     };
-    auto stage_chunk = [&]() {
-        *(uint4*)(As + r0 * RS + chunk * 16) = act_u4(ra0);
-        *(uint4*)(As + (r0 + 64) * RS + chunk * 16) = act_u4(ra1);
+    auto stage_chunk = [&](const RSet& q, unsigned char* st) {
+        unsigned char* As = st;
+        unsigned char* Bs = st + BM * RS;
+        *(uint4*)(As + r0 * RS + chunk * 16) = act_u4(q.a0);
+        *(uint4*)(As + (r0 + 64) * RS + chunk * 16) = act_u4(q.a1);
         if (b_thread) {
-            *(uint4*)(Bs + r0 * RS + chunk * 16) = rb0;
-            if (BROWS > 1) *(uint4*)(Bs + (r0 + 64) * RS + chunk * 16) = rb1;
+            *(uint4*)(Bs + r0 * RS + chunk * 16) = q.b0;
+            if (BROWS > 1) *(uint4*)(Bs + (r0 + 64) * RS + chunk * 16) = q.b1;
         }
     };
 
@@ -188,19 +190,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const unsigned char* a_base = As + (wm * TM * 32) * RS;
-    const unsigned char* b_base = Bs + (wn * TN * 32) * RS;
-
+    // Software pipeline: double-buffered LDS, one barrier per chunk, prefetch distance 2 (the loads of chunk c+2 are
+    // issued before the MFMAs of chunk c and land in LDS after the MFMAs of chunk c+1).
     const int total = p.ntaps * kchunks;
-    int t_next = 0, kc_next = 0;
-    load_chunk(0, 0);
-    for (int c = 0; c < total; ++c) {
-        stage_chunk();
+    load_chunk(s0, 0);
+    stage_chunk(s0, smem);
+    if (total > 1) load_chunk(s1, 1);
+    __syncthreads();
+    auto iter = [&](int c, RSet& ld_set, const RSet& st_set) {
+        if (c + 2 < total) load_chunk(ld_set, c + 2);
+        const unsigned char* st = smem + (c & 1) * STAGE;
+        Mma<T>::template chunk<TM, TN>(st + (wm * TM * 32) * RS, st + BM * RS + (wn * TN * 32) * RS, lane, acc);
+        if (c + 1 < total) stage_chunk(st_set, smem + ((c + 1) & 1) * STAGE);
         __syncthreads();
-        if (++kc_next == kchunks) { kc_next = 0; ++t_next; }
-        if (c + 1 < total) load_chunk(t_next, kc_next);  // in flight while the MFMAs below run
-        Mma<T>::template chunk<TM, TN>(a_base, b_base, lane, acc);
-        __syncthreads();
+    };
+    for (int c = 0; c < total; c += 2) {
+        iter(c, s0, s1);
+        if (c + 1 < total) iter(c + 1, s1, s0);
     }
 
     // ---- epilogue: row table in LDS (pixel index, CoordConv class, j, i)
@@ -280,14 +286,17 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
     const int kchunks = ups_cdiv(d.ci, 4 * EPC);
     const int ctot = d.co_fill;
     const int mtiles = ups_cdiv(M, BM);
-    if (ctot > 64) {
-        const int ntn = ups_cdiv(ctot, 128);
+    // tile width: 128 when the grid fills the chip, narrower tiles (more blocks) for skinny problems
+    int bn = ctot > 64 ? 128 : (ctot > 32 ? 64 : 32);
+    if (bn == 128 && mtiles * ups_cdiv(ctot, 128) < 256) bn = 64;
+    if (bn == 64 && mtiles * ups_cdiv(ctot, 64) < 256) bn = 32;
+    const int ntn = ups_cdiv(ctot, bn);
+    if (bn == 128)
         hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3(mtiles * ntn), dim3(256), 0, s, d, (int)M, ntn, kchunks);
-    } else if (ctot > 32) {
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3(mtiles), dim3(256), 0, s, d, (int)M, 1, kchunks);
-    } else {
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 32>), dim3(mtiles), dim3(256), 0, s, d, (int)M, 1, kchunks);
-    }
+    else if (bn == 64)
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3(mtiles * ntn), dim3(256), 0, s, d, (int)M, ntn, kchunks);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 32>), dim3(mtiles * ntn), dim3(256), 0, s, d, (int)M, ntn, kchunks);
     return UPS_OK;
 }
 

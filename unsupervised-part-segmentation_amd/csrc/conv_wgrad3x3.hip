@@ -8,7 +8,7 @@
 // same patch, fetched as an MFMA fragment with the transposing read ds_read_b64_tr_b16 (pixels are the GEMM K).
 // Staging traffic per MFMA is ~6x lower than in the generic split-K kernel (which re-stages X per tap).
 // Waves are arranged WCI x WCO x WK: input-channel half, output-channel block, and K (tile rows) split; each K-part
-// writes its own fp32 slab (deterministic reduce, no atomics).  The bias gradient is summed on the VALU from the dout
+// parts of a block are summed through LDS and each block writes one fp32 slab (deterministic reduce, no atomics).  The bias gradient is summed on the VALU from the dout
 // fragments the channel-slice-0 waves already hold.
 #include <stdlib.h>
 
@@ -174,11 +174,36 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
         __syncthreads();
     }
 
-    // ---- write this wave's slab: slab index = split * WK + w_k
+    // ---- reduce the WK K-parts of the block through LDS (tap by tap), then the w_k == 0 waves write the block's slab
+    bsum += __shfl_xor(bsum, 32, 64);                                  // the two lane halves own k = 0..7 / 8..15
+    if (WK > 1) {
+        float* red = (float*)smem;                                     // (WK-1) x (WCI*WCO) x 32x32 floats <= 28 KB
+        const int slot = ((w_k - 1) * (WCI * WCO) + w_ci + WCI * w_co) * 1024;
+        const int slot0 = (w_ci + WCI * w_co) * 1024;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            __syncthreads();
+            if (w_k > 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[slot + e * 64 + lane] = acc[t][e];
+            }
+            __syncthreads();
+            if (w_k == 0) {
+                for (int k = 1; k < WK; ++k)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t][e] += red[(k - 1) * (WCI * WCO) * 1024 + slot0 + e * 64 + lane];
+            }
+        }
+        __syncthreads();
+        if (w_k > 0) red[slot + lane] = bsum;
+        __syncthreads();
+        if (w_k == 0)
+            for (int k = 1; k < WK; ++k) bsum += red[(k - 1) * (WCI * WCO) * 1024 + slot0 + lane];
+    }
     const long long slab_sz = (long long)9 * p.cin_v * p.co + p.co;
-    float* slab = p.ws + ((long long)split * WK + w_k) * slab_sz;
+    float* slab = p.ws + (long long)split * slab_sz;
     const int col = co0 + w_co * 32 + (lane & 31);
-    if (col < p.co) {
+    if (w_k == 0 && col < p.co) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int tw = g_w(p.tap_wi, t);
@@ -188,8 +213,6 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
                 if (row < p.ci_log) slab[((long long)tw * p.cin_v + row) * p.co + col] = acc[t][e];
             }
         }
-        // bias part of the slab: written by the channel-slice-0 waves, zero-filled by nobody else (cit_i == 0 only)
-        bsum += __shfl_xor(bsum, 32, 64);                              // the two lane halves own k = 0..7 / 8..15
         if (do_bias && (lane >> 5) == 0) slab[(long long)9 * p.cin_v * p.co + col] = bsum;
     }
 }
@@ -244,7 +267,7 @@ int ups_wgrad3x3_plan(const ups_wgrad_desc* d, int* splitk, int* slabs) {
     if (sk > units / 4) sk = units / 4 > 0 ? units / 4 : 1;
     if (sk > 256) sk = 256;
     *splitk = sk;
-    *slabs = sk * v.wk;
+    *slabs = sk;                                   // the K-parts of a block are reduced in LDS
     return 0;
 }
 

@@ -195,13 +195,45 @@ __global__ void unpool_fwd_kernel(const float* __restrict__ hard, const float* _
     else { *(uint4*)o = Chunk<float>::pack(f); *(uint4*)((float*)o + 4) = Chunk<float>::pack(f + 4); }
 }
 
-// block = (image b, slab of pixels); wave pl walks pixels, lane f owns feature f.
-// g_hard via wavefront dot products, g_feat via private LDS columns (one-hot -> one RMW per pixel).
+// g_hard[b][px][p] = sum_f g[b][px][f] * feat[b][p][f] + g[b][px][F+p]
+// GP adjacent lanes own the parts of one pixel; feat[b] sits in LDS with an odd row stride (conflict-free reads).
+template <typename T, int GP>
+__global__ __launch_bounds__(256) void unpool_bwd_hard_kernel(const float* __restrict__ feat, const T* __restrict__ g,
+                                                              float* __restrict__ gh, long long hw, int P, int F, int ldo,
+                                                              int px_per_block) {
+    extern __shared__ float fs[];                  // [P][F+1]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < P * F; i += 256) fs[(i / F) * (F + 1) + (i % F)] = feat[(long long)b * P * F + i];
+    __syncthreads();
+    const int c = threadIdx.x % GP, pl = threadIdx.x / GP;
+    constexpr int PL = 256 / GP;
+    const long long p0 = (long long)blockIdx.x * px_per_block;
+    const long long p1 = min(hw, p0 + px_per_block);
+    if (c >= P) return;
+    const float* fr = fs + c * (F + 1);
+    for (long long px = p0 + pl; px < p1; px += PL) {
+        const T* row = g + ((long long)b * hw + px) * ldo;
+        float acc = ld_as_float<T>(row + F + c);
+        for (int f = 0; f < F; f += 8) {
+            float v[8];
+            if (sizeof(T) == 2) { uint4 u = *(const uint4*)(row + f); Chunk<bf16>::unpack(u, v); }
+            else {
+                uint4 u0 = *(const uint4*)(row + f), u1 = *(const uint4*)((const float*)(row + f) + 4);
+                Chunk<float>::unpack(u0, v); Chunk<float>::unpack(u1, v + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += v[e] * fr[f + e];
+        }
+        gh[((long long)b * hw + px) * P + c] = acc;
+    }
+}
+
+// g_feat partials: lane = feature, each wave walks its pixels and adds the gradient row into the LDS column of the
+// (usually single) active part; partial[b][slab][p][f]
 template <typename T>
-__global__ __launch_bounds__(256) void unpool_bwd_kernel(const float* __restrict__ hard, const float* __restrict__ feat,
-                                                         const T* __restrict__ g, float* __restrict__ gh,
-                                                         float* __restrict__ gfeat_partial, int B, long long hw, int P,
-                                                         int F, int ldo, int slab_px) {
+__global__ __launch_bounds__(256) void unpool_bwd_feat_kernel(const float* __restrict__ hard, const T* __restrict__ g,
+                                                              float* __restrict__ gfeat_partial, long long hw, int P, int F,
+                                                              int ldo, int slab_px) {
     extern __shared__ float acc[];  // [4][P][64]
     const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
     const int f = threadIdx.x & 63, pl = threadIdx.x >> 6;
@@ -212,19 +244,19 @@ __global__ __launch_bounds__(256) void unpool_bwd_kernel(const float* __restrict
     for (long long px = p0 + pl; px < p1; px += 4) {
         const long long bp = (long long)b * hw + px;
         const float gf = (f < F) ? ld_as_float<T>(g + bp * ldo + f) : 0.f;
-        for (int p = 0; p < P; ++p) {
-            const float hm = hard[bp * P + p];
-            if (hm != 0.f) my[p * 64 + f] += hm * gf;
-            float d = (f < F) ? gf * feat[((long long)b * P + p) * F + f] : 0.f;
-            d = wave_sum(d);
-            if (f == 0) gh[bp * P + p] = d + ld_as_float<T>(g + bp * ldo + F + p);
+        const float hv = (f < P) ? hard[bp * P + f] : 0.f;
+        unsigned long long m = __ballot(hv != 0.f);
+        while (m) {
+            const int pp = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            my[pp * 64 + f] += __shfl(hv, pp, 64) * gf;
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < P * 64; i += 256) {
-        const int p = i / 64, ff = i % 64;
+        const int pp = i / 64, ff = i % 64;
         if (ff < F)
-            gfeat_partial[(((long long)b * nslab + slab) * P + p) * F + ff] =
+            gfeat_partial[(((long long)b * nslab + slab) * P + pp) * F + ff] =
                 acc[i] + acc[P * 64 + i] + acc[2 * P * 64 + i] + acc[3 * P * 64 + i];
     }
 }
@@ -341,15 +373,29 @@ extern "C" int ups_unpool_fwd(const float* hard, const float* feat, void* out, i
 // g_feat: caller provides B*P*F floats followed by B*UNPOOL_SLABS*P*F floats of workspace.
 extern "C" int ups_unpool_bwd(const float* hard, const float* feat, const void* g, float* g_hard, float* g_feat, int32_t dtype,
                               int32_t B, int64_t hw, int32_t P, int32_t F, int32_t ldo, void* stream) {
-    UPS_CHECK_ARG(hard && feat && g && g_hard && g_feat && F <= 64 && P <= 64 && ldo >= F + P);
+    UPS_CHECK_ARG(hard && feat && g && g_hard && g_feat && F <= 64 && F % 8 == 0 && P <= 64 && ldo >= F + P);
     hipStream_t s = (hipStream_t)stream;
     float* partial = g_feat + (long long)B * P * F;
     const int slab_px = ups_cdiv(hw, UNPOOL_SLABS);
     const size_t shmem = (size_t)4 * P * 64 * sizeof(float);
-    if (dtype == UPS_F32) hipLaunchKernelGGL(unpool_bwd_kernel<float>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, feat, (const float*)g, g_hard, partial, B, (long long)hw, P, F, ldo, slab_px);
-    else hipLaunchKernelGGL(unpool_bwd_kernel<bf16>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, feat, (const bf16*)g, g_hard, partial, B, (long long)hw, P, F, ldo, slab_px);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(unpool_bwd_feat_kernel<float>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, (const float*)g, partial, (long long)hw, P, F, ldo, slab_px);
+    else hipLaunchKernelGGL(unpool_bwd_feat_kernel<bf16>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, (const bf16*)g, partial, (long long)hw, P, F, ldo, slab_px);
     UPS_LAUNCH_CHECK();
     hipLaunchKernelGGL(unpool_feat_reduce_kernel, dim3(ups_cdiv(B * P * F, 256)), dim3(256), 0, s, partial, B, UNPOOL_SLABS, P * F, g_feat);
+    UPS_LAUNCH_CHECK();
+    int gp = 2;
+    while (gp < P) gp *= 2;
+    const int ppb = 1024;                                    // pixels per block
+    const dim3 grid(ups_cdiv(hw, ppb), B);
+    const size_t sh2 = (size_t)P * (F + 1) * sizeof(float);
+#define UPS_UH(TT, G) hipLaunchKernelGGL((unpool_bwd_hard_kernel<TT, G>), grid, dim3(256), sh2, s, feat, (const TT*)g, g_hard, (long long)hw, P, F, ldo, ppb)
+#define UPS_UHD(G) do { if (dtype == UPS_F32) UPS_UH(float, G); else UPS_UH(bf16, G); } while (0)
+    switch (gp) {
+        case 2: UPS_UHD(2); break; case 4: UPS_UHD(4); break; case 8: UPS_UHD(8); break;
+        case 16: UPS_UHD(16); break; case 32: UPS_UHD(32); break; default: UPS_UHD(64); break;
+    }
+#undef UPS_UHD
+#undef UPS_UH
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }
