@@ -16,4 +16,4 @@ for r in rows[:26]:
     n=r['Name'].replace('_ZN12_GLOBAL__N_1','').replace('(anonymous namespace)::','')[:70]
     print(f"{n:72s} {int(r['Calls']):6d} {int(r['TotalDurationNs'])/1e6:9.2f} ms {float(r['Percentage']):6.2f}% avg {float(r['AverageNs'])/1e3:9.1f} us")
 PY
-python3 tools/trace_summary.py $(find gpurun_out/prof_$TAG -name "*kernel_trace.csv") "$PAT" > gpurun_out/trace_$TAG.txt; rm -f $(find gpurun_out/prof_$TAG -name "*kernel_trace.csv")
+python3 tools/trace_summary.py $(find gpurun_out/prof_$TAG -name "*kernel_trace.csv") "$PAT" $GRID > gpurun_out/trace_$TAG.txt; rm -f $(find gpurun_out/prof_$TAG -name "*kernel_trace.csv")

@@ -14,3 +14,8 @@ tot = sum(v[1] for v in agg.values())
 print("total us:", round(tot, 1))
 for (n, g, w), (c, t) in rows[:40]:
     print(f"{n:50s} grid {g:>9s} wg {w:>4s} calls {c:4d} total {t:10.1f} us avg {t/c:9.1f}")
+
+if len(sys.argv) > 3:   # list individual calls of one grid size
+    for r in csv.DictReader(open(path)):
+        if pat in r["Kernel_Name"] and r.get("Grid_Size_X", r.get("Grid_Size", "")) == sys.argv[3]:
+            print(r["Kernel_Name"][:40], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)

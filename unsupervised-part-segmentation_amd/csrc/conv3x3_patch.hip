@@ -230,6 +230,70 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
     const T* __restrict__ res = (const T*)p.res;
     const T* __restrict__ dact = (const T*)p.dact;
     const long long img_pix = (long long)img * p.h * p.w;
+
+    // bf16 fast path: the residual / activation-derivative tiles come in and the output tile goes out through LDS with
+    // 16-byte, fully coalesced accesses (a lane-per-column 2-byte epilogue runs the 1 GB residual read at < 1 TB/s).
+    if constexpr (sizeof(T) == 2) {
+        if (!p.out_f32 && (p.ldo & 7) == 0 && (p.co_fill & 7) == 0) {
+            constexpr int ERS = BN * 2 + 16;                 // staged row stride (bytes)
+            constexpr int CPR = BN / 8;                      // 16-byte chunks per row
+            constexpr int NIT = 256 * CPR / 512;             // chunks per thread
+            unsigned char* R0 = smem;                        // residual tile, then the output tile (in place)
+            unsigned char* R1 = smem + 256 * ERS;            // activation-derivative tile
+            const int c_lim = p.co_fill - nt * BN;           // valid channels of this N-tile (multiple of 8)
+            if (res || dact) {
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
+                    const long long pix = img_pix + (long long)(ty0 + (px >> 4)) * p.w + tx0 + (px & 15);
+                    if (ch * 8 < c_lim) {
+                        if (res) *(uint4*)(R0 + px * ERS + ch * 16) = *(const uint4*)(res + pix * p.ldr + nt * BN + ch * 8);
+                        if (dact) *(uint4*)(R1 + px * ERS + ch * 16) = *(const uint4*)(dact + pix * p.ldd + nt * BN + ch * 8);
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int cl = (wn * TN + tn) * 32 + (lane & 31);
+                const int col = nt * BN + cl;
+                const bool cvalid = col < p.co;
+                if (col >= p.co_fill) continue;
+                const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rr = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        const int px = ((wm * TM + tm) * 2 + (rr >> 4)) * 16 + (rr & 15);
+                        float v = 0.f;
+                        if (cvalid) {
+                            v = acc[tm][tn][e] + bias;
+                            if (p.coord_tab) {
+                                const int y = ty0 + (px >> 4), x = tx0 + (px & 15);
+                                const int ym = (y > 0 ? 1 : 0) | 2 | (y + 1 < p.h ? 4 : 0);
+                                const int xm = (x > 0 ? 1 : 0) | 2 | (x + 1 < p.w ? 4 : 0);
+                                const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
+                                v += tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co];
+                            }
+                            if (dact) v *= ups_dact((float)*(const bf16*)(R1 + px * ERS + cl * 2), p.dact_kind, p.act_slope);
+                            if (res) v += (float)*(const bf16*)(R0 + px * ERS + cl * 2);
+                        }
+                        *(bf16*)(R0 + px * ERS + cl * 2) = (bf16)v;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
+                const long long pix = img_pix + (long long)(ty0 + (px >> 4)) * p.w + tx0 + (px & 15);
+                if (ch * 8 < c_lim) *(uint4*)(outT + pix * p.ldo + nt * BN + ch * 8) = *(const uint4*)(R0 + px * ERS + ch * 16);
+            }
+            return;
+        }
+    }
+
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int col = nt * BN + (wn * TN + tn) * 32 + (lane & 31);
@@ -269,7 +333,9 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     const int ntn = ups_cdiv(k.co_fill, BN);
     const int kchunks = ups_cdiv(k.ci, 4 * EPC);
     const int nblocks = k.n * tiles_x * tiles_y * ntn;
-    const size_t shmem = 2 * A_BYTES + 2 * 3 * BN * RS;
+    size_t shmem = 2 * A_BYTES + 2 * 3 * BN * RS;
+    const size_t epi = sizeof(T) == 2 ? 2 * 256 * (size_t)(BN * 2 + 16) : 0;   // staged bf16 epilogue (2 tiles)
+    if (epi > shmem) shmem = epi;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN>,
