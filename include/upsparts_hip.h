@@ -65,7 +65,8 @@ typedef struct {
     int32_t dact_kind;        /* UPS_ACT_* of the activation whose derivative multiplies the result (dgrad) */
     int32_t ldr, ldd;         /* physical channels of res / dact */
     const void*  in;
-    const void*  w;           /* [n_slices][co][ci], k contiguous, dtype */
+    const void*  w;           /* blocked-K weights [n_slices][ceil(ci/BK)][co][BK], BK = 64 bytes / sizeof(dtype)
+                                 (32 bf16 / 16 f32), zero padded in K: produced by ups_weight_prep */
     void*        out;
     const float* bias;        /* [co] or NULL */
     const float* coord_tab;   /* [64][3][co] affine CoordConv table (ups_coord_table) or NULL */
@@ -98,7 +99,8 @@ typedef struct {
 int ups_conv_wgrad_plan(const ups_wgrad_desc* d, int32_t* splitk, size_t* workspace_bytes);
 int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream);
 
-/* fp32 HWIO master weights -> dtype copies: w_fwd [tap][co][ci_pad] and w_dgrad [tap][ci_pad_rows][co_pad_k].
+/* fp32 HWIO master weights -> dtype copies in the blocked-K layout [tap][k-chunk][row][BK] (BK = 64 bytes):
+ * w_fwd rows = co, K = ci_pad; w_dgrad rows = dgrad_rows, K = dgrad_k.
  * src [ntaps][cin_v][co]; only input channels < ci_log are copied (CoordConv rows are handled by
  * ups_coord_table); rows/cols beyond the logical extent are zero.  Either dst may be NULL. */
 int ups_weight_prep(const float* src, int32_t ntaps, int32_t cin_v, int32_t ci_log, int32_t co,

@@ -50,6 +50,37 @@ template <> struct PMma<bf16> {
         }
     }
 };
+// three taps (6 k-steps of 16) with the fragments of k-step s+1 fetched from LDS before the MFMAs of k-step s
+template <int TM, int TN>
+__device__ inline void bf16_three_taps(const unsigned char* A, const unsigned char* B, int po0, int po1, int po2,
+                                       int b_tap_stride, f32x16 (&acc)[TM][TN]) {
+    bf16x8 fa[2][TM], fb[2][TN];
+    auto fetch = [&](int s, int slot) {
+        const int tl = s >> 1, ks = s & 1;
+        const int po = tl == 0 ? po0 : (tl == 1 ? po1 : po2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *(const bf16x8*)(A + po + i * (2 * PW * RS) + ks * 32);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *(const bf16x8*)(B + tl * b_tap_stride + j * (32 * RS) + ks * 32);
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        if (s + 1 < 6) fetch(s + 1, (s + 1) & 1);
+#if !defined(UPS_NO_SETPRIO)
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
+#if !defined(UPS_NO_SETPRIO)
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+}
+
 template <> struct PMma<float> {
     template <int TM, int TN>
     __device__ static inline void tap(const unsigned char* a_lane, const unsigned char* b_lane, f32x16 (&acc)[TM][TN]) {
@@ -126,9 +157,19 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
     struct WSet { uint4 r0, r1, r2; } ws0, ws1;     // two weight stages in flight (prefetch distance 2)
 
     const int cha = (tid & 3) * EPC;            // 512 % 4 == 0: all three items of a thread share the chunk slot
+    // branch-free: always load (from the tensor base when masked) and select, so the number of loads in flight
+    // is static and the compiler can use counted vmcnt waits across the prefetch distance
     auto ld_a = [&](long long off, int koff) -> uint4 {
         uint4 v = zero4;
+#if !defined(UPS_ABLATE_GLOAD)
+#if !defined(UPS_BRANCHFREE_LOADS)
         if (off >= 0 && koff + cha < p.ci) v = *(const uint4*)(in + off + koff);
+#else
+        const bool ok = off >= 0 && koff + cha < p.ci;
+        const uint4 t = *(const uint4*)(in + (ok ? off + koff : 0));
+        v.x = ok ? t.x : 0u; v.y = ok ? t.y : 0u; v.z = ok ? t.z : 0u; v.w = ok ? t.w : 0u;
+#endif
+#endif
         return v;
     };
     auto load_patch = [&](int cc) {
@@ -152,22 +193,24 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
         if (pa2 != -2) *(uint4*)(A + ((tid + 1024) >> 2) * RS + (tid & 3) * 16) = act_u4(ra2);
     };
     // weights of tap-row g (taps 3g..3g+2), chunk cc: item -> (tap_local, row, ch)
-    auto ld_b = [&](int item, int g, int koff) -> uint4 {
+    // weights are stored blocked-K: [tap][k-chunk][row][BK] (conv_aux.hip) -> a tile is one contiguous range
+    auto ld_b = [&](int item, int g, int cc) -> uint4 {
         uint4 v = zero4;
         if (item < 3 * BN * 4) {
             const int tl = item / (BN * 4), rem = item - tl * (BN * 4);
             const int row = rem >> 2, ch = rem & 3;
-            const int c = nt * BN + row, k = koff + ch * EPC;
-            if (c < p.co && k < p.ci)
-                v = *(const uint4*)(w + ((long long)p_w(p.tap_wi, 3 * g + tl) * p.co + c) * p.ci + k);
+            const int c = nt * BN + row;
+#if !defined(UPS_ABLATE_GLOAD)
+            if (c < p.co)
+                v = *(const uint4*)(w + (((long long)p_w(p.tap_wi, 3 * g + tl) * kchunks + cc) * p.co + c) * BK + ch * EPC);
+#endif
         }
         return v;
     };
     auto load_w = [&](WSet& q, int g, int cc) {
-        const int koff = cc * BK;
-        q.r0 = ld_b(tid, g, koff);
-        if (NB > 1) q.r1 = ld_b(tid + 512, g, koff);
-        if (NB > 2) q.r2 = ld_b(tid + 1024, g, koff);
+        q.r0 = ld_b(tid, g, cc);
+        if (NB > 1) q.r1 = ld_b(tid + 512, g, cc);
+        if (NB > 2) q.r2 = ld_b(tid + 1024, g, cc);
     };
     auto store_w = [&](const WSet& q, unsigned char* B) {
         if (tid < 3 * BN * 4) *(uint4*)(B + (tid >> 2) * RS + (tid & 3) * 16) = q.r0;
@@ -207,17 +250,32 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
         }
         const unsigned char* A = Abuf + (cc & 1) * A_BYTES + a_lane_off;
         const unsigned char* B = Bbuf + (it & 1) * B_BYTES + b_lane_off;
+#if defined(UPS_NO_FRAGPF)
+        if constexpr (false) {
+#else
+        if constexpr (sizeof(T) == 2) {
+#endif
+            const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PW + (p_dx(p.tap_off, 3 * g) + 1)) * RS;
+            const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PW + (p_dx(p.tap_off, 3 * g + 1) + 1)) * RS;
+            const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PW + (p_dx(p.tap_off, 3 * g + 2) + 1)) * RS;
+            bf16_three_taps<TM, TN>(A, B, po0, po1, po2, BN * RS, acc);
+        } else {
 #pragma unroll
-        for (int tl = 0; tl < 3; ++tl) {
-            const int tp = 3 * g + tl;
-            const int po = ((p_dy(p.tap_off, tp) + 1) * PW + (p_dx(p.tap_off, tp) + 1)) * RS;
-            PMma<T>::template tap<TM, TN>(A + po, B + tl * BN * RS, acc);
+            for (int tl = 0; tl < 3; ++tl) {
+                const int tp = 3 * g + tl;
+                const int po = ((p_dy(p.tap_off, tp) + 1) * PW + (p_dx(p.tap_off, tp) + 1)) * RS;
+                PMma<T>::template tap<TM, TN>(A + po, B + tl * BN * RS, acc);
+            }
         }
+#if !defined(UPS_ABLATE_LSTORE)
         if (n1 < total) {
             store_w(st_set, Bbuf + (n1 & 1) * B_BYTES);
             if (n1 % 3 == 0) store_patch(Abuf + ((n1 / 3) & 1) * A_BYTES);
         }
+#endif
+#if !defined(UPS_ABLATE_BARRIER)
         __syncthreads();
+#endif
     };
     for (int it = 0; it < total; it += 2) {
         iter(it, ws0, ws1);

@@ -5,25 +5,33 @@
 
 namespace {
 
+// Blocked-K weight layout shared by every convolution kernel: [tap][k-chunk][row][64 bytes], so that the weight tile
+// of one (tap, k-chunk) -- rows x 64 B -- is one contiguous, fully coalesced range (whole cache lines, all L2 channels).
 template <typename T>
 __global__ void weight_prep_kernel(const float* __restrict__ src, int ntaps, int cin_v, int ci_log, int co,
                                    T* __restrict__ wf, int ci_pad, T* __restrict__ wd, int drows, int dk) {
-    const long long nf = wf ? (long long)ntaps * co * ci_pad : 0;
-    const long long nd = wd ? (long long)ntaps * drows * dk : 0;
+    constexpr int BK = 64 / (int)sizeof(T);
+    const int kcf = (ci_pad + BK - 1) / BK, kcd = (dk + BK - 1) / BK;
+    const long long nf = wf ? (long long)ntaps * kcf * co * BK : 0;
+    const long long nd = wd ? (long long)ntaps * kcd * drows * BK : 0;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd;
          idx += (long long)gridDim.x * blockDim.x) {
         if (idx < nf) {
-            const int k = (int)(idx % ci_pad);
-            const long long tc = idx / ci_pad;
-            const int c = (int)(tc % co), t = (int)(tc / co);
-            const float v = k < ci_log ? src[((long long)t * cin_v + k) * co + c] : 0.f;
+            const int kk = (int)(idx % BK);
+            long long t = idx / BK;
+            const int c = (int)(t % co); t /= co;
+            const int kc = (int)(t % kcf), tap = (int)(t / kcf);
+            const int k = kc * BK + kk;
+            const float v = k < ci_log ? src[((long long)tap * cin_v + k) * co + c] : 0.f;
             st_from_float<T>(wf + idx, v);
         } else {
             const long long j = idx - nf;
-            const int k = (int)(j % dk);
-            const long long tr = j / dk;
-            const int r = (int)(tr % drows), t = (int)(tr / drows);
-            const float v = (k < co && r < ci_log) ? src[((long long)t * cin_v + r) * co + k] : 0.f;
+            const int kk = (int)(j % BK);
+            long long t = j / BK;
+            const int r = (int)(t % drows); t /= drows;
+            const int kc = (int)(t % kcd), tap = (int)(t / kcd);
+            const int k = kc * BK + kk;
+            const float v = (k < co && r < ci_log) ? src[((long long)tap * cin_v + r) * co + k] : 0.f;
             st_from_float<T>(wd + j, v);
         }
     }
@@ -160,7 +168,9 @@ extern "C" int ups_weight_prep(const float* src, int32_t ntaps, int32_t cin_v, i
                                void* stream) {
     UPS_CHECK_ARG(src && (w_fwd || w_dgrad));
     UPS_CHECK_ARG(ci_log <= cin_v && (!w_fwd || ci_pad >= ci_log) && (!w_dgrad || dgrad_k >= co));
-    const long long total = (w_fwd ? (long long)ntaps * co * ci_pad : 0) + (w_dgrad ? (long long)ntaps * dgrad_rows * dgrad_k : 0);
+    const int bk = dtype == UPS_F32 ? 16 : 32;
+    const long long total = (w_fwd ? (long long)ntaps * ups_cdiv(ci_pad, bk) * bk * co : 0) +
+                            (w_dgrad ? (long long)ntaps * ups_cdiv(dgrad_k, bk) * bk * dgrad_rows : 0);
     int grid = ups_cdiv(total, 256);
     if (grid > 8192) grid = 8192;
     hipStream_t s = (hipStream_t)stream;

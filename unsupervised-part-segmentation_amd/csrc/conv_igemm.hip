@@ -145,9 +145,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
         if (ok) v = *(const uint4*)(in + ((ib + (long long)y * p.wi + x) * p.ldi + koff));
         return v;
     };
-    auto load_b = [&](const T* wt, int c, int koff, bool kok) -> uint4 {
+    // weights are stored blocked-K: [tap][k-chunk][row][BK] (conv_aux.hip) -> a tile is one contiguous range
+    auto load_b = [&](const T* wt, int c) -> uint4 {
         uint4 v = zero4;
-        if (b_thread && kok && c < p.co) v = *(const uint4*)(wt + (long long)c * p.ci + koff);
+        if (b_thread && c < p.co) v = *(const uint4*)(wt + (long long)c * BK + chunk * EPC);
         return v;
     };
     auto load_chunk = [&](RSet& q, int c) {
@@ -157,9 +158,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
         const int dy = tap_dy_of(p.tap_off, t), dx = tap_dx_of(p.tap_off, t);
         q.a0 = load_a(rv0, iy00, ix00, ib0, dy, dx, koff, kok);
         q.a1 = load_a(rv1, iy01, ix01, ib1, dy, dx, koff, kok);
-        const T* wt = w + (long long)tap_w_of(p.tap_wi, t) * p.co * p.ci;
-        q.b0 = load_b(wt, nt * BN + r0, koff, kok);
-        if (BROWS > 1) q.b1 = load_b(wt, nt * BN + r0 + 64, koff, kok);
+        const T* wt = w + ((long long)tap_w_of(p.tap_wi, t) * kchunks + kc) * p.co * BK;
+        q.b0 = load_b(wt, nt * BN + r0);
+        if (BROWS > 1) q.b1 = load_b(wt, nt * BN + r0 + 64);
     };
     auto act_u4 = [&](uint4 u) -> uint4 {
         if (p.act_in != UPS_ACT_NONE) {

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libupsparts_hip.so")
+LIB_PATH = os.environ.get("UPS_LIB", os.path.join(_HERE, "csrc", "libupsparts_hip.so"))   # UPS_LIB: A/B builds
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2

@@ -84,10 +84,11 @@ class ConvLayer(object):
         if ent["w_fwd"] is None or (need_dgrad and ent["w_dgrad"] is None):
             do_f = ent["w_fwd"] is None
             do_d = need_dgrad and ent["w_dgrad"] is None
+            bk = 16 if dtype_code == L.F32 else 32      # blocked-K layout [tap][k-chunk][row][64 B]
             if do_f:
-                ent["w_fwd"] = torch.empty((ntaps, self.co, ci_pad), dtype=td, device=dev)
+                ent["w_fwd"] = torch.empty((ntaps, -(-ci_pad // bk), self.co, bk), dtype=td, device=dev)
             if do_d:
-                ent["w_dgrad"] = torch.empty((ntaps, self.ci_log, round8(self.co)), dtype=td, device=dev)
+                ent["w_dgrad"] = torch.empty((ntaps, -(-round8(self.co) // bk), self.ci_log, bk), dtype=td, device=dev)
             L.call("ups_weight_prep", L.ptr(self.V), ntaps, self.cin_v, self.ci_log, self.co, dtype_code,
                    L.ptr(ent["w_fwd"]) if do_f else None, ci_pad,
                    L.ptr(ent["w_dgrad"]) if do_d else None, self.ci_log, round8(self.co), L.stream())
