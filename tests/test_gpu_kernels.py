@@ -55,6 +55,16 @@ CONV_CASES = [
     (1, 32, 32, 8, 3, 3, 1, False, "relu", False),
     (2, 9, 7, 8, 8, 3, 2, True, None, False),       # odd sizes: pad_before = 1 for stride 2
     (1, 40, 40, 256, 256, 3, 1, True, "leaky_relu", True),
+    # patch-tiled kernels (3x3 / stride 1 / 16-aligned): every tile-width variant, several tiles per image (image
+    # borders inside and between tiles), ragged channel counts, CoordConv + residual epilogues
+    (3, 32, 48, 64, 136, 3, 1, True, "leaky_relu", False),     # fwd BN=128 x2 N-tiles; wgrad3x3 <64,128>
+    (2, 32, 32, 128, 128, 3, 1, True, "leaky_relu", True),     # residual block, staged epilogue
+    (2, 48, 32, 72, 64, 3, 1, False, "relu", False),           # BN=64; wgrad3x3 <64,64>
+    (5, 16, 32, 24, 40, 3, 1, True, None, False),              # wgrad3x3 <32,64>
+    (2, 32, 32, 32, 96, 3, 1, False, "leaky_relu", False),     # wgrad3x3 <32,128>
+    (2, 32, 16, 80, 16, 3, 1, False, None, False),             # wgrad3x3 <64,32>
+    (2, 64, 64, 8, 32, 3, 1, False, None, False),              # first encoder conv (image input), <32,32>
+    (8, 64, 64, 32, 32, 3, 1, False, "leaky_relu", True),      # thin res-block, many tiles (XCD remap path)
 ]
 
 

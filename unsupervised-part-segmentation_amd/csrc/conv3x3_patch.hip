@@ -66,18 +66,14 @@ __device__ inline void bf16_three_taps(const unsigned char* A, const unsigned ch
     fetch(0, 0);
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
-        if (s + 1 < 6) fetch(s + 1, (s + 1) & 1);
-#if !defined(UPS_NO_SETPRIO)
+        if (s + 1 < 6) fetch(s + 1, (s + 1) & 1);     // (a third slot / distance 2 measured slower: +3 %)
         __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
-#if !defined(UPS_NO_SETPRIO)
         __builtin_amdgcn_s_setprio(0);
-#endif
     }
 }
 
@@ -318,6 +314,13 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
                 const bool cvalid = col < p.co;
                 if (col >= p.co_fill) continue;
                 const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
+                // CoordConv affine term: interior pixels (all nine taps valid, class 63) use three per-column
+                // constants held in registers; only image-border pixels look the table up
+                float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+                if (cvalid && p.coord_tab) {
+                    const float* tb = p.coord_tab + (long long)63 * 3 * p.co + col;
+                    t0 = tb[0]; t1 = tb[p.co]; t2 = tb[2 * p.co];
+                }
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -331,8 +334,11 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
                                 const int y = ty0 + (px >> 4), x = tx0 + (px & 15);
                                 const int ym = (y > 0 ? 1 : 0) | 2 | (y + 1 < p.h ? 4 : 0);
                                 const int xm = (x > 0 ? 1 : 0) | 2 | (x + 1 < p.w ? 4 : 0);
-                                const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
-                                v += tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co];
+                                if ((ym & xm) == 7) v += t0 + (float)x * t1 + (float)y * t2;
+                                else {
+                                    const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
+                                    v += tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co];
+                                }
                             }
                             if (dact) v *= ups_dact((float)*(const bf16*)(R1 + px * ERS + cl * 2), p.dact_kind, p.act_slope);
                             if (res) v += (float)*(const bf16*)(R0 + px * ERS + cl * 2);
