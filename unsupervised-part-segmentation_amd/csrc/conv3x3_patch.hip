@@ -50,23 +50,27 @@ template <> struct PMma<bf16> {
         }
     }
 };
-// three taps (6 k-steps of 16) with the fragments of k-step s+1 fetched from LDS before the MFMAs of k-step s
+// three taps (6 k-steps of 16) with the fragments of k-step s+1 fetched from LDS before the MFMAs of k-step s.
+// B addressing: B + tl*b_tap_stride + j*b_blk_stride + (ks ? boff1 : boff0)  (covers the padded register-staged
+// layout and the XOR-swizzled LDS-DMA layout)
 template <int TM, int TN>
-__device__ inline void bf16_three_taps(const unsigned char* A, const unsigned char* B, int po0, int po1, int po2,
-                                       int b_tap_stride, f32x16 (&acc)[TM][TN]) {
+__device__ __forceinline__ void bf16_three_taps(const unsigned char* A, const unsigned char* B, int po0, int po1, int po2,
+                                                int b_tap_stride, int b_blk_stride, int boff0, int boff1,
+                                                f32x16 (&acc)[TM][TN]) {
     bf16x8 fa[2][TM], fb[2][TN];
-    auto fetch = [&](int s, int slot) {
+    auto fetch = [&](int s, int slot) __attribute__((always_inline)) {
         const int tl = s >> 1, ks = s & 1;
         const int po = tl == 0 ? po0 : (tl == 1 ? po1 : po2);
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[slot][i] = *(const bf16x8*)(A + po + i * (2 * PW * RS) + ks * 32);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[slot][j] = *(const bf16x8*)(B + tl * b_tap_stride + j * (32 * RS) + ks * 32);
+        for (int j = 0; j < TN; ++j)
+            fb[slot][j] = *(const bf16x8*)(B + tl * b_tap_stride + j * b_blk_stride + (ks ? boff1 : boff0));
     };
     fetch(0, 0);
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
-        if (s + 1 < 6) fetch(s + 1, (s + 1) & 1);     // (a third slot / distance 2 measured slower: +3 %)
+        if (s + 1 < 6) fetch(s + 1, (s + 1) & 1);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
 #endif
         return v;
     };
-    auto load_patch = [&](int cc) {
+    auto load_patch = [&](int cc) __attribute__((always_inline)) {
         const int koff = cc * BK;
         ra0 = ld_a(pa0, koff); ra1 = ld_a(pa1, koff);
         if (pa2 != -2) ra2 = ld_a(pa2, koff);
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
         }
         return u;
     };
-    auto store_patch = [&](unsigned char* A) {
+    auto store_patch = [&](unsigned char* A) __attribute__((always_inline)) {
         *(uint4*)(A + (tid >> 2) * RS + (tid & 3) * 16) = act_u4(ra0);
         *(uint4*)(A + ((tid + 512) >> 2) * RS + (tid & 3) * 16) = act_u4(ra1);
         if (pa2 != -2) *(uint4*)(A + ((tid + 1024) >> 2) * RS + (tid & 3) * 16) = act_u4(ra2);
@@ -228,15 +232,86 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
     const int a_lane_off = (ty_l * PW + tx_l) * RS + hh * HALF_OFF;        // patch origin is (-1,-1): tap (dy,dx) adds (dy+1, dx+1)
     const int b_lane_off = (wn * TN * 32 + r) * RS + hh * HALF_OFF;
 
-    // Software pipeline, prefetch distance 2: the global loads of tap-row it+2 are issued before the MFMAs of
-    // tap-row it and written to LDS after the MFMAs of tap-row it+1 (their buffer was last read by tap-row it),
-    // so every load has two compute phases to land; one barrier per tap-row.
     const int total = 3 * kchunks;
+    if constexpr (sizeof(T) == 2) {
+        // ===== bf16: weights by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write), three stages, counted vmcnt.
+        // A stage is [3 taps x BN rows][64 B] unpadded (the DMA writes 64 lanes x 16 B contiguously); bank conflicts of
+        // the ds_read_b128 fragment reads are removed by an XOR swizzle applied on the SOURCE side: LDS slot
+        // (row, s) holds chunk s ^ ((row >> 2) & 3).  The DMA of tap-row it+2 is issued before the MFMAs of tap-row it
+        // and only waited for (s_waitcnt vmcnt(NW), raw s_barrier) at the end of tap-row it+1.
+        constexpr int BST = 3 * BN * 64;                 // bytes per weight stage
+        constexpr int NJ = 3 * BN * 4 / 64;              // DMA wave-instructions per stage: 24 / 12 / 6
+        constexpr int NW = (NJ + 7) / 8;                 // per wave: 3 / 2 / 1
+        unsigned char* Bst = smem + 2 * A_BYTES;         // 3 x BST
+        const int swz = (r >> 2) & 3;
+        const int boff0 = r * 64 + ((hh ^ swz) << 4), boff1 = r * 64 + (((2 + hh) ^ swz) << 4);
+        // per-lane source decode of this wave's DMA instructions (loop invariant)
+        int d_tl[NW];
+        long long d_off[NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int j = (wid + 8 * q) % NJ;
+            const int pos = j * 64 + lane, row = pos >> 2, slot = pos & 3;
+            const int tl = row / BN, rl = row - tl * BN;
+            const int c = min(nt * BN + rl, p.co - 1);   // rows past co: duplicate a valid row (masked in the epilogue)
+            d_tl[q] = tl;
+            d_off[q] = (long long)c * BK + (slot ^ ((row >> 2) & 3)) * 8;
+        }
+        auto dma_w = [&](int it) __attribute__((always_inline)) {
+            const int cc = it / 3, g = it - cc * 3;
+            unsigned char* stg = Bst + (it % 3) * BST;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                const int j = (wid + 8 * q) % NJ;
+                const T* src = w + ((long long)p_w(p.tap_wi, 3 * g + d_tl[q]) * kchunks + cc) * p.co * BK + d_off[q];
+#if !defined(UPS_ABLATE_DMA)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(stg + j * 1024), 16, 0, 0);
+#endif
+            }
+        };
+        load_patch(0);
+        store_patch(Abuf);
+        dma_w(0);
+        if (total > 1) dma_w(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int it = 0; it < total; ++it) {
+            const int cc = it / 3, g = it - cc * 3;
+            const int n2 = it + 2, n1 = it + 1;
+            if (n2 < total) {
+                if (n2 % 3 == 0) load_patch(n2 / 3);     // register loads first: they stay OLDER than this tap-row's DMAs
+                dma_w(n2);
+            }
+            const unsigned char* A = Abuf + (cc & 1) * A_BYTES + a_lane_off;
+            const unsigned char* B = Bst + (it % 3) * BST + (wn * TN * 32) * 64;
+            const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PW + (p_dx(p.tap_off, 3 * g) + 1)) * RS;
+            const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PW + (p_dx(p.tap_off, 3 * g + 1) + 1)) * RS;
+            const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PW + (p_dx(p.tap_off, 3 * g + 2) + 1)) * RS;
+            bf16_three_taps<TM, TN>(A, B, po0, po1, po2, BN * 64, 32 * 64, boff0, boff1, acc);
+#if !defined(UPS_ABLATE_LSTORE)
+            // (the activation patch goes through registers for the fused activation / zero padding; hipcc waits
+            // vmcnt(0) for it, which also drains the DMAs once per channel chunk -- measured cost ~0.2 ms of 3.2 ms)
+            if (n1 < total && n1 % 3 == 0) store_patch(Abuf + ((n1 / 3) & 1) * A_BYTES);
+#endif
+            // the weights of tap-row it+1 must have landed; the NW DMAs of tap-row it+2 may stay in flight
+            if (n2 < total) {
+                if (NW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (NW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+    // ===== fp32 (parity mode): register-staged weights, prefetch distance 2, one barrier per tap-row
     load_patch(0); load_w(ws0, 0, 0);
     store_patch(Abuf); store_w(ws0, Bbuf);
     if (total > 1) load_w(ws1, 1, 0);
     __syncthreads();
-    auto iter = [&](int it, WSet& ld_set, const WSet& st_set) {
+    auto iter = [&](int it, WSet& ld_set, const WSet& st_set) __attribute__((always_inline)) {
         const int cc = it / 3, g = it - cc * 3;
         const int n2 = it + 2, n1 = it + 1;
         if (n2 < total) {
@@ -246,36 +321,22 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
         }
         const unsigned char* A = Abuf + (cc & 1) * A_BYTES + a_lane_off;
         const unsigned char* B = Bbuf + (it & 1) * B_BYTES + b_lane_off;
-#if defined(UPS_NO_FRAGPF)
-        if constexpr (false) {
-#else
-        if constexpr (sizeof(T) == 2) {
-#endif
-            const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PW + (p_dx(p.tap_off, 3 * g) + 1)) * RS;
-            const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PW + (p_dx(p.tap_off, 3 * g + 1) + 1)) * RS;
-            const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PW + (p_dx(p.tap_off, 3 * g + 2) + 1)) * RS;
-            bf16_three_taps<TM, TN>(A, B, po0, po1, po2, BN * RS, acc);
-        } else {
 #pragma unroll
-            for (int tl = 0; tl < 3; ++tl) {
-                const int tp = 3 * g + tl;
-                const int po = ((p_dy(p.tap_off, tp) + 1) * PW + (p_dx(p.tap_off, tp) + 1)) * RS;
-                PMma<T>::template tap<TM, TN>(A + po, B + tl * BN * RS, acc);
-            }
+        for (int tl = 0; tl < 3; ++tl) {
+            const int tp = 3 * g + tl;
+            const int po = ((p_dy(p.tap_off, tp) + 1) * PW + (p_dx(p.tap_off, tp) + 1)) * RS;
+            PMma<T>::template tap<TM, TN>(A + po, B + tl * BN * RS, acc);
         }
-#if !defined(UPS_ABLATE_LSTORE)
         if (n1 < total) {
             store_w(st_set, Bbuf + (n1 & 1) * B_BYTES);
             if (n1 % 3 == 0) store_patch(Abuf + ((n1 / 3) & 1) * A_BYTES);
         }
-#endif
-#if !defined(UPS_ABLATE_BARRIER)
         __syncthreads();
-#endif
     };
     for (int it = 0; it < total; it += 2) {
         iter(it, ws0, ws1);
         if (it + 1 < total) iter(it + 1, ws1, ws0);
+    }
     }
 
     // ---- epilogue
@@ -397,7 +458,7 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     const int ntn = ups_cdiv(k.co_fill, BN);
     const int kchunks = ups_cdiv(k.ci, 4 * EPC);
     const int nblocks = k.n * tiles_x * tiles_y * ntn;
-    size_t shmem = 2 * A_BYTES + 2 * 3 * BN * RS;
+    size_t shmem = sizeof(T) == 2 ? 2 * A_BYTES + 3 * (size_t)(3 * BN * 64) : 2 * A_BYTES + 2 * 3 * BN * RS;
     const size_t epi = sizeof(T) == 2 ? 2 * 256 * (size_t)(BN * 2 + 16) : 0;   // staged bf16 epilogue (2 tiles)
     if (epi > shmem) shmem = epi;
     static bool attr_set = false;
