@@ -89,7 +89,9 @@ struct ConvK {
     const float* bias; const float* coord_tab; const void* res; const void* dact;
 };
 
-template <typename T, int BN>
+// CPS = K-chunks per pipeline stage: skinny problems (few blocks, long K loops) are bound by one exposed memory
+// latency per barrier, so they stage 2-4 chunks per barrier.
+template <typename T, int BN, int CPS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const int M, const int ntn,
                                                          const int kchunks) {
     constexpr int EPC = Chunk<T>::N;
@@ -100,8 +102,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = (BN + 63) / 64;  // B rows staged per thread (BN=32: only threads < 128)
 
-    constexpr int STAGE = (BM + BN) * RS;       // one LDS stage: A tile + B tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + BM * 8 + BM * 12];
+    constexpr int SUB = (BM + BN) * RS;         // one chunk: A tile + B tile
+    constexpr int STAGE = CPS * SUB;            // one LDS stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE + BM * 20
     long long* rowpix = (long long*)(smem + 2 * STAGE);
     int* rowaux = (int*)(rowpix + BM);  // [BM][3] = cls, j, i
 
@@ -131,14 +134,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
     }
     const bool b_thread = (BN >= 64) || (tid < 128);
 
-    // NOTE: named registers / plain structs, not arrays: uint4 arrays captured by the lambdas are demoted to scratch.
-    struct RSet { uint4 a0, a1, b0, b1; } s0, s1;     // two chunks in flight (prefetch distance 2)
+    // two stages in flight (prefetch distance 2); every lambda is force-inlined and every index static after
+    // unrolling, so the register arrays stay in VGPRs
+    struct RSet { uint4 a0[CPS], a1[CPS], b0[CPS], b1[CPS]; } s0, s1;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     const int iy00 = iy0[0], iy01 = iy0[1], ix00 = ix0[0], ix01 = ix0[1];
     const long long ib0 = ibase[0], ib1 = ibase[1];
     const bool rv0 = rv[0], rv1 = rv[1];
+    const int total = p.ntaps * kchunks;
 
-    auto load_a = [&](bool rvq, int iy, int ix, long long ib, int dy, int dx, int koff, bool kok) -> uint4 {
+    auto load_a = [&](bool rvq, int iy, int ix, long long ib, int dy, int dx, int koff, bool kok) __attribute__((always_inline)) -> uint4 {
         const int y = iy + dy, x = ix + dx;
         const bool ok = rvq && kok && (unsigned)y < (unsigned)p.hi && (unsigned)x < (unsigned)p.wi;
         uint4 v = zero4;
@@ -146,23 +151,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
         return v;
     };
     // weights are stored blocked-K: [tap][k-chunk][row][BK] (conv_aux.hip) -> a tile is one contiguous range
-    auto load_b = [&](const T* wt, int c) -> uint4 {
+    auto load_b = [&](const T* wt, int c, bool live) __attribute__((always_inline)) -> uint4 {
         uint4 v = zero4;
-        if (b_thread && c < p.co) v = *(const uint4*)(wt + (long long)c * BK + chunk * EPC);
+        if (live && b_thread && c < p.co) v = *(const uint4*)(wt + (long long)c * BK + chunk * EPC);
         return v;
     };
-    auto load_chunk = [&](RSet& q, int c) {
-        const int t = c / kchunks, kc = c - t * kchunks;
-        const int koff = kc * BK + chunk * EPC;
-        const bool kok = koff < p.ci;
-        const int dy = tap_dy_of(p.tap_off, t), dx = tap_dx_of(p.tap_off, t);
-        q.a0 = load_a(rv0, iy00, ix00, ib0, dy, dx, koff, kok);
-        q.a1 = load_a(rv1, iy01, ix01, ib1, dy, dx, koff, kok);
-        const T* wt = w + ((long long)tap_w_of(p.tap_wi, t) * kchunks + kc) * p.co * BK;
-        q.b0 = load_b(wt, nt * BN + r0);
-        if (BROWS > 1) q.b1 = load_b(wt, nt * BN + r0 + 64);
+    auto load_stage = [&](RSet& q, int sidx) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < CPS; ++u) {
+            const int c = sidx * CPS + u;
+            const bool live = c < total;
+            const int cs = live ? c : 0;
+            const int t = cs / kchunks, kc = cs - t * kchunks;
+            const int koff = kc * BK + chunk * EPC;
+            const bool kok = live && koff < p.ci;
+            const int dy = tap_dy_of(p.tap_off, t), dx = tap_dx_of(p.tap_off, t);
+            q.a0[u] = load_a(rv0, iy00, ix00, ib0, dy, dx, koff, kok);
+            q.a1[u] = load_a(rv1, iy01, ix01, ib1, dy, dx, koff, kok);
+            const T* wt = w + ((long long)tap_w_of(p.tap_wi, t) * kchunks + kc) * p.co * BK;
+            q.b0[u] = load_b(wt, nt * BN + r0, live);
+            if (BROWS > 1) q.b1[u] = load_b(wt, nt * BN + r0 + 64, live);
+        }
     };
-    auto act_u4 = [&](uint4 u) -> uint4 {
+    auto act_u4 = [&](uint4 u) __attribute__((always_inline)) -> uint4 {
         if (p.act_in != UPS_ACT_NONE) {
             float f[EPC];
             Chunk<T>::unpack(u, f);
@@ -172,14 +183,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
         }
         return u;
     };
-    auto stage_chunk = [&](const RSet& q, unsigned char* st) {
-        unsigned char* As = st;
-        unsigned char* Bs = st + BM * RS;
-        *(uint4*)(As + r0 * RS + chunk * 16) = act_u4(q.a0);
-        *(uint4*)(As + (r0 + 64) * RS + chunk * 16) = act_u4(q.a1);
-        if (b_thread) {
-            *(uint4*)(Bs + r0 * RS + chunk * 16) = q.b0;
-            if (BROWS > 1) *(uint4*)(Bs + (r0 + 64) * RS + chunk * 16) = q.b1;
+    auto store_stage = [&](const RSet& q, unsigned char* st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < CPS; ++u) {
+            unsigned char* As = st + u * SUB;
+            unsigned char* Bs = As + BM * RS;
+            *(uint4*)(As + r0 * RS + chunk * 16) = act_u4(q.a0[u]);
+            *(uint4*)(As + (r0 + 64) * RS + chunk * 16) = act_u4(q.a1[u]);
+            if (b_thread) {
+                *(uint4*)(Bs + r0 * RS + chunk * 16) = q.b0[u];
+                if (BROWS > 1) *(uint4*)(Bs + (r0 + 64) * RS + chunk * 16) = q.b1[u];
+            }
         }
     };
 
@@ -191,23 +205,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // Software pipeline: double-buffered LDS, one barrier per chunk, prefetch distance 2 (the loads of chunk c+2 are
-    // issued before the MFMAs of chunk c and land in LDS after the MFMAs of chunk c+1).
-    const int total = p.ntaps * kchunks;
-    load_chunk(s0, 0);
-    stage_chunk(s0, smem);
-    if (total > 1) load_chunk(s1, 1);
+    // Software pipeline: double-buffered LDS, one barrier per stage, prefetch distance 2 (the loads of stage s+2 are
+    // issued before the MFMAs of stage s and land in LDS after the MFMAs of stage s+1).
+    const int nstages = (total + CPS - 1) / CPS;
+    load_stage(s0, 0);
+    store_stage(s0, smem);
+    if (nstages > 1) load_stage(s1, 1);
     __syncthreads();
-    auto iter = [&](int c, RSet& ld_set, const RSet& st_set) {
-        if (c + 2 < total) load_chunk(ld_set, c + 2);
-        const unsigned char* st = smem + (c & 1) * STAGE;
-        Mma<T>::template chunk<TM, TN>(st + (wm * TM * 32) * RS, st + BM * RS + (wn * TN * 32) * RS, lane, acc);
-        if (c + 1 < total) stage_chunk(st_set, smem + ((c + 1) & 1) * STAGE);
+    auto iter = [&](int sidx, RSet& ld_set, const RSet& st_set) __attribute__((always_inline)) {
+        if (sidx + 2 < nstages) load_stage(ld_set, sidx + 2);
+        const unsigned char* st = smem + (sidx & 1) * STAGE;
+#pragma unroll
+        for (int u = 0; u < CPS; ++u)
+            Mma<T>::template chunk<TM, TN>(st + u * SUB + (wm * TM * 32) * RS, st + u * SUB + BM * RS + (wn * TN * 32) * RS,
+                                           lane, acc);
+        if (sidx + 1 < nstages) store_stage(st_set, smem + ((sidx + 1) & 1) * STAGE);
         __syncthreads();
     };
-    for (int c = 0; c < total; c += 2) {
-        iter(c, s0, s1);
-        if (c + 1 < total) iter(c + 1, s1, s0);
+    for (int sidx = 0; sidx < nstages; sidx += 2) {
+        iter(sidx, s0, s1);
+        if (sidx + 1 < nstages) iter(sidx + 1, s1, s0);
     }
 
     // ---- epilogue: row table in LDS (pixel index, CoordConv class, j, i)
@@ -287,17 +304,33 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
     const int kchunks = ups_cdiv(d.ci, 4 * EPC);
     const int ctot = d.co_fill;
     const int mtiles = ups_cdiv(M, BM);
-    // tile width: 128 when the grid fills the chip, narrower tiles (more blocks) for skinny problems
+    // tile width: 128 when the grid fills the chip, narrower tiles (more blocks) for skinny problems; skinny problems
+    // with long K loops also stage several chunks per barrier (CPS)
     int bn = ctot > 64 ? 128 : (ctot > 32 ? 64 : 32);
     if (bn == 128 && mtiles * ups_cdiv(ctot, 128) < 256) bn = 64;
     if (bn == 64 && mtiles * ups_cdiv(ctot, 64) < 256) bn = 32;
     const int ntn = ups_cdiv(ctot, bn);
-    if (bn == 128)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3(mtiles * ntn), dim3(256), 0, s, d, (int)M, ntn, kchunks);
-    else if (bn == 64)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3(mtiles * ntn), dim3(256), 0, s, d, (int)M, ntn, kchunks);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 32>), dim3(mtiles * ntn), dim3(256), 0, s, d, (int)M, ntn, kchunks);
+    const bool skinny = mtiles * ntn < 1024 && d.ntaps * kchunks >= 8;
+    const int cps = !skinny ? 1 : (bn == 32 ? 4 : (bn == 64 ? 2 : 1));
+#define UPS_LAUNCH_IG(BNV, CPSV)                                                                                      \
+    do {                                                                                                              \
+        const size_t shmem = 2 * (size_t)(CPSV) * (BM + (BNV)) * RS + BM * 20;                                        \
+        static bool attr_done = false;                                                                                \
+        if (!attr_done) {                                                                                             \
+            if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BNV, CPSV>,                                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)           \
+                return UPS_E_LAUNCH;                                                                                  \
+            attr_done = true;                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BNV, CPSV>), dim3(mtiles * ntn), dim3(256), shmem, s, d, (int)M, ntn, \
+                           kchunks);                                                                                  \
+    } while (0)
+    if (bn == 128) UPS_LAUNCH_IG(128, 1);
+    else if (bn == 64 && cps == 2) UPS_LAUNCH_IG(64, 2);
+    else if (bn == 64) UPS_LAUNCH_IG(64, 1);
+    else if (cps == 4) UPS_LAUNCH_IG(32, 4);
+    else UPS_LAUNCH_IG(32, 1);
+#undef UPS_LAUNCH_IG
     return UPS_OK;
 }
 
