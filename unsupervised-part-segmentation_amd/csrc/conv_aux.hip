@@ -65,16 +65,31 @@ __global__ void coord_table_kernel(const float* __restrict__ V, int kh, int kw, 
     tab[((long long)cls * 3 + 2) * co + c] = ki;
 }
 
+// gsum[pix][c] = sum_n d[n][pix][c]: one thread per (pixel, 16-byte channel chunk), n independent 16-B loads in flight
 template <typename T>
 __global__ void batch_sum_kernel(const T* __restrict__ d, int n, long long pix, int co, int ldo, float* __restrict__ g) {
-    const long long total = pix * co;
+    constexpr int E = Chunk<T>::N;
+    const int cpr = (co + E - 1) / E;
+    const long long total = pix * cpr;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % co);
-        const long long px = idx / co;
-        float s = 0.f;
-        for (int b = 0; b < n; ++b) s += ld_as_float<T>(d + ((long long)b * pix + px) * ldo + c);
-        g[idx] = s;
+        const int k = (int)(idx % cpr);
+        const long long px = idx / cpr;
+        float acc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.f;
+        const T* base = d + px * ldo + k * E;
+#pragma unroll 4
+        for (int b = 0; b < n; ++b) {
+            float f[E];
+            const uint4 u = *(const uint4*)(base + (long long)b * pix * ldo);
+            Chunk<T>::unpack(u, f);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (k * E + e < co) g[px * co + k * E + e] = acc[e];
     }
 }
 
@@ -205,7 +220,8 @@ extern "C" int ups_coord_table(const float* V, int32_t kh, int32_t kw, int32_t c
 extern "C" int ups_batch_sum(const void* dout, int32_t dtype, int32_t n, int64_t pix, int32_t co, int32_t ldo, float* gsum,
                              void* stream) {
     UPS_CHECK_ARG(dout && gsum && n > 0 && pix > 0);
-    int grid = ups_cdiv(pix * co, 256);
+    UPS_CHECK_ARG(ldo % 8 == 0 && ((uintptr_t)dout & 15) == 0);
+    int grid = ups_cdiv(pix * ups_cdiv(co, dtype == UPS_F32 ? 4 : 8), 256);
     if (grid > 16384) grid = 16384;
     if (dtype == UPS_F32)
         hipLaunchKernelGGL(batch_sum_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dout, n,

@@ -263,7 +263,8 @@ int ups_wgrad3x3_plan(const ups_wgrad_desc* d, int* splitk, int* slabs) {
     const Variant v = pick(d);
     const int pairs = ups_cdiv(d->ci, v.cb) * ups_cdiv(d->co, v.bn);
     const int units = d->n * (d->hi / 16) * (d->wi / 16) * 2;
-    int sk = ups_cdiv(512, pairs);                 // ~2 blocks per CU in flight over the launch
+    // one block per CU for the big variant (151 KB of LDS per block): fewer, longer blocks halve the slab traffic
+    int sk = ups_cdiv((v.cb == 64 && v.bn == 128) ? 256 : 512, pairs);
     if (sk > units / 4) sk = units / 4 > 0 ? units / 4 : 1;
     if (sk > 256) sk = 256;
     *splitk = sk;
