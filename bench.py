@@ -98,6 +98,12 @@ def main():
         images = args.batch * world * args.steps
         value = images / dt
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        traffic = None
+        try:   # HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/), not measured live
+            with open(os.path.join(ROOT, "profiles", "round1_pmc_dv_rb128.json")) as f:
+                traffic = json.load(f)["traffic_bytes_per_launch"] * (args.batch / 64.0) if args.precision == "bf16" else None
+        except Exception:
+            traffic = None
         kms = ops.KernelTimer.mean_ms()
         ach = ops.KernelTimer.flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         out = {"metric": "images/sec training (CUB 128x128, 10 parts)", "value": round(value, 2), "unit": "images/sec",
@@ -112,7 +118,8 @@ def main():
                "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel<{},128> @ {}".format(
                                 "bf16" if args.precision == "bf16" else "f32", ops.KernelTimer.layer),
                             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                            "kernel_ms": round(kms, 4), "launches_timed": len(ops.KernelTimer.events), "traffic": None}}
+                            "kernel_ms": round(kms, 4), "launches_timed": len(ops.KernelTimer.events), "traffic": traffic,
+                            "flop_per_launch": ops.KernelTimer.flops}}
         if world == 1 and not args.no_cpu_baseline:
             def cfg_fn(b):
                 from oracle import configs as oc

@@ -279,7 +279,9 @@ class VggTrunk(object):
                 V = (torch.randn((3, 3, cin, wd), generator=_rng(seed, name), dtype=torch.float64) * std).float().to(device)
                 b = torch.zeros(wd, device=device)
                 first = bi == 0 and ci == 0
-                blk.append(ConvLayer(name, V, b, 3, 1, False, L.ACT_NONE if first else L.ACT_RELU))
+                lay = ConvLayer(name, V, b, 3, 1, False, L.ACT_NONE if first else L.ACT_RELU)
+                lay.frozen = True
+                blk.append(lay)
                 cin = wd
             self.layers.append(blk)
 
@@ -287,7 +289,7 @@ class VggTrunk(object):
         for blk in self.layers:
             for lay in blk:
                 lay.V.copy_(state[lay.name + "/V"]); lay.b.copy_(state[lay.name + "/b"])
-        ops.WeightVersion.value += 1
+                lay._cache.clear()
 
     def features(self, x_img, act_dtype):
         """x_img [n,H,W,>=3] in [-1,1] -> list of (pre-activation feature, logical channels, act for L1)."""

@@ -68,13 +68,14 @@ class ConvLayer(object):
         self.co = V.shape[3]
         self.grad_V = None          # optional preallocated views into a flat gradient buffer
         self.grad_b = None
+        self.frozen = False         # frozen weights (perceptual trunk): converted copies survive optimizer steps
         self._cache = {}
 
     # ---- converted weights (refreshed when the optimizer has stepped)
     def prepared(self, dtype_code, hi, wi, need_dgrad):
         key = (dtype_code, hi, wi)
         ent = self._cache.get(key)
-        if ent is None or ent["version"] != WeightVersion.value:
+        if ent is None or (ent["version"] != WeightVersion.value and not self.frozen):
             ent = {"version": WeightVersion.value, "w_fwd": None, "w_dgrad": None, "ctab": None}
             self._cache[key] = ent
         dev = self.V.device
