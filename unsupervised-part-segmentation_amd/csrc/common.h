@@ -65,6 +65,10 @@ __device__ inline float ups_act(float x, int act, float slope) {
     if (act == UPS_ACT_RELU) return x > 0.f ? x : 0.f;
     return x;
 }
+// branch-free activation for the staging paths: leaky-relu(slope) and relu (slope_eff = 0) share one formula
+__device__ inline float ups_act_ns(float x, float slope_eff) { return fmaf(slope_eff, fminf(x, 0.f), fmaxf(x, 0.f)); }
+__device__ inline float ups_slope_eff(int act, float slope) { return act == UPS_ACT_LRELU ? slope : 0.f; }
+
 __device__ inline float ups_dact(float x, int act, float slope) {
     if (act == UPS_ACT_LRELU) return x > 0.f ? 1.f : slope;
     if (act == UPS_ACT_RELU) return x > 0.f ? 1.f : 0.f;

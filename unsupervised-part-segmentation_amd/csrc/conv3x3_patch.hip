@@ -125,6 +125,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
     unsigned char* Bbuf = smem + 2 * A_BYTES;    // 2 x B_BYTES
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float act_ns = ups_slope_eff(p.act_in, p.act_slope);   // branch-free activation-on-load
+    const float dact_ns = ups_slope_eff(p.dact_kind, p.act_slope); // act'(x) = x > 0 ? 1 : dact_ns (only used when dact != NULL)
     // XCD-aware order: consecutive logical tiles (which share halos / the same patch for both N-tiles) stay on
     // one XCD's L2 (blocks are dealt round-robin over the 8 XCDs)
     int bid = blockIdx.x;
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
             float f[EPC];
             Chunk<T>::unpack(u, f);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] = ups_act(f[e], p.act_in, p.act_slope);
+            for (int e = 0; e < EPC; ++e) f[e] = ups_act_ns(f[e], act_ns);
             u = Chunk<T>::pack(f);
         }
         return u;
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
                                     v += tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co];
                                 }
                             }
-                            if (dact) v *= ups_dact((float)*(const bf16*)(R1 + px * ERS + cl * 2), p.dact_kind, p.act_slope);
+                            if (dact) v *= ((float)*(const bf16*)(R1 + px * ERS + cl * 2) > 0.f) ? 1.f : dact_ns;
                             if (res) v += (float)*(const bf16*)(R0 + px * ERS + cl * 2);
                         }
                         *(bf16*)(R0 + px * ERS + cl * 2) = (bf16)v;
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
                         const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
                         v += tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co];
                     }
-                    if (dact) v *= ups_dact(ld_as_float<T>(dact + pix * p.ldd + col), p.dact_kind, p.act_slope);
+                    if (dact) v *= (ld_as_float<T>(dact + pix * p.ldd + col) > 0.f) ? 1.f : dact_ns;
                     if (res) v += ld_as_float<T>(res + pix * p.ldr + col);
                 }
                 if (p.out_f32) outF[pix * p.ldo + col] = v;

@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
     int* rowaux = (int*)(rowpix + BM);  // [BM][3] = cls, j, i
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float act_ns = ups_slope_eff(p.act_in, p.act_slope);   // branch-free activation-on-load
+    const float dact_ns = ups_slope_eff(p.dact_kind, p.act_slope); // act'(x) = x > 0 ? 1 : dact_ns (only used when dact != NULL)
     const int nt = blockIdx.x % ntn, mt = blockIdx.x / ntn;
     const int wm = wid / WN, wn = wid % WN;
 
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
             float f[EPC];
             Chunk<T>::unpack(u, f);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] = ups_act(f[e], p.act_in, p.act_slope);
+            for (int e = 0; e < EPC; ++e) f[e] = ups_act_ns(f[e], act_ns);
             u = Chunk<T>::pack(f);
         }
         return u;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const in
                         const float* tb = p.coord_tab + (long long)rowaux[rl * 3] * 3 * p.co + col;
                         v += tb[0] + (float)rowaux[rl * 3 + 1] * tb[p.co] + (float)rowaux[rl * 3 + 2] * tb[2 * p.co];
                     }
-                    if (dact) v *= ups_dact(ld_as_float<T>(dact + pix * p.ldd + col), p.dact_kind, p.act_slope);
+                    if (dact) v *= (ld_as_float<T>(dact + pix * p.ldd + col) > 0.f) ? 1.f : dact_ns;
                     if (res) v += ld_as_float<T>(res + pix * p.ldr + col);
                 }
                 if (p.out_f32) outF[pix * p.ldo + col] = v;

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int 
     unsigned char* Ds = smem + PK * RSA;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float act_ns = ups_slope_eff(p.act_in, p.act_slope);   // branch-free activation-on-load
     const int cot_i = blockIdx.x % cot, cit_i = blockIdx.x / cot;
     const int split = blockIdx.y;
     const int wm = wid / WN, wn = wid % WN;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int 
             float f[EPC];
             Chunk<T>::unpack(u, f);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] = ups_act(f[e], p.act_in, p.act_slope);
+            for (int e = 0; e < EPC; ++e) f[e] = ups_act_ns(f[e], act_ns);
             u = Chunk<T>::pack(f);
         }
         return u;

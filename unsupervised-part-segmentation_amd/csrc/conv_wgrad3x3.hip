@@ -60,6 +60,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
     unsigned char* Dbuf = smem + 2 * XB;        // 2 x DB
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float act_ns = ups_slope_eff(p.act_in, p.act_slope);   // branch-free activation-on-load
     const int cot_i = blockIdx.x % cot, cit_i = blockIdx.x / cot;
     const int split = blockIdx.y;
     const int w_ci = wid % WCI, w_co = (wid / WCI) % WCO, w_k = wid / (WCI * WCO);
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
             float f[8];
             Chunk<bf16>::unpack(u, f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = ups_act(f[e], p.act_in, p.act_slope);
+            for (int e = 0; e < 8; ++e) f[e] = ups_act_ns(f[e], act_ns);
             u = Chunk<bf16>::pack(f);
         }
         return u;
