@@ -107,6 +107,23 @@ int ups_weight_prep(const float* src, int32_t ntaps, int32_t cin_v, int32_t ci_l
                     int32_t dtype, void* w_fwd, int32_t ci_pad,
                     void* w_dgrad, int32_t dgrad_rows, int32_t dgrad_k, void* stream);
 
+/* Batched form: one launch converts every convolution of a sub-network after its optimizer step (weights in both
+ * layouts + the CoordConv table).  `items` is a DEVICE array of n_items descriptors, `block_prefix` a DEVICE array of
+ * n_items+1 cumulative 256-thread block counts (ups_prep_item_blocks gives the per-item count). */
+typedef struct {
+    const float* src;         /* fp32 HWIO variable V [ntaps][cin_v][co] */
+    void*  w_fwd;             /* [ntaps][ceil(ci_pad/BK)][co][BK] or NULL */
+    void*  w_dgrad;           /* [ntaps][ceil(dgrad_k/BK)][dgrad_rows][BK] or NULL */
+    float* ctab;              /* [64][3][co] or NULL (no CoordConv) */
+    int32_t ntaps, cin_v, ci_log, co, ci_pad, dgrad_rows, dgrad_k;
+    int32_t kh, kw, in_sy, in_sx;
+    int32_t dy[3], dx[3];
+    float ax, ay;
+} ups_prep_item;
+int64_t ups_prep_item_blocks(const ups_prep_item* item_host, int32_t dtype);
+int ups_weight_prep_batch(const ups_prep_item* items, const int64_t* block_prefix, int32_t n_items, int64_t total_blocks,
+                          int32_t dtype, void* stream);
+
 /* CoordConv (N:2123-2154) folded into an affine epilogue: tab[cls][0..2][c] with
  * cls = ymask*8 + xmask (valid-tap bitmasks of the output pixel);
  * contribution = tab[cls][0][c] + j*tab[cls][1][c] + i*tab[cls][2][c].

@@ -71,13 +71,24 @@ __device__ __forceinline__ void bf16_three_taps(const unsigned char* A, const un
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         if (s + 1 < 6) fetch(s + 1, (s + 1) & 1);
+#if !defined(UPS_SCHED_INTERLEAVE)
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
+#if !defined(UPS_SCHED_INTERLEAVE)
         __builtin_amdgcn_s_setprio(0);
+#else
+        // one LDS fragment read of k-step s+1 behind each MFMA of k-step s
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#endif
     }
 }
 

@@ -37,6 +37,69 @@ __global__ void weight_prep_kernel(const float* __restrict__ src, int ntaps, int
     }
 }
 
+__host__ __device__ inline long long prep_elems(const ups_prep_item& it, int bk) {
+    const long long nf = it.w_fwd ? (long long)it.ntaps * ((it.ci_pad + bk - 1) / bk) * it.co * bk : 0;
+    const long long nd = it.w_dgrad ? (long long)it.ntaps * ((it.dgrad_k + bk - 1) / bk) * it.dgrad_rows * bk : 0;
+    const long long nc = it.ctab ? (long long)64 * it.co : 0;
+    return nf + nd + nc;
+}
+
+// one launch for all layers: block -> item by binary search in the block prefix
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const ups_prep_item* __restrict__ items,
+                                                                const long long* __restrict__ prefix, int n_items) {
+    constexpr int BK = 64 / (int)sizeof(T);
+    int lo = 0, hi = n_items - 1;
+    const long long b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (prefix[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    const ups_prep_item it = items[lo];
+    const long long idx = (b - prefix[lo]) * 256 + threadIdx.x;
+    const int kcf = (it.ci_pad + BK - 1) / BK, kcd = (it.dgrad_k + BK - 1) / BK;
+    const long long nf = it.w_fwd ? (long long)it.ntaps * kcf * it.co * BK : 0;
+    const long long nd = it.w_dgrad ? (long long)it.ntaps * kcd * it.dgrad_rows * BK : 0;
+    const long long nc = it.ctab ? (long long)64 * it.co : 0;
+    if (idx < nf) {
+        const int kk = (int)(idx % BK);
+        long long t = idx / BK;
+        const int c = (int)(t % it.co); t /= it.co;
+        const int kc = (int)(t % kcf), tap = (int)(t / kcf);
+        const int k = kc * BK + kk;
+        st_from_float<T>((T*)it.w_fwd + idx, k < it.ci_log ? it.src[((long long)tap * it.cin_v + k) * it.co + c] : 0.f);
+    } else if (idx < nf + nd) {
+        const long long j = idx - nf;
+        const int kk = (int)(j % BK);
+        long long t = j / BK;
+        const int r = (int)(t % it.dgrad_rows); t /= it.dgrad_rows;
+        const int kc = (int)(t % kcd), tap = (int)(t / kcd);
+        const int k = kc * BK + kk;
+        st_from_float<T>((T*)it.w_dgrad + j, (k < it.co && r < it.ci_log) ? it.src[((long long)tap * it.cin_v + r) * it.co + k] : 0.f);
+    } else if (idx < nf + nd + nc) {
+        const long long j = idx - nf - nd;
+        const int c = (int)(j % it.co), cls = (int)(j / it.co);
+        const int ym = cls >> 3, xm = cls & 7;
+        float k0 = 0.f, kj = 0.f, ki = 0.f;
+        for (int r = 0; r < it.kh; ++r) {
+            if (!((ym >> r) & 1)) continue;
+            for (int s = 0; s < it.kw; ++s) {
+                if (!((xm >> s) & 1)) continue;
+                const float vx = it.src[((long long)(r * it.kw + s) * it.cin_v + it.ci_log) * it.co + c];
+                const float vy = it.src[((long long)(r * it.kw + s) * it.cin_v + it.ci_log + 1) * it.co + c];
+                const int dys = r == 0 ? it.dy[0] : (r == 1 ? it.dy[1] : it.dy[2]);
+                const int dxs = s == 0 ? it.dx[0] : (s == 1 ? it.dx[1] : it.dx[2]);
+                k0 += (it.ax * (float)dxs - 1.f) * vx + (it.ay * (float)dys - 1.f) * vy;
+                kj += it.ax * (float)it.in_sx * vx;
+                ki += it.ay * (float)it.in_sy * vy;
+            }
+        }
+        it.ctab[((long long)cls * 3 + 0) * it.co + c] = k0;
+        it.ctab[((long long)cls * 3 + 1) * it.co + c] = kj;
+        it.ctab[((long long)cls * 3 + 2) * it.co + c] = ki;
+    }
+}
+
 struct Taps3 { int dy[3], dx[3]; };
 
 __global__ void coord_table_kernel(const float* __restrict__ V, int kh, int kw, int ci_log, int co, Taps3 tp, int in_sy,
@@ -195,6 +258,24 @@ extern "C" int ups_weight_prep(const float* src, int32_t ntaps, int32_t cin_v, i
     else
         hipLaunchKernelGGL(weight_prep_kernel<bf16>, dim3(grid), dim3(256), 0, s, src, ntaps, cin_v, ci_log, co,
                            (bf16*)w_fwd, ci_pad, (bf16*)w_dgrad, dgrad_rows, dgrad_k);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int64_t ups_prep_item_blocks(const ups_prep_item* item_host, int32_t dtype) {
+    if (!item_host) return -1;
+    return (prep_elems(*item_host, dtype == UPS_F32 ? 16 : 32) + 255) / 256;
+}
+
+extern "C" int ups_weight_prep_batch(const ups_prep_item* items, const int64_t* block_prefix, int32_t n_items,
+                                     int64_t total_blocks, int32_t dtype, void* stream) {
+    UPS_CHECK_ARG(items && block_prefix && n_items >= 1 && total_blocks >= 1 && total_blocks < 0x7fffffffLL);
+    if (dtype == UPS_F32)
+        hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                           items, (const long long*)block_prefix, n_items);
+    else
+        hipLaunchKernelGGL(weight_prep_batch_kernel<bf16>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                           items, (const long long*)block_prefix, n_items);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

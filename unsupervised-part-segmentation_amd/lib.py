@@ -54,6 +54,14 @@ class PriorDesc(C.Structure):
                 ("per_np", C.c_void_p), ("sums", C.c_void_p), ("g_hard", C.c_void_p), ("dl", C.c_void_p)]
 
 
+class PrepItem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p), ("ctab", C.c_void_p),
+                ("ntaps", C.c_int32), ("cin_v", C.c_int32), ("ci_log", C.c_int32), ("co", C.c_int32),
+                ("ci_pad", C.c_int32), ("dgrad_rows", C.c_int32), ("dgrad_k", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("in_sy", C.c_int32), ("in_sx", C.c_int32),
+                ("dy", C.c_int32 * 3), ("dx", C.c_int32 * 3), ("ax", C.c_float), ("ay", C.c_float)]
+
+
 _lib = None
 
 _I, _L, _F, _P, _Z = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -63,6 +71,8 @@ _SIGS = {
     "ups_conv_wgrad_plan": ([C.POINTER(WgradDesc), C.POINTER(_I), C.POINTER(_Z)], C.c_int),
     "ups_conv_wgrad": ([C.POINTER(WgradDesc), _P], C.c_int),
     "ups_weight_prep": ([_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P], C.c_int),
+    "ups_prep_item_blocks": ([C.POINTER(PrepItem), _I], C.c_int64),
+    "ups_weight_prep_batch": ([_P, _P, _I, _L, _I, _P], C.c_int),
     "ups_coord_table": ([_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _I, _I, _F, _F, _P, _P], C.c_int),
     "ups_batch_sum": ([_P, _I, _I, _L, _I, _I, _P, _P], C.c_int),
     "ups_coord_wgrad": ([_P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _I, _I, _F, _F, _I, _P, _P, _P, _P], C.c_int),

@@ -484,6 +484,7 @@ class Trainer(object):
             f = grp["flat"]
             ops.adam_step(f["p"], f["g"], f["m"], f["v"], lr_t, self.beta1, self.beta2, self.adam_eps, 1.0 / self.world_size)
         ops.WeightVersion.value += 1
+        self.model.nets.prep.refresh()          # one launch: every layer's converted weights + CoordConv tables
 
     # ------------------------------------------------------------------ edflow iterate(): log cadence of LoggingHook
     def fetch_logs(self):

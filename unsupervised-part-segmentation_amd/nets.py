@@ -108,6 +108,7 @@ class Scope(object):
         if lay is None:
             lay = ConvLayer(name, own.bank.params[name + "/V"], own.bank.params[name + "/b"], k, stride, self.coords, act_in)
             lay.grad_V, lay.grad_b = own.bank.grads[name + "/V"], own.bank.grads[name + "/b"]
+            lay.registry = own.prep
             own.layers[key] = lay
         return lay
 
@@ -222,6 +223,7 @@ class Nets(object):
     def __init__(self, config, device, seed=0):
         self.config = config
         self.dry, self.specs, self.layers, self.bank = True, OrderedDict(), {}, None
+        self.prep = ops.PrepRegistry()
         S = config["spatial_size"]
         Z, A, P = config.get("z0_size", 256), config.get("local_app_size", 64), config["n_parts"]
         img = Act(None, 1, S, S, 3)
@@ -289,7 +291,8 @@ class VggTrunk(object):
         for blk in self.layers:
             for lay in blk:
                 lay.V.copy_(state[lay.name + "/V"]); lay.b.copy_(state[lay.name + "/b"])
-                lay._cache.clear()
+                for ent in lay._cache.values():
+                    ent["version"] = -1
 
     def features(self, x_img, act_dtype):
         """x_img [n,H,W,>=3] in [-1,1] -> list of (pre-activation feature, logical channels, act for L1)."""

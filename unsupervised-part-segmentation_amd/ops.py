@@ -55,6 +55,58 @@ class WeightVersion(object):
     value = 0
 
 
+class PrepRegistry(object):
+    """Converted-weight buffers of the layers of a model, refreshed by ONE launch after the optimizer step
+    (ups_weight_prep_batch) instead of two small launches per layer and step."""
+
+    def __init__(self):
+        self.entries = []          # (layer, ent, dtype_code, hi, wi)
+        self.tables = {}           # dtype_code -> (items_dev, prefix_dev, n, total_blocks)
+        self.dirty = True
+
+    def register(self, layer, ent, dtype_code, hi, wi):
+        self.entries.append((layer, ent, dtype_code, hi, wi))
+        self.dirty = True
+
+    def _build(self):
+        self.tables = {}
+        lib = L.load()
+        for dcode in sorted(set(e[2] for e in self.entries)):
+            ents = [e for e in self.entries if e[2] == dcode]
+            arr = (L.PrepItem * len(ents))()
+            prefix = [0]
+            for i, (lay, ent, _, hi, wi) in enumerate(ents):
+                it = arr[i]
+                it.src, it.w_fwd, it.w_dgrad = lay.V.data_ptr(), ent["w_fwd"].data_ptr(), ent["w_dgrad"].data_ptr()
+                it.ctab = ent["ctab"].data_ptr() if lay.coords else None
+                it.ntaps, it.cin_v, it.ci_log, it.co = lay.k * lay.k, lay.cin_v, lay.ci_log, lay.co
+                it.ci_pad, it.dgrad_rows, it.dgrad_k = round8(lay.ci_log), lay.ci_log, round8(lay.co)
+                it.kh = it.kw = lay.k
+                it.in_sy = it.in_sx = lay.stride
+                dy, dx, _ = lay.fwd_taps(hi, wi)
+                for r in range(3):
+                    it.dy[r] = dy[r * lay.k] if r < lay.k else 0
+                    it.dx[r] = dx[r] if r < lay.k else 0
+                it.ax, it.ay = 2.0 / max(1, hi - 1), 2.0 / max(1, wi - 1)
+                prefix.append(prefix[-1] + lib.ups_prep_item_blocks(C.byref(it), dcode))
+            dev = ents[0][0].V.device
+            items_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            prefix_dev = torch.tensor(prefix, dtype=torch.int64, device=dev)
+            self.tables[dcode] = (items_dev, prefix_dev, len(ents), prefix[-1])
+        self.dirty = False
+
+    def refresh(self):
+        """Re-convert every registered layer from the current fp32 master weights."""
+        if not self.entries:
+            return
+        if self.dirty:
+            self._build()
+        for dcode, (items_dev, prefix_dev, n, total) in self.tables.items():
+            L.call("ups_weight_prep_batch", L.ptr(items_dev), L.ptr(prefix_dev), n, total, dcode, L.stream())
+        for (_lay, ent, _d, _h, _w) in self.entries:
+            ent["version"] = WeightVersion.value
+
+
 class ConvLayer(object):
     """One conv2d variable pair (V [kh,kw,Cin(+2),Cout] HWIO fp32, b [Cout]) + its launch geometry."""
 
@@ -69,37 +121,36 @@ class ConvLayer(object):
         self.grad_V = None          # optional preallocated views into a flat gradient buffer
         self.grad_b = None
         self.frozen = False         # frozen weights (perceptual trunk): converted copies survive optimizer steps
+        self.registry = None        # PrepRegistry of the owning model (batched refresh) or None (lazy per-layer prep)
         self._cache = {}
 
     # ---- converted weights (refreshed when the optimizer has stepped)
     def prepared(self, dtype_code, hi, wi, need_dgrad):
         key = (dtype_code, hi, wi)
         ent = self._cache.get(key)
-        if ent is None or (ent["version"] != WeightVersion.value and not self.frozen):
-            ent = {"version": WeightVersion.value, "w_fwd": None, "w_dgrad": None, "ctab": None}
-            self._cache[key] = ent
         dev = self.V.device
         td = L.torch_dtype(dtype_code)
         ntaps = self.k * self.k
         ci_pad = round8(self.ci_log)
-        if ent["w_fwd"] is None or (need_dgrad and ent["w_dgrad"] is None):
-            do_f = ent["w_fwd"] is None
-            do_d = need_dgrad and ent["w_dgrad"] is None
-            bk = 16 if dtype_code == L.F32 else 32      # blocked-K layout [tap][k-chunk][row][64 B]
-            if do_f:
-                ent["w_fwd"] = torch.empty((ntaps, -(-ci_pad // bk), self.co, bk), dtype=td, device=dev)
-            if do_d:
-                ent["w_dgrad"] = torch.empty((ntaps, -(-round8(self.co) // bk), self.ci_log, bk), dtype=td, device=dev)
+        bk = 16 if dtype_code == L.F32 else 32          # blocked-K layout [tap][k-chunk][row][64 B]
+        if ent is None:                                 # persistent buffers (pointers stay valid for the batched refresh)
+            ent = {"version": -1,
+                   "w_fwd": torch.empty((ntaps, -(-ci_pad // bk), self.co, bk), dtype=td, device=dev),
+                   "w_dgrad": torch.empty((ntaps, -(-round8(self.co) // bk), self.ci_log, bk), dtype=td, device=dev),
+                   "ctab": torch.empty((64, 3, self.co), dtype=torch.float32, device=dev) if self.coords else None}
+            self._cache[key] = ent
+            if self.registry is not None and not self.frozen:
+                self.registry.register(self, ent, dtype_code, hi, wi)
+        if ent["version"] != WeightVersion.value and not (self.frozen and ent["version"] >= 0):
             L.call("ups_weight_prep", L.ptr(self.V), ntaps, self.cin_v, self.ci_log, self.co, dtype_code,
-                   L.ptr(ent["w_fwd"]) if do_f else None, ci_pad,
-                   L.ptr(ent["w_dgrad"]) if do_d else None, self.ci_log, round8(self.co), L.stream())
-        if self.coords and ent["ctab"] is None:
-            ent["ctab"] = torch.empty((64, 3, self.co), dtype=torch.float32, device=dev)
-            dy, dx, _ = self.fwd_taps(hi, wi)
-            ax, ay = 2.0 / max(1, hi - 1), 2.0 / max(1, wi - 1)     # nn.py:2145-2148 (xx / (H-1), yy / (W-1))
-            L.call("ups_coord_table", L.ptr(self.V), self.k, self.k, self.ci_log, self.co,
-                   (C.c_int32 * 9)(*dy), (C.c_int32 * 9)(*dx), self.stride, self.stride, ax, ay,
-                   L.ptr(ent["ctab"]), L.stream())
+                   L.ptr(ent["w_fwd"]), ci_pad, L.ptr(ent["w_dgrad"]), self.ci_log, round8(self.co), L.stream())
+            if self.coords:
+                dy, dx, _ = self.fwd_taps(hi, wi)
+                ax, ay = 2.0 / max(1, hi - 1), 2.0 / max(1, wi - 1)     # nn.py:2145-2148 (xx / (H-1), yy / (W-1))
+                L.call("ups_coord_table", L.ptr(self.V), self.k, self.k, self.ci_log, self.co,
+                       (C.c_int32 * 9)(*dy), (C.c_int32 * 9)(*dx), self.stride, self.stride, ax, ay,
+                       L.ptr(ent["ctab"]), L.stream())
+            ent["version"] = WeightVersion.value
         return ent
 
     def out_hw(self, hi, wi):
