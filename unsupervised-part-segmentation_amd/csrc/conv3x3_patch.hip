@@ -255,7 +255,9 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
         constexpr int BST = 3 * BN * 64;                 // bytes per weight stage
         constexpr int NJ = 3 * BN * 4 / 64;              // DMA wave-instructions per stage: 24 / 12 / 6
         constexpr int NW = (NJ + 7) / 8;                 // per wave: 3 / 2 / 1
-        unsigned char* Bst = smem + 2 * A_BYTES;         // 3 x BST
+        // a single-chunk problem (ci <= 32) never touches the second patch buffer: the launcher then requests less LDS
+        // (2 blocks per CU instead of 1, which hides the per-block load latency of these 3-iteration blocks)
+        unsigned char* Bst = smem + (kchunks == 1 ? 1 : 2) * A_BYTES;   // 3 x BST
         const int swz = (r >> 2) & 3;
         const int boff0 = r * 64 + ((hh ^ swz) << 4), boff1 = r * 64 + (((2 + hh) ^ swz) << 4);
         // per-lane source decode of this wave's DMA instructions (loop invariant)
@@ -471,13 +473,15 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     const int ntn = ups_cdiv(k.co_fill, BN);
     const int kchunks = ups_cdiv(k.ci, 4 * EPC);
     const int nblocks = k.n * tiles_x * tiles_y * ntn;
-    size_t shmem = sizeof(T) == 2 ? 2 * A_BYTES + 3 * (size_t)(3 * BN * 64) : 2 * A_BYTES + 2 * 3 * BN * RS;
+    const int nabuf = (sizeof(T) == 2 && kchunks == 1) ? 1 : 2;
+    size_t shmem = sizeof(T) == 2 ? nabuf * A_BYTES + 3 * (size_t)(3 * BN * 64) : 2 * A_BYTES + 2 * 3 * BN * RS;
+    const size_t shmem_max = sizeof(T) == 2 ? 2 * A_BYTES + 3 * (size_t)(3 * BN * 64) : shmem;
     const size_t epi = sizeof(T) == 2 ? 2 * 256 * (size_t)(BN * 2 + 16) : 0;   // staged bf16 epilogue (2 tiles)
     if (epi > shmem) shmem = epi;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(epi > shmem_max ? epi : shmem_max));
         if (e != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
@@ -488,7 +492,8 @@ int launch_bn(const PatchK& k, hipStream_t s) {
 
 template <typename T>
 int launch_t(const PatchK& k, hipStream_t s) {
-    if (k.co_fill > 64) return launch_bn<T, 128>(k, s);
+    // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv): 64-wide tiles fit two blocks per CU
+    if (k.co_fill > 64 && !(sizeof(T) == 2 && k.ci <= 32)) return launch_bn<T, 128>(k, s);
     if (k.co_fill > 32) return launch_bn<T, 64>(k, s);
     return launch_bn<T, 32>(k, s);
 }
