@@ -16,8 +16,15 @@ namespace {
 constexpr int TS = 16;                 // tile side
 constexpr int PW = TS + 2;             // patch side
 constexpr int PPIX = PW * PW;          // 324 patch pixels
-constexpr int RS = 80;                 // LDS row stride (bytes)
-constexpr int A_BYTES = PPIX * RS;     // 25920
+constexpr int RS = 80;                 // LDS row stride of the register-staged fp32 weight tiles (bytes)
+// Activation patch in LDS: [18 rows][PWP = 20 pixels][64 B], unpadded.  A pixel's four 16-byte chunks are XOR-swizzled
+// with ((px >> 2) & 3): with a row pitch that is a multiple of 4 pixels this makes every ds_read_b128 fragment read
+// conflict-free for the REAL b128 lane groups ({0-3,12-15,20-27}, ...: 8 pixels of tile row y and 8 of row y+1), for
+// all nine tap shifts.  (The former 80-byte padded rows were 2-way conflicted on every A fragment read.)
+constexpr int PWP = 20;
+constexpr int APX = 64;                // bytes per patch pixel
+constexpr int A_BYTES = PW * PWP * APX;   // 23040
+__device__ __forceinline__ int a_swz(int px) { return (px >> 2) & 3; }
 
 struct PatchK {
     int n, h, w, ci, ldi, co, co_fill, ldo, ldr, ldd, act_in, out_f32, dact_kind, has_ctab;
@@ -32,37 +39,23 @@ __device__ inline int p_dx(unsigned long long off, int t) { return (int)((off >>
 __device__ inline int p_w(unsigned long long wi, int t) { return (int)((wi >> (4 * t)) & 15); }
 
 template <typename T> struct PMma;
-template <> struct PMma<bf16> {
-    template <int TM, int TN>
-    __device__ static inline void tap(const unsigned char* a_lane, const unsigned char* b_lane, f32x16 (&acc)[TM][TN]) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(a_lane + i * (2 * PW * RS) + ks * 32);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(b_lane + j * (32 * RS) + ks * 32);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    }
-};
 // three taps (6 k-steps of 16) with the fragments of k-step s+1 fetched from LDS before the MFMAs of k-step s.
 // B addressing: B + tl*b_tap_stride + j*b_blk_stride + (ks ? boff1 : boff0)  (covers the padded register-staged
 // layout and the XOR-swizzled LDS-DMA layout)
 template <int TM, int TN>
 __device__ __forceinline__ void bf16_three_taps(const unsigned char* A, const unsigned char* B, int po0, int po1, int po2,
+                                                int sw0, int sw1, int sw2,
                                                 int b_tap_stride, int b_blk_stride, int boff0, int boff1,
                                                 f32x16 (&acc)[TM][TN]) {
+    // A = per-lane patch base (tile pixel (ty_l, tx_l), chunk 0); po* = uniform tap shift in bytes; sw* = per-lane byte
+    // offset of chunk hh under the tap's swizzle (chunk 2 + hh is sw ^ 32)
     bf16x8 fa[2][TM], fb[2][TN];
     auto fetch = [&](int s, int slot) __attribute__((always_inline)) {
         const int tl = s >> 1, ks = s & 1;
         const int po = tl == 0 ? po0 : (tl == 1 ? po1 : po2);
+        const int sw = (tl == 0 ? sw0 : (tl == 1 ? sw1 : sw2)) ^ (ks << 5);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[slot][i] = *(const bf16x8*)(A + po + i * (2 * PW * RS) + ks * 32);
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *(const bf16x8*)(A + po + i * (2 * PWP * APX) + sw);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             fb[slot][j] = *(const bf16x8*)(B + tl * b_tap_stride + j * b_blk_stride + (ks ? boff1 : boff0));
@@ -94,13 +87,15 @@ __device__ __forceinline__ void bf16_three_taps(const unsigned char* A, const un
 
 template <> struct PMma<float> {
     template <int TM, int TN>
-    __device__ static inline void tap(const unsigned char* a_lane, const unsigned char* b_lane, f32x16 (&acc)[TM][TN]) {
-        // a_lane / b_lane already include the lane-half offset h*16 (bf16 convention); fp32 halves own 32 bytes
+    __device__ static inline void tap(const unsigned char* a_pix, int hh, int v, const unsigned char* b_lane, f32x16 (&acc)[TM][TN]) {
+        // a_pix = per-lane patch pixel base (chunk 0) shifted by the tap; lane half hh owns chunks 2hh, 2hh+1 (swizzled
+        // by v); b_lane already includes the lane-half offset hh*32
         f32x4 a[TM][2], b[TN][2];
+        const int c0 = ((2 * hh) ^ v) << 4, c1 = ((2 * hh + 1) ^ v) << 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            a[i][0] = *(const f32x4*)(a_lane + i * (2 * PW * RS));
-            a[i][1] = *(const f32x4*)(a_lane + i * (2 * PW * RS) + 16);
+            a[i][0] = *(const f32x4*)(a_pix + i * (2 * PWP * APX) + c0);
+            a[i][1] = *(const f32x4*)(a_pix + i * (2 * PWP * APX) + c1);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -165,6 +160,13 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
         };
         pa0 = mk(tid); pa1 = mk(tid + 512); pa2 = mk(tid + 1024);
     }
+    // LDS byte offsets of the three staged items (swizzled patch layout)
+    auto mk_sa = [&](int item) -> int {
+        const int pix = item >> 2, ch = item & 3;
+        const int py = pix / PW, px = pix - py * PW;
+        return (py * PWP + px) * APX + ((ch ^ a_swz(px)) << 4);
+    };
+    const int sa0 = mk_sa(tid), sa1 = mk_sa(tid + 512), sa2 = mk_sa(min(tid + 1024, PPIX * 4 - 1));
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     uint4 ra0, ra1, ra2;
     struct WSet { uint4 r0, r1, r2; } ws0, ws1;     // two weight stages in flight (prefetch distance 2)
@@ -201,9 +203,9 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
         return u;
     };
     auto store_patch = [&](unsigned char* A) __attribute__((always_inline)) {
-        *(uint4*)(A + (tid >> 2) * RS + (tid & 3) * 16) = act_u4(ra0);
-        *(uint4*)(A + ((tid + 512) >> 2) * RS + (tid & 3) * 16) = act_u4(ra1);
-        if (pa2 != -2) *(uint4*)(A + ((tid + 1024) >> 2) * RS + (tid & 3) * 16) = act_u4(ra2);
+        *(uint4*)(A + sa0) = act_u4(ra0);
+        *(uint4*)(A + sa1) = act_u4(ra1);
+        if (pa2 != -2) *(uint4*)(A + sa2) = act_u4(ra2);
     };
     // weights of tap-row g (taps 3g..3g+2), chunk cc: item -> (tap_local, row, ch)
     // weights are stored blocked-K: [tap][k-chunk][row][BK] (conv_aux.hip) -> a tile is one contiguous range
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
     // per-lane fragment bases: output row r of MFMA block tm -> tile pixel (ty, tx)
     const int r = lane & 31, hh = lane >> 5;
     const int ty_l = (wm * TM * 2) + (r >> 4), tx_l = r & 15;
-    const int a_lane_off = (ty_l * PW + tx_l) * RS + hh * HALF_OFF;        // patch origin is (-1,-1): tap (dy,dx) adds (dy+1, dx+1)
+    const int a_lane_off = (ty_l * PWP + tx_l) * APX;                      // patch origin is (-1,-1): tap (dy,dx) adds (dy+1, dx+1)
     const int b_lane_off = (wn * TN * 32 + r) * RS + hh * HALF_OFF;
 
     const int total = 3 * kchunks;
@@ -300,10 +302,12 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
             }
             const unsigned char* A = Abuf + (cc & 1) * A_BYTES + a_lane_off;
             const unsigned char* B = Bst + (it % 3) * BST + (wn * TN * 32) * 64;
-            const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PW + (p_dx(p.tap_off, 3 * g) + 1)) * RS;
-            const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PW + (p_dx(p.tap_off, 3 * g + 1) + 1)) * RS;
-            const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PW + (p_dx(p.tap_off, 3 * g + 2) + 1)) * RS;
-            bf16_three_taps<TM, TN>(A, B, po0, po1, po2, BN * 64, 32 * 64, boff0, boff1, acc);
+            const int dx0 = p_dx(p.tap_off, 3 * g) + 1, dx1 = p_dx(p.tap_off, 3 * g + 1) + 1, dx2 = p_dx(p.tap_off, 3 * g + 2) + 1;
+            const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWP + dx0) * APX;
+            const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWP + dx1) * APX;
+            const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWP + dx2) * APX;
+            bf16_three_taps<TM, TN>(A, B, po0, po1, po2, (hh ^ a_swz(tx_l + dx0)) << 4, (hh ^ a_swz(tx_l + dx1)) << 4,
+                                    (hh ^ a_swz(tx_l + dx2)) << 4, BN * 64, 32 * 64, boff0, boff1, acc);
 #if !defined(UPS_ABLATE_LSTORE)
             // (the activation patch goes through registers for the fused activation / zero padding; hipcc waits
             // vmcnt(0) for it, which also drains the DMAs once per channel chunk -- measured cost ~0.2 ms of 3.2 ms)
@@ -339,8 +343,9 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
 #pragma unroll
         for (int tl = 0; tl < 3; ++tl) {
             const int tp = 3 * g + tl;
-            const int po = ((p_dy(p.tap_off, tp) + 1) * PW + (p_dx(p.tap_off, tp) + 1)) * RS;
-            PMma<T>::template tap<TM, TN>(A + po, B + tl * BN * RS, acc);
+            const int dxp = p_dx(p.tap_off, tp) + 1;
+            const int po = ((p_dy(p.tap_off, tp) + 1) * PWP + dxp) * APX;
+            PMma<float>::template tap<TM, TN>(A + po, hh, a_swz(tx_l + dxp), B + tl * BN * RS, acc);
         }
         if (n1 < total) {
             store_w(st_set, Bbuf + (n1 & 1) * B_BYTES);
