@@ -9,6 +9,8 @@
 //     issue global loads (next tap-row [+ next patch]) -> 24 MFMAs per wave from LDS -> write LDS -> 1 barrier.
 // LDS pixel / weight rows are padded 64 -> 80 bytes (conflict-free ds_read_b128 for 16 consecutive pixels).
 // MFMA: v_mfma_f32_32x32x16_bf16 or exact-fp32 v_mfma_f32_32x32x2_f32.  Epilogue identical to conv_igemm.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -42,14 +44,17 @@ template <typename T> struct PMma;
 // three taps (6 k-steps of 16) with the fragments of k-step s+1 fetched from LDS before the MFMAs of k-step s.
 // B addressing: B + tl*b_tap_stride + j*b_blk_stride + (ks ? boff1 : boff0)  (covers the padded register-staged
 // layout and the XOR-swizzled LDS-DMA layout)
-template <int TM, int TN>
+// NBUF = 2: fragments of k-step s+1 fetched before the MFMAs of k-step s (two register sets);
+// NBUF = 1: one register set, the reads of k-step s+1 are issued right behind the MFMAs of k-step s (the operands are
+//           read at issue) -- 16 VGPRs less, for the two-blocks-per-CU configuration whose other waves cover the latency
+template <int TM, int TN, int NBUF>
 __device__ __forceinline__ void bf16_three_taps(const unsigned char* A, const unsigned char* B, int po0, int po1, int po2,
                                                 int sw0, int sw1, int sw2,
                                                 int b_tap_stride, int b_blk_stride, int boff0, int boff1,
                                                 f32x16 (&acc)[TM][TN]) {
     // A = per-lane patch base (tile pixel (ty_l, tx_l), chunk 0); po* = uniform tap shift in bytes; sw* = per-lane byte
     // offset of chunk hh under the tap's swizzle (chunk 2 + hh is sw ^ 32)
-    bf16x8 fa[2][TM], fb[2][TN];
+    bf16x8 fa[NBUF][TM], fb[NBUF][TN];
     auto fetch = [&](int s, int slot) __attribute__((always_inline)) {
         const int tl = s >> 1, ks = s & 1;
         const int po = tl == 0 ? po0 : (tl == 1 ? po1 : po2);
@@ -63,25 +68,15 @@ __device__ __forceinline__ void bf16_three_taps(const unsigned char* A, const un
     fetch(0, 0);
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
-        if (s + 1 < 6) fetch(s + 1, (s + 1) & 1);
-#if !defined(UPS_SCHED_INTERLEAVE)
+        if (NBUF == 2 && s + 1 < 6) fetch(s + 1, (s + 1) & 1);
         __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
-#if !defined(UPS_SCHED_INTERLEAVE)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % NBUF][i], fb[s % NBUF][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-#else
-        // one LDS fragment read of k-step s+1 behind each MFMA of k-step s
-#pragma unroll
-        for (int q = 0; q < TM * TN; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#endif
+        if (NBUF == 1 && s + 1 < 6) fetch(s + 1, 0);
     }
 }
 
@@ -113,9 +108,13 @@ template <> struct PMma<float> {
     }
 };
 
-template <typename T, int BN>
-__global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, const int tiles_x, const int tiles_y,
-                                                            const int ntn, const int kchunks, const int nblocks) {
+// OCC = 1: one block per CU (3-stage weight ring, double-buffered patch, <= 256 VGPRs);
+// OCC = 2 (bf16 only): two blocks per CU (2-stage ring, single patch buffer, activation-derivative tile staged as sign
+// bytes, <= 80 KB LDS and <= 128 VGPRs) -- the second block's MFMAs hide this block's prologue, patch re-staging and
+// epilogue, none of which overlap anything when a CU holds a single block.
+template <typename T, int BN, int OCC>
+__global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const PatchK p, const int tiles_x, const int tiles_y,
+                                                                 const int ntn, const int kchunks, const int nblocks) {
     constexpr int EPC = Chunk<T>::N;
     constexpr int BK = 4 * EPC;
     constexpr int WN = (BN == 32) ? 1 : 2;
@@ -130,7 +129,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
     unsigned char* Abuf = smem;                  // 2 x A_BYTES
     unsigned char* Bbuf = smem + 2 * A_BYTES;    // 2 x B_BYTES
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values derived from it live in SGPRs
     const float act_ns = ups_slope_eff(p.act_in, p.act_slope);   // branch-free activation-on-load
     const float dact_ns = ups_slope_eff(p.dact_kind, p.act_slope); // act'(x) = x > 0 ? 1 : dact_ns (only used when dact != NULL)
     // XCD-aware order: consecutive logical tiles (which share halos / the same patch for both N-tiles) stay on
@@ -148,15 +148,17 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
     const T* __restrict__ w = (const T*)p.wgt;
 
     // ---- patch staging: items tid, tid+512, tid+1024 of the 324x4 16-byte chunks
-    long long pa0 = -1, pa1 = -1, pa2 = -1;      // element offsets (without the channel-chunk offset), -1 = zero fill
+    // 32-bit BYTE offsets inside the image (an image is < 2 GB), -1 = zero fill; the loads use the uniform image base as
+    // scalar address + this vector offset (no 64-bit vector address arithmetic, 1 VGPR per item)
+    int pa0 = -1, pa1 = -1, pa2 = -1;
     {
-        auto mk = [&](int item) -> long long {
+        auto mk = [&](int item) -> int {
             if (item >= PPIX * 4) return -2;      // no item
             const int pix = item >> 2, ch = item & 3;
             const int py = pix / PW, px = pix - py * PW;
             const int y = ty0 - 1 + py, x = tx0 - 1 + px;
             if ((unsigned)y >= (unsigned)p.h || (unsigned)x >= (unsigned)p.w) return -1;
-            return ((long long)y * p.w + x) * p.ldi + ch * EPC;
+            return ((y * p.w + x) * p.ldi + ch * EPC) * (int)sizeof(T);
         };
         pa0 = mk(tid); pa1 = mk(tid + 512); pa2 = mk(tid + 1024);
     }
@@ -174,16 +176,14 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
     const int cha = (tid & 3) * EPC;            // 512 % 4 == 0: all three items of a thread share the chunk slot
     // branch-free: always load (from the tensor base when masked) and select, so the number of loads in flight
     // is static and the compiler can use counted vmcnt waits across the prefetch distance
-    auto ld_a = [&](long long off, int koff) -> uint4 {
+    auto ld_a = [&](int off, int koff) -> uint4 {
         uint4 v = zero4;
 #if !defined(UPS_ABLATE_GLOAD)
-#if !defined(UPS_BRANCHFREE_LOADS)
-        if (off >= 0 && koff + cha < p.ci) v = *(const uint4*)(in + off + koff);
-#else
-        const bool ok = off >= 0 && koff + cha < p.ci;
-        const uint4 t = *(const uint4*)(in + (ok ? off + koff : 0));
-        v.x = ok ? t.x : 0u; v.y = ok ? t.y : 0u; v.z = ok ? t.z : 0u; v.w = ok ? t.w : 0u;
-#endif
+        if (off >= 0 && koff + cha < p.ci) {
+            int o = off;
+            asm volatile("" : "+v"(o));     // keep the 32-bit offset: scalar base (image + chunk) + vector offset addressing
+            v = *(const uint4*)((const unsigned char*)(in + koff) + (unsigned)o);
+        }
 #endif
         return v;
     };
@@ -257,42 +257,83 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
         constexpr int BST = 3 * BN * 64;                 // bytes per weight stage
         constexpr int NJ = 3 * BN * 4 / 64;              // DMA wave-instructions per stage: 24 / 12 / 6
         constexpr int NW = (NJ + 7) / 8;                 // per wave: 3 / 2 / 1
+        constexpr int NST = (OCC == 2) ? 2 : 3;          // ring stages
+#if defined(UPS_OCC2_FRAG2)
+        constexpr int FRAG_BUFS = 2;
+#else
+        constexpr int FRAG_BUFS = (BN == 128) ? 1 : 2;   // 128-wide tiles at two blocks per CU: <= 128 VGPRs without spills
+#endif
         // a single-chunk problem (ci <= 32) never touches the second patch buffer: the launcher then requests less LDS
         // (2 blocks per CU instead of 1, which hides the per-block load latency of these 3-iteration blocks)
-        unsigned char* Bst = smem + (kchunks == 1 ? 1 : 2) * A_BYTES;   // 3 x BST
+        unsigned char* Bst = smem + ((kchunks == 1 || OCC == 2) ? 1 : 2) * A_BYTES;   // NST x BST
         const int swz = (r >> 2) & 3;
         const int boff0 = r * 64 + ((hh ^ swz) << 4), boff1 = r * 64 + (((2 + hh) ^ swz) << 4);
         // per-lane source decode of this wave's DMA instructions (loop invariant)
         int d_tl[NW];
-        long long d_off[NW];
+        unsigned d_off[NW];                              // byte offset of the lane's 16 bytes inside one (tap, k-chunk) slab
 #pragma unroll
         for (int q = 0; q < NW; ++q) {
             const int j = (wid + 8 * q) % NJ;
             const int pos = j * 64 + lane, row = pos >> 2, slot = pos & 3;
-            const int tl = row / BN, rl = row - tl * BN;
+            const int tl = (j * 16) / BN, rl = row - tl * BN;   // a wave-instruction's 16 rows lie in one tap (wave-uniform)
             const int c = min(nt * BN + rl, p.co - 1);   // rows past co: duplicate a valid row (masked in the epilogue)
             d_tl[q] = tl;
-            d_off[q] = (long long)c * BK + (slot ^ ((row >> 2) & 3)) * 8;
+            d_off[q] = (unsigned)(c * BK + (slot ^ ((row >> 2) & 3)) * 8) * 2u;
         }
+        const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
         auto dma_w = [&](int it) __attribute__((always_inline)) {
             const int cc = it / 3, g = it - cc * 3;
-            unsigned char* stg = Bst + (it % 3) * BST;
+            unsigned char* stg = Bst + (it % NST) * BST;
 #pragma unroll
             for (int q = 0; q < NW; ++q) {
                 const int j = (wid + 8 * q) % NJ;
-                const T* src = w + ((long long)p_w(p.tap_wi, 3 * g + d_tl[q]) * kchunks + cc) * p.co * BK + d_off[q];
+                // uniform slab base (scalar) + per-lane 32-bit offset
+                const T* slab = w + ((long long)p_w(p.tap_wi, 3 * g + d_tl[q]) * kchunks + cc) * p.co * BK;
 #if !defined(UPS_ABLATE_DMA)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(stg + j * 1024), 16, 0, 0);
+                // issued as inline asm: hipcc's wait-count pass treats the builtin as a FLAT access that may touch LDS
+                // and from then on waits lgkmcnt(0) before every fragment use (no counted waits); hidden from the pass,
+                // the fragment waits are counted.  The pass's own vmcnt(N) waits stay safe (extra younger operations
+                // only make them wait longer).
+                const unsigned lds_dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(stg + j * 1024 - smem));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                             :: "s"(lds_dst), "v"(d_off[q]), "s"(slab) : "memory", "m0");
 #endif
             }
         };
         load_patch(0);
         store_patch(Abuf);
         dma_w(0);
-        if (total > 1) dma_w(1);
+        if (OCC != 2 && total > 1) dma_w(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (OCC == 2) {
+        // two blocks per CU: prefetch distance 1 on a 2-stage ring, one patch buffer (re-staged behind an extra barrier at
+        // each channel-chunk boundary); the stalls this exposes are covered by the other block's waves
+        for (int it = 0; it < total; ++it) {
+            const int cc = it / 3, g = it - cc * 3;
+            const int n1 = it + 1;
+            if (n1 < total) {
+                if (n1 % 3 == 0) load_patch(n1 / 3);
+                dma_w(n1);
+            }
+            const unsigned char* A = Abuf + a_lane_off;
+            const unsigned char* B = Bst + (it % NST) * BST + (wn * TN * 32) * 64;
+            const int dx0 = p_dx(p.tap_off, 3 * g) + 1, dx1 = p_dx(p.tap_off, 3 * g + 1) + 1, dx2 = p_dx(p.tap_off, 3 * g + 2) + 1;
+            const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWP + dx0) * APX;
+            const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWP + dx1) * APX;
+            const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWP + dx2) * APX;
+            bf16_three_taps<TM, TN, FRAG_BUFS>(A, B, po0, po1, po2, (hh ^ a_swz(tx_l + dx0)) << 4, (hh ^ a_swz(tx_l + dx1)) << 4,
+                                               (hh ^ a_swz(tx_l + dx2)) << 4, BN * 64, 32 * 64, boff0, boff1, acc);
+            if (n1 < total && n1 % 3 == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                 // every wave has read the last tap of this chunk's patch
+                store_patch(Abuf);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        } else {
         for (int it = 0; it < total; ++it) {
             const int cc = it / 3, g = it - cc * 3;
             const int n2 = it + 2, n1 = it + 1;
@@ -306,8 +347,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
             const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWP + dx0) * APX;
             const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWP + dx1) * APX;
             const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWP + dx2) * APX;
-            bf16_three_taps<TM, TN>(A, B, po0, po1, po2, (hh ^ a_swz(tx_l + dx0)) << 4, (hh ^ a_swz(tx_l + dx1)) << 4,
-                                    (hh ^ a_swz(tx_l + dx2)) << 4, BN * 64, 32 * 64, boff0, boff1, acc);
+            bf16_three_taps<TM, TN, 2>(A, B, po0, po1, po2, (hh ^ a_swz(tx_l + dx0)) << 4, (hh ^ a_swz(tx_l + dx1)) << 4,
+                                       (hh ^ a_swz(tx_l + dx2)) << 4, BN * 64, 32 * 64, boff0, boff1, acc);
 #if !defined(UPS_ABLATE_LSTORE)
             // (the activation patch goes through registers for the fused activation / zero padding; hipcc waits
             // vmcnt(0) for it, which also drains the DMAs once per channel chunk -- measured cost ~0.2 ms of 3.2 ms)
@@ -323,6 +364,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        }
         }
     } else {
     // ===== fp32 (parity mode): register-staged weights, prefetch distance 2, one barrier per tap-row
@@ -374,7 +416,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
             constexpr int CPR = BN / 8;                      // 16-byte chunks per row
             constexpr int NIT = 256 * CPR / 512;             // chunks per thread
             unsigned char* R0 = smem;                        // residual tile, then the output tile (in place)
-            unsigned char* R1 = smem + 256 * ERS;            // activation-derivative tile
+            unsigned char* R1 = smem + 256 * ERS;            // activation-derivative tile as sign bits: [256 px][BN / 8 bytes]
             const int c_lim = p.co_fill - nt * BN;           // valid channels of this N-tile (multiple of 8)
             if (res || dact) {
 #pragma unroll
@@ -383,7 +425,17 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
                     const long long pix = img_pix + (long long)(ty0 + (px >> 4)) * p.w + tx0 + (px & 15);
                     if (ch * 8 < c_lim) {
                         if (res) *(uint4*)(R0 + px * ERS + ch * 16) = *(const uint4*)(res + pix * p.ldr + nt * BN + ch * 8);
-                        if (dact) *(uint4*)(R1 + px * ERS + ch * 16) = *(const uint4*)(dact + pix * p.ldd + nt * BN + ch * 8);
+                        if (dact) {
+                            const uint4 dv = *(const uint4*)(dact + pix * p.ldd + nt * BN + ch * 8);
+                            const unsigned wv[4] = {dv.x, dv.y, dv.z, dv.w};
+                            unsigned sb = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {      // bit e = (element e > 0), elements = bf16 halves of the words
+                                sb |= ((short)(wv[k] & 0xffffu) > 0 ? 1u : 0u) << (2 * k);
+                                sb |= (((int)wv[k] >> 16) > 0 ? 1u : 0u) << (2 * k + 1);
+                            }
+                            R1[px * CPR + ch] = (unsigned char)sb;
+                        }
                     }
                 }
                 __syncthreads();
@@ -421,7 +473,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
                                     v += tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co];
                                 }
                             }
-                            if (dact) v *= ((float)*(const bf16*)(R1 + px * ERS + cl * 2) > 0.f) ? 1.f : dact_ns;
+                            if (dact) v *= ((R1[px * CPR + (cl >> 3)] >> (cl & 7)) & 1) ? 1.f : dact_ns;
                             if (res) v += (float)*(const bf16*)(R0 + px * ERS + cl * 2);
                         }
                         *(bf16*)(R0 + px * ERS + cl * 2) = (bf16)v;
@@ -471,36 +523,54 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchK p, cons
     }
 }
 
-template <typename T, int BN>
+template <typename T, int BN, int OCC>
 int launch_bn(const PatchK& k, hipStream_t s) {
     constexpr int EPC = Chunk<T>::N;
     const int tiles_x = k.w / TS, tiles_y = k.h / TS;
     const int ntn = ups_cdiv(k.co_fill, BN);
     const int kchunks = ups_cdiv(k.ci, 4 * EPC);
     const int nblocks = k.n * tiles_x * tiles_y * ntn;
-    const int nabuf = (sizeof(T) == 2 && kchunks == 1) ? 1 : 2;
-    size_t shmem = sizeof(T) == 2 ? nabuf * A_BYTES + 3 * (size_t)(3 * BN * 64) : 2 * A_BYTES + 2 * 3 * BN * RS;
-    const size_t shmem_max = sizeof(T) == 2 ? 2 * A_BYTES + 3 * (size_t)(3 * BN * 64) : shmem;
-    const size_t epi = sizeof(T) == 2 ? 2 * 256 * (size_t)(BN * 2 + 16) : 0;   // staged bf16 epilogue (2 tiles)
+    constexpr size_t BST = 3 * (size_t)BN * 64;
+    const int nabuf = (sizeof(T) == 2 && (kchunks == 1 || OCC == 2)) ? 1 : 2;
+    size_t shmem = sizeof(T) == 2 ? nabuf * A_BYTES + (OCC == 2 ? 2 : 3) * BST : 2 * A_BYTES + 2 * 3 * BN * RS;
+    const size_t shmem_max = sizeof(T) == 2 ? (OCC == 2 ? 1 : 2) * A_BYTES + (OCC == 2 ? 2 : 3) * BST : shmem;
+    const size_t epi = sizeof(T) == 2 ? 256 * (size_t)(BN * 2 + 16) + 256 * (size_t)(BN / 8) : 0;   // staged bf16 epilogue
     if (epi > shmem) shmem = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(epi > shmem_max ? epi : shmem_max));
         if (e != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN>), dim3(nblocks), dim3(512), shmem, s, k, tiles_x, tiles_y, ntn, kchunks,
+    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC>), dim3(nblocks), dim3(512), shmem, s, k, tiles_x, tiles_y, ntn, kchunks,
                        nblocks);
     return UPS_OK;
 }
 
+static int patch_occ() {   // UPS_PATCH_OCC=1 forces the one-block-per-CU configuration (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UPS_PATCH_OCC"); v = (e && e[0] == '1') ? 1 : 2; }
+    return v;
+}
+
 template <typename T>
 int launch_t(const PatchK& k, hipStream_t s) {
-    // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv): 64-wide tiles fit two blocks per CU
-    if (k.co_fill > 64 && !(sizeof(T) == 2 && k.ci <= 32)) return launch_bn<T, 128>(k, s);
-    if (k.co_fill > 32) return launch_bn<T, 64>(k, s);
-    return launch_bn<T, 32>(k, s);
+    if constexpr (sizeof(T) == 2) {
+        // two blocks per CU once the grid has at least two blocks for every CU (smaller grids spread over the chip instead);
+        // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv) use 64-wide tiles and one patch buffer
+        const int tiles = k.n * (k.w / TS) * (k.h / TS);
+        if (k.co_fill > 64 && k.ci > 32)
+            return (patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 128) >= 512) ? launch_bn<T, 128, 2>(k, s) : launch_bn<T, 128, 1>(k, s);
+        if (k.co_fill > 32)
+            return (patch_occ() == 2 && k.ci > 32 && tiles * ups_cdiv(k.co_fill, 64) >= 512) ? launch_bn<T, 64, 2>(k, s)
+                                                                                              : launch_bn<T, 64, 1>(k, s);
+        return launch_bn<T, 32, 1>(k, s);
+    } else {
+        if (k.co_fill > 64) return launch_bn<T, 128, 1>(k, s);
+        if (k.co_fill > 32) return launch_bn<T, 64, 1>(k, s);
+        return launch_bn<T, 32, 1>(k, s);
+    }
 }
 
 }  // namespace
