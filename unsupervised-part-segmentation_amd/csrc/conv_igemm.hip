@@ -92,7 +92,7 @@ struct ConvK {
 // CPS = K-chunks per pipeline stage: skinny problems (few blocks, long K loops) are bound by one exposed memory
 // latency per barrier, so they stage 2-4 chunks per barrier.
 template <typename T, int BN, int CPS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p, const int M, const int ntn,
+__global__ __launch_bounds__(256, (CPS == 1 ? 3 : 2)) void conv_igemm_kernel(const ConvK p, const int M, const int ntn,
                                                          const int kchunks) {
     constexpr int EPC = Chunk<T>::N;
     constexpr int BK = 4 * EPC;

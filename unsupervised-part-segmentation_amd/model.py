@@ -273,10 +273,64 @@ class Trainer(object):
         samples1, _ = ops.latent_fwd(pe_v1, noise["eps_pi1"][None], [1.0], False)
         bottleneck = kl_rows.sum(dim=1).mean()                            # nn.py:1196-1208
 
-        # appearance of the whole views feeds the critics only -> forward only (model.py:394-397)
-        with torch.no_grad():
-            alpha = nets.e_alpha(Act(img01, 2 * B, S, S, 3)).t            # [2B,1,1,A]
-            alpha_in = torch.cat([alpha[B:], torch.flip(alpha[:B], dims=[0])], 0).contiguous()
+        # ================= D: critics (model.py:502-521, 800-866) -- they depend on the latent samples and on the appearance
+        # code of the whole views only, and the main path needs them again at the encoder_0 backward: the whole block
+        # (72 tiny GEMMs that cannot fill the chip) runs on the "aux" stream beside segments B and C.
+        mi = cfg["MI"]
+        MI_TARGET, MI_SLACK = mi.get("mi_target", 0.125), mi.get("mi_slack", 0.05)
+
+        def critic_block():
+            # appearance of the whole views feeds the critics only -> forward only (model.py:394-397)
+            with torch.no_grad():
+                alpha = nets.e_alpha(Act(img01, 2 * B, S, S, 3)).t            # [2B,1,1,A]
+                alpha_in = torch.cat([alpha[B:], torch.flip(alpha[:B], dims=[0])], 0).contiguous()
+            crit = {}
+            for ci, name in enumerate(("mi0_discriminator", "mi1_discriminator", "mi_estimator")):
+                pi_in = model.to_act(torch.cat([samples0[1 + 2 * ci], samples0[2 + 2 * ci]], 0).view(2 * B, 1, 1, Z))
+                pi_in.requires_grad_(name == "mi0_discriminator")
+                h_pi, h_al = nets.critic(name, (Act(pi_in, 2 * B, 1, 1, Z), Act(alpha_in, 2 * B, 1, 1, A)))
+                logits = (h_pi.t.float() * h_al.t.float()).sum(dim=(1, 2, 3))
+                joint, marg = logits[:B], logits[B:]
+                loss = 0.5 * (torch.nn.functional.softplus(-joint).mean() + torch.nn.functional.softplus(marg).mean())
+                acc = ((joint > 0).sum() + (marg < 0).sum()).float() / (2 * B)
+                crit[name] = (loss, joint, acc, pi_in)
+            loss_dis0, joint0, acc0, pi_leaf0 = crit["mi0_discriminator"]
+            loss_dis1, joint1, acc1, _ = crit["mi1_discriminator"]
+            loss_est, _, acc_est, _ = crit["mi_estimator"]
+            mim = joint0.mean()                                                # logit_constraint(real=False), model.py:855
+            ind_mim = joint1.mean()
+
+            adv = None
+            g_adv = None
+            if cfg.get("adversarial_regularization", True):                   # model.py:886-909
+                loa, loa_lr = st["loa"], mi.get("loa_lr", 4.0)
+                loa_gain = mim - (1.0 - MI_SLACK) * MI_TARGET
+                if mi.get("loa_adaptive", True):
+                    active = (loa_lr * loa_gain.detach() >= -loa).float()
+                    adv = active * (loa * loa_gain + loa_lr / 2.0 * loa_gain ** 2)
+                else:
+                    adv = loa * loa_gain
+                if "encoder_0" in keys:
+                    with ops.skip_wgrad():
+                        g_adv = torch.autograd.grad([adv], [pi_leaf0], retain_graph=True)[0].float().view(2 * B, Z)[:B]
+            for name in ("mi0_discriminator", "mi1_discriminator", "mi_estimator"):
+                if name in keys:
+                    ps = [bank.params[n] for n in bank.groups[name]["names"]]
+                    torch.autograd.grad([crit[name][0]], ps)
+
+            return crit, adv, g_adv, mim, ind_mim
+
+        main_stream = torch.cuda.current_stream(dev)
+        if ops.Streams.enabled:
+            aux = ops.Streams.get("aux", dev)
+            aux.wait_stream(main_stream)
+            with torch.cuda.stream(aux):
+                crit, adv, g_adv, mim, ind_mim = critic_block()
+        else:
+            crit, adv, g_adv, mim, ind_mim = critic_block()
+        loss_dis0, joint0, acc0, _ = crit["mi0_discriminator"]
+        loss_dis1, joint1, acc1, _ = crit["mi1_discriminator"]
+        loss_est, _, acc_est, _ = crit["mi_estimator"]
 
         # ================= B: mask decoder (model.py:411-412)
         z_leaf = model.to_act(torch.cat([samples0[0], samples1[0]], 0).view(2 * B, 1, 1, Z)).requires_grad_(True)
@@ -310,6 +364,7 @@ class Trainer(object):
                 rec_params += [bank.params[n] for n in bank.groups[k]["names"]]
         gr = torch.autograd.grad([auto_rec], [hard0, hard1] + rec_params)  # conv wgrads land in bank.grads
         g_hard0, g_hard1 = gr[0].contiguous(), gr[1].contiguous()
+        pending = self._launch_reduce([k for k in ("encoder_1", "decoder_delta") if k in keys])
 
         # ================= mask priors: fused forward sums + fused backward (model.py:652-797)
         nfl = L.load().ups_prior_sums_floats(B, P)
@@ -347,45 +402,13 @@ class Trainer(object):
         if "decoder_visualize" in keys:
             dv_params = [bank.params[n] for n in bank.groups["decoder_visualize"]["names"]]
             torch.autograd.grad([l_mean], dv_params, grad_outputs=[dl_tot], retain_graph=True)
+        pending += self._launch_reduce([k for k in ("decoder_visualize",) if k in keys])
         with ops.skip_wgrad():
             gz = torch.autograd.grad([l_mean], [z_leaf], grad_outputs=[dl_rec])[0].float().view(2 * B, Z)
 
-        # ================= D: critics (model.py:502-521, 800-866)
-        mi = cfg["MI"]
-        MI_TARGET, MI_SLACK = mi.get("mi_target", 0.125), mi.get("mi_slack", 0.05)
-        crit = {}
-        for ci, name in enumerate(("mi0_discriminator", "mi1_discriminator", "mi_estimator")):
-            pi_in = model.to_act(torch.cat([samples0[1 + 2 * ci], samples0[2 + 2 * ci]], 0).view(2 * B, 1, 1, Z))
-            pi_in.requires_grad_(name == "mi0_discriminator")
-            h_pi, h_al = nets.critic(name, (Act(pi_in, 2 * B, 1, 1, Z), Act(alpha_in, 2 * B, 1, 1, A)))
-            logits = (h_pi.t.float() * h_al.t.float()).sum(dim=(1, 2, 3))
-            joint, marg = logits[:B], logits[B:]
-            loss = 0.5 * (torch.nn.functional.softplus(-joint).mean() + torch.nn.functional.softplus(marg).mean())
-            acc = ((joint > 0).sum() + (marg < 0).sum()).float() / (2 * B)
-            crit[name] = (loss, joint, acc, pi_in)
-        loss_dis0, joint0, acc0, pi_leaf0 = crit["mi0_discriminator"]
-        loss_dis1, joint1, acc1, _ = crit["mi1_discriminator"]
-        loss_est, _, acc_est, _ = crit["mi_estimator"]
-        mim = joint0.mean()                                                # logit_constraint(real=False), model.py:855
-        ind_mim = joint1.mean()
-
-        adv = None
-        g_adv = None
-        if cfg.get("adversarial_regularization", True):                   # model.py:886-909
-            loa, loa_lr = st["loa"], mi.get("loa_lr", 4.0)
-            loa_gain = mim - (1.0 - MI_SLACK) * MI_TARGET
-            if mi.get("loa_adaptive", True):
-                active = (loa_lr * loa_gain.detach() >= -loa).float()
-                adv = active * (loa * loa_gain + loa_lr / 2.0 * loa_gain ** 2)
-            else:
-                adv = loa * loa_gain
-            if "encoder_0" in keys:
-                with ops.skip_wgrad():
-                    g_adv = torch.autograd.grad([adv], [pi_leaf0], retain_graph=True)[0].float().view(2 * B, Z)[:B]
-        for name in ("mi0_discriminator", "mi1_discriminator", "mi_estimator"):
-            if name in keys:
-                ps = [bank.params[n] for n in bank.groups[name]["names"]]
-                torch.autograd.grad([crit[name][0]], ps)
+        # the critics' block (aux stream) must be complete from here on: g_adv, the critic losses and their gradients
+        ops.Streams.join(dev, names=("aux",))
+        pending += self._launch_reduce([k for k in ("mi0_discriminator", "mi1_discriminator", "mi_estimator") if k in keys])
 
         # ================= A backward (model.py:739, 909, 930)
         bw = None
@@ -408,7 +431,8 @@ class Trainer(object):
             torch.autograd.grad([pe], e0_params, grad_outputs=[g_pe])
 
         # ================= gradient all-reduce (data parallel) + TF Adam per key
-        self._reduce_and_step(keys)
+        pending += self._launch_reduce([k for k in ("encoder_0",) if k in keys])
+        self._finish_step(keys, pending)
 
         # ================= state updates (update_ops; Appendix A.15: losses above used the pre-update state)
         stats = torch.stack([mim.detach(), ind_mim.detach(), acc0, acc1, loss_dis0.detach(), loss_dis1.detach()])
@@ -469,11 +493,20 @@ class Trainer(object):
                        "dl_tot": dl_tot, "dl_rec": dl_rec, "g_hard0": g_hard0, "g_hard1": g_hard1, "pe": pe2}
         return self.losses
 
-    def _reduce_and_step(self, keys):
-        """RCCL all-reduce (sum, scaled by 1/world in the Adam kernel) of each key's flat gradient,
-        then one fused Adam launch per key (tf.train.AdamOptimizer semantics, Appendix A.12)."""
+    def _launch_reduce(self, key_list):
+        """Called when the backward segment of these optimizer keys is complete: their weight gradients (side stream)
+        are joined and each key's flat gradient bucket starts its RCCL all-reduce (sum; 1/world is folded into Adam),
+        overlapping the backward segments that are still to run.  Returns the work handles."""
+        if not key_list:
+            return []
+        ops.Streams.join(self.device, names=("wgrad",))
         bank = self.model.bank
-        handles = [D.allreduce_bucket(bank.groups[k]["flat"]["g"], self.world_size, self.process_group) for k in keys]
+        return [D.allreduce_bucket(bank.groups[k]["flat"]["g"], self.world_size, self.process_group) for k in key_list]
+
+    def _finish_step(self, keys, handles):
+        """Wait for the buckets, then one fused Adam launch per key (tf.train.AdamOptimizer semantics, Appendix A.12)."""
+        bank = self.model.bank
+        ops.Streams.join(self.device)
         D.wait_all(handles)
         lr = self.learning_rate()
         for k in keys:

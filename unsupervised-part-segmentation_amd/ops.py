@@ -7,6 +7,7 @@ Activations are NHWC tensors whose last dimension is the PHYSICAL channel count 
 weights stay fp32 in the TF variable layout HWIO and are re-laid-out / converted once per optimizer step.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -25,19 +26,56 @@ def same_geometry(size, k, stride):
 
 
 class _Workspace(object):
-    """Grow-only device scratch (one per process; all launches are on the current stream)."""
+    """Grow-only device scratch, one buffer per (device, stream): launches on different HIP streams may overlap."""
 
     def __init__(self):
-        self.buf = None
+        self.bufs = {}
 
     def get(self, nbytes, device):
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        return self.buf
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
 
 
 WORKSPACE = _Workspace()
 COLSUM_WS = _Workspace()
+
+
+class Streams(object):
+    """Side HIP streams of the training step.  ``wgrad``: every layer's weight gradient is enqueued there while the
+    input gradient continues on the launching stream (the two are independent; small layers that cannot fill 256 CUs
+    then overlap).  ``aux``: the critics + the appearance code of the whole views, which the main path only needs
+    again at the encoder_0 backward.  UPS_NO_OVERLAP=1 keeps everything on one stream (A/B runs, debugging)."""
+    enabled = os.environ.get("UPS_NO_OVERLAP", "0") != "1"
+    _pool = {}
+
+    @classmethod
+    def get(cls, name, device):
+        key = (name, torch.device(device).index)
+        st = cls._pool.get(key)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            cls._pool[key] = st
+        return st
+
+    @classmethod
+    def on_aux(cls, device):
+        st = cls._pool.get(("aux", torch.device(device).index))
+        return st is not None and torch.cuda.current_stream(device) == st
+
+    @classmethod
+    def join(cls, device, names=("wgrad", "aux")):
+        """The current stream waits for everything enqueued on the side streams so far."""
+        if not cls.enabled:
+            return
+        cur = torch.cuda.current_stream(device)
+        for n in names:
+            st = cls._pool.get((n, torch.device(device).index))
+            if st is not None and st != cur:
+                cur.wait_stream(st)
 
 
 class KernelTimer(object):
@@ -342,7 +380,18 @@ class ConvFn(torch.autograd.Function):
         g = to_act_dtype(g, x.dtype, layer.co)
         gx = gV = gb = gres = None
         if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not GradMode.skip_wgrad:
-            gV, gb = conv_wgrad(g, x, layer)
+            if Streams.enabled and layer.grad_V is not None and not Streams.on_aux(x.device):
+                # weight gradient on the side stream (it lands in the layer's view of the flat gradient bucket, which
+                # nothing reads before Streams.join); g and x must outlive the side stream's reads
+                cur = torch.cuda.current_stream(x.device)
+                side = Streams.get("wgrad", x.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    gV, gb = conv_wgrad(g, x, layer)
+                g.record_stream(side)
+                x.record_stream(side)
+            else:
+                gV, gb = conv_wgrad(g, x, layer)
         if ctx.needs_input_grad[0]:
             gx = conv_dgrad(g, x, layer, res=g if ctx.res_mode == 2 else None)
         if ctx.res_mode == 1 and ctx.needs_input_grad[3]:
