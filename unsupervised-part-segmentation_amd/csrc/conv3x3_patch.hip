@@ -440,6 +440,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 }
                 __syncthreads();
             }
+            // Accumulator element e of lane (c = lane & 31, hh = lane >> 5) is tile pixel row 2*(wm*TM+tm) + (e >> 3),
+            // column 4*hh + cx(j), j = (e & 3) + 4*((e >> 2) & 1), cx = {0,1,2,3,8,9,10,11}.  The CoordConv term of an
+            // interior pixel (all nine taps valid) is affine in (x, y): it is folded with the bias into 8 per-column x
+            // terms and 2 y terms per MFMA block (2 adds per element); only tiles that touch the image border look the
+            // class table up, and only for their border pixels.
+            const int hh4 = 4 * (lane >> 5);
+            const bool border_tile = p.coord_tab && (ty0 == 0 || ty0 + TS >= p.h || tx0 == 0 || tx0 + TS >= p.w);
+            const float xf0 = (float)(tx0 + hh4);
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int cl = (wn * TN + tn) * 32 + (lane & 31);
@@ -447,35 +455,37 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 const bool cvalid = col < p.co;
                 if (col >= p.co_fill) continue;
                 const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
-                // CoordConv affine term: interior pixels (all nine taps valid, class 63) use three per-column
-                // constants held in registers; only image-border pixels look the table up
                 float t0 = 0.f, t1 = 0.f, t2 = 0.f;
                 if (cvalid && p.coord_tab) {
                     const float* tb = p.coord_tab + (long long)63 * 3 * p.co + col;
                     t0 = tb[0]; t1 = tb[p.co]; t2 = tb[2 * p.co];
                 }
+                float xs[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xs[j] = fmaf(xf0 + (float)((j & 3) + 8 * (j >> 2)), t1, bias + t0);
+                const unsigned dbit = 1u << (cl & 7);
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
+                    const int yrow = (wm * TM + tm) * 2;
+                    const float ys0 = (float)(ty0 + yrow) * t2, ys1 = (float)(ty0 + yrow + 1) * t2;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int rr = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        const int px = ((wm * TM + tm) * 2 + (rr >> 4)) * 16 + (rr & 15);
-                        float v = 0.f;
-                        if (cvalid) {
-                            v = acc[tm][tn][e] + bias;
-                            if (p.coord_tab) {
-                                const int y = ty0 + (px >> 4), x = tx0 + (px & 15);
-                                const int ym = (y > 0 ? 1 : 0) | 2 | (y + 1 < p.h ? 4 : 0);
-                                const int xm = (x > 0 ? 1 : 0) | 2 | (x + 1 < p.w ? 4 : 0);
-                                if ((ym & xm) == 7) v += t0 + (float)x * t1 + (float)y * t2;
-                                else {
-                                    const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
-                                    v += tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co];
-                                }
+                        const int j = (e & 3) + 4 * ((e >> 2) & 1), k = e >> 3;
+                        const int pxc = hh4 + (j & 3) + 8 * (j >> 2);
+                        const int px = (yrow + k) * 16 + pxc;
+                        float v = acc[tm][tn][e] + xs[j] + (k ? ys1 : ys0);
+                        if (border_tile) {
+                            const int y = ty0 + yrow + k, x = tx0 + pxc;
+                            const int ym = (y > 0 ? 1 : 0) | 2 | (y + 1 < p.h ? 4 : 0);
+                            const int xm = (x > 0 ? 1 : 0) | 2 | (x + 1 < p.w ? 4 : 0);
+                            if ((ym & xm) != 7 && cvalid) {
+                                const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
+                                v = acc[tm][tn][e] + bias + (tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co]);
                             }
-                            if (dact) v *= ((R1[px * CPR + (cl >> 3)] >> (cl & 7)) & 1) ? 1.f : dact_ns;
-                            if (res) v += (float)*(const bf16*)(R0 + px * ERS + cl * 2);
                         }
+                        if (dact) v *= (R1[px * CPR + (cl >> 3)] & dbit) ? 1.f : dact_ns;
+                        if (res) v += (float)*(const bf16*)(R0 + px * ERS + cl * 2);
+                        if (!cvalid) v = 0.f;
                         *(bf16*)(R0 + px * ERS + cl * 2) = (bf16)v;
                     }
                 }
