@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=${1:-.}
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-inline-asm"
 mkdir -p build
 pids=()
 for f in conv_igemm conv3x3_patch conv_wgrad conv_wgrad3x3 conv_aux pointwise partpath priors latent_adam; do
