@@ -65,6 +65,10 @@ CONV_CASES = [
     (2, 32, 16, 80, 16, 3, 1, False, None, False),             # wgrad3x3 <64,32>
     (2, 64, 64, 8, 32, 3, 1, False, None, False),              # first encoder conv (image input), <32,32>
     (8, 64, 64, 32, 32, 3, 1, False, "leaky_relu", True),      # thin res-block, many tiles (XCD remap path)
+    # grids of >= 512 blocks: the two-blocks-per-CU configuration of the patch kernel (2-stage weight ring, single patch
+    # buffer, sign-byte activation-derivative tile), forward with CoordConv + residual and dgrad with act' + residual
+    (16, 64, 64, 136, 136, 3, 1, True, "leaky_relu", True),    # <bf16,128,2>, ragged second N-tile
+    (34, 64, 64, 64, 64, 3, 1, False, "relu", True),           # <bf16,64,2>
 ]
 
 
