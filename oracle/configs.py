@@ -51,13 +51,36 @@ def cub_config(n_parts=10, batch_size=8, spatial_size=128, use_tps=False):
     return c
 
 
-def tiny_config(n_parts=3, batch_size=2, spatial_size=16):
+def pennaction_config(n_parts=10, batch_size=8, spatial_size=128):
+    """pennaction/code/SB_model48i/train_pennaction.yaml: the CUB yaml with ``encoder1.coords: True`` (line 163),
+    ``MI.mi_target: 1.5`` (line 50) and ``use_tps: False`` (line 186); the model file differs from CUB's only in
+    ``make_tps`` (unused with use_tps False)."""
+    c = cub_config(n_parts, batch_size, spatial_size, use_tps=False)
+    c["encoder1"]["coords"] = True
+    c["MI"]["mi_target"] = 1.5
+    return c
+
+
+def tiny_config(n_parts=3, batch_size=2, spatial_size=16, variant="cub"):
     """Same graph, tiny widths: encoders 16->8->4, dv 4->8->16, z=8, app=8."""
-    c = cub_config(n_parts, batch_size, spatial_size)
+    c = pennaction_config(n_parts, batch_size, spatial_size) if variant == "pennaction" else cub_config(n_parts, batch_size, spatial_size)
     c = copy.deepcopy(c)
     c.update({"patch_size": 6, "z0_size": 8, "local_app_size": 8})
     c["encoder0"].update({"config": [8, 16, 16], "extra_resnets": 1})
     c["encoder1"].update({"config": [8, 16, 16], "extra_resnets": 1})
     c["dv"].update({"config": [8, 16, 16], "upsample_config": ["linear"] * 2})
     c["final_hour"].update({"config": [8, 16]})
+    return c
+
+
+def small_config(n_parts=4, batch_size=2, spatial_size=32, variant="cub"):
+    """Mid-size parity config: 32x32 images (16-aligned, so the patch-tiled 3x3 kernels run inside the whole-step
+    tests), encoders 32->16->8->4, dv 4->8->16->32, z=16, app=16."""
+    c = pennaction_config(n_parts, batch_size, spatial_size) if variant == "pennaction" else cub_config(n_parts, batch_size, spatial_size)
+    c = copy.deepcopy(c)
+    c.update({"patch_size": 8, "z0_size": 16, "local_app_size": 16})
+    c["encoder0"].update({"config": [16, 32, 32, 64], "extra_resnets": 1})
+    c["encoder1"].update({"config": [16, 32, 32, 64], "extra_resnets": 1})
+    c["dv"].update({"config": [8, 16, 32, 40], "upsample_config": ["linear"] * 3})
+    c["final_hour"].update({"config": [16, 32]})
     return c

@@ -1,4 +1,5 @@
-"""Generates tests/golden/tiny_step.npz from the CPU oracle (fp64) on the tiny config:
+"""Generates tests/golden/tiny_step.npz (CUB yaml) and tiny_step_pennaction.npz (PennAction yaml: encoder1 with
+CoordConv, mi_target 1.5) from the CPU oracle (fp64) on the tiny config:
 inputs (views, every noise tensor), forward outputs, all loss scalars, per-key gradients
 (full tensors for small variables, norms for all), parameters after 1 and 2 TF-Adam steps and the
 Lagrangian / EMA state.  The reference itself cannot be imported here (TensorFlow 1.14 / edflow absent),
@@ -22,8 +23,8 @@ FULL = ("encoder_0/conv2d_0/V", "encoder_0/conv2d_3/b", "encoder_1/conv2d_0/V", 
         "mi0_discriminator/conv2d_0/V", "mi_estimator/conv2d_11/b")
 
 
-def main():
-    cfg = configs.tiny_config()
+def main(variant="cub"):
+    cfg = configs.tiny_config(variant=variant)
     params = R.init_params(cfg, 0)
     vp = R.vgg_params(7, widths=VGG_W)
     views, noise = R.synthetic_views(cfg), R.synthetic_noise(cfg)
@@ -55,10 +56,11 @@ def main():
             out[pre + "param/" + n] = p[n].float().numpy()
         for k, v in state.items():
             out[pre + "state_" + k] = np.float64(v)
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tiny_step.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tiny_step.npz" if variant == "cub" else "tiny_step_{}.npz".format(variant))
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":
-    main()
+    for v in (sys.argv[1:] or ["cub", "pennaction"]):
+        main(v)

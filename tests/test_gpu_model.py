@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 VGG_W = (8, 8, 16, 16, 16)
 
 
-def _setup(precision, dev):
+def _setup(precision, dev, variant="cub", size="tiny"):
     import upsparts_amd  # noqa: F401
     from upsparts_amd.model import TrainModel, Trainer
     from oracle import ref_model as R, configs
-    cfg = configs.tiny_config()
+    cfg = configs.tiny_config(variant=variant) if size == "tiny" else configs.small_config(variant=variant)
     cfg = copy.deepcopy(cfg)
     cfg["precision"] = precision
     cfg["vgg_widths"] = VGG_W
@@ -35,8 +35,9 @@ def _setup(precision, dev):
     return cfg, R, params, vp, model, trainer, views, noise
 
 
-def test_train_step_fp32_matches_oracle(dev):
-    cfg, R, params, vp, model, trainer, views, noise = _setup("fp32", dev)
+@pytest.mark.parametrize("variant,size", [("cub", "tiny"), ("pennaction", "tiny"), ("cub", "small")])
+def test_train_step_fp32_matches_oracle(dev, variant, size):
+    cfg, R, params, vp, model, trainer, views, noise = _setup("fp32", dev, variant, size)
     state = R.initial_state(cfg)
     adam = R.init_adam(params)
     p = params
@@ -83,8 +84,9 @@ def test_train_step_fp32_matches_oracle(dev):
         p, state = p_new, state_new
 
 
-def test_train_step_bf16_close_to_oracle(dev):
-    cfg, R, params, vp, model, trainer, views, noise = _setup("bf16", dev)
+@pytest.mark.parametrize("variant,size", [("cub", "tiny"), ("pennaction", "tiny"), ("cub", "small")])
+def test_train_step_bf16_close_to_oracle(dev, variant, size):
+    cfg, R, params, vp, model, trainer, views, noise = _setup("bf16", dev, variant, size)
     state = R.initial_state(cfg)
     o, Lo, log, _, grads = R.gradients(params, cfg, views, noise, state, 0, vp, dtype=torch.float64)
     losses = trainer.train_step(views, noise)
