@@ -61,26 +61,64 @@ def pennaction_config(n_parts=10, batch_size=8, spatial_size=128):
     return c
 
 
+def deepfashion_config(n_parts=16, batch_size=8, spatial_size=128):
+    """deepfashion/code/SB_model48c/train_deepfashion.yaml as a dict (n_parts / batch / size overridable; the yaml ships
+    25 parts at 128x128, BASELINE config #3 asks for 16 parts at 256x256).  The model is the SB_model48c variant: two
+    inputs, no rectangles / patch loss, Mumford-Shah prior on the logits, squared renormalised variance and the three
+    single-sample decoders d_single / d_alpha / d_pi.  At 256x256 the mask decoders need one more upsampling level."""
+    c = cub_config(n_parts, batch_size, spatial_size, use_tps=False)
+    c.update({"model": "nips19.SB_model48c.model.TrainModel", "iterator": "nips19.SB_model48c.model.Trainer",
+              "lr_decay_begin": 500000, "lr_decay_end": 500001, "ckpt_freq": 20000, "num_steps": 500000})
+    c["MI"].update({"mi_target": 2.0, "mi_slack": 0.5, "lor_min": 0.0})
+    c["variance_weight"] = _stair(41000, 1, 40000, 10, 1.0, 1.0e5)
+    c["prior_mumford_sha_weight"] = _stair(100000, 1.0e-2, 20000, 3.14, 1.0e-6, 1.0e-6)
+    c["weakly_superv_loss_weight_p"] = _stair(41000, 1, 1, 1.0e3, 1.0, 1.0e3)
+    for k in ("patch_loss_weight", "gamma", "patch_size", "entropy_func", "use_tps", "tps_parameters",
+              "adversarial_regularization", "variational_regularization"):
+        c.pop(k, None)
+    levels = 5 + max(0, (spatial_size // 128).bit_length() - 1)       # 4 -> 128 takes 5 doublings, 4 -> 256 six
+    dvc = [16, 32, 32, 128, 128, 256]
+    dvc = [16] * (levels + 1 - len(dvc)) + dvc
+    c["dv"] = {"config": dvc, "upsample_config": ["linear"] * levels, "activation": "leaky_relu", "coords": True}
+    c["d_single"] = copy.deepcopy(c["dv"])
+    return c
+
+
 def tiny_config(n_parts=3, batch_size=2, spatial_size=16, variant="cub"):
     """Same graph, tiny widths: encoders 16->8->4, dv 4->8->16, z=8, app=8."""
-    c = pennaction_config(n_parts, batch_size, spatial_size) if variant == "pennaction" else cub_config(n_parts, batch_size, spatial_size)
-    c = copy.deepcopy(c)
+    c = _variant(variant, n_parts, batch_size, spatial_size)
     c.update({"patch_size": 6, "z0_size": 8, "local_app_size": 8})
     c["encoder0"].update({"config": [8, 16, 16], "extra_resnets": 1})
     c["encoder1"].update({"config": [8, 16, 16], "extra_resnets": 1})
     c["dv"].update({"config": [8, 16, 16], "upsample_config": ["linear"] * 2})
+    if "d_single" in c:
+        c["d_single"].update({"config": [8, 16, 16], "upsample_config": ["linear"] * 2})
+        c.pop("patch_size")
     c["final_hour"].update({"config": [8, 16]})
+    return c
+
+
+def _variant(variant, n_parts, batch_size, spatial_size):
+    fn = {"cub": cub_config, "pennaction": pennaction_config, "deepfashion": deepfashion_config}[variant]
+    c = copy.deepcopy(fn(n_parts, batch_size, spatial_size))
+    if variant == "deepfashion":
+        # parity configs: make the Mumford-Shah prior on the logits visible (the yaml's weight is 1e-6) and put its
+        # clamp min(alpha * g, lambda) inside the range of the synthetic logits so both branches are exercised
+        c["prior_mumford_sha_weight"] = _stair(100000, 1.0e-2, 20000, 3.14, 1.0e-1, 1.0e-1)
+        c["mumford_sha_lambda"] = _stair(65000, 1.0, 5000, 10, 5.0e-4, 5.0e-4)
     return c
 
 
 def small_config(n_parts=4, batch_size=2, spatial_size=32, variant="cub"):
     """Mid-size parity config: 32x32 images (16-aligned, so the patch-tiled 3x3 kernels run inside the whole-step
     tests), encoders 32->16->8->4, dv 4->8->16->32, z=16, app=16."""
-    c = pennaction_config(n_parts, batch_size, spatial_size) if variant == "pennaction" else cub_config(n_parts, batch_size, spatial_size)
-    c = copy.deepcopy(c)
+    c = _variant(variant, n_parts, batch_size, spatial_size)
     c.update({"patch_size": 8, "z0_size": 16, "local_app_size": 16})
     c["encoder0"].update({"config": [16, 32, 32, 64], "extra_resnets": 1})
     c["encoder1"].update({"config": [16, 32, 32, 64], "extra_resnets": 1})
     c["dv"].update({"config": [8, 16, 32, 40], "upsample_config": ["linear"] * 3})
+    if "d_single" in c:
+        c["d_single"].update({"config": [8, 16, 32, 40], "upsample_config": ["linear"] * 3})
+        c.pop("patch_size")
     c["final_hour"].update({"config": [16, 32]})
     return c

@@ -231,6 +231,17 @@ class Nets(object):
     def critic(self, name, pair):
         return discriminator_model(self._scope(name, self.config["discriminator"]), pair)
 
+    def dsingle(self, name, z):
+        """d_single / d_alpha / d_pi of deepfashion/code/SB_model48c/model.py:320-323 (n_out = 3, DF:132-154)."""
+        kw = self.config["d_single"]
+        return single_decoder_model(self._scope(name, kw), z, 3, kw["config"], kw.get("upsample_config", "subpixel"))
+
+
+def is_48c(config):
+    """The DeepFashion model variant (deepfashion/code/SB_model48c/model.py): selected by the yaml's
+    ``model: ...SB_model48c.model.TrainModel`` or an explicit ``variant: sb48c`` key."""
+    return config.get("variant") == "sb48c" or "SB_model48c" in str(config.get("model", ""))
+
 
 def init_params(config, seed=0):
     """Create every trainable variable by running the templates once on zeros."""
@@ -244,6 +255,10 @@ def init_params(config, seed=0):
         nets.dd(torch.zeros(b, s, s, a + p))
         for name in ("mi0_discriminator", "mi1_discriminator", "mi_estimator"):
             nets.critic(name, (torch.zeros(b, 1, 1, z), torch.zeros(b, 1, 1, a)))
+        if is_48c(config):
+            nets.dsingle("d_single", torch.zeros(b, 1, 1, z + a))
+            nets.dsingle("d_alpha", torch.zeros(b, 1, 1, a))
+            nets.dsingle("d_pi", torch.zeros(b, 1, 1, z))
     return nets.params
 
 
@@ -340,7 +355,9 @@ def forward(params, config, views, noise, lon=1.0, dtype=torch.float32, seed=Non
     assert not config.get("use_tps", False), "TPS augmentation is outside the oracle's scope"
     nets = Nets(config, params, seed)
     o = {}
-    v0, v1, vt = (views[k].to(dtype) for k in ("view0", "view1", "view0_target"))
+    df = is_48c(config)
+    v0, v1 = views["view0"].to(dtype), views["view1"].to(dtype)
+    vt = v0 if df else views["view0_target"].to(dtype)      # DF:253,669: two inputs, the target is view0 itself
     B = v0.shape[0]
     Z = config.get("z0_size", 256)
     gamma = config.get("gamma", 3.0)
@@ -373,8 +390,11 @@ def forward(params, config, views, noise, lon=1.0, dtype=torch.float32, seed=Non
     hard0 = ste(hard_max(m0), m0)                       # M:434-436
     hard1 = ste(hard_max(m1), m1)                       # M:453-455
     o["hard0"], o["hard1"] = hard0, hard1
-    o["rect0"], o["px0"] = patch_mask(hard0, gamma, patch)   # M:437-445
-    o["rect1"], o["px1"] = patch_mask(hard1, gamma, patch)   # M:456-463
+    if df:      # DF:402-413: no rectangles
+        o["rect0"] = o["rect1"] = o["px0"] = o["px1"] = None
+    else:
+        o["rect0"], o["px0"] = patch_mask(hard0, gamma, patch)   # M:437-445
+        o["rect1"], o["px1"] = patch_mask(hard1, gamma, patch)   # M:456-463
     o["out_parts_soft"] = torch.softmax(l0_mean, dim=-1)     # M:469
     o["out_parts_hard"] = torch.argmax(o["out_parts_soft"], dim=3)   # M:470
     o["m0_sample_argmax"] = torch.argmax(m0, dim=3)          # M:447
@@ -402,6 +422,13 @@ def forward(params, config, views, noise, lon=1.0, dtype=torch.float32, seed=Non
     o["logit_marginal1"] = nets.critic("mi1_discriminator", (smp(4), z1_indep))
     o["mi_logit_joint"] = nets.critic("mi_estimator", (smp(5), alpha_v1))
     o["mi_logit_marginal"] = nets.critic("mi_estimator", (smp(6), z1_indep))
+    if df:
+        # DF:491-505: three single decoders on batch item 0, inputs under stop_gradient (two more draws of z_00)
+        zj = torch.cat([smp(7), alpha_v1], dim=3)[:1]
+        o["global_generated"] = nets.dsingle("d_single", zj.detach())
+        o["alpha_generated"] = nets.dsingle("d_alpha", alpha_v1[:1].detach())
+        o["pi_generated"] = nets.dsingle("d_pi", smp(8)[:1].detach())
+        o["x0"], o["x1"] = v0[:1], v1[:1]
     return o
 
 
@@ -493,9 +520,14 @@ def losses(o, config, state, step, vp, perceptual_mode="native", vgg_depths=VGG_
     dt = o["l0"].dtype
     H = o["l0"].shape[1]
     dim = H * H * 3                                           # M:613
+    df = is_48c(config)
     rec = perceptual_loss(vp, o["target"], o["generated"], perceptual_mode, vgg_depths)
     auto_rec_loss = 1e-3 * 0.5 * dim * rec                    # M:614-619
     log["perceptual"] = rec
+    if df:      # DF:672-684
+        global_rec = 1e-3 * 0.5 * dim * perceptual_loss(vp, o["x0"], o["global_generated"], perceptual_mode, vgg_depths)
+        alpha_rec = 1e-3 * 0.5 * dim * perceptual_loss(vp, o["x1"], o["alpha_generated"], perceptual_mode, vgg_depths)
+        pi_rec = 1e-3 * 0.5 * dim * perceptual_loss(vp, o["x0"], o["pi_generated"], perceptual_mode, vgg_depths)
 
     w_gmrf = make_var(step, config["prior_gmrf_weight"])
     w_ms = make_var(step, config["prior_mumford_sha_weight"])
@@ -519,7 +551,7 @@ def losses(o, config, state, step, vp, perceptual_mode="native", vgg_depths=VGG_
     # M:667-681 (softmax_cross_entropy_with_logits_v2 back-propagates into labels too)
     log_probs = o["l0"]
     p_labels = torch.softmax(log_probs, dim=-1)
-    ef = config.get("entropy_func", "cross_entropy")
+    ef = "cross_entropy" if df else config.get("entropy_func", "cross_entropy")    # DF:744-746: always the STE labels
     if ef == "cross_entropy":
         labels = ste(hard_max(p_labels), p_labels)
     elif ef == "entropy":
@@ -530,9 +562,18 @@ def losses(o, config, state, step, vp, perceptual_mode="native", vgg_depths=VGG_
 
     # M:683-719
     gamma = config.get("gamma", 3.0)
-    c1 = spatial_softmax(torch.softmax(o["l1"], dim=-1) * gamma) * (1 - o["rect1"]).detach()
-    _, sigma = probs_to_mu_sigma(c1)
-    variances = (sigma[:, :, 0, 0] + sigma[:, :, 1, 1]).sum(dim=1).mean()
+    if df:      # DF:750-776: no gamma, no rectangle, renormalised maps, squared variances
+        c1 = spatial_softmax(torch.softmax(o["l1"], dim=-1))
+        c1 = c1 / c1.sum(dim=(1, 2), keepdim=True)
+        _, sigma = probs_to_mu_sigma(c1)
+        variances = (sigma[:, :, 0, 0] ** 2 + sigma[:, :, 1, 1] ** 2).sum(dim=1).mean()
+        for i in range(sigma.shape[1]):
+            log["sigma1_{:02d}".format(i)] = sigma[0, i, 0, 0]
+            log["sigma2_{:02d}".format(i)] = sigma[0, i, 1, 1]
+    else:
+        c1 = spatial_softmax(torch.softmax(o["l1"], dim=-1) * gamma) * (1 - o["rect1"]).detach()
+        _, sigma = probs_to_mu_sigma(c1)
+        variances = (sigma[:, :, 0, 0] + sigma[:, :, 1, 1]).sum(dim=1).mean()
     w_var = make_var(step, config["variance_weight"])
     log["variance_loss_weighted"] = w_var * variances; log["variance_loss"] = variances
     log["variance_weight"] = w_var
@@ -544,26 +585,43 @@ def losses(o, config, state, step, vp, perceptual_mode="native", vgg_depths=VGG_
     L["encoder_0"] = auto_rec_loss; L["encoder_1"] = auto_rec_loss; L["decoder_delta"] = auto_rec_loss
     extra = OrderedDict()       # loss_k - auto_rec_loss, built explicitly (merged-gradient scheme)
 
-    # M:744-769 (alpha = 1, lambda = 1e-2 hard-coded at the call site)
-    g = squared_grad(o["m0"])
-    r = torch.clamp(g, max=1.0e-2)
-    smooth = torch.where(g < 1.0e-2, r, torch.zeros_like(r))
-    contour = torch.where(g >= 1.0e-2, r, torch.zeros_like(r))
-    sq = lambda t: (t.sum(dim=(1, 2)) ** 2).sum(dim=1).mean()
-    p_mumford_sha = w_ms * sq(r)
-    area_cost = 1.0e-12 * sq(o["m0"])
-    # M:771-783
-    patch_loss = (o["hard0"] * (1 - o["rect0"]).detach()).sum(dim=(1, 2, 3)).mean()
-    w_patch = make_var(step, config["patch_loss_weight"])
-    log["patch_loss"] = patch_loss; log["patch_loss_weight"] = w_patch
-    log["patch_loss_weighted"] = patch_loss * w_patch
-
-    if not config.get("pretrain", False):                    # M:785-797
-        extra["decoder_visualize"] = (w_gmrf * prior_gmrf + w_kl * mask0_kl + weakly * w_weak
-                                      + w_var * variances + p_mumford_sha + area_cost + patch_loss * w_patch)
-        L["decoder_visualize"] = auto_rec_loss + extra["decoder_visualize"]
+    if df:
+        # DF:719-722, 1112-1114, deepfashion/code/nn.py:1388-1391,1451-1455: Mumford-Shah on the noise-free LOGITS,
+        # alpha / lambda from the yaml schedules, summed (not squared) per image
+        ms_alpha, ms_lambda = log["mumford_sha_alpha"], log["mumford_sha_lambda"]
+        prior_ms = torch.clamp(ms_alpha * squared_grad(o["l0_mean"]), max=ms_lambda).sum(dim=(1, 2, 3)).mean()
+        log["prior_mumford_sha"] = prior_ms; log["prior_mumford_sha_weight"] = w_ms
+        log["prior_mumford_sha_weighted"] = prior_ms * w_ms
+        L["encoder_0"] = auto_rec_loss + global_rec           # DF:809-814 (the extra term has no path to these keys:
+        L["encoder_1"] = auto_rec_loss + global_rec           #  d_single's input is under stop_gradient)
+        L["d_single"], L["d_alpha"], L["d_pi"] = global_rec, alpha_rec, pi_rec
+        if not config.get("pretrain", False):                # DF:830-838
+            extra["decoder_visualize"] = (w_gmrf * prior_gmrf + prior_ms * w_ms + w_kl * mask0_kl + weakly * w_weak
+                                          + w_var * variances)
+            L["decoder_visualize"] = auto_rec_loss + extra["decoder_visualize"]
+        else:
+            L["decoder_visualize"] = auto_rec_loss
     else:
-        L["decoder_visualize"] = auto_rec_loss
+        # M:744-769 (alpha = 1, lambda = 1e-2 hard-coded at the call site)
+        g = squared_grad(o["m0"])
+        r = torch.clamp(g, max=1.0e-2)
+        smooth = torch.where(g < 1.0e-2, r, torch.zeros_like(r))
+        contour = torch.where(g >= 1.0e-2, r, torch.zeros_like(r))
+        sq = lambda t: (t.sum(dim=(1, 2)) ** 2).sum(dim=1).mean()
+        p_mumford_sha = w_ms * sq(r)
+        area_cost = 1.0e-12 * sq(o["m0"])
+        # M:771-783
+        patch_loss = (o["hard0"] * (1 - o["rect0"]).detach()).sum(dim=(1, 2, 3)).mean()
+        w_patch = make_var(step, config["patch_loss_weight"])
+        log["patch_loss"] = patch_loss; log["patch_loss_weight"] = w_patch
+        log["patch_loss_weighted"] = patch_loss * w_patch
+
+        if not config.get("pretrain", False):                    # M:785-797
+            extra["decoder_visualize"] = (w_gmrf * prior_gmrf + w_kl * mask0_kl + weakly * w_weak
+                                          + w_var * variances + p_mumford_sha + area_cost + patch_loss * w_patch)
+            L["decoder_visualize"] = auto_rec_loss + extra["decoder_visualize"]
+        else:
+            L["decoder_visualize"] = auto_rec_loss
 
     # M:800-834
     sp = F.softplus
@@ -635,9 +693,10 @@ def losses(o, config, state, step, vp, perceptual_mode="native", vgg_depths=VGG_
     log["avg_dis0_accuracy"] = state["avg_acc0"]; log["avg_dis1_accuracy"] = state["avg_acc1"]
     log["avg_loss_dis0"] = state["avg_loss_dis0"]; log["avg_loss_dis1"] = state["avg_loss_dis1"]
     log["mi_constraint"] = mim; log["independent_mi_constraint"] = ind_mim
-    log["zr_mumford_sha"] = p_mumford_sha
-    log["z_mumford_sha_smoothness_cost"] = sq(smooth); log["z_mumford_sha_contour_cost"] = sq(contour)
-    log["z_area_cost"] = area_cost; log["prior_mumford_sha_weight"] = w_ms
+    if not df:
+        log["zr_mumford_sha"] = p_mumford_sha
+        log["z_mumford_sha_smoothness_cost"] = sq(smooth); log["z_mumford_sha_contour_cost"] = sq(contour)
+        log["z_area_cost"] = area_cost; log["prior_mumford_sha_weight"] = w_ms
     # pieces reused by the merged-gradient scheme
     log["_auto_rec_loss"] = auto_rec_loss
     log["_extra"] = extra
@@ -748,5 +807,5 @@ def synthetic_noise(config, seed=4321, batch=None):
     B = batch or config["batch_size"]; S = config["spatial_size"]
     Z = config.get("z0_size", 256); P = config["n_parts"]
     g = torch.Generator(); g.manual_seed(seed)
-    return {"eps_pi0": torch.randn(7, B, Z, generator=g), "eps_pi1": torch.randn(B, Z, generator=g),
+    return {"eps_pi0": torch.randn(9 if is_48c(config) else 7, B, Z, generator=g), "eps_pi1": torch.randn(B, Z, generator=g),
             "eps_l0": torch.randn(B, S, S, P, generator=g), "eps_l1": torch.randn(B, S, S, P, generator=g)}

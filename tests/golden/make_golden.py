@@ -1,5 +1,5 @@
 """Generates tests/golden/tiny_step.npz (CUB yaml) and tiny_step_pennaction.npz (PennAction yaml: encoder1 with
-CoordConv, mi_target 1.5) from the CPU oracle (fp64) on the tiny config:
+CoordConv, mi_target 1.5) / tiny_step_deepfashion.npz (SB_model48c variant) from the CPU oracle (fp64) on the tiny config:
 inputs (views, every noise tensor), forward outputs, all loss scalars, per-key gradients
 (full tensors for small variables, norms for all), parameters after 1 and 2 TF-Adam steps and the
 Lagrangian / EMA state.  The reference itself cannot be imported here (TensorFlow 1.14 / edflow absent),
@@ -39,8 +39,9 @@ def main(variant="cub"):
             out[pre + k] = o[k].detach().float().numpy()
         out[pre + "hard0"] = R.hard_max(o["m0"]).numpy().astype(np.uint8)
         out[pre + "hard1"] = R.hard_max(o["m1"]).numpy().astype(np.uint8)
-        out[pre + "px0"] = o["px0"].numpy().astype(np.int32)
-        out[pre + "px1"] = o["px1"].numpy().astype(np.int32)
+        if o["px0"] is not None:
+            out[pre + "px0"] = o["px0"].numpy().astype(np.int32)
+            out[pre + "px1"] = o["px1"].numpy().astype(np.int32)
         out[pre + "out_parts_hard"] = o["out_parts_hard"].numpy().astype(np.int32)
         for k, v in L.items():
             out[pre + "loss_" + k] = np.float64(float(v))
@@ -51,7 +52,7 @@ def main(variant="cub"):
         out[pre + "grad_names"] = np.array(names)
         out[pre + "grad_norms"] = np.array([float(grads[n].norm()) for n in names])
         out[pre + "param_norms"] = np.array([float(p[n].double().norm()) for n in names])
-        for n in FULL:
+        for n in FULL + (("d_single/conv2d_0/V", "d_alpha/conv2d_3/V", "d_pi/conv2d_6/V") if variant == "deepfashion" else ()):
             out[pre + "grad/" + n] = grads[n].float().numpy()
             out[pre + "param/" + n] = p[n].float().numpy()
         for k, v in state.items():
@@ -62,5 +63,5 @@ def main(variant="cub"):
 
 
 if __name__ == "__main__":
-    for v in (sys.argv[1:] or ["cub", "pennaction"]):
+    for v in (sys.argv[1:] or ["cub", "pennaction", "deepfashion"]):
         main(v)
