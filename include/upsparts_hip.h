@@ -179,10 +179,10 @@ int ups_part_softmax_fwd(const float* mean, const float* eps, float* l, float* m
                          int64_t pixels, int32_t P, void* stream);
 /* spatial soft-max moments (N:65-71, N:1541-1587) of gamma*x per (n,p) over H*W, optionally masked by
  * (1 - rect) with integer rectangle centres `rect_c` [n*P][2] (y,x) and half sizes:
- * stats[n][p] = {max, Z, sum e*k, sum e*k*gy, sum e*k*gx, sum e*k*(gy^2+gx^2), 0, 0},  e = exp(gamma*x - max) */
+ * stats[n][p] = {max, Z, sum e*k, sum e*k*gy, sum e*k*gx, sum e*k*(gy^2+gx^2), sum e*k*gy^2, 0},  e = exp(gamma*x - max) */
 int ups_spatial_moments(const float* x, int32_t n, int32_t h, int32_t w, int32_t P, float gamma,
                         const int32_t* rect_c, int32_t half_h, int32_t half_w, float* stats, void* stream);
-/* `stats` must hold n*P*8 floats of result followed by n*8*P*6 floats of scratch (ups_spatial_moments_floats). */
+/* `stats` must hold n*P*8 floats of result followed by n*8*P*8 floats of scratch (ups_spatial_moments_floats). */
 size_t ups_spatial_moments_floats(int32_t n, int32_t P);
 /* px[n*P][2] = int32(mu*h/2 + h/2) (M:441,459; truncation) from the un-masked stats */
 int ups_moments_to_px(const float* stats, int32_t count, int32_t h, int32_t* px, void* stream);
@@ -221,6 +221,11 @@ typedef struct {
     float* sums;                  /* [16] global sums (zeroed by the call) */
     const float* g_hard;          /* upstream gradient w.r.t. the STE hard mask or NULL (bwd) */
     float* dl;                    /* d total / d l_mean (bwd); l = l_mean + eps, so the gmrf term is fused in */
+    int32_t variant;              /* 0: cub/pennaction SB_model48i; 1: deepfashion SB_model48c (DF:719-776): no rectangles
+                                   * (px may be NULL), view 0 adds w_ms_logits * mean_b sum min(ms_alpha * g(l_mean), ms_lambda)
+                                   * (deepfashion/code/nn.py:1388-1391,1451-1455; its sum is returned in sums[2], the patch slot),
+                                   * view 1 variance = sum_p (S00^2 + S11^2) of the renormalised, un-masked spatial soft-max */
+    float w_ms_logits;
 } ups_prior_desc;
 /* `sums` must hold 16 floats of result followed by scratch; total = ups_prior_sums_floats(n, P). */
 size_t ups_prior_sums_floats(int32_t n, int32_t P);
@@ -229,7 +234,7 @@ int ups_prior_bwd(const ups_prior_desc* d, void* stream);
 
 /* ---------------------------------------------------------------- full-covariance latent (N:1134-1208, util.py:878-995)
  * params [B][dim + dim(dim+1)/2] fp32.  samples[s][b][i] = mean + L (level[s]*eps[s][b]) ; kl_rows[b][i]. */
-/* `level` is a HOST array of S noise levels (S <= 8).  kl_rows may be NULL. */
+/* `level` is a HOST array of S noise levels (S <= 12).  kl_rows may be NULL. */
 int ups_latent_fwd(const float* params, const float* eps, const float* level, int32_t S, int32_t B, int32_t dim,
                    float* samples, float* kl_rows, void* stream);
 /* g_params = J^T g_samples + gk * d(sum_i kl_rows[b][i])/d params, gk = g_kl_scale * (g_kl_dev ? *g_kl_dev : 1) */

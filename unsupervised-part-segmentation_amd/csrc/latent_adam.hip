@@ -18,7 +18,7 @@ extern "C" int ups_abi_version(void) { return UPS_ABI_VERSION; }
 
 namespace {
 
-constexpr int MAXS = 8;
+constexpr int MAXS = 12;
 
 // index into the triangular parameter vector x (length m = n(n+1)/2) of element (i, j<=i) of
 // fill_triangular(x) (util.py:981-993): row-major position q of concat(x[n:], reverse(x))

@@ -44,17 +44,17 @@ __global__ void part_softmax_kernel(const float* __restrict__ mean, const float*
 }
 
 // ------------------------------------------------------------------ spatial soft-max moments (nn.py:65-71, 1541-1587)
-// partial[n][slab][p][6] = {max, Z, S0, Sy, Sx, Q} relative to the slab max
+// partial[n][slab][p][8] = {max, Z, S0, Sy, Sx, Q, Qy, -} relative to the slab max (Q = sum e*k*(gy^2+gx^2), Qy = sum e*k*gy^2)
 template <int GP>
 __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ x, int h, int w, int P, float gamma,
                                                               const int* __restrict__ rc, int hh, int hw_half,
                                                               int rows_per_slab, float* __restrict__ partial) {
     constexpr int PL = 256 / GP;
-    __shared__ float red[PL][GP][6];
+    __shared__ float red[PL][GP][7];
     const int n = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
     const int c = threadIdx.x % GP, pl = threadIdx.x / GP;
     const int y0 = slab * rows_per_slab, y1 = min(h, y0 + rows_per_slab);
-    float mx = -INFINITY, Z = 0.f, S0 = 0.f, Sy = 0.f, Sx = 0.f, Q = 0.f;
+    float mx = -INFINITY, Z = 0.f, S0 = 0.f, Sy = 0.f, Sx = 0.f, Q = 0.f, Qy = 0.f;
     int cy = 0, cx = 0;
     if (rc && c < P) { cy = rc[((long long)n * P + c) * 2]; cx = rc[((long long)n * P + c) * 2 + 1]; }
     if (c < P) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
             const float v = gamma * x[((long long)n * h * w + px) * P + c];
             if (v > mx) {
                 const float sc = expf(mx - v);  // exp(-inf) = 0 on the first element
-                Z *= sc; S0 *= sc; Sy *= sc; Sx *= sc; Q *= sc;
+                Z *= sc; S0 *= sc; Sy *= sc; Sx *= sc; Q *= sc; Qy *= sc;
                 mx = v;
             }
             const float e = expf(v - mx);
@@ -73,23 +73,25 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
             if (rc && abs(yy - cy) <= hh && abs(xx - cx) <= hw_half) k = 0.f;
             const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
             const float ek = e * k;
-            S0 += ek; Sy += ek * gy; Sx += ek * gx; Q += ek * (gy * gy + gx * gx);
+            S0 += ek; Sy += ek * gy; Sx += ek * gx; Q += ek * (gy * gy + gx * gx); Qy += ek * gy * gy;
         }
     }
     red[pl][c][0] = mx; red[pl][c][1] = Z; red[pl][c][2] = S0; red[pl][c][3] = Sy; red[pl][c][4] = Sx; red[pl][c][5] = Q;
+    red[pl][c][6] = Qy;
     __syncthreads();
     if (pl == 0 && c < P) {
         float M = mx;
         for (int q = 1; q < PL; ++q) M = fmaxf(M, red[q][c][0]);
-        float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int q = 0; q < PL; ++q) {
             const float mq = red[q][c][0];
             const float sc = (mq == -INFINITY) ? 0.f : expf(mq - M);
-            for (int k = 0; k < 5; ++k) o[k] += sc * red[q][c][1 + k];
+            for (int k = 0; k < 6; ++k) o[k] += sc * red[q][c][1 + k];
         }
-        float* dst = partial + (((long long)n * nslab + slab) * P + c) * 6;
+        float* dst = partial + (((long long)n * nslab + slab) * P + c) * 8;
         dst[0] = M;
-        for (int k = 0; k < 5; ++k) dst[1 + k] = o[k];
+        for (int k = 0; k < 6; ++k) dst[1 + k] = o[k];
+        dst[7] = 0.f;
     }
 }
 
@@ -98,15 +100,15 @@ __global__ void moments_combine_kernel(const float* __restrict__ partial, int co
     if (idx >= count_n * P) return;
     const int n = idx / P, c = idx - n * P;
     float M = -INFINITY;
-    for (int s = 0; s < nslab; ++s) M = fmaxf(M, partial[(((long long)n * nslab + s) * P + c) * 6]);
-    float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nslab; ++s) M = fmaxf(M, partial[(((long long)n * nslab + s) * P + c) * 8]);
+    float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < nslab; ++s) {
-        const float* src = partial + (((long long)n * nslab + s) * P + c) * 6;
+        const float* src = partial + (((long long)n * nslab + s) * P + c) * 8;
         const float sc = (src[0] == -INFINITY) ? 0.f : expf(src[0] - M);
-        for (int k = 0; k < 5; ++k) o[k] += sc * src[1 + k];
+        for (int k = 0; k < 6; ++k) o[k] += sc * src[1 + k];
     }
     float* d = stats + (long long)idx * 8;
-    d[0] = M; d[1] = o[0]; d[2] = o[1]; d[3] = o[2]; d[4] = o[3]; d[5] = o[4]; d[6] = 0.f; d[7] = 0.f;
+    d[0] = M; d[1] = o[0]; d[2] = o[1]; d[3] = o[2]; d[4] = o[3]; d[5] = o[4]; d[6] = o[5]; d[7] = 0.f;
 }
 
 __global__ void moments_to_px_kernel(const float* __restrict__ stats, int count, int h, int* __restrict__ px) {
@@ -322,7 +324,7 @@ extern "C" int ups_spatial_moments(const float* x, int32_t n, int32_t h, int32_t
     return UPS_OK;
 }
 
-extern "C" size_t ups_spatial_moments_floats(int32_t n, int32_t P) { return (size_t)n * P * 8 + (size_t)n * 8 * P * 6; }
+extern "C" size_t ups_spatial_moments_floats(int32_t n, int32_t P) { return (size_t)n * P * 8 + (size_t)n * 8 * P * 8; }
 extern "C" size_t ups_unpool_bwd_floats(int32_t B, int32_t P, int32_t F) { return (size_t)B * P * F * (1 + UNPOOL_SLABS); }
 
 extern "C" int ups_moments_to_px(const float* stats, int32_t count, int32_t h, int32_t* px, void* stream) {

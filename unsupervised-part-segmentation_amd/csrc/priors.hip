@@ -21,8 +21,8 @@ namespace {
 constexpr int NSLAB = 8;
 
 struct PriorK {
-    int n, h, w, P, view, entropy_ce, half_h, half_w;
-    float gamma, ms_alpha, ms_lambda, w_kl, w_entropy, w_ms, w_area, w_patch, w_gmrf, w_var;
+    int n, h, w, P, view, entropy_ce, half_h, half_w, variant;
+    float gamma, ms_alpha, ms_lambda, w_kl, w_entropy, w_ms, w_area, w_patch, w_gmrf, w_var, w_msl;
     const float* l; const float* l_mean; const float* m; const float* hard; const int* px;
     float* per_np; float* sums; const float* g_hard; float* dl; float* ws;
 };
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void prior_fwd_kernel(const PriorK p, int rows
     float kl = 0.f, ent = 0.f, patch = 0.f, gmrf = 0.f;
     float S = 0.f, R = 0.f, Rs = 0.f, Rc = 0.f;
     int cy = 0, cx = 0;
-    if (p.view == 0 && cok) { cy = p.px[((long long)n * p.P + c) * 2]; cx = p.px[((long long)n * p.P + c) * 2 + 1]; }
+    if (p.view == 0 && cok && p.px) { cy = p.px[((long long)n * p.P + c) * 2]; cx = p.px[((long long)n * p.P + c) * 2 + 1]; }
     const int npix = (y1 - y0) * p.w;
     const int iters = (npix + PL - 1) / PL;
     for (int it = 0; it < iters; ++it) {
@@ -79,9 +79,17 @@ __global__ __launch_bounds__(256) void prior_fwd_kernel(const PriorK p, int rows
                 const float hv = p.hard[pix * p.P + c];
                 const float lab = p.entropy_ce ? hv : mc;
                 ent += -lab * s;
-                const bool in_rect = abs(yy - cy) <= p.half_h && abs(xx - cx) <= p.half_w;
-                patch += hv * (in_rect ? 0.f : 1.f);
                 const float lm = p.l_mean[pix * p.P + c];
+                if (p.variant == 0) {
+                    const bool in_rect = abs(yy - cy) <= p.half_h && abs(xx - cx) <= p.half_w;
+                    patch += hv * (in_rect ? 0.f : 1.f);
+                } else {
+                    // SB_model48c: Mumford-Shah on the noise-free logits, min(alpha * g, lambda) summed (patch slot)
+                    const float lr = mval(p.l_mean, img, yy, xx + 1, p.h, p.w, p.P, c);
+                    const float ld = mval(p.l_mean, img, yy + 1, xx, p.h, p.w, p.P, c);
+                    const float gw = 0.25f * (lm - lr), gh = 0.25f * (lm - ld);
+                    patch += fminf(p.ms_alpha * (gw * gw + gh * gh), p.ms_lambda);
+                }
                 if (yy + 1 < p.h) { const float d = p.l_mean[(pix + p.w) * p.P + c] - lm; gmrf += 0.5f * d * d; }
                 if (xx + 1 < p.w) { const float d = p.l_mean[(pix + 1) * p.P + c] - lm; gmrf += 0.5f * d * d; }
                 const float mr = mval(p.m, img, yy, xx + 1, p.h, p.w, p.P, c);
@@ -177,9 +185,11 @@ __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p) {
             direct += p.w_entropy * inv_pix * (-mc * (s - qs));
             if (p.entropy_ce) direct += p.w_entropy * inv_pix * (-(hv - mc * labsum));
             // patch (STE)
-            const int cy = p.px[((long long)n * p.P + c) * 2], cx = p.px[((long long)n * p.P + c) * 2 + 1];
-            const bool in_rect = abs(yy - cy) <= p.half_h && abs(xx - cx) <= p.half_w;
-            gm += p.w_patch * inv_n * (in_rect ? 0.f : 1.f);
+            if (p.variant == 0) {
+                const int cy = p.px[((long long)n * p.P + c) * 2], cx = p.px[((long long)n * p.P + c) * 2 + 1];
+                const bool in_rect = abs(yy - cy) <= p.half_h && abs(xx - cx) <= p.half_w;
+                gm += p.w_patch * inv_n * (in_rect ? 0.f : 1.f);
+            }
             // area + mumford-shah
             const float* np = p.per_np + ((long long)n * p.P + c) * 8;
             gm += p.w_area * inv_n * 2.f * np[0];
@@ -206,6 +216,29 @@ __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p) {
             gm += p.w_ms * inv_n * 2.f * np[1] * dR;
             // gmrf on the noise-free logits (same tensor path: l = l_mean + eps)
             const float lm = p.l_mean[pp * p.P + c];
+            if (p.variant == 1) {
+                // SB_model48c: d/d l_mean of sum min(alpha * g(l_mean), lambda): the stencil above applied to the logits
+                const float l_r = mval(p.l_mean, img, yy, xx + 1, p.h, p.w, p.P, c);
+                const float l_d = mval(p.l_mean, img, yy + 1, xx, p.h, p.w, p.P, c);
+                float dL = 0.f;
+                {
+                    const float g = a16 * ((lm - l_r) * (lm - l_r) + (lm - l_d) * (lm - l_d));
+                    if (g <= p.ms_lambda) dL += a8 * ((lm - l_r) + (lm - l_d));
+                }
+                if (xx > 0) {
+                    const float l_l = mval(p.l_mean, img, yy, xx - 1, p.h, p.w, p.P, c);
+                    const float l_ld = mval(p.l_mean, img, yy + 1, xx - 1, p.h, p.w, p.P, c);
+                    const float g = a16 * ((l_l - lm) * (l_l - lm) + (l_l - l_ld) * (l_l - l_ld));
+                    if (g <= p.ms_lambda) dL -= a8 * (l_l - lm);
+                }
+                if (yy > 0) {
+                    const float l_u = mval(p.l_mean, img, yy - 1, xx, p.h, p.w, p.P, c);
+                    const float l_ur = mval(p.l_mean, img, yy - 1, xx + 1, p.h, p.w, p.P, c);
+                    const float g = a16 * ((l_u - l_ur) * (l_u - l_ur) + (l_u - lm) * (l_u - lm));
+                    if (g <= p.ms_lambda) dL -= a8 * (l_u - lm);
+                }
+                direct += p.w_msl * inv_n * dL;
+            }
             float gg = 0.f;
             if (yy > 0) gg += lm - p.l_mean[(pp - p.w) * p.P + c];
             if (yy + 1 < p.h) gg -= p.l_mean[(pp + p.w) * p.P + c] - lm;
@@ -213,6 +246,18 @@ __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p) {
             if (xx + 1 < p.w) gg -= p.l_mean[(pp + 1) * p.P + c] - lm;
             direct += p.w_gmrf * inv_n * gg;
         }
+    } else if (ok && p.variant == 1) {
+        // SB_model48c variance (DF:750-776): v_np = S00^2 + S11^2 of c = softmax_hw(gamma*m) (no rectangle, renormalised),
+        // S00 = Qy/Z - muy^2, S11 = Qx/Z - mux^2
+        const float* st = p.per_np + ((long long)n * p.P + c) * 8;
+        const float Z = st[1], muy = st[3] / Z, mux = st[4] / Z, Qyn = st[6] / Z, Qxn = (st[5] - st[6]) / Z;
+        const float S00 = Qyn - muy * muy, S11 = Qxn - mux * mux;
+        const float sy = p.h > 1 ? 2.f / (float)(p.h - 1) : 0.f, sx = p.w > 1 ? 2.f / (float)(p.w - 1) : 0.f;
+        const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
+        const float ay = gy * gy - 2.f * muy * gy - (Qyn - 2.f * muy * muy);
+        const float ax = gx * gx - 2.f * mux * gx - (Qxn - 2.f * mux * mux);
+        const float sq = expf(p.gamma * mc - st[0]) / Z;
+        gm += p.w_var * inv_n * p.gamma * sq * 2.f * (S00 * ay + S11 * ax);
     } else if (ok) {
         // variance: v_np = Q/Z - muy^2 - mux^2 over c = softmax_hw(gamma*m) * (1-rect)
         const float* st = p.per_np + ((long long)n * p.P + c) * 8;
@@ -237,7 +282,7 @@ PriorK to_k(const ups_prior_desc* d, float* ws) {
     k.n = d->n; k.h = d->h; k.w = d->w; k.P = d->P; k.view = d->view; k.entropy_ce = d->entropy_ce;
     k.half_h = d->half_h; k.half_w = d->half_w; k.gamma = d->gamma; k.ms_alpha = d->ms_alpha; k.ms_lambda = d->ms_lambda;
     k.w_kl = d->w_kl; k.w_entropy = d->w_entropy; k.w_ms = d->w_ms; k.w_area = d->w_area; k.w_patch = d->w_patch;
-    k.w_gmrf = d->w_gmrf; k.w_var = d->w_var;
+    k.w_gmrf = d->w_gmrf; k.w_var = d->w_var; k.variant = d->variant; k.w_msl = d->w_ms_logits;
     k.l = d->l; k.l_mean = d->l_mean; k.m = d->m; k.hard = d->hard; k.px = d->px; k.per_np = d->per_np; k.sums = d->sums;
     k.g_hard = d->g_hard; k.dl = d->dl; k.ws = ws;
     return k;
@@ -250,7 +295,7 @@ extern "C" size_t ups_prior_sums_floats(int32_t n, int32_t P) { return 16 + (siz
 // workspace convention: `sums` points at 16 floats followed by n*NSLAB*4 + n*NSLAB*P*4 floats of scratch.
 extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
     UPS_CHECK_ARG(d && d->m && d->sums && d->P >= 1 && d->P <= 64 && d->n > 0);
-    UPS_CHECK_ARG(d->view == 1 || (d->l && d->l_mean && d->hard && d->px && d->per_np));
+    UPS_CHECK_ARG(d->view == 1 || (d->l && d->l_mean && d->hard && (d->px || d->variant == 1) && d->per_np));
     hipStream_t s = (hipStream_t)stream;
     PriorK k = to_k(d, d->sums + 16);
     const int rows = ups_cdiv(d->h, NSLAB);
@@ -268,7 +313,7 @@ extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
 }
 
 extern "C" int ups_prior_bwd(const ups_prior_desc* d, void* stream) {
-    UPS_CHECK_ARG(d && d->m && d->dl && d->per_np && d->px && d->P >= 1 && d->P <= 64);
+    UPS_CHECK_ARG(d && d->m && d->dl && d->per_np && (d->px || d->variant == 1) && d->P >= 1 && d->P <= 64);
     UPS_CHECK_ARG(d->view == 1 || (d->l && d->l_mean && d->hard));
     hipStream_t s = (hipStream_t)stream;
     PriorK k = to_k(d, nullptr);

@@ -51,6 +51,7 @@ class TrainModel(object):
         prec = str(config.get("precision", "bf16")).lower()
         self.act_dtype = torch.float32 if prec in ("fp32", "f32", "float32") else torch.bfloat16
         self.patch_size = config.get("patch_size", 32)
+        self.df = N.is_48c(config)          # DeepFashion SB_model48c variant (two inputs, no rectangles, extra decoders)
         self.nets = N.Nets(config, self.device, seed if seed is not None else config.get("seed", 0))
         self.bank = self.nets.bank
         self._last = {}
@@ -59,7 +60,8 @@ class TrainModel(object):
     @property
     def inputs(self):
         B, S = self.config["batch_size"], self.config["spatial_size"]
-        return {k: (B, S, S, 3) for k in ("view0", "view1", "view0_target")}
+        names = ("view0", "view1") if self.df else ("view0", "view1", "view0_target")     # SB_model48c:253
+        return {k: (B, S, S, 3) for k in names}
 
     @property
     def variables(self):
@@ -157,7 +159,7 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ edflow hook surface
     def loss_keys(self):
-        keys = list(N.SUBMODULES)
+        keys = list(N.submodules(self.config))
         for k in self.config.get("fix_weights", []):      # model.py:1062-1067
             if k in keys:
                 keys.remove(k)
@@ -212,7 +214,8 @@ class Trainer(object):
         cfg = self.config
         S, P, Z = cfg["spatial_size"], self.model.n_parts, cfg.get("z0_size", 256)
         r = lambda *s: torch.randn(*s, generator=self._gen, device=self.device, dtype=torch.float32)
-        return {"eps_pi0": r(7, B, Z), "eps_pi1": r(B, Z), "eps_l0": r(B, S, S, P), "eps_l1": r(B, S, S, P)}
+        return {"eps_pi0": r(9 if self.model.df else 7, B, Z), "eps_pi1": r(B, Z), "eps_l0": r(B, S, S, P),
+                "eps_l1": r(B, S, S, P)}
 
     def learning_rate(self):
         cfg = self.config
@@ -223,10 +226,17 @@ class Trainer(object):
     def _prior(self, view, n, S, P, l, lm, m, hard, px, per_np, sums, w, g_hard=None, dl=None, bwd=False):
         d = L.PriorDesc()
         d.n, d.h, d.w, d.P, d.view = n, S, S, P, view
-        d.entropy_ce = int(self.config.get("entropy_func", "cross_entropy") == "cross_entropy")
-        d.gamma = float(self.config.get("gamma", 3.0))
         d.half_h = d.half_w = self.model.patch_size // 2
-        d.ms_alpha, d.ms_lambda = 1.0, 1.0e-2                      # hard-coded at model.py:744-746
+        if self.model.df:        # SB_model48c:719-776: CE labels always, no gamma, alpha / lambda from the yaml schedules
+            d.variant, d.entropy_ce, d.gamma = 1, 1, 1.0
+            d.ms_alpha = make_var(self.global_step, self.config["mumford_sha_alpha"])
+            d.ms_lambda = make_var(self.global_step, self.config["mumford_sha_lambda"])
+            d.w_ms_logits = w.get("msl", 0.0)
+        else:
+            d.variant = 0
+            d.entropy_ce = int(self.config.get("entropy_func", "cross_entropy") == "cross_entropy")
+            d.gamma = float(self.config.get("gamma", 3.0))
+            d.ms_alpha, d.ms_lambda = 1.0, 1.0e-2                  # hard-coded at model.py:744-746
         d.w_kl, d.w_entropy, d.w_ms, d.w_area = w["kl"], w["entropy"], w["ms"], w["area"]
         d.w_patch, d.w_gmrf, d.w_var = w["patch"], w["gmrf"], w["var"]
         g = lambda t: t.data_ptr() if t is not None else None
@@ -242,7 +252,8 @@ class Trainer(object):
         keys = self.loss_keys()
         v0 = batch["view0"].to(dev, torch.float32).contiguous()
         v1 = batch["view1"].to(dev, torch.float32).contiguous()
-        vt = batch["view0_target"].to(dev, torch.float32).contiguous()
+        df = model.df
+        vt = v0 if df else batch["view0_target"].to(dev, torch.float32).contiguous()    # SB_model48c:669: target = view0
         B, S = v0.shape[0], v0.shape[1]
         Z, A, P = cfg.get("z0_size", 256), cfg.get("local_app_size", 64), model.n_parts
         gamma = float(cfg.get("gamma", 3.0))
@@ -259,7 +270,7 @@ class Trainer(object):
         w_kl = make_linear_var(step, **cfg["kl_weight"])
         w_var = make_var(step, cfg["variance_weight"])
         w_weak = make_var(step, cfg["weakly_superv_loss_weight_p"])
-        w_patch = make_var(step, cfg["patch_loss_weight"])
+        w_patch = 0.0 if df else make_var(step, cfg["patch_loss_weight"])
         pretrain = bool(cfg.get("pretrain", False))
 
         # ================= A: pose encoder + latent (model.py:382-409)
@@ -269,6 +280,8 @@ class Trainer(object):
         pe_v0, pe_v1 = pe2[:B].contiguous(), pe2[B:].contiguous()
         lon = 1.0                                                         # LON_ADAPTIVE = False (model.py:842): lon stays 1
         levels0 = [1.0, lon, lon, 1.0, 1.0, 1.0, 1.0]                     # draw order model.py:406,506,509,512,514,518,520
+        if df:
+            levels0 += [1.0, 1.0]                                         # SB_model48c:492,502: two more draws of z_00
         samples0, kl_rows = ops.latent_fwd(pe_v0, noise["eps_pi0"], levels0, True)
         samples1, _ = ops.latent_fwd(pe_v1, noise["eps_pi1"][None], [1.0], False)
         bottleneck = kl_rows.sum(dim=1).mean()                            # nn.py:1196-1208
@@ -318,6 +331,19 @@ class Trainer(object):
                     ps = [bank.params[n] for n in bank.groups[name]["names"]]
                     torch.autograd.grad([crit[name][0]], ps)
 
+            if df:
+                # SB_model48c:491-505, 672-684, 812-814: three single-sample decoders on batch item 0 (inputs under
+                # stop_gradient), each with its own perceptual loss and optimizer key
+                scale = 1e-3 * 0.5 * (S * S * 3)
+                a1 = alpha[B:B + 1, ..., :A].float().reshape(1, A)
+                ins = {"d_single": (torch.cat([samples0[7][:1], a1], 1), v0[:1], Z + A),
+                       "d_alpha": (a1, v1[:1], A), "d_pi": (samples0[8][:1], v0[:1], Z)}
+                for name, (zin, tgt, cz) in ins.items():
+                    g_img = nets.dsingle(name, Act(model.to_act(zin.view(1, 1, 1, cz)), 1, 1, 1, cz)).t
+                    lss = scale * self.vgg.loss(tgt.contiguous(), g_img, T)
+                    crit[name] = (lss, g_img)
+                    if name in keys:
+                        torch.autograd.grad([lss], [bank.params[n] for n in bank.groups[name]["names"]])
             return crit, adv, g_adv, mim, ind_mim
 
         main_stream = torch.cuda.current_stream(dev)
@@ -340,7 +366,8 @@ class Trainer(object):
         # ================= part path, untaped (model.py:414-473)
         eps_l = torch.cat([noise["eps_l0"], noise["eps_l1"]], 0)
         l, m, hard, _ = ops.part_softmax(lm, eps_l)
-        px = ops.moments_to_px(ops.spatial_moments(hard, gamma), S)       # [2B,P,2] rectangle centres (stop-gradient)
+        # [2B,P,2] rectangle centres (stop-gradient); SB_model48c has no rectangles
+        px = None if df else ops.moments_to_px(ops.spatial_moments(hard, gamma), S)
         hard0 = hard[:B].detach().requires_grad_(True)
         hard1 = hard[B:].detach().requires_grad_(True)
 
@@ -372,13 +399,19 @@ class Trainer(object):
         sums1 = torch.empty(nfl, dtype=torch.float32, device=dev)
         per_np0 = torch.empty((B, P, 8), dtype=torch.float32, device=dev)
         l0, l1, m0, m1 = l[:B], l[B:], m[:B], m[B:]
-        px0, px1 = px[:B].contiguous(), px[B:].contiguous()
-        wz = {"kl": 0.0, "entropy": 0.0, "ms": 0.0, "area": 0.0, "patch": 0.0, "gmrf": 0.0, "var": 0.0}
-        wp = dict(wz) if pretrain else {"kl": w_kl, "entropy": w_weak, "ms": w_ms, "area": 1.0e-12, "patch": w_patch,
-                                        "gmrf": w_gmrf, "var": w_var}
+        px0, px1 = (None, None) if df else (px[:B].contiguous(), px[B:].contiguous())
+        wz = {"kl": 0.0, "entropy": 0.0, "ms": 0.0, "area": 0.0, "patch": 0.0, "gmrf": 0.0, "var": 0.0, "msl": 0.0}
+        if pretrain:
+            wp = dict(wz)
+        elif df:     # SB_model48c:830-838
+            wp = {"kl": w_kl, "entropy": w_weak, "ms": 0.0, "area": 0.0, "patch": 0.0, "gmrf": w_gmrf, "var": w_var, "msl": w_ms}
+        else:
+            wp = {"kl": w_kl, "entropy": w_weak, "ms": w_ms, "area": 1.0e-12, "patch": w_patch, "gmrf": w_gmrf, "var": w_var,
+                  "msl": 0.0}
         self._prior(0, B, S, P, l0, lm[:B], m0, hard[:B], px0, per_np0, sums0, wp)
         self._prior(1, B, S, P, l1, None, m1, None, px1, None, sums1, wp)
-        stats_v = ops.spatial_moments(m1.contiguous(), gamma, rect_px=px1, half=half)     # variance moments (model.py:683-707)
+        # variance moments (model.py:683-707; SB_model48c:750-756: no gamma, no rectangle)
+        stats_v = ops.spatial_moments(m1.contiguous(), 1.0 if df else gamma, rect_px=px1, half=half)
         npx = float(B * S * S)
         prior_gmrf = sums0[3] / B
         mask0_kl = (sums0[0] + sums1[0]) / npx
@@ -387,9 +420,16 @@ class Trainer(object):
         p_ms = w_ms * sums0[4] / B
         area_cost = 1.0e-12 * sums0[5] / B
         Zs = stats_v[..., 1]
-        variances = (stats_v[..., 5] / Zs - (stats_v[..., 3] / Zs) ** 2 - (stats_v[..., 4] / Zs) ** 2).sum(dim=1).mean()
-        prior_total = (w_gmrf * prior_gmrf + w_kl * mask0_kl + weakly * w_weak + w_var * variances + p_ms + area_cost
-                       + patch_loss * w_patch)
+        if df:       # SB_model48c:757-776: squared diagonal variances of the (already normalised) maps
+            s00 = stats_v[..., 6] / Zs - (stats_v[..., 3] / Zs) ** 2
+            s11 = (stats_v[..., 5] - stats_v[..., 6]) / Zs - (stats_v[..., 4] / Zs) ** 2
+            variances = (s00 ** 2 + s11 ** 2).sum(dim=1).mean()
+            prior_ms = sums0[2] / B                                   # variant 1: the patch slot holds sum min(alpha g, lambda)
+            prior_total = w_gmrf * prior_gmrf + prior_ms * w_ms + w_kl * mask0_kl + weakly * w_weak + w_var * variances
+        else:
+            variances = (stats_v[..., 5] / Zs - (stats_v[..., 3] / Zs) ** 2 - (stats_v[..., 4] / Zs) ** 2).sum(dim=1).mean()
+            prior_total = (w_gmrf * prior_gmrf + w_kl * mask0_kl + weakly * w_weak + w_var * variances + p_ms + area_cost
+                           + patch_loss * w_patch)
 
         dl_tot = torch.empty_like(lm)
         dl_rec = torch.empty_like(lm)
@@ -408,7 +448,8 @@ class Trainer(object):
 
         # the critics' block (aux stream) must be complete from here on: g_adv, the critic losses and their gradients
         ops.Streams.join(dev, names=("aux",))
-        pending += self._launch_reduce([k for k in ("mi0_discriminator", "mi1_discriminator", "mi_estimator") if k in keys])
+        pending += self._launch_reduce([k for k in ("mi0_discriminator", "mi1_discriminator", "mi_estimator") + N.EXTRA_48C
+                                        if k in keys])
 
         # ================= A backward (model.py:739, 909, 930)
         bw = None
@@ -419,7 +460,7 @@ class Trainer(object):
             explor = torch.exp(st["lor"])
             bw = beta_0 * explor * bottleneck
         if "encoder_0" in keys:
-            g_s0 = torch.zeros((7, B, Z), dtype=torch.float32, device=dev)
+            g_s0 = torch.zeros((len(levels0), B, Z), dtype=torch.float32, device=dev)
             g_s0[0] = gz[:B]
             if g_adv is not None:
                 g_s0[1] = g_adv
@@ -457,6 +498,11 @@ class Trainer(object):
         Ls["decoder_delta"] = auto_rec
         Ls["decoder_visualize"] = auto_rec if pretrain else auto_rec + prior_total
         Ls["mi0_discriminator"], Ls["mi1_discriminator"], Ls["mi_estimator"] = loss_dis0, loss_dis1, loss_est
+        if df:       # SB_model48c:809-815 (the global term has no gradient path to the encoders: stop_gradient inputs)
+            Ls["encoder_0"] = Ls["encoder_0"] + crit["d_single"][0].detach()
+            Ls["encoder_1"] = Ls["encoder_1"] + crit["d_single"][0].detach()
+            for k in N.EXTRA_48C:
+                Ls[k] = crit[k][0]
         self.losses = OrderedDict((k, Ls[k].detach()) for k in keys)
         avg_mim = torch.clamp(st["avg_mim"], min=0.0); avg_ind = torch.clamp(st["avg_independent_mim"], min=0.0)
         loo = torch.clamp((avg_ind - avg_mim) / (avg_ind + 1e-6), 0.0, 1.0)
@@ -470,6 +516,9 @@ class Trainer(object):
                     "mumford_sha_alpha": make_var(step, cfg["mumford_sha_alpha"]),
                     "avg_acc_error": st["avg_acc_error"], "avg_mim": avg_mim, "avg_independent_mim": avg_ind,
                     "loo": loo, "lon_gain": -loo + 0.025, "model_lon": st["lon"]})
+        if df:
+            for k in ("patch_loss", "patch_loss_weight", "patch_loss_weighted"):
+                log.pop(k)
         for k in Ls:
             log["loss_" + k] = Ls[k].detach()
         log.update({"dis0_accuracy": acc0, "dis1_accuracy": acc1, "avg_dis0_accuracy": st["avg_acc0"],
@@ -483,9 +532,16 @@ class Trainer(object):
         if bw is not None:
             log.update({"bottleneck_weight": st["lor"], "bottleneck_loss": bottleneck, "bottleneck_weighted_loss": bw,
                         "lor": st["lor"], "explor": beta_0 * torch.exp(st["lor"]), "lor_gain": (ind_mim - MI_TARGET).detach()})
-        log.update({"zr_mumford_sha": p_ms, "z_mumford_sha_smoothness_cost": sums0[6] / B,
-                    "z_mumford_sha_contour_cost": sums0[7] / B, "z_area_cost": area_cost,
-                    "prior_mumford_sha_weight": w_ms, "perceptual": rec.detach(), "lr": self.learning_rate()})
+        if df:
+            log.update({"prior_mumford_sha": prior_ms, "prior_mumford_sha_weight": w_ms, "prior_mumford_sha_weighted": prior_ms * w_ms,
+                        "perceptual": rec.detach(), "lr": self.learning_rate()})
+            for i in range(P):
+                log["sigma1_{:02d}".format(i)] = s00[0, i]
+                log["sigma2_{:02d}".format(i)] = s11[0, i]
+        else:
+            log.update({"zr_mumford_sha": p_ms, "z_mumford_sha_smoothness_cost": sums0[6] / B,
+                        "z_mumford_sha_contour_cost": sums0[7] / B, "z_area_cost": area_cost,
+                        "prior_mumford_sha_weight": w_ms, "perceptual": rec.detach(), "lr": self.learning_rate()})
         self.log_ops = log
         self.state = new
         self.global_step += 1

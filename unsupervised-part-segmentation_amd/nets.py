@@ -18,7 +18,18 @@ from .ops import ConvLayer, round8
 
 SUBMODULES = ("encoder_0", "encoder_1", "decoder_delta", "decoder_visualize",
               "mi0_discriminator", "mi1_discriminator", "mi_estimator")
+EXTRA_48C = ("d_single", "d_alpha", "d_pi")      # deepfashion/code/SB_model48c/model.py:320-323, 809-815
 DSIZE = 512                     # model.py:10
+
+
+def is_48c(config):
+    """DeepFashion model variant (deepfashion/code/SB_model48c/model.py), selected by the yaml's ``model:`` path or an
+    explicit ``variant: sb48c`` key."""
+    return config.get("variant") == "sb48c" or "SB_model48c" in str(config.get("model", ""))
+
+
+def submodules(config):
+    return SUBMODULES + (EXTRA_48C if is_48c(config) else ())
 VGG_WIDTHS = (64, 128, 256, 512, 512)
 VGG_DEPTHS = (2, 2, 4, 4, 2)
 
@@ -40,12 +51,12 @@ class ParamBank(object):
     (params / grads / Adam m / Adam v) so that the optimizer and the DP all-reduce touch one
     contiguous range per sub-network.  ``specs``: name -> (shape, bound)."""
 
-    def __init__(self, specs, device, seed=0):
+    def __init__(self, specs, device, seed=0, keys=SUBMODULES):
         self.specs = specs
         self.device = device
         self.groups = OrderedDict()
         self.params, self.grads = OrderedDict(), OrderedDict()
-        for key in SUBMODULES:
+        for key in keys:
             names = [n for n in specs if key in n]      # edflow: var_list = [v for v in variables if key in v.name]
             total = sum(int(torch.Size(specs[n][0]).numel()) for n in names)
             flat = {k: torch.zeros(total, dtype=torch.float32, device=device) for k in ("p", "g", "m", "v")}
@@ -162,7 +173,7 @@ def encoder_model(sc, x, out_size, config, extra_resnets, out_f32=False):
     return sc.nin(h, out_size, out_f32=out_f32)
 
 
-def single_decoder_model(sc, z, n_out, config, upsample_config):
+def single_decoder_model(sc, z, n_out, config, upsample_config, out_f32=True):
     """model.py:134-156 (upsample 'linear' ignores num_units: nn.py:834-847)."""
     if isinstance(upsample_config, str):
         upsample_config = [upsample_config] * (len(config) - 1)
@@ -182,7 +193,7 @@ def single_decoder_model(sc, z, n_out, config, upsample_config):
         h = sc.residual_block(h)
         h = sc.upsample_linear(h)
     h = sc.residual_block(h)
-    return sc.conv2d(h, n_out, out_f32=True)
+    return sc.conv2d(h, n_out, out_f32=out_f32)
 
 
 def hourglass_model(sc, x, config, extra_resnets, n_out=3, upsample_method="subpixel"):
@@ -232,8 +243,12 @@ class Nets(object):
         self.dd(Act(None, 1, S, S, A + P))
         for name in ("mi0_discriminator", "mi1_discriminator", "mi_estimator"):
             self.critic(name, (Act(None, 1, 1, 1, Z), Act(None, 1, 1, 1, A)))
+        if is_48c(config):
+            self.dsingle("d_single", Act(None, 1, 1, 1, Z + A))
+            self.dsingle("d_alpha", Act(None, 1, 1, 1, A))
+            self.dsingle("d_pi", Act(None, 1, 1, 1, Z))
         self.dry = False
-        self.bank = ParamBank(self.specs, device, seed)
+        self.bank = ParamBank(self.specs, device, seed, keys=submodules(config))
 
     def _scope(self, name, kw):
         return Scope(self, name, kw.get("activation", "relu"), kw.get("coords", False))
@@ -261,6 +276,13 @@ class Nets(object):
 
     def critic(self, name, pair):
         return discriminator_towers(self._scope(name, self.config["discriminator"]), pair)
+
+    def dsingle(self, name, z):
+        """d_single / d_alpha / d_pi (SB_model48c:320-323): single_decoder_model with n_out = 3; the image stays in the
+        activation dtype because it feeds the perceptual trunk."""
+        kw = self.config["d_single"]
+        return single_decoder_model(self._scope(name, kw), z, 3, kw["config"], kw.get("upsample_config", "subpixel"),
+                                    out_f32=False)
 
 
 # --------------------------------------------------------------------------- perceptual trunk (EXTERNAL, stand-in weights)
