@@ -29,6 +29,13 @@ CASES = [
     ("vgg3_2", 64, 32, 256, 256, 3, 1, False, "relu"),
     ("vgg4_2", 64, 16, 512, 512, 3, 1, False, "relu"),
     ("crit_nin", 128, 1, 512, 512, 1, 1, False, "leaky_relu"),
+    ("dv_rb4", 128, 4, 256, 256, 3, 1, True, "leaky_relu"),
+    ("dv_rb8", 128, 8, 256, 256, 3, 1, True, "leaky_relu"),
+    ("ea_rb4x4", 768, 4, 256, 256, 3, 1, False, "leaky_relu"),
+    ("ea_rb8x8", 768, 8, 256, 256, 3, 1, False, "leaky_relu"),
+    ("vgg5_1", 128, 8, 512, 512, 3, 1, False, "relu"),
+    ("ea_down0", 640, 128, 32, 64, 3, 2, False, None),
+    ("ea_down1", 640, 64, 64, 128, 3, 2, False, None),
 ]
 
 

@@ -311,9 +311,23 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
     int bn = ctot > 64 ? 128 : (ctot > 32 ? 64 : 32);
     if (bn == 128 && mtiles * ups_cdiv(ctot, 128) < 256) bn = 64;
     if (bn == 64 && mtiles * ups_cdiv(ctot, 64) < 256) bn = 32;
+    {   // UPS_IGEMM_FORCE="<bn>,<cps>": tuning override (one of 128,1 / 64,2 / 64,1 / 32,4 / 32,1)
+        static int fbn = -1, fcps = -1;
+        if (fbn < 0) {
+            const char* e = getenv("UPS_IGEMM_FORCE");
+            fbn = 0;
+            if (e) sscanf(e, "%d,%d", &fbn, &fcps);
+        }
+        if (fbn > 0) bn = fbn;
+    }
     const int ntn = ups_cdiv(ctot, bn);
     const bool skinny = mtiles * ntn < 1024 && d.ntaps * kchunks >= 8;
-    const int cps = !skinny ? 1 : (bn == 32 ? 4 : (bn == 64 ? 2 : 1));
+    int cps = !skinny ? 1 : (bn == 32 ? 4 : (bn == 64 ? 2 : 1));
+    {
+        const char* e = getenv("UPS_IGEMM_FORCE");
+        int a = 0, b = 0;
+        if (e && sscanf(e, "%d,%d", &a, &b) == 2 && b > 0) cps = b;
+    }
 #define UPS_LAUNCH_IG(BNV, CPSV)                                                                                      \
     do {                                                                                                              \
         const size_t shmem = 2 * (size_t)(CPSV) * (BM + (BNV)) * RS + BM * 20;                                        \
