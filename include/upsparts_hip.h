@@ -72,6 +72,9 @@ typedef struct {
     const float* coord_tab;   /* [64][3][co] affine CoordConv table (ups_coord_table) or NULL */
     const void*  res;         /* residual, same pixel lattice as out, or NULL */
     const void*  dact;        /* pre-activation tensor for dact_kind, same lattice as out, or NULL */
+    float*       workspace;   /* optional fp32 scratch for the deterministic split-K path of small-M problems (few tiles,
+                               * long K loops); NULL or too small = no split */
+    size_t       workspace_bytes;
 } ups_conv_desc;
 
 int ups_conv_igemm(const ups_conv_desc* d, void* stream);

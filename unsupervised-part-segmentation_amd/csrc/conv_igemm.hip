@@ -87,6 +87,7 @@ struct ConvK {
     unsigned long long tap_off, tap_wi;
     const void* in; const void* w; void* out;
     const float* bias; const float* coord_tab; const void* res; const void* dact;
+    float* ws; int splits, stages_per_split, ldw;   // split-K: partial [split][M][ldw] fp32 (ldw = ntn * BN)
 };
 
 // CPS = K-chunks per pipeline stage: skinny problems (few blocks, long K loops) are bound by one exposed memory
@@ -209,13 +210,16 @@ __global__ __launch_bounds__(256, (CPS == 1 ? 3 : 2)) void conv_igemm_kernel(con
 
     // Software pipeline: double-buffered LDS, one barrier per stage, prefetch distance 2 (the loads of stage s+2 are
     // issued before the MFMAs of stage s and land in LDS after the MFMAs of stage s+1).
-    const int nstages = (total + CPS - 1) / CPS;
-    load_stage(s0, 0);
+    // split-K (blockIdx.y): this block walks stages [sbase, sbase + nstages) of the K loop
+    const int all_stages = (total + CPS - 1) / CPS;
+    const int sbase = p.splits > 1 ? blockIdx.y * p.stages_per_split : 0;
+    const int nstages = p.splits > 1 ? min(p.stages_per_split, all_stages - sbase) : all_stages;
+    load_stage(s0, sbase);
     store_stage(s0, smem);
-    if (nstages > 1) load_stage(s1, 1);
+    if (nstages > 1) load_stage(s1, sbase + 1);
     __syncthreads();
     auto iter = [&](int sidx, RSet& ld_set, const RSet& st_set) __attribute__((always_inline)) {
-        if (sidx + 2 < nstages) load_stage(ld_set, sidx + 2);
+        if (sidx + 2 < nstages) load_stage(ld_set, sbase + sidx + 2);
         const unsigned char* st = smem + (sidx & 1) * STAGE;
 #pragma unroll
         for (int u = 0; u < CPS; ++u)
@@ -229,6 +233,22 @@ __global__ __launch_bounds__(256, (CPS == 1 ? 3 : 2)) void conv_igemm_kernel(con
         if (sidx + 1 < nstages) iter(sidx + 1, s1, s0);
     }
 
+    if (p.splits > 1) {
+        // split-K partial: raw fp32 accumulators, [split][m][ldw]; bias / CoordConv / act' / residual in the reduce kernel
+        float* wsp = p.ws + ((long long)blockIdx.y * M) * p.ldw;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = nt * BN + (wn * TN + tn) * 32 + (lane & 31);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mt * BM + (wm * TM + tm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (m < M) wsp[(long long)m * p.ldw + col] = acc[tm][tn][e];
+                }
+        }
+        return;
+    }
     // ---- epilogue: row table in LDS (pixel index, CoordConv class, j, i)
     if (tid < BM) {
         const int m = mt * BM + tid;
@@ -284,6 +304,38 @@ __global__ __launch_bounds__(256, (CPS == 1 ? 3 : 2)) void conv_igemm_kernel(con
     }
 }
 
+// Deterministic reduce of the split-K partials + the full epilogue (one thread per output element, columns fastest).
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const ConvK p, const int M) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int col = (int)(gid % p.co_fill);
+    const long long m = gid / p.co_fill;
+    if (m >= M) return;
+    float v = 0.f;
+    for (int sp = 0; sp < p.splits; ++sp) v += p.ws[((long long)sp * M + m) * p.ldw + col];
+    const int hw_o = p.ho * p.wo;
+    const int img = (int)(m / hw_o), rem = (int)(m - (long long)img * hw_o);
+    const int i = rem / p.wo, j = rem - i * p.wo;
+    const long long pix = ((long long)img * p.out_h + (i * p.out_sy + p.out_oy)) * p.out_w + (j * p.out_sx + p.out_ox);
+    const bool cvalid = col < p.co;
+    if (cvalid) {
+        if (p.bias) v += p.bias[col];
+        if (p.coord_tab) {
+            int ym = 0, xm = 0;
+            for (int r = 0; r < p.kh; ++r) ym |= ((unsigned)(i * p.in_sy + tap_dy_of(p.tap_off, r * p.kw)) < (unsigned)p.hi) << r;
+            for (int q = 0; q < p.kw; ++q) xm |= ((unsigned)(j * p.in_sx + tap_dx_of(p.tap_off, q)) < (unsigned)p.wi) << q;
+            const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
+            v += tb[0] + (float)j * tb[p.co] + (float)i * tb[2 * p.co];
+        }
+        if (p.dact) v *= (ld_as_float<T>((const T*)p.dact + pix * p.ldd + col) > 0.f) ? 1.f : ups_slope_eff(p.dact_kind, p.act_slope);
+        if (p.res) v += ld_as_float<T>((const T*)p.res + pix * p.ldr + col);
+    } else {
+        v = 0.f;
+    }
+    if (p.out_f32) ((float*)p.out)[pix * p.ldo + col] = v;
+    else st_from_float<T>((T*)p.out + pix * p.ldo + col, v);
+}
+
 template <typename T>
 int launch(const ups_conv_desc& dd, hipStream_t s) {
     constexpr int EPC = Chunk<T>::N;
@@ -328,6 +380,34 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
         int a = 0, b = 0;
         if (e && sscanf(e, "%d,%d", &a, &b) == 2 && b > 0) cps = b;
     }
+    // split-K for latency-bound problems: few tiles, long K loop, workspace supplied.  Wider tiles + more blocks.
+    d.ws = nullptr; d.splits = 1; d.stages_per_split = 0; d.ldw = 0;
+    {
+        static int sk_on = -1;
+        if (sk_on < 0) { const char* e = getenv("UPS_NO_SPLITK"); sk_on = (e && e[0] == '1') ? 0 : 1; }
+        const int chunks = d.ntaps * kchunks;
+        const int bn_sk = ctot > 32 ? 64 : 32;
+        const int blocks_sk = mtiles * ups_cdiv(ctot, bn_sk);
+        // (a) fewer than 192 tiles: split up to ~512 blocks; (b) long K loops on grids that fill the chip at most about
+        // twice: split up to ~1024 blocks (measured: 4x4 / 8x8 layers of the encoders, dv and the VGG trunk)
+        const bool few = blocks_sk < 192 && chunks >= 16;
+        const bool longk = (blocks_sk <= 320 && chunks >= 64) || (blocks_sk <= 512 && chunks >= 128);
+        if (sk_on && dd.workspace && (few || longk)) {
+            const int cps_sk = bn_sk == 64 ? 2 : 4;
+            const int stages = ups_cdiv(chunks, cps_sk);
+            int splits = ups_cdiv(few ? 512 : 1024, blocks_sk);
+            if (splits > stages / 2) splits = stages / 2;
+            const int sps = ups_cdiv(stages, splits);
+            splits = ups_cdiv(stages, sps);
+            const int ldw = ups_cdiv(ctot, bn_sk) * bn_sk;
+            const size_t need = (size_t)splits * (size_t)M * ldw * sizeof(float);
+            if (splits >= 2 && need <= dd.workspace_bytes) {
+                bn = bn_sk; d.ws = dd.workspace; d.splits = splits; d.stages_per_split = sps; d.ldw = ldw;
+            }
+        }
+    }
+    const int ntn_l = ups_cdiv(ctot, bn);
+    const int cps_l = d.splits > 1 ? (bn == 64 ? 2 : 4) : cps;
 #define UPS_LAUNCH_IG(BNV, CPSV)                                                                                      \
     do {                                                                                                              \
         const size_t shmem = 2 * (size_t)(CPSV) * (BM + (BNV)) * RS + BM * 20;                                        \
@@ -338,15 +418,19 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
                 return UPS_E_LAUNCH;                                                                                  \
             attr_done = true;                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BNV, CPSV>), dim3(mtiles * ntn), dim3(256), shmem, s, d, (int)M, ntn, \
-                           kchunks);                                                                                  \
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BNV, CPSV>), dim3(mtiles * ntn_l, d.splits), dim3(256), shmem, s, d,  \
+                           (int)M, ntn_l, kchunks);                                                                   \
     } while (0)
     if (bn == 128) UPS_LAUNCH_IG(128, 1);
-    else if (bn == 64 && cps == 2) UPS_LAUNCH_IG(64, 2);
+    else if (bn == 64 && cps_l == 2) UPS_LAUNCH_IG(64, 2);
     else if (bn == 64) UPS_LAUNCH_IG(64, 1);
-    else if (cps == 4) UPS_LAUNCH_IG(32, 4);
+    else if (cps_l == 4) UPS_LAUNCH_IG(32, 4);
     else UPS_LAUNCH_IG(32, 1);
 #undef UPS_LAUNCH_IG
+    if (d.splits > 1) {
+        const long long elems = M * (long long)d.co_fill;
+        hipLaunchKernelGGL((igemm_splitk_epilogue<T>), dim3(ups_cdiv(elems, 256)), dim3(256), 0, s, d, (int)M);
+    }
     return UPS_OK;
 }
 

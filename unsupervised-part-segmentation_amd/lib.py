@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ("act_in", C.c_int32), ("act_slope", C.c_float), ("out_f32", C.c_int32), ("dact_kind", C.c_int32),
                 ("ldr", C.c_int32), ("ldd", C.c_int32),
                 ("in_", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p), ("bias", C.c_void_p),
-                ("coord_tab", C.c_void_p), ("res", C.c_void_p), ("dact", C.c_void_p)]
+                ("coord_tab", C.c_void_p), ("res", C.c_void_p), ("dact", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class WgradDesc(C.Structure):

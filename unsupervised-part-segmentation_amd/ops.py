@@ -213,6 +213,15 @@ def _fill_taps(desc, dy, dx, tw, ntaps):
     desc.ntaps = ntaps
 
 
+SPLITK_WS_BYTES = 48 << 20
+
+
+def _attach_ws(d, device):
+    """Scratch of the split-K path of ups_conv_igemm (per stream; grown once to SPLITK_WS_BYTES)."""
+    ws = WORKSPACE.get(SPLITK_WS_BYTES, device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+
+
 def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None):
     """out = conv(act(x) (+coords), V) + b (+ res);  x [n,hi,wi,ldi]."""
     n, hi, wi, ldi = x.shape
@@ -239,6 +248,7 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None):
     d.coord_tab = ent["ctab"].data_ptr() if layer.coords else None
     d.res = res.data_ptr() if res is not None else None
     d.dact = None
+    _attach_ws(d, x.device)
     assert round8(layer.ci_log) <= ldi, (layer.name, layer.ci_log, ldi)
     if KernelTimer.layer == layer.name and KernelTimer.enabled:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -295,6 +305,7 @@ def conv_dgrad(g, x, layer, res=None):
         d.bias, d.coord_tab = None, None
         d.res = res.data_ptr() if res is not None else None
         d.dact = x.data_ptr() if layer.act_in != L.ACT_NONE else None
+        _attach_ws(d, x.device)
         assert round8(layer.co) <= g.shape[-1]
         L.call("ups_conv_igemm", C.byref(d), L.stream())
     return gx
@@ -379,8 +390,10 @@ class ConvFn(torch.autograd.Function):
         layer = ctx.layer
         g = to_act_dtype(g, x.dtype, layer.co)
         gx = gV = gb = gres = None
+        offloaded = False
         if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not GradMode.skip_wgrad:
             if Streams.enabled and layer.grad_V is not None and not Streams.on_aux(x.device):
+                offloaded = True
                 # weight gradient on the side stream (it lands in the layer's view of the flat gradient bucket, which
                 # nothing reads before Streams.join); g and x must outlive the side stream's reads
                 cur = torch.cuda.current_stream(x.device)
@@ -395,7 +408,9 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = conv_dgrad(g, x, layer, res=g if ctx.res_mode == 2 else None)
         if ctx.res_mode == 1 and ctx.needs_input_grad[3]:
-            gres = g
+            # the autograd engine may accumulate other branches into the returned tensor IN PLACE; the side stream
+            # is still reading g, so hand out a copy in that case
+            gres = g.clone() if offloaded else g
         return gx, gV, gb, gres, None, None, None, None
 
 
