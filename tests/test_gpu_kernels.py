@@ -69,6 +69,11 @@ CONV_CASES = [
     # buffer, sign-byte activation-derivative tile), forward with CoordConv + residual and dgrad with act' + residual
     (16, 64, 64, 136, 136, 3, 1, True, "leaky_relu", True),    # <bf16,128,2>, ragged second N-tile
     (34, 64, 64, 64, 64, 3, 1, False, "relu", True),           # <bf16,64,2>
+    # whole 8x8 / 4x4 images packed 4 / 16 to a patch tile (each with its own zero halo): every N-tile width
+    (8, 8, 8, 72, 72, 3, 1, True, "leaky_relu", True),         # SUB=8, 2 tiles, BN=32 (small grid)
+    (256, 8, 8, 24, 72, 3, 1, False, "relu", False),           # SUB=8, BN=64
+    (32, 4, 4, 136, 136, 3, 1, True, "leaky_relu", True),      # SUB=4, 2 tiles, BN=32
+    (1536, 4, 4, 16, 136, 3, 1, True, None, False),            # SUB=4, BN=128 with a ragged second N-tile
 ]
 
 

@@ -47,7 +47,7 @@ template <typename T> struct PMma;
 // NBUF = 2: fragments of k-step s+1 fetched before the MFMAs of k-step s (two register sets);
 // NBUF = 1: one register set, the reads of k-step s+1 are issued right behind the MFMAs of k-step s (the operands are
 //           read at issue) -- 16 VGPRs less, for the two-blocks-per-CU configuration whose other waves cover the latency
-template <int TM, int TN, int NBUF>
+template <int TM, int TN, int NBUF, int PITCH>
 __device__ __forceinline__ void bf16_three_taps(const unsigned char* A, const unsigned char* B, int po0, int po1, int po2,
                                                 int sw0, int sw1, int sw2,
                                                 int b_tap_stride, int b_blk_stride, int boff0, int boff1,
@@ -60,7 +60,7 @@ __device__ __forceinline__ void bf16_three_taps(const unsigned char* A, const un
         const int po = tl == 0 ? po0 : (tl == 1 ? po1 : po2);
         const int sw = (tl == 0 ? sw0 : (tl == 1 ? sw1 : sw2)) ^ (ks << 5);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[slot][i] = *(const bf16x8*)(A + po + i * (2 * PWP * APX) + sw);
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *(const bf16x8*)(A + po + i * (2 * PITCH * APX) + sw);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             fb[slot][j] = *(const bf16x8*)(B + tl * b_tap_stride + j * b_blk_stride + (ks ? boff1 : boff0));
@@ -81,7 +81,7 @@ __device__ __forceinline__ void bf16_three_taps(const unsigned char* A, const un
 }
 
 template <> struct PMma<float> {
-    template <int TM, int TN>
+    template <int TM, int TN, int PITCH>
     __device__ static inline void tap(const unsigned char* a_pix, int hh, int v, const unsigned char* b_lane, f32x16 (&acc)[TM][TN]) {
         // a_pix = per-lane patch pixel base (chunk 0) shifted by the tap; lane half hh owns chunks 2hh, 2hh+1 (swizzled
         // by v); b_lane already includes the lane-half offset hh*32
@@ -89,8 +89,8 @@ template <> struct PMma<float> {
         const int c0 = ((2 * hh) ^ v) << 4, c1 = ((2 * hh + 1) ^ v) << 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            a[i][0] = *(const f32x4*)(a_pix + i * (2 * PWP * APX) + c0);
-            a[i][1] = *(const f32x4*)(a_pix + i * (2 * PWP * APX) + c1);
+            a[i][0] = *(const f32x4*)(a_pix + i * (2 * PITCH * APX) + c0);
+            a[i][1] = *(const f32x4*)(a_pix + i * (2 * PITCH * APX) + c1);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -112,7 +112,10 @@ template <> struct PMma<float> {
 // OCC = 2 (bf16 only): two blocks per CU (2-stage ring, single patch buffer, activation-derivative tile staged as sign
 // bytes, <= 80 KB LDS and <= 128 VGPRs) -- the second block's MFMAs hide this block's prologue, patch re-staging and
 // epilogue, none of which overlap anything when a CU holds a single block.
-template <typename T, int BN, int OCC>
+// SUB = 16: a tile is a 16x16 window of one image (halo from the neighbouring pixels).  SUB = 8 / 4: the images themselves
+// are 8x8 / 4x4 (encoder bottoms, first decoder levels, VGG block 5) and a tile packs G x G = 4 / 16 whole images, each
+// with its own all-zero halo (the patch grid is G*(SUB+2) wide; halo slots are zeroed once and never written).
+template <typename T, int BN, int OCC, int SUB>
 __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const PatchK p, const int tiles_x, const int tiles_y,
                                                                  const int ntn, const int kchunks, const int nblocks) {
     constexpr int EPC = Chunk<T>::N;
@@ -124,10 +127,15 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     constexpr int B_BYTES = 3 * BN * RS;         // one tap-row of weights
     constexpr int NB = (3 * BN * 4 + 511) / 512; // weight chunks per thread per tap-row: 3, 2, 1
     constexpr int HALF_OFF = (sizeof(T) == 2) ? 16 : 32;
+    constexpr int G = TS / SUB;                  // sub-images per tile side
+    constexpr int PR = G * (SUB + 2);            // patch rows = columns: 18 / 20 / 24
+    constexpr int PWPS = (PR + 3) / 4 * 4;       // row pitch in pixels (multiple of 4): 20 / 20 / 24
+    constexpr int ABY = PR * PWPS * APX;         // bytes of one patch buffer
+    static_assert(SUB == 16 || OCC == 1, "multi-image tiles run one block per CU");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Abuf = smem;                  // 2 x A_BYTES
-    unsigned char* Bbuf = smem + 2 * A_BYTES;    // 2 x B_BYTES
+    unsigned char* Abuf = smem;                  // 2 x ABY
+    unsigned char* Bbuf = smem + 2 * ABY;        // 2 x B_BYTES
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values derived from it live in SGPRs
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     int t = bid / ntn;
     const int tx0 = (t % tiles_x) * TS; t /= tiles_x;
     const int ty0 = (t % tiles_y) * TS;
-    const int img = t / tiles_y;
+    const int img = (t / tiles_y) * (G * G);     // first image of the tile
     const int wm = wid / WN, wn = wid % WN;
 
     const T* __restrict__ in = (const T*)p.in + (long long)img * p.h * p.w * p.ldi;
@@ -151,7 +159,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     // 32-bit BYTE offsets inside the image (an image is < 2 GB), -1 = zero fill; the loads use the uniform image base as
     // scalar address + this vector offset (no 64-bit vector address arithmetic, 1 VGPR per item)
     int pa0 = -1, pa1 = -1, pa2 = -1;
-    {
+    int sa0, sa1, sa2;      // LDS byte offsets of the staged items (swizzled patch layout)
+    if constexpr (SUB == TS) {
         auto mk = [&](int item) -> int {
             if (item >= PPIX * 4) return -2;      // no item
             const int pix = item >> 2, ch = item & 3;
@@ -161,14 +170,26 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             return ((y * p.w + x) * p.ldi + ch * EPC) * (int)sizeof(T);
         };
         pa0 = mk(tid); pa1 = mk(tid + 512); pa2 = mk(tid + 1024);
+        auto mk_sa = [&](int item) -> int {
+            const int pix = item >> 2, ch = item & 3;
+            const int py = pix / PW, px = pix - py * PW;
+            return (py * PWPS + px) * APX + ((ch ^ a_swz(px)) << 4);
+        };
+        sa0 = mk_sa(tid); sa1 = mk_sa(tid + 512); sa2 = mk_sa(min(tid + 1024, PPIX * 4 - 1));
+    } else {
+        // only the 256 interior pixels are ever loaded (2 items per thread); every halo slot stays zero
+        auto mk = [&](int item, int& sa) -> int {
+            const int q = item >> 2, ch = item & 3;
+            const int ty = q >> 4, tx = q & 15;
+            const int sy = ty / SUB, ly = ty - sy * SUB, sx = tx / SUB, lx = tx - sx * SUB;
+            const int px = tx + 2 * sx + 1;
+            sa = ((ty + 2 * sy + 1) * PWPS + px) * APX + ((ch ^ a_swz(px)) << 4);
+            return ((((sy * G + sx) * SUB + ly) * SUB + lx) * p.ldi + ch * EPC) * (int)sizeof(T);
+        };
+        pa0 = mk(tid, sa0); pa1 = mk(tid + 512, sa1); pa2 = -2; sa2 = 0;
+        for (int i = tid * 16; i < 2 * ABY; i += 512 * 16) *(uint4*)(Abuf + i) = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
     }
-    // LDS byte offsets of the three staged items (swizzled patch layout)
-    auto mk_sa = [&](int item) -> int {
-        const int pix = item >> 2, ch = item & 3;
-        const int py = pix / PW, px = pix - py * PW;
-        return (py * PWP + px) * APX + ((ch ^ a_swz(px)) << 4);
-    };
-    const int sa0 = mk_sa(tid), sa1 = mk_sa(tid + 512), sa2 = mk_sa(min(tid + 1024, PPIX * 4 - 1));
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     uint4 ra0, ra1, ra2;
     struct WSet { uint4 r0, r1, r2; } ws0, ws1;     // two weight stages in flight (prefetch distance 2)
@@ -244,7 +265,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     // per-lane fragment bases: output row r of MFMA block tm -> tile pixel (ty, tx)
     const int r = lane & 31, hh = lane >> 5;
     const int ty_l = (wm * TM * 2) + (r >> 4), tx_l = r & 15;
-    const int a_lane_off = (ty_l * PWP + tx_l) * APX;                      // patch origin is (-1,-1): tap (dy,dx) adds (dy+1, dx+1)
+    // patch coordinates of the lane's pixel minus the halo origin: tap (dy,dx) adds (dy+1, dx+1)
+    const int py_l = ty_l + 2 * (ty_l / SUB) * (SUB < TS ? 1 : 0), px_l = tx_l + 2 * (tx_l / SUB) * (SUB < TS ? 1 : 0);
+    const int a_lane_off = (py_l * PWPS + px_l) * APX;
     const int b_lane_off = (wn * TN * 32 + r) * RS + hh * HALF_OFF;
 
     const int total = 3 * kchunks;
@@ -265,7 +288,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #endif
         // a single-chunk problem (ci <= 32) never touches the second patch buffer: the launcher then requests less LDS
         // (2 blocks per CU instead of 1, which hides the per-block load latency of these 3-iteration blocks)
-        unsigned char* Bst = smem + ((kchunks == 1 || OCC == 2) ? 1 : 2) * A_BYTES;   // NST x BST
+        unsigned char* Bst = smem + (((kchunks == 1 && SUB == TS) || OCC == 2) ? 1 : 2) * ABY;   // NST x BST
         const int swz = (r >> 2) & 3;
         const int boff0 = r * 64 + ((hh ^ swz) << 4), boff1 = r * 64 + (((2 + hh) ^ swz) << 4);
         // per-lane source decode of this wave's DMA instructions (loop invariant)
@@ -319,11 +342,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const unsigned char* A = Abuf + a_lane_off;
             const unsigned char* B = Bst + (it % NST) * BST + (wn * TN * 32) * 64;
             const int dx0 = p_dx(p.tap_off, 3 * g) + 1, dx1 = p_dx(p.tap_off, 3 * g + 1) + 1, dx2 = p_dx(p.tap_off, 3 * g + 2) + 1;
-            const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWP + dx0) * APX;
-            const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWP + dx1) * APX;
-            const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWP + dx2) * APX;
-            bf16_three_taps<TM, TN, FRAG_BUFS>(A, B, po0, po1, po2, (hh ^ a_swz(tx_l + dx0)) << 4, (hh ^ a_swz(tx_l + dx1)) << 4,
-                                               (hh ^ a_swz(tx_l + dx2)) << 4, BN * 64, 32 * 64, boff0, boff1, acc);
+            const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
+            const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
+            const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
+            bf16_three_taps<TM, TN, FRAG_BUFS, PWPS>(A, B, po0, po1, po2, (hh ^ a_swz(px_l + dx0)) << 4, (hh ^ a_swz(px_l + dx1)) << 4,
+                                               (hh ^ a_swz(px_l + dx2)) << 4, BN * 64, 32 * 64, boff0, boff1, acc);
             if (n1 < total && n1 % 3 == 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                 // every wave has read the last tap of this chunk's patch
@@ -343,18 +366,18 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 if (n2 % 3 == 0) load_patch(n2 / 3);     // register loads first: they stay OLDER than this tap-row's DMAs
                 dma_w(n2);
             }
-            const unsigned char* A = Abuf + (cc & 1) * A_BYTES + a_lane_off;
+            const unsigned char* A = Abuf + (cc & 1) * ABY + a_lane_off;
             const unsigned char* B = Bst + (it % 3) * BST + (wn * TN * 32) * 64;
             const int dx0 = p_dx(p.tap_off, 3 * g) + 1, dx1 = p_dx(p.tap_off, 3 * g + 1) + 1, dx2 = p_dx(p.tap_off, 3 * g + 2) + 1;
-            const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWP + dx0) * APX;
-            const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWP + dx1) * APX;
-            const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWP + dx2) * APX;
-            bf16_three_taps<TM, TN, 2>(A, B, po0, po1, po2, (hh ^ a_swz(tx_l + dx0)) << 4, (hh ^ a_swz(tx_l + dx1)) << 4,
-                                       (hh ^ a_swz(tx_l + dx2)) << 4, BN * 64, 32 * 64, boff0, boff1, acc);
+            const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
+            const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
+            const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
+            bf16_three_taps<TM, TN, 2, PWPS>(A, B, po0, po1, po2, (hh ^ a_swz(px_l + dx0)) << 4, (hh ^ a_swz(px_l + dx1)) << 4,
+                                       (hh ^ a_swz(px_l + dx2)) << 4, BN * 64, 32 * 64, boff0, boff1, acc);
 #if !defined(UPS_ABLATE_LSTORE)
             // (the activation patch goes through registers for the fused activation / zero padding; hipcc waits
             // vmcnt(0) for it, which also drains the DMAs once per channel chunk -- measured cost ~0.2 ms of 3.2 ms)
-            if (n1 < total && n1 % 3 == 0) store_patch(Abuf + ((n1 / 3) & 1) * A_BYTES);
+            if (n1 < total && n1 % 3 == 0) store_patch(Abuf + ((n1 / 3) & 1) * ABY);
 #endif
             // the weights of tap-row it+1 must have landed; the NW DMAs of tap-row it+2 may stay in flight
             if (n2 < total) {
@@ -382,18 +405,18 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             load_w(ld_set, g2, c2);
             if (g2 == 0) load_patch(c2);
         }
-        const unsigned char* A = Abuf + (cc & 1) * A_BYTES + a_lane_off;
+        const unsigned char* A = Abuf + (cc & 1) * ABY + a_lane_off;
         const unsigned char* B = Bbuf + (it & 1) * B_BYTES + b_lane_off;
 #pragma unroll
         for (int tl = 0; tl < 3; ++tl) {
             const int tp = 3 * g + tl;
             const int dxp = p_dx(p.tap_off, tp) + 1;
-            const int po = ((p_dy(p.tap_off, tp) + 1) * PWP + dxp) * APX;
-            PMma<float>::template tap<TM, TN>(A + po, hh, a_swz(tx_l + dxp), B + tl * BN * RS, acc);
+            const int po = ((p_dy(p.tap_off, tp) + 1) * PWPS + dxp) * APX;
+            PMma<float>::template tap<TM, TN, PWPS>(A + po, hh, a_swz(px_l + dxp), B + tl * BN * RS, acc);
         }
         if (n1 < total) {
             store_w(st_set, Bbuf + (n1 & 1) * B_BYTES);
-            if (n1 % 3 == 0) store_patch(Abuf + ((n1 / 3) & 1) * A_BYTES);
+            if (n1 % 3 == 0) store_patch(Abuf + ((n1 / 3) & 1) * ABY);
         }
         __syncthreads();
     };
@@ -422,6 +445,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     const T* __restrict__ res = (const T*)p.res;
     const T* __restrict__ dact = (const T*)p.dact;
     const long long img_pix = (long long)img * p.h * p.w;
+    // tile pixel index (ty * 16 + tx) -> global pixel index / coordinates inside its image
+    auto gpix = [&](int q) -> long long {
+        const int ty = q >> 4, tx = q & 15;
+        if constexpr (SUB == TS) return img_pix + (long long)(ty0 + ty) * p.w + tx0 + tx;
+        else return img_pix + (long long)((ty / SUB) * G + tx / SUB) * (SUB * SUB) + (ty % SUB) * SUB + (tx % SUB);
+    };
+    auto ycoord = [&](int ty) -> int { return SUB == TS ? ty0 + ty : ty % SUB; };
+    auto xcoord = [&](int tx) -> int { return SUB == TS ? tx0 + tx : tx % SUB; };
 
     // bf16 fast path: the residual / activation-derivative tiles come in and the output tile goes out through LDS with
     // 16-byte, fully coalesced accesses (a lane-per-column 2-byte epilogue runs the 1 GB residual read at < 1 TB/s).
@@ -437,7 +468,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #pragma unroll
                 for (int i = 0; i < NIT; ++i) {
                     const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
-                    const long long pix = img_pix + (long long)(ty0 + (px >> 4)) * p.w + tx0 + (px & 15);
+                    const long long pix = gpix(px);
                     if (ch * 8 < c_lim) {
                         if (res) *(uint4*)(R0 + px * ERS + ch * 16) = *(const uint4*)(res + pix * p.ldr + nt * BN + ch * 8);
                         if (dact) {
@@ -461,7 +492,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             // terms and 2 y terms per MFMA block (2 adds per element); only tiles that touch the image border look the
             // class table up, and only for their border pixels.
             const int hh4 = 4 * (lane >> 5);
-            const bool border_tile = p.coord_tab && (ty0 == 0 || ty0 + TS >= p.h || tx0 == 0 || tx0 + TS >= p.w);
+            // (multi-image tiles: every pixel takes the class-table path; the folded terms are then unused)
+            const bool border_tile = p.coord_tab && (SUB < TS || ty0 == 0 || ty0 + TS >= p.h || tx0 == 0 || tx0 + TS >= p.w);
             const float xf0 = (float)(tx0 + hh4);
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
@@ -490,10 +522,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                         const int px = (yrow + k) * 16 + pxc;
                         float v = acc[tm][tn][e] + xs[j] + (k ? ys1 : ys0);
                         if (border_tile) {
-                            const int y = ty0 + yrow + k, x = tx0 + pxc;
+                            const int y = ycoord(yrow + k), x = xcoord(pxc);
                             const int ym = (y > 0 ? 1 : 0) | 2 | (y + 1 < p.h ? 4 : 0);
                             const int xm = (x > 0 ? 1 : 0) | 2 | (x + 1 < p.w ? 4 : 0);
-                            if ((ym & xm) != 7 && cvalid) {
+                            if (((ym & xm) != 7 || SUB < TS) && cvalid) {
                                 const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
                                 v = acc[tm][tn][e] + bias + (tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co]);
                             }
@@ -509,7 +541,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
-                const long long pix = img_pix + (long long)(ty0 + (px >> 4)) * p.w + tx0 + (px & 15);
+                const long long pix = gpix(px);
                 if (ch * 8 < c_lim) *(uint4*)(outT + pix * p.ldo + nt * BN + ch * 8) = *(const uint4*)(R0 + px * ERS + ch * 16);
             }
             return;
@@ -527,8 +559,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rr = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int y = ty0 + (wm * TM + tm) * 2 + (rr >> 4), x = tx0 + (rr & 15);
-                const long long pix = img_pix + (long long)y * p.w + x;
+                const int tyq = (wm * TM + tm) * 2 + (rr >> 4), txq = rr & 15;
+                const int y = ycoord(tyq), x = xcoord(txq);
+                const long long pix = gpix(tyq * 16 + txq);
                 float v = 0.f;
                 if (cvalid) {
                     v = acc[tm][tn][e] + bias;
@@ -548,28 +581,30 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
 }
 
-template <typename T, int BN, int OCC>
+template <typename T, int BN, int OCC, int SUB>
 int launch_bn(const PatchK& k, hipStream_t s) {
     constexpr int EPC = Chunk<T>::N;
-    const int tiles_x = k.w / TS, tiles_y = k.h / TS;
+    constexpr int G = TS / SUB, PR = G * (SUB + 2), PWPS = (PR + 3) / 4 * 4;
+    constexpr size_t ABY = (size_t)PR * PWPS * APX;
+    const int tiles_x = SUB == TS ? k.w / TS : 1, tiles_y = SUB == TS ? k.h / TS : 1;
     const int ntn = ups_cdiv(k.co_fill, BN);
     const int kchunks = ups_cdiv(k.ci, 4 * EPC);
-    const int nblocks = k.n * tiles_x * tiles_y * ntn;
+    const int nblocks = (k.n / (G * G)) * tiles_x * tiles_y * ntn;
     constexpr size_t BST = 3 * (size_t)BN * 64;
-    const int nabuf = (sizeof(T) == 2 && (kchunks == 1 || OCC == 2)) ? 1 : 2;
-    size_t shmem = sizeof(T) == 2 ? nabuf * A_BYTES + (OCC == 2 ? 2 : 3) * BST : 2 * A_BYTES + 2 * 3 * BN * RS;
-    const size_t shmem_max = sizeof(T) == 2 ? (OCC == 2 ? 1 : 2) * A_BYTES + (OCC == 2 ? 2 : 3) * BST : shmem;
+    const int nabuf = (sizeof(T) == 2 && SUB == TS && (kchunks == 1 || OCC == 2)) ? 1 : 2;
+    size_t shmem = sizeof(T) == 2 ? nabuf * ABY + (OCC == 2 ? 2 : 3) * BST : 2 * ABY + 2 * 3 * BN * RS;
+    const size_t shmem_max = sizeof(T) == 2 ? (OCC == 2 ? 1 : 2) * ABY + (OCC == 2 ? 2 : 3) * BST : shmem;
     const size_t epi = sizeof(T) == 2 ? 256 * (size_t)(BN * 2 + 16) + 256 * (size_t)(BN / 8) : 0;   // staged bf16 epilogue
     if (epi > shmem) shmem = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(epi > shmem_max ? epi : shmem_max));
         if (e != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC>), dim3(nblocks), dim3(512), shmem, s, k, tiles_x, tiles_y, ntn, kchunks,
-                       nblocks);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC, SUB>), dim3(nblocks), dim3(512), shmem, s, k, tiles_x, tiles_y, ntn,
+                       kchunks, nblocks);
     return UPS_OK;
 }
 
@@ -579,22 +614,34 @@ static int patch_occ() {   // UPS_PATCH_OCC=1 forces the one-block-per-CU config
     return v;
 }
 
+template <typename T, int SUB>
+int launch_small(const PatchK& k, hipStream_t s) {
+    // whole 8x8 / 4x4 images packed 4 / 16 to a tile: narrower N-tiles when the grid would not fill the chip
+    const int tiles = k.n / ((TS / SUB) * (TS / SUB));
+    if (k.co_fill > 64 && tiles * ups_cdiv(k.co_fill, 128) >= 192) return launch_bn<T, 128, 1, SUB>(k, s);
+    if (k.co_fill > 32 && tiles * ups_cdiv(k.co_fill, 64) >= 128) return launch_bn<T, 64, 1, SUB>(k, s);
+    return launch_bn<T, 32, 1, SUB>(k, s);
+}
+
 template <typename T>
 int launch_t(const PatchK& k, hipStream_t s) {
+    if (k.h == 8) return launch_small<T, 8>(k, s);
+    if (k.h == 4) return launch_small<T, 4>(k, s);
     if constexpr (sizeof(T) == 2) {
         // two blocks per CU once the grid has at least two blocks for every CU (smaller grids spread over the chip instead);
         // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv) use 64-wide tiles and one patch buffer
         const int tiles = k.n * (k.w / TS) * (k.h / TS);
         if (k.co_fill > 64 && k.ci > 32)
-            return (patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 128) >= 512) ? launch_bn<T, 128, 2>(k, s) : launch_bn<T, 128, 1>(k, s);
+            return (patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 128) >= 512) ? launch_bn<T, 128, 2, TS>(k, s)
+                                                                                  : launch_bn<T, 128, 1, TS>(k, s);
         if (k.co_fill > 32)
-            return (patch_occ() == 2 && k.ci > 32 && tiles * ups_cdiv(k.co_fill, 64) >= 512) ? launch_bn<T, 64, 2>(k, s)
-                                                                                              : launch_bn<T, 64, 1>(k, s);
-        return launch_bn<T, 32, 1>(k, s);
+            return (patch_occ() == 2 && k.ci > 32 && tiles * ups_cdiv(k.co_fill, 64) >= 512) ? launch_bn<T, 64, 2, TS>(k, s)
+                                                                                              : launch_bn<T, 64, 1, TS>(k, s);
+        return launch_bn<T, 32, 1, TS>(k, s);
     } else {
-        if (k.co_fill > 64) return launch_bn<T, 128, 1>(k, s);
-        if (k.co_fill > 32) return launch_bn<T, 64, 1>(k, s);
-        return launch_bn<T, 32, 1>(k, s);
+        if (k.co_fill > 64) return launch_bn<T, 128, 1, TS>(k, s);
+        if (k.co_fill > 32) return launch_bn<T, 64, 1, TS>(k, s);
+        return launch_bn<T, 32, 1, TS>(k, s);
     }
 }
 
@@ -605,7 +652,12 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox)
         return 1;
     if (d->hi != d->ho || d->wi != d->wo || d->out_h != d->ho || d->out_w != d->wo) return 1;
-    if (d->hi % TS || d->wi % TS) return 1;
+    const bool small = d->hi == d->wi && (d->hi == 8 || d->hi == 4) && d->n % ((TS / d->hi) * (TS / d->hi)) == 0;
+    {
+        static int small_on = -1;
+        if (small_on < 0) { const char* e = getenv("UPS_NO_SMALL_PATCH"); small_on = (e && e[0] == '1') ? 0 : 1; }
+        if ((d->hi % TS || d->wi % TS) && !(small && small_on)) return 1;
+    }
     bool seen[9] = {false, false, false, false, false, false, false, false, false};
     for (int t = 0; t < 9; ++t) {
         const int dy = d->tap_dy[t], dx = d->tap_dx[t];
