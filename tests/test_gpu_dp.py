@@ -62,6 +62,9 @@ def _worker(rank, world, port, out):
         if step == 0:
             grads0 = {k: g["flat"]["g"].detach().cpu().clone() for k, g in model.bank.groups.items()}
     torch.cuda.synchronize()
+    # the encoder_0 head slice is all-reduced early (Trainer._hook_early_reduce): the hook must be installed and consumed
+    assert tr._early_hooked and not tr._early
+    assert any(lay.after_wgrad is not None for lay in model.nets.layers.values())
     out[rank] = {"params": {k: g["flat"]["p"].detach().cpu() for k, g in model.bank.groups.items()},
                  "grads0": grads0, "state": {k: float(v) for k, v in tr.state.items()}}
     torch.distributed.destroy_process_group()

@@ -156,6 +156,7 @@ class Trainer(object):
         self._gen = torch.Generator(device=d)
         self._gen.manual_seed(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))
         self.losses = OrderedDict((k, None) for k in self.loss_keys())
+        self._early, self._early_hooked = {}, False
 
     # ------------------------------------------------------------------ edflow hook surface
     def loss_keys(self):
@@ -469,6 +470,9 @@ class Trainer(object):
             gp1 = ops.latent_bwd(pe_v1, noise["eps_pi1"][None], [1.0], gz[B:].contiguous()[None], None, 0.0)
             g_pe = torch.cat([gp0, gp1], 0).view_as(pe)
             e0_params = [bank.params[n] for n in bank.groups["encoder_0"]["names"]]
+            if self.world_size > 1 and not self._early_hooked:      # layers exist once the first forward has run
+                self._hook_early_reduce()
+                self._early_hooked = True
             torch.autograd.grad([pe], e0_params, grad_outputs=[g_pe])
 
         # ================= gradient all-reduce (data parallel) + TF Adam per key
@@ -549,6 +553,33 @@ class Trainer(object):
                        "dl_tot": dl_tot, "dl_rec": dl_rec, "g_hard0": g_hard0, "g_hard1": g_hard1, "pe": pe2}
         return self.losses
 
+    def _hook_early_reduce(self):
+        """The 1x1 head of encoder_0 (258 x 33152 weights = 34 of the key's 54.6 MB) is the FIRST weight gradient of the
+        last backward segment: its slice of the flat bucket starts its all-reduce as soon as it has been enqueued, so
+        only the remaining 20 MB follow the end of the backward pass."""
+        grp = self.model.bank.groups["encoder_0"]
+        head = max((n for n in grp["names"] if n.endswith("/V")), key=lambda n: int(n.split("conv2d_")[1].split("/")[0]))
+        prefix = head[:-2]
+        off = 0
+        for n in grp["names"]:
+            if n.startswith(prefix + "/"):
+                break
+            off += self.model.bank.params[n].numel()
+        tail = sum(self.model.bank.params[n].numel() for n in grp["names"] if n.startswith(prefix + "/"))
+        assert off + tail == grp["flat"]["g"].numel(), "the head's variables must close the flat bucket"
+        trainer = self
+
+        def launch():
+            if "encoder_0" in trainer._early:
+                return
+            ops.Streams.join(trainer.device, names=("wgrad",))
+            h = D.allreduce_bucket(grp["flat"]["g"][off:], trainer.world_size, trainer.process_group)
+            trainer._early["encoder_0"] = (off, h)
+
+        for (name, _act), lay in self.model.nets.layers.items():
+            if name == prefix:
+                lay.after_wgrad = launch
+
     def _launch_reduce(self, key_list):
         """Called when the backward segment of these optimizer keys is complete: their weight gradients (side stream)
         are joined and each key's flat gradient bucket starts its RCCL all-reduce (sum; 1/world is folded into Adam),
@@ -557,7 +588,15 @@ class Trainer(object):
             return []
         ops.Streams.join(self.device, names=("wgrad",))
         bank = self.model.bank
-        return [D.allreduce_bucket(bank.groups[k]["flat"]["g"], self.world_size, self.process_group) for k in key_list]
+        handles = []
+        for k in key_list:
+            g = bank.groups[k]["flat"]["g"]
+            early = self._early.pop(k, None)
+            if early is not None:            # the tail slice is already in flight (see _hook_early_reduce)
+                handles.append(early[1])
+                g = g[:early[0]]
+            handles.append(D.allreduce_bucket(g, self.world_size, self.process_group))
+        return handles
 
     def _finish_step(self, keys, handles):
         """Wait for the buckets, then one fused Adam launch per key (tf.train.AdamOptimizer semantics, Appendix A.12)."""

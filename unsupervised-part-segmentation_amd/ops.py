@@ -159,6 +159,7 @@ class ConvLayer(object):
         self.grad_V = None          # optional preallocated views into a flat gradient buffer
         self.grad_b = None
         self.frozen = False         # frozen weights (perceptual trunk): converted copies survive optimizer steps
+        self.after_wgrad = None     # optional callback run right after this layer's weight gradient has been enqueued
         self.registry = None        # PrepRegistry of the owning model (batched refresh) or None (lazy per-layer prep)
         self._cache = {}
 
@@ -405,6 +406,8 @@ class ConvFn(torch.autograd.Function):
                 x.record_stream(side)
             else:
                 gV, gb = conv_wgrad(g, x, layer)
+            if layer.after_wgrad is not None:
+                layer.after_wgrad()
         if ctx.needs_input_grad[0]:
             gx = conv_dgrad(g, x, layer, res=g if ctx.res_mode == 2 else None)
         if ctx.res_mode == 1 and ctx.needs_input_grad[3]:
