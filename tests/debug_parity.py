@@ -1,5 +1,5 @@
 """Per-variable gradient / loss parity of one fp32 step against the CPU oracle (debug aid).
-Usage: python tools/debug_parity.py [cub|pennaction|deepfashion] [tiny|small]"""
+Usage: python tests/debug_parity.py [cub|pennaction|deepfashion] [tiny|small]"""
 import copy, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -52,6 +52,19 @@ def test_product_does_not_import_the_oracle():
             assert "oracle" not in src.replace("the oracle /", ""), fn + " must not reference oracle/"
 
 
+def test_tools_do_not_import_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    tdir = os.path.join(ROOT, "tools")
+    for fn in os.listdir(tdir):
+        if fn.endswith(".py"):
+            assert "oracle" not in open(os.path.join(tdir, fn)).read(), "tools/" + fn + " must not use oracle/"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head, _, tail = src.partition("def cpu_baseline")
+    body, _, rest = tail.partition("\ndef main")
+    assert "from oracle" not in head and "import oracle" not in head
+    assert rest.count("from oracle") == 1 and "cpu_baseline(cfg_fn" in rest     # only the config factory of that leg
+
+
 def test_same_geometry_and_taps():
     lib, ops, *_ = _pkg()
     assert ops.same_geometry(128, 3, 1) == (128, 1)
