@@ -16,7 +16,10 @@ def _setup(precision, dev, variant="cub", size="tiny"):
     import upsparts_amd  # noqa: F401
     from upsparts_amd.model import TrainModel, Trainer
     from oracle import ref_model as R, configs
-    cfg = configs.tiny_config(variant=variant) if size == "tiny" else configs.small_config(variant=variant)
+    if size == "tiny25":        # 25 parts (the shipped yamls' part count), odd batch: ragged lane groups / fallback conv paths
+        cfg = configs.tiny_config(n_parts=25, batch_size=3, variant=variant)
+    else:
+        cfg = configs.tiny_config(variant=variant) if size == "tiny" else configs.small_config(variant=variant)
     cfg = copy.deepcopy(cfg)
     cfg["precision"] = precision
     cfg["vgg_widths"] = VGG_W
@@ -35,7 +38,8 @@ def _setup(precision, dev, variant="cub", size="tiny"):
     return cfg, R, params, vp, model, trainer, views, noise
 
 
-CASES = [("cub", "tiny"), ("pennaction", "tiny"), ("deepfashion", "tiny"), ("cub", "small"), ("deepfashion", "small")]
+CASES = [("cub", "tiny"), ("pennaction", "tiny"), ("deepfashion", "tiny"), ("cub", "small"), ("deepfashion", "small"),
+         ("cub", "tiny25"), ("deepfashion", "tiny25")]
 
 
 @pytest.mark.parametrize("variant,size", CASES)
