@@ -250,6 +250,15 @@ int ups_latent_bwd(const float* params, const float* eps, const float* level, co
 int ups_adam(float* p, const float* g, float* m, float* v, int64_t count, float lr_t, float beta1, float beta2, float eps,
              float grad_scale, void* stream);
 
+/* ---------------------------------------------------------------- thin-plate-spline augmentation (M:282-311)
+ * Replaces eddata.utils.tps.ThinPlateSpline (un-vendored; "adapted from CompVis/unsupervised-disentangling", Y:188):
+ * out[n][y][x][:] = bilinear sample of img[n] at (x_s, y_s) = T[n] @ [1, x, y, phi(|(x,y) - coord[n][i]|^2)...],
+ * phi(d2) = d2 log(d2 + 1e-6), (x, y) on linspace(-1, 1); `_interpolate` convention: pixel = (coord + 1) * size / 2,
+ * clamped corner indices.  img / out fp32 [n,h,w,c]; T fp32 [n][2][K+3]; coord fp32 [n][K][2] (x, y); K <= 32.
+ * Semantics re-derived from the published algorithm: UNVERIFIED (parity unpinned). */
+int ups_tps_warp(const float* img, const float* T, const float* coord, float* out, int32_t n, int32_t h, int32_t w,
+                 int32_t c, int32_t K, void* stream);
+
 /* ---------------------------------------------------------------- Gaussian renderers (N:1639-1702, N:1976-2021)
  * tf_hm: P_xy [B][K][2], stddev [B][K][2] on the integer pixel grid (x,y order) -> heat [B,h,w,K] */
 int ups_gauss_hm(const float* pts, const float* stddev, float* out, int32_t B, int32_t h, int32_t w, int32_t K, void* stream);

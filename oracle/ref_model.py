@@ -351,13 +351,17 @@ def patch_mask(sample_hard, gamma, patch_size):
 # ----------------------------------------------------------------------------- forward graph  (M:313-521)
 def forward(params, config, views, noise, lon=1.0, dtype=torch.float32, seed=None):
     """views: dict view0/view1/view0_target [B,S,S,3]; noise: eps_pi0 [7,B,Z], eps_pi1 [B,Z],
-    eps_l0/eps_l1 [B,S,S,P].  use_tps must be False (TPS is a 'next' row)."""
-    assert not config.get("use_tps", False), "TPS augmentation is outside the oracle's scope"
+    eps_l0/eps_l1 [B,S,S,P] (+ tps_u [2B, tps.N_UNIFORMS] uniforms when use_tps is set)."""
     nets = Nets(config, params, seed)
     o = {}
     df = is_48c(config)
     v0, v1 = views["view0"].to(dtype), views["view1"].to(dtype)
     vt = v0 if df else views["view0_target"].to(dtype)      # DF:253,669: two inputs, the target is view0 itself
+    if config.get("use_tps", False):                         # M:334-337, 282-311 (oracle/tps.py: UNVERIFIED semantics)
+        from . import tps as TPS
+        v0, v1, vt2 = TPS.make_tps((v0, v1, vt), noise["tps_u"].to(dtype), config["tps_parameters"])
+        vt = v0 if df else vt2
+        o["tps_view0"], o["tps_view1"], o["tps_view0_target"] = v0, v1, vt
     B = v0.shape[0]
     Z = config.get("z0_size", 256)
     gamma = config.get("gamma", 3.0)
@@ -807,5 +811,9 @@ def synthetic_noise(config, seed=4321, batch=None):
     B = batch or config["batch_size"]; S = config["spatial_size"]
     Z = config.get("z0_size", 256); P = config["n_parts"]
     g = torch.Generator(); g.manual_seed(seed)
-    return {"eps_pi0": torch.randn(9 if is_48c(config) else 7, B, Z, generator=g), "eps_pi1": torch.randn(B, Z, generator=g),
-            "eps_l0": torch.randn(B, S, S, P, generator=g), "eps_l1": torch.randn(B, S, S, P, generator=g)}
+    out = {"eps_pi0": torch.randn(9 if is_48c(config) else 7, B, Z, generator=g), "eps_pi1": torch.randn(B, Z, generator=g),
+           "eps_l0": torch.randn(B, S, S, P, generator=g), "eps_l1": torch.randn(B, S, S, P, generator=g)}
+    if config.get("use_tps", False):
+        from . import tps as TPS
+        out["tps_u"] = torch.rand(2 * B, TPS.N_UNIFORMS, generator=g)
+    return out

@@ -338,3 +338,22 @@ def test_adam_and_gauss(dev):
     Lt[..., 1, 0] = torch.randn(2, 3, generator=g) * 0.2
     hm3 = ops.gauss_hm3(mu.to(dev), Lt.to(dev), 9, 11)
     assert np.allclose(hm3.cpu().numpy(), np_ops.tf_hm3(9, 11, mu.numpy(), Lt.numpy()), rtol=1e-4, atol=1e-6)
+
+
+def test_tps_warp_matches_oracle(dev):
+    """ups_tps_warp + the host-side parameter / solve code (upsparts_amd.tps) against oracle/tps.py on identical uniforms."""
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import tps as PT
+    from oracle import tps as OT
+    g = torch.Generator().manual_seed(11)
+    P = dict(scal=0.8, tps_scal=0.15, rot_scal=0.2, off_scal=0.2, scal_var=0.1, augm_scal=1.0)
+    B, S = 3, 40
+    views = [torch.rand(B, S, S, 3, generator=g) * 2 - 1 for _ in range(3)]
+    u = torch.rand(2 * B, OT.N_UNIFORMS, generator=g)
+    want = OT.make_tps([v.double() for v in views], u.double(), P)
+    got = PT.make_tps([v.to(dev) for v in views], P, uniforms=u.to(dev))
+    for a, b, name in zip(got, want, ("view0", "view1", "target")):
+        assert_close(a.float().cpu(), b.float(), 2e-4, "tps " + name)
+    c, v = PT.make_input_tps_param(PT.tps_parameters(2 * B, uniforms=u.to(dev), **P))
+    co, vo = OT.make_input_tps_param(OT.uniforms_to_params(u.double(), **P))
+    assert_close(PT.solve_system(c, v).cpu(), OT.solve_system(co, vo).float(), 1e-5, "tps solve")

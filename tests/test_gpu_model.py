@@ -16,7 +16,12 @@ def _setup(precision, dev, variant="cub", size="tiny"):
     import upsparts_amd  # noqa: F401
     from upsparts_amd.model import TrainModel, Trainer
     from oracle import ref_model as R, configs
-    if size == "tiny25":        # 25 parts (the shipped yamls' part count), odd batch: ragged lane groups / fallback conv paths
+    if size == "tiny_tps":      # the shipped CUB yaml's default: in-graph TPS augmentation of all three views
+        cfg = configs.tiny_config(variant=variant)
+        cfg["use_tps"] = True
+        cfg.setdefault("tps_parameters", {"scal": 0.8, "tps_scal": 0.15, "rot_scal": 0.2, "off_scal": 0.2, "scal_var": 0.1,
+                                          "augm_scal": 1.0})
+    elif size == "tiny25":        # 25 parts (the shipped yamls' part count), odd batch: ragged lane groups / fallback conv paths
         cfg = configs.tiny_config(n_parts=25, batch_size=3, variant=variant)
     else:
         cfg = configs.tiny_config(variant=variant) if size == "tiny" else configs.small_config(variant=variant)
@@ -39,7 +44,7 @@ def _setup(precision, dev, variant="cub", size="tiny"):
 
 
 CASES = [("cub", "tiny"), ("pennaction", "tiny"), ("deepfashion", "tiny"), ("cub", "small"), ("deepfashion", "small"),
-         ("cub", "tiny25"), ("deepfashion", "tiny25")]
+         ("cub", "tiny25"), ("deepfashion", "tiny25"), ("cub", "tiny_tps")]
 
 
 @pytest.mark.parametrize("variant,size", CASES)

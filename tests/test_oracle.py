@@ -174,3 +174,29 @@ def test_gaussian_renderers_docstring_example():
     mu = np.zeros((1, 1, 2)); Lm = np.eye(2)[None, None] * 0.5
     d = np_ops.tf_hm3(5, 5, mu, Lm)
     assert abs(d[0, 2, 2, 0] - 1.0 / (2 * math.pi * 0.25)) < 1e-9
+
+
+def test_tps_oracle_properties():
+    """TPS restatement (oracle/tps.py): the solved map sends every control point to its target, the target view shares
+    view0's transform, and a zero-vector / unit-scale / zero-rotation draw is the plain re-sampling of the classic STN
+    (pixel = (coord + 1) * size / 2)."""
+    from oracle import tps
+    g = torch.Generator().manual_seed(3)
+    u = torch.rand(6, tps.N_UNIFORMS, generator=g, dtype=torch.float64)
+    P = dict(scal=0.8, tps_scal=0.15, rot_scal=0.2, off_scal=0.2, scal_var=0.1, augm_scal=1.0)
+    c, v = tps.make_input_tps_param(tps.uniforms_to_params(u, **P))
+    T = tps.solve_system(c, v)
+    K = c.shape[1]
+    d2 = ((c.unsqueeze(2) - c.unsqueeze(1)) ** 2).sum(-1)
+    feats = torch.cat([torch.ones(6, K, 1, dtype=torch.float64), c, d2 * torch.log(d2 + 1e-6)], -1)
+    f = torch.einsum("nck,nik->nic", T, feats)
+    assert float((f - (c + v)).abs().max()) < 1e-12
+    imgs = [torch.rand(3, 16, 16, 3, generator=g, dtype=torch.float64) for _ in range(3)]
+    a0, a1, at = tps.make_tps(imgs, u, P)
+    b0, _, _ = tps.make_tps((imgs[2], imgs[1], imgs[0]), u, P)
+    assert torch.equal(at, b0)                      # the target is warped with view0's parameters
+    ident = tps.thin_plate_spline(imgs[0], c[:3], torch.zeros_like(v[:3]))
+    xs = torch.linspace(-1, 1, 16, dtype=torch.float64)
+    ref = tps.interpolate(imgs[0], xs.view(1, 1, 16).expand(3, 16, 16), xs.view(1, 16, 1).expand(3, 16, 16))
+    # (interior only: the STN formula is discontinuous where a sample position crosses the first / last pixel centre)
+    assert float((ident - ref)[:, 1:-1, 1:-1].abs().max()) < 1e-9

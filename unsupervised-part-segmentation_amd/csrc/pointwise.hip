@@ -446,3 +446,57 @@ extern "C" int ups_pad_convert(const float* src, int32_t c, void* dst, int32_t d
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }
+
+// ------------------------------------------------------------------ thin-plate-spline warp (cub/code/SB_model48i/model.py:282-311)
+// The reference calls the un-vendored eddata.utils.tps ("adapted from CompVis/unsupervised-disentangling",
+// train_cub_subset_tps.yaml:188): TPS spatial transformer, source position of every output pixel
+//   (x_s, y_s) = T @ [1, x, y, phi_1 .. phi_K],  phi_i = d2 * log(d2 + 1e-6), d2 = |(x,y) - coord_i|^2   on linspace(-1,1),
+// then the classic `_interpolate`: pixel = (coord + 1) * size / 2, corner indices clamped, weights from the clamped corners.
+// One thread per output pixel; T and the control points of the image sit in LDS.  Semantics UNVERIFIED (parity unpinned).
+namespace {
+constexpr int TPS_MAXK = 32;
+__global__ __launch_bounds__(256) void tps_warp_kernel(const float* __restrict__ img, const float* __restrict__ T,
+                                                        const float* __restrict__ coord, float* __restrict__ out,
+                                                        int h, int w, int c, int K) {
+    __shared__ float sT[2 * (TPS_MAXK + 3)], sC[2 * TPS_MAXK];
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * (K + 3); i += 256) sT[i] = T[(long long)n * 2 * (K + 3) + i];
+    for (int i = threadIdx.x; i < 2 * K; i += 256) sC[i] = coord[(long long)n * 2 * K + i];
+    __syncthreads();
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= h * w) return;
+    const int yy = q / w, xx = q - yy * w;
+    const float x = w > 1 ? -1.f + 2.f * (float)xx / (float)(w - 1) : -1.f;
+    const float y = h > 1 ? -1.f + 2.f * (float)yy / (float)(h - 1) : -1.f;
+    float xs = sT[0] + sT[1] * x + sT[2] * y;
+    float ys = sT[K + 3] + sT[K + 4] * x + sT[K + 5] * y;
+    for (int i = 0; i < K; ++i) {
+        const float dx = x - sC[2 * i], dy = y - sC[2 * i + 1];
+        const float d2 = dx * dx + dy * dy;
+        const float r = d2 * logf(d2 + 1e-6f);
+        xs += sT[3 + i] * r;
+        ys += sT[K + 6 + i] * r;
+    }
+    const float px = (xs + 1.f) * (float)w * 0.5f, py = (ys + 1.f) * (float)h * 0.5f;
+    const float x0 = floorf(px), y0 = floorf(py);
+    const float x0c = fminf(fmaxf(x0, 0.f), (float)(w - 1)), x1c = fminf(fmaxf(x0 + 1.f, 0.f), (float)(w - 1));
+    const float y0c = fminf(fmaxf(y0, 0.f), (float)(h - 1)), y1c = fminf(fmaxf(y0 + 1.f, 0.f), (float)(h - 1));
+    const float wa = (x1c - px) * (y1c - py), wb = (x1c - px) * (py - y0c), wc = (px - x0c) * (y1c - py), wd = (px - x0c) * (py - y0c);
+    const long long base = (long long)n * h * w;
+    const float* pa = img + (base + (long long)y0c * w + (long long)x0c) * c;
+    const float* pb = img + (base + (long long)y1c * w + (long long)x0c) * c;
+    const float* pc = img + (base + (long long)y0c * w + (long long)x1c) * c;
+    const float* pd = img + (base + (long long)y1c * w + (long long)x1c) * c;
+    float* o = out + (base + q) * c;
+    for (int k = 0; k < c; ++k) o[k] = wa * pa[k] + wb * pb[k] + wc * pc[k] + wd * pd[k];
+}
+}  // namespace
+
+extern "C" int ups_tps_warp(const float* img, const float* T, const float* coord, float* out, int32_t n, int32_t h, int32_t w,
+                            int32_t c, int32_t K, void* stream) {
+    UPS_CHECK_ARG(img && T && coord && out && n > 0 && h > 0 && w > 0 && c > 0 && K >= 1 && K <= TPS_MAXK);
+    hipLaunchKernelGGL(tps_warp_kernel, dim3(ups_cdiv((long long)h * w, 256), n), dim3(256), 0, (hipStream_t)stream, img, T, coord,
+                       out, h, w, c, K);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}

@@ -25,6 +25,7 @@ from . import lib as L
 from . import nets as N
 from . import ops
 from . import dist as D
+from . import tps as TPS
 from .nets import Act
 from .schedules import make_var, make_linear_var
 
@@ -44,10 +45,8 @@ class TrainModel(object):
         self.device = torch.device(device if device is not None else "cuda:{}".format(torch.cuda.current_device()))
         self.pretty = config.get("use_pretty", False)
         self.n_parts = config.get("n_parts")
-        self.use_tps = config.get("use_tps", False)
-        if self.use_tps:
-            raise NotImplementedError("in-graph TPS (eddata.utils.tps) is a 'next' row: feed pre-warped views "
-                                      "or set use_tps: False")
+        self.use_tps = config.get("use_tps", False)             # model.py:334-337: in-graph TPS augmentation (tps.py, UNVERIFIED)
+        self.tps_parameters = dict(config.get("tps_parameters") or {}) if self.use_tps else None
         prec = str(config.get("precision", "bf16")).lower()
         self.act_dtype = torch.float32 if prec in ("fp32", "f32", "float32") else torch.bfloat16
         self.patch_size = config.get("patch_size", 32)
@@ -70,7 +69,10 @@ class TrainModel(object):
     # model.py:265-280 -- evaluated for the most recent batch given to ``forward``
     @property
     def outputs(self):
-        return self._last
+        out = dict(self._last)
+        if self.use_tps:
+            out.update(getattr(self, "_tps", {}))        # model.py:272-279
+        return out
 
     def to_act(self, x_f32):
         """fp32 [n,H,W,c] -> activation dtype, 8-padded channels."""
@@ -255,6 +257,12 @@ class Trainer(object):
         v1 = batch["view1"].to(dev, torch.float32).contiguous()
         df = model.df
         vt = v0 if df else batch["view0_target"].to(dev, torch.float32).contiguous()    # SB_model48c:669: target = view0
+        if model.use_tps:           # model.py:334-337, 282-311
+            tu = None if noise is None or "tps_u" not in noise else noise["tps_u"].to(dev, torch.float32)
+            aug = TPS.make_tps([v0, v1] if df else [v0, v1, vt], model.tps_parameters, uniforms=tu, generator=self._gen)
+            v0, v1 = aug[0], aug[1]
+            vt = v0 if df else aug[2]
+            model._tps = {"tps_view0": v0, "tps_view1": v1, "tps_view0_target": vt}
         B, S = v0.shape[0], v0.shape[1]
         Z, A, P = cfg.get("z0_size", 256), cfg.get("local_app_size", 64), model.n_parts
         gamma = float(cfg.get("gamma", 3.0))
