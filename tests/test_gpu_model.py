@@ -124,3 +124,41 @@ def test_inference_outputs(dev):
     assert_close(out["out_parts_soft"], o["out_parts_soft"].float(), 1e-3, "out_parts_soft")
     assert float((out["out_parts_hard"].cpu() == o["out_parts_hard"]).float().mean()) >= 0.999
     assert_close(out["generated"], o["generated"].float(), 1e-3, "generated")
+
+
+def test_runner_end_to_end_with_csv_dataset_and_checkpoint(dev, tmp_path):
+    """`python -m upsparts_amd.runner -t <yaml>` (the `edflow -t` work-alike): reference import paths in the yaml, the csv pair
+    dataset, LoggingHook lines at steps 0,1,2,4, a checkpoint every ckpt_freq steps and a lazy restore from it."""
+    import numpy as np
+    import yaml
+    from PIL import Image
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import configs, runner
+    rng = np.random.RandomState(0)
+    rows = ["character_id,relative_file_path_,foo,category"]
+    for i in range(8):
+        Image.fromarray(rng.randint(0, 255, (24, 24, 3), dtype=np.uint8)).save(str(tmp_path / "im{}.png".format(i)))
+        rows.append("{},im{}.png,x,bird".format(i // 2, i))
+    (tmp_path / "train.csv").write_text("\n".join(rows) + "\n")
+    cfg = copy.deepcopy(configs.tiny_config())
+    cfg.update({"dataset": "src.data.data.AugmentedPair2", "data_root": str(tmp_path), "data_csv": str(tmp_path / "train.csv"),
+                "data_csv_columns": ["character_id", "relative_file_path_", "foo", "category"], "data_csv_has_header": True,
+                "data_avoid_identity": False, "precision": "bf16", "vgg_widths": list(VGG_W), "use_tps": True,
+                "ckpt_freq": 2, "log_freq": 250, "num_steps": 5})
+    assert cfg["model"] == "nips19.SB_model48i.model.TrainModel"
+    ypath = tmp_path / "train.yaml"
+    ypath.write_text(yaml.safe_dump(cfg))
+    root = tmp_path / "run"
+    it = runner.main(["-t", str(ypath), "-p", str(root), "--strict-dataset"])
+    assert it.global_step == 5
+    log = (root / "train" / "log.txt").read_text()
+    for s in (0, 1, 2, 4):
+        assert "[INFO] [LoggingHook]: global_step: {}\n".format(s) in log
+    assert "[INFO] [LoggingHook]: global_step: 3\n" not in log and "loss_decoder_visualize" in log
+    ck = root / "train" / "checkpoints" / "model.ckpt-4"
+    assert ck.exists() and (root / "train" / "checkpoints" / "model.ckpt-2").exists()
+    it2 = runner.main(["-t", str(ypath), "-p", str(tmp_path / "run2"), "-c", str(ck), "--num_steps", "6", "--strict-dataset"])
+    assert it2.global_step == 6
+    # restored weights: the step-4 checkpoint was written after the update of step 4, training resumed at global step 4
+    saved = torch.load(str(ck), map_location="cpu")
+    assert saved["global_step"] == 5 or saved["global_step"] == 4

@@ -153,3 +153,36 @@ def test_data_parallel_helpers_gloo_world2():
     assert out[0][1] == out[1][1] == 9.0
     assert out[0][2] == out[1][2] == [0.5, 1.0]
     assert out[0][3] != out[1][3]
+
+
+def test_csv_pair_datasets(tmp_path):
+    """upsparts_amd.data: csv -> pairs by character_id (cub/code/data/data.py:31-50,157-175), [-1,1] float32 NHWC, target copy,
+    avoid_identity, static batch size."""
+    import numpy as np
+    from PIL import Image
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import data
+    rng = np.random.RandomState(0)
+    rows = ["character_id,relative_file_path_,foo,category"]
+    for i in range(7):
+        Image.fromarray(rng.randint(0, 255, (20 + i, 24, 3), dtype=np.uint8)).save(str(tmp_path / "im{}.png".format(i)))
+        rows.append("{},im{}.png,x,bird".format(i // 3, i))          # characters 0,0,0,1,1,1,2
+    (tmp_path / "train.csv").write_text("\n".join(rows) + "\n")
+    cfg = {"data_root": str(tmp_path), "data_csv": str(tmp_path / "train.csv"), "data_csv_has_header": True,
+           "data_csv_columns": ["character_id", "relative_file_path_", "foo", "category"], "spatial_size": 16,
+           "data_avoid_identity": True, "batch_size": 3}
+    ds = data.AugmentedPair2(cfg)
+    assert len(ds) == 7 and [len(c) for c in ds.labels["choices"]] == [3, 3, 3, 3, 3, 3, 1]
+    for i in range(7):
+        j = ds.pick_partner(i)
+        assert ds.labels["character_id"][j] == ds.labels["character_id"][i] and (j != i or i == 6)
+    ex = ds.get_example(1)
+    assert set(ex) == {"view0", "view1", "view0_target"} and ex["view0"].shape == (16, 16, 3) and ex["view0"].dtype == np.float32
+    assert -1.0 <= ex["view0"].min() and ex["view0"].max() <= 1.0 and np.array_equal(ex["view0"], ex["view0_target"])
+    it = data.batches(ds, 3, workers=2, epochs=1)
+    bs = list(it)
+    assert len(bs) == 2 and bs[0]["view1"].shape == (3, 16, 16, 3) and bs[0]["view1"].dtype == torch.float32
+    pair = data.StochasticPairs(dict(cfg, data_flip_h=True))
+    assert set(pair.get_example(0)) == {"view0", "view1"}
+    with pytest.raises(NotImplementedError):
+        data.AugmentedPair2(dict(cfg, data_augment_shape=True))

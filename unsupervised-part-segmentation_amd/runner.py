@@ -8,8 +8,9 @@ reference: requirements.txt:33).  Keeps the surface the shipped configs rely on:
   * ``[INFO] [LoggingHook]: name: value`` lines at steps 0,1,2,4,8,... and every ``log_freq``; checkpoints every
     ``ckpt_freq`` under ``<root>/train/checkpoints/model.ckpt-<step>``.
 
-Data: the CSV/albumentations pipeline (cub/code/data/data.py) is out of the hot path; ``dataset:`` values that
-cannot be imported fall back to ``SyntheticPairs`` (U(-1,1) views) unless ``--strict-dataset`` is given.
+Data: ``dataset: src.data.data.AugmentedPair2`` / ``eddata.stochastic_pair.StochasticPairs`` resolve to the csv pair
+datasets of ``data.py``; when the csv / images are not there (or any other class cannot be imported) the runner falls back
+to ``SyntheticPairs`` (U(-1,1) views) unless ``--strict-dataset`` is given.
 """
 import argparse
 import importlib
@@ -21,7 +22,11 @@ import yaml
 
 from .model import TrainModel, Trainer
 
+from . import data as _data
+
 ALIASES = {"TrainModel": TrainModel, "Trainer": Trainer}
+DATA_ALIASES = {"src.data.data.AugmentedPair2": _data.AugmentedPair2, "nips19.data.data.AugmentedPair2": _data.AugmentedPair2,
+                "eddata.stochastic_pair.StochasticPairs": _data.StochasticPairs}
 
 
 def get_obj_from_str(path):
@@ -69,7 +74,9 @@ def main(argv=None):
     os.makedirs(os.path.join(root, "train"), exist_ok=True)
     Model, Iterator = get_obj_from_str(cfg["model"]), get_obj_from_str(cfg["iterator"])
     try:
-        dataset = get_obj_from_str(cfg["dataset"])(cfg)
+        cls = DATA_ALIASES.get(cfg["dataset"]) or get_obj_from_str(cfg["dataset"])
+        ds = cls(cfg)
+        dataset = _data.batches(ds, cfg["batch_size"]) if isinstance(ds, _data.StochasticPairs) else ds
     except Exception:
         if args.strict_dataset:
             raise
