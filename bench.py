@@ -123,7 +123,7 @@ def main():
                                       "stand-in weights at native 128x128".format(args.parts, args.batch),
                           "global_batch": args.batch * world, "parallelism": "dp{}".format(world)},
                "model_tflops_per_gpu": round(value * TRAIN_GFLOP_PER_IMAGE / 1e3 / world, 2),
-               "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel<{},128> @ {}".format(
+               "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel<{},128,2,16> @ {}".format(
                                 "bf16" if args.precision == "bf16" else "f32", ops.KernelTimer.layer),
                             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                             "kernel_ms": round(kms, 4), "launches_timed": len(ops.KernelTimer.events), "traffic": traffic,
