@@ -108,7 +108,7 @@ def main():
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         traffic = None
         try:   # HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/), not measured live
-            with open(os.path.join(ROOT, "profiles", "round1_v14_pmc_dv_rb128.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "round1_v15_pmc_dv_rb128.json")) as f:
                 traffic = json.load(f)["traffic_bytes_per_launch"] * (args.batch / 64.0) if args.precision == "bf16" else None
         except Exception:
             traffic = None

@@ -12,6 +12,9 @@ rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline > $O/bench.log 2>&1
 grep '"metric"' $O/bench.log > $O/round1_${TAG}_bench_b64.json
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/round1_${TAG}_bench_b64_kernel_stats.csv
+# per-(kernel, grid) durations of the patch kernel from the same trace: the roofline launch is the 8388608-thread grid of
+# conv3x3_patch_kernel<bf16,128,2,16> (one forward + two input-gradient launches of decoder_visualize/conv2d_8 per step)
+python3 tools/trace_summary.py $(find $O/stats -name "*kernel_trace.csv" | head -1) conv3x3_patch > $O/round1_${TAG}_patch_kernel_by_grid.txt
 rm -rf $O/stats
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 tools/one_conv.py fwd > /dev/null 2>&1
