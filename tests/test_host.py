@@ -186,3 +186,20 @@ def test_csv_pair_datasets(tmp_path):
     assert set(pair.get_example(0)) == {"view0", "view1"}
     with pytest.raises(NotImplementedError):
         data.AugmentedPair2(dict(cfg, data_augment_shape=True))
+
+
+def test_part_iou_evaluation():
+    """evalutil: best-IoU remapping of inferred part ids to ground-truth labels + per-label IoU (eval_01.py:229-383 protocol)."""
+    import numpy as np
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import evalutil as E
+    gt = np.zeros((2, 8, 8), dtype=np.int64)
+    gt[:, :4, :4] = 1; gt[:, 4:, 4:] = 2                      # background 0, head 1, tail 2
+    pred = np.full((2, 8, 8), 7, dtype=np.int64)              # part 7 ~ background
+    pred[:, :4, :4] = 3; pred[:, 4:, 4:] = 5; pred[0, 4, 4] = 3  # parts 3 -> head, 5 -> tail (one pixel wrong)
+    r = E.evaluate_parts(pred, gt)
+    assert r["mapping"] == {3: 1, 5: 2, 7: 0}
+    assert abs(r["iou"][1] - 32 / 33) < 1e-12 and abs(r["iou"][2] - 31 / 32) < 1e-12 and r["iou"][0] == 1.0
+    assert abs(r["overall"] - 0.5 * (32 / 33 + 31 / 32)) < 1e-12
+    same = E.evaluate_parts(gt, gt)
+    assert same["overall"] == 1.0
