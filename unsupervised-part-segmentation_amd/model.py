@@ -640,8 +640,12 @@ class Trainer(object):
             self.train_step(batch)
             if s % log_freq == 0 or (s & (s - 1)) == 0:      # edflow LoggingHook: steps 0,1,2,4,8,... and every log_freq
                 log_fn("[INFO] [LoggingHook]: global_step: {}".format(s))
-                for k, v in self.fetch_logs().items():
+                logs = self.fetch_logs()
+                for k, v in logs.items():
                     log_fn("[INFO] [LoggingHook]: {}: {}".format(k, v))
+                bad = [k for k, v in logs.items() if k.startswith("loss_") and not math.isfinite(v)]
+                if bad:       # failure detection on log steps only (the step itself never synchronises with the host)
+                    raise FloatingPointError("non-finite {} at global step {}".format(", ".join(bad), s))
             if self.root and ckpt_freq and s > 0 and s % ckpt_freq == 0:
                 os.makedirs(os.path.join(self.root, "train", "checkpoints"), exist_ok=True)
                 self.save_checkpoint(os.path.join(self.root, "train", "checkpoints", "model.ckpt-{}".format(s)))
