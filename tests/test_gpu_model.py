@@ -162,3 +162,29 @@ def test_runner_end_to_end_with_csv_dataset_and_checkpoint(dev, tmp_path):
     # restored weights: the step-4 checkpoint was written after the update of step 4, training resumed at global step 4
     saved = torch.load(str(ck), map_location="cpu")
     assert saved["global_step"] == 5 or saved["global_step"] == 4
+
+
+def test_fix_weights_and_pretrain_keys(dev):
+    """yaml keys `fix_weights` (model.py:1062-1067: the listed optimizer keys are dropped) and `pretrain` (model.py:785-797:
+    decoder_visualize is trained on the reconstruction loss only)."""
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd.model import TrainModel, Trainer
+    from oracle import ref_model as R, configs
+    cfg = copy.deepcopy(configs.tiny_config())
+    cfg.update(precision="fp32", vgg_widths=VGG_W, fix_weights=["encoder_1", "mi_estimator"], pretrain=True)
+    model = TrainModel(cfg, device=dev, seed=0)
+    tr = Trainer(cfg, None, model)
+    before = {k: g["flat"]["p"].clone() for k, g in model.bank.groups.items()}
+    views, noise = R.synthetic_views(cfg), R.synthetic_noise(cfg)
+    losses = tr.train_step(views, noise)
+    assert set(losses) == set(R.SUBMODULES) - {"encoder_1", "mi_estimator"}
+    for k, g in model.bank.groups.items():
+        changed = not torch.equal(before[k], g["flat"]["p"])
+        assert changed == (k not in ("encoder_1", "mi_estimator")), k
+    assert abs(float(losses["decoder_visualize"]) - float(losses["decoder_delta"])) < 1e-6      # pretrain: no prior terms
+    params, vp = R.init_params(cfg, 0), R.vgg_params(7, widths=VGG_W)
+    _, Lo, _, _, grads = R.gradients(params, cfg, views, noise, R.initial_state(cfg), 0, vp, dtype=torch.float64)
+    assert set(Lo) == set(losses)
+    for n, g in grads.items():
+        if "decoder_visualize" in n:
+            assert rel_err(model.bank.grads[n], g.float()) <= 2e-3, n
