@@ -16,7 +16,10 @@ def _setup(precision, dev, variant="cub", size="tiny"):
     import upsparts_amd  # noqa: F401
     from upsparts_amd.model import TrainModel, Trainer
     from oracle import ref_model as R, configs
-    if size == "tiny_tps":      # the shipped CUB yaml's default: in-graph TPS augmentation of all three views
+    if size == "tiny_det":      # stochastic_l: False -> the mask logits are used without noise (model.py:420-421)
+        cfg = configs.tiny_config(variant=variant)
+        cfg["stochastic_l"] = False
+    elif size == "tiny_tps":      # the shipped CUB yaml's default: in-graph TPS augmentation of all three views
         cfg = configs.tiny_config(variant=variant)
         cfg["use_tps"] = True
         cfg.setdefault("tps_parameters", {"scal": 0.8, "tps_scal": 0.15, "rot_scal": 0.2, "off_scal": 0.2, "scal_var": 0.1,
@@ -44,7 +47,7 @@ def _setup(precision, dev, variant="cub", size="tiny"):
 
 
 CASES = [("cub", "tiny"), ("pennaction", "tiny"), ("deepfashion", "tiny"), ("cub", "small"), ("deepfashion", "small"),
-         ("cub", "tiny25"), ("deepfashion", "tiny25"), ("cub", "tiny_tps")]
+         ("cub", "tiny25"), ("deepfashion", "tiny25"), ("cub", "tiny_tps"), ("cub", "tiny_det")]
 
 
 @pytest.mark.parametrize("variant,size", CASES)

@@ -237,7 +237,10 @@ class Trainer(object):
             d.w_ms_logits = w.get("msl", 0.0)
         else:
             d.variant = 0
-            d.entropy_ce = int(self.config.get("entropy_func", "cross_entropy") == "cross_entropy")
+            ef = self.config.get("entropy_func", "cross_entropy")
+            if ef not in ("cross_entropy", "entropy"):
+                raise ValueError("unkown entropy_func")               # model.py:680 (spelling as in the reference)
+            d.entropy_ce = int(ef == "cross_entropy")
             d.gamma = float(self.config.get("gamma", 3.0))
             d.ms_alpha, d.ms_lambda = 1.0, 1.0e-2                  # hard-coded at model.py:744-746
         d.w_kl, d.w_entropy, d.w_ms, d.w_area = w["kl"], w["entropy"], w["ms"], w["area"]
@@ -373,7 +376,9 @@ class Trainer(object):
         lm = l_mean.detach()
 
         # ================= part path, untaped (model.py:414-473)
-        eps_l = torch.cat([noise["eps_l0"], noise["eps_l1"]], 0)
+        # model.py:420-421 / nn.py:1427-1433: l = mean + eps unless `stochastic_l: False` (default: not test_mode)
+        stochastic_l = cfg.get("stochastic_l", not cfg.get("test_mode", False))
+        eps_l = torch.cat([noise["eps_l0"], noise["eps_l1"]], 0) if stochastic_l else None
         l, m, hard, _ = ops.part_softmax(lm, eps_l)
         # [2B,P,2] rectangle centres (stop-gradient); SB_model48c has no rectangles
         px = None if df else ops.moments_to_px(ops.spatial_moments(hard, gamma), S)
