@@ -145,6 +145,10 @@ class Trainer(object):
         self.beta2 = config.get("beta2", 0.9)
         self.adam_eps = 1e-8
         self.perceptual_input = config.get("perceptual_input", "native")
+        if float(config.get("gram_weight", 0.0)) != 0.0:        # model.py:608: default 0.0 in every shipped yaml
+            raise NotImplementedError("gram_weight != 0 (Gram-matrix terms of edflow's VGG19Features) is not on the shipped path")
+        if config.get("use_pretty", False) or config.get("add_pretty", False):
+            raise NotImplementedError("the 'pretty' image discriminator (model.py:190-212) is not used by the shipped configs")
         vw = config.get("vgg_widths", N.VGG_WIDTHS)
         self.vgg = N.VggTrunk(self.device, seed=config.get("vgg_seed", 7), widths=tuple(vw))
         mi = config["MI"]
