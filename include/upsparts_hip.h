@@ -249,6 +249,9 @@ int ups_latent_bwd(const float* params, const float* eps, const float* level, co
  * p -= lr_t * m / (sqrt(v) + eps) over a flat fp32 buffer; lr_t computed by the caller. */
 int ups_adam(float* p, const float* g, float* m, float* v, int64_t count, float lr_t, float beta1, float beta2, float eps,
              float grad_scale, void* stream);
+/* same update with the step size read from a device scalar (a captured HIP graph of the step is replayed with new values) */
+int ups_adam_dev(float* p, const float* g, float* m, float* v, int64_t count, const float* lr_t_dev, float beta1, float beta2,
+                 float eps, float grad_scale, void* stream);
 
 /* ---------------------------------------------------------------- thin-plate-spline augmentation (M:282-311)
  * Replaces eddata.utils.tps.ThinPlateSpline (un-vendored; "adapted from CompVis/unsupervised-disentangling", Y:188):

@@ -191,3 +191,35 @@ def test_fix_weights_and_pretrain_keys(dev):
     for n, g in grads.items():
         if "decoder_visualize" in n:
             assert rel_err(model.bank.grads[n], g.float()) <= 2e-3, n
+
+
+def test_hip_graph_replay_matches_eager(dev):
+    """`hip_graph: True`: the captured step (three streams, ~2 000 launches) replayed with new inputs / noise / Adam step
+    size must reproduce the eager trainer bit for bit, including a re-capture when a schedule constant changes."""
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd.model import TrainModel, Trainer
+    from oracle import ref_model as R, configs
+    cfg = copy.deepcopy(configs.tiny_config())
+    cfg.update(precision="bf16", vgg_widths=VGG_W)
+    cfg["variance_weight"]["options"].update(start=4, step_size=1, stair_factor=2.0, clip_min=1.0, clip_max=64.0)   # moves at step 5
+    runs = {}
+    for mode in ("eager", "graph"):
+        c = copy.deepcopy(cfg)
+        c["hip_graph"] = mode == "graph"
+        model = TrainModel(c, device=dev, seed=0)
+        tr = Trainer(c, None, model)
+        hist = []
+        for step in range(7):
+            views = R.synthetic_views(c, seed=100 + step)
+            noise = R.synthetic_noise(c, seed=200 + step)
+            losses = tr.train_step(views, noise)
+            hist.append({k: float(v) for k, v in losses.items()})
+        runs[mode] = (hist, {k: g["flat"]["p"].detach().cpu().clone() for k, g in model.bank.groups.items()},
+                      {k: float(v) for k, v in tr.state.items()}, tr.global_step, tr._g)
+    assert runs["graph"][4] is not None and runs["graph"][4]["graph"] is not None, "the graph was never captured"
+    assert runs["eager"][3] == runs["graph"][3] == 7
+    for a, b in zip(runs["eager"][0], runs["graph"][0]):
+        assert a == b, (a, b)
+    for k in runs["eager"][1]:
+        assert torch.equal(runs["eager"][1][k], runs["graph"][1][k]), k
+    assert runs["eager"][2] == runs["graph"][2]

@@ -17,11 +17,12 @@ if name != "deepfashion" and S == 256:      # 4 -> 256 takes six doublings (SURV
     cfg["dv"]["config"] = [16] + cfg["dv"]["config"]; cfg["dv"]["upsample_config"] = ["linear"] * 6
     cfg["patch_size"] = 64
 cfg["precision"] = "bf16"
+cfg["hip_graph"] = os.environ.get("UPS_GRAPH", "0") == "1"
 dev = torch.device("cuda:0")
 model = TrainModel(cfg, device=dev, seed=0); tr = Trainer(cfg, None, model)
 g = torch.Generator().manual_seed(1)
 batch = {k: (torch.rand(B, S, S, 3, generator=g) * 2 - 1).to(dev) for k in ("view0", "view1", "view0_target")}
-for _ in range(2):
+for _ in range(4):
     tr.train_step(batch)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):

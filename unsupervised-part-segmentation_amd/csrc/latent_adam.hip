@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long long count, float lr_t, float b1, float b2, float eps, float gscale) {
+                            long long count, float lr_t, const float* __restrict__ lr_t_dev, float b1, float b2, float eps,
+                            float gscale) {
+    if (lr_t_dev) lr_t = *lr_t_dev;       // device scalar: lets a captured HIP graph be replayed with the step's learning rate
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
         const float gg = g[i] * gscale;
         const float mm = b1 * m[i] + (1.f - b1) * gg;
@@ -175,6 +177,18 @@ extern "C" int ups_adam(float* p, const float* g, float* m, float* v, int64_t co
     long long grid = (count + 255) / 256;
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(adam_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)count, lr_t,
+                       (const float*)nullptr, beta1, beta2, eps, grad_scale);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_adam_dev(float* p, const float* g, float* m, float* v, int64_t count, const float* lr_t_dev, float beta1,
+                            float beta2, float eps, float grad_scale, void* stream) {
+    UPS_CHECK_ARG(p && g && m && v && lr_t_dev && count >= 0);
+    if (count == 0) return UPS_OK;
+    long long grid = (count + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)count, 0.f, lr_t_dev,
                        beta1, beta2, eps, grad_scale);
     UPS_LAUNCH_CHECK();
     return UPS_OK;

@@ -108,6 +108,7 @@ _SIGS = {
     "ups_latent_fwd": ([_P, _P, C.POINTER(_F), _I, _I, _I, _P, _P, _P], C.c_int),
     "ups_latent_bwd": ([_P, _P, C.POINTER(_F), _P, _P, _F, _I, _I, _I, _P, _P], C.c_int),
     "ups_adam": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P], C.c_int),
+    "ups_adam_dev": ([_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P], C.c_int),
     "ups_tps_warp": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "ups_gauss_hm": ([_P, _P, _P, _I, _I, _I, _I, _P], C.c_int),
     "ups_gauss_hm3": ([_P, _P, _P, _I, _I, _I, _I, _P], C.c_int),

@@ -163,6 +163,8 @@ class Trainer(object):
         self._gen.manual_seed(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))
         self.losses = OrderedDict((k, None) for k in self.loss_keys())
         self._early, self._early_hooked = {}, False
+        self._graph_enabled = bool(config.get("hip_graph", os.environ.get("UPS_GRAPH", "0") == "1"))
+        self._g = None
 
     # ------------------------------------------------------------------ edflow hook surface
     def loss_keys(self):
@@ -256,6 +258,65 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ one session.run(train_op)
     def train_step(self, batch, noise=None):
+        """One session.run(train_op).  With ``hip_graph: True`` (single GPU) the whole step -- ~2 400 kernel launches on three
+        streams -- is captured once into a HIP graph and replayed; see ``_graph_step``."""
+        if self._graph_enabled and self.world_size == 1 and not self.model.use_tps:
+            return self._graph_step(batch, noise)
+        return self._step_impl(batch, noise)
+
+    # ------------------------------------------------------------------ HIP-graph replay of the step
+    def _schedule_signature(self):
+        """Everything the captured launches bake in by value: the step's schedule constants."""
+        cfg, step = self.config, self.global_step
+        keys = ("prior_gmrf_weight", "prior_mumford_sha_weight", "variance_weight", "weakly_superv_loss_weight_p",
+                "patch_loss_weight", "mumford_sha_alpha", "mumford_sha_lambda")
+        sig = tuple(make_var(step, cfg[k]) for k in keys if k in cfg)
+        return sig + (make_linear_var(step, **cfg["kl_weight"]), bool(cfg.get("pretrain", False)))
+
+    def _graph_step(self, batch, noise):
+        """Static input / noise buffers + a device scalar for Adam's step size; the graph is (re)captured after two eager
+        steps and whenever a schedule constant changes (staircases move every few thousand steps).  The small-batch
+        configs of the reference (batch 8: ~2 400 launches for 24 ms of GPU work) are launch-bound without it."""
+        dev = self.device
+        B, S = batch["view0"].shape[0], batch["view0"].shape[1]
+        if self._g is None:
+            self._g = {"in": {k: torch.empty((B, S, S, 3), dtype=torch.float32, device=dev) for k in self.model.inputs},
+                       "noise": {k: torch.empty_like(v) for k, v in self.draw_noise(B).items()},
+                       "lr": torch.zeros(1, dtype=torch.float32, device=dev), "graph": None, "sig": None, "eager": 0}
+        g = self._g
+        for k, buf in g["in"].items():
+            buf.copy_(batch[k], non_blocking=True)
+        for k, buf in g["noise"].items():
+            if noise is None:
+                buf.normal_(generator=self._gen)
+            else:
+                buf.copy_(noise[k], non_blocking=True)
+        t = next(iter(self.model.bank.groups.values()))["t"] + 1
+        lr = self.learning_rate()
+        g["lr"].fill_(lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t))
+        sig = self._schedule_signature() + (lr > 0,)
+        if g["eager"] < 2:                       # warm-up: kernel attributes, side streams, allocator pools
+            g["eager"] += 1
+            out = self._step_impl(g["in"], g["noise"], graph_lr=g["lr"])
+            self._after_graph_step()
+            return out
+        if g["graph"] is None or g["sig"] != sig:
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._step_impl(g["in"], g["noise"], graph_lr=g["lr"])
+            g["graph"], g["sig"] = graph, sig   # (capturing does not execute: the replay below runs the step)
+        g["graph"].replay()
+        self._after_graph_step()
+        return self.losses
+
+    def _after_graph_step(self):
+        # (WeightVersion is not bumped: the step's own batched weight_prep has already refreshed every converted copy)
+        for grp in self.model.bank.groups.values():
+            grp["t"] += 1
+        self.global_step += 1
+
+    def _step_impl(self, batch, noise=None, graph_lr=None):
         cfg, model, nets, bank = self.config, self.model, self.model.nets, self.model.bank
         dev, T = self.device, model.act_dtype
         step = self.global_step
@@ -494,7 +555,7 @@ class Trainer(object):
 
         # ================= gradient all-reduce (data parallel) + TF Adam per key
         pending += self._launch_reduce([k for k in ("encoder_0",) if k in keys])
-        self._finish_step(keys, pending)
+        self._finish_step(keys, pending, graph_lr)
 
         # ================= state updates (update_ops; Appendix A.15: losses above used the pre-update state)
         stats = torch.stack([mim.detach(), ind_mim.detach(), acc0, acc1, loss_dis0.detach(), loss_dis1.detach()])
@@ -564,8 +625,13 @@ class Trainer(object):
                         "z_mumford_sha_contour_cost": sums0[7] / B, "z_area_cost": area_cost,
                         "prior_mumford_sha_weight": w_ms, "perceptual": rec.detach(), "lr": self.learning_rate()})
         self.log_ops = log
-        self.state = new
-        self.global_step += 1
+        if graph_lr is not None:        # graph mode: state lives in fixed device scalars, python counters advance outside
+            for k in st:
+                if new[k] is not st[k]:
+                    st[k].copy_(new[k])
+        else:
+            self.state = new
+            self.global_step += 1
         self._debug = {"l_mean": lm, "l": l, "m": m, "hard": hard, "px": px, "generated": gen.detach(), "feat": feat.detach(),
                        "dl_tot": dl_tot, "dl_rec": dl_rec, "g_hard0": g_hard0, "g_hard1": g_hard1, "pe": pe2}
         return self.losses
@@ -615,20 +681,25 @@ class Trainer(object):
             handles.append(D.allreduce_bucket(g, self.world_size, self.process_group))
         return handles
 
-    def _finish_step(self, keys, handles):
-        """Wait for the buckets, then one fused Adam launch per key (tf.train.AdamOptimizer semantics, Appendix A.12)."""
+    def _finish_step(self, keys, handles, graph_lr=None):
+        """Wait for the buckets, then one fused Adam launch per key (tf.train.AdamOptimizer semantics, Appendix A.12).
+        graph_lr: device scalar holding lr_t (HIP-graph mode; the python step counters then advance outside)."""
         bank = self.model.bank
         ops.Streams.join(self.device)
         D.wait_all(handles)
         lr = self.learning_rate()
         for k in keys:
             grp = bank.groups[k]
-            grp["t"] += 1
-            t = grp["t"]
-            lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
             f = grp["flat"]
+            if graph_lr is not None:
+                lr_t = graph_lr
+            else:
+                grp["t"] += 1
+                t = grp["t"]
+                lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
             ops.adam_step(f["p"], f["g"], f["m"], f["v"], lr_t, self.beta1, self.beta2, self.adam_eps, 1.0 / self.world_size)
-        ops.WeightVersion.value += 1
+        if graph_lr is None:
+            ops.WeightVersion.value += 1
         self.model.nets.prep.refresh()          # one launch: every layer's converted weights + CoordConv tables
 
     # ------------------------------------------------------------------ edflow iterate(): log cadence of LoggingHook

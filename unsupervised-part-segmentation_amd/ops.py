@@ -638,8 +638,13 @@ def latent_bwd(params, eps, levels, g_samples, g_kl_dev, g_kl_scale):
 
 
 def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0):
-    L.call("ups_adam", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), float(lr_t), float(beta1), float(beta2),
-           float(eps), float(grad_scale), L.stream())
+    """lr_t: python float, or a 1-element fp32 device tensor (HIP-graph mode: the value is read on the device)."""
+    if torch.is_tensor(lr_t):
+        L.call("ups_adam_dev", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(lr_t), float(beta1), float(beta2),
+               float(eps), float(grad_scale), L.stream())
+    else:
+        L.call("ups_adam", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), float(lr_t), float(beta1), float(beta2),
+               float(eps), float(grad_scale), L.stream())
 
 
 def gauss_hm(pts, stddev, h, w):
