@@ -229,6 +229,8 @@ typedef struct {
                                    * (deepfashion/code/nn.py:1388-1391,1451-1455; its sum is returned in sums[2], the patch slot),
                                    * view 1 variance = sum_p (S00^2 + S11^2) of the renormalised, un-masked spatial soft-max */
     float w_ms_logits;
+    float* dl_rec;                /* optional (bwd): d(reconstruction loss alone)/d l, i.e. the result of a second call with every
+                                   * weight zero -- the encoder_0 key sees this one, decoder_visualize sees `dl` */
 } ups_prior_desc;
 /* `sums` must hold 16 floats of result followed by scratch; total = ups_prior_sums_floats(n, P). */
 size_t ups_prior_sums_floats(int32_t n, int32_t P);

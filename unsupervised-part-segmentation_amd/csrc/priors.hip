@@ -24,7 +24,7 @@ struct PriorK {
     int n, h, w, P, view, entropy_ce, half_h, half_w, variant;
     float gamma, ms_alpha, ms_lambda, w_kl, w_entropy, w_ms, w_area, w_patch, w_gmrf, w_var, w_msl;
     const float* l; const float* l_mean; const float* m; const float* hard; const int* px;
-    float* per_np; float* sums; const float* g_hard; float* dl; float* ws;
+    float* per_np; float* sums; const float* g_hard; float* dl; float* ws; float* dl_rec;
 };
 
 template <int GP>
@@ -167,11 +167,11 @@ __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p) {
     const float inv_pix = 1.f / (float)npix_total, inv_n = 1.f / (float)p.n;
 
     const float mc = ok ? p.m[pp * p.P + c] : 0.f;
-    float gm = 0.f, direct = 0.f;
+    float gm = 0.f, direct = 0.f, gh = 0.f;
     if (ok) {
         const float pm = (float)p.P * mc;
         gm += p.w_kl * inv_pix * (logf(pm + 1e-20f) + pm / (pm + 1e-20f));
-        if (p.g_hard) gm += p.g_hard[pp * p.P + c];
+        if (p.g_hard) { gh = p.g_hard[pp * p.P + c]; gm += gh; }
     }
     if (p.view == 0) {
         const float lv = ok ? p.l[pp * p.P + c] : -INFINITY;
@@ -273,6 +273,10 @@ __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p) {
     }
     const float dot = gsum<GP>(mc * gm);
     if (ok) p.dl[pp * p.P + c] = mc * (gm - dot) + direct;
+    if (p.dl_rec) {     // the same launch also emits the gradient of the reconstruction loss alone (all prior weights zero)
+        const float dot_r = gsum<GP>(mc * gh);
+        if (ok) p.dl_rec[pp * p.P + c] = mc * (gh - dot_r);
+    }
 }
 
 int gp_of(int P) { int g = 2; while (g < P) g *= 2; return g; }
@@ -284,7 +288,7 @@ PriorK to_k(const ups_prior_desc* d, float* ws) {
     k.w_kl = d->w_kl; k.w_entropy = d->w_entropy; k.w_ms = d->w_ms; k.w_area = d->w_area; k.w_patch = d->w_patch;
     k.w_gmrf = d->w_gmrf; k.w_var = d->w_var; k.variant = d->variant; k.w_msl = d->w_ms_logits;
     k.l = d->l; k.l_mean = d->l_mean; k.m = d->m; k.hard = d->hard; k.px = d->px; k.per_np = d->per_np; k.sums = d->sums;
-    k.g_hard = d->g_hard; k.dl = d->dl; k.ws = ws;
+    k.g_hard = d->g_hard; k.dl = d->dl; k.ws = ws; k.dl_rec = d->dl_rec;
     return k;
 }
 

@@ -53,7 +53,7 @@ class PriorDesc(C.Structure):
                 ("w_patch", C.c_float), ("w_gmrf", C.c_float), ("w_var", C.c_float),
                 ("l", C.c_void_p), ("l_mean", C.c_void_p), ("m", C.c_void_p), ("hard", C.c_void_p), ("px", C.c_void_p),
                 ("per_np", C.c_void_p), ("sums", C.c_void_p), ("g_hard", C.c_void_p), ("dl", C.c_void_p),
-                ("variant", C.c_int32), ("w_ms_logits", C.c_float)]
+                ("variant", C.c_int32), ("w_ms_logits", C.c_float), ("dl_rec", C.c_void_p)]
 
 
 class PrepItem(C.Structure):

@@ -232,7 +232,7 @@ class Trainer(object):
         return make_linear_var(self.global_step, cfg.get("lr_decay_begin", 1000), cfg.get("lr_decay_end", 1001), lr, 0.0,
                                0.0, lr)
 
-    def _prior(self, view, n, S, P, l, lm, m, hard, px, per_np, sums, w, g_hard=None, dl=None, bwd=False):
+    def _prior(self, view, n, S, P, l, lm, m, hard, px, per_np, sums, w, g_hard=None, dl=None, bwd=False, dl_rec=None):
         d = L.PriorDesc()
         d.n, d.h, d.w, d.P, d.view = n, S, S, P, view
         d.half_h = d.half_w = self.model.patch_size // 2
@@ -254,6 +254,7 @@ class Trainer(object):
         g = lambda t: t.data_ptr() if t is not None else None
         d.l, d.l_mean, d.m, d.hard, d.px = g(l), g(lm), g(m), g(hard), g(px)
         d.per_np, d.sums, d.g_hard, d.dl = g(per_np), g(sums), g(g_hard), g(dl)
+        d.dl_rec = g(dl_rec)
         L.call("ups_prior_bwd" if bwd else "ups_prior_fwd", C.byref(d), L.stream())
 
     # ------------------------------------------------------------------ one session.run(train_op)
@@ -512,10 +513,9 @@ class Trainer(object):
 
         dl_tot = torch.empty_like(lm)
         dl_rec = torch.empty_like(lm)
-        self._prior(0, B, S, P, l0, lm[:B], m0, hard[:B], px0, per_np0, sums0, wp, g_hard0, dl_tot[:B], bwd=True)
-        self._prior(1, B, S, P, l1, None, m1, None, px1, stats_v, sums1, wp, g_hard1, dl_tot[B:], bwd=True)
-        self._prior(0, B, S, P, l0, lm[:B], m0, hard[:B], px0, per_np0, sums0, wz, g_hard0, dl_rec[:B], bwd=True)
-        self._prior(1, B, S, P, l1, None, m1, None, px1, stats_v, sums1, wz, g_hard1, dl_rec[B:], bwd=True)
+        # one launch per view emits both d(rec + priors)/dl (decoder_visualize key) and d(rec)/dl (what encoder_0 sees)
+        self._prior(0, B, S, P, l0, lm[:B], m0, hard[:B], px0, per_np0, sums0, wp, g_hard0, dl_tot[:B], bwd=True, dl_rec=dl_rec[:B])
+        self._prior(1, B, S, P, l1, None, m1, None, px1, stats_v, sums1, wp, g_hard1, dl_tot[B:], bwd=True, dl_rec=dl_rec[B:])
 
         # ---- B backward: weights see rec + priors, the latent sees rec only
         if "decoder_visualize" in keys:
