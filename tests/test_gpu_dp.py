@@ -95,3 +95,14 @@ def test_two_rank_step_matches_sum_of_local_gradients(dev):
         want = local[0][k] + local[1][k]
         err = float((r0["grads0"][k] - want).abs().max() / max(float(want.abs().max()), 1e-12))
         assert err <= 1e-5, "bucket {}: all-reduced gradient vs sum of local gradients, rel err {:.2e}".format(k, err)
+
+
+def test_rccl_call_pattern_at_world_size_one(dev):
+    """tools/nccl_trainer_check.py in a child process: a world-size-1 NCCL (= RCCL) group with UPS_FORCE_COLLECTIVES=1 issues
+    every bucket all-reduce where the multi-GPU run does (asynchronously, inside backward, early encoder_0 head slice) and
+    must leave the parameters bit-identical to a run without collectives."""
+    import subprocess
+    env = dict(os.environ, UPS_FORCE_COLLECTIVES="1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_trainer_check.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "nccl trainer check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,37 @@
+"""RCCL call pattern of the trainer on ONE GPU: a world-size-1 NCCL group with UPS_FORCE_COLLECTIVES=1 runs every bucket
+all-reduce (identity) exactly where the multi-GPU run issues it -- asynchronously, from inside the backward pass, beside the
+side streams, with the early encoder_0 head slice -- and the result must equal the run without collectives bit for bit.
+Usage: UPS_FORCE_COLLECTIVES=1 python tools/nccl_trainer_check.py"""
+import copy, os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("UPS_FORCE_COLLECTIVES", "1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29544"), RANK="0", WORLD_SIZE="1")
+import upsparts_amd  # noqa
+from upsparts_amd import configs, dist as D
+from upsparts_amd.model import TrainModel, Trainer
+assert D.FORCE_COLLECTIVES
+dev = torch.device("cuda:0")
+cfg = copy.deepcopy(configs.small_config())
+cfg.update(precision="bf16", vgg_widths=(8, 8, 16, 16, 16))
+g = torch.Generator().manual_seed(3)
+B, S = cfg["batch_size"], cfg["spatial_size"]
+batches = [{k: torch.rand(B, S, S, 3, generator=g) * 2 - 1 for k in ("view0", "view1", "view0_target")} for _ in range(3)]
+res = []
+for use_nccl in (False, True):
+    D.FORCE_COLLECTIVES = use_nccl
+    if use_nccl:
+        dist.init_process_group("nccl", world_size=1, rank=0)
+    model = TrainModel(cfg, device=dev, seed=0)
+    tr = Trainer(cfg, None, model)
+    for b in batches:
+        tr.train_step(b)
+    torch.cuda.synchronize()
+    res.append({k: grp["flat"]["p"].detach().cpu().clone() for k, grp in model.bank.groups.items()})
+    if use_nccl:
+        assert tr._early_hooked
+        dist.destroy_process_group()
+for k in res[0]:
+    assert torch.equal(res[0][k], res[1][k]), k
+print("nccl trainer check ok")

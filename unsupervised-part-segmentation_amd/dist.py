@@ -12,6 +12,11 @@ import torch
 import torch.distributed as dist
 
 
+# UPS_FORCE_COLLECTIVES=1: issue the gradient all-reduces even at world size 1 (identity) -- exercises the RCCL call pattern
+# (asynchronous bucket all-reduces launched from inside the backward pass beside the side streams) on a single-GPU box
+FORCE_COLLECTIVES = __import__("os").environ.get("UPS_FORCE_COLLECTIVES", "0") == "1"
+
+
 def init_from_env(backend="nccl"):
     """torchrun / torch.distributed.run contract: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT."""
     import os
@@ -26,7 +31,7 @@ def init_from_env(backend="nccl"):
 
 def allreduce_bucket(flat_grad, world_size, group=None, async_op=True):
     """Sum-all-reduce one optimizer key's flat gradient; returns the work handle (or None)."""
-    if world_size <= 1:
+    if world_size <= 1 and not FORCE_COLLECTIVES:
         return None
     return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 

@@ -548,7 +548,7 @@ class Trainer(object):
             gp1 = ops.latent_bwd(pe_v1, noise["eps_pi1"][None], [1.0], gz[B:].contiguous()[None], None, 0.0)
             g_pe = torch.cat([gp0, gp1], 0).view_as(pe)
             e0_params = [bank.params[n] for n in bank.groups["encoder_0"]["names"]]
-            if self.world_size > 1 and not self._early_hooked:      # layers exist once the first forward has run
+            if (self.world_size > 1 or D.FORCE_COLLECTIVES) and not self._early_hooked:      # layers exist once the first forward has run
                 self._hook_early_reduce()
                 self._early_hooked = True
             torch.autograd.grad([pe], e0_params, grad_outputs=[g_pe])
