@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/pmcmem_$TAG
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum --kernel-trace --output-format csv -d $OUT/p1 -- python3 tools/one_conv.py $MODE > /dev/null 2>&1
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum --kernel-trace --output-format csv -d $OUT/p2 -- python3 tools/one_conv.py $MODE > /dev/null 2>&1
-rocprofv3 --pmc TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_READ_LDS_WAVEFRONTS_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/p3 -- python3 tools/one_conv.py $MODE > /dev/null 2>&1
+# (a third pass with TA_* + GRBM_GUI_ACTIVE counters hung on this pool: left out)
 python3 - $OUT <<'PY' > $R/gpurun_out/pmcmem_$TAG.txt
 import csv, glob, sys, collections
 for f in sorted(glob.glob(sys.argv[1] + "/*/*/*counter_collection.csv")):
