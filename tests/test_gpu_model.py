@@ -165,6 +165,14 @@ def test_runner_end_to_end_with_csv_dataset_and_checkpoint(dev, tmp_path):
     # restored weights: the step-4 checkpoint was written after the update of step 4, training resumed at global step 4
     saved = torch.load(str(ck), map_location="cpu")
     assert saved["global_step"] == 5 or saved["global_step"] == 4
+    # `-e`: test-mode forward over one epoch of the csv dataset from the checkpoint, outputs pickled
+    import pickle
+    data = runner.main(["-e", str(ypath), "-p", str(tmp_path / "ev"), "-c", str(ck), "--strict-dataset"])
+    with open(str(tmp_path / "ev" / "eval" / "4" / "model_outputs.p"), "rb") as f:
+        disk = pickle.load(f)
+    assert disk["outputs"]["out_parts_hard"].shape == (8, 16, 16) and disk["outputs"]["generated"].shape == (8, 16, 16, 3)
+    assert np.array_equal(disk["outputs"]["out_parts_hard"], data["outputs"]["out_parts_hard"])
+    assert disk["outputs"]["out_parts_hard"].max() < cfg["n_parts"]
 
 
 def test_fix_weights_and_pretrain_keys(dev):

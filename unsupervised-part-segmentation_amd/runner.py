@@ -59,13 +59,20 @@ def load_config(paths):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="upsparts-run")
-    ap.add_argument("-t", "--train", nargs="+", required=True, help="training yaml(s)")
+    ap.add_argument("-t", "--train", nargs="+", default=None, help="training yaml(s)")
+    ap.add_argument("-e", "--eval", nargs="+", default=None,
+                    help="evaluation yaml(s): test-mode forward over the dataset, outputs pickled (edflow -e work-alike)")
+    ap.add_argument("--eval-batches", type=int, default=None, help="number of batches to evaluate (default: one epoch)")
     ap.add_argument("-c", "--checkpoint", default=None)
     ap.add_argument("-p", "--project", default=None, help="log root (default logs/<timestamp>)")
     ap.add_argument("--num_steps", type=int, default=None)
     ap.add_argument("--set", nargs="*", default=[], help="key=value overrides (yaml-parsed)")
     ap.add_argument("--strict-dataset", action="store_true")
     args = ap.parse_args(argv)
+    if (args.train is None) == (args.eval is None):
+        ap.error("exactly one of -t / -e is required")
+    if args.eval is not None:
+        return evaluate(args)
     cfg = load_config(args.train)
     for kv in args.set:
         k, v = kv.split("=", 1)
@@ -91,6 +98,59 @@ def main(argv=None):
             lf.write(line + "\n")
         it.iterate(iter(dataset), num_steps=args.num_steps, log_fn=log_fn)
     return it
+
+
+def evaluate(args):
+    """``edflow -e eval.yaml -c ckpt`` (cub/code/eval/eval_iclr_01/infer.py:216-224, eval_01.py:152-190): the test-mode graph
+    (no sampling noise) is run over the dataset, ``model.outputs[k]`` for k in ``fetch_output_keys`` is collected and
+    ``{"inputs", "outputs"}`` is pickled to <root>/eval/<global_step>/model_outputs.p; with ground-truth label maps in the
+    batches (key ``gt_segmentation``) the part-IoU protocol of eval_01.py:229-383 is reported too (evalutil.py)."""
+    import pickle
+    import numpy as np
+    from . import evalutil
+    cfg = load_config(args.eval)
+    for kv in args.set:
+        k, v = kv.split("=", 1)
+        cfg[k] = yaml.safe_load(v)
+    cfg["test_mode"] = True
+    root = args.project or os.path.join("logs", time.strftime("%Y-%m-%dT%H-%M-%S") + "_eval")
+    Model, Iterator = get_obj_from_str(cfg["model"]), get_obj_from_str(cfg["iterator"])
+    try:
+        cls = DATA_ALIASES.get(cfg["dataset"]) or get_obj_from_str(cfg["dataset"])
+        ds = cls(cfg)
+        batches_it = _data.batches(ds, cfg["batch_size"], shuffle=False, epochs=1) if isinstance(ds, _data.StochasticPairs) else iter(ds)
+    except Exception:
+        if args.strict_dataset:
+            raise
+        batches_it = iter(SyntheticPairs(cfg))
+        args.eval_batches = args.eval_batches or 1
+    model = Model(cfg)
+    it = Iterator(cfg, root, model)
+    it.initialize(args.checkpoint)
+    keys = cfg.get("fetch_output_keys", ["out_parts_hard", "out_parts_soft", "generated", "m0_sample"])
+    outs, ins, gts = {k: [] for k in keys}, {"view0": [], "view1": []}, []
+    for bi, batch in enumerate(batches_it):
+        if args.eval_batches is not None and bi >= args.eval_batches:
+            break
+        o = model.forward(batch)
+        for k in keys:
+            outs[k].append(o[k].detach().float().cpu().numpy() if o[k].dtype.is_floating_point else o[k].cpu().numpy())
+        for k in ins:
+            ins[k].append(np.asarray(batch[k]))
+        if "gt_segmentation" in batch:
+            gts.append(np.asarray(batch["gt_segmentation"]))
+    data = {"inputs": {k: np.concatenate(v) for k, v in ins.items()}, "outputs": {k: np.concatenate(v) for k, v in outs.items()}}
+    odir = os.path.join(root, "eval", str(it.global_step))
+    os.makedirs(odir, exist_ok=True)
+    with open(os.path.join(odir, "model_outputs.p"), "wb") as f:
+        pickle.dump(data, f)
+    if gts:
+        res = evalutil.evaluate_parts(data["outputs"]["out_parts_hard"], np.concatenate(gts))
+        with open(os.path.join(odir, "iou.yml"), "w") as f:
+            yaml.safe_dump({"iou": {int(k): float(v) for k, v in res["iou"].items()}, "overall": res["overall"],
+                            "best_remapping": {int(k): int(v) for k, v in res["mapping"].items()}}, f)
+    print("[INFO] evaluation outputs written to", odir)
+    return data
 
 
 if __name__ == "__main__":
