@@ -20,7 +20,9 @@ tfutils are absent and there is no network), so:
     its NumPy cross-checks, the docstring known-answers of nn.py and the
     closed-form step-0 log values of cub/train/log.txt:204-260.
 
-Three externals are restated from their published behaviour and flagged
+Four externals are restated from their published behaviour and flagged
 UNVERIFIED where used: edflow ``VGG19Features`` (perceptual loss),
-``tfutils.draw_rect`` and the edflow per-key Adam wiring.
+``tfutils.draw_rect``, the edflow per-key Adam wiring and ``eddata.utils.tps``
+(``tps.py``).  The DeepFashion variant (deepfashion/code/SB_model48c/model.py) is
+restated in the same module behind ``is_48c(config)``.
 """
