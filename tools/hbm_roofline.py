@@ -1,0 +1,107 @@
+"""Achieved HBM bandwidth of the HBM-bound kernel families at the headline shapes (B = 64, 128x128, P = 10, bf16),
+timed in isolation with HIP events: algorithmic bytes (every tensor read once + written once)
+/ mean launch time, as a fraction of the 8 TB/s HBM3E peak.   python tools/hbm_roofline.py [--json out.json]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import upsparts_amd  # noqa: E402,F401
+from upsparts_amd import lib as L, ops  # noqa: E402
+
+PEAK = 8000.0   # GB/s
+dev = torch.device("cuda:0")
+B, S, P, A = 64, 128, 10, 64
+T = torch.bfloat16
+
+
+def timeit(fn, iters=20):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def prior_desc(view, n, l, lm, m, hard, px, per_np, sums, g_hard=None, dl=None, dl_rec=None):
+    d = L.PriorDesc()
+    d.n, d.h, d.w, d.P, d.view, d.entropy_ce, d.gamma = n, S, S, P, view, 0, 10.0
+    d.half_h = d.half_w = 16
+    d.ms_alpha, d.ms_lambda = 1.0, 1e-2
+    d.w_kl, d.w_entropy, d.w_ms, d.w_area, d.w_patch, d.w_gmrf, d.w_var = 1.0, 1.0, 1e-5, 1e-12, 1e-4, 1e-3, 1.0
+    g = lambda t: t.data_ptr() if t is not None else None
+    d.l, d.l_mean, d.m, d.hard, d.px, d.per_np, d.sums = g(l), g(lm), g(m), g(hard), g(px), g(per_np), g(sums)
+    d.g_hard, d.dl, d.dl_rec = g(g_hard), g(dl), g(dl_rec)
+    return d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    g = torch.Generator(device=dev).manual_seed(0)
+    rows = []
+
+    def add(name, nbytes, fn, note=""):
+        ms = timeit(fn)
+        gbs = nbytes / ms / 1e6
+        rows.append({"kernel": name, "algorithmic_MB": round(nbytes / 1e6, 1), "ms": round(ms, 4), "GBps": round(gbs, 1),
+                     "frac_of_8TBps": round(gbs / PEAK, 3), "note": note})
+
+    n2 = 2 * B
+    mean = torch.randn(n2, S, S, P, device=dev, generator=g)
+    eps = torch.randn(n2, S, S, P, device=dev, generator=g)
+    map_b = mean.numel() * 4
+    add("part_softmax (l, m, hard)", 5 * map_b, lambda: ops.part_softmax(mean, eps), "2 reads + 3 writes of a [2B,S,S,P] fp32 map")
+    l, m, hard, _ = ops.part_softmax(mean, eps)
+    add("spatial_moments", map_b, lambda: ops.spatial_moments(hard, 10.0), "1 read of the map")
+    px = ops.moments_to_px(ops.spatial_moments(hard, 10.0), S)
+    l0, m0, h0, lm0, px0 = l[:B].contiguous(), m[:B].contiguous(), hard[:B].contiguous(), mean[:B].contiguous(), px[:B].contiguous()
+    nfl = L.load().ups_prior_sums_floats(B, P)
+    sums = torch.empty(nfl, dtype=torch.float32, device=dev)
+    per_np = torch.empty((B, P, 8), dtype=torch.float32, device=dev)
+    half_b = map_b // 2
+    d_f = prior_desc(0, B, l0, lm0, m0, h0, px0, per_np, sums)
+    add("prior_fwd (view 0)", 4 * half_b, lambda: L.call("ups_prior_fwd", C.byref(d_f), L.stream()), "l, l_mean, m, hard read once")
+    gh = torch.randn(B, S, S, P, device=dev, generator=g)
+    dl, dlr = torch.empty_like(l0), torch.empty_like(l0)
+    d_b = prior_desc(0, B, l0, lm0, m0, h0, px0, per_np, sums, gh, dl, dlr)
+    add("prior_bwd (view 0, dl_tot + dl_rec)", 7 * half_b, lambda: L.call("ups_prior_bwd", C.byref(d_b), L.stream()),
+        "5 reads + 2 writes (neighbour taps served by cache)")
+    x = torch.randn(n2, 64, 64, 256, device=dev, generator=g).to(T)
+    up_b = x.numel() * 2 * 5
+    add("bilinear2x_fwd 64->128, 256 ch", up_b, lambda: ops.BilinearFn.apply(x), "read h*w, write 4*h*w")
+    gy = torch.randn(n2, 128, 128, 256, device=dev, generator=g).to(T)
+    gx = torch.empty_like(x)
+    add("bilinear2x_bwd 128->64, 256 ch", up_b,
+        lambda: L.call("ups_bilinear2x_bwd", L.ptr(gy), L.ptr(gx), L.dt(gy), n2, 64, 64, 256, L.stream()))
+    npar = 33_100_000
+    p_, g_, m_, v_ = (torch.randn(npar, device=dev, generator=g) for _ in range(4))
+    v_.abs_()
+    add("adam (33.1 M parameters)", npar * 28, lambda: ops.adam_step(p_, g_, m_, v_, 1e-4, 0.5, 0.9, 1e-8), "p, g, m, v read; p, m, v written")
+    view = torch.rand(B, S, S, 3, device=dev, generator=g)
+    add("mask_parts_fwd", view.numel() * 4 + half_b + P * B * S * S * 8 * 2, lambda: ops.MaskPartsFn.apply(view, h0, T),
+        "view + hard read, [P*B,S,S,8] bf16 written")
+    feat = torch.randn(B, P, A, device=dev, generator=g)
+    add("unpool_fwd", half_b + B * S * S * 80 * 2, lambda: ops.UnpoolFn.apply(h0, feat, T), "hard read, [B,S,S,80] bf16 written")
+    fa = torch.randn(B, S, S, 64, device=dev, generator=g).to(T)
+    fb = torch.randn(B, S, S, 64, device=dev, generator=g).to(T)
+    add("l1_fwd (VGG block1 features)", 2 * fa.numel() * 2, lambda: ops.L1MeanFn.apply(fa, fb, 64, L.ACT_RELU), "two reads")
+    add("maxpool2_fwd 128->64, 64 ch", int(fa.numel() * 2 * 1.25), lambda: ops.MaxPoolFn.apply(fa), "read + quarter-size write")
+
+    print("{:40s} {:>10s} {:>9s} {:>9s} {:>7s}".format("kernel", "alg. MB", "ms", "GB/s", "of 8T"))
+    for r in rows:
+        print("{:40s} {:10.1f} {:9.4f} {:9.1f} {:7.3f}".format(r["kernel"], r["algorithmic_MB"], r["ms"], r["GBps"], r["frac_of_8TBps"]))
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump({"peak_GBps": PEAK, "shapes": "B=64, 128x128, P=10, bf16 activations", "kernels": rows}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int NSLAB = 8;
+constexpr int NSLAB = 32;     // row slabs per image in the forward pass (n x NSLAB blocks: 2 048 at B = 64)
 
 struct PriorK {
     int n, h, w, P, view, entropy_ce, half_h, half_w, variant;
