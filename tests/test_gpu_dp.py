@@ -106,3 +106,18 @@ def test_rccl_call_pattern_at_world_size_one(dev):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_trainer_check.py")], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "nccl trainer check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_two_ranks_over_rccl():
+    """`python bench.py --gpus 2` on a box with >= 2 GPUs: the launcher starts two ranks over RCCL and rank 0's line says so."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["config"]["rccl_world_size"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["global_batch"] == 8 and out["value"] > 0

@@ -203,3 +203,42 @@ def test_part_iou_evaluation():
     assert abs(r["overall"] - 0.5 * (32 / 33 + 31 / 32)) < 1e-12
     same = E.evaluate_parts(gt, gt)
     assert same["overall"] == 1.0
+
+
+_RANK_STANDIN = '''
+import json, os, sys
+import torch
+import torch.distributed as dist
+world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+dist.init_process_group("gloo", init_method="env://", world_size=world, rank=rank)
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+dist.barrier()
+if "--fail" in sys.argv and rank == 1:
+    sys.exit(7)
+if rank == 0:
+    print("some warm-up chatter")
+    print(json.dumps({"metric": "stand-in", "n_gpus": dist.get_world_size(), "sum": float(t), "argv": sys.argv[1:]}))
+dist.destroy_process_group()
+'''
+
+
+def test_bench_launcher_spawns_n_ranks(tmp_path):
+    """`python bench.py --gpus N` (no WORLD_SIZE in the environment): the parent never touches a GPU, starts N rank processes
+    with the torch.distributed.run environment contract, relays rank 0's JSON line, fails when a rank fails."""
+    import json
+    import subprocess
+    import sys
+    entry = tmp_path / "rank.py"
+    entry.write_text(_RANK_STANDIN)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--rank-entry", str(entry)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                     # ONE JSON line on stdout, chatter goes to stderr
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["sum"] == 3.0 and "--steps" in out["argv"]
+    bad = subprocess.run(cmd + ["--fail"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert bad.returncode != 0 and not bad.stdout.decode().strip()
