@@ -187,8 +187,10 @@ int ups_spatial_moments(const float* x, int32_t n, int32_t h, int32_t w, int32_t
                         const int32_t* rect_c, int32_t half_h, int32_t half_w, float* stats, void* stream);
 /* `stats` must hold n*P*8 floats of result followed by n*8*P*8 floats of scratch (ups_spatial_moments_floats). */
 size_t ups_spatial_moments_floats(int32_t n, int32_t P);
-/* px[n*P][2] = int32(mu*h/2 + h/2) (M:441,459; truncation) from the un-masked stats */
-int ups_moments_to_px(const float* stats, int32_t count, int32_t h, int32_t* px, void* stream);
+/* px[n*P][2] = (row, column) centre of the rectangle tfutils.draw_rect paints for int32(mu*h/2 + h/2) (M:441,459;
+   truncation) from the un-masked stats.  xy_order != 0: the helper reads the (y, x) pair as (x, y) -- row centre from mu_x,
+   column centre from mu_y (the reading the reference's step-0 patch_loss supports; oracle/ref_model.py draw_rect) */
+int ups_moments_to_px(const float* stats, int32_t count, int32_t h, int32_t xy_order, int32_t* px, void* stream);
 /* tfutils.draw_rect (external; semantics inferred): out [n,h,w,P] fp32 */
 int ups_draw_rect(const int32_t* px, int32_t n, int32_t h, int32_t w, int32_t P, int32_t half_h, int32_t half_w,
                   float* out, void* stream);

@@ -93,17 +93,19 @@ def mu_to_pixel(mu, h):
     return np.trunc(mu * h / 2.0 + h / 2.0).astype(np.int32)
 
 
-def draw_rect(centers, ph, pw, h, w, dtype=np.float32):
+def draw_rect(centers, ph, pw, h, w, dtype=np.float32, order="xy"):
     """tfutils.draw_rect (EXTERNAL, semantics inferred - SURVEY 8a-9, Appendix C).
 
-    centers: int [K,2] as (y, x).  Box spans c-ph//2 .. c+ph//2 INCLUSIVE
+    centers: int [K,2], read as (x, y) for order "xy" (default: the reading the reference's step-0 patch_loss supports,
+    see oracle/ref_model.py draw_rect) or (y, x) for "yx".  Box spans c-ph//2 .. c+ph//2 INCLUSIVE
     (33 px for patch_size 32, matches step-0 patch_loss 15294.75 ~= 128^2-33^2,
     cub/train/log.txt:244), clipped to the image.  Returns [K,h,w].
     """
     k = centers.shape[0]
     out = np.zeros((k, h, w), dtype)
+    iy, ix = (1, 0) if order == "xy" else (0, 1)
     for i in range(k):
-        cy, cx = int(centers[i, 0]), int(centers[i, 1])
+        cy, cx = int(centers[i, iy]), int(centers[i, ix])
         y0, y1 = max(cy - ph // 2, 0), min(cy + ph // 2, h - 1)
         x0, x1 = max(cx - pw // 2, 0), min(cx + pw // 2, w - 1)
         if y1 >= y0 and x1 >= x0:

@@ -328,24 +328,37 @@ def probs_to_mu_sigma(probs):
     return mu, sigma
 
 
-def draw_rect(centers, ph, pw, h, w, dtype):
-    """tfutils.draw_rect -- EXTERNAL, inferred (SURVEY 8a-9): inclusive c-ph//2..c+ph//2, (y,x)."""
+RECT_ORDER = "xy"
+
+
+def draw_rect(centers, ph, pw, h, w, dtype, order=RECT_ORDER):
+    """tfutils.draw_rect -- EXTERNAL, inferred (SURVEY 8a-9): inclusive c-ph//2..c+ph//2.
+
+    ``order``: how the external helper reads the two columns of ``centers``.  The call sites (M:441-442, 459-460) pass
+    ``mu`` from probs_to_mu_sigma, whose columns are (y, x) (N:1570-1576).  "xy" (default): the helper takes
+    (x, y) -- i.e. the reference draws each rectangle at the TRANSPOSED location of its part's centroid; "yx": it takes
+    (y, x).  Pinned statistically by the reference's step-0 log: run through this graph at P=25, B=8, 128x128, random init,
+    patch_loss is 15301 +- 10 under "xy" and 15227 +- 4 under "yx" (rectangle on top of its own part -> 6 % more of the
+    part's mass inside); the reference logged 15294.75 (cub/train/log.txt:244; tests/test_oracle.py)."""
     ys = torch.arange(h).view(1, h, 1)
     xs = torch.arange(w).view(1, 1, w)
-    cy = centers[:, 0].view(-1, 1, 1)
-    cx = centers[:, 1].view(-1, 1, 1)
+    iy, ix = (1, 0) if order == "xy" else (0, 1)
+    cy = centers[:, iy].view(-1, 1, 1)
+    cx = centers[:, ix].view(-1, 1, 1)
     inside = ((ys - cy).abs() <= ph // 2) & ((xs - cx).abs() <= pw // 2)
     return inside.to(dtype)
 
 
-def patch_mask(sample_hard, gamma, patch_size):
-    """M:437-445 / M:456-463: spatial softmax of gamma*hard -> mu -> int px -> rectangle [N,H,W,P]."""
+def patch_mask(sample_hard, gamma, patch_size, order=RECT_ORDER):
+    """M:437-445 / M:456-463: spatial softmax of gamma*hard -> mu -> int px -> rectangle [N,H,W,P].
+    Returns the rectangles and their centres as (row, column) of the box actually drawn (see draw_rect)."""
     n, h, w, p = sample_hard.shape
     corrected = spatial_softmax(sample_hard * gamma)
     mu, _ = probs_to_mu_sigma(corrected)
     px = torch.trunc(mu.reshape(n * p, 2) * h / 2.0 + h / 2.0).to(torch.int64).detach()
-    rect = draw_rect(px, patch_size, patch_size, h, w, sample_hard.dtype)
-    return rect.reshape(n, p, h, w).permute(0, 2, 3, 1), px.reshape(n, p, 2)
+    rect = draw_rect(px, patch_size, patch_size, h, w, sample_hard.dtype, order)
+    rc = px.flip(-1) if order == "xy" else px
+    return rect.reshape(n, p, h, w).permute(0, 2, 3, 1), rc.reshape(n, p, 2)
 
 
 # ----------------------------------------------------------------------------- forward graph  (M:313-521)
@@ -397,8 +410,9 @@ def forward(params, config, views, noise, lon=1.0, dtype=torch.float32, seed=Non
     if df:      # DF:402-413: no rectangles
         o["rect0"] = o["rect1"] = o["px0"] = o["px1"] = None
     else:
-        o["rect0"], o["px0"] = patch_mask(hard0, gamma, patch)   # M:437-445
-        o["rect1"], o["px1"] = patch_mask(hard1, gamma, patch)   # M:456-463
+        order = config.get("rect_order", RECT_ORDER)
+        o["rect0"], o["px0"] = patch_mask(hard0, gamma, patch, order)   # M:437-445
+        o["rect1"], o["px1"] = patch_mask(hard1, gamma, patch, order)   # M:456-463
     o["out_parts_soft"] = torch.softmax(l0_mean, dim=-1)     # M:469
     o["out_parts_hard"] = torch.argmax(o["out_parts_soft"], dim=3)   # M:470
     o["m0_sample_argmax"] = torch.argmax(m0, dim=3)          # M:447

@@ -74,6 +74,15 @@ CONV_CASES = [
     (256, 8, 8, 24, 72, 3, 1, False, "relu", False),           # SUB=8, BN=64
     (32, 4, 4, 136, 136, 3, 1, True, "leaky_relu", True),      # SUB=4, 2 tiles, BN=32
     (1536, 4, 4, 16, 136, 3, 1, True, None, False),            # SUB=4, BN=128 with a ragged second N-tile
+    # the instantiations bench.py runs, at their real K depth (BASELINE config #2 widths)
+    (8, 128, 128, 256, 256, 3, 1, True, "leaky_relu", True),   # decoder_visualize/conv2d_8 (37 % of the forward FLOPs): patch
+                                                               # kernel <bf16,128,OCC=2>, kchunks 8, 1024 blocks through the XCD
+                                                               # remap, CoordConv + residual epilogue; wgrad3x3 <64,128> at 128x128
+    (64, 16, 16, 512, 512, 3, 1, False, "relu", False),        # VGG block 4 / 5 depth: kchunks 16, one block per CU (3-stage ring)
+    (64, 8, 8, 512, 512, 3, 1, False, "relu", False),          # VGG block 5 at 8x8: whole images packed 4 to a tile, kchunks 16
+    (4, 128, 128, 32, 32, 3, 1, True, "leaky_relu", True),     # encoder_0 first res-block: thin CoordConv layer at 128x128
+    (2, 128, 128, 80, 32, 3, 1, False, None, False),           # decoder_delta input conv (74 + pad -> 32)
+    (16, 64, 64, 256, 256, 3, 1, True, "leaky_relu", True),    # dv res-block at 64x64
 ]
 
 
@@ -144,6 +153,44 @@ def test_conv_f32_out_and_padded_input(dev):
     assert_close(gx[..., :cin], xo.grad.float(), F32_TOL, "dgrad padded")
     assert float(gx[..., cin:].abs().max()) == 0.0
     assert_close(gV, Vo.grad.float(), F32_TOL, "wgrad padded")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [
+    # n, h, w, cin, cout, k, coords, act
+    (128, 1, 1, 256, 33152, 1, True, "leaky_relu"),     # encoder_0 head 258 -> 33152 (8.55 M weights): skinny GEMM, split-K dgrad
+    (4, 128, 128, 256, 10, 3, True, None),              # decoder_visualize logit conv 258 -> P at 128x128, fp32 logits
+    (128, 1, 1, 256, 4096, 1, True, None),              # decoder_visualize input nin 258 -> 4 x 4 x 256
+])
+def test_conv_heads_at_full_width(case, dtype, dev):
+    """The fp32-output heads of the full-width CUB graph: forward, input gradient and weight gradient."""
+    lib, ops, R = _mods()
+    n, h, w, cin, cout, k, coords, act = case
+    g = torch.Generator().manual_seed(77 + cout)
+    cin_v = cin + (2 if coords else 0)
+    T = torch.float32 if dtype == "fp32" else torch.bfloat16
+    tol = F32_TOL if dtype == "fp32" else BF16_TOL
+    x = torch.randn(n, h, w, cin, generator=g).to(T).float()
+    V = torch.randn(k, k, cin_v, cout, generator=g) / math.sqrt(cin_v * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    Vo = V.double().clone()
+    if dtype == "bf16":
+        Vo[:, :, :cin] = V[:, :, :cin].to(T).double()
+    xo = x.double().requires_grad_(True)
+    Vo.requires_grad_(True)
+    bo = b.double().requires_grad_(True)
+    yo = _oracle_conv(R, xo, Vo, bo, 1, coords, act, False, None)
+    go = torch.randn(yo.shape, generator=g)
+    yo.backward(go.double())
+    lay = _layer(ops, lib, V, b, k, 1, coords, act, dev)
+    xd = x.to(dev, T).requires_grad_(True)
+    y = ops.conv(xd, lay, out_f32=True)
+    assert y.dtype == torch.float32 and y.shape[-1] == cout
+    assert_close(y, yo.float(), tol, "head fwd {}".format(case))
+    gx, gV, gb = torch.autograd.grad([y], [xd, lay.V, lay.b], grad_outputs=[go.to(dev)])
+    assert_close(gx.float(), xo.grad.float(), tol, "head dgrad {}".format(case))
+    assert_close(gV.float(), Vo.grad.float(), tol * (4 if dtype == "bf16" else 1), "head wgrad {}".format(case))
+    assert_close(gb.float(), bo.grad.float(), tol, "head bias grad {}".format(case))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -236,8 +283,12 @@ def test_part_path(P, dev):
     stable = ((frac - frac.round()).abs() > 1e-3).all(-1)      # truncation is only compared away from integer boundaries
     assert torch.equal(px.cpu()[stable].long(), px_o[stable])
     rect = ops.draw_rect(px, S, S, patch // 2)
-    rect_np = np_ops.draw_rect(px.cpu().numpy().reshape(-1, 2), patch, patch, S, S).reshape(N, P, S, S).transpose(0, 2, 3, 1)
+    # px is (row, column) of the box drawn; np_ops.draw_rect(order="yx") paints exactly that
+    rect_np = np_ops.draw_rect(px.cpu().numpy().reshape(-1, 2), patch, patch, S, S, order="yx").reshape(N, P, S, S).transpose(0, 2, 3, 1)
     assert np.array_equal(rect.cpu().numpy(), rect_np)
+    assert np.array_equal(rect_np[stable.all(-1)], rect_o.numpy()[stable.all(-1)])      # == the oracle's rectangles
+    px_yx = ops.moments_to_px(stats, S, "yx")
+    assert torch.equal(px_yx.flip(-1), px)
     # masked moments (variance-loss statistics)
     st2 = ops.spatial_moments(m, gamma, rect_px=px, half=patch // 2)
     c1 = R.spatial_softmax(mo * gamma) * (1 - torch.from_numpy(rect_np).double())

@@ -60,9 +60,10 @@ def test_tools_do_not_import_the_oracle():
             assert "oracle" not in open(os.path.join(tdir, fn)).read(), "tools/" + fn + " must not use oracle/"
     src = open(os.path.join(ROOT, "bench.py")).read()
     head, _, tail = src.partition("def cpu_baseline")
-    body, _, rest = tail.partition("\ndef main")
-    assert "from oracle" not in head and "import oracle" not in head
-    assert rest.count("from oracle") == 1 and "cpu_baseline(cfg_fn" in rest     # only the config factory of that leg
+    body, _, rest = tail.partition("\ndef run_rank")
+    assert "oracle" not in head.replace("(oracle)", "")
+    assert body.count("from oracle") == 1                                       # the cpu_baseline leg is the only importer
+    assert "from oracle" not in rest and "import oracle" not in rest
 
 
 def test_same_geometry_and_taps():

@@ -101,6 +101,13 @@ def test_draw_rect_convention():
     assert r[1].sum() == 17 * 17                       # clipped at the image border
     rt = R.draw_rect(torch.tensor([[64, 64], [0, 127]]), 32, 32, 128, 128, torch.float32)
     assert np.array_equal(r, rt.numpy())
+    # default order "xy": the first column is the COLUMN of the box centre (see R.draw_rect's docstring)
+    one = np_ops.draw_rect(np.array([[20, 100]]), 8, 8, 128, 128)[0]
+    ys, xs = np.nonzero(one)
+    assert (ys.min(), ys.max(), xs.min(), xs.max()) == (96, 104, 16, 24)
+    alt = np_ops.draw_rect(np.array([[20, 100]]), 8, 8, 128, 128, order="yx")[0]
+    assert np.array_equal(alt, one.T)
+    assert np.array_equal(R.draw_rect(torch.tensor([[20, 100]]), 8, 8, 128, 128, torch.float32, "yx")[0].numpy(), alt)
 
 
 def test_step0_closed_forms_of_the_reference_log():
@@ -200,3 +207,50 @@ def test_tps_oracle_properties():
     ref = tps.interpolate(imgs[0], xs.view(1, 1, 16).expand(3, 16, 16), xs.view(1, 16, 1).expand(3, 16, 16))
     # (interior only: the STN formula is discontinuous where a sample position crosses the first / last pixel centre)
     assert float((ident - ref)[:, 1:-1, 1:-1].abs().max()) < 1e-9
+
+
+# cub/train/log.txt:204-260 (global_step 0 of the shipped CUB run: n_parts 25, batch 8, 128x128, random init, real CUB images).
+REF_STEP0 = {"prior_gmrf": 136.2645263671875, "mask0_kl": 0.9168158769607544, "weakly_superv_loss_p": 2.7595229148864746,
+             "variance_loss": 16.765602111816406, "patch_loss": 15294.75, "bottleneck_loss": 2.1749637126922607,
+             "z_mumford_sha_smoothness_cost": 1389.4407958984375, "z_mumford_sha_contour_cost": 13.409610748291016,
+             "z_area_cost": 1.0836170076800045e-05, "zr_mumford_sha": 0.01669233664870262,
+             "loss_mi0_discriminator": 0.6604994535446167, "loss_mi1_discriminator": 0.7923544049263,
+             "loss_mi_estimator": 0.7718303203582764}
+# relative windows = the restatement's own spread over weight / data / noise seeds at this config (measured over 5 seeds: e.g.
+# prior_gmrf 115.6 ... 142.9, bottleneck 2.18 ... 2.45, contour 12.7 ... 14.0), widened by half; values that hardly depend on the
+# draw (entropy, KL to uniform, area, variance of a near-uniform map) are held tightly
+STEP0_TOL = {"prior_gmrf": 0.25, "mask0_kl": 0.01, "weakly_superv_loss_p": 0.004, "variance_loss": 0.006, "patch_loss": 0.002,
+             "bottleneck_loss": 0.15, "z_mumford_sha_smoothness_cost": 0.03, "z_mumford_sha_contour_cost": 0.10,
+             "z_area_cost": 0.01, "zr_mumford_sha": 0.04, "loss_mi0_discriminator": 0.2, "loss_mi1_discriminator": 0.2,
+             "loss_mi_estimator": 0.2}
+
+
+def test_step0_reference_log_through_the_oracle_graph():
+    """Pins the restated GRAPH (conv init U(+-1/sqrt(fan_in)) incl. CoordConv fan-in, encoder_0 -> FullLatent -> decoder_visualize,
+    soft-max / hard-max / rectangle path, every mask prior, the critics) to the only numbers the reference holds for it: the
+    step-0 log of its own CUB run.  The reference ran on real birds and its own RNG, so the check is distributional: R.forward +
+    R.losses at random init with P=25, B=8, 128x128 must land within the windows above of the logged values.  It also
+    discriminates the two readings of the external tfutils.draw_rect: with the (y, x) reading patch_loss comes out at
+    15227 +- 4 (68 below the log, outside the window), with the (x, y) reading at 15301 +- 10."""
+    cfg = configs.cub_config(n_parts=25, batch_size=8)
+    params = R.init_params(cfg, 0)
+    vp = R.vgg_params(7, widths=(8, 8, 8, 8, 8))        # the perceptual trunk (external weights) is not part of what is pinned
+    views = R.synthetic_views(cfg, smooth=True)
+    noise = R.synthetic_noise(cfg)
+    with torch.no_grad():
+        o = R.forward(params, cfg, views, noise, dtype=torch.float32)
+        L, log, _ = R.losses(o, cfg, R.initial_state(cfg), 0, vp)
+    got = {k: float(log[k]) for k in REF_STEP0 if k in log}
+    got.update({"loss_" + k: float(v) for k, v in L.items() if "loss_" + k in REF_STEP0})
+    assert set(got) == set(REF_STEP0)
+    bad = {k: (got[k], REF_STEP0[k]) for k in REF_STEP0 if abs(got[k] - REF_STEP0[k]) > STEP0_TOL[k] * abs(REF_STEP0[k])}
+    assert not bad, "oracle graph at init vs cub/train/log.txt:204-260 (got, logged): {}".format(bad)
+    # schedule constants logged at step 0 (fp32 of the yaml values)
+    assert abs(float(log["prior_gmrf_weight"]) - 1e-3) < 1e-9 and abs(float(log["patch_loss_weight"]) - 1e-4) < 1e-10
+    assert abs(float(log["prior_mumford_sha_weight"]) - 1e-5) < 1e-11 and float(log["variance_weight"]) == 1.0
+    assert abs(R.learning_rate(cfg, 0) - 2e-4) < 1e-12
+    # the other reading of draw_rect is rejected by the same log value
+    hard0 = R.hard_max(o["m0"])
+    rect_yx, _ = R.patch_mask(hard0, float(cfg["gamma"]), cfg["patch_size"], order="yx")
+    patch_yx = float((hard0 * (1 - rect_yx)).sum(dim=(1, 2, 3)).mean())
+    assert abs(patch_yx - REF_STEP0["patch_loss"]) > STEP0_TOL["patch_loss"] * REF_STEP0["patch_loss"]

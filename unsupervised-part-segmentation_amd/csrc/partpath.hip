@@ -111,13 +111,17 @@ __global__ void moments_combine_kernel(const float* __restrict__ partial, int co
     d[0] = M; d[1] = o[0]; d[2] = o[1]; d[3] = o[2]; d[4] = o[3]; d[5] = o[4]; d[6] = o[5]; d[7] = 0.f;
 }
 
-__global__ void moments_to_px_kernel(const float* __restrict__ stats, int count, int h, int* __restrict__ px) {
+// px = (row centre, column centre) of the rectangle draw_rect paints.  xy_order: the external tfutils.draw_rect reads the
+// (y, x) pair it is handed (M:441-442) as (x, y), so the row centre comes from mu_x and the column centre from mu_y.
+__global__ void moments_to_px_kernel(const float* __restrict__ stats, int count, int h, int xy_order, int* __restrict__ px) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
     const float* s = stats + (long long)idx * 8;
     const float muy = s[3] / s[1], mux = s[4] / s[1];
-    px[idx * 2 + 0] = (int)(muy * (float)h / 2.0f + (float)h / 2.0f);   // tf.cast(float->int32): truncation
-    px[idx * 2 + 1] = (int)(mux * (float)h / 2.0f + (float)h / 2.0f);
+    const int cy = (int)(muy * (float)h / 2.0f + (float)h / 2.0f);   // tf.cast(float->int32): truncation
+    const int cx = (int)(mux * (float)h / 2.0f + (float)h / 2.0f);
+    px[idx * 2 + 0] = xy_order ? cx : cy;
+    px[idx * 2 + 1] = xy_order ? cy : cx;
 }
 
 __global__ void draw_rect_kernel(const int* __restrict__ px, int n, int h, int w, int P, int hh, int hwid, float* __restrict__ out) {
@@ -327,9 +331,9 @@ extern "C" int ups_spatial_moments(const float* x, int32_t n, int32_t h, int32_t
 extern "C" size_t ups_spatial_moments_floats(int32_t n, int32_t P) { return (size_t)n * P * 8 + (size_t)n * 8 * P * 8; }
 extern "C" size_t ups_unpool_bwd_floats(int32_t B, int32_t P, int32_t F) { return (size_t)B * P * F * (1 + UNPOOL_SLABS); }
 
-extern "C" int ups_moments_to_px(const float* stats, int32_t count, int32_t h, int32_t* px, void* stream) {
+extern "C" int ups_moments_to_px(const float* stats, int32_t count, int32_t h, int32_t xy_order, int32_t* px, void* stream) {
     UPS_CHECK_ARG(stats && px && count > 0);
-    hipLaunchKernelGGL(moments_to_px_kernel, dim3(ups_cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, stats, count, h, px);
+    hipLaunchKernelGGL(moments_to_px_kernel, dim3(ups_cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, stats, count, h, xy_order, px);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

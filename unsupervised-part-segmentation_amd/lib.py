@@ -95,7 +95,7 @@ _SIGS = {
     "ups_part_softmax_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _P], C.c_int),
     "ups_spatial_moments": ([_P, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P], C.c_int),
     "ups_spatial_moments_floats": ([_I, _I], _Z),
-    "ups_moments_to_px": ([_P, _I, _I, _P, _P], C.c_int),
+    "ups_moments_to_px": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "ups_draw_rect": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "ups_mask_parts_fwd": ([_P, _P, _P, _I, _I, _L, _I, _P], C.c_int),
     "ups_mask_parts_bwd": ([_P, _P, _P, _I, _I, _L, _I, _P], C.c_int),

@@ -447,7 +447,7 @@ class Trainer(object):
         eps_l = torch.cat([noise["eps_l0"], noise["eps_l1"]], 0) if stochastic_l else None
         l, m, hard, _ = ops.part_softmax(lm, eps_l)
         # [2B,P,2] rectangle centres (stop-gradient); SB_model48c has no rectangles
-        px = None if df else ops.moments_to_px(ops.spatial_moments(hard, gamma), S)
+        px = None if df else ops.moments_to_px(ops.spatial_moments(hard, gamma), S, cfg.get("rect_order", "xy"))
         hard0 = hard[:B].detach().requires_grad_(True)
         hard1 = hard[B:].detach().requires_grad_(True)
 

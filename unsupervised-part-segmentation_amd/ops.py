@@ -614,10 +614,11 @@ def spatial_moments(x, gamma, rect_px=None, half=0):
     return buf[:n * P * 8].view(n, P, 8)
 
 
-def moments_to_px(stats, h):
+def moments_to_px(stats, h, order="xy"):
+    """(row, column) centres of the rectangles; order "xy": tfutils.draw_rect reads the (y, x) pair as (x, y)."""
     n, P, _ = stats.shape
     px = torch.empty((n, P, 2), dtype=torch.int32, device=stats.device)
-    L.call("ups_moments_to_px", L.ptr(stats), n * P, h, L.ptr(px), L.stream())
+    L.call("ups_moments_to_px", L.ptr(stats), n * P, h, int(order == "xy"), L.ptr(px), L.stream())
     return px
 
 
