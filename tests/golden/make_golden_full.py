@@ -1,0 +1,61 @@
+"""Generates tests/golden/full_cub128_step.npz: ONE training step of the FULL-WIDTH CUB yaml (128x128, n_parts 10, batch 2,
+widths of train_cub_subset_tps.yaml:147-182, VGG19-topology trunk at its real widths with the seeded stand-in weights) from
+the fp64 CPU oracle -- scalars, per-variable gradient norms, a few small summaries and the hard-mask argmax maps only (< 1 MB).
+With `resize256` as argument: the same step with `perceptual_input: resize256` (edflow's original_scale reading) ->
+full_cub128_step_resize256.npz.  Inputs are regenerated from seeds by the test (R.synthetic_views / R.synthetic_noise).
+
+    python tests/golden/make_golden_full.py [native|resize256]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import configs, ref_model as R  # noqa: E402
+
+
+def main(mode="native"):
+    cfg = configs.cub_config(n_parts=10, batch_size=2)
+    params = R.init_params(cfg, 0)
+    vp = R.vgg_params(7)
+    views, noise = R.synthetic_views(cfg), R.synthetic_noise(cfg)
+    t0 = time.time()
+    o, L, log, new_state, grads = R.gradients(params, cfg, views, noise, R.initial_state(cfg), 0, vp, dtype=torch.float64,
+                                              perceptual_mode=mode, scheme="per_key")
+    print("oracle step: {:.1f} s".format(time.time() - t0))
+    out = {}
+    for k, v in L.items():
+        out["loss_" + k] = np.float64(float(v))
+    for k, v in log.items():
+        if not k.startswith("_"):
+            out["log_" + k] = np.float64(float(v))
+    names = sorted(grads)
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array([float(grads[n].norm()) for n in names])
+    out["grad_sums"] = np.array([float(grads[n].sum()) for n in names])
+    out["hard0_argmax"] = R.hard_max(o["m0"]).argmax(-1).numpy().astype(np.uint8)
+    out["hard1_argmax"] = R.hard_max(o["m1"]).argmax(-1).numpy().astype(np.uint8)
+    out["out_parts_hard"] = o["out_parts_hard"].numpy().astype(np.uint8)
+    out["px0"] = o["px0"].numpy().astype(np.int32)
+    out["px1"] = o["px1"].numpy().astype(np.int32)
+    gen = o["generated"].detach()
+    out["generated_8x8"] = torch.nn.functional.avg_pool2d(gen.permute(0, 3, 1, 2), 16).permute(0, 2, 3, 1).float().numpy()
+    out["generated_absmean"] = np.float64(float(gen.abs().mean()))
+    out["l0_mean_16x16"] = torch.nn.functional.avg_pool2d(o["l0_mean"].detach().permute(0, 3, 1, 2), 8).permute(0, 2, 3, 1).float().numpy()
+    out["l0_mean_norm"] = np.float64(float(o["l0_mean"].norm()))
+    out["l1_mean_norm"] = np.float64(float(o["l1_mean"].norm()))
+    out["feat_norm"] = np.float64(float(o["local_app_features1"].norm()))
+    for k, v in new_state.items():
+        out["state_" + k] = np.float64(v)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                        "full_cub128_step.npz" if mode == "native" else "full_cub128_step_{}.npz".format(mode))
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main(*(sys.argv[1:2]))

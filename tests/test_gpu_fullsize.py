@@ -1,0 +1,100 @@
+"""GPU parity at the REAL widths of the benchmark: one whole training step of the full-width CUB yaml (128x128, n_parts 10,
+256-channel mask decoder, 33152-wide pose head, VGG19-topology trunk at 64...512 channels), batch 2, against the fp64 oracle
+fixture tests/golden/full_cub128_step*.npz (tests/golden/make_golden_full.py).  fp32 mode: north_star's 1e-3 on losses,
+log scalars and outputs, 2e-3 on per-variable gradient norms; bf16 mode (the headline dtype): part-mask IoU >= 0.99."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _trainer(dev, precision, perceptual_input="native"):
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import configs
+    from upsparts_amd.model import TrainModel, Trainer
+    from oracle import ref_model as R
+    cfg = copy.deepcopy(configs.cub_config(n_parts=10, batch_size=2))
+    cfg["precision"] = precision
+    cfg["perceptual_input"] = perceptual_input
+    model = TrainModel(cfg, device=dev, seed=0)
+    trainer = Trainer(cfg, None, model)
+    return cfg, model, trainer, R.synthetic_views(cfg), R.synthetic_noise(cfg)
+
+
+def _iou(hard, gold_argmax, P):
+    a = hard.argmax(-1).cpu().numpy()
+    ious = []
+    for b in range(a.shape[0]):
+        for p in range(P):
+            inter = np.logical_and(a[b] == p, gold_argmax[b] == p).sum()
+            union = np.logical_or(a[b] == p, gold_argmax[b] == p).sum()
+            if union:
+                ious.append(inter / union)
+    return float(np.mean(ious))
+
+
+@pytest.mark.parametrize("mode", ["native", "resize256"])
+def test_full_width_step_fp32_matches_oracle_fixture(dev, mode):
+    z = np.load(os.path.join(GOLD, "full_cub128_step.npz" if mode == "native" else "full_cub128_step_resize256.npz"))
+    cfg, model, trainer, views, noise = _trainer(dev, "fp32", mode)
+    losses = trainer.train_step(views, noise)
+    dbg = trainer._debug
+    B, P = cfg["batch_size"], cfg["n_parts"]
+    hard = dbg["hard"]
+    agree0 = float((hard[:B].argmax(-1).cpu().numpy() == z["hard0_argmax"]).mean())
+    agree1 = float((hard[B:].argmax(-1).cpu().numpy() == z["hard1_argmax"]).mean())
+    assert min(agree0, agree1) >= 0.999, "hard masks: agreement {} / {}".format(agree0, agree1)
+    assert np.array_equal(dbg["px"].cpu().numpy()[:B], z["px0"]) and np.array_equal(dbg["px"].cpu().numpy()[B:], z["px1"])
+    lm = dbg["l_mean"]
+    assert abs(float(lm[:B].double().norm()) - float(z["l0_mean_norm"])) <= 1e-3 * float(z["l0_mean_norm"])
+    assert abs(float(lm[B:].double().norm()) - float(z["l1_mean_norm"])) <= 1e-3 * float(z["l1_mean_norm"])
+    pooled = torch.nn.functional.avg_pool2d(lm[:B].permute(0, 3, 1, 2), 8).permute(0, 2, 3, 1).cpu().numpy()
+    assert np.abs(pooled - z["l0_mean_16x16"]).max() <= 1e-3 * np.abs(z["l0_mean_16x16"]).max()
+    gen = dbg["generated"][..., :3].float()
+    g8 = torch.nn.functional.avg_pool2d(gen.permute(0, 3, 1, 2), 16).permute(0, 2, 3, 1).cpu().numpy()
+    assert np.abs(g8 - z["generated_8x8"]).max() <= 1e-3 * np.abs(z["generated_8x8"]).max(), "generated (16x16-pooled)"
+    assert abs(float(gen.abs().mean()) - float(z["generated_absmean"])) <= 1e-3 * float(z["generated_absmean"])
+    assert abs(float(dbg["feat"].double().norm()) - float(z["feat_norm"])) <= 1e-3 * float(z["feat_norm"])
+    for k in losses:
+        lo, lh = float(z["loss_" + k]), float(losses[k])
+        assert abs(lo - lh) <= 1e-3 * max(1.0, abs(lo)), "loss {}: oracle {} hip {}".format(k, lo, lh)
+    logs = trainer.fetch_logs()
+    for k in ("prior_gmrf", "mask0_kl", "weakly_superv_loss_p", "variance_loss", "bottleneck_loss", "mi_constraint",
+              "independent_mi_constraint", "perceptual", "patch_loss", "zr_mumford_sha", "z_area_cost",
+              "z_mumford_sha_smoothness_cost", "z_mumford_sha_contour_cost"):
+        lo = float(z["log_" + k])
+        assert abs(lo - logs[k]) <= 1e-3 * max(1e-6, abs(lo)) + 1e-9, "log {}: oracle {} hip {}".format(k, lo, logs[k])
+    names, norms, sums = list(z["grad_names"]), z["grad_norms"], z["grad_sums"]
+    worst = ("", 0.0)
+    for n, gn, gs in zip(names, norms, sums):
+        g = model.bank.grads[str(n)].double()
+        e = abs(float(g.norm()) - gn) / max(gn, 1e-30)
+        if gn > 1e-12 and e > worst[1]:
+            worst = (str(n), e)
+    assert worst[1] <= 2e-3, "gradient norm of {}: rel err {:.3e}".format(*worst)
+    for k in ("loa", "lor", "avg_mim", "avg_independent_mim", "avg_acc0", "avg_loss_dis1"):
+        want = float(z["state_" + k])
+        assert abs(float(trainer.state[k]) - want) <= 1e-3 * max(1e-3, abs(want)), k
+
+
+def test_full_width_step_bf16_mask_iou(dev):
+    """The benchmark's dtype at the benchmark's widths: part-mask IoU vs the fp64 oracle >= 0.99 (north_star), losses within 5 %."""
+    z = np.load(os.path.join(GOLD, "full_cub128_step.npz"))
+    cfg, model, trainer, views, noise = _trainer(dev, "bf16")
+    losses = trainer.train_step(views, noise)
+    B, P = cfg["batch_size"], cfg["n_parts"]
+    hard = trainer._debug["hard"]
+    iou0, iou1 = _iou(hard[:B], z["hard0_argmax"], P), _iou(hard[B:], z["hard1_argmax"], P)
+    assert min(iou0, iou1) >= 0.99, "bf16 part-mask IoU vs oracle: {} / {}".format(iou0, iou1)
+    out = model.forward(views)
+    agree = float((out["out_parts_hard"].cpu().numpy() == z["out_parts_hard"]).mean())
+    assert agree >= 0.99, "test-mode out_parts_hard agreement {}".format(agree)
+    for k in losses:
+        lo, lh = float(z["loss_" + k]), float(losses[k])
+        assert abs(lo - lh) <= 5e-2 * max(1.0, abs(lo)), "loss {}: oracle {} hip(bf16) {}".format(k, lo, lh)

@@ -160,11 +160,12 @@ def test_runner_end_to_end_with_csv_dataset_and_checkpoint(dev, tmp_path):
     assert "[INFO] [LoggingHook]: global_step: 3\n" not in log and "loss_decoder_visualize" in log
     ck = root / "train" / "checkpoints" / "model.ckpt-4"
     assert ck.exists() and (root / "train" / "checkpoints" / "model.ckpt-2").exists()
+    assert (root / "train" / "checkpoints" / "model.ckpt-5").exists()          # final state at loop exit
     it2 = runner.main(["-t", str(ypath), "-p", str(tmp_path / "run2"), "-c", str(ck), "--num_steps", "6", "--strict-dataset"])
     assert it2.global_step == 6
     # restored weights: the step-4 checkpoint was written after the update of step 4, training resumed at global step 4
     saved = torch.load(str(ck), map_location="cpu")
-    assert saved["global_step"] == 5 or saved["global_step"] == 4
+    assert saved["global_step"] == 4 and saved["adam"]["encoder_0"]["t"] == 4      # file name == stored step == Adam t
     # `-e`: test-mode forward over one epoch of the csv dataset from the checkpoint, outputs pickled
     import pickle
     data = runner.main(["-e", str(ypath), "-p", str(tmp_path / "ev"), "-c", str(ck), "--strict-dataset"])
@@ -173,6 +174,34 @@ def test_runner_end_to_end_with_csv_dataset_and_checkpoint(dev, tmp_path):
     assert disk["outputs"]["out_parts_hard"].shape == (8, 16, 16) and disk["outputs"]["generated"].shape == (8, 16, 16, 3)
     assert np.array_equal(disk["outputs"]["out_parts_hard"], data["outputs"]["out_parts_hard"])
     assert disk["outputs"]["out_parts_hard"].max() < cfg["n_parts"]
+
+
+def test_vgg_weights_key_loads_keras_style_kernels(dev, tmp_path):
+    """`vgg_weights`: the perceptual trunk takes real (here: random, Keras-named) HWIO kernels instead of the stand-ins."""
+    import numpy as np
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd.model import TrainModel, Trainer
+    from oracle import ref_model as R, configs
+    cfg = copy.deepcopy(configs.tiny_config())
+    cfg.update(precision="fp32", vgg_widths=VGG_W)
+    vp = R.vgg_params(123, widths=VGG_W)                      # a different seed than the stand-ins (7)
+    keras = {}
+    for k, v in vp.items():
+        blk = k.split("/")[1]
+        keras[blk + ("/kernel:0" if k.endswith("/V") else "/bias:0")] = v.numpy()
+    np.savez(str(tmp_path / "vgg.npz"), **keras)
+    cfg["vgg_weights"] = str(tmp_path / "vgg.npz")
+    model = TrainModel(cfg, device=dev, seed=0)
+    tr = Trainer(cfg, None, model)
+    assert tr.vgg_pretrained
+    views, noise = R.synthetic_views(cfg), R.synthetic_noise(cfg)
+    losses = tr.train_step(views, noise)
+    _, Lo, _, _, _ = R.gradients(R.init_params(cfg, 0), cfg, views, noise, R.initial_state(cfg), 0, vp, dtype=torch.float64)
+    for k in Lo:
+        assert abs(float(Lo[k]) - float(losses[k])) <= 1e-3 * max(1.0, abs(float(Lo[k]))), k
+    with pytest.raises(KeyError):
+        np.savez(str(tmp_path / "bad.npz"), **{k: v for k, v in keras.items() if "block3" not in k})
+        Trainer(dict(cfg, vgg_weights=str(tmp_path / "bad.npz")), None, model)
 
 
 def test_fix_weights_and_pretrain_keys(dev):

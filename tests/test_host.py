@@ -243,3 +243,17 @@ def test_bench_launcher_spawns_n_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["sum"] == 3.0 and "--steps" in out["argv"]
     bad = subprocess.run(cmd + ["--fail"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert bad.returncode != 0 and not bad.stdout.decode().strip()
+
+
+def test_read_vgg_weights_key_spellings(tmp_path):
+    import numpy as np
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import nets
+    k = np.ones((3, 3, 3, 8), np.float32)
+    np.savez(str(tmp_path / "a.npz"), **{"block1_conv1/kernel:0": k, "block1_conv1/bias:0": np.zeros(8, np.float32),
+                                         "block2_conv1_W": k, "block2_conv1_b": np.zeros(8, np.float32),
+                                         "vgg19/block3_conv4/V": k, "vgg19/block3_conv4/b": np.zeros(8, np.float32)})
+    st = nets.read_vgg_weights(str(tmp_path / "a.npz"))
+    assert sorted(st) == ["vgg19/block1_conv1/V", "vgg19/block1_conv1/b", "vgg19/block2_conv1/V", "vgg19/block2_conv1/b",
+                          "vgg19/block3_conv4/V", "vgg19/block3_conv4/b"]
+    assert st["vgg19/block1_conv1/V"].shape == (3, 3, 3, 8) and st["vgg19/block1_conv1/V"].dtype == torch.float32

@@ -140,6 +140,7 @@ class Trainer(object):
         self.global_step = 0
         self.log_ops, self.img_ops, self.update_ops = OrderedDict(), OrderedDict(), []
         self.world_size = kwargs.get("world_size", 1)
+        self.rank = kwargs.get("rank", 0)
         self.process_group = kwargs.get("process_group")
         self.beta1 = config.get("beta1", 0.5)        # edflow TFBaseTrainer defaults (UNVERIFIED)
         self.beta2 = config.get("beta2", 0.9)
@@ -151,6 +152,21 @@ class Trainer(object):
             raise NotImplementedError("the 'pretty' image discriminator (model.py:190-212) is not used by the shipped configs")
         vw = config.get("vgg_widths", N.VGG_WIDTHS)
         self.vgg = N.VggTrunk(self.device, seed=config.get("vgg_seed", 7), widths=tuple(vw))
+        # `vgg_weights`: npz / torch file with the Keras VGG19 ImageNet kernels in HWIO (edflow downloads them at run time;
+        # they are not obtainable offline).  Without it the perceptual loss runs on seeded He-normal stand-ins: fine for
+        # timing and parity, NOT for training a model that should match the reference's part quality -- say so loudly.
+        if config.get("vgg_weights"):
+            self.vgg.load(N.read_vgg_weights(config["vgg_weights"]))
+            self.vgg_pretrained = True
+        else:
+            self.vgg_pretrained = False
+            msg = ("perceptual trunk runs on seeded stand-in weights (no `vgg_weights` in the config): losses are not the "
+                   "reference's ImageNet-VGG19 perceptual loss")
+            if self.logger:
+                self.logger.warning(msg)
+            elif root is not None and self.rank == 0:
+                import sys
+                sys.stderr.write("[WARNING] " + msg + "\n")
         mi = config["MI"]
         d = self.device
         # non-trainable state (model.py:503, 829-834, 861-866, 890, 921) -- device scalars
@@ -207,7 +223,8 @@ class Trainer(object):
                 self.state[k].fill_(float(v))
         base = os.path.basename(checkpoint_path)
         digits = "".join(ch for ch in base.split("-")[-1] if ch.isdigit())
-        self.set_global_step(int(digits) if digits else ck.get("global_step", 0))
+        # the stored step is authoritative (it agrees with the restored Adam t); the file name is the fallback (model.py:597-601)
+        self.set_global_step(int(ck["global_step"]) if "global_step" in ck else (int(digits) if digits else 0))
         if self.logger:
             self.logger.info("Lazily restored from {}".format(checkpoint_path))
 
@@ -262,7 +279,11 @@ class Trainer(object):
         """One session.run(train_op).  With ``hip_graph: True`` (single GPU) the whole step -- ~2 400 kernel launches on three
         streams -- is captured once into a HIP graph and replayed; see ``_graph_step``."""
         if self._graph_enabled and self.world_size == 1 and not self.model.use_tps:
-            return self._graph_step(batch, noise)
+            # one device scalar carries Adam's bias-corrected step size: usable only while every trained key is at the same
+            # Adam step (not after restoring a checkpoint whose keys were trained for different numbers of steps)
+            ts = set(self.model.bank.groups[k]["t"] for k in self.loss_keys())
+            if len(ts) <= 1:
+                return self._graph_step(batch, noise)
         return self._step_impl(batch, noise)
 
     # ------------------------------------------------------------------ HIP-graph replay of the step
@@ -280,6 +301,8 @@ class Trainer(object):
         configs of the reference (batch 8: ~2 400 launches for 24 ms of GPU work) are launch-bound without it."""
         dev = self.device
         B, S = batch["view0"].shape[0], batch["view0"].shape[1]
+        if self._g is not None and tuple(next(iter(self._g["in"].values())).shape[:2]) != (B, S):
+            self._g = None                       # the capture bakes in shapes and workspace pointers: start over
         if self._g is None:
             self._g = {"in": {k: torch.empty((B, S, S, 3), dtype=torch.float32, device=dev) for k in self.model.inputs},
                        "noise": {k: torch.empty_like(v) for k, v in self.draw_noise(B).items()},
@@ -292,7 +315,7 @@ class Trainer(object):
                 buf.normal_(generator=self._gen)
             else:
                 buf.copy_(noise[k], non_blocking=True)
-        t = next(iter(self.model.bank.groups.values()))["t"] + 1
+        t = self.model.bank.groups[self.loss_keys()[0]]["t"] + 1
         lr = self.learning_rate()
         g["lr"].fill_(lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t))
         sig = self._schedule_signature() + (lr > 0,)
@@ -313,8 +336,8 @@ class Trainer(object):
 
     def _after_graph_step(self):
         # (WeightVersion is not bumped: the step's own batched weight_prep has already refreshed every converted copy)
-        for grp in self.model.bank.groups.values():
-            grp["t"] += 1
+        for k in self.loss_keys():               # keys under `fix_weights` are not stepped (as in eager mode)
+            self.model.bank.groups[k]["t"] += 1
         self.global_step += 1
 
     def _step_impl(self, batch, noise=None, graph_lr=None):
@@ -624,8 +647,13 @@ class Trainer(object):
             log.update({"zr_mumford_sha": p_ms, "z_mumford_sha_smoothness_cost": sums0[6] / B,
                         "z_mumford_sha_contour_cost": sums0[7] / B, "z_area_cost": area_cost,
                         "prior_mumford_sha_weight": w_ms, "perceptual": rec.detach(), "lr": self.learning_rate()})
-        self.log_ops = log
         if graph_lr is not None:        # graph mode: state lives in fixed device scalars, python counters advance outside
+            # the logged state is the PRE-update value in both modes: snapshot before the in-place update below
+            for k, v in list(log.items()):
+                if torch.is_tensor(v) and any(v is sv for sv in st.values()):
+                    log[k] = v.clone()
+        self.log_ops = log
+        if graph_lr is not None:
             for k in st:
                 if new[k] is not st[k]:
                     st[k].copy_(new[k])
@@ -726,6 +754,15 @@ class Trainer(object):
                 bad = [k for k, v in logs.items() if k.startswith("loss_") and not math.isfinite(v)]
                 if bad:       # failure detection on log steps only (the step itself never synchronises with the host)
                     raise FloatingPointError("non-finite {} at global step {}".format(", ".join(bad), s))
-            if self.root and ckpt_freq and s > 0 and s % ckpt_freq == 0:
-                os.makedirs(os.path.join(self.root, "train", "checkpoints"), exist_ok=True)
-                self.save_checkpoint(os.path.join(self.root, "train", "checkpoints", "model.ckpt-{}".format(s)))
+            # edflow CheckpointHook: the file is named after the global step the restored run continues FROM
+            if ckpt_freq and self.global_step % ckpt_freq == 0:
+                self._checkpoint()
+        self._checkpoint()                # final state at loop exit
+
+    def _checkpoint(self):
+        if not self.root or self.rank != 0:
+            return
+        path = os.path.join(self.root, "train", "checkpoints", "model.ckpt-{}".format(self.global_step))
+        if not os.path.exists(path):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            self.save_checkpoint(path)

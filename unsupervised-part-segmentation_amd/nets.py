@@ -285,6 +285,24 @@ class Nets(object):
                                     out_f32=False)
 
 
+def read_vgg_weights(path):
+    """`vgg_weights` file -> {"vgg19/block{b}_conv{c}/V": HWIO kernel, ".../b": bias}.  Accepts .npz or torch files keyed
+    either that way or the Keras way ("block1_conv1/kernel", "block1_conv1/bias", with or without a ":0" suffix, or
+    "block1_conv1_W" / "block1_conv1_b" as in the keras-applications h5 dumps)."""
+    import numpy as np
+    raw = dict(np.load(path)) if str(path).endswith(".npz") else torch.load(path, map_location="cpu")
+    out = {}
+    for k, v in raw.items():
+        t = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v).float()
+        k = k[:-2] if k.endswith(":0") else k
+        k = k.split("vgg19/")[-1]
+        for suf, tgt in (("/kernel", "/V"), ("_W", "/V"), ("/V", "/V"), ("/bias", "/b"), ("_b", "/b"), ("/b", "/b")):
+            if k.endswith(suf):
+                out["vgg19/" + k[:-len(suf)] + tgt] = t
+                break
+    return out
+
+
 # --------------------------------------------------------------------------- perceptual trunk (EXTERNAL, stand-in weights)
 class VggTrunk(object):
     """Keras-VGG19 topology up to block5_conv2 with frozen weights (edflow VGG19Features, UNVERIFIED;
@@ -310,8 +328,14 @@ class VggTrunk(object):
             self.layers.append(blk)
 
     def load(self, state):
+        missing = [lay.name for blk in self.layers for lay in blk if lay.name + "/V" not in state or lay.name + "/b" not in state]
+        if missing:
+            raise KeyError("vgg_weights lacks {}".format(missing))
         for blk in self.layers:
             for lay in blk:
+                if tuple(state[lay.name + "/V"].shape) != tuple(lay.V.shape):
+                    raise ValueError("{}: kernel {} does not fit {} (HWIO expected)".format(
+                        lay.name, tuple(state[lay.name + "/V"].shape), tuple(lay.V.shape)))
                 lay.V.copy_(state[lay.name + "/V"]); lay.b.copy_(state[lay.name + "/b"])
                 for ent in lay._cache.values():
                     ent["version"] = -1

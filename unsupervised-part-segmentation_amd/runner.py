@@ -23,6 +23,7 @@ import yaml
 from .model import TrainModel, Trainer
 
 from . import data as _data
+from . import dist as D
 
 ALIASES = {"TrainModel": TrainModel, "Trainer": Trainer}
 DATA_ALIASES = {"src.data.data.AugmentedPair2": _data.AugmentedPair2, "nips19.data.data.AugmentedPair2": _data.AugmentedPair2,
@@ -34,6 +35,17 @@ def get_obj_from_str(path):
     if mod.split(".")[0] in ("nips19", "src") and name in ALIASES:
         return ALIASES[name]
     return getattr(importlib.import_module(mod), name)
+
+
+def dist_setup():
+    """One process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*): pick this rank's device
+    BEFORE anything touches the GPU, then join the RCCL group.  Returns (world_size, rank, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    world, rank, local = D.init_from_env(os.environ.get("UPS_DIST_BACKEND", "nccl"))
+    return world, rank, local
 
 
 class SyntheticPairs(object):
@@ -77,20 +89,28 @@ def main(argv=None):
     for kv in args.set:
         k, v = kv.split("=", 1)
         cfg[k] = yaml.safe_load(v)
+    world, rank, local = dist_setup()
     root = args.project or os.path.join("logs", time.strftime("%Y-%m-%dT%H-%M-%S") + "_" + os.path.basename(args.train[0]).split(".")[0])
-    os.makedirs(os.path.join(root, "train"), exist_ok=True)
+    if rank == 0:
+        os.makedirs(os.path.join(root, "train"), exist_ok=True)
     Model, Iterator = get_obj_from_str(cfg["model"]), get_obj_from_str(cfg["iterator"])
+    # data parallel: `batch_size` is the per-GPU batch (the graph is static in it, model.py:320); every rank draws its own
+    # shard order / partners / noise from rank-offset seeds, the weights come from the same seed on every rank
     try:
         cls = DATA_ALIASES.get(cfg["dataset"]) or get_obj_from_str(cfg["dataset"])
-        ds = cls(cfg)
-        dataset = _data.batches(ds, cfg["batch_size"]) if isinstance(ds, _data.StochasticPairs) else ds
+        ds = cls(dict(cfg, data_seed=D.shard_seed(cfg.get("data_seed", 1), rank)))
+        dataset = _data.batches(ds, cfg["batch_size"], seed=D.shard_seed(0, rank)) if isinstance(ds, _data.StochasticPairs) else ds
     except Exception:
         if args.strict_dataset:
             raise
-        dataset = SyntheticPairs(cfg)
-    model = Model(cfg)
-    it = Iterator(cfg, root, model)
+        dataset = SyntheticPairs(cfg, seed=D.shard_seed(1234, rank))
+    model = Model(cfg) if Model is not TrainModel else Model(cfg, device=torch.device("cuda", local))
+    kw = {"world_size": world, "rank": rank} if Iterator is Trainer else {}
+    it = Iterator(cfg, root, model, **kw)
     it.initialize(args.checkpoint)
+    if rank != 0:           # logs and checkpoints are written by rank 0 only
+        it.iterate(iter(dataset), num_steps=args.num_steps, log_fn=lambda line: None)
+        return it
     log_path = os.path.join(root, "train", "log.txt")
     with open(log_path, "a") as lf:
         def log_fn(line):
@@ -113,6 +133,7 @@ def evaluate(args):
         k, v = kv.split("=", 1)
         cfg[k] = yaml.safe_load(v)
     cfg["test_mode"] = True
+    dist_setup()            # evaluation is single-process; this only selects LOCAL_RANK's device when launched under a launcher
     root = args.project or os.path.join("logs", time.strftime("%Y-%m-%dT%H-%M-%S") + "_eval")
     Model, Iterator = get_obj_from_str(cfg["model"]), get_obj_from_str(cfg["iterator"])
     try:
