@@ -29,7 +29,7 @@ def _free_port():
 
 
 def _cfg():
-    from upsparts_amd import configs
+    from oracle import configs
     cfg = copy.deepcopy(configs.tiny_config())
     cfg.update(precision="fp32", vgg_widths=VGG_W)
     return cfg
@@ -139,8 +139,7 @@ def test_runner_wires_data_parallelism(dev, tmp_path):
     """`torchrun ... -m upsparts_amd.runner -t yaml`: every rank joins the process group, trains on its own shard with
     all-reduced gradients (identical replicas), and only rank 0 writes the log and the checkpoints."""
     import yaml
-    import upsparts_amd  # noqa: F401
-    from upsparts_amd import configs
+    from oracle import configs
     cfg = copy.deepcopy(configs.tiny_config())
     cfg.update(precision="fp32", vgg_widths=list(VGG_W), ckpt_freq=2, dataset="no.such.Dataset")     # -> synthetic pairs, per-rank seed
     ypath = tmp_path / "t.yaml"

@@ -408,3 +408,29 @@ def test_tps_warp_matches_oracle(dev):
     c, v = PT.make_input_tps_param(PT.tps_parameters(2 * B, uniforms=u.to(dev), **P))
     co, vo = OT.make_input_tps_param(OT.uniforms_to_params(u.double(), **P))
     assert_close(PT.solve_system(c, v).cpu(), OT.solve_system(co, vo).float(), 1e-5, "tps solve")
+
+
+def test_integration_stub_runs(dev):
+    """INTEGRATION.md section 2, executed as written: weight_prep + residual_block_conv through raw pointers."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host import _integration_stub
+    lib, ops, R = _mods()
+    ns = {}
+    exec(_integration_stub(), ns)
+    g = torch.Generator().manual_seed(11)
+    n, h, w, c = 2, 32, 32, 64
+    x = torch.randn(n, h, w, c, generator=g).bfloat16()
+    V = (torch.randn(3, 3, c, c, generator=g) / math.sqrt(9 * c))
+    b = torch.randn(c, generator=g) * 0.1
+    xd, Vd, bd = x.to(dev), V.to(dev), b.to(dev)
+    wq = torch.empty(9 * ((c + 31) // 32) * c * 32, dtype=torch.bfloat16, device=dev)
+    out = torch.empty_like(xd)
+    st = torch.cuda.current_stream().cuda_stream
+    ns["weight_prep"](Vd.data_ptr(), wq.data_ptr(), c, c, st)
+    ns["residual_block_conv"](xd.data_ptr(), wq.data_ptr(), bd.data_ptr(), out.data_ptr(), n, h, w, c, st)
+    torch.cuda.synchronize()
+    xo = x.double()
+    yo = xo + R.conv2d_same(torch.nn.functional.leaky_relu(xo, 0.2), V.bfloat16().double(), b.double(), 1)
+    assert_close(out.float(), yo.float(), BF16_TOL, "INTEGRATION.md stub")

@@ -136,7 +136,8 @@ def test_runner_end_to_end_with_csv_dataset_and_checkpoint(dev, tmp_path):
     import yaml
     from PIL import Image
     import upsparts_amd  # noqa: F401
-    from upsparts_amd import configs, runner
+    from upsparts_amd import runner
+    from oracle import configs
     rng = np.random.RandomState(0)
     rows = ["character_id,relative_file_path_,foo,category"]
     for i in range(8):

@@ -37,7 +37,7 @@ def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch):
     from upsparts_amd.model import TrainModel
     if not torch.cuda.is_available():
         with pytest.raises(lib.UpsError):
-            TrainModel(_pkg()[4].tiny_config())
+            TrainModel(_pkg()[4].cub_config())
     monkeypatch.setattr(lib, "_lib", None)
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libupsparts_hip.so")
     with pytest.raises(lib.UpsError):
@@ -93,8 +93,8 @@ def test_schedules_match_yaml_semantics():
 
 
 def test_variable_names_shapes_and_optimizer_groups_match_oracle():
-    lib, ops, nets, sch, configs = _pkg()
-    from oracle import ref_model as R
+    lib, ops, nets, sch, _ = _pkg()
+    from oracle import ref_model as R, configs
     cfg = configs.tiny_config()
     n = nets.Nets(cfg, torch.device("cpu"), seed=0)
     ref = R.init_params(cfg, 0)
@@ -257,3 +257,35 @@ def test_read_vgg_weights_key_spellings(tmp_path):
     assert sorted(st) == ["vgg19/block1_conv1/V", "vgg19/block1_conv1/b", "vgg19/block2_conv1/V", "vgg19/block2_conv1/b",
                           "vgg19/block3_conv4/V", "vgg19/block3_conv4/b"]
     assert st["vgg19/block1_conv1/V"].shape == (3, 3, 3, 8) and st["vgg19/block1_conv1/V"].dtype == torch.float32
+
+
+def _integration_stub():
+    """The python block of INTEGRATION.md section 2, with the library path made absolute."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text.split("```python\n", 1)[1].split("```", 1)[0]
+    return block.replace('"unsupervised-part-segmentation_amd/csrc/libupsparts_hip.so"',
+                         repr(os.path.join(ROOT, "unsupervised-part-segmentation_amd", "csrc", "libupsparts_hip.so")))
+
+
+def test_integration_stub_matches_the_header():
+    """The binder stub a maintainer would copy out of INTEGRATION.md declares the FULL ups_conv_desc: same fields, order
+    and size as the header (and as the product's own ctypes mirror)."""
+    import ctypes as C
+    lib, *_ = _pkg()
+    ns = {}
+    exec(_integration_stub(), ns)
+    stub = ns["ups_conv_desc"]
+    assert [f[0] for f in stub._fields_] == [f[0].rstrip("_") for f in lib.ConvDesc._fields_]
+    assert C.sizeof(stub) == C.sizeof(lib.ConvDesc)
+    for (n0, t0), (n1, t1) in zip(stub._fields_, lib.ConvDesc._fields_):
+        assert C.sizeof(t0) == C.sizeof(t1) and getattr(stub, n0).offset == getattr(lib.ConvDesc, n1).offset, n0
+    hdr = open(os.path.join(ROOT, "include", "upsparts_hip.h")).read()
+    body = hdr.split("typedef struct {", 1)[1].split("} ups_conv_desc;", 1)[0]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            for part in decl.split(","):
+                names.append(re.sub(r"\[\d+\]", "", part.strip().split()[-1].lstrip("*")))
+    assert names == [f[0] for f in stub._fields_], (names, [f[0] for f in stub._fields_])

@@ -13,8 +13,12 @@ from upsparts_amd import configs, dist as D
 from upsparts_amd.model import TrainModel, Trainer
 assert D.FORCE_COLLECTIVES
 dev = torch.device("cuda:0")
-cfg = copy.deepcopy(configs.small_config())
-cfg.update(precision="bf16", vgg_widths=(8, 8, 16, 16, 16))
+cfg = copy.deepcopy(configs.cub_config(n_parts=4, batch_size=2, spatial_size=32))      # the CUB yaml at reduced widths
+cfg.update(precision="bf16", vgg_widths=(8, 8, 16, 16, 16), patch_size=8, z0_size=16, local_app_size=16)
+cfg["encoder0"].update(config=[16, 32, 32, 64], extra_resnets=1)
+cfg["encoder1"].update(config=[16, 32, 32, 64], extra_resnets=1)
+cfg["dv"].update(config=[8, 16, 32, 40], upsample_config=["linear"] * 3)
+cfg["final_hour"].update(config=[16, 32])
 g = torch.Generator().manual_seed(3)
 B, S = cfg["batch_size"], cfg["spatial_size"]
 batches = [{k: torch.rand(B, S, S, 3, generator=g) * 2 - 1 for k in ("view0", "view1", "view0_target")} for _ in range(3)]

@@ -1,8 +1,9 @@
 """Configs of the product path (the yaml surface as dicts).
 
 ``cub_config`` restates cub/code/SB_model48i/train_cub_subset_tps.yaml (Y:19-194) as a dict,
-with n_parts / batch_size / use_tps overridable (BASELINE configs use P=10, use_tps False).
-``tiny_config`` is the golden-fixture config: S=16, P=3, B=2.
+with n_parts / batch_size / use_tps overridable (BASELINE configs use P=10, use_tps False);
+``pennaction_config`` / ``deepfashion_config`` do the same for the other two shipped yamls.
+(The reduced-width parity configs of the test suite live with the test infrastructure, not here.)
 """
 import copy
 
@@ -81,44 +82,4 @@ def deepfashion_config(n_parts=16, batch_size=8, spatial_size=128):
     dvc = [16] * (levels + 1 - len(dvc)) + dvc
     c["dv"] = {"config": dvc, "upsample_config": ["linear"] * levels, "activation": "leaky_relu", "coords": True}
     c["d_single"] = copy.deepcopy(c["dv"])
-    return c
-
-
-def tiny_config(n_parts=3, batch_size=2, spatial_size=16, variant="cub"):
-    """Same graph, tiny widths: encoders 16->8->4, dv 4->8->16, z=8, app=8."""
-    c = _variant(variant, n_parts, batch_size, spatial_size)
-    c.update({"patch_size": 6, "z0_size": 8, "local_app_size": 8})
-    c["encoder0"].update({"config": [8, 16, 16], "extra_resnets": 1})
-    c["encoder1"].update({"config": [8, 16, 16], "extra_resnets": 1})
-    c["dv"].update({"config": [8, 16, 16], "upsample_config": ["linear"] * 2})
-    if "d_single" in c:
-        c["d_single"].update({"config": [8, 16, 16], "upsample_config": ["linear"] * 2})
-        c.pop("patch_size")
-    c["final_hour"].update({"config": [8, 16]})
-    return c
-
-
-def _variant(variant, n_parts, batch_size, spatial_size):
-    fn = {"cub": cub_config, "pennaction": pennaction_config, "deepfashion": deepfashion_config}[variant]
-    c = copy.deepcopy(fn(n_parts, batch_size, spatial_size))
-    if variant == "deepfashion":
-        # parity configs: make the Mumford-Shah prior on the logits visible (the yaml's weight is 1e-6) and put its
-        # clamp min(alpha * g, lambda) inside the range of the synthetic logits so both branches are exercised
-        c["prior_mumford_sha_weight"] = _stair(100000, 1.0e-2, 20000, 3.14, 1.0e-1, 1.0e-1)
-        c["mumford_sha_lambda"] = _stair(65000, 1.0, 5000, 10, 5.0e-4, 5.0e-4)
-    return c
-
-
-def small_config(n_parts=4, batch_size=2, spatial_size=32, variant="cub"):
-    """Mid-size parity config: 32x32 images (16-aligned, so the patch-tiled 3x3 kernels run inside the whole-step
-    tests), encoders 32->16->8->4, dv 4->8->16->32, z=16, app=16."""
-    c = _variant(variant, n_parts, batch_size, spatial_size)
-    c.update({"patch_size": 8, "z0_size": 16, "local_app_size": 16})
-    c["encoder0"].update({"config": [16, 32, 32, 64], "extra_resnets": 1})
-    c["encoder1"].update({"config": [16, 32, 32, 64], "extra_resnets": 1})
-    c["dv"].update({"config": [8, 16, 32, 40], "upsample_config": ["linear"] * 3})
-    if "d_single" in c:
-        c["d_single"].update({"config": [8, 16, 32, 40], "upsample_config": ["linear"] * 3})
-        c.pop("patch_size")
-    c["final_hour"].update({"config": [16, 32]})
     return c
