@@ -4,7 +4,11 @@ the fp64 CPU oracle -- scalars, per-variable gradient norms, a few small summari
 With `resize256` as argument: the same step with `perceptual_input: resize256` (edflow's original_scale reading) ->
 full_cub128_step_resize256.npz.  Inputs are regenerated from seeds by the test (R.synthetic_views / R.synthetic_noise).
 
-    python tests/golden/make_golden_full.py [native|resize256]
+With `confident`: forward only, with the last convolution of the mask decoder scaled by CONFIDENT_SCALE so that the mean
+logits have the spread of a TRAINED model (std ~4 instead of ~0.2 at random init, where the noise-free argmax is decided
+by 1e-2 gaps) -> full_cub128_confident.npz: the masks a bf16 run must reproduce at IoU >= 0.99.
+
+    python tests/golden/make_golden_full.py [native|resize256|confident]
 """
 import os
 import sys
@@ -18,7 +22,37 @@ sys.path.insert(0, ROOT)
 from oracle import configs, ref_model as R  # noqa: E402
 
 
+CONFIDENT_SCALE = 25.0
+CONFIDENT_LAYER = "decoder_visualize/conv2d_9"
+
+
+def confident_params(cfg, seed=0):
+    params = R.init_params(cfg, seed)
+    for suf in ("/V", "/b"):
+        params[CONFIDENT_LAYER + suf] = params[CONFIDENT_LAYER + suf] * CONFIDENT_SCALE
+    return params
+
+
+def confident():
+    cfg = configs.cub_config(n_parts=10, batch_size=2)
+    params = confident_params(cfg)
+    views, noise = R.synthetic_views(cfg), R.synthetic_noise(cfg)
+    with torch.no_grad():
+        o = R.forward(params, cfg, views, noise, dtype=torch.float64)
+    out = {"hard0_argmax": R.hard_max(o["m0"]).argmax(-1).numpy().astype(np.uint8),
+           "hard1_argmax": R.hard_max(o["m1"]).argmax(-1).numpy().astype(np.uint8),
+           "out_parts_hard": o["out_parts_hard"].numpy().astype(np.uint8),
+           "l0_mean_std": np.float64(float(o["l0_mean"].std())),
+           "top2_gap_median": np.float64(float((o["l0_mean"].topk(2, dim=-1).values[..., 0] - o["l0_mean"].topk(2, dim=-1).values[..., 1]).median())),
+           "generated_8x8": torch.nn.functional.avg_pool2d(o["generated"].permute(0, 3, 1, 2), 16).permute(0, 2, 3, 1).float().numpy()}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "full_cub128_confident.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes; l0_mean std", out["l0_mean_std"], "median top-2 gap", out["top2_gap_median"])
+
+
 def main(mode="native"):
+    if mode == "confident":
+        return confident()
     cfg = configs.cub_config(n_parts=10, batch_size=2)
     params = R.init_params(cfg, 0)
     vp = R.vgg_params(7)

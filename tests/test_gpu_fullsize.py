@@ -92,9 +92,36 @@ def test_full_width_step_bf16_mask_iou(dev):
     hard = trainer._debug["hard"]
     iou0, iou1 = _iou(hard[:B], z["hard0_argmax"], P), _iou(hard[B:], z["hard1_argmax"], P)
     assert min(iou0, iou1) >= 0.99, "bf16 part-mask IoU vs oracle: {} / {}".format(iou0, iou1)
-    out = model.forward(views)
-    agree = float((out["out_parts_hard"].cpu().numpy() == z["out_parts_hard"]).mean())
-    assert agree >= 0.99, "test-mode out_parts_hard agreement {}".format(agree)
     for k in losses:
         lo, lh = float(z["loss_" + k]), float(losses[k])
         assert abs(lo - lh) <= 5e-2 * max(1.0, abs(lo)), "loss {}: oracle {} hip(bf16) {}".format(k, lo, lh)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_full_width_confident_masks_iou(dev, precision):
+    """Part-mask IoU vs the fp64 oracle where it means something.  At random init the mask decoder's output is nearly flat
+    (noise-free argmax decided by ~1e-2 logit gaps, sampled masks decided by the unit noise), so the fixture scales the last
+    decoder convolution to the logit spread of a trained model (tests/golden/make_golden_full.py confident): the noise-free
+    `out_parts_hard` (model.py:469-470) and the sampled hard masks of a bf16 run must reach IoU >= 0.99 (north_star)."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_golden_full as G
+    z = np.load(os.path.join(GOLD, "full_cub128_confident.npz"))
+    cfg, model, trainer, views, noise = _trainer(dev, precision)
+    with torch.no_grad():
+        for suf in ("/V", "/b"):
+            model.variables[G.CONFIDENT_LAYER + suf].mul_(G.CONFIDENT_SCALE)
+    from upsparts_amd import ops
+    ops.WeightVersion.value += 1
+    B, P = cfg["batch_size"], cfg["n_parts"]
+    out = model.forward(views, noise)
+    a = out["out_parts_hard"].cpu().numpy()
+    onehot = torch.nn.functional.one_hot(torch.from_numpy(a).long(), P)
+    iou_mean = _iou(onehot, z["out_parts_hard"], P)
+    agree = float((a == z["out_parts_hard"]).mean())
+    m0 = out["m0_sample"]
+    iou_s = _iou((m0 == m0.max(dim=-1, keepdim=True).values).float(), z["hard0_argmax"], P)
+    print("{} full width, confident logits: out_parts_hard IoU {:.4f} (pixel agreement {:.4f}), sampled-mask IoU {:.4f}".format(
+        precision, iou_mean, agree, iou_s))
+    bar = 0.99 if precision == "bf16" else 0.999
+    assert iou_mean >= bar and iou_s >= bar, (iou_mean, iou_s)
