@@ -4,9 +4,10 @@ the fp64 CPU oracle -- scalars, per-variable gradient norms, a few small summari
 With `resize256` as argument: the same step with `perceptual_input: resize256` (edflow's original_scale reading) ->
 full_cub128_step_resize256.npz.  Inputs are regenerated from seeds by the test (R.synthetic_views / R.synthetic_noise).
 
-With `confident`: forward only, with the last convolution of the mask decoder scaled by CONFIDENT_SCALE so that the mean
-logits have the spread of a TRAINED model (std ~4 instead of ~0.2 at random init, where the noise-free argmax is decided
-by 1e-2 gaps) -> full_cub128_confident.npz: the masks a bf16 run must reproduce at IoU >= 0.99.
+With `confident`: forward only, with the last convolution of the mask decoder scaled by CONFIDENT_SCALE so that the masks
+are as confident as the reference's after training: its log reports mask0_kl 6.18 at step ~71k (cub/train/log.txt:20385-20442;
+two maps, P = 25 -> 0.13 nats of entropy per pixel); scale 100 gives 0.124 nats here (random init: 2.2 of ln 10 = 2.30, with
+the noise-free argmax decided by 1e-2 logit gaps) -> full_cub128_confident.npz.
 
     python tests/golden/make_golden_full.py [native|resize256|confident]
 """
@@ -22,7 +23,7 @@ sys.path.insert(0, ROOT)
 from oracle import configs, ref_model as R  # noqa: E402
 
 
-CONFIDENT_SCALE = 25.0
+CONFIDENT_SCALE = 100.0
 CONFIDENT_LAYER = "decoder_visualize/conv2d_9"
 
 

@@ -90,6 +90,27 @@ def main():
         "view + hard read, [P*B,S,S,8] bf16 written")
     feat = torch.randn(B, P, A, device=dev, generator=g)
     add("unpool_fwd", half_b + B * S * S * 80 * 2, lambda: ops.UnpoolFn.apply(h0, feat, T), "hard read, [B,S,S,80] bf16 written")
+    gparts = torch.randn(P * B, S, S, 8, device=dev, generator=g).to(T)
+    ghp = torch.empty(B, S, S, P, device=dev)
+    add("mask_parts_bwd", gparts.numel() * 2 + view.numel() * 4 + half_b,
+        lambda: L.call("ups_mask_parts_bwd", L.ptr(view), L.ptr(gparts), L.ptr(ghp), L.dt(gparts), B, S * S, P, L.stream()),
+        "[P*B,S,S,8] bf16 gradient + view read, g_hard written")
+    ginj = torch.randn(B, S, S, 80, device=dev, generator=g).to(T)
+    gfe = torch.empty(L.load().ups_unpool_bwd_floats(B, P, A), dtype=torch.float32, device=dev)
+    add("unpool_bwd (g_hard + g_feat)", 2 * ginj.numel() * 2 + 2 * half_b,
+        lambda: L.call("ups_unpool_bwd", L.ptr(h0), L.ptr(feat), L.ptr(ginj), L.ptr(ghp), L.ptr(gfe), L.dt(ginj), B, S * S, P, A, 80,
+                       L.stream()),
+        "two kernels: [B,S,S,80] bf16 gradient read twice, hard read, g_hard written")
+    m1 = m[B:].contiguous()
+    px1 = px[B:].contiguous()
+    add("spatial_moments (masked, soft map)", half_b, lambda: ops.spatial_moments(m1, 10.0, rect_px=px1, half=16), "1 read of the map")
+    sums1 = torch.empty(nfl, dtype=torch.float32, device=dev)
+    d_f1 = prior_desc(1, B, l[B:].contiguous(), None, m1, None, px1, None, sums1)
+    add("prior_fwd (view 1)", half_b, lambda: L.call("ups_prior_fwd", C.byref(d_f1), L.stream()), "m read once")
+    st1 = ops.spatial_moments(m1, 10.0, rect_px=px1, half=16)
+    d_b1 = prior_desc(1, B, l[B:].contiguous(), None, m1, None, px1, st1, sums1, gh, dl, dlr)
+    add("prior_bwd (view 1, dl_tot + dl_rec)", 4 * half_b, lambda: L.call("ups_prior_bwd", C.byref(d_b1), L.stream()),
+        "m, g_hard read; 2 writes")
     fa = torch.randn(B, S, S, 64, device=dev, generator=g).to(T)
     fb = torch.randn(B, S, S, 64, device=dev, generator=g).to(T)
     add("l1_fwd (VGG block1 features)", 2 * fa.numel() * 2, lambda: ops.L1MeanFn.apply(fa, fb, 64, L.ACT_RELU), "two reads")

@@ -1,46 +1,58 @@
 // The part path between the mask decoder and the image decoder (cub/code/SB_model48i/model.py:414-484):
 // per-pixel soft-max over parts + hard max, spatial soft-max moments -> rectangle centres, part-masked
-// appearance images, part-feature un-pooling.  All HBM-bound; lanes run along the part / feature axis so
-// every global access is coalesced and the part reductions are wavefront shuffles.
+// appearance images, part-feature un-pooling.  All HBM-bound.  Data moves between HBM and LDS in whole pixel tiles with
+// 16-byte accesses (tile.h: enough bytes in flight to cover the HBM latency); compute runs out of LDS with lanes along the
+// part / feature axis so the part reductions are wavefront shuffles.
 #include "common.h"
+#include "tile.h"
 
 namespace {
 
 // ------------------------------------------------------------------ softmax_P + hard_max (nn.py:58-62, 134-136)
+// One block = one tile of `tpx` consecutive pixels: l = mean (+ eps) is staged (and echoed to `l`) with 16-byte accesses,
+// GP lanes per pixel reduce over the parts, the tile then holds +m / -m (sign = hard-max flag: m of a maximum is >= 1/P > 0)
+// and goes out as the two maps m and hard.
+struct TileAbs { __device__ float operator()(float v) const { return fabsf(v); } };
+struct TileSign { __device__ float operator()(float v) const { return (__float_as_uint(v) >> 31) ? 1.f : 0.f; } };
+
 template <int GP>
-__global__ void part_softmax_kernel(const float* __restrict__ mean, const float* __restrict__ eps, float* __restrict__ l,
-                                    float* __restrict__ m, float* __restrict__ hard, long long* __restrict__ amax,
-                                    long long pixels, int P) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long pix = gid / GP;
-    const int c = (int)(gid % GP);
-    const bool ok = pix < pixels && c < P;
-    float v = -INFINITY;
-    if (ok) {
-        v = mean[pix * P + c];
-        if (eps) v += eps[pix * P + c];
-        if (l) l[pix * P + c] = v;
+__global__ __launch_bounds__(256) void part_softmax_kernel(const float* __restrict__ mean, const float* __restrict__ eps,
+                                                           float* __restrict__ l, float* __restrict__ m, float* __restrict__ hard,
+                                                           long long* __restrict__ amax, long long pixels, int P, int tpx) {
+    extern __shared__ __attribute__((aligned(16))) float ts[];          // [tpx][PP]
+    constexpr int PL = 256 / GP;
+    const int PP = tile_pitch(P);
+    const long long pix0 = (long long)blockIdx.x * tpx;
+    const int cnt = (int)min((long long)tpx, pixels - pix0);
+    tile_load_f32(mean + pix0 * P, cnt, P, PP, ts, eps ? eps + pix0 * P : nullptr, (eps && l) ? l + pix0 * P : nullptr);
+    __syncthreads();
+    const int c = threadIdx.x % GP, pl = threadIdx.x / GP;
+    for (int px = pl; px < tpx; px += PL) {          // uniform trip count: the shuffles need every lane of a group
+        const bool ok = px < cnt && c < P;
+        const float v = ok ? ts[px * PP + c] : -INFINITY;
+        float mx = v;
+#pragma unroll
+        for (int o = GP / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, GP));
+        const float e = ok ? expf(v - mx) : 0.f;
+        float sm = e;
+#pragma unroll
+        for (int o = GP / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o, GP);
+        const float pm = e / sm;
+        float mm = ok ? pm : -1.f;
+#pragma unroll
+        for (int o = GP / 2; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, GP));
+        const bool is_max = ok && pm == mm;
+        int first = is_max ? c : GP;
+#pragma unroll
+        for (int o = GP / 2; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, GP));
+        if (ok) {
+            ts[px * PP + c] = is_max ? -pm : pm;
+            if (amax && c == 0) amax[pix0 + px] = first;
+        }
     }
-    float mx = v;
-#pragma unroll
-    for (int o = GP / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, GP));
-    const float e = ok ? expf(v - mx) : 0.f;
-    float s = e;
-#pragma unroll
-    for (int o = GP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, GP);
-    const float pm = e / s;
-    float mm = ok ? pm : -1.f;
-#pragma unroll
-    for (int o = GP / 2; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, GP));
-    const bool is_max = ok && pm == mm;
-    int first = is_max ? c : GP;
-#pragma unroll
-    for (int o = GP / 2; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, GP));
-    if (ok) {
-        m[pix * P + c] = pm;
-        if (hard) hard[pix * P + c] = is_max ? 1.f : 0.f;
-        if (amax && c == 0) amax[pix] = first;
-    }
+    __syncthreads();
+    tile_store_f32(m + pix0 * P, cnt, P, PP, ts, TileAbs());
+    if (hard) tile_store_f32(hard + pix0 * P, cnt, P, PP, ts, TileSign());
 }
 
 // ------------------------------------------------------------------ spatial soft-max moments (nn.py:65-71, 1541-1587)
@@ -48,32 +60,43 @@ __global__ void part_softmax_kernel(const float* __restrict__ mean, const float*
 template <int GP>
 __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ x, int h, int w, int P, float gamma,
                                                               const int* __restrict__ rc, int hh, int hw_half,
-                                                              int rows_per_slab, float* __restrict__ partial) {
+                                                              int rows_per_slab, int tpx, float* __restrict__ partial) {
     constexpr int PL = 256 / GP;
-    __shared__ float red[PL][GP][7];
+    extern __shared__ __attribute__((aligned(16))) float ts[];          // [tpx][PP], then red[PL][GP][7]
+    const int PP = tile_pitch(P);
+    float (*red)[GP][7] = (float (*)[GP][7])(ts + (size_t)tpx * PP);
     const int n = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
     const int c = threadIdx.x % GP, pl = threadIdx.x / GP;
     const int y0 = slab * rows_per_slab, y1 = min(h, y0 + rows_per_slab);
     float mx = -INFINITY, Z = 0.f, S0 = 0.f, Sy = 0.f, Sx = 0.f, Q = 0.f, Qy = 0.f;
     int cy = 0, cx = 0;
     if (rc && c < P) { cy = rc[((long long)n * P + c) * 2]; cx = rc[((long long)n * P + c) * 2 + 1]; }
-    if (c < P) {
-        const float sy = h > 1 ? 2.f / (float)(h - 1) : 0.f, sx = w > 1 ? 2.f / (float)(w - 1) : 0.f;
-        for (int px = y0 * w + pl; px < y1 * w; px += PL) {
-            const int yy = px / w, xx = px - yy * w;
-            const float v = gamma * x[((long long)n * h * w + px) * P + c];
-            if (v > mx) {
-                const float sc = expf(mx - v);  // exp(-inf) = 0 on the first element
-                Z *= sc; S0 *= sc; Sy *= sc; Sx *= sc; Q *= sc; Qy *= sc;
-                mx = v;
+    const float sy = h > 1 ? 2.f / (float)(h - 1) : 0.f, sx = w > 1 ? 2.f / (float)(w - 1) : 0.f;
+    const int q0 = y0 * w, q1 = max(y1, y0) * w;
+    const float* img = x + (long long)n * h * w * P;
+    for (int t0 = q0; t0 < q1; t0 += tpx) {
+        const int cnt = min(tpx, q1 - t0);
+        __syncthreads();                      // the previous tile has been consumed
+        tile_load_f32(img + (long long)t0 * P, cnt, P, PP, ts);
+        __syncthreads();
+        if (c < P) {
+            for (int px = pl; px < cnt; px += PL) {
+                const int q = t0 + px;
+                const int yy = q / w, xx = q - yy * w;
+                const float v = gamma * ts[px * PP + c];
+                if (v > mx) {
+                    const float sc = expf(mx - v);  // exp(-inf) = 0 on the first element
+                    Z *= sc; S0 *= sc; Sy *= sc; Sx *= sc; Q *= sc; Qy *= sc;
+                    mx = v;
+                }
+                const float e = expf(v - mx);
+                Z += e;
+                float k = 1.f;
+                if (rc && abs(yy - cy) <= hh && abs(xx - cx) <= hw_half) k = 0.f;
+                const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
+                const float ek = e * k;
+                S0 += ek; Sy += ek * gy; Sx += ek * gx; Q += ek * (gy * gy + gx * gx); Qy += ek * gy * gy;
             }
-            const float e = expf(v - mx);
-            Z += e;
-            float k = 1.f;
-            if (rc && abs(yy - cy) <= hh && abs(xx - cx) <= hw_half) k = 0.f;
-            const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
-            const float ek = e * k;
-            S0 += ek; Sy += ek * gy; Sx += ek * gx; Q += ek * (gy * gy + gx * gx); Qy += ek * gy * gy;
         }
     }
     red[pl][c][0] = mx; red[pl][c][1] = Z; red[pl][c][2] = S0; red[pl][c][3] = Sy; red[pl][c][4] = Sx; red[pl][c][5] = Q;
@@ -153,109 +176,163 @@ __global__ void mask_parts_fwd_kernel(const float* __restrict__ view, const floa
         else { *(uint4*)o = Chunk<float>::pack(f); *(uint4*)((float*)o + 4) = Chunk<float>::pack(f + 4); }
     }
 }
+// thread = pixel: P 16-byte loads (coalesced along the pixels of one part image), results staged as a [256][P] tile and
+// written with 16-byte stores (a thread-per-pixel store of P floats at a 4 P byte stride ran at 7 % of the HBM roof)
 template <typename T>
-__global__ void mask_parts_bwd_kernel(const float* __restrict__ view, const T* __restrict__ g, float* __restrict__ gh,
-                                      int B, long long hw, int P) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)B * hw) return;
-    const int b = (int)(idx / hw);
-    const long long px = idx - (long long)b * hw;
-    const float v0 = view[idx * 3], v1 = view[idx * 3 + 1], v2 = view[idx * 3 + 2];
-    for (int p = 0; p < P; ++p) {
-        const T* gp = g + (((long long)p * B + b) * hw + px) * 8;
-        gh[idx * P + p] = ld_as_float<T>(gp) * v0 + ld_as_float<T>(gp + 1) * v1 + ld_as_float<T>(gp + 2) * v2;
+__global__ __launch_bounds__(256) void mask_parts_bwd_kernel(const float* __restrict__ view, const T* __restrict__ g,
+                                                             float* __restrict__ gh, int B, long long hw, int P) {
+    extern __shared__ __attribute__((aligned(16))) float ts[];          // [256][PP]
+    const int PP = tile_pitch(P);
+    const long long total = (long long)B * hw;
+    const long long pix0 = (long long)blockIdx.x * 256;
+    const int cnt = (int)min(256ll, total - pix0);
+    const long long idx = pix0 + threadIdx.x;
+    if (threadIdx.x < cnt) {
+        const int b = (int)(idx / hw);
+        const long long px = idx - (long long)b * hw;
+        const float v0 = view[idx * 3], v1 = view[idx * 3 + 1], v2 = view[idx * 3 + 2];
+        for (int p = 0; p < P; ++p) {
+            const T* gp = g + (((long long)p * B + b) * hw + px) * 8;
+            float f[4];
+            if (sizeof(T) == 2) {
+                const uint2 u = *(const uint2*)gp;
+                f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u); f[2] = __uint_as_float(u.y << 16);
+            } else {
+                const float4 u = *(const float4*)gp;
+                f[0] = u.x; f[1] = u.y; f[2] = u.z;
+            }
+            ts[threadIdx.x * PP + p] = f[0] * v0 + f[1] * v1 + f[2] * v2;
+        }
     }
+    __syncthreads();
+    tile_store_f32(gh + pix0 * P, cnt, P, PP, ts);
 }
 
 // ------------------------------------------------------------------ unpool_features + concat (model.py:225-249, 482-484)
-// one thread per (pixel, 8-channel chunk); chunks >= F/8 carry the hard mask itself, then zero padding
+// block = 256 consecutive pixels of one image: the hard tile and feat[b] sit in LDS; one item per (pixel, 8-channel chunk)
+// -> consecutive items write consecutive 16-byte chunks.  Chunks >= F/8 carry the hard mask itself, then zero padding.
 template <typename T>
-__global__ void unpool_fwd_kernel(const float* __restrict__ hard, const float* __restrict__ feat, T* __restrict__ out, int B,
-                                  long long hw, int P, int F, int ldo) {
+__global__ __launch_bounds__(256) void unpool_fwd_kernel(const float* __restrict__ hard, const float* __restrict__ feat,
+                                                         T* __restrict__ out, long long hw, int P, int F, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) float ts[];          // hard [256][PP], feat [P][F]
+    const int PP = tile_pitch(P);
+    float* fs = ts + 256 * PP;
+    const int b = blockIdx.y;
+    const long long q0 = (long long)blockIdx.x * 256;
+    const int cnt = (int)min(256ll, hw - q0);
+    const long long pix0 = (long long)b * hw + q0;
+    tile_load_f32(hard + pix0 * P, cnt, P, PP, ts);
+    for (int i = threadIdx.x; i < P * F; i += 256) fs[i] = feat[(long long)b * P * F + i];
+    __syncthreads();
     const int cpp = ldo / 8;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)B * hw * cpp) return;
-    const int k = (int)(idx % cpp);
-    const long long bp = idx / cpp;
-    const int b = (int)(bp / hw);
-    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* hrow = hard + bp * P;
-    if (k * 8 < F) {
-        for (int p = 0; p < P; ++p) {
-            const float hm = hrow[p];
-            if (hm != 0.f) {
-                const float* fr = feat + ((long long)b * P + p) * F + k * 8;
+    for (int i = threadIdx.x; i < cnt * cpp; i += 256) {
+        const int px = i / cpp, k = i - px * cpp;
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* hrow = ts + px * PP;
+        if (k * 8 < F) {
+            for (int p = 0; p < P; ++p) {
+                const float hm = hrow[p];
+                if (hm != 0.f) {
+                    const float* fr = fs + p * F + k * 8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] += hm * fr[e];
+                    for (int e = 0; e < 8; ++e) f[e] += hm * fr[e];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = k * 8 + e - F;
+                if (ch < P) f[e] = hrow[ch];
             }
         }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ch = k * 8 + e - F;
-            if (ch < P) f[e] = hrow[ch];
-        }
+        T* o = out + (pix0 + px) * ldo + k * 8;
+        if (sizeof(T) == 2) *(uint4*)o = Chunk<bf16>::pack(f);
+        else { *(uint4*)o = Chunk<float>::pack(f); *(uint4*)((float*)o + 4) = Chunk<float>::pack(f + 4); }
     }
-    T* o = out + bp * ldo + k * 8;
-    if (sizeof(T) == 2) *(uint4*)o = Chunk<bf16>::pack(f);
-    else { *(uint4*)o = Chunk<float>::pack(f); *(uint4*)((float*)o + 4) = Chunk<float>::pack(f + 4); }
 }
 
 // g_hard[b][px][p] = sum_f g[b][px][f] * feat[b][p][f] + g[b][px][F+p]
-// GP adjacent lanes own the parts of one pixel; feat[b] sits in LDS with an odd row stride (conflict-free reads).
+// block = tpx consecutive pixels of one image: their gradient rows (16-byte loads) and feat[b] (odd row stride) sit in LDS;
+// GP adjacent lanes own the parts of one pixel; the result tile goes out with 16-byte stores.
 template <typename T, int GP>
 __global__ __launch_bounds__(256) void unpool_bwd_hard_kernel(const float* __restrict__ feat, const T* __restrict__ g,
                                                               float* __restrict__ gh, long long hw, int P, int F, int ldo,
-                                                              int px_per_block) {
-    extern __shared__ float fs[];                  // [P][F+1]
+                                                              int tpx) {
+    extern __shared__ __attribute__((aligned(16))) float ts[];          // out [tpx][PP], feat [P][F+1], g [tpx][ldo] (T)
+    const int PP = tile_pitch(P);
+    float* fs = ts + (size_t)tpx * PP;
+    T* gs = (T*)(fs + ((P * (F + 1) + 3) & ~3));
     const int b = blockIdx.y;
+    const long long q0 = (long long)blockIdx.x * tpx;
+    const int cnt = (int)min((long long)tpx, hw - q0);
+    const long long pix0 = (long long)b * hw + q0;
     for (int i = threadIdx.x; i < P * F; i += 256) fs[(i / F) * (F + 1) + (i % F)] = feat[(long long)b * P * F + i];
+    {
+        const uint4* src = (const uint4*)(g + pix0 * ldo);
+        const int nv = (int)((size_t)cnt * ldo * sizeof(T) / 16);
+        for (int i = threadIdx.x; i < nv; i += 256) ((uint4*)gs)[i] = src[i];
+    }
     __syncthreads();
     const int c = threadIdx.x % GP, pl = threadIdx.x / GP;
     constexpr int PL = 256 / GP;
-    const long long p0 = (long long)blockIdx.x * px_per_block;
-    const long long p1 = min(hw, p0 + px_per_block);
-    if (c >= P) return;
-    const float* fr = fs + c * (F + 1);
-    for (long long px = p0 + pl; px < p1; px += PL) {
-        const T* row = g + ((long long)b * hw + px) * ldo;
-        float acc = ld_as_float<T>(row + F + c);
-        for (int f = 0; f < F; f += 8) {
-            float v[8];
-            if (sizeof(T) == 2) { uint4 u = *(const uint4*)(row + f); Chunk<bf16>::unpack(u, v); }
-            else {
-                uint4 u0 = *(const uint4*)(row + f), u1 = *(const uint4*)((const float*)(row + f) + 4);
-                Chunk<float>::unpack(u0, v); Chunk<float>::unpack(u1, v + 4);
-            }
+    if (c < P) {
+        const float* fr = fs + c * (F + 1);
+        for (int px = pl; px < cnt; px += PL) {
+            const T* row = gs + (size_t)px * ldo;
+            float acc = ld_as_float<T>(row + F + c);
+            for (int f = 0; f < F; f += 8) {
+                float v[8];
+                if (sizeof(T) == 2) { uint4 u = *(const uint4*)(row + f); Chunk<bf16>::unpack(u, v); }
+                else {
+                    uint4 u0 = *(const uint4*)(row + f), u1 = *(const uint4*)((const float*)(row + f) + 4);
+                    Chunk<float>::unpack(u0, v); Chunk<float>::unpack(u1, v + 4);
+                }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc += v[e] * fr[f + e];
+                for (int e = 0; e < 8; ++e) acc += v[e] * fr[f + e];
+            }
+            ts[px * PP + c] = acc;
         }
-        gh[((long long)b * hw + px) * P + c] = acc;
     }
+    __syncthreads();
+    tile_store_f32(gh + pix0 * P, cnt, P, PP, ts);
 }
 
-// g_feat partials: lane = feature, each wave walks its pixels and adds the gradient row into the LDS column of the
-// (usually single) active part; partial[b][slab][p][f]
+// g_feat partials: lane = feature; each wave walks the pixels of the staged tile (gradient rows + hard rows in LDS) and adds
+// the gradient row into the LDS column of the (usually single) active part; partial[b][slab][p][f]
 template <typename T>
 __global__ __launch_bounds__(256) void unpool_bwd_feat_kernel(const float* __restrict__ hard, const T* __restrict__ g,
                                                               float* __restrict__ gfeat_partial, long long hw, int P, int F,
-                                                              int ldo, int slab_px) {
-    extern __shared__ float acc[];  // [4][P][64]
+                                                              int ldo, int slab_px, int tpx) {
+    extern __shared__ __attribute__((aligned(16))) float ts[];  // acc [4][P][64], hard [tpx][PP], g [tpx][ldo] (T)
+    const int PP = tile_pitch(P);
+    float* acc = ts;
+    float* hs = acc + 4 * P * 64;
+    T* gs = (T*)(hs + (((size_t)tpx * PP + 3) & ~(size_t)3));
     const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
     const int f = threadIdx.x & 63, pl = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * P * 64; i += 256) acc[i] = 0.f;
-    __syncthreads();
     const long long p0 = (long long)slab * slab_px, p1 = min(hw, p0 + slab_px);
     float* my = acc + (long long)pl * P * 64;
-    for (long long px = p0 + pl; px < p1; px += 4) {
-        const long long bp = (long long)b * hw + px;
-        const float gf = (f < F) ? ld_as_float<T>(g + bp * ldo + f) : 0.f;
-        const float hv = (f < P) ? hard[bp * P + f] : 0.f;
-        unsigned long long m = __ballot(hv != 0.f);
-        while (m) {
-            const int pp = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            my[pp * 64 + f] += __shfl(hv, pp, 64) * gf;
+    for (long long t0 = p0; t0 < p1; t0 += tpx) {
+        const int cnt = (int)min((long long)tpx, p1 - t0);
+        const long long pix0 = (long long)b * hw + t0;
+        __syncthreads();
+        tile_load_f32(hard + pix0 * P, cnt, P, PP, hs);
+        {
+            const uint4* src = (const uint4*)(g + pix0 * ldo);
+            const int nv = (int)((size_t)cnt * ldo * sizeof(T) / 16);
+            for (int i = threadIdx.x; i < nv; i += 256) ((uint4*)gs)[i] = src[i];
+        }
+        __syncthreads();
+        for (int px = pl; px < cnt; px += 4) {
+            const float gf = (f < F) ? ld_as_float<T>(gs + (size_t)px * ldo + f) : 0.f;
+            const float hv = (f < P) ? hs[px * PP + f] : 0.f;
+            unsigned long long m = __ballot(hv != 0.f);
+            while (m) {
+                const int pp = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                my[pp * 64 + f] += __shfl(hv, pp, 64) * gf;
+            }
         }
     }
     __syncthreads();
@@ -278,6 +355,16 @@ __global__ void unpool_feat_reduce_kernel(const float* __restrict__ partial, int
 
 constexpr int UNPOOL_SLABS = 16;
 
+// kernels whose LDS images can exceed the 64 KB default at P = 64: raise the limit once per kernel
+template <typename K>
+bool allow_big_lds(K kernel, bool& done) {
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        done = true;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" int ups_part_softmax_fwd(const float* mean, const float* eps, float* l, float* m, float* hard, int64_t* argmax,
@@ -286,8 +373,10 @@ extern "C" int ups_part_softmax_fwd(const float* mean, const float* eps, float* 
     hipStream_t s = (hipStream_t)stream;
     int gp = 2;
     while (gp < P) gp *= 2;
-    const int grid = ups_cdiv(pixels * gp, 256);
-#define UPS_PS(G) hipLaunchKernelGGL(part_softmax_kernel<G>, dim3(grid), dim3(256), 0, s, mean, eps, l, m, hard, (long long*)argmax, (long long)pixels, P)
+    const int tpx = tile_pixels(P, 1, 24 * 1024);
+    const int grid = ups_cdiv(pixels, tpx);
+    const size_t shm = (size_t)tpx * (P | 1) * sizeof(float);
+#define UPS_PS(G) hipLaunchKernelGGL(part_softmax_kernel<G>, dim3(grid), dim3(256), shm, s, mean, eps, l, m, hard, (long long*)argmax, (long long)pixels, P, tpx)
     switch (gp) {
         case 2: UPS_PS(2); break;
         case 4: UPS_PS(4); break;
@@ -312,7 +401,9 @@ extern "C" int ups_spatial_moments(const float* x, int32_t n, int32_t h, int32_t
     const int rows = ups_cdiv(h, nslab);
     int gp = 2;
     while (gp < P) gp *= 2;
-#define UPS_MP(G) hipLaunchKernelGGL(moments_partial_kernel<G>, dim3(n, nslab), dim3(256), 0, s, x, h, w, P, gamma, rect_c, half_h, half_w, rows, partial)
+    const int tpx = tile_pixels(P, 1, 24 * 1024);
+    const size_t shm = ((size_t)tpx * (P | 1) + (size_t)(256 / gp) * gp * 7) * sizeof(float);
+#define UPS_MP(G) hipLaunchKernelGGL(moments_partial_kernel<G>, dim3(n, nslab), dim3(256), shm, s, x, h, w, P, gamma, rect_c, half_h, half_w, rows, tpx, partial)
     switch (gp) {
         case 2: UPS_MP(2); break;
         case 4: UPS_MP(4); break;
@@ -359,19 +450,26 @@ extern "C" int ups_mask_parts_fwd(const float* view, const float* hard, void* ou
 extern "C" int ups_mask_parts_bwd(const float* view, const void* g_out, float* g_hard, int32_t dtype, int32_t B, int64_t hw,
                                   int32_t P, void* stream) {
     UPS_CHECK_ARG(view && g_out && g_hard);
+    UPS_CHECK_ARG(P >= 1 && P <= 64);
     const int grid = ups_cdiv((long long)B * hw, 256);
-    if (dtype == UPS_F32) hipLaunchKernelGGL(mask_parts_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, view, (const float*)g_out, g_hard, B, (long long)hw, P);
-    else hipLaunchKernelGGL(mask_parts_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, view, (const bf16*)g_out, g_hard, B, (long long)hw, P);
+    const size_t shm = (size_t)256 * (P | 1) * sizeof(float);
+    static bool a0 = false, a1 = false;
+    if (!allow_big_lds(mask_parts_bwd_kernel<float>, a0) || !allow_big_lds(mask_parts_bwd_kernel<bf16>, a1)) return UPS_E_LAUNCH;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(mask_parts_bwd_kernel<float>, dim3(grid), dim3(256), shm, (hipStream_t)stream, view, (const float*)g_out, g_hard, B, (long long)hw, P);
+    else hipLaunchKernelGGL(mask_parts_bwd_kernel<bf16>, dim3(grid), dim3(256), shm, (hipStream_t)stream, view, (const bf16*)g_out, g_hard, B, (long long)hw, P);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }
 
 extern "C" int ups_unpool_fwd(const float* hard, const float* feat, void* out, int32_t dtype, int32_t B, int64_t hw, int32_t P,
                               int32_t F, int32_t ldo, void* stream) {
-    UPS_CHECK_ARG(hard && feat && out && F % 8 == 0 && ldo % 8 == 0 && ldo >= F + P);
-    const int grid = ups_cdiv((long long)B * hw * (ldo / 8), 256);
-    if (dtype == UPS_F32) hipLaunchKernelGGL(unpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, hard, feat, (float*)out, B, (long long)hw, P, F, ldo);
-    else hipLaunchKernelGGL(unpool_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, hard, feat, (bf16*)out, B, (long long)hw, P, F, ldo);
+    UPS_CHECK_ARG(hard && feat && out && F % 8 == 0 && ldo % 8 == 0 && ldo >= F + P && P >= 1 && P <= 64);
+    const dim3 grid(ups_cdiv(hw, 256), B);
+    const size_t shm = ((size_t)256 * (P | 1) + (size_t)P * F) * sizeof(float);
+    static bool a0 = false, a1 = false;
+    if (!allow_big_lds(unpool_fwd_kernel<float>, a0) || !allow_big_lds(unpool_fwd_kernel<bf16>, a1)) return UPS_E_LAUNCH;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(unpool_fwd_kernel<float>, grid, dim3(256), shm, (hipStream_t)stream, hard, feat, (float*)out, (long long)hw, P, F, ldo);
+    else hipLaunchKernelGGL(unpool_fwd_kernel<bf16>, grid, dim3(256), shm, (hipStream_t)stream, hard, feat, (bf16*)out, (long long)hw, P, F, ldo);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }
@@ -383,18 +481,25 @@ extern "C" int ups_unpool_bwd(const float* hard, const float* feat, const void* 
     hipStream_t s = (hipStream_t)stream;
     float* partial = g_feat + (long long)B * P * F;
     const int slab_px = ups_cdiv(hw, UNPOOL_SLABS);
-    const size_t shmem = (size_t)4 * P * 64 * sizeof(float);
-    if (dtype == UPS_F32) hipLaunchKernelGGL(unpool_bwd_feat_kernel<float>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, (const float*)g, partial, (long long)hw, P, F, ldo, slab_px);
-    else hipLaunchKernelGGL(unpool_bwd_feat_kernel<bf16>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, (const bf16*)g, partial, (long long)hw, P, F, ldo, slab_px);
+    const size_t esz = dtype == UPS_F32 ? 4 : 2;
+    const int tpx = 128;
+    const size_t shmem = ((size_t)4 * P * 64 + (((size_t)tpx * (P | 1) + 3) & ~(size_t)3)) * sizeof(float) + (size_t)tpx * ldo * esz;
+    static bool af0 = false, af1 = false;
+    if (!allow_big_lds(unpool_bwd_feat_kernel<float>, af0) || !allow_big_lds(unpool_bwd_feat_kernel<bf16>, af1)) return UPS_E_LAUNCH;
+    UPS_CHECK_ARG(shmem <= 160 * 1024);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(unpool_bwd_feat_kernel<float>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, (const float*)g, partial, (long long)hw, P, F, ldo, slab_px, tpx);
+    else hipLaunchKernelGGL(unpool_bwd_feat_kernel<bf16>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, (const bf16*)g, partial, (long long)hw, P, F, ldo, slab_px, tpx);
     UPS_LAUNCH_CHECK();
     hipLaunchKernelGGL(unpool_feat_reduce_kernel, dim3(ups_cdiv(B * P * F, 256)), dim3(256), 0, s, partial, B, UNPOOL_SLABS, P * F, g_feat);
     UPS_LAUNCH_CHECK();
     int gp = 2;
     while (gp < P) gp *= 2;
-    const int ppb = 1024;                                    // pixels per block
+    const int ppb = 128;                                     // pixels per block (one staged tile)
     const dim3 grid(ups_cdiv(hw, ppb), B);
-    const size_t sh2 = (size_t)P * (F + 1) * sizeof(float);
-#define UPS_UH(TT, G) hipLaunchKernelGGL((unpool_bwd_hard_kernel<TT, G>), grid, dim3(256), sh2, s, feat, (const TT*)g, g_hard, (long long)hw, P, F, ldo, ppb)
+    const size_t sh2 = ((size_t)ppb * (P | 1) + (((size_t)P * (F + 1) + 3) & ~(size_t)3)) * sizeof(float) + (size_t)ppb * ldo * esz;
+    UPS_CHECK_ARG(sh2 <= 160 * 1024);
+#define UPS_UH(TT, G) do { static bool ah = false; if (!allow_big_lds(unpool_bwd_hard_kernel<TT, G>, ah)) return UPS_E_LAUNCH; \
+        hipLaunchKernelGGL((unpool_bwd_hard_kernel<TT, G>), grid, dim3(256), sh2, s, feat, (const TT*)g, g_hard, (long long)hw, P, F, ldo, ppb); } while (0)
 #define UPS_UHD(G) do { if (dtype == UPS_F32) UPS_UH(float, G); else UPS_UH(bf16, G); } while (0)
     switch (gp) {
         case 2: UPS_UHD(2); break; case 4: UPS_UHD(4); break; case 8: UPS_UHD(8); break;
