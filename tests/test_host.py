@@ -289,3 +289,40 @@ def test_integration_stub_matches_the_header():
             for part in decl.split(","):
                 names.append(re.sub(r"\[\d+\]", "", part.strip().split()[-1].lstrip("*")))
     assert names == [f[0] for f in stub._fields_], (names, [f[0] for f in stub._fields_])
+
+
+def test_tf_checkpoint_bundle_reader_and_writer(tmp_path):
+    """tfckpt: the tensor-bundle (V2) format of TF-1.x checkpoints -- LevelDB-format index table with prefix-compressed keys
+    over several blocks, BundleEntryProto values, raw little-endian data shard -- round trip and byte-level structure."""
+    import struct
+    import numpy as np
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import tfckpt
+    rng = np.random.RandomState(0)
+    tensors = {"encoder_0/conv2d_{}/V".format(i): rng.randn(3, 3, 5 + i, 8).astype(np.float32) for i in range(40)}
+    tensors.update({"encoder_0/conv2d_{}/b".format(i): rng.randn(8).astype(np.float32) for i in range(40)})
+    tensors["encoder_0/conv2d_0/V/Adam"] = rng.randn(3, 3, 5, 8).astype(np.float32)
+    tensors["global_step"] = np.asarray(60000, dtype=np.int64)
+    tensors["some/int32"] = np.arange(6, dtype=np.int32).reshape(2, 3)
+    prefix = str(tmp_path / "model.ckpt-60000")
+    tfckpt.write_bundle(prefix, tensors, block_bytes=512)                 # many data blocks
+    assert tfckpt.is_bundle(prefix) and not tfckpt.is_bundle(str(tmp_path / "nope"))
+    raw = open(prefix + ".index", "rb").read()
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57          # table magic (leveldb kTableMagicNumber)
+    header, entries = tfckpt.read_index(prefix + ".index")
+    assert header["num_shards"] == 1 and set(entries) == set(tensors)
+    e = entries["encoder_0/conv2d_3/V"]
+    assert e["dtype"] == 1 and e["shape"] == [3, 3, 8, 8] and e["size"] == 3 * 3 * 8 * 8 * 4
+    back = tfckpt.read_bundle(prefix)
+    for k, v in tensors.items():
+        assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v), k
+    some = tfckpt.read_bundle(prefix, names=["global_step", "encoder_0/conv2d_7/b"])
+    assert set(some) == {"global_step", "encoder_0/conv2d_7/b"} and int(some["global_step"]) == 60000
+    # known-answer checks of the pieces TF verifies: CRC-32C (Castagnoli) and its LevelDB masking
+    assert tfckpt.crc32c(b"123456789") == 0xE3069283
+    assert tfckpt._mask(tfckpt.crc32c(b"123456789")) == ((0xE3069283 >> 15 | 0xE3069283 << 17) + 0xA282EAD8) & 0xFFFFFFFF
+    params, m, v, other = tfckpt.to_trainer_state(back)
+    assert "encoder_0/conv2d_0/V" in params and "encoder_0/conv2d_0/V" in m and "global_step" in other
+    with pytest.raises(ValueError):
+        (tmp_path / "stub.index").write_bytes(b"version https://git-lfs.github.com/spec/v1\n" * 3)
+        tfckpt.read_index(str(tmp_path / "stub.index"))

@@ -211,6 +211,9 @@ class Trainer(object):
         """model.py:592-602: lazy restore, missing variables ignored, step parsed from the file name."""
         if checkpoint_path is None:
             return
+        from . import tfckpt
+        if tfckpt.is_bundle(checkpoint_path):
+            return self._initialize_from_tf(checkpoint_path)
         ck = torch.load(checkpoint_path, map_location="cpu")
         keep = set(self.get_restore_variables())
         self.model.bank.load({n: t for n, t in ck["params"].items() if n in keep})
@@ -227,6 +230,47 @@ class Trainer(object):
         self.set_global_step(int(ck["global_step"]) if "global_step" in ck else (int(digits) if digits else 0))
         if self.logger:
             self.logger.info("Lazily restored from {}".format(checkpoint_path))
+
+    def _initialize_from_tf(self, prefix):
+        """A TensorFlow-1.x checkpoint of the reference (``model.ckpt-<step>.index`` + ``.data-*``): variables are matched by
+        name exactly as slim.assign_from_checkpoint(ignore_missing_vars=True) does (model.py:597-601), Adam slots
+        (``<var>/Adam``, ``<var>/Adam_1``) are taken when present, the step comes from the file name."""
+        from . import tfckpt
+        import numpy as np
+        bundle = tfckpt.read_bundle(prefix)
+        params, m, v, _other = tfckpt.to_trainer_state(bundle)
+        keep = set(self.get_restore_variables())
+        bank = self.model.bank
+        loaded = {n: torch.from_numpy(np.ascontiguousarray(a)) for n, a in params.items()
+                  if n in keep and n in bank.params and tuple(a.shape) == tuple(bank.params[n].shape)}
+        bank.load(loaded)
+        with torch.no_grad():
+            for n in loaded:
+                if n in m and n in v:
+                    bank.adam_m[n].copy_(torch.from_numpy(np.ascontiguousarray(m[n])))
+                    bank.adam_v[n].copy_(torch.from_numpy(np.ascontiguousarray(v[n])))
+        digits = "".join(ch for ch in os.path.basename(prefix).split("-")[-1] if ch.isdigit())
+        self.set_global_step(int(digits) if digits else 0)
+        for key, grp in bank.groups.items():
+            if any(n in m for n in grp["names"]):
+                grp["t"] = self.global_step        # one Adam step per global step and key (beta powers are not stored per name)
+        if self.logger:
+            self.logger.info("Lazily restored {} of {} variables from the TensorFlow checkpoint {}".format(
+                len(loaded), len(bank.params), prefix))
+        self.restored_from_tf = sorted(loaded)
+
+    def export_tf_checkpoint(self, prefix):
+        """Write the trainable variables (+ Adam slots) as a TensorFlow tensor bundle the reference's graph can restore."""
+        from . import tfckpt
+        import numpy as np
+        bank = self.model.bank
+        tensors = {}
+        for n, p in bank.params.items():
+            tensors[n] = p.detach().cpu().numpy()
+            tensors[n + "/Adam"] = bank.adam_m[n].detach().cpu().numpy()
+            tensors[n + "/Adam_1"] = bank.adam_v[n].detach().cpu().numpy()
+        tensors["global_step"] = np.asarray(self.global_step, dtype=np.int64)
+        tfckpt.write_bundle(prefix, tensors)
 
     def save_checkpoint(self, path):
         bank = self.model.bank

@@ -56,6 +56,7 @@ class ParamBank(object):
         self.device = device
         self.groups = OrderedDict()
         self.params, self.grads = OrderedDict(), OrderedDict()
+        self.adam_m, self.adam_v = OrderedDict(), OrderedDict()      # per-variable views of the flat Adam slots
         for key in keys:
             names = [n for n in specs if key in n]      # edflow: var_list = [v for v in variables if key in v.name]
             total = sum(int(torch.Size(specs[n][0]).numel()) for n in names)
@@ -66,6 +67,8 @@ class ParamBank(object):
                 cnt = int(torch.Size(shape).numel())
                 self.params[n] = flat["p"][off:off + cnt].view(shape).requires_grad_(True)
                 self.grads[n] = flat["g"][off:off + cnt].view(shape)
+                self.adam_m[n] = flat["m"][off:off + cnt].view(shape)
+                self.adam_v[n] = flat["v"][off:off + cnt].view(shape)
                 off += cnt
             self.groups[key] = {"names": names, "flat": flat, "t": 0}
         self.initialize(seed)
