@@ -235,14 +235,12 @@ def test_tensorflow_checkpoint_import_export(dev, tmp_path):
     assert torch.equal(model.bank.adam_v["decoder_delta/conv2d_2/V"], model2.bank.adam_v["decoder_delta/conv2d_2/V"])
     assert model2.bank.groups["encoder_0"]["t"] == 3 and model2.bank.groups["mi_estimator"]["t"] == 0
     # the restored trainer continues exactly like the original (same Adam state, same step)
-    l1 = tr.train_step(views, noise)
+    tr.train_step(views, noise)
     cfg3 = copy.deepcopy(cfg)
     model3 = TrainModel(cfg3, device=dev, seed=9)
     tr3 = Trainer(cfg3, None, model3)
     tr3.initialize(prefix)
-    for k in tr.state:
-        tr3.state[k].copy_(tr.state[k]) if False else None          # (Lagrangian scalars are unnamed tf.Variables: not in the bundle)
-    l3 = tr3.train_step(views, noise)
+    tr3.train_step(views, noise)          # (the Lagrangian scalars are unnamed tf.Variables: not in the bundle, tr3 starts them afresh)
     for n in model.variables:
         if "mi" not in n and "encoder_0" not in n:                   # keys whose losses do not involve the Lagrangian state
             assert torch.allclose(model.variables[n], model3.variables[n], atol=1e-7), n
