@@ -75,6 +75,16 @@ typedef struct {
     float*       workspace;   /* optional fp32 scratch for the deterministic split-K path of small-M problems (few tiles,
                                * long K loops); NULL or too small = no split */
     size_t       workspace_bytes;
+    /* Part-masked input (mask_parts + apply_partwise, M:176-187, N:81-113) fused into the load, so that the
+     * [P*B,H,W,C] part tensor never exists (3x3 / stride-1 patch kernels, bf16, 16-aligned images; else UPS_E_UNSUPPORTED):
+     * `n` = P*mask_batch logical images in part-major order (image p*mask_batch + b); `in` is the UNMASKED view tensor
+     * [mask_batch, hi, wi, ldi]; pixel (b,y,x) of part image p reads as in[b,y,x,:] if bit p of mask_bits[b,y,x] is set, else 0. */
+    const uint32_t* mask_bits;   /* [mask_batch, hi, wi] hard-mask bit sets (ups_part_softmax_fwd) or NULL */
+    int32_t      mask_batch;
+    /* Input gradient of such a convolution reduced straight to the hard mask (the dgrad call of the same layer): instead
+     * of out[p*B+b][y][x][c] the kernel writes mask_grad[b][y][x][p] = sum_c out * mask_view[b][y][x][c] (M:185 backward). */
+    float*       mask_grad;      /* [mask_batch, out_h, out_w, n / mask_batch] fp32 or NULL (`out` may then be NULL) */
+    const float* mask_view;      /* [mask_batch, out_h, out_w, co] fp32 view tensor, required with mask_grad */
 } ups_conv_desc;
 
 int ups_conv_igemm(const ups_conv_desc* d, void* stream);
@@ -97,6 +107,8 @@ typedef struct {
     float* grad;                      /* [kh*kw][cin_v][co] fp32 */
     float* grad_bias;                 /* [co] fp32 or NULL: sum_pix dout, reduced from the same dout tiles */
     float* workspace;                 /* bytes from ups_conv_wgrad_plan */
+    const uint32_t* mask_bits;        /* part-masked input, same meaning as in the conv descriptor; bf16 3x3 / stride-1 patch kernel only; or NULL */
+    int32_t mask_batch;
 } ups_wgrad_desc;
 
 int ups_conv_wgrad_plan(const ups_wgrad_desc* d, int32_t* splitk, size_t* workspace_bytes);
@@ -177,9 +189,10 @@ int ups_sum_scale(const float* partial, int32_t n, float scale, float* out, int3
 
 /* ---------------------------------------------------------------- part path
  * l = mean + eps (N:1427-1433); m = softmax_P(l) (N:58-62); hard = (m == max_P m) (N:134-136);
- * argmax = first maximal index (M:447,470).  eps, hard, argmax may be NULL.  All fp32, [pixels][P]. */
+ * argmax = first maximal index (M:447,470); hard_bits[pixel] = bit set of the hard mask (bit p = hard[pixel][p], P <= 32:
+ * the compact form the part-masked convolution reads).  eps, hard, argmax, hard_bits may be NULL.  All fp32, [pixels][P]. */
 int ups_part_softmax_fwd(const float* mean, const float* eps, float* l, float* m, float* hard, int64_t* argmax,
-                         int64_t pixels, int32_t P, void* stream);
+                         uint32_t* hard_bits, int64_t pixels, int32_t P, void* stream);
 /* spatial soft-max moments (N:65-71, N:1541-1587) of gamma*x per (n,p) over H*W, optionally masked by
  * (1 - rect) with integer rectangle centres `rect_c` [n*P][2] (y,x) and half sizes:
  * stats[n][p] = {max, Z, sum e*k, sum e*k*gy, sum e*k*gx, sum e*k*(gy^2+gx^2), sum e*k*gy^2, 0},  e = exp(gamma*x - max) */

@@ -438,3 +438,47 @@ def test_integration_stub_runs(dev):
     xo = x.double()
     yo = xo + R.conv2d_same(torch.nn.functional.leaky_relu(xo, 0.2), V.bfloat16().double(), b.double(), 1)
     assert_close(out.float(), yo.float(), BF16_TOL, "INTEGRATION.md stub")
+
+
+@pytest.mark.parametrize("P,B,S,coords", [(10, 3, 32, False), (25, 2, 48, True), (3, 5, 16, False)])
+def test_part_masked_convolution_matches_the_materialised_path(P, B, S, coords, dev):
+    """mask_parts fused into encoder_1's first convolution (model.py:176-187, nn.py:81-113): forward, weight gradient and the
+    gradient w.r.t. the hard mask (reduced in the dgrad epilogue) must equal the path that builds the [P*B,S,S,8] part tensor
+    (bit for bit: the same bf16 operands meet the same kernels), and the oracle's fp64 result within bf16 tolerance."""
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(40 + P)
+    view = (torch.rand(B, S, S, 3, generator=g) * 2 - 1).to(dev)
+    mean = torch.randn(B, S, S, P, generator=g).to(dev)
+    mean[0, :4, :4] = 0.0                                            # ties: several parts own a pixel
+    _, m, hard, _, bits = ops.part_softmax(mean, None, want_bits=True)
+    assert torch.equal(((bits.unsqueeze(-1) >> torch.arange(P, device=dev)) & 1).float(), hard)
+    cin_v = 3 + (2 if coords else 0)
+    V = torch.randn(3, 3, cin_v, 32, generator=g) / math.sqrt(9 * cin_v)
+    b = torch.randn(32, generator=g) * 0.1
+    T = torch.bfloat16
+    view_act = torch.zeros(B, S, S, 8, dtype=T, device=dev)
+    view_act[..., :3] = view.to(T)
+    res = {}
+    for mode in ("fused", "materialised"):
+        lay = _layer(ops, lib, V, b, 3, 1, coords, None, dev)
+        h = hard.clone().requires_grad_(True)
+        if mode == "fused":
+            y = ops.conv(view_act, lay, mask=(h, bits, view))
+        else:
+            parts = ops.MaskPartsFn.apply(view, h, T)
+            y = ops.conv(parts, lay)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).to(dev, T)
+        gh, gV, gb = torch.autograd.grad([y], [h, lay.V, lay.b], grad_outputs=[gy])
+        res[mode] = (y, gh, gV, gb)
+    for a, c, name in zip(res["fused"], res["materialised"], ("forward", "d hard", "dV", "db")):
+        if name == "d hard":      # three-term fp32 dot product: summation order differs by an ulp
+            assert_close(a, c, 1e-5, "d hard: fused vs materialised")
+        else:
+            assert torch.equal(a, c), "{}: fused and materialised paths differ by {}".format(name, float((a.float() - c.float()).abs().max()))
+    # oracle: part images in fp64 from the same bf16-rounded view / weights
+    vq = view.to(T).double().cpu()
+    xo = (vq.unsqueeze(3) * hard.double().cpu().unsqueeze(-1)).permute(3, 0, 1, 2, 4).reshape(P * B, S, S, 3)
+    Vo = V.double().clone()
+    Vo[:, :, :3] = V[:, :, :3].to(T).double()
+    yo = _oracle_conv(R, xo, Vo, b.double(), 1, coords, None, False, None)
+    assert_close(res["fused"][0][..., :32].float(), yo.float(), BF16_TOL, "part-masked conv vs oracle")

@@ -34,6 +34,10 @@ struct PatchK {
     unsigned long long tap_off, tap_wi;   // 4 bits per tap: (dy+1)<<2|(dx+1) ; weight slice
     const void* in; const void* wgt; void* out;
     const float* bias; const float* coord_tab; const void* res; const void* dact;
+    // part-masked input / mask gradient (ups_conv_desc.mask_*): mask_B > 0 switches the block order to (image b, tile, part)
+    // with the part fastest, so that the P blocks that read one view patch / write one g_hard line run back to back on one XCD
+    const unsigned* mask; float* mask_grad; const float* mask_view;
+    int mask_B, mask_P, mask_shift;
 };
 
 __device__ inline int p_dy(unsigned long long off, int t) { return (int)((off >> (4 * t + 2)) & 3) - 1; }
@@ -147,12 +151,17 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     if ((nblocks & 7) == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
     const int nt = bid % ntn;
     int t = bid / ntn;
+    int part = 0;
+    if (p.mask_B > 0) { part = t % p.mask_P; t /= p.mask_P; }
     const int tx0 = (t % tiles_x) * TS; t /= tiles_x;
     const int ty0 = (t % tiles_y) * TS;
-    const int img = (t / tiles_y) * (G * G);     // first image of the tile
+    const int img = (t / tiles_y) * (G * G);     // first image of the tile (part mode: the view image b)
+    const int img_pm = p.mask_B > 0 ? part * p.mask_B + img : img;      // part-major image p * B + b
+    const int img_in = p.mask ? img : img_pm;    // masked forward reads the view; the mask-gradient pass reads d(out) of part image
     const int wm = wid / WN, wn = wid % WN;
 
-    const T* __restrict__ in = (const T*)p.in + (long long)img * p.h * p.w * p.ldi;
+    const T* __restrict__ in = (const T*)p.in + (long long)img_in * p.h * p.w * p.ldi;
+    const unsigned* __restrict__ mbits = p.mask ? p.mask + (long long)img * p.h * p.w : nullptr;
     const T* __restrict__ w = (const T*)p.wgt;
 
     // ---- patch staging: items tid, tid+512, tid+1024 of the 324x4 16-byte chunks
@@ -204,6 +213,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             int o = off;
             asm volatile("" : "+v"(o));     // keep the 32-bit offset: scalar base (image + chunk) + vector offset addressing
             v = *(const uint4*)((const unsigned char*)(in + koff) + (unsigned)o);
+            // part-masked input (model.py:185): the pixel belongs to this block's part image only where its hard-mask bit is set
+            if (mbits && !((mbits[(unsigned)off >> p.mask_shift] >> part) & 1u)) v = zero4;
         }
 #endif
         return v;
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     float* __restrict__ outF = (float*)p.out;
     const T* __restrict__ res = (const T*)p.res;
     const T* __restrict__ dact = (const T*)p.dact;
-    const long long img_pix = (long long)img * p.h * p.w;
+    const long long img_pix = (long long)img_pm * p.h * p.w;
     // tile pixel index (ty * 16 + tx) -> global pixel index / coordinates inside its image
     auto gpix = [&](int q) -> long long {
         const int ty = q >> 4, tx = q & 15;
@@ -538,6 +549,19 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 }
             }
             __syncthreads();
+            if (p.mask_grad) {
+                // input gradient of the part-masked convolution, reduced to the hard mask: g_hard[b][y][x][part] =
+                // sum_c gx[c] * view[b][y][x][c] with gx rounded to the activation dtype first (as the tensor it replaces was)
+                if (SUB == TS && tid < 256) {
+                    const long long pixb = (long long)img * p.h * p.w + (long long)(ty0 + (tid >> 4)) * p.w + tx0 + (tid & 15);
+                    const bf16* gv = (const bf16*)(R0 + tid * ERS);
+                    const float* vv = p.mask_view + pixb * p.co;
+                    float sacc = 0.f;
+                    for (int c = 0; c < p.co; ++c) sacc += (float)gv[c] * vv[c];
+                    p.mask_grad[pixb * p.mask_P + part] = sacc;
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
@@ -669,6 +693,21 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
         for (int t = 0; t < 9; ++t) if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1) return 1;
     }
     PatchK k;
+    k.mask = d->mask_bits; k.mask_grad = d->mask_grad; k.mask_view = d->mask_view;
+    k.mask_B = 0; k.mask_P = 1; k.mask_shift = 0;
+    if (d->mask_bits || d->mask_grad) {
+        // part mode: bf16, one image per tile, staged epilogue; the masked load recovers the pixel index from the byte offset
+        if (d->dtype != UPS_BF16 || small || d->mask_batch <= 0 || d->n % d->mask_batch) return 1;
+        if (d->mask_bits && d->mask_grad) return 1;
+        k.mask_B = d->mask_batch; k.mask_P = d->n / d->mask_batch;
+        if (k.mask_P > 32) return 1;
+        if (d->mask_bits) {
+            const int row_bytes = d->ldi * 2;
+            if (row_bytes & (row_bytes - 1)) return 1;
+            while ((1 << k.mask_shift) < row_bytes) ++k.mask_shift;
+        }
+        if (d->mask_grad && (!d->mask_view || d->out_f32 || (d->ldo & 7) || (d->co_fill & 7) || d->co_fill > 32 || d->res || d->dact)) return 1;
+    }
     k.n = d->n; k.h = d->hi; k.w = d->wi; k.ci = d->ci; k.ldi = d->ldi; k.co = d->co; k.co_fill = d->co_fill;
     k.ldo = d->ldo; k.ldr = d->ldr; k.ldd = d->ldd; k.act_in = d->act_in; k.out_f32 = d->out_f32;
     k.dact_kind = d->dact_kind; k.has_ctab = d->coord_tab != nullptr; k.act_slope = d->act_slope;

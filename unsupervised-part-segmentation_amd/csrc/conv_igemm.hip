@@ -441,7 +441,7 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_p
 extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d != nullptr);
     UPS_CHECK_ARG(d->dtype == UPS_F32 || d->dtype == UPS_BF16);
-    UPS_CHECK_ARG(d->in && d->w && d->out);
+    UPS_CHECK_ARG(d->in && d->w && (d->out || d->mask_grad));
     UPS_CHECK_ARG(d->ci > 0 && d->ci % 8 == 0 && d->ldi % 8 == 0 && d->ci <= d->ldi);
     UPS_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= 9);
     UPS_CHECK_ARG(d->co >= 1 && d->co_fill >= d->co && d->co_fill <= d->ldo);
@@ -455,6 +455,10 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
         const int pr = ups_conv3x3_patch_try(d, (hipStream_t)stream);
         if (pr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
         if (pr < 0) { ups_set_error("ups_conv_igemm: patch kernel launch setup failed"); return pr; }
+    }
+    if (d->mask_bits || d->mask_grad) {
+        ups_set_error("ups_conv_igemm: the part-masked forms need the bf16 3x3 / stride-1 patch kernel (16-aligned images, P <= 32)");
+        return UPS_E_UNSUPPORTED;
     }
     int rc = (d->dtype == UPS_F32) ? launch<float>(*d, (hipStream_t)stream) : launch<bf16>(*d, (hipStream_t)stream);
     if (rc != UPS_OK) { ups_set_error("ups_conv_igemm: bad problem size"); return rc; }

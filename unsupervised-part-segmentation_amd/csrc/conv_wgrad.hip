@@ -353,6 +353,13 @@ extern "C" int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int nslabs = d->splitk;
     int sk3 = 0, slabs3 = 0;
+    if (d->mask_bits) {
+        UPS_CHECK_ARG(d->mask_batch > 0 && d->n % d->mask_batch == 0 && d->n / d->mask_batch <= 32);
+        if (ups_wgrad3x3_plan(d, &sk3, &slabs3) != 0) {
+            ups_set_error("ups_conv_wgrad: the part-masked form needs the bf16 3x3 / stride-1 patch kernel (16-aligned images)");
+            return UPS_E_UNSUPPORTED;
+        }
+    }
     if (ups_wgrad3x3_plan(d, &sk3, &slabs3) == 0) {
         UPS_CHECK_ARG(d->splitk == sk3);
         if (ups_wgrad3x3_run(d, s) != UPS_OK) { ups_set_error("ups_conv_wgrad: patch kernel launch setup failed"); return UPS_E_LAUNCH; }

@@ -24,6 +24,7 @@ struct Wg3K {
     float act_slope;
     unsigned long long tap_off, tap_wi;
     const void* in; const void* dout; float* ws;
+    const unsigned* mask; int mask_B;     // part-masked input (ups_wgrad_desc.mask_*): in = view [mask_B,h,w,ldi], image = p*mask_B + b
 };
 
 __device__ inline int g_dy(unsigned long long off, int t) { return (int)((off >> (4 * t + 2)) & 3) - 1; }
@@ -89,8 +90,15 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
             const int pix = item / CPX, cc = item - pix * CPX;
             const int py = pix / PWID, px = pix - py * PWID;
             const int y = y0 - 1 + py, x = x0 - 1 + px, ch = ci0 + cc * 8;
-            if ((unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w && ch < p.ci)
-                v = *(const uint4*)(in + (((long long)img * p.h + y) * p.w + x) * p.ldi + ch);
+            if ((unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w && ch < p.ci) {
+                if (p.mask) {      // part image p * B + b = view image b where bit p of the hard-mask bit set is on (model.py:185)
+                    const int b = img % p.mask_B, part = img / p.mask_B;
+                    const long long q = ((long long)b * p.h + y) * p.w + x;
+                    if ((p.mask[q] >> part) & 1u) v = *(const uint4*)(in + q * p.ldi + ch);
+                } else {
+                    v = *(const uint4*)(in + (((long long)img * p.h + y) * p.w + x) * p.ldi + ch);
+                }
+            }
         }
         return v;
     };
@@ -282,6 +290,7 @@ int ups_wgrad3x3_run(const ups_wgrad_desc* d, hipStream_t s) {
     k.units_total = d->n * k.tiles_x * k.tiles_y * 2;
     k.units_per = ups_cdiv(k.units_total, d->splitk);
     k.in = d->in; k.dout = d->dout; k.ws = d->workspace;
+    k.mask = d->mask_bits; k.mask_B = d->mask_batch;
     k.tap_off = 0; k.tap_wi = 0;
     for (int t = 0; t < 9; ++t) {
         k.tap_off |= (unsigned long long)(((d->tap_dy[t] + 1) << 2) | (d->tap_dx[t] + 1)) << (4 * t);

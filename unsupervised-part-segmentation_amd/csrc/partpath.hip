@@ -18,7 +18,8 @@ struct TileSign { __device__ float operator()(float v) const { return (__float_a
 template <int GP>
 __global__ __launch_bounds__(256) void part_softmax_kernel(const float* __restrict__ mean, const float* __restrict__ eps,
                                                            float* __restrict__ l, float* __restrict__ m, float* __restrict__ hard,
-                                                           long long* __restrict__ amax, long long pixels, int P, int tpx) {
+                                                           long long* __restrict__ amax, unsigned* __restrict__ bits,
+                                                           long long pixels, int P, int tpx) {
     extern __shared__ __attribute__((aligned(16))) float ts[];          // [tpx][PP]
     constexpr int PL = 256 / GP;
     const int PP = tile_pitch(P);
@@ -45,6 +46,12 @@ __global__ __launch_bounds__(256) void part_softmax_kernel(const float* __restri
         int first = is_max ? c : GP;
 #pragma unroll
         for (int o = GP / 2; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, GP));
+        if (bits) {
+            unsigned bm = (is_max && c < 32) ? (1u << c) : 0u;
+#pragma unroll
+            for (int o = GP / 2; o > 0; o >>= 1) bm |= (unsigned)__shfl_xor((int)bm, o, GP);
+            if (ok && c == 0) bits[pix0 + px] = bm;
+        }
         if (ok) {
             ts[px * PP + c] = is_max ? -pm : pm;
             if (amax && c == 0) amax[pix0 + px] = first;
@@ -368,15 +375,16 @@ bool allow_big_lds(K kernel, bool& done) {
 }  // namespace
 
 extern "C" int ups_part_softmax_fwd(const float* mean, const float* eps, float* l, float* m, float* hard, int64_t* argmax,
-                                    int64_t pixels, int32_t P, void* stream) {
+                                    uint32_t* hard_bits, int64_t pixels, int32_t P, void* stream) {
     UPS_CHECK_ARG(mean && m && pixels > 0 && P >= 1 && P <= 64);
+    UPS_CHECK_ARG(!hard_bits || P <= 32);
     hipStream_t s = (hipStream_t)stream;
     int gp = 2;
     while (gp < P) gp *= 2;
     const int tpx = tile_pixels(P, 1, 24 * 1024);
     const int grid = ups_cdiv(pixels, tpx);
     const size_t shm = (size_t)tpx * (P | 1) * sizeof(float);
-#define UPS_PS(G) hipLaunchKernelGGL(part_softmax_kernel<G>, dim3(grid), dim3(256), shm, s, mean, eps, l, m, hard, (long long*)argmax, (long long)pixels, P, tpx)
+#define UPS_PS(G) hipLaunchKernelGGL(part_softmax_kernel<G>, dim3(grid), dim3(256), shm, s, mean, eps, l, m, hard, (long long*)argmax, (unsigned*)hard_bits, (long long)pixels, P, tpx)
     switch (gp) {
         case 2: UPS_PS(2); break;
         case 4: UPS_PS(4); break;

@@ -32,7 +32,8 @@ class ConvDesc(C.Structure):
                 ("ldr", C.c_int32), ("ldd", C.c_int32),
                 ("in_", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p), ("bias", C.c_void_p),
                 ("coord_tab", C.c_void_p), ("res", C.c_void_p), ("dact", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("mask_bits", C.c_void_p), ("mask_batch", C.c_int32), ("mask_grad", C.c_void_p), ("mask_view", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -42,7 +43,7 @@ class WgradDesc(C.Structure):
                 ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9), ("tap_w", C.c_int32 * 9),
                 ("act_in", C.c_int32), ("act_slope", C.c_float), ("splitk", C.c_int32),
                 ("in_", C.c_void_p), ("dout", C.c_void_p), ("grad", C.c_void_p), ("grad_bias", C.c_void_p),
-                ("workspace", C.c_void_p)]
+                ("workspace", C.c_void_p), ("mask_bits", C.c_void_p), ("mask_batch", C.c_int32)]
 
 
 class PriorDesc(C.Structure):
@@ -92,7 +93,7 @@ _SIGS = {
     "ups_l1_fwd": ([_P, _P, _I, _L, _I, _I, _I, _P, _I, _P], C.c_int),
     "ups_l1_bwd": ([_P, _P, _P, _I, _L, _I, _I, _I, _P, _F, _P], C.c_int),
     "ups_sum_scale": ([_P, _I, _F, _P, _I, _P], C.c_int),
-    "ups_part_softmax_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _P], C.c_int),
+    "ups_part_softmax_fwd": ([_P, _P, _P, _P, _P, _P, _P, _L, _I, _P], C.c_int),
     "ups_spatial_moments": ([_P, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P], C.c_int),
     "ups_spatial_moments_floats": ([_I, _I], _Z),
     "ups_moments_to_px": ([_P, _I, _I, _I, _P, _P], C.c_int),

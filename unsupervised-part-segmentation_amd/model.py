@@ -82,6 +82,17 @@ class TrainModel(object):
         L.call("ups_pad_convert", L.ptr(x_f32), x_f32.shape[-1], L.ptr(out), L.dt(out), out.shape[-1], rows, L.stream())
         return out
 
+    def part_images(self, view_act, view_f32, hard, hard_bits):
+        """The P*B part images view1[b] * hard1[b,:,:,p] in part-major order (mask_parts + apply_partwise, model.py:176-187,
+        nn.py:97-103) as an activation handle for encoder_1.  Where the fused form applies (`fuse_mask_parts`, default on; bf16,
+        16-aligned images, P <= 32) the [P*B,S,S,8] tensor is never built: the first convolution masks the view while it loads
+        and its input gradient is reduced to d/d hard in the epilogue."""
+        B, S, _, P = hard.shape
+        if (hard_bits is not None and self.config.get("fuse_mask_parts", True)
+                and ops.masked_conv_eligible(self.act_dtype, S, P)):
+            return Act(view_act.contiguous(), P * B, S, S, 3, mask=(hard, hard_bits, view_f32))
+        return Act(ops.MaskPartsFn.apply(view_f32, hard, self.act_dtype), P * B, S, S, 3)
+
     @torch.no_grad()
     def forward(self, batch, noise=None):
         """Inference graph (test_mode semantics when ``noise`` is None): fills ``outputs``."""
@@ -100,10 +111,10 @@ class TrainModel(object):
             z = torch.cat([s0[0], s1[0]], 0)
         lm = self.nets.dv(Act(self.to_act(z.view(2 * B, 1, 1, Z)), 2 * B, 1, 1, Z)).t
         eps = None if noise is None else torch.cat([noise["eps_l0"], noise["eps_l1"]], 0).to(self.device)
-        _, m, hard, _ = ops.part_softmax(lm, eps)
+        _, m, hard, _, bits = ops.part_softmax(lm, eps, want_bits=P <= 32)
         _, soft, _, amax = ops.part_softmax(lm[:B].contiguous(), None, want_hard=False, want_argmax=True)
-        parts = ops.MaskPartsFn.apply(v1.contiguous(), hard[B:].contiguous(), self.act_dtype)
-        yp = self.nets.e_alpha(Act(parts, P * B, S, S, 3)).t
+        yp = self.nets.e_alpha(self.part_images(img01[B:], v1.contiguous(), hard[B:].contiguous(),
+                                                None if bits is None else bits[B:].contiguous())).t
         feat = yp.float().view(P, B, A).permute(1, 0, 2).contiguous()
         inj = ops.UnpoolFn.apply(hard[:B].contiguous(), feat, self.act_dtype)
         gen = self.nets.dd(Act(inj, B, S, S, A + P)).t
@@ -252,7 +263,7 @@ class Trainer(object):
         digits = "".join(ch for ch in os.path.basename(prefix).split("-")[-1] if ch.isdigit())
         self.set_global_step(int(digits) if digits else 0)
         for key, grp in bank.groups.items():
-            if any(n in m for n in grp["names"]):
+            if any(n in loaded and n in m for n in grp["names"]):
                 grp["t"] = self.global_step        # one Adam step per global step and key (beta powers are not stored per name)
         if self.logger:
             self.logger.info("Lazily restored {} of {} variables from the TensorFlow checkpoint {}".format(
@@ -512,15 +523,15 @@ class Trainer(object):
         # model.py:420-421 / nn.py:1427-1433: l = mean + eps unless `stochastic_l: False` (default: not test_mode)
         stochastic_l = cfg.get("stochastic_l", not cfg.get("test_mode", False))
         eps_l = torch.cat([noise["eps_l0"], noise["eps_l1"]], 0) if stochastic_l else None
-        l, m, hard, _ = ops.part_softmax(lm, eps_l)
+        l, m, hard, _, hbits = ops.part_softmax(lm, eps_l, want_bits=P <= 32)
         # [2B,P,2] rectangle centres (stop-gradient); SB_model48c has no rectangles
         px = None if df else ops.moments_to_px(ops.spatial_moments(hard, gamma), S, cfg.get("rect_order", "xy"))
         hard0 = hard[:B].detach().requires_grad_(True)
         hard1 = hard[B:].detach().requires_grad_(True)
 
         # ================= C: part-wise appearance -> unpool -> image decoder -> perceptual loss (model.py:478-485, 607-619)
-        parts = ops.MaskPartsFn.apply(v1, hard1, T)                        # [P*B,S,S,8]
-        yp = nets.e_alpha(Act(parts, P * B, S, S, 3)).t                    # [P*B,1,1,A]
+        parts = model.part_images(img01[B:], v1, hard1, None if hbits is None else hbits[B:].contiguous())
+        yp = nets.e_alpha(parts).t                                         # [P*B,1,1,A]
         feat = yp.float().view(P, B, A).permute(1, 0, 2).contiguous()      # [B,P,A]
         inj = ops.UnpoolFn.apply(hard0, feat, T)
         gen = nets.dd(Act(inj, B, S, S, A + P)).t                          # [B,S,S,8]

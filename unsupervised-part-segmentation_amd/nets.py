@@ -93,10 +93,12 @@ class ParamBank(object):
 
 class Act(object):
     """Activation handle: tensor (None in the shape-only dry run) + logical channel count."""
-    __slots__ = ("t", "n", "h", "w", "c")
+    __slots__ = ("t", "n", "h", "w", "c", "mask")
 
-    def __init__(self, t, n, h, w, c):
-        self.t, self.n, self.h, self.w, self.c = t, n, h, w, c
+    def __init__(self, t, n, h, w, c, mask=None):
+        # mask = (hard, hard_bits, view_f32): `t` is the unmasked view [B,h,w,8] and the handle stands for the n = P*B
+        # part images view[b] * hard[b,:,:,p] that the first convolution forms while it loads (ops.conv)
+        self.t, self.n, self.h, self.w, self.c, self.mask = t, n, h, w, c, mask
 
 
 class Scope(object):
@@ -131,7 +133,7 @@ class Scope(object):
         ho, wo = ops.same_geometry(x.h, k, stride)[0], ops.same_geometry(x.w, k, stride)[0]
         if lay is None:
             return Act(None, x.n, ho, wo, cout)
-        t = ops.conv(x.t, lay, res=None if res is None else res.t, res_self=res_self, out_f32=out_f32)
+        t = ops.conv(x.t, lay, res=None if res is None else res.t, res_self=res_self, out_f32=out_f32, mask=x.mask)
         return Act(t, x.n, ho, wo, cout)
 
     def nin(self, x, cout, **kw):

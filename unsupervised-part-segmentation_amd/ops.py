@@ -233,9 +233,13 @@ def _attach_ws(d, device):
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
 
 
-def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None):
-    """out = conv(act(x) (+coords), V) + b (+ res);  x [n,hi,wi,ldi]."""
+def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask=None):
+    """out = conv(act(x) (+coords), V) + b (+ res);  x [n,hi,wi,ldi].
+    mask = (hard_bits [B,hi,wi] int32, P): x is the UNMASKED view [B,hi,wi,ldi] and the convolution runs on the P*B part images
+    x[b] * hard[b,:,:,p] (part-major) without materialising them (model.py:176-187, nn.py:81-113)."""
     n, hi, wi, ldi = x.shape
+    if mask is not None:
+        n = n * mask[1]
     dcode = L.dt(x)
     ho, wo = layer.out_hw(hi, wi)
     ent = layer.prepared(dcode, hi, wi, need_dgrad=False)
@@ -259,6 +263,8 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None):
     d.coord_tab = ent["ctab"].data_ptr() if layer.coords else None
     d.res = res.data_ptr() if res is not None else None
     d.dact = None
+    if mask is not None:
+        d.mask_bits, d.mask_batch = mask[0].data_ptr(), x.shape[0]
     _attach_ws(d, x.device)
     assert round8(layer.ci_log) <= ldi, (layer.name, layer.ci_log, ldi)
     if KernelTimer.layer == layer.name and KernelTimer.enabled:
@@ -273,13 +279,23 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None):
     return out
 
 
-def conv_dgrad(g, x, layer, res=None):
-    """gx = act'(x) * conv^T(g) (+ res);  g [n,ho,wo,ldg] in the activation dtype, x the forward input."""
+def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
+    """gx = act'(x) * conv^T(g) (+ res);  g [n,ho,wo,ldg] in the activation dtype, x the forward input.
+    mask_view (fp32 [B,hi,wi,3], with n_parts): the forward was the part-masked convolution; returns d loss / d hard
+    [B,hi,wi,P] = sum_c gx[p*B+b,...,c] * view[b,...,c] straight from the kernel's epilogue (gx is never written)."""
     n, hi, wi, ldi = x.shape
     dcode = L.dt(x)
     ho, wo = layer.out_hw(hi, wi)
     ent = layer.prepared(dcode, hi, wi, need_dgrad=True)
-    gx = torch.empty_like(x)
+    g_hard = None
+    if mask_view is not None:
+        assert layer.stride == 1 and layer.act_in == L.ACT_NONE and res is None
+        g_hard = torch.empty((n, hi, wi, n_parts), dtype=torch.float32, device=x.device)
+        gx = None
+        n_img = n * n_parts
+    else:
+        gx = torch.empty_like(x)
+        n_img = n
     k, st = layer.k, layer.stride
     _, pby = same_geometry(hi, k, st)
     _, pbx = same_geometry(wi, k, st)
@@ -299,7 +315,7 @@ def conv_dgrad(g, x, layer, res=None):
                 dy.append((py + pby - r) // st); dx.append((px + pbx - s) // st); tw.append(r * k + s)
         d = L.ConvDesc()
         d.dtype = dcode
-        d.n, d.hi, d.wi, d.ci, d.ldi = n, ho, wo, round8(layer.co), g.shape[-1]
+        d.n, d.hi, d.wi, d.ci, d.ldi = n_img, ho, wo, round8(layer.co), g.shape[-1]
         d.ho, d.wo, d.co, d.co_fill, d.ldo = lat_h, lat_w, layer.ci_log, ldi, ldi
         d.out_h, d.out_w, d.out_sy, d.out_sx, d.out_oy, d.out_ox = hi, wi, st, st, py, px
         d.in_sy = d.in_sx = 1
@@ -312,19 +328,23 @@ def conv_dgrad(g, x, layer, res=None):
         d.dact_kind = layer.act_in
         d.ldr = res.shape[-1] if res is not None else 0
         d.ldd = ldi
-        d.in_, d.w, d.out = g.data_ptr(), ent["w_dgrad"].data_ptr(), gx.data_ptr()
+        d.in_, d.w, d.out = g.data_ptr(), ent["w_dgrad"].data_ptr(), gx.data_ptr() if gx is not None else None
         d.bias, d.coord_tab = None, None
         d.res = res.data_ptr() if res is not None else None
         d.dact = x.data_ptr() if layer.act_in != L.ACT_NONE else None
+        if mask_view is not None:
+            d.mask_grad, d.mask_view, d.mask_batch = g_hard.data_ptr(), mask_view.data_ptr(), n
         _attach_ws(d, x.device)
         assert round8(layer.co) <= g.shape[-1]
         L.call("ups_conv_igemm", C.byref(d), L.stream())
-    return gx
+    return gx if mask_view is None else g_hard
 
 
-def conv_wgrad(g, x, layer):
-    """(dV [kh,kw,cin_v,co] fp32, db [co] fp32)."""
+def conv_wgrad(g, x, layer, mask=None):
+    """(dV [kh,kw,cin_v,co] fp32, db [co] fp32).  mask = (hard_bits, P): x is the unmasked view of a part-masked convolution."""
     n, hi, wi, ldi = x.shape
+    if mask is not None:
+        n = n * mask[1]
     dcode = L.dt(x)
     ho, wo = layer.out_hw(hi, wi)
     dev = x.device
@@ -341,6 +361,8 @@ def conv_wgrad(g, x, layer):
     d.act_in, d.act_slope = layer.act_in, layer.slope
     sk, wsb = C.c_int32(0), C.c_size_t(0)
     d.in_, d.dout, d.grad, d.grad_bias = x.data_ptr(), g.data_ptr(), gV.data_ptr(), gb.data_ptr()
+    if mask is not None:
+        d.mask_bits, d.mask_batch = mask[0].data_ptr(), x.shape[0]
     L.call("ups_conv_wgrad_plan", C.byref(d), C.byref(sk), C.byref(wsb))
     ws = WORKSPACE.get(wsb.value, dev)
     d.splitk, d.workspace = sk.value, ws.data_ptr()
@@ -387,20 +409,23 @@ class ConvFn(torch.autograd.Function):
     """res_mode 0: plain; 1: out = res + conv(x); 2: out = x + conv(act(x)) (residual_block, nn.py:1042-1056)."""
 
     @staticmethod
-    def forward(ctx, x, V, b, res, layer, res_mode, out_f32, ldo):
+    def forward(ctx, x, V, b, res, layer, res_mode, out_f32, ldo, hard=None, hard_bits=None, view_f32=None):
+        """hard / hard_bits / view_f32 given: the part-masked convolution (x = the unmasked view in the activation dtype,
+        the P*B part images are formed in the kernel's load); the gradient w.r.t. `hard` comes out of the dgrad epilogue."""
         x = x.contiguous()
         r = x if res_mode == 2 else (res.contiguous() if res_mode == 1 else None)
-        out = conv_forward(x, layer, res=r, out_f32=out_f32, ldo=ldo)
-        ctx.save_for_backward(x)
+        ctx.mask = None if hard is None else (hard_bits, hard.shape[-1])
+        out = conv_forward(x, layer, res=r, out_f32=out_f32, ldo=ldo, mask=ctx.mask)
+        ctx.save_for_backward(x, view_f32)
         ctx.layer, ctx.res_mode = layer, res_mode
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
+        x, view_f32 = ctx.saved_tensors
         layer = ctx.layer
         g = to_act_dtype(g, x.dtype, layer.co)
-        gx = gV = gb = gres = None
+        gx = gV = gb = gres = g_hard = None
         offloaded = False
         if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not GradMode.skip_wgrad:
             if Streams.enabled and layer.grad_V is not None and not Streams.on_aux(x.device):
@@ -411,24 +436,36 @@ class ConvFn(torch.autograd.Function):
                 side = Streams.get("wgrad", x.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    gV, gb = conv_wgrad(g, x, layer)
+                    gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask)
                 Streams.keep(x.device, g, x)      # alive until the launching stream has joined the side stream
             else:
-                gV, gb = conv_wgrad(g, x, layer)
+                gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask)
             if layer.after_wgrad is not None:
                 layer.after_wgrad()
-        if ctx.needs_input_grad[0]:
+        if ctx.mask is not None:
+            if ctx.needs_input_grad[8]:
+                g_hard = conv_dgrad(g, x, layer, mask_view=view_f32, n_parts=ctx.mask[1])
+        elif ctx.needs_input_grad[0]:
             gx = conv_dgrad(g, x, layer, res=g if ctx.res_mode == 2 else None)
         if ctx.res_mode == 1 and ctx.needs_input_grad[3]:
             # the autograd engine may accumulate other branches into the returned tensor IN PLACE; the side stream
             # is still reading g, so hand out a copy in that case
             gres = g.clone() if offloaded else g
-        return gx, gV, gb, gres, None, None, None, None
+        return gx, gV, gb, gres, None, None, None, None, g_hard, None, None
 
 
-def conv(x, layer, res=None, res_self=False, out_f32=False, ldo=None):
+def conv(x, layer, res=None, res_self=False, out_f32=False, ldo=None, mask=None):
+    """mask = (hard [B,H,W,P] fp32 autograd leaf, hard_bits [B,H,W] int32, view_f32 [B,H,W,3]): part-masked convolution."""
     mode = 2 if res_self else (1 if res is not None else 0)
-    return ConvFn.apply(x, layer.V, layer.b, res, layer, mode, out_f32, ldo)
+    if mask is None:
+        return ConvFn.apply(x, layer.V, layer.b, res, layer, mode, out_f32, ldo)
+    assert mode == 0
+    return ConvFn.apply(x, layer.V, layer.b, None, layer, 0, out_f32, ldo, mask[0], mask[1], mask[2].contiguous())
+
+
+def masked_conv_eligible(dtype, size, n_parts):
+    """The fused form runs on the bf16 3x3 / stride-1 patch kernels: 16-aligned images, at most 32 parts."""
+    return dtype == torch.bfloat16 and size % 16 == 0 and size >= 16 and n_parts <= 32
 
 
 class BilinearFn(torch.autograd.Function):
@@ -594,16 +631,19 @@ class UnpoolFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- raw (non-autograd) part-path / latent calls
-def part_softmax(mean, eps=None, want_hard=True, want_argmax=False):
+def part_softmax(mean, eps=None, want_hard=True, want_argmax=False, want_bits=None):
+    """-> (l, m, hard, argmax), or (l, m, hard, argmax, hard_bits) when `want_bits` is given (True / False):
+    hard_bits [..] int32 = the hard mask as a bit set per pixel (P <= 32; None when not wanted)."""
     mean = mean.contiguous()
     pixels, P = mean.numel() // mean.shape[-1], mean.shape[-1]
     l = torch.empty_like(mean) if eps is not None else mean
     m = torch.empty_like(mean)
     hard = torch.empty_like(mean) if want_hard else None
     am = torch.empty(mean.shape[:-1], dtype=torch.int64, device=mean.device) if want_argmax else None
+    bits = torch.empty(mean.shape[:-1], dtype=torch.int32, device=mean.device) if want_bits else None
     L.call("ups_part_softmax_fwd", L.ptr(mean), L.ptr(eps.contiguous()) if eps is not None else None,
-           L.ptr(l) if eps is not None else None, L.ptr(m), L.ptr(hard), L.ptr(am), pixels, P, L.stream())
-    return l, m, hard, am
+           L.ptr(l) if eps is not None else None, L.ptr(m), L.ptr(hard), L.ptr(am), L.ptr(bits), pixels, P, L.stream())
+    return (l, m, hard, am) if want_bits is None else (l, m, hard, am, bits)
 
 
 def spatial_moments(x, gamma, rect_px=None, half=0):
