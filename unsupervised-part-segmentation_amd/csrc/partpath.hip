@@ -15,47 +15,38 @@ namespace {
 struct TileAbs { __device__ float operator()(float v) const { return fabsf(v); } };
 struct TileSign { __device__ float operator()(float v) const { return (__float_as_uint(v) >> 31) ? 1.f : 0.f; } };
 
-template <int GP>
+// thread = pixel: the P values of the pixel are walked in LDS (odd pixel pitch: conflict-free), no cross-lane traffic at all
+// (a lane-per-part layout spends 16 ds_bpermute per 4 pixels on the max / sum / arg-max reductions: LDS-issue bound)
 __global__ __launch_bounds__(256) void part_softmax_kernel(const float* __restrict__ mean, const float* __restrict__ eps,
                                                            float* __restrict__ l, float* __restrict__ m, float* __restrict__ hard,
                                                            long long* __restrict__ amax, unsigned* __restrict__ bits,
                                                            long long pixels, int P, int tpx) {
     extern __shared__ __attribute__((aligned(16))) float ts[];          // [tpx][PP]
-    constexpr int PL = 256 / GP;
     const int PP = tile_pitch(P);
     const long long pix0 = (long long)blockIdx.x * tpx;
     const int cnt = (int)min((long long)tpx, pixels - pix0);
     tile_load_f32(mean + pix0 * P, cnt, P, PP, ts, eps ? eps + pix0 * P : nullptr, (eps && l) ? l + pix0 * P : nullptr);
     __syncthreads();
-    const int c = threadIdx.x % GP, pl = threadIdx.x / GP;
-    for (int px = pl; px < tpx; px += PL) {          // uniform trip count: the shuffles need every lane of a group
-        const bool ok = px < cnt && c < P;
-        const float v = ok ? ts[px * PP + c] : -INFINITY;
-        float mx = v;
-#pragma unroll
-        for (int o = GP / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, GP));
-        const float e = ok ? expf(v - mx) : 0.f;
-        float sm = e;
-#pragma unroll
-        for (int o = GP / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o, GP);
-        const float pm = e / sm;
-        float mm = ok ? pm : -1.f;
-#pragma unroll
-        for (int o = GP / 2; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, GP));
-        const bool is_max = ok && pm == mm;
-        int first = is_max ? c : GP;
-#pragma unroll
-        for (int o = GP / 2; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, GP));
-        if (bits) {
-            unsigned bm = (is_max && c < 32) ? (1u << c) : 0u;
-#pragma unroll
-            for (int o = GP / 2; o > 0; o >>= 1) bm |= (unsigned)__shfl_xor((int)bm, o, GP);
-            if (ok && c == 0) bits[pix0 + px] = bm;
+    for (int px = threadIdx.x; px < cnt; px += 256) {
+        float* row = ts + px * PP;
+        float mx = -INFINITY;
+        for (int c = 0; c < P; ++c) mx = fmaxf(mx, row[c]);
+        float sm = 0.f;
+        for (int c = 0; c < P; ++c) { const float e = expf(row[c] - mx); row[c] = e; sm += e; }
+        float mm = -1.f;
+        for (int c = 0; c < P; ++c) { const float pm = row[c] / sm; row[c] = pm; mm = fmaxf(mm, pm); }
+        int first = -1;
+        unsigned bm = 0u;
+        for (int c = 0; c < P; ++c) {
+            const float pm = row[c];
+            if (pm == mm) {
+                if (first < 0) first = c;
+                if (c < 32) bm |= 1u << c;
+                row[c] = -pm;                        // sign = hard-max flag
+            }
         }
-        if (ok) {
-            ts[px * PP + c] = is_max ? -pm : pm;
-            if (amax && c == 0) amax[pix0 + px] = first;
-        }
+        if (amax) amax[pix0 + px] = first;
+        if (bits) bits[pix0 + px] = bm;
     }
     __syncthreads();
     tile_store_f32(m + pix0 * P, cnt, P, PP, ts, TileAbs());
@@ -64,32 +55,34 @@ __global__ __launch_bounds__(256) void part_softmax_kernel(const float* __restri
 
 // ------------------------------------------------------------------ spatial soft-max moments (nn.py:65-71, 1541-1587)
 // partial[n][slab][p][8] = {max, Z, S0, Sy, Sx, Q, Qy, -} relative to the slab max (Q = sum e*k*(gy^2+gx^2), Qy = sum e*k*gy^2)
-template <int GP>
+// threads = (part c, sub-lane s) with NS = 256 / P sub-lanes per part (250 of 256 lanes busy at P = 10, against 160 with a
+// power-of-two lane group); each walks the column c of the staged tile with its pixel coordinates advanced incrementally.
 __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ x, int h, int w, int P, float gamma,
                                                               const int* __restrict__ rc, int hh, int hw_half,
                                                               int rows_per_slab, int tpx, float* __restrict__ partial) {
-    constexpr int PL = 256 / GP;
-    extern __shared__ __attribute__((aligned(16))) float ts[];          // [tpx][PP], then red[PL][GP][7]
+    extern __shared__ __attribute__((aligned(16))) float ts[];          // [tpx][PP], then red[NS][P][7]
     const int PP = tile_pitch(P);
-    float (*red)[GP][7] = (float (*)[GP][7])(ts + (size_t)tpx * PP);
+    const int NS = 256 / P;
+    float* red = ts + (size_t)tpx * PP;
     const int n = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
-    const int c = threadIdx.x % GP, pl = threadIdx.x / GP;
+    const int c = threadIdx.x % P, sl = threadIdx.x / P;
+    const bool act = sl < NS;
     const int y0 = slab * rows_per_slab, y1 = min(h, y0 + rows_per_slab);
     float mx = -INFINITY, Z = 0.f, S0 = 0.f, Sy = 0.f, Sx = 0.f, Q = 0.f, Qy = 0.f;
     int cy = 0, cx = 0;
-    if (rc && c < P) { cy = rc[((long long)n * P + c) * 2]; cx = rc[((long long)n * P + c) * 2 + 1]; }
+    if (rc) { cy = rc[((long long)n * P + c) * 2]; cx = rc[((long long)n * P + c) * 2 + 1]; }
     const float sy = h > 1 ? 2.f / (float)(h - 1) : 0.f, sx = w > 1 ? 2.f / (float)(w - 1) : 0.f;
     const int q0 = y0 * w, q1 = max(y1, y0) * w;
     const float* img = x + (long long)n * h * w * P;
+    const int dyy = NS / w, dxx = NS - dyy * w;                         // pixel step NS in (row, column) form
     for (int t0 = q0; t0 < q1; t0 += tpx) {
         const int cnt = min(tpx, q1 - t0);
         __syncthreads();                      // the previous tile has been consumed
         tile_load_f32(img + (long long)t0 * P, cnt, P, PP, ts);
         __syncthreads();
-        if (c < P) {
-            for (int px = pl; px < cnt; px += PL) {
-                const int q = t0 + px;
-                const int yy = q / w, xx = q - yy * w;
+        if (act) {
+            int yy = (t0 + sl) / w, xx = (t0 + sl) - yy * w;
+            for (int px = sl; px < cnt; px += NS) {
                 const float v = gamma * ts[px * PP + c];
                 if (v > mx) {
                     const float sc = expf(mx - v);  // exp(-inf) = 0 on the first element
@@ -103,20 +96,25 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
                 const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
                 const float ek = e * k;
                 S0 += ek; Sy += ek * gy; Sx += ek * gx; Q += ek * (gy * gy + gx * gx); Qy += ek * gy * gy;
+                yy += dyy; xx += dxx;
+                if (xx >= w) { xx -= w; ++yy; }
             }
         }
     }
-    red[pl][c][0] = mx; red[pl][c][1] = Z; red[pl][c][2] = S0; red[pl][c][3] = Sy; red[pl][c][4] = Sx; red[pl][c][5] = Q;
-    red[pl][c][6] = Qy;
     __syncthreads();
-    if (pl == 0 && c < P) {
-        float M = mx;
-        for (int q = 1; q < PL; ++q) M = fmaxf(M, red[q][c][0]);
+    if (act) {
+        float* d = red + ((size_t)sl * P + c) * 7;
+        d[0] = mx; d[1] = Z; d[2] = S0; d[3] = Sy; d[4] = Sx; d[5] = Q; d[6] = Qy;
+    }
+    __syncthreads();
+    if (threadIdx.x < P) {
+        float M = -INFINITY;
+        for (int q = 0; q < NS; ++q) M = fmaxf(M, red[((size_t)q * P + c) * 7]);
         float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < PL; ++q) {
-            const float mq = red[q][c][0];
-            const float sc = (mq == -INFINITY) ? 0.f : expf(mq - M);
-            for (int k = 0; k < 6; ++k) o[k] += sc * red[q][c][1 + k];
+        for (int q = 0; q < NS; ++q) {
+            const float* r = red + ((size_t)q * P + c) * 7;
+            const float sc = (r[0] == -INFINITY) ? 0.f : expf(r[0] - M);
+            for (int k = 0; k < 6; ++k) o[k] += sc * r[1 + k];
         }
         float* dst = partial + (((long long)n * nslab + slab) * P + c) * 8;
         dst[0] = M;
@@ -379,21 +377,11 @@ extern "C" int ups_part_softmax_fwd(const float* mean, const float* eps, float* 
     UPS_CHECK_ARG(mean && m && pixels > 0 && P >= 1 && P <= 64);
     UPS_CHECK_ARG(!hard_bits || P <= 32);
     hipStream_t s = (hipStream_t)stream;
-    int gp = 2;
-    while (gp < P) gp *= 2;
     const int tpx = tile_pixels(P, 1, 24 * 1024);
     const int grid = ups_cdiv(pixels, tpx);
     const size_t shm = (size_t)tpx * (P | 1) * sizeof(float);
-#define UPS_PS(G) hipLaunchKernelGGL(part_softmax_kernel<G>, dim3(grid), dim3(256), shm, s, mean, eps, l, m, hard, (long long*)argmax, (unsigned*)hard_bits, (long long)pixels, P, tpx)
-    switch (gp) {
-        case 2: UPS_PS(2); break;
-        case 4: UPS_PS(4); break;
-        case 8: UPS_PS(8); break;
-        case 16: UPS_PS(16); break;
-        case 32: UPS_PS(32); break;
-        default: UPS_PS(64); break;
-    }
-#undef UPS_PS
+    hipLaunchKernelGGL(part_softmax_kernel, dim3(grid), dim3(256), shm, s, mean, eps, l, m, hard, (long long*)argmax,
+                       (unsigned*)hard_bits, (long long)pixels, P, tpx);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }
@@ -407,20 +395,10 @@ extern "C" int ups_spatial_moments(const float* x, int32_t n, int32_t h, int32_t
     const int nslab = 8;
     float* partial = stats + (long long)n * P * 8;
     const int rows = ups_cdiv(h, nslab);
-    int gp = 2;
-    while (gp < P) gp *= 2;
     const int tpx = tile_pixels(P, 1, 24 * 1024);
-    const size_t shm = ((size_t)tpx * (P | 1) + (size_t)(256 / gp) * gp * 7) * sizeof(float);
-#define UPS_MP(G) hipLaunchKernelGGL(moments_partial_kernel<G>, dim3(n, nslab), dim3(256), shm, s, x, h, w, P, gamma, rect_c, half_h, half_w, rows, tpx, partial)
-    switch (gp) {
-        case 2: UPS_MP(2); break;
-        case 4: UPS_MP(4); break;
-        case 8: UPS_MP(8); break;
-        case 16: UPS_MP(16); break;
-        case 32: UPS_MP(32); break;
-        default: UPS_MP(64); break;
-    }
-#undef UPS_MP
+    const size_t shm = ((size_t)tpx * (P | 1) + (size_t)(256 / P) * P * 7) * sizeof(float);
+    hipLaunchKernelGGL(moments_partial_kernel, dim3(n, nslab), dim3(256), shm, s, x, h, w, P, gamma, rect_c, half_h, half_w, rows, tpx,
+                       partial);
     UPS_LAUNCH_CHECK();
     hipLaunchKernelGGL(moments_combine_kernel, dim3(ups_cdiv(n * P, 256)), dim3(256), 0, s, partial, n, nslab, P, stats);
     UPS_LAUNCH_CHECK();
