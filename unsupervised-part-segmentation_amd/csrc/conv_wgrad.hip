@@ -240,27 +240,51 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int 
 }
 
 // grad[tap][row < ci_log][co] = sum_s slab[s][...] ; grad_bias[co] = sum_s slab[s][bias part]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ grad, float* __restrict__ gbias,
-                                    int splitk, int ntaps_w, int cin_v, int ci_log, int co, long long slab) {
+// 256 threads = 32 consecutive outputs x 8 slab groups: a thread sums every 8th slab (4 loads in flight), the groups are
+// combined through LDS in a fixed order.  (One thread per output walking all the slabs -- up to 256 dependent round trips
+// on grids of a few dozen blocks for the thin layers -- cost 3.6 ms of kernel time per step.)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ grad,
+                                                           float* __restrict__ gbias, int splitk, int ntaps_w, int cin_v,
+                                                           int ci_log, int co, long long slab) {
+    __shared__ float red[8][32];
     const long long nw = (long long)ntaps_w * ci_log * co;
     const long long total = nw + (gbias ? co : 0);
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        long long off;
-        float* dst;
-        if (idx < nw) {
-            const int c = (int)(idx % co);
-            const long long tr = idx / co;
-            const int row = (int)(tr % ci_log), tap = (int)(tr / ci_log);
-            off = ((long long)tap * cin_v + row) * co + c;
-            dst = grad + off;
-        } else {
-            off = (long long)ntaps_w * cin_v * co + (idx - nw);
-            dst = gbias + (idx - nw);
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
+        const long long idx = base + o;
+        const bool ok = idx < total;
+        long long off = 0;
+        float* dst = nullptr;
+        if (ok) {
+            if (idx < nw) {
+                const int c = (int)(idx % co);
+                const long long tr = idx / co;
+                const int row = (int)(tr % ci_log), tap = (int)(tr / ci_log);
+                off = ((long long)tap * cin_v + row) * co + c;
+                dst = grad + off;
+            } else {
+                off = (long long)ntaps_w * cin_v * co + (idx - nw);
+                dst = gbias + (idx - nw);
+            }
         }
-        float s = 0.f;
-        for (int k = 0; k < splitk; ++k) s += ws[k * slab + off];
-        *dst = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (ok) {
+            int k = g;
+            for (; k + 24 < splitk; k += 32) {
+                s0 += ws[(long long)k * slab + off]; s1 += ws[(long long)(k + 8) * slab + off];
+                s2 += ws[(long long)(k + 16) * slab + off]; s3 += ws[(long long)(k + 24) * slab + off];
+            }
+            for (; k < splitk; k += 8) s0 += ws[(long long)k * slab + off];
+        }
+        red[g][o] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (g == 0 && ok) {
+            float t = red[0][o];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) t += red[q][o];
+            *dst = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -369,7 +393,7 @@ extern "C" int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream) {
     UPS_LAUNCH_CHECK();
     const long long slab = (long long)d->ntaps * d->cin_v * d->co + d->co;
     const long long total = (long long)d->ntaps * d->ci_log * d->co + d->co;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ups_cdiv(total, 256) > 4096 ? 4096 : ups_cdiv(total, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ups_cdiv(total, 32) > 8192 ? 8192 : ups_cdiv(total, 32)), dim3(256), 0,
                        s, d->workspace, d->grad, d->grad_bias, nslabs, d->ntaps, d->cin_v, d->ci_log, d->co, slab);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
