@@ -414,6 +414,19 @@ class Trainer(object):
         Z, A, P = cfg.get("z0_size", 256), cfg.get("local_app_size", 64), model.n_parts
         gamma = float(cfg.get("gamma", 3.0))
         half = model.patch_size // 2
+        main_stream = torch.cuda.current_stream(dev)
+        # the perceptual features of the TARGET depend on the data only: evaluated on a side stream from the start of the step
+        # (they fill the bubbles of the small layers at the network ends), joined where the loss needs them
+        ft_pre, ft_ready = None, None
+        if self.perceptual_input == "resize256":
+            assert S == 128
+        if ops.Streams.enabled:
+            pre = ops.Streams.get("pre", dev)
+            pre.wait_stream(main_stream)
+            with torch.cuda.stream(pre), torch.no_grad():
+                tgt_pre = ops.BilinearFn.apply(model.to_act(vt)) if self.perceptual_input == "resize256" else vt
+                ft_pre = self.vgg.features(tgt_pre, T)
+            ft_ready = pre.record_event()
         if noise is None:
             noise = self.draw_noise(B)
         noise = {k: v.to(dev, torch.float32).contiguous() for k, v in noise.items()}
@@ -502,7 +515,6 @@ class Trainer(object):
                         torch.autograd.grad([lss], [bank.params[n] for n in bank.groups[name]["names"]])
             return crit, adv, g_adv, mim, ind_mim
 
-        main_stream = torch.cuda.current_stream(dev)
         if ops.Streams.enabled:
             aux = ops.Streams.get("aux", dev)
             aux.wait_stream(main_stream)
@@ -535,12 +547,13 @@ class Trainer(object):
         feat = yp.float().view(P, B, A).permute(1, 0, 2).contiguous()      # [B,P,A]
         inj = ops.UnpoolFn.apply(hard0, feat, T)
         gen = nets.dd(Act(inj, B, S, S, A + P)).t                          # [B,S,S,8]
-        if self.perceptual_input == "resize256":
-            assert S == 128
-            tgt_in = ops.BilinearFn.apply(model.to_act(vt)); gen_in = ops.BilinearFn.apply(gen)
+        gen_in = ops.BilinearFn.apply(gen) if self.perceptual_input == "resize256" else gen
+        if ft_pre is not None:
+            main_stream.wait_event(ft_ready)
+            rec = self.vgg.loss(None, gen_in, T, target_features=ft_pre)
         else:
-            tgt_in, gen_in = vt, gen
-        rec = self.vgg.loss(tgt_in, gen_in, T)
+            tgt_in = ops.BilinearFn.apply(model.to_act(vt)) if self.perceptual_input == "resize256" else vt
+            rec = self.vgg.loss(tgt_in, gen_in, T)
         auto_rec = (1e-3 * 0.5 * (S * S * 3)) * rec                        # model.py:613-619
 
         rec_params = []

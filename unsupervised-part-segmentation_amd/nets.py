@@ -359,10 +359,13 @@ class VggTrunk(object):
                     feats.append((h, lay.co, L.ACT_RELU))
         return feats
 
-    def loss(self, target_img, generated_img, act_dtype):
-        """sum_l mean |f_l(target) - f_l(generated)| (feature weights 1, gram weight 0: model.py:608)."""
-        with torch.no_grad():
-            ft = self.features(target_img, act_dtype)
+    def loss(self, target_img, generated_img, act_dtype, target_features=None):
+        """sum_l mean |f_l(target) - f_l(generated)| (feature weights 1, gram weight 0: model.py:608).
+        target_features: f(target) computed earlier (the target is a data input: the trainer evaluates it on a side stream)."""
+        if target_features is None:
+            with torch.no_grad():
+                target_features = self.features(target_img, act_dtype)
+        ft = target_features
         fg = self.features(generated_img, act_dtype)
         total = None
         for (a, c, act), (b, _, _) in zip(ft, fg):
