@@ -83,6 +83,10 @@ CONV_CASES = [
     (4, 128, 128, 32, 32, 3, 1, True, "leaky_relu", True),     # encoder_0 first res-block: thin CoordConv layer at 128x128
     (2, 128, 128, 80, 32, 3, 1, False, None, False),           # decoder_delta input conv (74 + pad -> 32)
     (16, 64, 64, 256, 256, 3, 1, True, "leaky_relu", True),    # dv res-block at 64x64
+    # wide layers on >= 256 tiles: ragged second N-tile, an odd number of 32-channel chunks, 512 outputs, dgrad with act' + residual
+    (16, 64, 64, 96, 200, 3, 1, True, "leaky_relu", False),
+    (4, 128, 128, 200, 200, 3, 1, False, "relu", True),
+    (16, 64, 64, 64, 512, 3, 1, False, "relu", False),
     # thin single-chunk layers on large grids (>= 1536 tiles, three blocks per CU): the HBM-bound streams of encoder_1 on parts
     (24, 128, 128, 32, 32, 3, 1, True, "leaky_relu", True),    # <bf16,32,1,16>: res-block with CoordConv
     (25, 128, 128, 8, 32, 3, 1, False, None, False),           # image-input conv
