@@ -182,10 +182,15 @@ def run_rank(args):
                           "global_batch": args.batch * world, "parallelism": "dp{}".format(world),
                           "rccl_world_size": rccl_world},
                "model_tflops_per_gpu": round(value * TRAIN_GFLOP_PER_IMAGE / 1e3 / world, 2),
-               "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel<{}> @ {}".format(
+               "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel<{},128,2,16> @ {} (1 forward + 2 input-gradient "
+                                                        "launches per step, all timed)".format(
                                 "bf16" if args.precision == "bf16" else "f32", ops.KernelTimer.layer),
                             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                            "kernel_ms": round(kms, 4), "launches_timed": len(ops.KernelTimer.events), "traffic": traffic,
+                            "kernel_ms": round(kms, 4), "kernel_ms_forward": round(ops.KernelTimer.mean_ms("fwd"), 4),
+                            "kernel_ms_dgrad": round(ops.KernelTimer.mean_ms("dgrad"), 4),
+                            "launches_timed": len(ops.KernelTimer.events), "traffic": traffic,
+                            "traffic_note": "HBM bytes of the forward launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                            "(profiles/round2_pmc_dv_rb128.json); tensor-once algorithmic bytes 2.15e9",
                             "flop_per_launch": ops.KernelTimer.flops}}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, CPU_THREAD_CAP)

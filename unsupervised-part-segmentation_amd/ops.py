@@ -89,13 +89,16 @@ class Streams(object):
 
 
 class KernelTimer(object):
-    """bench.py hook: HIP events (recorded on the launch stream) around the forward launch of one named
-    convolution, so the roofline figure is that kernel's own duration, measured live."""
+    """bench.py hook: HIP events (recorded on the launch stream) around every launch of the patch kernel for one named
+    convolution -- its forward and its input-gradient launches: the same kernel on the same problem size -- so the roofline
+    figure is that kernel's own duration, measured live."""
     layer, enabled, events, flops = None, False, [], 0.0
+    kinds = []        # "fwd" / "dgrad" per timed launch
 
     @classmethod
-    def mean_ms(cls):
-        return sum(a.elapsed_time(b) for a, b in cls.events) / max(1, len(cls.events))
+    def mean_ms(cls, kind=None):
+        ev = [e for e, k in zip(cls.events, cls.kinds) if kind is None or k == kind]
+        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
 
 
 class WeightVersion(object):
@@ -273,6 +276,7 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
         L.call("ups_conv_igemm", C.byref(d), L.stream())
         e1.record()
         KernelTimer.events.append((e0, e1))
+        KernelTimer.kinds.append("fwd")
         KernelTimer.flops = 2.0 * n * ho * wo * layer.k * layer.k * layer.cin_v * layer.co
     else:
         L.call("ups_conv_igemm", C.byref(d), L.stream())
@@ -336,7 +340,15 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
             d.mask_grad, d.mask_view, d.mask_batch = g_hard.data_ptr(), mask_view.data_ptr(), n
         _attach_ws(d, x.device)
         assert round8(layer.co) <= g.shape[-1]
-        L.call("ups_conv_igemm", C.byref(d), L.stream())
+        if KernelTimer.layer == layer.name and KernelTimer.enabled and st == 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            L.call("ups_conv_igemm", C.byref(d), L.stream())
+            e1.record()
+            KernelTimer.events.append((e0, e1))
+            KernelTimer.kinds.append("dgrad")
+        else:
+            L.call("ups_conv_igemm", C.byref(d), L.stream())
     return gx if mask_view is None else g_hard
 
 
