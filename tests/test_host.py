@@ -183,6 +183,22 @@ def test_csv_pair_datasets(tmp_path):
     it = data.batches(ds, 3, workers=2, epochs=1)
     bs = list(it)
     assert len(bs) == 2 and bs[0]["view1"].shape == (3, 16, 16, 3) and bs[0]["view1"].dtype == torch.float32
+    # evaluation: the ragged last batch is padded to the static size and says how many rows are real
+    ev = list(data.batches(ds, 3, shuffle=False, workers=2, epochs=1, pad_last=True))
+    assert [b["valid"] for b in ev] == [3, 3, 1] and ev[2]["view0"].shape == (3, 16, 16, 3)
+    # pairings are reproducible whatever the decoding threads do: a per-index, per-draw generator
+    a = [data.AugmentedPair2(cfg).pick_partner(i) for i in range(7)]
+    b = [data.AugmentedPair2(cfg).pick_partner(i) for i in reversed(range(7))][::-1]
+    assert a == b
+    # ground-truth label maps travel with the examples when the csv names them
+    for i in range(7):
+        Image.fromarray((np.arange(24 * 24).reshape(24, 24) % 5).astype(np.uint8)).save(str(tmp_path / "gt{}.png".format(i)))
+    rows_gt = ["character_id,relative_file_path_,foo,category,gt"] + ["{},im{}.png,x,bird,gt{}.png".format(i // 3, i, i) for i in range(7)]
+    (tmp_path / "gt.csv").write_text("\n".join(rows_gt) + "\n")
+    dsg = data.AugmentedPair2(dict(cfg, data_csv=str(tmp_path / "gt.csv"), data_gt_segmentation_column="gt",
+                                   data_csv_columns=["character_id", "relative_file_path_", "foo", "category", "gt"]))
+    ex = dsg.get_example(2)
+    assert ex["gt_segmentation"].shape == (16, 16) and ex["gt_segmentation"].dtype == np.int64 and ex["gt_segmentation"].max() <= 4
     pair = data.StochasticPairs(dict(cfg, data_flip_h=True))
     assert set(pair.get_example(0)) == {"view0", "view1"}
     with pytest.raises(NotImplementedError):
@@ -200,8 +216,12 @@ def test_part_iou_evaluation():
     pred[:, :4, :4] = 3; pred[:, 4:, 4:] = 5; pred[0, 4, 4] = 3  # parts 3 -> head, 5 -> tail (one pixel wrong)
     r = E.evaluate_parts(pred, gt)
     assert r["mapping"] == {3: 1, 5: 2, 7: 0}
-    assert abs(r["iou"][1] - 32 / 33) < 1e-12 and abs(r["iou"][2] - 31 / 32) < 1e-12 and r["iou"][0] == 1.0
-    assert abs(r["overall"] - 0.5 * (32 / 33 + 31 / 32)) < 1e-12
+    # pooled over the set (one IoU per label over all pixels)
+    assert abs(r["pooled"][1] - 32 / 33) < 1e-12 and abs(r["pooled"][2] - 31 / 32) < 1e-12 and r["pooled"][0] == 1.0
+    # eval_01.py protocol: IoU per image, then the mean over the images (image 0 has the wrong pixel, image 1 is perfect)
+    assert abs(r["per_image"][0][1] - 16 / 17) < 1e-12 and r["per_image"][1][1] == 1.0
+    assert abs(r["iou"][1] - 0.5 * (16 / 17 + 1.0)) < 1e-12 and abs(r["iou"][2] - 0.5 * (15 / 16 + 1.0)) < 1e-12
+    assert abs(r["overall"] - 0.5 * (r["iou"][1] + r["iou"][2])) < 1e-12
     same = E.evaluate_parts(gt, gt)
     assert same["overall"] == 1.0
 

@@ -44,7 +44,12 @@ class StochasticPairs(object):
         self.labels["choices"] = add_choices(self.labels["character_id"])
         self.avoid_identity = config.get("data_avoid_identity", True)
         self.flip_h, self.flip_v = config.get("data_flip_h", False), config.get("data_flip_v", False)
-        self.prng = np.random.RandomState(config.get("data_seed", 1))
+        self.seed = int(config.get("data_seed", 1))
+        self.prng = np.random.RandomState(self.seed)          # (kept for callers that draw from the dataset-wide stream)
+        self.draws = {}                                        # index -> number of examples drawn so far
+        # optional ground-truth label maps for evaluation (eval_01.py:229-383 reads them as batch["gt_segmentation"]):
+        # a csv column with the relative path of a label image (nearest-neighbour resized like denseposelib.resize_labels)
+        self.gt_column = config.get("data_gt_segmentation_column")
 
     def __len__(self):
         return len(self.labels["character_id"])
@@ -54,21 +59,44 @@ class StochasticPairs(object):
         img = Image.open(path).convert("RGB").resize((self.size, self.size), Image.BILINEAR)
         return np.asarray(img, dtype=np.float32) / 127.5 - 1.0
 
-    def pick_partner(self, i):
+    def _rng(self, i):
+        """Per-index, per-draw generator: examples are decoded by a thread pool, so partner and flip decisions must not
+        depend on which thread reaches a shared stream first (reproducible pairings)."""
+        k = self.draws.get(int(i), 0)
+        self.draws[int(i)] = k + 1
+        return np.random.RandomState([self.seed & 0x7fffffff, int(i), k])
+
+    def pick_partner(self, i, rng=None):
+        rng = rng if rng is not None else self._rng(i)
         choices = self.labels["choices"][i]
         if self.avoid_identity and len(choices) > 1:
             choices = [c for c in choices if c != i]
-        return int(self.prng.choice(choices))
+        return int(rng.choice(choices))
+
+    def preprocess_labels(self, path):
+        from PIL import Image
+        return np.asarray(Image.open(path).resize((self.size, self.size), Image.NEAREST), dtype=np.int64)
 
     def get_example(self, i):
-        j = self.pick_partner(i)
+        rng = self._rng(i)
+        j = self.pick_partner(i, rng)
         view0 = self.preprocess_image(self.labels["file_path_"][i])
         view1 = self.preprocess_image(self.labels["file_path_"][j])
-        if self.flip_h and self.prng.rand() < 0.5:
+        flip_h = self.flip_h and rng.rand() < 0.5
+        flip_v = self.flip_v and rng.rand() < 0.5
+        if flip_h:
             view0, view1 = view0[:, ::-1].copy(), view1[:, ::-1].copy()
-        if self.flip_v and self.prng.rand() < 0.5:
+        if flip_v:
             view0, view1 = view0[::-1].copy(), view1[::-1].copy()
-        return {"view0": view0, "view1": view1}
+        ex = {"view0": view0, "view1": view1}
+        if self.gt_column and self.gt_column in self.labels:
+            gt = self.preprocess_labels(os.path.join(self.root, self.labels[self.gt_column][i]))
+            if flip_h:
+                gt = gt[:, ::-1].copy()
+            if flip_v:
+                gt = gt[::-1].copy()
+            ex["gt_segmentation"] = gt
+        return ex
 
 
 class AugmentedPair2(StochasticPairs):
@@ -86,16 +114,23 @@ class AugmentedPair2(StochasticPairs):
         return ex
 
 
-def batches(dataset, batch_size, shuffle=True, workers=8, seed=0, epochs=None):
-    """Endless (or ``epochs``-bounded) iterator of float32 NHWC torch batches; the last ragged batch of an epoch is dropped
-    (the model's batch size is static, model.py:320)."""
+def batches(dataset, batch_size, shuffle=True, workers=8, seed=0, epochs=None, pad_last=False):
+    """Endless (or ``epochs``-bounded) iterator of float32 NHWC torch batches.  The model's batch size is static
+    (model.py:320): in training the ragged last batch of an epoch is dropped; with ``pad_last`` (evaluation) it is filled up
+    by repeating its last example and carries ``"valid": n`` so that the caller keeps only the first n rows."""
     rng = np.random.RandomState(seed)
     pool = cf.ThreadPoolExecutor(max_workers=workers)
     ep = 0
     while epochs is None or ep < epochs:
         order = rng.permutation(len(dataset)) if shuffle else np.arange(len(dataset))
-        for b in range(len(order) // batch_size):
-            idx = order[b * batch_size:(b + 1) * batch_size]
-            exs = list(pool.map(dataset.get_example, idx))
-            yield {k: torch.from_numpy(np.stack([e[k] for e in exs])) for k in exs[0]}
+        nb = -(-len(order) // batch_size) if pad_last else len(order) // batch_size
+        for b in range(nb):
+            idx = list(order[b * batch_size:(b + 1) * batch_size])
+            valid = len(idx)
+            idx += [idx[-1]] * (batch_size - valid)
+            exs = [dataset.get_example(i) for i in idx] if workers <= 1 else list(pool.map(dataset.get_example, idx))
+            out = {k: torch.from_numpy(np.stack([e[k] for e in exs])) for k in exs[0]}
+            if pad_last:
+                out["valid"] = valid
+            yield out
         ep += 1

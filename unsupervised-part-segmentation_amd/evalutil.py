@@ -47,10 +47,23 @@ def compute_iou(pred, gt):
 
 
 def evaluate_parts(out_parts_hard, gt_segmentation, background_label=0):
-    """out_parts_hard [N,H,W] (TrainModel.outputs["out_parts_hard"]), gt [N,H,W] -> dict(per-label IoU, overall without background)."""
+    """out_parts_hard [N,H,W] (TrainModel.outputs["out_parts_hard"]), gt [N,H,W] -> per-label IoU and the overall number.
+
+    Protocol of eval_01.py:229-383: ONE remapping for the whole set (best IoU over all images), then the IoU of every label
+    PER IMAGE (a row of part_ious.csv; labels absent from an image's ground truth are left out of that row), the per-label
+    means over the images (mean_part_ios.csv) and their mean without the background = "overall".  ``pooled`` additionally
+    reports the IoU over all pixels of the set at once."""
+    out_parts_hard, gt_segmentation = np.asarray(out_parts_hard), np.asarray(gt_segmentation)
     mapping = compute_best_iou_remapping(out_parts_hard, gt_segmentation)
     pred = remap_parts(out_parts_hard, mapping)
-    ious, labels = compute_iou(pred, gt_segmentation)
-    keep = labels != background_label
-    return {"mapping": mapping, "iou": dict(zip(labels.tolist(), ious.tolist())),
-            "overall": float(ious[keep].mean()) if keep.any() else float("nan")}
+    labels_all = np.unique(gt_segmentation)
+    rows = []
+    for i in range(len(pred)):
+        ious, labels = compute_iou(pred[i], gt_segmentation[i])
+        rows.append(dict(zip(labels.tolist(), ious.tolist())))
+    per_label = {int(g): float(np.mean([r[g] for r in rows if g in r])) for g in labels_all.tolist()}
+    fg = [v for g, v in per_label.items() if g != background_label]
+    pooled, pl = compute_iou(pred, gt_segmentation)
+    return {"mapping": mapping, "iou": per_label, "per_image": rows,
+            "overall": float(np.mean(fg)) if fg else float("nan"),
+            "pooled": dict(zip(pl.tolist(), pooled.tolist()))}

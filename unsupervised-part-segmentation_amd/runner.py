@@ -139,7 +139,8 @@ def evaluate(args):
     try:
         cls = DATA_ALIASES.get(cfg["dataset"]) or get_obj_from_str(cfg["dataset"])
         ds = cls(cfg)
-        batches_it = _data.batches(ds, cfg["batch_size"], shuffle=False, epochs=1) if isinstance(ds, _data.StochasticPairs) else iter(ds)
+        batches_it = (_data.batches(ds, cfg["batch_size"], shuffle=False, epochs=1, pad_last=True)
+                      if isinstance(ds, _data.StochasticPairs) else iter(ds))
     except Exception:
         if args.strict_dataset:
             raise
@@ -153,13 +154,14 @@ def evaluate(args):
     for bi, batch in enumerate(batches_it):
         if args.eval_batches is not None and bi >= args.eval_batches:
             break
+        valid = batch.pop("valid", None)           # ragged last batch: padded to the static batch size, only `valid` rows count
         o = model.forward(batch)
         for k in keys:
-            outs[k].append(o[k].detach().float().cpu().numpy() if o[k].dtype.is_floating_point else o[k].cpu().numpy())
+            outs[k].append((o[k].detach().float().cpu().numpy() if o[k].dtype.is_floating_point else o[k].cpu().numpy())[:valid])
         for k in ins:
-            ins[k].append(np.asarray(batch[k]))
+            ins[k].append(np.asarray(batch[k])[:valid])
         if "gt_segmentation" in batch:
-            gts.append(np.asarray(batch["gt_segmentation"]))
+            gts.append(np.asarray(batch["gt_segmentation"])[:valid])
     data = {"inputs": {k: np.concatenate(v) for k, v in ins.items()}, "outputs": {k: np.concatenate(v) for k, v in outs.items()}}
     odir = os.path.join(root, "eval", str(it.global_step))
     os.makedirs(odir, exist_ok=True)
@@ -169,6 +171,7 @@ def evaluate(args):
         res = evalutil.evaluate_parts(data["outputs"]["out_parts_hard"], np.concatenate(gts))
         with open(os.path.join(odir, "iou.yml"), "w") as f:
             yaml.safe_dump({"iou": {int(k): float(v) for k, v in res["iou"].items()}, "overall": res["overall"],
+                            "pooled_iou": {int(k): float(v) for k, v in res["pooled"].items()},
                             "best_remapping": {int(k): int(v) for k, v in res["mapping"].items()}}, f)
     print("[INFO] evaluation outputs written to", odir)
     return data
