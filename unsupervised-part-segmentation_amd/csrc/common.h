@@ -65,9 +65,35 @@ __device__ inline float ups_act(float x, int act, float slope) {
     if (act == UPS_ACT_RELU) return x > 0.f ? x : 0.f;
     return x;
 }
-// branch-free activation for the staging paths: leaky-relu(slope) and relu (slope_eff = 0) share one formula
-__device__ inline float ups_act_ns(float x, float slope_eff) { return fmaf(slope_eff, fminf(x, 0.f), fmaxf(x, 0.f)); }
+// branch-free activation for the staging paths: leaky-relu(slope) and relu (slope_eff = 0) share one formula,
+// max(x, slope * x) for 0 <= slope <= 1 (the launchers check the range): the same product and hence the same bits as
+// x > 0 ? x : slope * x.  v_max_f32 is written out so that no canonicalising max(x, x) is put in front of it.
+__device__ __forceinline__ float ups_vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ inline float ups_act_ns(float x, float slope_eff) { return ups_vmax(x, slope_eff * x); }
 __device__ inline float ups_slope_eff(int act, float slope) { return act == UPS_ACT_LRELU ? slope : 0.f; }
+typedef float ups_f32x2 __attribute__((ext_vector_type(2)));
+// activation-on-load of a 16-byte chunk: 6 VALU per bf16 pair (unpack 2, v_pk_mul_f32, 2 max, v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint4 ups_act_chunk(uint4 u, float s, bf16*) {
+    unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ups_f32x2 x = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+        const ups_f32x2 sx = x * s;
+        w[i] = Chunk<bf16>::pk(ups_vmax(x[0], sx[0]), ups_vmax(x[1], sx[1]));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint4 ups_act_chunk(uint4 u, float s, float*) {
+    float f[4];
+    Chunk<float>::unpack(u, f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = ups_act_ns(f[e], s);
+    return Chunk<float>::pack(f);
+}
 
 __device__ inline float ups_dact(float x, int act, float slope) {
     if (act == UPS_ACT_LRELU) return x > 0.f ? 1.f : slope;

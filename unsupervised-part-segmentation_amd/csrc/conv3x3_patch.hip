@@ -43,7 +43,7 @@ struct PatchK {
     // part-masked input / mask gradient (ups_conv_desc.mask_*): mask_B > 0 switches the block order to (image b, tile, part)
     // with the part fastest, so that the P blocks that read one view patch / write one g_hard line run back to back on one XCD
     const unsigned* mask; float* mask_grad; const float* mask_view;
-    int mask_B, mask_P, mask_shift;
+    int mask_B, mask_P;
 };
 
 __device__ inline int p_dy(unsigned long long off, int t) { return (int)((off >> (4 * t + 2)) & 3) - 1; }
@@ -59,7 +59,9 @@ template <typename T> struct PMma;
 // requested ahead of the current pair's MFMAs, the next tap's A fragments right behind the MFMAs that consumed the current
 // ones (operands are read at issue).
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
-template <int TM16, int TN16>
+// ROWB > 0: the wave's tile rows are ROWB bytes apart in the patch image (one image per tile): fragment i is read at an
+// immediate offset i * ROWB from one per-tap lane address (no address arithmetic per read); ROWB == 0: rows from arow[].
+template <int TM16, int TN16, int ROWB>
 __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsigned char* B, const int (&arow)[TM16],
                                             int po0, int po1, int po2, int sw0, int sw1, int sw2, int b_tap_stride,
                                             f32x4v (&acc)[TM16][TN16]) {
@@ -67,8 +69,14 @@ __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsign
     auto fetch_a = [&](int t) __attribute__((always_inline)) {
         const int po = t == 0 ? po0 : (t == 1 ? po1 : po2);
         const int sw = t == 0 ? sw0 : (t == 1 ? sw1 : sw2);
+        if constexpr (ROWB > 0) {
+            const unsigned char* at = A + (arow[0] + po) + sw;       // uniform part added on the scalar unit, one v_add
 #pragma unroll
-        for (int i = 0; i < TM16; ++i) fa[i] = *(const bf16x8*)(A + arow[i] + po + sw);
+            for (int i = 0; i < TM16; ++i) fa[i] = *(const bf16x8*)(at + i * ROWB);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM16; ++i) fa[i] = *(const bf16x8*)(A + arow[i] + po + sw);
+        }
     };
     auto fetch_b = [&](int t, int jh, int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -90,7 +98,8 @@ __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsign
             for (int i = 0; i < TM16; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
-                    acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[step & 1][jj], acc[i][2 * jh + jj], 0, 0, 0);
+                    // weights as the row operand: a lane then holds 4 CONSECUTIVE channels of one pixel (8-byte epilogue accesses)
+                    acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[step & 1][jj], fa[i], acc[i][2 * jh + jj], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             if (jh + 1 == NP && t + 1 < 3) fetch_a(t + 1);
         }
@@ -178,26 +187,27 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     const T* __restrict__ w = (const T*)p.wgt;
 
     // ---- patch staging: items tid, tid+512, tid+1024 of the 324x4 16-byte chunks
-    // 32-bit BYTE offsets inside the image (an image is < 2 GB), -1 = zero fill; the loads use the uniform image base as
-    // scalar address + this vector offset (no 64-bit vector address arithmetic, 1 VGPR per item)
-    int pa0 = -1, pa1 = -1, pa2 = -1;
-    int sa0, sa1, sa2;      // LDS byte offsets of the staged items (swizzled patch layout)
+    // One tile per image (SUB == TS): ONE dword per item held across the channel loop -- low 16 bits = pixel index relative
+    // to the patch origin in IMAGE pitch (py * w + px; 0xffff = outside the image, zero fill), high 16 bits = LDS byte offset
+    // of the slot (swizzled patch layout).  The load address is a uniform base (image + chunk + patch origin, scalar) plus
+    // rel * row bytes: one v_mad per item and chunk instead of the divisions / bounds tests (the launcher checks
+    // 18 * w < 65535).  Multi-image tiles keep separate 32-bit offsets (one block per CU there, registers are free).
+    unsigned pk0 = 0xffffu, pk1 = 0xffffu, pk2 = 0xffffu;
+    int pa0 = -1, pa1 = -1, pa2 = -2;
+    int sa0 = 0, sa1 = 0, sa2 = 0;
+    const int origin = (ty0 - 1) * p.w + (tx0 - 1);      // may be negative on the top / left edge; valid items never are
+    const bool has2 = tid + 1024 < PPIX * 4;
     if constexpr (SUB == TS) {
-        auto mk = [&](int item) -> int {
-            if (item >= PPIX * 4) return -2;      // no item
+        auto mk = [&](int item) -> unsigned {
+            item = min(item, PPIX * 4 - 1);
             const int pix = item >> 2, ch = item & 3;
             const int py = pix / PW, px = pix - py * PW;
             const int y = ty0 - 1 + py, x = tx0 - 1 + px;
-            if ((unsigned)y >= (unsigned)p.h || (unsigned)x >= (unsigned)p.w) return -1;
-            return ((y * p.w + x) * p.ldi + ch * EPC) * (int)sizeof(T);
+            const unsigned sa = (py * PWPS + px) * APX + ((ch ^ a_swz_t<T>(px)) << 4);
+            const unsigned rel = ((unsigned)y >= (unsigned)p.h || (unsigned)x >= (unsigned)p.w) ? 0xffffu : (unsigned)(py * p.w + px);
+            return (sa << 16) | rel;
         };
-        pa0 = mk(tid); pa1 = mk(tid + 512); pa2 = mk(tid + 1024);
-        auto mk_sa = [&](int item) -> int {
-            const int pix = item >> 2, ch = item & 3;
-            const int py = pix / PW, px = pix - py * PW;
-            return (py * PWPS + px) * APX + ((ch ^ a_swz_t<T>(px)) << 4);
-        };
-        sa0 = mk_sa(tid); sa1 = mk_sa(tid + 512); sa2 = mk_sa(min(tid + 1024, PPIX * 4 - 1));
+        pk0 = mk(tid); pk1 = mk(tid + 512); pk2 = mk(tid + 1024);
     } else {
         // only the 256 interior pixels are ever loaded (2 items per thread); every halo slot stays zero
         auto mk = [&](int item, int& sa) -> int {
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             sa = ((ty + 2 * sy + 1) * PWPS + px) * APX + ((ch ^ a_swz_t<T>(px)) << 4);
             return ((((sy * G + sx) * SUB + ly) * SUB + lx) * p.ldi + ch * EPC) * (int)sizeof(T);
         };
-        pa0 = mk(tid, sa0); pa1 = mk(tid + 512, sa1); pa2 = -2; sa2 = 0;
+        pa0 = mk(tid, sa0); pa1 = mk(tid + 512, sa1);
         for (int i = tid * 16; i < 2 * ABY; i += 512 * 16) *(uint4*)(Abuf + i) = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
     }
@@ -226,60 +236,55 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             int o = off;
             asm volatile("" : "+v"(o));     // keep the 32-bit offset: scalar base (image + chunk) + vector offset addressing
             v = *(const uint4*)((const unsigned char*)(in + koff) + (unsigned)o);
-            // part-masked input (model.py:185): the pixel belongs to this block's part image only where its hard-mask bit is set
-            if (mbits && !((mbits[(unsigned)off >> p.mask_shift] >> part) & 1u)) v = zero4;
         }
 #endif
         return v;
     };
-    // two blocks per CU (128 VGPRs): the six per-thread staging offsets are recomputed once per channel chunk from a
-    // laundered thread index instead of being held across the MFMA loop
-    constexpr bool RECOMP = (OCC == 2) && (SUB == TS) && (sizeof(T) == 2);
-    auto tid_l = [&]() __attribute__((always_inline)) -> int { int t = tid; asm volatile("" : "+v"(t)); return t; };
-    auto mk_g = [&](int item) -> int {          // as mk of the SUB == TS branch
-        if (item >= PPIX * 4) return -2;
-        const int pix = item >> 2, ch = item & 3;
-        const int py = pix / PW, px = pix - py * PW;
-        const int y = ty0 - 1 + py, x = tx0 - 1 + px;
-        if ((unsigned)y >= (unsigned)p.h || (unsigned)x >= (unsigned)p.w) return -1;
-        return ((y * p.w + x) * p.ldi + ch * EPC) * (int)sizeof(T);
-    };
-    auto mk_s = [&](int item) -> int {
-        const int pix = item >> 2, ch = item & 3;
-        const int py = pix / PW, px = pix - py * PW;
-        return (py * PWPS + px) * APX + ((ch ^ a_swz_t<T>(px)) << 4);
+    const T* __restrict__ in_o = in + (long long)origin * p.ldi;
+    const unsigned* __restrict__ mbits_o = mbits ? mbits + origin : nullptr;
+    const unsigned row_b = (unsigned)p.ldi * (unsigned)sizeof(T);
+    auto ld_rel = [&](unsigned pk, int koff) -> uint4 {
+        uint4 v = zero4;
+#if !defined(UPS_ABLATE_GLOAD)
+        asm volatile("" : "+v"(pk));        // derived offsets are recomputed per chunk, not hoisted into held registers
+        const unsigned rel = pk & 0xffffu;
+        if (rel != 0xffffu && koff + cha < p.ci) {
+            // scalar base (image + chunk + origin) + 32-bit vector offset addressing
+            const unsigned o = __umul24(rel, row_b) + (unsigned)(cha * (int)sizeof(T));
+            v = *(const uint4*)((const unsigned char*)(in_o + koff) + o);
+            // part-masked input (model.py:185): the pixel belongs to this block's part image only where its hard-mask bit is set
+            if (mbits_o && !((mbits_o[rel] >> part) & 1u)) v = zero4;
+        }
+#endif
+        return v;
     };
     auto load_patch = [&](int cc) __attribute__((always_inline)) {
         const int koff = cc * BK;
-        if constexpr (RECOMP) {
-            const int t = tid_l();
-            ra0 = ld_a(mk_g(t), koff); ra1 = ld_a(mk_g(t + 512), koff);
-            if (t + 1024 < PPIX * 4) ra2 = ld_a(mk_g(t + 1024), koff);
+        if constexpr (SUB == TS) {
+            ra0 = ld_rel(pk0, koff); ra1 = ld_rel(pk1, koff);
+            if (has2) ra2 = ld_rel(pk2, koff);
         } else {
             ra0 = ld_a(pa0, koff); ra1 = ld_a(pa1, koff);
-            if (pa2 != -2) ra2 = ld_a(pa2, koff);
         }
     };
     auto act_u4 = [&](uint4 u) -> uint4 {
         if (p.act_in != UPS_ACT_NONE) {
-            float f[EPC];
-            Chunk<T>::unpack(u, f);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] = ups_act_ns(f[e], act_ns);
-            u = Chunk<T>::pack(f);
+            u = ups_act_chunk(u, act_ns, (T*)nullptr);
         }
         return u;
     };
     auto store_patch = [&](unsigned char* A) __attribute__((always_inline)) {
-        if constexpr (RECOMP) {
-            const int t = tid_l();
-            *(uint4*)(A + mk_s(t)) = act_u4(ra0);
-            *(uint4*)(A + mk_s(t + 512)) = act_u4(ra1);
-            if (t + 1024 < PPIX * 4) *(uint4*)(A + mk_s(t + 1024)) = act_u4(ra2);
+        if constexpr (SUB == TS) {
+            // one item at a time (the scheduler would otherwise unpack all three chunks at once: 24 more live registers)
+            auto slot = [&](unsigned pk) __attribute__((always_inline)) -> unsigned { asm volatile("" : "+v"(pk)); return pk >> 16; };
+            *(uint4*)(A + slot(pk0)) = act_u4(ra0);
+            __builtin_amdgcn_sched_barrier(0);
+            *(uint4*)(A + slot(pk1)) = act_u4(ra1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has2) *(uint4*)(A + slot(pk2)) = act_u4(ra2);
         } else {
             *(uint4*)(A + sa0) = act_u4(ra0);
             *(uint4*)(A + sa1) = act_u4(ra1);
-            if (pa2 != -2) *(uint4*)(A + sa2) = act_u4(ra2);
         }
     };
     // weights of tap-row g (taps 3g..3g+2), chunk cc: item -> (tap_local, row, ch)
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
             const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
             const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
-            bf16_taps16<TM16, TN16>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
+            bf16_taps16<TM16, TN16, (SUB == TS ? PWPS * APX : 0)>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
             if (n1 < total && n1 % 3 == 0) {
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
             const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
             const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
-            bf16_taps16<TM16, TN16>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
+            bf16_taps16<TM16, TN16, (SUB == TS ? PWPS * APX : 0)>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
 #if !defined(UPS_ABLATE_LSTORE)
@@ -565,54 +570,76 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 }
                 __syncthreads();
             }
-            // Accumulator element e of acc16[i][j], lane (p16 = lane & 15, q16 = lane >> 4), is tile pixel row wm*TM16 + i,
-            // column 4*q16 + e, channel (wn*TN16 + j)*16 + p16 of the N-tile.  The CoordConv term of an interior pixel (all
-            // nine taps valid) is affine in (x, y): it is folded with the bias into 4 per-column x terms and one y term per
-            // tile row (2 adds per element); only tiles that touch the image border look the class table up, and only for
-            // their border pixels.
-            const int x4 = 4 * q16;
+            // Accumulator element e of acc16[i][j], lane (p16 = lane & 15, q16 = lane >> 4), is tile pixel (row wm*TM16 + i,
+            // column p16), channel (wn*TN16 + j)*16 + 4*q16 + e of the N-tile: 4 consecutive channels per lane, so the
+            // residual comes in and the result goes out with one 8-byte LDS access per (i, j).  The CoordConv term of an
+            // interior pixel (all nine taps valid) is affine in (x, y): its x part is folded with the bias into one term per
+            // channel, the y part is one multiply-add; only tiles that touch the image border look the class table up, and
+            // only for their border pixels.
             // (multi-image tiles: every pixel takes the class-table path; the folded terms are then unused)
             const bool border_tile = p.coord_tab && (SUB < TS || ty0 == 0 || ty0 + TS >= p.h || tx0 == 0 || tx0 + TS >= p.w);
-            const float xf0 = (float)(tx0 + x4);
+            const float xf = (float)(tx0 + p16);
+            const int xq = xcoord(p16);
+            const int xm = (xq > 0 ? 1 : 0) | 2 | (xq + 1 < p.w ? 4 : 0);
 #pragma unroll
             for (int j = 0; j < TN16; ++j) {
-                const int cl = (wn * TN16 + j) * 16 + p16;
+                const int cl = (wn * TN16 + j) * 16 + 4 * q16;
                 const int col = nt * BN + cl;
-                const bool cvalid = col < p.co;
-                if (col >= p.co_fill) continue;
-                const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
-                float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-                if (cvalid && p.coord_tab) {
-                    const float* tb = p.coord_tab + (long long)63 * 3 * p.co + col;
-                    t0 = tb[0]; t1 = tb[p.co]; t2 = tb[2 * p.co];
-                }
-                float xs[4];
+                if (col >= p.co_fill) continue;          // co_fill is a multiple of 8: the 4 channels go together
+                float xs[4], t2v[4];
+                bool cv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xs[e] = fmaf(xf0 + (float)e, t1, bias + t0);
-                const unsigned dbit = 1u << (cl & 7);
+                for (int e = 0; e < 4; ++e) {
+                    cv[e] = col + e < p.co;
+                    const float bias = (cv[e] && p.bias) ? p.bias[col + e] : 0.f;
+                    float t0 = 0.f, t1 = 0.f;
+                    t2v[e] = 0.f;
+                    if (cv[e] && p.coord_tab) {
+                        const float* tb = p.coord_tab + (long long)63 * 3 * p.co + col + e;
+                        t0 = tb[0]; t1 = tb[p.co]; t2v[e] = tb[2 * p.co];
+                    }
+                    xs[e] = fmaf(xf, t1, bias + t0);
+                }
+                const int dsh = cl & 4;                  // the lane's 4 sign bits inside the tile's derivative byte
 #pragma unroll
                 for (int i = 0; i < TM16; ++i) {
                     const int yrow = wm * TM16 + i;
-                    const float ys = (float)(ty0 + yrow) * t2;
+                    const int px = yrow * 16 + p16;
+                    float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int pxc = x4 + e;
-                        const int px = yrow * 16 + pxc;
-                        float v = acc16[i][j][e] + xs[e] + ys;
+                    for (int e = 0; e < 4; ++e) v[e] = acc16[i][j][e] + xs[e];
+                    if (p.coord_tab) {
+                        const float yf = (float)(ty0 + yrow);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += yf * t2v[e];
                         if (border_tile) {
-                            const int y = ycoord(yrow), x = xcoord(pxc);
+                            const int y = ycoord(yrow);
                             const int ym = (y > 0 ? 1 : 0) | 2 | (y + 1 < p.h ? 4 : 0);
-                            const int xm = (x > 0 ? 1 : 0) | 2 | (x + 1 < p.w ? 4 : 0);
-                            if (((ym & xm) != 7 || SUB < TS) && cvalid) {
-                                const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
-                                v = acc16[i][j][e] + bias + (tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co]);
+                            if ((ym & xm) != 7 || SUB < TS) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (!cv[e]) continue;
+                                    const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col + e;
+                                    const float bias = p.bias ? p.bias[col + e] : 0.f;
+                                    v[e] = acc16[i][j][e] + bias + (tb[0] + (float)xq * tb[p.co] + (float)y * tb[2 * p.co]);
+                                }
                             }
                         }
-                        if (dact) v *= (R1[px * CPR + (cl >> 3)] & dbit) ? 1.f : dact_ns;
-                        if (res) v += (float)*(const bf16*)(R0 + px * ERS + cl * 2);
-                        if (!cvalid) v = 0.f;
-                        *(bf16*)(R0 + px * ERS + cl * 2) = (bf16)v;
                     }
+                    if (dact) {
+                        const unsigned db = (unsigned)R1[px * CPR + (cl >> 3)] >> dsh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= (db >> e) & 1u ? 1.f : dact_ns;
+                    }
+                    uint2* slot = (uint2*)(R0 + px * ERS + cl * 2);
+                    if (res) {
+                        const uint2 rv = *slot;
+                        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+                        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (!cv[e]) v[e] = 0.f;
+                    *slot = make_uint2(Chunk<bf16>::pk(v[0], v[1]), Chunk<bf16>::pk(v[2], v[3]));
                 }
             }
             __syncthreads();
@@ -639,45 +666,53 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         }
     }
 
-    // per-element epilogue (fp32 mode, fp32 outputs, unaligned channel counts).  blocks x elements of the accumulator layout:
-    // fp32 path 32x32 blocks (16 elements per lane), bf16 path 16x16 blocks (4 elements per lane)
-    constexpr int NBM = sizeof(T) == 2 ? TM16 : TM, NBN = sizeof(T) == 2 ? TN16 : TN, NEL = sizeof(T) == 2 ? 4 : 16;
-#pragma unroll
-    for (int tn = 0; tn < NBN; ++tn) {
-        const int col = sizeof(T) == 2 ? nt * BN + (wn * TN16 + tn) * 16 + p16 : nt * BN + (wn * TN + tn) * 32 + (lane & 31);
+    // per-element epilogue (fp32 mode, fp32 outputs, unaligned channel counts).  fp32 path: 32x32 accumulator blocks, element e
+    // of lane l = pixel rr(e, l >> 5) of the block, channel l & 31; bf16 path: 16x16 blocks, element e = channel 4*q16 + e of
+    // pixel column p16 (see above)
+    auto emit = [&](float a, int tyq, int txq, int col, float bias) __attribute__((always_inline)) {
         const bool cvalid = col < p.co;
-        if (col >= p.co_fill) continue;
-        const float bias = (cvalid && p.bias) ? p.bias[col] : 0.f;
+        const int y = ycoord(tyq), x = xcoord(txq);
+        const long long pix = gpix(tyq * 16 + txq);
+        float v = 0.f;
+        if (cvalid) {
+            v = a + bias;
+            if (p.coord_tab) {
+                const int ym = (y > 0 ? 1 : 0) | 2 | (y + 1 < p.h ? 4 : 0);
+                const int xm = (x > 0 ? 1 : 0) | 2 | (x + 1 < p.w ? 4 : 0);
+                const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
+                v += tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co];
+            }
+            if (dact) v *= (ld_as_float<T>(dact + pix * p.ldd + col) > 0.f) ? 1.f : dact_ns;
+            if (res) v += ld_as_float<T>(res + pix * p.ldr + col);
+        }
+        if (p.out_f32) outF[pix * p.ldo + col] = v;
+        else st_from_float<T>(outT + pix * p.ldo + col, v);
+    };
+    if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int tm = 0; tm < NBM; ++tm) {
+        for (int tn = 0; tn < TN16; ++tn) {
 #pragma unroll
-            for (int e = 0; e < NEL; ++e) {
-                int tyq, txq;
-                float a;
-                if constexpr (sizeof(T) == 2) {
-                    tyq = wm * TM16 + tm; txq = 4 * q16 + e;
-                    a = acc16[tm][tn][e];
-                } else {
+            for (int e = 0; e < 4; ++e) {
+                const int col = nt * BN + (wn * TN16 + tn) * 16 + 4 * q16 + e;
+                if (col >= p.co_fill) continue;
+                const float bias = (col < p.co && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int tm = 0; tm < TM16; ++tm) emit(acc16[tm][tn][e], wm * TM16 + tm, p16, col, bias);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = nt * BN + (wn * TN + tn) * 32 + (lane & 31);
+            if (col >= p.co_fill) continue;
+            const float bias = (col < p.co && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
                     const int rr = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    tyq = (wm * TM + tm) * 2 + (rr >> 4); txq = rr & 15;
-                    a = acc[tm][tn][e];
+                    emit(acc[tm][tn][e], (wm * TM + tm) * 2 + (rr >> 4), rr & 15, col, bias);
                 }
-                const int y = ycoord(tyq), x = xcoord(txq);
-                const long long pix = gpix(tyq * 16 + txq);
-                float v = 0.f;
-                if (cvalid) {
-                    v = a + bias;
-                    if (p.coord_tab) {
-                        const int ym = (y > 0 ? 1 : 0) | 2 | (y + 1 < p.h ? 4 : 0);
-                        const int xm = (x > 0 ? 1 : 0) | 2 | (x + 1 < p.w ? 4 : 0);
-                        const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
-                        v += tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co];
-                    }
-                    if (dact) v *= (ld_as_float<T>(dact + pix * p.ldd + col) > 0.f) ? 1.f : dact_ns;
-                    if (res) v += ld_as_float<T>(res + pix * p.ldr + col);
-                }
-                if (p.out_f32) outF[pix * p.ldo + col] = v;
-                else st_from_float<T>(outT + pix * p.ldo + col, v);
             }
         }
     }
@@ -754,6 +789,8 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox)
         return 1;
     if (d->hi != d->ho || d->wi != d->wo || d->out_h != d->ho || d->out_w != d->wo) return 1;
+    // 16-bit image-pitch pixel index of a staged item, 24-bit row pitch for its v_mad_u32_u24
+    if ((long long)(TS + 2) * d->wi >= 0xffff || (long long)d->ldi * 4 >= (1 << 24)) return 1;
     const bool small = d->hi == d->wi && (d->hi == 8 || d->hi == 4) && d->n % ((TS / d->hi) * (TS / d->hi)) == 0;
     {
         static int small_on = -1;
@@ -772,18 +809,13 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     }
     PatchK k;
     k.mask = d->mask_bits; k.mask_grad = d->mask_grad; k.mask_view = d->mask_view;
-    k.mask_B = 0; k.mask_P = 1; k.mask_shift = 0;
+    k.mask_B = 0; k.mask_P = 1;
     if (d->mask_bits || d->mask_grad) {
-        // part mode: bf16, one image per tile, staged epilogue; the masked load recovers the pixel index from the byte offset
+        // part mode: bf16, one image per tile, staged epilogue
         if (d->dtype != UPS_BF16 || small || d->mask_batch <= 0 || d->n % d->mask_batch) return 1;
         if (d->mask_bits && d->mask_grad) return 1;
         k.mask_B = d->mask_batch; k.mask_P = d->n / d->mask_batch;
         if (k.mask_P > 32) return 1;
-        if (d->mask_bits) {
-            const int row_bytes = d->ldi * 2;
-            if (row_bytes & (row_bytes - 1)) return 1;
-            while ((1 << k.mask_shift) < row_bytes) ++k.mask_shift;
-        }
         if (d->mask_grad && (!d->mask_view || d->out_f32 || (d->ldo & 7) || (d->co_fill & 7) || d->co_fill > 32 || d->res || d->dact)) return 1;
     }
     k.n = d->n; k.h = d->hi; k.w = d->wi; k.ci = d->ci; k.ldi = d->ldi; k.co = d->co; k.co_fill = d->co_fill;

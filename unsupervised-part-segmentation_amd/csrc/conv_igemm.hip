@@ -178,11 +178,7 @@ __global__ __launch_bounds__(256, (CPS == 1 ? 3 : 2)) void conv_igemm_kernel(con
     };
     auto act_u4 = [&](uint4 u) __attribute__((always_inline)) -> uint4 {
         if (p.act_in != UPS_ACT_NONE) {
-            float f[EPC];
-            Chunk<T>::unpack(u, f);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] = ups_act_ns(f[e], act_ns);
-            u = Chunk<T>::pack(f);
+            u = ups_act_chunk(u, act_ns, (T*)nullptr);
         }
         return u;
     };
@@ -444,6 +440,7 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d->in && d->w && (d->out || d->mask_grad));
     UPS_CHECK_ARG(d->ci > 0 && d->ci % 8 == 0 && d->ldi % 8 == 0 && d->ci <= d->ldi);
     UPS_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= 9);
+    UPS_CHECK_ARG(d->act_slope >= 0.f && d->act_slope <= 1.f);    // activation-on-load is max(x, slope * x)
     UPS_CHECK_ARG(d->co >= 1 && d->co_fill >= d->co && d->co_fill <= d->ldo);
     UPS_CHECK_ARG(d->n > 0 && d->ho > 0 && d->wo > 0 && d->hi > 0 && d->wi > 0);
     UPS_CHECK_ARG(!d->coord_tab || (d->kh * d->kw == d->ntaps && d->kh <= 3 && d->kw <= 3));

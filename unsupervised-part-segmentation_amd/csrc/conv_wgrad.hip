@@ -130,11 +130,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int 
     };
     auto act_u4 = [&](uint4 u) -> uint4 {
         if (p.act_in != UPS_ACT_NONE) {
-            float f[EPC];
-            Chunk<T>::unpack(u, f);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] = ups_act_ns(f[e], act_ns);
-            u = Chunk<T>::pack(f);
+            u = ups_act_chunk(u, act_ns, (T*)nullptr);
         }
         return u;
     };
@@ -356,6 +352,7 @@ extern "C" int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream) {
     UPS_CHECK_ARG(d->ci > 0 && d->ci % 8 == 0 && d->ldi % 8 == 0 && d->ci <= d->ldi && d->ldo % 8 == 0);
     UPS_CHECK_ARG(d->ci_log >= 1 && d->ci_log <= d->ci && d->cin_v >= d->ci_log);
     UPS_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= 9 && d->splitk >= 1);
+    UPS_CHECK_ARG(d->act_slope >= 0.f && d->act_slope <= 1.f);    // activation-on-load is max(x, slope * x)
     UPS_CHECK_ARG(((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->dout & 15) == 0);
     const long long M = (long long)d->n * d->ho * d->wo;
     UPS_CHECK_ARG(M > 0 && M <= 0x7fffffffLL);

@@ -47,23 +47,57 @@ __device__ inline bf16x8 tr_frag3(const unsigned char* tile, int rs, int row0, i
     return u.b;
 }
 
+// D-tile swizzle: the dout tile is written by LDS-DMA, which fills 64 lanes x 16 B contiguously, so its rows are unpadded
+// (BN * 2 bytes).  The transposing fragment read touches 4 consecutive rows x one 64-byte block per LDS cycle; the block
+// index is XORed with a function of the row so that those four windows fall into different 64-byte bank quarters.
+template <int BN> __device__ __forceinline__ int d_swz(int row) {
+    if constexpr (BN == 128) return row & 3;
+    else if constexpr (BN == 64) return (row >> 1) & 1;
+    else return 0;
+}
+
+// dout fragment of tile row block row0 (multiple of 16), 32-channel block wco: as tr_frag3 on the swizzled unpadded tile
+template <int BN>
+__device__ inline bf16x8 tr_frag_d(const unsigned char* tile, int row0, int wco, int lane) {
+    constexpr int RS = BN * 2;
+    const int g = lane >> 4, i = lane & 15, h = g >> 1, q = i >> 2, pp = i & 3;
+    const int row = row0 + 8 * h + q;
+    const unsigned char* a0 = tile + row * RS + ((wco ^ d_swz<BN>(row)) << 6) + 32 * (g & 1) + 8 * pp;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds3_s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds3_s16x4*)(a0 + 4 * RS));     // d_swz(row + 4) == d_swz(row)
+    union { s16x4 s[2]; bf16x8 b; } u;
+    u.s[0] = lo; u.s[1] = hi;
+    return u.b;
+}
+
 template <int CB, int BN>
-__global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const int cit, const int cot) {
+__global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const int cit, const int cot, const int nsplit) {
     constexpr int WCI = CB / 32, WCO = BN / 32, WK = 8 / (WCI * WCO);
-    constexpr int RSX = lds_stride3(CB * 2), RSD = lds_stride3(BN * 2);
+    constexpr int RSX = lds_stride3(CB * 2), RSD = BN * 2;
     constexpr int XB = PPIX * RSX, DB = TH * TW * RSD;
     constexpr int CPX = CB / 8, CPD = BN / 8;                 // 16-byte chunks per row
-    constexpr int NX = (PPIX * CPX + 511) / 512, ND = (TH * TW * CPD + 511) / 512;
-    static_assert(NX <= 3 && ND <= 4, "staging register budget");
+    constexpr int NX = (PPIX * CPX + 511) / 512;              // X items per thread: 3 / 2
+    constexpr int NWD = TH * TW * CPD / 512;                  // dout DMA wave-instructions per wave and unit: 4 / 2 / 1
+    static_assert(NX <= 3 && NWD >= 1, "staging layout");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Xbuf = smem;                 // 2 x XB
     unsigned char* Dbuf = smem + 2 * XB;        // 2 x DB
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float act_ns = ups_slope_eff(p.act_in, p.act_slope);   // branch-free activation-on-load
-    const int cot_i = blockIdx.x % cot, cit_i = blockIdx.x / cot;
-    const int split = blockIdx.y;
+    // XCD-aware order: the cit * cot blocks that walk the SAME units (one K split) sit on one XCD, so the X / dout slices
+    // they share are fetched from HBM once and served to the others by that XCD's L2 (blocks are dealt round-robin over
+    // the 8 XCDs; dealt by (pair, split) every block of a split would land on a different one)
+    const int pairs = cit * cot;
+    int pair = blockIdx.x % pairs, split = blockIdx.x / pairs;
+    if ((nsplit & 7) == 0) {
+        const int j = blockIdx.x >> 3;
+        pair = j % pairs;
+        split = (j / pairs) * 8 + (blockIdx.x & 7);
+    }
+    const int cot_i = pair % cot, cit_i = pair / cot;
     const int w_ci = wid % WCI, w_co = (wid / WCI) % WCO, w_k = wid / (WCI * WCO);
     const int ci0 = cit_i * CB, co0 = cot_i * BN;
     const bf16* __restrict__ in = (const bf16*)p.in;
@@ -73,7 +107,38 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
     const int u_begin = split * p.units_per;
     const int u_end = min(p.units_total, u_begin + p.units_per);
 
-    uint4 rx0, rx1, rx2, rd0, rd1, rd2, rd3;
+    // ---- staging.  Everything that depends only on the thread is decoded once; a unit contributes scalar bases.
+    // X (input halo patch, activation-on-load): item k = tid + 512 k -> patch pixel (py, px), 16-byte chunk cc.
+    //   xr[k]  pixel index relative to the patch origin in IMAGE pitch (py * w + px)
+    //   xs[k]  LDS byte offset of the slot | edge flags << 16 (bit 0 top halo row, 1 bottom, 2 left column, 3 right,
+    //          4 = never valid: past the item count or the channel count)
+    unsigned xr[NX], xs[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int item = min(tid + 512 * k, PPIX * CPX - 1);
+        const int pix = item / CPX, cc = item - pix * CPX;
+        const int py = pix / PWID, px = pix - py * PWID;
+        unsigned fl = (py == 0 ? 1u : 0u) | (py == PROWS - 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == PWID - 1 ? 8u : 0u);
+        if (tid + 512 * k >= PPIX * CPX || ci0 + cc * 8 >= p.ci) fl |= 16u;
+        xr[k] = (unsigned)(py * p.w + px);
+        xs[k] = (unsigned)(pix * RSX + cc * 16) | (fl << 16);
+    }
+    const unsigned x_rowb = (unsigned)p.ldi * 2u;                     // bytes per pixel of the input
+    const unsigned x_chb = (unsigned)(ci0 + (tid % CPX) * 8) * 2u;    // 512 % CPX == 0: one chunk column per thread
+    // dout tile by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write): wave-instruction j = wid + 8 q fills the LDS
+    // slots j*64 + lane (16 B each) of the unpadded tile; slot (row, s) receives chunk s ^ (d_swz(row) << 2) (source-side
+    // swizzle).  dd[q] = the lane's byte offset from the unit's first dout pixel.
+    unsigned dd[NWD];
+#pragma unroll
+    for (int q = 0; q < NWD; ++q) {
+        const int L = (wid + 8 * q) * 64 + lane, row = L / CPD, sl = L - row * CPD;
+        const int c = sl ^ (d_swz<BN>(row) << 2);
+        const int ch = min(co0 + c * 8, p.ldo - 8);                   // channels past ldo: a valid duplicate (never stored)
+        dd[q] = (unsigned)((((row >> 4) * p.w + (row & 15)) * p.ldo + ch) * 2);
+    }
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    uint4 rx[NX];
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 
     auto unit_origin = [&](int u, int& img, int& y0, int& x0) {
@@ -84,70 +149,48 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
         img = t / p.tiles_y;
         y0 = ty * 16 + half * TH; x0 = tx * TW;
     };
-    auto ld_x = [&](int item, int img, int y0, int x0) -> uint4 {
-        uint4 v = zero4;
-        if (item < PPIX * CPX) {
-            const int pix = item / CPX, cc = item - pix * CPX;
-            const int py = pix / PWID, px = pix - py * PWID;
-            const int y = y0 - 1 + py, x = x0 - 1 + px, ch = ci0 + cc * 8;
-            if ((unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w && ch < p.ci) {
-                if (p.mask) {      // part image p * B + b = view image b where bit p of the hard-mask bit set is on (model.py:185)
-                    const int b = img % p.mask_B, part = img / p.mask_B;
-                    const long long q = ((long long)b * p.h + y) * p.w + x;
-                    if ((p.mask[q] >> part) & 1u) v = *(const uint4*)(in + q * p.ldi + ch);
-                } else {
-                    v = *(const uint4*)(in + (((long long)img * p.h + y) * p.w + x) * p.ldi + ch);
-                }
-            }
-        }
-        return v;
-    };
-    auto ld_d = [&](int item, int img, int y0, int x0) -> uint4 {
-        uint4 v = zero4;
-        if (item < TH * TW * CPD) {
-            const int pix = item / CPD, cc = item - pix * CPD;
-            const int y = y0 + (pix >> 4), x = x0 + (pix & 15), ch = co0 + cc * 8;
-            if (ch < p.ldo) v = *(const uint4*)(dout + (((long long)img * p.h + y) * p.w + x) * p.ldo + ch);
-        }
-        return v;
-    };
-    auto load_unit = [&](int u) {
+    // global loads of unit u: X into registers, dout straight into D buffer `buf`
+    auto load_unit = [&](int u, int buf) __attribute__((always_inline)) {
         int img, y0, x0;
         unit_origin(u, img, y0, x0);
-        rx0 = ld_x(tid, img, y0, x0);
-        if (NX > 1) rx1 = ld_x(tid + 512, img, y0, x0);
-        if (NX > 2) rx2 = ld_x(tid + 1024, img, y0, x0);
-        rd0 = ld_d(tid, img, y0, x0);
-        if (ND > 1) rd1 = ld_d(tid + 512, img, y0, x0);
-        if (ND > 2) rd2 = ld_d(tid + 1024, img, y0, x0);
-        if (ND > 3) rd3 = ld_d(tid + 1536, img, y0, x0);
-    };
-    auto act_u4 = [&](uint4 u) -> uint4 {
-        if (p.act_in != UPS_ACT_NONE) {
-            float f[8];
-            Chunk<bf16>::unpack(u, f);
+        const unsigned edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.h ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == p.w ? 8u : 0u) | 16u;
+        // part-masked input (ups_wgrad_desc.mask_*): image = part * B + b reads view image b where bit `part` is set
+        const int img_x = p.mask ? img % p.mask_B : img;
+        const int part = p.mask ? img / p.mask_B : 0;
+        const long long org = ((long long)img_x * p.h + (y0 - 1)) * p.w + (x0 - 1);     // patch origin (may lie before the tensor)
+        const unsigned char* xb = (const unsigned char*)(in + org * p.ldi);
+        const unsigned* mb = p.mask ? p.mask + org : nullptr;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = ups_act_ns(f[e], act_ns);
-            u = Chunk<bf16>::pack(f);
+        for (int k = 0; k < NX; ++k) {
+            unsigned r = xr[k], f = xs[k];
+            asm volatile("" : "+v"(r), "+v"(f));      // per-unit address arithmetic stays inside the loop (no hoisted copies)
+            uint4 v = zero4;
+            if (((f >> 16) & edge) == 0u) {
+                v = *(const uint4*)(xb + (__umul24(r, x_rowb) + x_chb));
+                if (mb && !((mb[r] >> part) & 1u)) v = zero4;
+            }
+            rx[k] = v;
         }
-        return u;
+        const unsigned char* db = (const unsigned char*)(dout + (((long long)img * p.h + y0) * p.w + x0) * p.ldo);
+#pragma unroll
+        for (int q = 0; q < NWD; ++q) {
+            const unsigned lds_dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(2 * XB + buf * DB + (wid + 8 * q) * 1024));
+            // inline asm: see conv3x3_patch.hip (the builtin makes hipcc wait lgkmcnt(0) before every later LDS use)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(lds_dst), "v"(dd[q]), "s"(db) : "memory", "m0");
+        }
     };
-    auto st_x = [&](unsigned char* X, int item, uint4 v) {
-        if (item < PPIX * CPX) { const int pix = item / CPX, cc = item - pix * CPX; *(uint4*)(X + pix * RSX + cc * 16) = act_u4(v); }
-    };
-    auto st_d = [&](unsigned char* D, int item, uint4 v) {
-        if (item < TH * TW * CPD) { const int pix = item / CPD, cc = item - pix * CPD; *(uint4*)(D + pix * RSD + cc * 16) = v; }
-    };
-    auto store_unit = [&](int buf) {
+    auto store_unit = [&](int buf) __attribute__((always_inline)) {
         unsigned char* X = Xbuf + buf * XB;
-        unsigned char* D = Dbuf + buf * DB;
-        st_x(X, tid, rx0);
-        if (NX > 1) st_x(X, tid + 512, rx1);
-        if (NX > 2) st_x(X, tid + 1024, rx2);
-        st_d(D, tid, rd0);
-        if (ND > 1) st_d(D, tid + 512, rd1);
-        if (ND > 2) st_d(D, tid + 1024, rd2);
-        if (ND > 3) st_d(D, tid + 1536, rd3);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            unsigned f = xs[k];
+            asm volatile("" : "+v"(f));
+            uint4 v = rx[k];
+            if (p.act_in != UPS_ACT_NONE) v = ups_act_chunk(v, act_ns, (bf16*)nullptr);
+            if (k + 1 < NX || tid + 512 * k < PPIX * CPX) *(uint4*)(X + (f & 0xffffu)) = v;
+            __builtin_amdgcn_sched_barrier(0);        // one item at a time (register pressure)
+        }
     };
 
     f32x16 acc[9];
@@ -157,17 +200,18 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     float bsum = 0.f;        // bias gradient: column sums straight from the dout fragments (k = 8*(lane>>5)+j, col = lane&31)
 
-    if (u_begin < u_end) { load_unit(u_begin); store_unit(0); }
+    if (u_begin < u_end) { load_unit(u_begin, 0); store_unit(0); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int u = u_begin; u < u_end; ++u) {
         const int buf = (u - u_begin) & 1;
-        if (u + 1 < u_end) load_unit(u + 1);
+        if (u + 1 < u_end) load_unit(u + 1, buf ^ 1);
         const unsigned char* X = Xbuf + buf * XB;
         const unsigned char* D = Dbuf + buf * DB;
 #pragma unroll 1
         for (int kk = 0; kk < TH / WK; ++kk) {
             const int ks = w_k + kk * WK;                               // tile row handled by this wave
-            const bf16x8 b = tr_frag3(D, RSD, ks * TW, w_co * 32, lane);
+            const bf16x8 b = tr_frag_d<BN>(D, ks * TW, w_co, lane);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int row0 = (ks + g_dy(p.tap_off, t) + 1) * PWID + g_dx(p.tap_off, t) + 1;
@@ -180,6 +224,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
             }
         }
         if (u + 1 < u_end) store_unit(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA of the next dout tile has landed
         __syncthreads();
     }
 
@@ -252,15 +297,17 @@ bool eligible(const ups_wgrad_desc* d) {
 
 template <int CB, int BN>
 int launch3(const Wg3K& k, int cit, int cot, int splitk, hipStream_t s) {
-    constexpr int RSX = lds_stride3(CB * 2), RSD = lds_stride3(BN * 2);
-    const size_t shmem = 2 * (size_t)(PPIX * RSX + TH * TW * RSD);
+    constexpr int RSX = lds_stride3(CB * 2), RSD = BN * 2;
+    size_t shmem = 2 * (size_t)(PPIX * RSX + TH * TW * RSD);
+    constexpr size_t red = (size_t)(8 / ((CB / 32) * (BN / 32)) - 1) * (CB / 32) * (BN / 32) * 4096;   // K-part reduction scratch
+    if (shmem < red) shmem = red;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<CB, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shmem) != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wgrad3x3_kernel<CB, BN>), dim3(cit * cot, splitk), dim3(512), shmem, s, k, cit, cot);
+    hipLaunchKernelGGL((conv_wgrad3x3_kernel<CB, BN>), dim3(cit * cot * splitk), dim3(512), shmem, s, k, cit, cot, splitk);
     return UPS_OK;
 }
 
@@ -276,6 +323,7 @@ int ups_wgrad3x3_plan(const ups_wgrad_desc* d, int* splitk, int* slabs) {
     int sk = ups_cdiv((v.cb == 64 && v.bn == 128) ? 256 : 512, pairs);
     if (sk > units / 4) sk = units / 4 > 0 ? units / 4 : 1;
     if (sk > 256) sk = 256;
+    if (sk >= 8) sk &= ~7;                          // whole splits per XCD (see the block order in the kernel)
     *splitk = sk;
     *slabs = sk;                                   // the K-parts of a block are reduced in LDS
     return 0;
