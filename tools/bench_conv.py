@@ -17,6 +17,7 @@ CASES = [
     ("dv_rb128", 128, 128, 256, 256, 3, 1, True, "leaky_relu"),
     ("dv_rb64", 128, 64, 256, 256, 3, 1, True, "leaky_relu"),
     ("dv_rb32", 128, 32, 256, 256, 3, 1, True, "leaky_relu"),
+    ("dv_rb16", 128, 16, 256, 256, 3, 1, True, "leaky_relu"),
     ("dv_out", 128, 128, 256, 10, 3, 1, True, None),
     ("ea_in", 640, 128, 3, 32, 3, 1, False, None),
     ("ea_rb0", 640, 128, 32, 32, 3, 1, False, "leaky_relu"),

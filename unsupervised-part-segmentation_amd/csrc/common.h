@@ -77,16 +77,23 @@ __device__ inline float ups_act_ns(float x, float slope_eff) { return ups_vmax(x
 __device__ inline float ups_slope_eff(int act, float slope) { return act == UPS_ACT_LRELU ? slope : 0.f; }
 typedef float ups_f32x2 __attribute__((ext_vector_type(2)));
 // activation-on-load of a 16-byte chunk: 6 VALU per bf16 pair (unpack 2, v_pk_mul_f32, 2 max, v_cvt_pk_bf16_f32)
+// TIGHT: leave the pack order to the compiler (its interleaved form costs 8 more VALU per chunk but peaks at fewer live
+// registers: the 128-wide patch kernel at two blocks per CU has none to spare)
+template <bool TIGHT = false>
 __device__ __forceinline__ uint4 ups_act_chunk(uint4 u, float s, bf16*) {
     unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         ups_f32x2 x = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
         const ups_f32x2 sx = x * s;
-        w[i] = Chunk<bf16>::pk(ups_vmax(x[0], sx[0]), ups_vmax(x[1], sx[1]));
+        const float lo = ups_vmax(x[0], sx[0]), hi = ups_vmax(x[1], sx[1]);
+        // written out: the vectoriser otherwise converts (lo, lo) / (hi, hi) pairs of two words and re-interleaves them
+        if constexpr (TIGHT) w[i] = Chunk<bf16>::pk(lo, hi);
+        else asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[i]) : "v"(lo), "v"(hi));
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
+template <bool TIGHT = false>
 __device__ __forceinline__ uint4 ups_act_chunk(uint4 u, float s, float*) {
     float f[4];
     Chunk<float>::unpack(u, f);

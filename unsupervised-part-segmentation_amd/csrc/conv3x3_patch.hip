@@ -44,7 +44,18 @@ struct PatchK {
     // with the part fastest, so that the P blocks that read one view patch / write one g_hard line run back to back on one XCD
     const unsigned* mask; float* mask_grad; const float* mask_view;
     int mask_B, mask_P;
+    // block index decode without integer divisions: n / d = umulhi(n, m) for n * d < 2^32 (launcher; m = 0: plain division)
+    unsigned m_ntn, m_parts, m_tx, m_ty;
 };
+
+__device__ __forceinline__ int fast_div(int n, int d, unsigned m) {
+    if (d == 1) return n;
+    return m ? (int)__umulhi((unsigned)n, m) : n / d;
+}
+static inline unsigned div_magic(long long n_max, int d) {
+    if (d <= 1 || n_max * d >= (1ll << 32)) return 0u;
+    return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d);
+}
 
 __device__ inline int p_dy(unsigned long long off, int t) { return (int)((off >> (4 * t + 2)) & 3) - 1; }
 __device__ inline int p_dx(unsigned long long off, int t) { return (int)((off >> (4 * t)) & 3) - 1; }
@@ -171,13 +182,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     // one XCD's L2 (blocks are dealt round-robin over the 8 XCDs)
     int bid = blockIdx.x;
     if ((nblocks & 7) == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
-    const int nt = bid % ntn;
-    int t = bid / ntn;
+    int t = fast_div(bid, ntn, p.m_ntn);
+    const int nt = bid - t * ntn;
     int part = 0;
-    if (p.mask_B > 0) { part = t % p.mask_P; t /= p.mask_P; }
-    const int tx0 = (t % tiles_x) * TS; t /= tiles_x;
-    const int ty0 = (t % tiles_y) * TS;
-    const int img = (t / tiles_y) * (G * G);     // first image of the tile (part mode: the view image b)
+    if (p.mask_B > 0) { const int q = fast_div(t, p.mask_P, p.m_parts); part = t - q * p.mask_P; t = q; }
+    const int t1 = fast_div(t, tiles_x, p.m_tx), t2 = fast_div(t1, tiles_y, p.m_ty);
+    const int tx0 = (t - t1 * tiles_x) * TS;
+    const int ty0 = (t1 - t2 * tiles_y) * TS;
+    const int img = t2 * (G * G);                // first image of the tile (part mode: the view image b)
     const int img_pm = p.mask_B > 0 ? part * p.mask_B + img : img;      // part-major image p * B + b
     const int img_in = p.mask ? img : img_pm;    // masked forward reads the view; the mask-gradient pass reads d(out) of part image
     const int wm = wid / WN, wn = wid % WN;
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     };
     auto act_u4 = [&](uint4 u) -> uint4 {
         if (p.act_in != UPS_ACT_NONE) {
-            u = ups_act_chunk(u, act_ns, (T*)nullptr);
+            u = ups_act_chunk<(OCC == 2 && BN == 128)>(u, act_ns, (T*)nullptr);
         }
         return u;
     };
@@ -528,12 +540,16 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     float* __restrict__ outF = (float*)p.out;
     const T* __restrict__ res = (const T*)p.res;
     const T* __restrict__ dact = (const T*)p.dact;
+    // the block's first image as uniform (scalar) bases; tile pixel index (ty * 16 + tx) -> 32-bit pixel index from there
+    // (the launcher checks that an image group stays below 2^31 bytes in every tensor)
     const long long img_pix = (long long)img_pm * p.h * p.w;
-    // tile pixel index (ty * 16 + tx) -> global pixel index / coordinates inside its image
-    auto gpix = [&](int q) -> long long {
+    outT += img_pix * p.ldo; outF += img_pix * p.ldo;
+    if (res) res += img_pix * p.ldr;
+    if (dact) dact += img_pix * p.ldd;
+    auto gpix = [&](int q) -> unsigned {
         const int ty = q >> 4, tx = q & 15;
-        if constexpr (SUB == TS) return img_pix + (long long)(ty0 + ty) * p.w + tx0 + tx;
-        else return img_pix + (long long)((ty / SUB) * G + tx / SUB) * (SUB * SUB) + (ty % SUB) * SUB + (tx % SUB);
+        if constexpr (SUB == TS) return (unsigned)((ty0 + ty) * p.w + tx0 + tx);
+        else return (unsigned)(((ty / SUB) * G + tx / SUB) * (SUB * SUB) + (ty % SUB) * SUB + (tx % SUB));
     };
     auto ycoord = [&](int ty) -> int { return SUB == TS ? ty0 + ty : ty % SUB; };
     auto xcoord = [&](int tx) -> int { return SUB == TS ? tx0 + tx : tx % SUB; };
@@ -552,7 +568,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #pragma unroll
                 for (int i = 0; i < NIT; ++i) {
                     const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
-                    const long long pix = gpix(px);
+                    const unsigned pix = gpix(px);
                     if (ch * 8 < c_lim) {
                         if (res) *(uint4*)(R0 + px * ERS + ch * 16) = *(const uint4*)(res + pix * p.ldr + nt * BN + ch * 8);
                         if (dact) {
@@ -659,7 +675,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
-                const long long pix = gpix(px);
+                const unsigned pix = gpix(px);
                 if (ch * 8 < c_lim) *(uint4*)(outT + pix * p.ldo + nt * BN + ch * 8) = *(const uint4*)(R0 + px * ERS + ch * 16);
             }
             return;
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     auto emit = [&](float a, int tyq, int txq, int col, float bias) __attribute__((always_inline)) {
         const bool cvalid = col < p.co;
         const int y = ycoord(tyq), x = xcoord(txq);
-        const long long pix = gpix(tyq * 16 + txq);
+        const unsigned pix = gpix(tyq * 16 + txq);
         float v = 0.f;
         if (cvalid) {
             v = a + bias;
@@ -727,6 +743,9 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     const int ntn = ups_cdiv(k.co_fill, BN);
     const int kchunks = ups_cdiv(k.ci, 4 * EPC);
     const int nblocks = (k.n / (G * G)) * tiles_x * tiles_y * ntn;
+    PatchK kk = k;
+    kk.m_ntn = div_magic(nblocks, ntn); kk.m_parts = div_magic(nblocks, k.mask_P);
+    kk.m_tx = div_magic(nblocks, tiles_x); kk.m_ty = div_magic(nblocks, tiles_y);
     constexpr size_t BST = 3 * (size_t)BN * 64;
     const int nabuf = (sizeof(T) == 2 && SUB == TS && (kchunks == 1 || OCC == 2)) ? 1 : 2;
     size_t shmem = sizeof(T) == 2 ? nabuf * ABY + (OCC == 2 ? 2 : 3) * BST : 2 * ABY + 2 * 3 * BN * RS;
@@ -740,7 +759,7 @@ int launch_bn(const PatchK& k, hipStream_t s) {
         if (e != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC, SUB>), dim3(nblocks), dim3(512), shmem, s, k, tiles_x, tiles_y, ntn,
+    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC, SUB>), dim3(nblocks), dim3(512), shmem, s, kk, tiles_x, tiles_y, ntn,
                        kchunks, nblocks);
     return UPS_OK;
 }
@@ -768,9 +787,14 @@ int launch_t(const PatchK& k, hipStream_t s) {
         // two blocks per CU once the grid has at least two blocks for every CU (smaller grids spread over the chip instead);
         // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv) use 64-wide tiles and one patch buffer
         const int tiles = k.n * (k.w / TS) * (k.h / TS);
-        if (k.co_fill > 64 && k.ci > 32)
-            return (patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 128) >= 512) ? launch_bn<T, 128, 2, TS>(k, s)
-                                                                                  : launch_bn<T, 128, 1, TS>(k, s);
+        if (k.co_fill > 64 && k.ci > 32) {
+            if (patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 128) >= 512) return launch_bn<T, 128, 2, TS>(k, s);
+            // a grid of one 128-wide block per CU: 64-wide tiles put two blocks on every CU instead (4 waves per SIMD)
+            static int mid = -1;
+            if (mid < 0) { const char* e = getenv("UPS_PATCH_MID"); mid = (e && e[0] == '0') ? 0 : 1; }
+            if (mid && patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 64) >= 512) return launch_bn<T, 64, 2, TS>(k, s);
+            return launch_bn<T, 128, 1, TS>(k, s);
+        }
         if (k.co_fill > 32)
             return (patch_occ() == 2 && k.ci > 32 && tiles * ups_cdiv(k.co_fill, 64) >= 512) ? launch_bn<T, 64, 2, TS>(k, s)
                                                                                               : launch_bn<T, 64, 1, TS>(k, s);
@@ -791,6 +815,12 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     if (d->hi != d->ho || d->wi != d->wo || d->out_h != d->ho || d->out_w != d->wo) return 1;
     // 16-bit image-pitch pixel index of a staged item, 24-bit row pitch for its v_mad_u32_u24
     if ((long long)(TS + 2) * d->wi >= 0xffff || (long long)d->ldi * 4 >= (1 << 24)) return 1;
+    {   // 32-bit offsets inside the image group of a block (up to 16 images per tile for the 4x4 case)
+        long long ldmax = d->ldi > d->ldo ? d->ldi : d->ldo;
+        if (d->res && d->ldr > ldmax) ldmax = d->ldr;
+        if (d->dact && d->ldd > ldmax) ldmax = d->ldd;
+        if (16ll * d->hi * d->wi * ldmax * 4 >= (1ll << 31)) return 1;
+    }
     const bool small = d->hi == d->wi && (d->hi == 8 || d->hi == 4) && d->n % ((TS / d->hi) * (TS / d->hi)) == 0;
     {
         static int small_on = -1;
