@@ -85,9 +85,23 @@ typedef struct {
      * of out[p*B+b][y][x][c] the kernel writes mask_grad[b][y][x][p] = sum_c out * mask_view[b][y][x][c] (M:185 backward). */
     float*       mask_grad;      /* [mask_batch, out_h, out_w, n / mask_batch] fp32 or NULL (`out` may then be NULL) */
     const float* mask_view;      /* [mask_batch, out_h, out_w, co] fp32 view tensor, required with mask_grad */
+    /* fp8 forward (BASELINE config #5: e4m3 MFMA operands, fp32 accumulate, bf16 tensors; 3x3 / stride-1 patch kernels,
+     * dtype UPS_BF16, 16-aligned images, ci % 64 == 0, no mask; else UPS_E_UNSUPPORTED).  f8_deq != NULL selects it:
+     * `w` then holds e4m3 weights [9][ci/64][co][64] scaled per output channel (ups_weight_prep_f8), f8_deq[c] = 1 / that
+     * scale; the staged activations are multiplied by *f8_scale before the conversion (device scalar, delayed scaling) and
+     * max |act(in)| of this launch is collected into the 64 slots of f8_amax (atomic max of non-negative float bits). */
+    const float* f8_deq;         /* [co] or NULL */
+    const float* f8_scale;       /* device scalar */
+    float*       f8_amax;        /* [64] */
 } ups_conv_desc;
 
 int ups_conv_igemm(const ups_conv_desc* d, void* stream);
+
+/* e4m3 weights for the fp8 forward: w_f8[tap][k][c][64] = e4m3(V[tap][64 k + j][c] * 448 / amax_c), zero padded in K,
+ * deq[c] = amax_c / 448 with amax_c = max |V[:, :ci_log, c]| (the CoordConv rows ci_log.. stay fp32 in ups_coord_table).
+ * src is the HWIO fp32 variable [ntaps][cin_v][co] (N:644-652). */
+int ups_weight_prep_f8(const float* src, int32_t ntaps, int32_t cin_v, int32_t ci_log, int32_t co, void* w_f8, float* deq,
+                       void* stream);
 
 /* Weight gradient  dV[tap][ci][co] = sum_pix act(in)[src(pix,tap)][ci] * dout[pix][co]
  * (gradient of N:661-663 w.r.t. V), split-K over pixels into fp32 slabs + deterministic reduce.

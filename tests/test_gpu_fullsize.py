@@ -97,7 +97,7 @@ def test_full_width_step_bf16_mask_iou(dev):
         assert abs(lo - lh) <= 5e-2 * max(1.0, abs(lo)), "loss {}: oracle {} hip(bf16) {}".format(k, lo, lh)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32", "fp8"])
 def test_full_width_confident_masks_iou(dev, precision):
     """Part-mask IoU vs the fp64 oracle on CONFIDENT masks.  At random init the mask decoder's output is nearly flat (noise-free
     argmax decided by ~1e-2 logit gaps, sampled masks decided by the unit noise: the >= 0.99 of the test above is easy there),
@@ -106,7 +106,9 @@ def test_full_width_confident_masks_iou(dev, precision):
     decoder, whose part regions meet along long, shallow boundaries: a relative logit error e flips the pixels whose top-2 gap
     is below e * |logit|, whatever the scale.  fp32 must reproduce the masks (IoU >= 0.999); bf16 storage through the ~30
     convolutions of encoder_0 + decoder_visualize (1-2 % relative logit error) must agree on >= 99 % of the pixels; its mean
-    per-part IoU (small parts weigh as much as large ones) is reported and held to >= 0.9 (measured 0.93 - 0.97)."""
+    per-part IoU (small parts weigh as much as large ones) is reported and held to >= 0.9 (measured 0.93 - 0.97).
+    fp8 (BASELINE config #5's arithmetic at config #2's size: e4m3 forward of the wide 3x3 convolutions) is reported the same
+    way and held to the agreement its 2^-4 operand resolution allows (pixels >= 0.95, mean per-part IoU >= 0.8)."""
     import sys
     sys.path.insert(0, GOLD)
     import make_golden_full as G
@@ -127,7 +129,11 @@ def test_full_width_confident_masks_iou(dev, precision):
     iou_s = _iou((m0 == m0.max(dim=-1, keepdim=True).values).float(), z["hard0_argmax"], P)
     print("{} full width, confident logits: out_parts_hard IoU {:.4f} (pixel agreement {:.4f}), sampled-mask IoU {:.4f}".format(
         precision, iou_mean, agree, iou_s))
-    if precision == "bf16":
+    if precision == "fp8":
+        assert ops.Fp8.count > 0, "no layer took the fp8 path"
+        ops.Fp8.enabled = False
+        assert agree >= 0.95 and iou_mean >= 0.8 and iou_s >= 0.8, (agree, iou_mean, iou_s)     # measured 0.979 / 0.90 / 0.92
+    elif precision == "bf16":
         assert agree >= 0.99 and iou_mean >= 0.9 and iou_s >= 0.9, (agree, iou_mean, iou_s)
     else:
         assert iou_mean >= 0.999 and iou_s >= 0.999, (iou_mean, iou_s)

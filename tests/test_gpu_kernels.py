@@ -486,3 +486,61 @@ def test_part_masked_convolution_matches_the_materialised_path(P, B, S, coords, 
     Vo[:, :, :3] = V[:, :, :3].to(T).double()
     yo = _oracle_conv(R, xo, Vo, b.double(), 1, coords, None, False, None)
     assert_close(res["fused"][0][..., :32].float(), yo.float(), BF16_TOL, "part-masked conv vs oracle")
+
+
+@pytest.mark.parametrize("case", [
+    # n, h, cin, cout, coords, act, res_self
+    (4, 32, 128, 128, False, "leaky_relu", True),
+    (2, 128, 256, 256, True, "leaky_relu", True),      # the dominant decoder res-block layer (kchunks 4 at 64 channels each)
+    (3, 16, 64, 96, True, None, False),                # one chunk, 64-wide N-tile with a ragged tail
+    (2, 48, 192, 40, False, "relu", False),            # 32-wide N-tile is never taken (co >= 64 gate): stays bf16
+])
+def test_conv_fp8_forward(case, dev):
+    """fp8 forward (BASELINE config #5): the kernel against the same arithmetic restated in torch -- activations and weights
+    rounded to e4m3 (RNE) after the per-tensor / per-output-channel scaling, exact accumulation, dequantised, CoordConv rows
+    and bias in fp32 -- at bf16 output resolution; and against the unquantised fp64 convolution at the fp8 error level."""
+    lib, ops, R = _mods()
+    n, h, cin, cout, coords, act, res_self = case
+    g = torch.Generator().manual_seed(11)
+    cv = cin + (2 if coords else 0)
+    V = torch.randn(3, 3, cv, cout, generator=g) / math.sqrt(9 * cv)
+    V[..., : cout // 3] *= 4.0                 # unequal channel ranges: the per-channel scales matter
+    b = torch.randn(cout, generator=g) * 0.1
+    x = (torch.randn(n, h, h, cin, generator=g) * 1.5).to(torch.bfloat16)
+    lay = _layer(ops, lib, V, b, 3, 1, coords, act, dev)
+    xd = x.to(dev)
+    ops.Fp8.enabled = True
+    try:
+        eligible = ops.Fp8.eligible(lay, xd)
+        y = ops.conv_forward(xd, lay, res=xd if res_self else None)
+        torch.cuda.synchronize()
+        if not eligible:
+            assert cout < 64
+            ref = _oracle_conv(R, x.double(), V.double(), b.double(), 1, coords, act, res_self, None)
+            assert_close(y[..., :cout].float().cpu(), ref.float(), BF16_TOL, "bf16 path of an ineligible layer")
+            return
+        f8 = lay._cache["f8"]
+        s_a = float(ops.Fp8.scale[f8["slot"]].cpu())
+        amax_seen = float(ops.Fp8.amax[f8["slot"]].max().cpu())
+    finally:
+        ops.Fp8.enabled = False
+    xf = x.float()
+    xa = torch.maximum(xf, 0.2 * xf) if act == "leaky_relu" else (torch.relu(xf) if act == "relu" else xf)
+    assert abs(amax_seen - float(xa.abs().max())) <= 1e-6 * amax_seen, "recorded activation maximum"
+    assert abs(s_a - 448.0 * ops.Fp8.MARGIN / float(xf.abs().max())) <= 1e-5 * s_a
+    xq = (xa * s_a).clamp(-448, 448).to(torch.float8_e4m3fn).double()
+    wmax = V[:, :, :cin].abs().amax(dim=(0, 1, 2))
+    wq = (V[:, :, :cin] * (448.0 / wmax)).clamp(-448, 448).to(torch.float8_e4m3fn).double()
+    assert_close(f8["deq"].cpu(), (wmax / 448.0), 1e-6, "per-channel dequantisation factors")
+    acc = R.conv2d_same(xq, wq, torch.zeros(cout, dtype=torch.float64), 1) * (wmax.double() / 448.0) / s_a
+    extra = b.double().view(1, 1, 1, -1).expand_as(acc).clone()
+    if coords:      # CoordConv rows stay fp32 (ups_coord_table): their contribution = conv of the coordinate planes alone
+        cz = torch.zeros(n, h, h, cin, dtype=torch.float64)
+        Vc = V.double().clone(); Vc[:, :, :cin] = 0
+        extra = extra + R.conv2d_same(R.Scope.add_coordinates(cz), Vc, torch.zeros(cout, dtype=torch.float64), 1)
+    ref_q = acc + extra + (x.double() if res_self else 0)
+    got = y[..., :cout].float().cpu()
+    assert_close(got, ref_q.float(), 1e-2, "fp8 kernel vs e4m3 emulation")          # bf16 output rounding
+    ref = _oracle_conv(R, x.double(), V.double(), b.double(), 1, coords, act, res_self, None)
+    err = float((got.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert err < 0.05, "fp8 forward vs unquantised convolution: rel RMS {:.3g}".format(err)

@@ -119,6 +119,44 @@ def test_train_step_bf16_close_to_oracle(dev, variant, size):
         assert abs(lo - lh) <= 5e-2 * max(1.0, abs(lo)), "loss {}: oracle {} hip(bf16) {}".format(k, lo, lh)
 
 
+def test_fp8_step_tracks_bf16(dev):
+    """precision: fp8 (BASELINE config #5): forward of the wide 3x3 / stride-1 convolutions on e4m3 MFMA operands with delayed
+    activation scaling.  Three training steps from the same initial weights as a bf16 run: every loss stays within 10 % and the
+    sampled part masks agree on >= 95 % of the pixels; the fp8 layers are re-quantised after each optimizer step."""
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import ops
+    from upsparts_amd.model import TrainModel, Trainer
+    from oracle import ref_model as R, configs
+    cfg = copy.deepcopy(configs.small_config())
+    cfg["vgg_widths"] = (64, 64, 64, 64, 64)
+    cfg["dv"].update({"config": [64, 64, 64, 64]})
+    cfg["encoder0"].update({"config": [64, 64, 64, 64]})
+    views, noise = R.synthetic_views(cfg), R.synthetic_noise(cfg)
+    runs = {}
+    for prec in ("bf16", "fp8"):
+        c = copy.deepcopy(cfg)
+        c["precision"] = prec
+        model = TrainModel(c, device=dev, seed=0)
+        trainer = Trainer(c, None, model)
+        out = []
+        for _ in range(3):
+            losses = trainer.train_step(views, noise)
+            out.append({k: float(v) for k, v in losses.items()})
+        runs[prec] = (out, trainer._debug["hard"].cpu().clone())
+        if prec == "fp8":
+            assert ops.Fp8.count >= 4, "fp8 layers used: {}".format(ops.Fp8.count)
+            scales = ops.Fp8.scale[:ops.Fp8.count].cpu()
+            assert bool(torch.isfinite(scales).all()) and float(scales.min()) > 0
+            assert all(l._cache["f8"]["version"] == ops.WeightVersion.value for l in ops.Fp8.layers)
+    ops.Fp8.enabled = False
+    for step in range(3):
+        for k, vb in runs["bf16"][0][step].items():
+            vf = runs["fp8"][0][step][k]
+            assert abs(vb - vf) <= 0.1 * max(1.0, abs(vb)), "step {} loss {}: bf16 {} fp8 {}".format(step, k, vb, vf)
+    agree = float(((runs["bf16"][1] > 0) == (runs["fp8"][1] > 0)).float().mean())
+    assert agree >= 0.95, agree
+
+
 def test_inference_outputs(dev):
     cfg, R, params, vp, model, trainer, views, noise = _setup("fp32", dev)
     out = model.forward(views, noise)

@@ -56,8 +56,10 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--fp8", action="store_true", help="forward of the eligible layers on the e4m3 path (ops.Fp8)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    ops.Fp8.enabled = args.fp8
     T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     only = set(args.only.split(",")) if args.only else None
     print("{:10s} {:>9s} {:>8s} {:>9s} {:>8s} {:>9s} {:>8s}".format("layer", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))

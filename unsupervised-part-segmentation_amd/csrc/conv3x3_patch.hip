@@ -46,6 +46,9 @@ struct PatchK {
     int mask_B, mask_P;
     // block index decode without integer divisions: n / d = umulhi(n, m) for n * d < 2^32 (launcher; m = 0: plain division)
     unsigned m_ntn, m_parts, m_tx, m_ty;
+    // fp8 forward (ups_conv_desc.f8_*): wgt holds e4m3 weights scaled per output channel, f8_deq[c] = 1 / that scale,
+    // *f8_scale the activation scale of this launch, f8_amax 64 slots that collect max |act(x)| for the next one
+    const float* f8_deq; const float* f8_scale; float* f8_amax;
 };
 
 __device__ __forceinline__ int fast_div(int n, int d, unsigned m) {
@@ -72,26 +75,32 @@ template <typename T> struct PMma;
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 // ROWB > 0: the wave's tile rows are ROWB bytes apart in the patch image (one image per tile): fragment i is read at an
 // immediate offset i * ROWB from one per-tap lane address (no address arithmetic per read); ROWB == 0: rows from arow[].
-template <int TM16, int TN16, int ROWB>
+typedef __attribute__((ext_vector_type(2))) long i64x2;
+template <bool F8> struct Frag16 { typedef bf16x8 type; };
+template <> struct Frag16<true> { typedef i64x2 type; };
+// F8: a 16-byte fragment holds 16 e4m3 channels -- two v_mfma_f32_16x16x32_fp8_fp8 per fragment pair (low / high 8 bytes:
+// both operands use the same byte -> k mapping), a 64-byte pixel / weight row is a chunk of 64 channels.
+template <int TM16, int TN16, int ROWB, bool F8>
 __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsigned char* B, const int (&arow)[TM16],
                                             int po0, int po1, int po2, int sw0, int sw1, int sw2, int b_tap_stride,
                                             f32x4v (&acc)[TM16][TN16]) {
-    bf16x8 fa[TM16], fb[2][2];
+    typedef typename Frag16<F8>::type frag_t;
+    frag_t fa[TM16], fb[2][2];
     auto fetch_a = [&](int t) __attribute__((always_inline)) {
         const int po = t == 0 ? po0 : (t == 1 ? po1 : po2);
         const int sw = t == 0 ? sw0 : (t == 1 ? sw1 : sw2);
         if constexpr (ROWB > 0) {
             const unsigned char* at = A + (arow[0] + po) + sw;       // uniform part added on the scalar unit, one v_add
 #pragma unroll
-            for (int i = 0; i < TM16; ++i) fa[i] = *(const bf16x8*)(at + i * ROWB);
+            for (int i = 0; i < TM16; ++i) fa[i] = *(const frag_t*)(at + i * ROWB);
         } else {
 #pragma unroll
-            for (int i = 0; i < TM16; ++i) fa[i] = *(const bf16x8*)(A + arow[i] + po + sw);
+            for (int i = 0; i < TM16; ++i) fa[i] = *(const frag_t*)(A + arow[i] + po + sw);
         }
     };
     auto fetch_b = [&](int t, int jh, int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) fb[slot][jj] = *(const bf16x8*)(B + t * b_tap_stride + (2 * jh + jj) * (16 * 64));
+        for (int jj = 0; jj < 2; ++jj) fb[slot][jj] = *(const frag_t*)(B + t * b_tap_stride + (2 * jh + jj) * (16 * 64));
     };
     constexpr int NP = TN16 / 2;          // B fragment pairs per tap
     fetch_a(0);
@@ -110,7 +119,12 @@ __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsign
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
                     // weights as the row operand: a lane then holds 4 CONSECUTIVE channels of one pixel (8-byte epilogue accesses)
-                    acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[step & 1][jj], fa[i], acc[i][2 * jh + jj], 0, 0, 0);
+                    if constexpr (F8) {
+                        acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[step & 1][jj][0], fa[i][0], acc[i][2 * jh + jj], 0, 0, 0);
+                        acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[step & 1][jj][1], fa[i][1], acc[i][2 * jh + jj], 0, 0, 0);
+                    } else {
+                        acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[step & 1][jj], fa[i], acc[i][2 * jh + jj], 0, 0, 0);
+                    }
             __builtin_amdgcn_s_setprio(0);
             if (jh + 1 == NP && t + 1 < 3) fetch_a(t + 1);
         }
@@ -152,11 +166,13 @@ template <> struct PMma<float> {
 // SUB = 16: a tile is a 16x16 window of one image (halo from the neighbouring pixels).  SUB = 8 / 4: the images themselves
 // are 8x8 / 4x4 (encoder bottoms, first decoder levels, VGG block 5) and a tile packs G x G = 4 / 16 whole images, each
 // with its own all-zero halo (the patch grid is G*(SUB+2) wide; halo slots are zeroed once and never written).
-template <typename T, int BN, int OCC, int SUB>
+template <typename T, int BN, int OCC, int SUB, bool F8 = false>
 __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const PatchK p, const int tiles_x, const int tiles_y,
                                                                  const int ntn, const int kchunks, const int nblocks) {
     constexpr int EPC = Chunk<T>::N;
-    constexpr int BK = 4 * EPC;
+    constexpr int BK = 4 * EPC;                  // weight-row elements of T per 64-byte row (the fp8 rows are addressed as T too)
+    constexpr int BKA = F8 ? 64 : BK;            // input channels per chunk
+    static_assert(!F8 || (sizeof(T) == 2 && SUB == TS && OCC == 1), "fp8 forward: bf16 tensors, one tile per image, one block per CU");
     constexpr int WN = (BN == 32) ? 1 : 2;
     constexpr int WM = 8 / WN;                   // 4 or 8 waves along the pixels
     constexpr int TM = 256 / WM / 32;            // 2 or 1
@@ -236,9 +252,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     uint4 ra0, ra1, ra2;
+    uint4 rb0, rb1, rb2;        // fp8: channels 8..15 of the items (an item is 16 bf16 channels -> 16 e4m3 bytes)
+    float f8_amax_t = 0.f;      // fp8: max |act(x)| this thread has staged
     struct WSet { uint4 r0, r1, r2; } ws0, ws1;     // two weight stages in flight (prefetch distance 2)
 
-    const int cha = (tid & 3) * EPC;            // 512 % 4 == 0: all three items of a thread share the chunk slot
+    const int cha = (tid & 3) * (F8 ? 16 : EPC); // 512 % 4 == 0: all three items of a thread share the chunk slot
     // branch-free: always load (from the tensor base when masked) and select, so the number of loads in flight
     // is static and the compiler can use counted vmcnt waits across the prefetch distance
     auto ld_a = [&](int off, int koff) -> uint4 {
@@ -255,8 +273,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     const T* __restrict__ in_o = in + (long long)origin * p.ldi;
     const unsigned* __restrict__ mbits_o = mbits ? mbits + origin : nullptr;
     const unsigned row_b = (unsigned)p.ldi * (unsigned)sizeof(T);
-    auto ld_rel = [&](unsigned pk, int koff) -> uint4 {
+    auto ld_rel = [&](unsigned pk, int koff, uint4& hi) -> uint4 {
         uint4 v = zero4;
+        if constexpr (F8) hi = zero4;
 #if !defined(UPS_ABLATE_GLOAD)
         asm volatile("" : "+v"(pk));        // derived offsets are recomputed per chunk, not hoisted into held registers
         const unsigned rel = pk & 0xffffu;
@@ -264,6 +283,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             // scalar base (image + chunk + origin) + 32-bit vector offset addressing
             const unsigned o = __umul24(rel, row_b) + (unsigned)(cha * (int)sizeof(T));
             v = *(const uint4*)((const unsigned char*)(in_o + koff) + o);
+            if constexpr (F8) hi = *(const uint4*)((const unsigned char*)(in_o + koff) + o + 16);
             // part-masked input (model.py:185): the pixel belongs to this block's part image only where its hard-mask bit is set
             if (mbits_o && !((mbits_o[rel] >> part) & 1u)) v = zero4;
         }
@@ -271,10 +291,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         return v;
     };
     auto load_patch = [&](int cc) __attribute__((always_inline)) {
-        const int koff = cc * BK;
+        const int koff = cc * BKA;
         if constexpr (SUB == TS) {
-            ra0 = ld_rel(pk0, koff); ra1 = ld_rel(pk1, koff);
-            if (has2) ra2 = ld_rel(pk2, koff);
+            ra0 = ld_rel(pk0, koff, rb0); ra1 = ld_rel(pk1, koff, rb1);
+            if (has2) ra2 = ld_rel(pk2, koff, rb2);
         } else {
             ra0 = ld_a(pa0, koff); ra1 = ld_a(pa1, koff);
         }
@@ -285,8 +305,35 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         }
         return u;
     };
+    // fp8: 16 bf16 channels -> activation -> running max -> * scale -> 16 e4m3 bytes (v_cvt_pk_fp8_f32: RNE, saturating)
+    float f8_sa = 1.f;
+    if constexpr (F8) f8_sa = *p.f8_scale;
+    auto cvt_f8 = [&](uint4 lo, uint4 hi) __attribute__((always_inline)) -> uint4 {
+        const unsigned wsrc[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        unsigned wd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f[4] = {__uint_as_float(wsrc[2 * k] << 16), __uint_as_float(wsrc[2 * k] & 0xffff0000u),
+                          __uint_as_float(wsrc[2 * k + 1] << 16), __uint_as_float(wsrc[2 * k + 1] & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (p.act_in != UPS_ACT_NONE) f[e] = ups_act_ns(f[e], act_ns);
+                f8_amax_t = fmaxf(f8_amax_t, fabsf(f[e]));
+                f[e] = __builtin_amdgcn_fmed3f(f[e] * f8_sa, -448.f, 448.f);
+            }
+            int d = 0;
+            d = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], d, false);
+            d = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], d, true);
+            wd[k] = (unsigned)d;
+        }
+        return make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    };
     auto store_patch = [&](unsigned char* A) __attribute__((always_inline)) {
-        if constexpr (SUB == TS) {
+        if constexpr (F8) {
+            *(uint4*)(A + (pk0 >> 16)) = cvt_f8(ra0, rb0);
+            *(uint4*)(A + (pk1 >> 16)) = cvt_f8(ra1, rb1);
+            if (has2) *(uint4*)(A + (pk2 >> 16)) = cvt_f8(ra2, rb2);
+        } else if constexpr (SUB == TS) {
             // one item at a time (the scheduler would otherwise unpack all three chunks at once: 24 more live registers)
             auto slot = [&](unsigned pk) __attribute__((always_inline)) -> unsigned { asm volatile("" : "+v"(pk)); return pk >> 16; };
             *(uint4*)(A + slot(pk0)) = act_u4(ra0);
@@ -439,7 +486,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
             const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
             const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
-            bf16_taps16<TM16, TN16, (SUB == TS ? PWPS * APX : 0)>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
+            bf16_taps16<TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
             if (n1 < total && n1 % 3 == 0) {
@@ -467,7 +514,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
             const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
             const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
-            bf16_taps16<TM16, TN16, (SUB == TS ? PWPS * APX : 0)>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
+            bf16_taps16<TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
 #if !defined(UPS_ABLATE_LSTORE)
@@ -536,6 +583,22 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         return;
     }
 #endif
+    if constexpr (F8) {
+        // max |act(x)| of the launch (blocks of the first N-tile; 64 slots spread the atomics): next launch's scale
+        const float m = wave_max(f8_amax_t);
+        if (nt == 0 && lane == 0) atomicMax((unsigned*)(p.f8_amax + (bid & 63)), __float_as_uint(m));
+        // dequantise: acc = sum (s_a x)(s_w[c] w)  ->  * 1 / (s_a s_w[c])
+        const float inv_sa = 1.f / f8_sa;
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = nt * BN + (wn * 2 * TN + j) * 16 + 4 * (lane >> 4) + e;
+                const float dq = col < p.co ? p.f8_deq[col] * inv_sa : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2 * TM; ++i) acc16[i][j][e] *= dq;
+            }
+    }
     T* __restrict__ outT = (T*)p.out;
     float* __restrict__ outF = (float*)p.out;
     const T* __restrict__ res = (const T*)p.res;
@@ -734,14 +797,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
 }
 
-template <typename T, int BN, int OCC, int SUB>
+template <typename T, int BN, int OCC, int SUB, bool F8 = false>
 int launch_bn(const PatchK& k, hipStream_t s) {
     constexpr int EPC = Chunk<T>::N;
     constexpr int G = TS / SUB, PR = G * (SUB + 2), PWPS = (PR + 3) / 4 * 4;
     constexpr size_t ABY = (size_t)PR * PWPS * APX;
     const int tiles_x = SUB == TS ? k.w / TS : 1, tiles_y = SUB == TS ? k.h / TS : 1;
     const int ntn = ups_cdiv(k.co_fill, BN);
-    const int kchunks = ups_cdiv(k.ci, 4 * EPC);
+    const int kchunks = ups_cdiv(k.ci, F8 ? 64 : 4 * EPC);
     const int nblocks = (k.n / (G * G)) * tiles_x * tiles_y * ntn;
     PatchK kk = k;
     kk.m_ntn = div_magic(nblocks, ntn); kk.m_parts = div_magic(nblocks, k.mask_P);
@@ -754,12 +817,12 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     if (epi > shmem) shmem = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB, F8>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(epi > shmem_max ? epi : shmem_max));
         if (e != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC, SUB>), dim3(nblocks), dim3(512), shmem, s, kk, tiles_x, tiles_y, ntn,
+    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC, SUB, F8>), dim3(nblocks), dim3(512), shmem, s, kk, tiles_x, tiles_y, ntn,
                        kchunks, nblocks);
     return UPS_OK;
 }
@@ -784,6 +847,11 @@ int launch_t(const PatchK& k, hipStream_t s) {
     if (k.h == 8) return launch_small<T, 8>(k, s);
     if (k.h == 4) return launch_small<T, 4>(k, s);
     if constexpr (sizeof(T) == 2) {
+        if (k.f8_deq) {      // fp8 forward (eligibility checked by the caller)
+            if (k.co_fill > 64) return launch_bn<T, 128, 1, TS, true>(k, s);
+            if (k.co_fill > 32) return launch_bn<T, 64, 1, TS, true>(k, s);
+            return launch_bn<T, 32, 1, TS, true>(k, s);
+        }
         // two blocks per CU once the grid has at least two blocks for every CU (smaller grids spread over the chip instead);
         // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv) use 64-wide tiles and one patch buffer
         const int tiles = k.n * (k.w / TS) * (k.h / TS);
@@ -839,6 +907,12 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     }
     PatchK k;
     k.mask = d->mask_bits; k.mask_grad = d->mask_grad; k.mask_view = d->mask_view;
+    k.f8_deq = d->f8_deq; k.f8_scale = d->f8_scale; k.f8_amax = d->f8_amax;
+    if (d->f8_deq) {
+        if (d->dtype != UPS_BF16 || small || (d->hi % TS) || (d->wi % TS) || d->ci % 64 || d->mask_bits || d->mask_grad ||
+            !d->f8_scale || !d->f8_amax || d->dact)
+            return 1;
+    }
     k.mask_B = 0; k.mask_P = 1;
     if (d->mask_bits || d->mask_grad) {
         // part mode: bf16, one image per tile, staged epilogue

@@ -262,6 +262,49 @@ extern "C" int ups_weight_prep(const float* src, int32_t ntaps, int32_t cin_v, i
     return UPS_OK;
 }
 
+namespace {
+// one block per output channel: column max, then the 64-byte rows of that channel for every (tap, 64-channel chunk)
+__global__ __launch_bounds__(256) void weight_prep_f8_kernel(const float* __restrict__ src, int ntaps, int cin_v, int ci_log,
+                                                             int co, unsigned* __restrict__ wq, float* __restrict__ deq) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int kc = (ci_log + 63) / 64;
+    float m = 0.f;
+    for (int i = tid; i < ntaps * ci_log; i += 256) {
+        const int t = i / ci_log, ci = i - t * ci_log;
+        m = fmaxf(m, fabsf(src[((long long)t * cin_v + ci) * co + c]));
+    }
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = m > 0.f ? 448.f / m : 1.f;
+    if (tid == 0) deq[c] = m > 0.f ? m / 448.f : 1.f;
+    for (int i = tid; i < ntaps * kc * 16; i += 256) {          // one dword (4 channels) per thread and step
+        const int t = i / (kc * 16), r = i - t * (kc * 16), k = r >> 4, j4 = r & 15;
+        float f[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ci = k * 64 + j4 * 4 + e;
+            f[e] = ci < ci_log ? __builtin_amdgcn_fmed3f(src[((long long)t * cin_v + ci) * co + c] * sc, -448.f, 448.f) : 0.f;
+        }
+        int d = 0;
+        d = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], d, false);
+        d = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], d, true);
+        wq[(((long long)t * kc + k) * co + c) * 16 + j4] = (unsigned)d;
+    }
+}
+}  // namespace
+
+extern "C" int ups_weight_prep_f8(const float* src, int32_t ntaps, int32_t cin_v, int32_t ci_log, int32_t co, void* w_f8,
+                                  float* deq, void* stream) {
+    UPS_CHECK_ARG(src && w_f8 && deq && ntaps >= 1 && ci_log >= 1 && cin_v >= ci_log && co >= 1);
+    hipLaunchKernelGGL(weight_prep_f8_kernel, dim3(co), dim3(256), 0, (hipStream_t)stream, src, ntaps, cin_v, ci_log, co,
+                       (unsigned*)w_f8, deq);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
 extern "C" int64_t ups_prep_item_blocks(const ups_prep_item* item_host, int32_t dtype) {
     if (!item_host) return -1;
     return (prep_elems(*item_host, dtype == UPS_F32 ? 16 : 32) + 255) / 256;

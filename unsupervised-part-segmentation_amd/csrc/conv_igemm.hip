@@ -453,6 +453,10 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
         if (pr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
         if (pr < 0) { ups_set_error("ups_conv_igemm: patch kernel launch setup failed"); return pr; }
     }
+    if (d->f8_deq) {
+        ups_set_error("ups_conv_igemm: the fp8 forward needs the bf16 3x3 / stride-1 patch kernel (16-aligned images, ci %% 64 == 0, no mask)");
+        return UPS_E_UNSUPPORTED;
+    }
     if (d->mask_bits || d->mask_grad) {
         ups_set_error("ups_conv_igemm: the part-masked forms need the bf16 3x3 / stride-1 patch kernel (16-aligned images, P <= 32)");
         return UPS_E_UNSUPPORTED;

@@ -158,6 +158,59 @@ class PrepRegistry(object):
             ent["version"] = WeightVersion.value
 
 
+class Fp8(object):
+    """fp8 forward of the wide 3x3 / stride-1 convolutions (BASELINE config #5: e4m3 MFMA operands, fp32 accumulate, bf16
+    tensors; ``precision: fp8`` in the config).  Weights are scaled per output channel when they are converted; activations
+    use delayed per-tensor scaling: every launch records max |act(x)| (kernel epilogue, 64 atomic slots per layer) and
+    ``update()`` -- once per step, three tiny launches for all layers -- turns it into the next step's scale
+    448 * MARGIN / amax.  A layer's first launch scales from the tensor at hand."""
+    enabled = False
+    MARGIN = 0.5            # headroom for the step-to-step growth of amax (e4m3 max normal = 448)
+    MAX_LAYERS = 512
+    amax = None             # [MAX_LAYERS, 64] fp32
+    scale = None            # [MAX_LAYERS] fp32
+    count = 0
+    layers = []             # trainable layers with e4m3 weights (re-converted by after_step)
+
+    @classmethod
+    def slot(cls, device):
+        if cls.amax is None or cls.amax.device != device:
+            cls.amax = torch.zeros((cls.MAX_LAYERS, 64), dtype=torch.float32, device=device)
+            cls.scale = torch.ones((cls.MAX_LAYERS,), dtype=torch.float32, device=device)
+            cls.count = 0
+            cls.layers = []
+        i = cls.count
+        cls.count += 1
+        if i >= cls.MAX_LAYERS:
+            raise L.UpsError("more than {} fp8 layers".format(cls.MAX_LAYERS))
+        return i
+
+    @classmethod
+    def update(cls):
+        """Next step's activation scales from this step's maxima (layers that did not run keep theirs)."""
+        if cls.amax is None or cls.count == 0:
+            return
+        n = cls.count
+        m = cls.amax[:n].amax(dim=1)
+        cls.scale[:n] = torch.where(m > 0, (448.0 * cls.MARGIN) / m.clamp_min(1e-30), cls.scale[:n])
+        cls.amax[:n].zero_()
+
+    @classmethod
+    def after_step(cls):
+        """After the optimizer step: new activation scales, e4m3 copies of the updated weights (one launch per layer)."""
+        cls.update()
+        for lay in cls.layers:
+            ent = lay._cache["f8"]
+            L.call("ups_weight_prep_f8", L.ptr(lay.V), lay.k * lay.k, lay.cin_v, lay.ci_log, lay.co,
+                   L.ptr(ent["w"]), L.ptr(ent["deq"]), L.stream())
+            ent["version"] = WeightVersion.value
+
+    @staticmethod
+    def eligible(layer, x):
+        return (Fp8.enabled and x.dtype == torch.bfloat16 and layer.k == 3 and layer.stride == 1
+                and x.shape[1] % 16 == 0 and x.shape[2] % 16 == 0 and round8(layer.ci_log) % 64 == 0 and layer.co >= 64)
+
+
 class ConvLayer(object):
     """One conv2d variable pair (V [kh,kw,Cin(+2),Cout] HWIO fp32, b [Cout]) + its launch geometry."""
 
@@ -203,6 +256,28 @@ class ConvLayer(object):
                        (C.c_int32 * 9)(*dy), (C.c_int32 * 9)(*dx), self.stride, self.stride, ax, ay,
                        L.ptr(ent["ctab"]), L.stream())
             ent["version"] = WeightVersion.value
+        return ent
+
+    def prepared_f8(self, x):
+        """e4m3 weights + per-channel dequantisation factors + this layer's activation-scale slot."""
+        ent = self._cache.get("f8")
+        dev = self.V.device
+        if ent is None:
+            kc = -(-self.ci_log // 64)
+            ent = {"version": -1, "slot": Fp8.slot(dev), "primed": False,
+                   "w": torch.empty((self.k * self.k, kc, self.co, 64), dtype=torch.uint8, device=dev),
+                   "deq": torch.empty((self.co,), dtype=torch.float32, device=dev)}
+            self._cache["f8"] = ent
+            if not self.frozen:
+                Fp8.layers.append(self)
+        if ent["version"] != WeightVersion.value and not (self.frozen and ent["version"] >= 0):
+            L.call("ups_weight_prep_f8", L.ptr(self.V), self.k * self.k, self.cin_v, self.ci_log, self.co,
+                   L.ptr(ent["w"]), L.ptr(ent["deq"]), L.stream())
+            ent["version"] = WeightVersion.value
+        if not ent["primed"]:       # first launch of the layer: scale from the tensor at hand (|act(x)| <= |x|)
+            m = x[..., :self.ci_log].abs().amax().float()
+            Fp8.scale[ent["slot"]] = torch.where(m > 0, (448.0 * Fp8.MARGIN) / m.clamp_min(1e-30), torch.ones_like(m))
+            ent["primed"] = True
         return ent
 
     def out_hw(self, hi, wi):
@@ -268,6 +343,12 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
     d.dact = None
     if mask is not None:
         d.mask_bits, d.mask_batch = mask[0].data_ptr(), x.shape[0]
+    elif Fp8.eligible(layer, x):
+        f8 = layer.prepared_f8(x)
+        d.w = f8["w"].data_ptr()
+        d.f8_deq = f8["deq"].data_ptr()
+        d.f8_scale = Fp8.scale[f8["slot"]:].data_ptr()
+        d.f8_amax = Fp8.amax[f8["slot"]].data_ptr()
     _attach_ws(d, x.device)
     assert round8(layer.ci_log) <= ldi, (layer.name, layer.ci_log, ldi)
     if KernelTimer.layer == layer.name and KernelTimer.enabled:
