@@ -4,7 +4,8 @@
 #      the bench line, and the per-(kernel, grid) durations of the patch kernel from the same trace
 #   2. the same with UPS_NO_OVERLAP=1 (everything on one stream: per-kernel durations without CU sharing)
 #   3. two --pmc passes (FETCH_SIZE, WRITE_SIZE) on the hot conv launch -> <tag>_pmc_dv_rb128.json (HBM bytes per launch)
-#   4. SQ counter passes on the same launch -> <tag>_sq_dv_rb128.txt (MFMA-pipe busy cycles vs CU-busy cycles, LDS conflicts)
+#   4. SQ counter passes on the same layer, forward / input gradient / weight gradient -> <tag>_sq_dv_rb128.txt (MFMA-pipe busy
+#      cycles vs CU-busy cycles, instruction counts, LDS conflicts); tools/bench_conv.py tables (bf16 and the fp8 forward)
 #   5. isolated timings of the HBM-bound kernel families -> <tag>_hbm_kernels.json
 # Everything lands in gpurun_out/profiles_<tag>/ on the box (merged back); copy what is to be judged into profiles/.
 export TMPDIR=/tmp
@@ -26,6 +27,7 @@ grep '"metric"' $O/bench_nooverlap.log > $O/${TAG}_bench_b64_nooverlap.json
 cp $(find $O/stats1 -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_b64_nooverlap_kernel_stats.csv
 python3 tools/trace_summary.py $(find $O/stats1 -name "*kernel_trace.csv" | head -1) bilinear > $O/${TAG}_bilinear_by_grid_nooverlap.txt
 python3 tools/trace_summary.py $(find $O/stats1 -name "*kernel_trace.csv" | head -1) conv3x3_patch > $O/${TAG}_patch_kernel_by_grid_nooverlap.txt
+python3 tools/by_grid.py $(find $O/stats1 -name "*kernel_trace.csv" | head -1) 10 0.1 > $O/${TAG}_by_kernel_and_grid_nooverlap.txt
 rm -rf $O/stats1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 tools/one_conv.py fwd > /dev/null 2>&1
@@ -55,9 +57,13 @@ json.dump({"kernel": "conv3x3_patch_kernel<bf16,128,2>",
           open(O + "/%s_pmc_dv_rb128.json" % tag, "w"), indent=1)
 PY
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-bash tools/pmc_conv.sh ${TAG}_sq fwd > /dev/null 2>&1
-cp $R/gpurun_out/pmc_${TAG}_sq.txt $O/${TAG}_sq_dv_rb128.txt 2>/dev/null
-rm -rf $R/gpurun_out/pmc_${TAG}_sq
+for m in fwd dgrad wgrad; do
+  bash tools/pmc_conv.sh ${TAG}_sq_$m $m > /dev/null 2>&1
+  (echo "== $m"; cat $R/gpurun_out/pmc_${TAG}_sq_$m.txt) >> $O/${TAG}_sq_dv_rb128.txt 2>/dev/null
+  rm -rf $R/gpurun_out/pmc_${TAG}_sq_$m $R/gpurun_out/pmc_${TAG}_sq_$m.txt
+done
+python3 tools/bench_conv.py --iters 10 > $O/${TAG}_bench_conv.txt 2>&1
+python3 tools/bench_conv.py --fp8 --iters 10 --only dv_rb128,dv_rb64,dv_rb32,dv_rb16,ea_rb2,vgg3_2,vgg4_2 > $O/${TAG}_bench_conv_fp8.txt 2>&1
 python3 tools/hbm_roofline.py --json $O/${TAG}_hbm_kernels.json > $O/${TAG}_hbm_kernels.txt 2>&1
 cat $O/${TAG}_bench_b64.json | cut -c1-300; cat $O/${TAG}_bench_b64_nooverlap.json | cut -c1-200
 head -14 $O/${TAG}_bench_b64_kernel_stats.csv | cut -c1-160
