@@ -14,12 +14,25 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+FIXTURES = {"native": "full_cub128_step.npz", "resize256": "full_cub128_step_resize256.npz",
+            # the other BASELINE.json configs at their full widths (tests/golden/make_golden_full.py CONFIGS)
+            "pennaction128": "full_pennaction128_step.npz", "deepfashion256": "full_deepfashion256_step.npz",
+            "cub256p20": "full_cub256p20_step.npz"}
+
+
 def _trainer(dev, precision, perceptual_input="native"):
+    import sys
     import upsparts_amd  # noqa: F401
     from upsparts_amd import configs
     from upsparts_amd.model import TrainModel, Trainer
     from oracle import ref_model as R
-    cfg = copy.deepcopy(configs.cub_config(n_parts=10, batch_size=2))
+    if perceptual_input in ("native", "resize256"):
+        cfg = copy.deepcopy(configs.cub_config(n_parts=10, batch_size=2))
+    else:
+        sys.path.insert(0, GOLD)
+        import make_golden_full as G
+        cfg = copy.deepcopy(G.CONFIGS[perceptual_input]())
+        perceptual_input = "native"
     cfg["precision"] = precision
     cfg["perceptual_input"] = perceptual_input
     model = TrainModel(cfg, device=dev, seed=0)
@@ -39,35 +52,39 @@ def _iou(hard, gold_argmax, P):
     return float(np.mean(ious))
 
 
-@pytest.mark.parametrize("mode", ["native", "resize256"])
+@pytest.mark.parametrize("mode", ["native", "resize256", "pennaction128", "deepfashion256", "cub256p20"])
 def test_full_width_step_fp32_matches_oracle_fixture(dev, mode):
-    z = np.load(os.path.join(GOLD, "full_cub128_step.npz" if mode == "native" else "full_cub128_step_resize256.npz"))
+    z = np.load(os.path.join(GOLD, FIXTURES[mode]))
     cfg, model, trainer, views, noise = _trainer(dev, "fp32", mode)
     losses = trainer.train_step(views, noise)
     dbg = trainer._debug
-    B, P = cfg["batch_size"], cfg["n_parts"]
+    B, P, S = cfg["batch_size"], cfg["n_parts"], cfg["spatial_size"]
     hard = dbg["hard"]
     agree0 = float((hard[:B].argmax(-1).cpu().numpy() == z["hard0_argmax"]).mean())
     agree1 = float((hard[B:].argmax(-1).cpu().numpy() == z["hard1_argmax"]).mean())
     assert min(agree0, agree1) >= 0.999, "hard masks: agreement {} / {}".format(agree0, agree1)
-    assert np.array_equal(dbg["px"].cpu().numpy()[:B], z["px0"]) and np.array_equal(dbg["px"].cpu().numpy()[B:], z["px1"])
+    if "px0" in z.files:
+        assert np.array_equal(dbg["px"].cpu().numpy()[:B], z["px0"]) and np.array_equal(dbg["px"].cpu().numpy()[B:], z["px1"])
     lm = dbg["l_mean"]
     assert abs(float(lm[:B].double().norm()) - float(z["l0_mean_norm"])) <= 1e-3 * float(z["l0_mean_norm"])
     assert abs(float(lm[B:].double().norm()) - float(z["l1_mean_norm"])) <= 1e-3 * float(z["l1_mean_norm"])
-    pooled = torch.nn.functional.avg_pool2d(lm[:B].permute(0, 3, 1, 2), 8).permute(0, 2, 3, 1).cpu().numpy()
+    pooled = torch.nn.functional.avg_pool2d(lm[:B].permute(0, 3, 1, 2), S // 16).permute(0, 2, 3, 1).cpu().numpy()
     assert np.abs(pooled - z["l0_mean_16x16"]).max() <= 1e-3 * np.abs(z["l0_mean_16x16"]).max()
     gen = dbg["generated"][..., :3].float()
-    g8 = torch.nn.functional.avg_pool2d(gen.permute(0, 3, 1, 2), 16).permute(0, 2, 3, 1).cpu().numpy()
-    assert np.abs(g8 - z["generated_8x8"]).max() <= 1e-3 * np.abs(z["generated_8x8"]).max(), "generated (16x16-pooled)"
+    g8 = torch.nn.functional.avg_pool2d(gen.permute(0, 3, 1, 2), S // 8).permute(0, 2, 3, 1).cpu().numpy()
+    assert np.abs(g8 - z["generated_8x8"]).max() <= 1e-3 * np.abs(z["generated_8x8"]).max(), "generated (pooled to 8x8)"
     assert abs(float(gen.abs().mean()) - float(z["generated_absmean"])) <= 1e-3 * float(z["generated_absmean"])
     assert abs(float(dbg["feat"].double().norm()) - float(z["feat_norm"])) <= 1e-3 * float(z["feat_norm"])
     for k in losses:
         lo, lh = float(z["loss_" + k]), float(losses[k])
         assert abs(lo - lh) <= 1e-3 * max(1.0, abs(lo)), "loss {}: oracle {} hip {}".format(k, lo, lh)
     logs = trainer.fetch_logs()
-    for k in ("prior_gmrf", "mask0_kl", "weakly_superv_loss_p", "variance_loss", "bottleneck_loss", "mi_constraint",
-              "independent_mi_constraint", "perceptual", "patch_loss", "zr_mumford_sha", "z_area_cost",
-              "z_mumford_sha_smoothness_cost", "z_mumford_sha_contour_cost"):
+    want_logs = ("prior_gmrf", "mask0_kl", "weakly_superv_loss_p", "variance_loss", "bottleneck_loss", "mi_constraint",
+                 "independent_mi_constraint", "perceptual", "patch_loss", "zr_mumford_sha", "z_area_cost",
+                 "z_mumford_sha_smoothness_cost", "z_mumford_sha_contour_cost")
+    checked = [k for k in want_logs if "log_" + k in z.files and k in logs]
+    assert len(checked) >= 8, checked
+    for k in checked:
         lo = float(z["log_" + k])
         assert abs(lo - logs[k]) <= 1e-3 * max(1e-6, abs(lo)) + 1e-9, "log {}: oracle {} hip {}".format(k, lo, logs[k])
     names, norms, sums = list(z["grad_names"]), z["grad_norms"], z["grad_sums"]
@@ -79,22 +96,34 @@ def test_full_width_step_fp32_matches_oracle_fixture(dev, mode):
             worst = (str(n), e)
     assert worst[1] <= 2e-3, "gradient norm of {}: rel err {:.3e}".format(*worst)
     for k in ("loa", "lor", "avg_mim", "avg_independent_mim", "avg_acc0", "avg_loss_dis1"):
+        if "state_" + k not in z.files:
+            continue
         want = float(z["state_" + k])
         assert abs(float(trainer.state[k]) - want) <= 1e-3 * max(1e-3, abs(want)), k
 
 
-def test_full_width_step_bf16_mask_iou(dev):
-    """The benchmark's dtype at the benchmark's widths: part-mask IoU vs the fp64 oracle >= 0.99 (north_star), losses within 5 %."""
-    z = np.load(os.path.join(GOLD, "full_cub128_step.npz"))
-    cfg, model, trainer, views, noise = _trainer(dev, "bf16")
+@pytest.mark.parametrize("mode,precision", [("native", "bf16"), ("pennaction128", "bf16"), ("deepfashion256", "bf16"),
+                                            ("cub256p20", "bf16"), ("cub256p20", "fp8")])
+def test_full_width_step_bf16_mask_iou(dev, mode, precision):
+    """The benchmark's dtype at the benchmark's widths -- and at the widths / sizes of the other BASELINE configs; config #5 (CUB
+    256x256, 20 parts) also with the fp8 forward: part-mask IoU vs the fp64 oracle >= 0.99 (north_star), losses within 5 %
+    (fp8: IoU >= 0.98, losses within 10 %)."""
+    z = np.load(os.path.join(GOLD, FIXTURES[mode]))
+    cfg, model, trainer, views, noise = _trainer(dev, precision, mode)
     losses = trainer.train_step(views, noise)
     B, P = cfg["batch_size"], cfg["n_parts"]
     hard = trainer._debug["hard"]
     iou0, iou1 = _iou(hard[:B], z["hard0_argmax"], P), _iou(hard[B:], z["hard1_argmax"], P)
-    assert min(iou0, iou1) >= 0.99, "bf16 part-mask IoU vs oracle: {} / {}".format(iou0, iou1)
+    print("{} {}: part-mask IoU vs oracle {:.4f} / {:.4f}".format(mode, precision, iou0, iou1))
+    if precision == "fp8":
+        from upsparts_amd import ops
+        assert ops.Fp8.count > 0
+        ops.Fp8.enabled = False
+    bar, tol = (0.98, 0.10) if precision == "fp8" else (0.99, 0.05)
+    assert min(iou0, iou1) >= bar, "{} part-mask IoU vs oracle: {} / {}".format(precision, iou0, iou1)
     for k in losses:
         lo, lh = float(z["loss_" + k]), float(losses[k])
-        assert abs(lo - lh) <= 5e-2 * max(1.0, abs(lo)), "loss {}: oracle {} hip(bf16) {}".format(k, lo, lh)
+        assert abs(lo - lh) <= tol * max(1.0, abs(lo)), "loss {}: oracle {} hip({}) {}".format(k, lo, precision, lh)
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp32", "fp8"])
