@@ -284,6 +284,9 @@ Variant pick(const ups_wgrad_desc* d) {
 bool eligible(const ups_wgrad_desc* d) {
     if (d->dtype != UPS_BF16 || d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1) return false;
     if (d->hi != d->ho || d->wi != d->wo || d->hi % 16 || d->wi % 16) return false;
+    // 32-bit byte offsets of a staged item from the unit's scalar base (patch of 10 rows; 24-bit operands of the v_mad_u32_u24)
+    if ((long long)(PROWS + 1) * d->wi * d->ldi * 2 >= (1ll << 31) || (long long)(TH + 1) * d->wi * d->ldo * 2 >= (1ll << 31)) return false;
+    if ((long long)PROWS * d->wi >= (1 << 24) || (long long)d->ldi * 2 >= (1 << 24)) return false;
     bool seen[9] = {false, false, false, false, false, false, false, false, false};
     for (int t = 0; t < 9; ++t) {
         const int dy = d->tap_dy[t], dx = d->tap_dx[t];
