@@ -93,9 +93,21 @@ typedef struct {
     const float* f8_deq;         /* [co] or NULL */
     const float* f8_scale;       /* device scalar */
     float*       f8_amax;        /* [64] */
+    /* Depth-to-space output (input gradient of a 3x3 / stride-2 convolution as ONE stride-1 convolution over the gradient
+     * lattice, N:811-817 backward): d2s = C > 0 (power of two, >= 8) declares co = 4 C GEMM channels ordered (py, px, c); channel c of
+     * class (py, px) at lattice pixel (y, x) is written to out[n][2y + py][2x + px][c] of a [n, out_h = 2 ho, out_w = 2 wo, ldo]
+     * tensor; res / dact are read on that lattice.  `w` = ups_weight_prep_d2s.  bf16 patch kernel only (else UPS_E_UNSUPPORTED). */
+    int32_t      d2s;
 } ups_conv_desc;
 
 int ups_conv_igemm(const ups_conv_desc* d, void* stream);
+
+/* Weights of the depth-to-space input gradient of a 3x3 / stride-2 'SAME' convolution with forward variable V [3][3][cin_v][co]:
+ * w[t9][k][(py*2+px)*C + c][32] (blocked-K over the co gradient channels, bf16), t9 = (dy+1)*3 + (dx+1) the 3x3 neighbourhood of
+ * the gradient lattice, C = ci_log rounded up to a power of two (>= 8), = V[r][s][c][k-chunk] where tap (r, s) reaches class (py, px)
+ * from lattice offset (dy, dx) -- r = py + pad_y - 2 dy, s likewise -- and zero elsewhere. */
+int ups_weight_prep_d2s(const float* src, int32_t cin_v, int32_t ci_log, int32_t co, int32_t pad_y, int32_t pad_x, int32_t C,
+                        void* w, void* stream);
 
 /* e4m3 weights for the fp8 forward: w_f8[tap][k][c][64] = e4m3(V[tap][64 k + j][c] * 448 / amax_c), zero padded in K,
  * deq[c] = amax_c / 448 with amax_c = max |V[:, :ci_log, c]| (the CoordConv rows ci_log.. stay fp32 in ups_coord_table).

@@ -91,6 +91,11 @@ CONV_CASES = [
     (24, 128, 128, 32, 32, 3, 1, True, "leaky_relu", True),    # <bf16,32,1,16>: res-block with CoordConv
     (25, 128, 128, 8, 32, 3, 1, False, None, False),           # image-input conv
     (24, 128, 128, 32, 64, 3, 1, False, "relu", False),        # <bf16,64,1,16>
+    # 3x3 / stride-2 downsample layers whose bf16 input gradient runs as ONE depth-to-space convolution over the gradient lattice
+    (4, 64, 64, 32, 64, 3, 2, False, None, False),             # encoder first downsample: 4 x 32 = 128 GEMM channels, one N-tile
+    (2, 128, 128, 32, 64, 3, 2, False, "leaky_relu", False),   # with act' on the 2x lattice
+    (3, 32, 32, 128, 256, 3, 2, True, None, False),            # CoordConv layer, 512 GEMM channels (4 N-tiles), kchunks 8
+    (2, 64, 32, 64, 128, 3, 2, False, "relu", False),          # non-square, two N-tiles
 ]
 
 

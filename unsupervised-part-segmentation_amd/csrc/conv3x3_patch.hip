@@ -49,6 +49,9 @@ struct PatchK {
     // fp8 forward (ups_conv_desc.f8_*): wgt holds e4m3 weights scaled per output channel, f8_deq[c] = 1 / that scale,
     // *f8_scale the activation scale of this launch, f8_amax 64 slots that collect max |act(x)| for the next one
     const float* f8_deq; const float* f8_scale; float* f8_amax;
+    // depth-to-space output (ups_conv_desc.d2s): GEMM channel ch = (py*2 + px) * (1 << d2s_shift) + c is channel c of output
+    // pixel (2y + py, 2x + px) of a [n, 2h, 2w, ld] tensor (res / dact live on that lattice too)
+    int d2s, d2s_shift;
 };
 
 __device__ __forceinline__ int fast_div(int n, int d, unsigned m) {
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     const T* __restrict__ dact = (const T*)p.dact;
     // the block's first image as uniform (scalar) bases; tile pixel index (ty * 16 + tx) -> 32-bit pixel index from there
     // (the launcher checks that an image group stays below 2^31 bytes in every tensor)
-    const long long img_pix = (long long)img_pm * p.h * p.w;
+    const long long img_pix = (long long)img_pm * p.h * p.w * (p.d2s ? 4 : 1);
     outT += img_pix * p.ldo; outF += img_pix * p.ldo;
     if (res) res += img_pix * p.ldr;
     if (dact) dact += img_pix * p.ldd;
@@ -613,6 +616,15 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         const int ty = q >> 4, tx = q & 15;
         if constexpr (SUB == TS) return (unsigned)((ty0 + ty) * p.w + tx0 + tx);
         else return (unsigned)(((ty / SUB) * G + tx / SUB) * (SUB * SUB) + (ty % SUB) * SUB + (tx % SUB));
+    };
+    // element offset of GEMM channel chn of tile pixel q in a tensor of ld physical channels (plain or depth-to-space)
+    auto gaddr = [&](int q, int chn, int ld) __attribute__((always_inline)) -> unsigned {
+        if (SUB == TS && p.d2s) {
+            const int cls = chn >> p.d2s_shift, c = chn - (cls << p.d2s_shift);
+            const int y2 = 2 * (ty0 + (q >> 4)) + (cls >> 1), x2 = 2 * (tx0 + (q & 15)) + (cls & 1);
+            return (unsigned)((y2 * (2 * p.w) + x2) * ld + c);
+        }
+        return gpix(q) * (unsigned)ld + (unsigned)chn;
     };
     auto ycoord = [&](int ty) -> int { return SUB == TS ? ty0 + ty : ty % SUB; };
     auto xcoord = [&](int tx) -> int { return SUB == TS ? tx0 + tx : tx % SUB; };
@@ -631,11 +643,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #pragma unroll
                 for (int i = 0; i < NIT; ++i) {
                     const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
-                    const unsigned pix = gpix(px);
                     if (ch * 8 < c_lim) {
-                        if (res) *(uint4*)(R0 + px * ERS + ch * 16) = *(const uint4*)(res + pix * p.ldr + nt * BN + ch * 8);
+                        if (res) *(uint4*)(R0 + px * ERS + ch * 16) = *(const uint4*)(res + gaddr(px, nt * BN + ch * 8, p.ldr));
                         if (dact) {
-                            const uint4 dv = *(const uint4*)(dact + pix * p.ldd + nt * BN + ch * 8);
+                            const uint4 dv = *(const uint4*)(dact + gaddr(px, nt * BN + ch * 8, p.ldd));
                             const unsigned wv[4] = {dv.x, dv.y, dv.z, dv.w};
                             unsigned sb = 0;
 #pragma unroll
@@ -738,8 +749,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
-                const unsigned pix = gpix(px);
-                if (ch * 8 < c_lim) *(uint4*)(outT + pix * p.ldo + nt * BN + ch * 8) = *(const uint4*)(R0 + px * ERS + ch * 16);
+                if (ch * 8 < c_lim) *(uint4*)(outT + gaddr(px, nt * BN + ch * 8, p.ldo)) = *(const uint4*)(R0 + px * ERS + ch * 16);
             }
             return;
         }
@@ -880,7 +890,8 @@ int launch_t(const PatchK& k, hipStream_t s) {
 int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox)
         return 1;
-    if (d->hi != d->ho || d->wi != d->wo || d->out_h != d->ho || d->out_w != d->wo) return 1;
+    if (d->hi != d->ho || d->wi != d->wo) return 1;
+    if (d->d2s ? (d->out_h != 2 * d->ho || d->out_w != 2 * d->wo) : (d->out_h != d->ho || d->out_w != d->wo)) return 1;
     // 16-bit image-pitch pixel index of a staged item, 24-bit row pitch for its v_mad_u32_u24
     if ((long long)(TS + 2) * d->wi >= 0xffff || (long long)d->ldi * 4 >= (1 << 24)) return 1;
     {   // 32-bit offsets inside the image group of a block (up to 16 images per tile for the 4x4 case)
@@ -908,6 +919,16 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     PatchK k;
     k.mask = d->mask_bits; k.mask_grad = d->mask_grad; k.mask_view = d->mask_view;
     k.f8_deq = d->f8_deq; k.f8_scale = d->f8_scale; k.f8_amax = d->f8_amax;
+    k.d2s = 0; k.d2s_shift = 0;
+    if (d->d2s) {
+        // depth-to-space output: bf16 staged epilogue on 16-aligned lattices, 4 classes of d2s (power of two, >= 8) channels
+        if (d->dtype != UPS_BF16 || small || (d->hi % TS) || (d->wi % TS) || d->d2s < 8 || (d->d2s & (d->d2s - 1)) ||
+            d->co != 4 * d->d2s || d->co_fill != d->co || d->out_f32 || (d->ldo & 7) || d->mask_bits || d->mask_grad ||
+            d->coord_tab || d->bias || d->f8_deq)
+            return 1;
+        k.d2s = 1;
+        while ((1 << k.d2s_shift) < d->d2s) ++k.d2s_shift;
+    }
     if (d->f8_deq) {
         if (d->dtype != UPS_BF16 || small || (d->hi % TS) || (d->wi % TS) || d->ci % 64 || d->mask_bits || d->mask_grad ||
             !d->f8_scale || !d->f8_amax || d->dact)

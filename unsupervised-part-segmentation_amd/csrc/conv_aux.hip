@@ -296,6 +296,43 @@ __global__ __launch_bounds__(256) void weight_prep_f8_kernel(const float* __rest
 }
 }  // namespace
 
+namespace {
+// one thread per (t9, k-chunk, row, 8-element piece) of the blocked-K weight image
+__global__ __launch_bounds__(256) void weight_prep_d2s_kernel(const float* __restrict__ src, int cin_v, int ci_log, int co,
+                                                              int pad_y, int pad_x, int C, int kc, uint4* __restrict__ w,
+                                                              long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int piece = (int)(i & 3);
+    long long r = i >> 2;
+    const int row = (int)(r % (4 * C)); r /= 4 * C;
+    const int k = (int)(r % kc);
+    const int t9 = (int)(r / kc);
+    const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+    const int cls = row / C, c = row - cls * C, py = cls >> 1, px = cls & 1;
+    const int rr = py + pad_y - 2 * dy, ss = px + pad_x - 2 * dx;      // forward tap that maps lattice offset (dy, dx) to this class
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kk = k * 32 + piece * 8 + e;                        // gradient channel = forward output channel
+        f[e] = (rr >= 0 && rr < 3 && ss >= 0 && ss < 3 && c < ci_log && kk < co)
+                   ? src[((long long)(rr * 3 + ss) * cin_v + c) * co + kk] : 0.f;
+    }
+    w[i] = Chunk<bf16>::pack(f);
+}
+}  // namespace
+
+extern "C" int ups_weight_prep_d2s(const float* src, int32_t cin_v, int32_t ci_log, int32_t co, int32_t pad_y, int32_t pad_x,
+                                   int32_t C, void* w, void* stream) {
+    UPS_CHECK_ARG(src && w && ci_log >= 1 && cin_v >= ci_log && co >= 1 && C >= ci_log && C >= 8 && (C & (C - 1)) == 0);
+    const int kc = (co + 31) / 32;
+    const long long total = 9ll * kc * 4 * C * 4;
+    hipLaunchKernelGGL(weight_prep_d2s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, cin_v,
+                       ci_log, co, pad_y, pad_x, C, kc, (uint4*)w, total);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
 extern "C" int ups_weight_prep_f8(const float* src, int32_t ntaps, int32_t cin_v, int32_t ci_log, int32_t co, void* w_f8,
                                   float* deq, void* stream) {
     UPS_CHECK_ARG(src && w_f8 && deq && ntaps >= 1 && ci_log >= 1 && cin_v >= ci_log && co >= 1);

@@ -441,7 +441,7 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d->ci > 0 && d->ci % 8 == 0 && d->ldi % 8 == 0 && d->ci <= d->ldi);
     UPS_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= 9);
     UPS_CHECK_ARG(d->act_slope >= 0.f && d->act_slope <= 1.f);    // activation-on-load is max(x, slope * x)
-    UPS_CHECK_ARG(d->co >= 1 && d->co_fill >= d->co && d->co_fill <= d->ldo);
+    UPS_CHECK_ARG(d->co >= 1 && d->co_fill >= d->co && (d->d2s ? d->d2s <= d->ldo : d->co_fill <= d->ldo));
     UPS_CHECK_ARG(d->n > 0 && d->ho > 0 && d->wo > 0 && d->hi > 0 && d->wi > 0);
     UPS_CHECK_ARG(!d->coord_tab || (d->kh * d->kw == d->ntaps && d->kh <= 3 && d->kw <= 3));
     UPS_CHECK_ARG(((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->w & 15) == 0);
@@ -452,6 +452,10 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
         const int pr = ups_conv3x3_patch_try(d, (hipStream_t)stream);
         if (pr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
         if (pr < 0) { ups_set_error("ups_conv_igemm: patch kernel launch setup failed"); return pr; }
+    }
+    if (d->d2s) {
+        ups_set_error("ups_conv_igemm: the depth-to-space output needs the bf16 3x3 / stride-1 patch kernel (16-aligned lattice, 4 x 2^k channels)");
+        return UPS_E_UNSUPPORTED;
     }
     if (d->f8_deq) {
         ups_set_error("ups_conv_igemm: the fp8 forward needs the bf16 3x3 / stride-1 patch kernel (16-aligned images, ci %% 64 == 0, no mask)");

@@ -113,6 +113,7 @@ class PrepRegistry(object):
     def __init__(self):
         self.entries = []          # (layer, ent, dtype_code, hi, wi)
         self.tables = {}           # dtype_code -> (items_dev, prefix_dev, n, total_blocks)
+        self.extra = []            # per-layer conversions outside the batched launch (depth-to-space dgrad weights)
         self.dirty = True
 
     def register(self, layer, ent, dtype_code, hi, wi):
@@ -156,6 +157,8 @@ class PrepRegistry(object):
             L.call("ups_weight_prep_batch", L.ptr(items_dev), L.ptr(prefix_dev), n, total, dcode, L.stream())
         for (_lay, ent, _d, _h, _w) in self.entries:
             ent["version"] = WeightVersion.value
+        for fn in self.extra:
+            fn()
 
 
 class Fp8(object):
@@ -258,6 +261,34 @@ class ConvLayer(object):
             ent["version"] = WeightVersion.value
         return ent
 
+    def d2s_channels(self, x):
+        """C of the depth-to-space input gradient (ups_conv_desc.d2s) when this layer / tensor can take it, else 0."""
+        c = self.ci_log
+        ok = (D2S_DGRAD and self.k == 3 and self.stride == 2 and x.dtype == torch.bfloat16 and c >= 8 and (c & (c - 1)) == 0
+              and x.shape[-1] == c and x.shape[1] % 32 == 0 and x.shape[2] % 32 == 0)
+        return c if ok else 0
+
+    def prepared_d2s(self, hi, wi):
+        """Weights of the one-launch input gradient of a 3x3 / stride-2 layer (ups_weight_prep_d2s)."""
+        ent = self._cache.get("d2s")
+        if ent is None:
+            kc = -(-self.co // 32)
+            ent = {"version": -1, "w": torch.empty((9, kc, 4 * self.ci_log, 32), dtype=torch.bfloat16, device=self.V.device)}
+            _, pby = same_geometry(hi, 3, 2)
+            _, pbx = same_geometry(wi, 3, 2)
+
+            def prep():
+                L.call("ups_weight_prep_d2s", L.ptr(self.V), self.cin_v, self.ci_log, self.co, pby, pbx, self.ci_log,
+                       L.ptr(ent["w"]), L.stream())
+                ent["version"] = WeightVersion.value
+            ent["prep"] = prep
+            self._cache["d2s"] = ent
+            if self.registry is not None and not self.frozen:
+                self.registry.extra.append(prep)
+        if ent["version"] != WeightVersion.value and not (self.frozen and ent["version"] >= 0):
+            ent["prep"]()
+        return ent
+
     def prepared_f8(self, x):
         """e4m3 weights + per-channel dequantisation factors + this layer's activation-scale slot."""
         ent = self._cache.get("f8")
@@ -303,6 +334,7 @@ def _fill_taps(desc, dy, dx, tw, ntaps):
 
 
 SPLITK_WS_BYTES = 48 << 20
+D2S_DGRAD = os.environ.get("UPS_NO_D2S", "0") != "1"      # one-launch input gradient of the stride-2 layers (A/B switch)
 
 
 def _attach_ws(d, device):
@@ -384,6 +416,30 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
     k, st = layer.k, layer.stride
     _, pby = same_geometry(hi, k, st)
     _, pbx = same_geometry(wi, k, st)
+    cd2s = layer.d2s_channels(x) if mask_view is None else 0
+    if cd2s:
+        # one stride-1 3x3 convolution over the gradient lattice with 4 C channels (parity class, channel), written
+        # depth-to-space: g is read once and whole output rows are stored (the per-class launches below store every other pixel)
+        d = L.ConvDesc()
+        d.dtype = dcode
+        d.n, d.hi, d.wi, d.ci, d.ldi = n, ho, wo, round8(layer.co), g.shape[-1]
+        d.ho, d.wo, d.co, d.co_fill, d.ldo = ho, wo, 4 * cd2s, 4 * cd2s, ldi
+        d.out_h, d.out_w, d.out_sy, d.out_sx, d.out_oy, d.out_ox = hi, wi, 1, 1, 0, 0
+        d.in_sy = d.in_sx = 1
+        _fill_taps(d, [t // 3 - 1 for t in range(9)], [t % 3 - 1 for t in range(9)], list(range(9)), 9)
+        d.kh = d.kw = 3
+        d.act_in, d.act_slope, d.out_f32 = 0, layer.slope, 0
+        d.dact_kind = layer.act_in
+        d.ldr = res.shape[-1] if res is not None else 0
+        d.ldd = ldi
+        d.in_, d.w, d.out = g.data_ptr(), layer.prepared_d2s(hi, wi)["w"].data_ptr(), gx.data_ptr()
+        d.bias, d.coord_tab = None, None
+        d.res = res.data_ptr() if res is not None else None
+        d.dact = x.data_ptr() if layer.act_in != L.ACT_NONE else None
+        d.d2s = cd2s
+        _attach_ws(d, x.device)
+        L.call("ups_conv_igemm", C.byref(d), L.stream())
+        return gx
     classes = [(0, 0)] if st == 1 else [(py, px) for py in range(st) for px in range(st)]
     for (py, px) in classes:
         lat_h = (hi - py + st - 1) // st
