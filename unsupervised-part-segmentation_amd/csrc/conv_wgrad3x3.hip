@@ -16,8 +16,11 @@
 
 namespace {
 
-constexpr int TW = 16, TH = 8;           // half-tile: 8 rows x 16 pixels
-constexpr int PWID = TW + 2, PROWS = TH + 2, PPIX = PWID * PROWS;   // 18 x 10 = 180 patch pixels
+// A unit is TH rows x 16 pixels of one image: half-tiles (TH = 8; 18 x 10 = 180 patch pixels) for the wide variants, whose two
+// LDS buffers would not fit otherwise, whole 16x16 tiles (TH = 16) for the thin ones (CB = 32, BN <= 64): those are bound by the
+// load -> LDS -> barrier round trip of a unit, and a unit twice as large halves the number of round trips.
+constexpr int TW = 16;
+constexpr int PWID = TW + 2;
 
 struct Wg3K {
     int n, h, w, ci, ldi, ci_log, cin_v, co, ldo, act_in, want_bias, units_total, units_per, tiles_x, tiles_y;
@@ -70,8 +73,9 @@ __device__ inline bf16x8 tr_frag_d(const unsigned char* tile, int row0, int wco,
     return u.b;
 }
 
-template <int CB, int BN>
+template <int CB, int BN, int TH>
 __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const int cit, const int cot, const int nsplit) {
+    constexpr int PROWS = TH + 2, PPIX = PWID * PROWS;
     constexpr int WCI = CB / 32, WCO = BN / 32, WK = 8 / (WCI * WCO);
     constexpr int RSX = lds_stride3(CB * 2), RSD = BN * 2;
     constexpr int XB = PPIX * RSX, DB = TH * TW * RSD;
@@ -142,8 +146,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 
     auto unit_origin = [&](int u, int& img, int& y0, int& x0) {
-        const int half = u & 1;
-        int t = u >> 1;
+        const int half = TH == 8 ? (u & 1) : 0;
+        int t = TH == 8 ? (u >> 1) : u;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y;
         img = t / p.tiles_y;
@@ -271,13 +275,14 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
     }
 }
 
-struct Variant { int cb, bn, wk; };
+struct Variant { int cb, bn, wk, th; };
 
 Variant pick(const ups_wgrad_desc* d) {
     Variant v;
     v.cb = d->ci > 32 ? 64 : 32;
     v.bn = d->co > 64 ? 128 : (d->co > 32 ? 64 : 32);
     v.wk = 8 / ((v.cb / 32) * (v.bn / 32));
+    v.th = (v.cb == 32 && v.bn <= 64) ? 16 : 8;
     return v;
 }
 
@@ -285,8 +290,8 @@ bool eligible(const ups_wgrad_desc* d) {
     if (d->dtype != UPS_BF16 || d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1) return false;
     if (d->hi != d->ho || d->wi != d->wo || d->hi % 16 || d->wi % 16) return false;
     // 32-bit byte offsets of a staged item from the unit's scalar base (patch of 10 rows; 24-bit operands of the v_mad_u32_u24)
-    if ((long long)(PROWS + 1) * d->wi * d->ldi * 2 >= (1ll << 31) || (long long)(TH + 1) * d->wi * d->ldo * 2 >= (1ll << 31)) return false;
-    if ((long long)PROWS * d->wi >= (1 << 24) || (long long)d->ldi * 2 >= (1 << 24)) return false;
+    if (19ll * d->wi * d->ldi * 2 >= (1ll << 31) || 17ll * d->wi * d->ldo * 2 >= (1ll << 31)) return false;
+    if (18ll * d->wi >= (1 << 24) || (long long)d->ldi * 2 >= (1 << 24)) return false;
     bool seen[9] = {false, false, false, false, false, false, false, false, false};
     for (int t = 0; t < 9; ++t) {
         const int dy = d->tap_dy[t], dx = d->tap_dx[t];
@@ -298,19 +303,20 @@ bool eligible(const ups_wgrad_desc* d) {
     return !(force && force[0] == '1');
 }
 
-template <int CB, int BN>
+template <int CB, int BN, int TH>
 int launch3(const Wg3K& k, int cit, int cot, int splitk, hipStream_t s) {
     constexpr int RSX = lds_stride3(CB * 2), RSD = BN * 2;
+    constexpr int PPIX = PWID * (TH + 2);
     size_t shmem = 2 * (size_t)(PPIX * RSX + TH * TW * RSD);
     constexpr size_t red = (size_t)(8 / ((CB / 32) * (BN / 32)) - 1) * (CB / 32) * (BN / 32) * 4096;   // K-part reduction scratch
     if (shmem < red) shmem = red;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<CB, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<CB, BN, TH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shmem) != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wgrad3x3_kernel<CB, BN>), dim3(cit * cot * splitk), dim3(512), shmem, s, k, cit, cot, splitk);
+    hipLaunchKernelGGL((conv_wgrad3x3_kernel<CB, BN, TH>), dim3(cit * cot * splitk), dim3(512), shmem, s, k, cit, cot, splitk);
     return UPS_OK;
 }
 
@@ -321,7 +327,7 @@ int ups_wgrad3x3_plan(const ups_wgrad_desc* d, int* splitk, int* slabs) {
     if (!eligible(d)) return 1;
     const Variant v = pick(d);
     const int pairs = ups_cdiv(d->ci, v.cb) * ups_cdiv(d->co, v.bn);
-    const int units = d->n * (d->hi / 16) * (d->wi / 16) * 2;
+    const int units = d->n * (d->hi / 16) * (d->wi / 16) * (16 / v.th);
     // one block per CU for the big variant (151 KB of LDS per block): fewer, longer blocks halve the slab traffic
     int sk = ups_cdiv((v.cb == 64 && v.bn == 128) ? 256 : 512, pairs);
     if (sk > units / 4) sk = units / 4 > 0 ? units / 4 : 1;
@@ -338,7 +344,7 @@ int ups_wgrad3x3_run(const ups_wgrad_desc* d, hipStream_t s) {
     k.n = d->n; k.h = d->hi; k.w = d->wi; k.ci = d->ci; k.ldi = d->ldi; k.ci_log = d->ci_log; k.cin_v = d->cin_v;
     k.co = d->co; k.ldo = d->ldo; k.act_in = d->act_in; k.act_slope = d->act_slope; k.want_bias = d->grad_bias != nullptr;
     k.tiles_x = d->wi / 16; k.tiles_y = d->hi / 16;
-    k.units_total = d->n * k.tiles_x * k.tiles_y * 2;
+    k.units_total = d->n * k.tiles_x * k.tiles_y * (16 / v.th);
     k.units_per = ups_cdiv(k.units_total, d->splitk);
     k.in = d->in; k.dout = d->dout; k.ws = d->workspace;
     k.mask = d->mask_bits; k.mask_B = d->mask_batch;
@@ -348,10 +354,10 @@ int ups_wgrad3x3_run(const ups_wgrad_desc* d, hipStream_t s) {
         k.tap_wi |= (unsigned long long)d->tap_w[t] << (4 * t);
     }
     const int cit = ups_cdiv(d->ci, v.cb), cot = ups_cdiv(d->co, v.bn);
-    if (v.cb == 64 && v.bn == 128) return launch3<64, 128>(k, cit, cot, d->splitk, s);
-    if (v.cb == 64 && v.bn == 64) return launch3<64, 64>(k, cit, cot, d->splitk, s);
-    if (v.cb == 64 && v.bn == 32) return launch3<64, 32>(k, cit, cot, d->splitk, s);
-    if (v.cb == 32 && v.bn == 128) return launch3<32, 128>(k, cit, cot, d->splitk, s);
-    if (v.cb == 32 && v.bn == 64) return launch3<32, 64>(k, cit, cot, d->splitk, s);
-    return launch3<32, 32>(k, cit, cot, d->splitk, s);
+    if (v.cb == 64 && v.bn == 128) return launch3<64, 128, 8>(k, cit, cot, d->splitk, s);
+    if (v.cb == 64 && v.bn == 64) return launch3<64, 64, 8>(k, cit, cot, d->splitk, s);
+    if (v.cb == 64 && v.bn == 32) return launch3<64, 32, 8>(k, cit, cot, d->splitk, s);
+    if (v.cb == 32 && v.bn == 128) return launch3<32, 128, 8>(k, cit, cot, d->splitk, s);
+    if (v.cb == 32 && v.bn == 64) return launch3<32, 64, 16>(k, cit, cot, d->splitk, s);
+    return launch3<32, 32, 16>(k, cit, cot, d->splitk, s);
 }
