@@ -93,6 +93,8 @@ typedef struct {
     const float* f8_deq;         /* [co] or NULL */
     const float* f8_scale;       /* device scalar */
     float*       f8_amax;        /* [64] */
+    int32_t      f8_e5m2;        /* 1: `in` is a gradient -- staged as e5m2 (the input-gradient call of an fp8 layer; `w` from
+                                  * ups_weight_prep_f8 with transpose = 1), 0: e4m3 */
     /* Depth-to-space output (input gradient of a 3x3 / stride-2 convolution as ONE stride-1 convolution over the gradient
      * lattice, N:811-817 backward): d2s = C > 0 (power of two, >= 8) declares co = 4 C GEMM channels ordered (py, px, c); channel c of
      * class (py, px) at lattice pixel (y, x) is written to out[n][2y + py][2x + px][c] of a [n, out_h = 2 ho, out_w = 2 wo, ldo]
@@ -111,9 +113,11 @@ int ups_weight_prep_d2s(const float* src, int32_t cin_v, int32_t ci_log, int32_t
 
 /* e4m3 weights for the fp8 forward: w_f8[tap][k][c][64] = e4m3(V[tap][64 k + j][c] * 448 / amax_c), zero padded in K,
  * deq[c] = amax_c / 448 with amax_c = max |V[:, :ci_log, c]| (the CoordConv rows ci_log.. stay fp32 in ups_coord_table).
+ * transpose = 1: the input-gradient operand -- rows = input channels, K = output channels: w_f8[tap][k][ci][64] =
+ * e4m3(V[tap][ci][64 k + j] * 448 / amax_ci), deq[ci] = amax_ci / 448.
  * src is the HWIO fp32 variable [ntaps][cin_v][co] (N:644-652). */
-int ups_weight_prep_f8(const float* src, int32_t ntaps, int32_t cin_v, int32_t ci_log, int32_t co, void* w_f8, float* deq,
-                       void* stream);
+int ups_weight_prep_f8(const float* src, int32_t ntaps, int32_t cin_v, int32_t ci_log, int32_t co, int32_t transpose,
+                       void* w_f8, float* deq, void* stream);
 
 /* Weight gradient  dV[tap][ci][co] = sum_pix act(in)[src(pix,tap)][ci] * dout[pix][co]
  * (gradient of N:661-663 w.r.t. V), split-K over pixels into fp32 slabs + deterministic reduce.

@@ -549,3 +549,58 @@ def test_conv_fp8_forward(case, dev):
     ref = _oracle_conv(R, x.double(), V.double(), b.double(), 1, coords, act, res_self, None)
     err = float((got.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     assert err < 0.05, "fp8 forward vs unquantised convolution: rel RMS {:.3g}".format(err)
+
+
+@pytest.mark.parametrize("case", [
+    # n, h, cin, cout, coords, act
+    (4, 32, 128, 128, False, "leaky_relu"),
+    (2, 128, 256, 256, True, "leaky_relu"),
+    (3, 16, 64, 192, False, None),
+])
+def test_conv_fp8_input_gradient(case, dev):
+    """Input gradient of an fp8 layer: the gradient tensor staged as e5m2 (per-tensor scale), the transposed weights as e4m3
+    scaled per input channel, fp32 accumulation, act' from the bf16 forward input -- against the same arithmetic in torch."""
+    lib, ops, R = _mods()
+    n, h, cin, cout, coords, act = case
+    g0 = torch.Generator().manual_seed(12)
+    cv = cin + (2 if coords else 0)
+    V = torch.randn(3, 3, cv, cout, generator=g0) / math.sqrt(9 * cv)
+    V[:, :, : cin // 2] *= 3.0
+    b = torch.zeros(cout)
+    x = (torch.randn(n, h, h, cin, generator=g0)).to(torch.bfloat16)
+    gy = (torch.randn(n, h, h, cout, generator=g0) * 0.02).to(torch.bfloat16)
+    lay = _layer(ops, lib, V, b, 3, 1, coords, act, dev)
+    ops.Fp8.enabled = True
+    try:
+        assert ops.Fp8.eligible_grad(lay, gy.to(dev), x.to(dev))
+        gx = ops.conv_dgrad(gy.to(dev), x.to(dev), lay)
+        torch.cuda.synchronize()
+        f8 = lay._cache["f8g"]
+        s_g = float(ops.Fp8.scale[f8["slot"]].cpu())
+        amax_seen = float(ops.Fp8.amax[f8["slot"]].max().cpu())
+    finally:
+        ops.Fp8.enabled = False
+    gf = gy.float()
+    assert abs(amax_seen - float(gf.abs().max())) <= 1e-6 * amax_seen
+    assert abs(s_g - 57344.0 * ops.Fp8.MARGIN / float(gf.abs().max())) <= 1e-5 * s_g
+    gq = (gf * s_g).clamp(-57344, 57344).to(torch.float8_e5m2).double()
+    wmax = V[:, :, :cin].abs().amax(dim=(0, 1, 3))                              # per input channel
+    wq = (V[:, :, :cin] * (448.0 / wmax).view(1, 1, -1, 1)).clamp(-448, 448).to(torch.float8_e4m3fn).double()
+    assert_close(f8["deq"].cpu(), wmax / 448.0, 1e-6, "per-row dequantisation factors")
+    # conv^T with the quantised operands: gradient of sum(conv(z, wq) * gq) w.r.t. z
+    z = torch.zeros(n, h, h, cin, dtype=torch.float64, requires_grad=True)
+    y = R.conv2d_same(z, wq, torch.zeros(cout, dtype=torch.float64), 1)
+    ref_q, = torch.autograd.grad((y * gq).sum(), z)
+    ref_q = ref_q * (wmax.double() / 448.0) / s_g
+    xf = x.double()
+    if act == "leaky_relu":
+        ref_q = ref_q * torch.where(xf > 0, torch.ones_like(xf), torch.full_like(xf, 0.2))
+    assert_close(gx[..., :cin].float().cpu(), ref_q.float(), 1e-2, "fp8 input gradient vs e5m2 / e4m3 emulation")
+    # and against the unquantised gradient at the e5m2 error level
+    z2 = torch.zeros(n, h, h, cin, dtype=torch.float64, requires_grad=True)
+    y2 = R.conv2d_same(z2, V[:, :, :cin].double(), torch.zeros(cout, dtype=torch.float64), 1)
+    ref, = torch.autograd.grad((y2 * gf.double()).sum(), z2)
+    if act == "leaky_relu":
+        ref = ref * torch.where(xf > 0, torch.ones_like(xf), torch.full_like(xf, 0.2))
+    err = float((gx[..., :cin].double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert err < 0.08, "fp8 input gradient vs unquantised: rel RMS {:.3g}".format(err)

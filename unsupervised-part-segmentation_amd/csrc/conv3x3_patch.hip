@@ -49,6 +49,7 @@ struct PatchK {
     // fp8 forward (ups_conv_desc.f8_*): wgt holds e4m3 weights scaled per output channel, f8_deq[c] = 1 / that scale,
     // *f8_scale the activation scale of this launch, f8_amax 64 slots that collect max |act(x)| for the next one
     const float* f8_deq; const float* f8_scale; float* f8_amax;
+    int f8_e5m2;      // the staged tensor is a gradient: e5m2 operands (ups_conv_desc.f8_e5m2)
     // depth-to-space output (ups_conv_desc.d2s): GEMM channel ch = (py*2 + px) * (1 << d2s_shift) + c is channel c of output
     // pixel (2y + py, 2x + px) of a [n, 2h, 2w, ld] tensor (res / dact live on that lattice too)
     int d2s, d2s_shift;
@@ -79,11 +80,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 // ROWB > 0: the wave's tile rows are ROWB bytes apart in the patch image (one image per tile): fragment i is read at an
 // immediate offset i * ROWB from one per-tap lane address (no address arithmetic per read); ROWB == 0: rows from arow[].
 typedef __attribute__((ext_vector_type(2))) long i64x2;
-template <bool F8> struct Frag16 { typedef bf16x8 type; };
-template <> struct Frag16<true> { typedef i64x2 type; };
+template <int F8> struct Frag16 { typedef i64x2 type; };
+template <> struct Frag16<0> { typedef bf16x8 type; };
 // F8: a 16-byte fragment holds 16 e4m3 channels -- two v_mfma_f32_16x16x32_fp8_fp8 per fragment pair (low / high 8 bytes:
 // both operands use the same byte -> k mapping), a 64-byte pixel / weight row is a chunk of 64 channels.
-template <int TM16, int TN16, int ROWB, bool F8>
+template <int TM16, int TN16, int ROWB, int F8>
 __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsigned char* B, const int (&arow)[TM16],
                                             int po0, int po1, int po2, int sw0, int sw1, int sw2, int b_tap_stride,
                                             f32x4v (&acc)[TM16][TN16]) {
@@ -122,7 +123,10 @@ __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsign
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
                     // weights as the row operand: a lane then holds 4 CONSECUTIVE channels of one pixel (8-byte epilogue accesses)
-                    if constexpr (F8) {
+                    if constexpr (F8 == 2) {        // e4m3 weights x e5m2 pixels (gradients)
+                        acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(fb[step & 1][jj][0], fa[i][0], acc[i][2 * jh + jj], 0, 0, 0);
+                        acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(fb[step & 1][jj][1], fa[i][1], acc[i][2 * jh + jj], 0, 0, 0);
+                    } else if constexpr (F8 == 1) {
                         acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[step & 1][jj][0], fa[i][0], acc[i][2 * jh + jj], 0, 0, 0);
                         acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[step & 1][jj][1], fa[i][1], acc[i][2 * jh + jj], 0, 0, 0);
                     } else {
@@ -169,7 +173,7 @@ template <> struct PMma<float> {
 // SUB = 16: a tile is a 16x16 window of one image (halo from the neighbouring pixels).  SUB = 8 / 4: the images themselves
 // are 8x8 / 4x4 (encoder bottoms, first decoder levels, VGG block 5) and a tile packs G x G = 4 / 16 whole images, each
 // with its own all-zero halo (the patch grid is G*(SUB+2) wide; halo slots are zeroed once and never written).
-template <typename T, int BN, int OCC, int SUB, bool F8 = false>
+template <typename T, int BN, int OCC, int SUB, int F8 = 0>
 __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const PatchK p, const int tiles_x, const int tiles_y,
                                                                  const int ntn, const int kchunks, const int nblocks) {
     constexpr int EPC = Chunk<T>::N;
@@ -322,11 +326,17 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             for (int e = 0; e < 4; ++e) {
                 if (p.act_in != UPS_ACT_NONE) f[e] = ups_act_ns(f[e], act_ns);
                 f8_amax_t = fmaxf(f8_amax_t, fabsf(f[e]));
-                f[e] = __builtin_amdgcn_fmed3f(f[e] * f8_sa, -448.f, 448.f);
+                constexpr float FMAX = F8 == 2 ? 57344.f : 448.f;      // e5m2 / e4m3 largest normal
+                f[e] = __builtin_amdgcn_fmed3f(f[e] * f8_sa, -FMAX, FMAX);
             }
             int d = 0;
-            d = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], d, false);
-            d = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], d, true);
+            if constexpr (F8 == 2) {
+                d = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], d, false);
+                d = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], d, true);
+            } else {
+                d = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], d, false);
+                d = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], d, true);
+            }
             wd[k] = (unsigned)d;
         }
         return make_uint4(wd[0], wd[1], wd[2], wd[3]);
@@ -807,7 +817,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
 }
 
-template <typename T, int BN, int OCC, int SUB, bool F8 = false>
+template <typename T, int BN, int OCC, int SUB, int F8 = 0>
 int launch_bn(const PatchK& k, hipStream_t s) {
     constexpr int EPC = Chunk<T>::N;
     constexpr int G = TS / SUB, PR = G * (SUB + 2), PWPS = (PR + 3) / 4 * 4;
@@ -857,10 +867,15 @@ int launch_t(const PatchK& k, hipStream_t s) {
     if (k.h == 8) return launch_small<T, 8>(k, s);
     if (k.h == 4) return launch_small<T, 4>(k, s);
     if constexpr (sizeof(T) == 2) {
-        if (k.f8_deq) {      // fp8 forward (eligibility checked by the caller)
-            if (k.co_fill > 64) return launch_bn<T, 128, 1, TS, true>(k, s);
-            if (k.co_fill > 32) return launch_bn<T, 64, 1, TS, true>(k, s);
-            return launch_bn<T, 32, 1, TS, true>(k, s);
+        if (k.f8_deq) {      // fp8 operands (eligibility checked by the caller): e4m3 activations or e5m2 gradients
+            if (k.f8_e5m2) {
+                if (k.co_fill > 64) return launch_bn<T, 128, 1, TS, 2>(k, s);
+                if (k.co_fill > 32) return launch_bn<T, 64, 1, TS, 2>(k, s);
+                return launch_bn<T, 32, 1, TS, 2>(k, s);
+            }
+            if (k.co_fill > 64) return launch_bn<T, 128, 1, TS, 1>(k, s);
+            if (k.co_fill > 32) return launch_bn<T, 64, 1, TS, 1>(k, s);
+            return launch_bn<T, 32, 1, TS, 1>(k, s);
         }
         // two blocks per CU once the grid has at least two blocks for every CU (smaller grids spread over the chip instead);
         // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv) use 64-wide tiles and one patch buffer
@@ -918,7 +933,7 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     }
     PatchK k;
     k.mask = d->mask_bits; k.mask_grad = d->mask_grad; k.mask_view = d->mask_view;
-    k.f8_deq = d->f8_deq; k.f8_scale = d->f8_scale; k.f8_amax = d->f8_amax;
+    k.f8_deq = d->f8_deq; k.f8_scale = d->f8_scale; k.f8_amax = d->f8_amax; k.f8_e5m2 = d->f8_e5m2;
     k.d2s = 0; k.d2s_shift = 0;
     if (d->d2s) {
         // depth-to-space output: bf16 staged epilogue on 16-aligned lattices, 4 classes of d2s (power of two, >= 8) channels
@@ -931,7 +946,7 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     }
     if (d->f8_deq) {
         if (d->dtype != UPS_BF16 || small || (d->hi % TS) || (d->wi % TS) || d->ci % 64 || d->mask_bits || d->mask_grad ||
-            !d->f8_scale || !d->f8_amax || d->dact)
+            !d->f8_scale || !d->f8_amax)
             return 1;
     }
     k.mask_B = 0; k.mask_P = 1;

@@ -263,16 +263,21 @@ extern "C" int ups_weight_prep(const float* src, int32_t ntaps, int32_t cin_v, i
 }
 
 namespace {
-// one block per output channel: column max, then the 64-byte rows of that channel for every (tap, 64-channel chunk)
-__global__ __launch_bounds__(256) void weight_prep_f8_kernel(const float* __restrict__ src, int ntaps, int cin_v, int ci_log,
-                                                             int co, unsigned* __restrict__ wq, float* __restrict__ deq) {
+// one block per row (output channel; transposed: input channel): row max, then the 64-byte pieces of that row for every
+// (tap, 64-channel chunk).  Element (t, row, k) = V[t][k][row] (forward) or V[t][row][k] (transposed)
+__global__ __launch_bounds__(256) void weight_prep_f8_kernel(const float* __restrict__ src, int ntaps, int cin_v, int rows, int kdim,
+                                                             int co, int transpose, unsigned* __restrict__ wq,
+                                                             float* __restrict__ deq) {
     __shared__ float red[4];
     const int c = blockIdx.x, tid = threadIdx.x;
-    const int kc = (ci_log + 63) / 64;
+    const int kc = (kdim + 63) / 64;
+    auto at = [&](int t, int k) -> float {
+        return transpose ? src[((long long)t * cin_v + c) * co + k] : src[((long long)t * cin_v + k) * co + c];
+    };
     float m = 0.f;
-    for (int i = tid; i < ntaps * ci_log; i += 256) {
-        const int t = i / ci_log, ci = i - t * ci_log;
-        m = fmaxf(m, fabsf(src[((long long)t * cin_v + ci) * co + c]));
+    for (int i = tid; i < ntaps * kdim; i += 256) {
+        const int t = i / kdim, k = i - t * kdim;
+        m = fmaxf(m, fabsf(at(t, k)));
     }
     m = wave_max(m);
     if ((tid & 63) == 0) red[tid >> 6] = m;
@@ -285,16 +290,26 @@ __global__ __launch_bounds__(256) void weight_prep_f8_kernel(const float* __rest
         float f[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int ci = k * 64 + j4 * 4 + e;
-            f[e] = ci < ci_log ? __builtin_amdgcn_fmed3f(src[((long long)t * cin_v + ci) * co + c] * sc, -448.f, 448.f) : 0.f;
+            const int kk = k * 64 + j4 * 4 + e;
+            f[e] = kk < kdim ? __builtin_amdgcn_fmed3f(at(t, kk) * sc, -448.f, 448.f) : 0.f;
         }
         int d = 0;
         d = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], d, false);
         d = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], d, true);
-        wq[(((long long)t * kc + k) * co + c) * 16 + j4] = (unsigned)d;
+        wq[(((long long)t * kc + k) * rows + c) * 16 + j4] = (unsigned)d;
     }
 }
 }  // namespace
+
+extern "C" int ups_weight_prep_f8(const float* src, int32_t ntaps, int32_t cin_v, int32_t ci_log, int32_t co, int32_t transpose,
+                                  void* w_f8, float* deq, void* stream) {
+    UPS_CHECK_ARG(src && w_f8 && deq && ntaps >= 1 && ci_log >= 1 && cin_v >= ci_log && co >= 1);
+    const int rows = transpose ? ci_log : co, kdim = transpose ? co : ci_log;
+    hipLaunchKernelGGL(weight_prep_f8_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, src, ntaps, cin_v, rows, kdim, co,
+                       transpose, (unsigned*)w_f8, deq);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
 
 namespace {
 // one thread per (t9, k-chunk, row, 8-element piece) of the blocked-K weight image
@@ -329,15 +344,6 @@ extern "C" int ups_weight_prep_d2s(const float* src, int32_t cin_v, int32_t ci_l
     const long long total = 9ll * kc * 4 * C * 4;
     hipLaunchKernelGGL(weight_prep_d2s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, cin_v,
                        ci_log, co, pad_y, pad_x, C, kc, (uint4*)w, total);
-    UPS_LAUNCH_CHECK();
-    return UPS_OK;
-}
-
-extern "C" int ups_weight_prep_f8(const float* src, int32_t ntaps, int32_t cin_v, int32_t ci_log, int32_t co, void* w_f8,
-                                  float* deq, void* stream) {
-    UPS_CHECK_ARG(src && w_f8 && deq && ntaps >= 1 && ci_log >= 1 && cin_v >= ci_log && co >= 1);
-    hipLaunchKernelGGL(weight_prep_f8_kernel, dim3(co), dim3(256), 0, (hipStream_t)stream, src, ntaps, cin_v, ci_log, co,
-                       (unsigned*)w_f8, deq);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

@@ -34,7 +34,8 @@ class ConvDesc(C.Structure):
                 ("coord_tab", C.c_void_p), ("res", C.c_void_p), ("dact", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("mask_bits", C.c_void_p), ("mask_batch", C.c_int32), ("mask_grad", C.c_void_p), ("mask_view", C.c_void_p),
-                ("f8_deq", C.c_void_p), ("f8_scale", C.c_void_p), ("f8_amax", C.c_void_p), ("d2s", C.c_int32)]
+                ("f8_deq", C.c_void_p), ("f8_scale", C.c_void_p), ("f8_amax", C.c_void_p), ("f8_e5m2", C.c_int32),
+                ("d2s", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -75,7 +76,7 @@ _SIGS = {
     "ups_conv_wgrad_plan": ([C.POINTER(WgradDesc), C.POINTER(_I), C.POINTER(_Z)], C.c_int),
     "ups_conv_wgrad": ([C.POINTER(WgradDesc), _P], C.c_int),
     "ups_weight_prep": ([_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P], C.c_int),
-    "ups_weight_prep_f8": ([_P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "ups_weight_prep_f8": ([_P, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "ups_weight_prep_d2s": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "ups_prep_item_blocks": ([C.POINTER(PrepItem), _I], C.c_int64),
     "ups_weight_prep_batch": ([_P, _P, _I, _L, _I, _P], C.c_int),

@@ -49,8 +49,8 @@ class TrainModel(object):
         self.tps_parameters = dict(config.get("tps_parameters") or {}) if self.use_tps else None
         prec = str(config.get("precision", "bf16")).lower()
         self.act_dtype = torch.float32 if prec in ("fp32", "f32", "float32") else torch.bfloat16
-        # precision: fp8 (BASELINE config #5) = bf16 tensors, forward of the wide 3x3 / stride-1 convolutions with e4m3 MFMA
-        # operands and fp32 accumulation (ops.Fp8); input / weight gradients stay on the bf16 kernels
+        # precision: fp8 (BASELINE config #5) = bf16 tensors, forward and input gradient of the wide 3x3 / stride-1 convolutions
+        # with e4m3 / e5m2 MFMA operands and fp32 accumulation (ops.Fp8); weight gradients stay on the bf16 kernels
         ops.Fp8.enabled = prec in ("fp8", "f8", "e4m3")
         self.patch_size = config.get("patch_size", 32)
         self.df = N.is_48c(config)          # DeepFashion SB_model48c variant (two inputs, no rectangles, extra decoders)

@@ -172,6 +172,7 @@ class Fp8(object):
     MAX_LAYERS = 512
     amax = None             # [MAX_LAYERS, 64] fp32
     scale = None            # [MAX_LAYERS] fp32
+    fmax = None             # [MAX_LAYERS] fp32: largest normal of the slot's format
     count = 0
     layers = []             # trainable layers with e4m3 weights (re-converted by after_step)
 
@@ -180,6 +181,7 @@ class Fp8(object):
         if cls.amax is None or cls.amax.device != device:
             cls.amax = torch.zeros((cls.MAX_LAYERS, 64), dtype=torch.float32, device=device)
             cls.scale = torch.ones((cls.MAX_LAYERS,), dtype=torch.float32, device=device)
+            cls.fmax = torch.full((cls.MAX_LAYERS,), 448.0, dtype=torch.float32, device=device)   # e4m3; gradient slots: e5m2
             cls.count = 0
             cls.layers = []
         i = cls.count
@@ -195,7 +197,7 @@ class Fp8(object):
             return
         n = cls.count
         m = cls.amax[:n].amax(dim=1)
-        cls.scale[:n] = torch.where(m > 0, (448.0 * cls.MARGIN) / m.clamp_min(1e-30), cls.scale[:n])
+        cls.scale[:n] = torch.where(m > 0, (cls.fmax[:n] * cls.MARGIN) / m.clamp_min(1e-30), cls.scale[:n])
         cls.amax[:n].zero_()
 
     @classmethod
@@ -203,10 +205,22 @@ class Fp8(object):
         """After the optimizer step: new activation scales, e4m3 copies of the updated weights (one launch per layer)."""
         cls.update()
         for lay in cls.layers:
-            ent = lay._cache["f8"]
-            L.call("ups_weight_prep_f8", L.ptr(lay.V), lay.k * lay.k, lay.cin_v, lay.ci_log, lay.co,
-                   L.ptr(ent["w"]), L.ptr(ent["deq"]), L.stream())
-            ent["version"] = WeightVersion.value
+            for key, tr in (("f8", 0), ("f8g", 1)):
+                ent = lay._cache.get(key)
+                if ent is not None:
+                    L.call("ups_weight_prep_f8", L.ptr(lay.V), lay.k * lay.k, lay.cin_v, lay.ci_log, lay.co, tr,
+                           L.ptr(ent["w"]), L.ptr(ent["deq"]), L.stream())
+                    ent["version"] = WeightVersion.value
+
+    GRAD = True             # input gradients of the fp8 layers on e5m2 operands (False: bf16 kernels)
+    E5M2_MAX = 57344.0
+
+    @staticmethod
+    def eligible_grad(layer, g, x):
+        """Input gradient of a stride-1 3x3 layer on fp8 operands: K = output channels of the forward."""
+        return (Fp8.enabled and Fp8.GRAD and g.dtype == torch.bfloat16 and layer.k == 3 and layer.stride == 1
+                and x.shape[1] % 16 == 0 and x.shape[2] % 16 == 0 and round8(layer.co) % 64 == 0 and layer.ci_log >= 64
+                and g.shape[-1] >= round8(layer.co))
 
     @staticmethod
     def eligible(layer, x):
@@ -289,6 +303,29 @@ class ConvLayer(object):
             ent["prep"]()
         return ent
 
+    def prepared_f8_grad(self, g):
+        """e4m3 weights of the input-gradient GEMM (rows = input channels, scaled per row) + the gradient tensor's e5m2 scale slot."""
+        ent = self._cache.get("f8g")
+        dev = self.V.device
+        if ent is None:
+            kc = -(-self.co // 64)
+            ent = {"version": -1, "slot": Fp8.slot(dev), "primed": False,
+                   "w": torch.empty((self.k * self.k, kc, self.ci_log, 64), dtype=torch.uint8, device=dev),
+                   "deq": torch.empty((self.ci_log,), dtype=torch.float32, device=dev)}
+            self._cache["f8g"] = ent
+            Fp8.fmax[ent["slot"]] = Fp8.E5M2_MAX
+            if not self.frozen and self not in Fp8.layers:
+                Fp8.layers.append(self)
+        if ent["version"] != WeightVersion.value and not (self.frozen and ent["version"] >= 0):
+            L.call("ups_weight_prep_f8", L.ptr(self.V), self.k * self.k, self.cin_v, self.ci_log, self.co, 1,
+                   L.ptr(ent["w"]), L.ptr(ent["deq"]), L.stream())
+            ent["version"] = WeightVersion.value
+        if not ent["primed"]:
+            m = g[..., :self.co].abs().amax().float()
+            Fp8.scale[ent["slot"]] = torch.where(m > 0, (Fp8.E5M2_MAX * Fp8.MARGIN) / m.clamp_min(1e-30), torch.ones_like(m))
+            ent["primed"] = True
+        return ent
+
     def prepared_f8(self, x):
         """e4m3 weights + per-channel dequantisation factors + this layer's activation-scale slot."""
         ent = self._cache.get("f8")
@@ -299,10 +336,10 @@ class ConvLayer(object):
                    "w": torch.empty((self.k * self.k, kc, self.co, 64), dtype=torch.uint8, device=dev),
                    "deq": torch.empty((self.co,), dtype=torch.float32, device=dev)}
             self._cache["f8"] = ent
-            if not self.frozen:
+            if not self.frozen and self not in Fp8.layers:
                 Fp8.layers.append(self)
         if ent["version"] != WeightVersion.value and not (self.frozen and ent["version"] >= 0):
-            L.call("ups_weight_prep_f8", L.ptr(self.V), self.k * self.k, self.cin_v, self.ci_log, self.co,
+            L.call("ups_weight_prep_f8", L.ptr(self.V), self.k * self.k, self.cin_v, self.ci_log, self.co, 0,
                    L.ptr(ent["w"]), L.ptr(ent["deq"]), L.stream())
             ent["version"] = WeightVersion.value
         if not ent["primed"]:       # first launch of the layer: scale from the tensor at hand (|act(x)| <= |x|)
@@ -475,6 +512,13 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
         d.dact = x.data_ptr() if layer.act_in != L.ACT_NONE else None
         if mask_view is not None:
             d.mask_grad, d.mask_view, d.mask_batch = g_hard.data_ptr(), mask_view.data_ptr(), n
+        elif st == 1 and Fp8.eligible_grad(layer, g, x):
+            f8 = layer.prepared_f8_grad(g)
+            d.w = f8["w"].data_ptr()
+            d.f8_deq = f8["deq"].data_ptr()
+            d.f8_scale = Fp8.scale[f8["slot"]:].data_ptr()
+            d.f8_amax = Fp8.amax[f8["slot"]].data_ptr()
+            d.f8_e5m2 = 1
         _attach_ws(d, x.device)
         assert round8(layer.co) <= g.shape[-1]
         if KernelTimer.layer == layer.name and KernelTimer.enabled and st == 1:
