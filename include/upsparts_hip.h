@@ -95,6 +95,16 @@ typedef struct {
     float*       f8_amax;        /* [64] */
     int32_t      f8_e5m2;        /* 1: `in` is a gradient -- staged as e5m2 (the input-gradient call of an fp8 layer; `w` from
                                   * ups_weight_prep_f8 with transpose = 1), 0: e4m3 */
+    /* fp8 copies handed from layer to layer.  Producer side (any bf16 patch-kernel call with the staged epilogue): out_f8_amax != NULL
+     * records max |act(out)| (act = out_f8_act, the consumer's activation-on-load) into its 64 slots; with out_f8 != NULL the epilogue also
+     * writes e4m3 (out_f8_e5m2: e5m2) of act(out) * *out_f8_scale to out_f8 [n, out_h, out_w, ldo] bytes, next to the bf16 tensor.
+     * Consumer side: in_f8 != NULL (with f8_deq) = that byte tensor [n, hi, wi, ldi]; it is staged as it is (f8_scale = the scale it was
+     * written with, act_in is not applied again, f8_amax unused) with the bf16 kernel's register budget (two blocks per CU). */
+    const void*  in_f8;
+    void*        out_f8;
+    const float* out_f8_scale;
+    float*       out_f8_amax;
+    int32_t      out_f8_act, out_f8_e5m2;
     /* Depth-to-space output (input gradient of a 3x3 / stride-2 convolution as ONE stride-1 convolution over the gradient
      * lattice, N:811-817 backward): d2s = C > 0 (power of two, >= 8) declares co = 4 C GEMM channels ordered (py, px, c); channel c of
      * class (py, px) at lattice pixel (y, x) is written to out[n][2y + py][2x + px][c] of a [n, out_h = 2 ho, out_w = 2 wo, ldo]

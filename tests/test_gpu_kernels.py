@@ -604,3 +604,55 @@ def test_conv_fp8_input_gradient(case, dev):
         ref = ref * torch.where(xf > 0, torch.ones_like(xf), torch.full_like(xf, 0.2))
     err = float((gx[..., :cin].double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     assert err < 0.08, "fp8 input gradient vs unquantised: rel RMS {:.3g}".format(err)
+
+
+@pytest.mark.parametrize("case", [(4, 64, 128, 128, True), (2, 128, 256, 256, True), (8, 32, 64, 192, False)])
+def test_conv_fp8_copy_handed_from_producer_to_consumer(case, dev):
+    """fp8 copies between layers: the producing convolution's epilogue writes e4m3(act(out) * scale) next to its bf16 output (one
+    step after that tensor's first maximum was recorded), the consuming convolution stages those bytes as they are.  The copy must
+    equal the quantisation of the stored bf16 tensor bit for bit, and the consumer must produce what it produces when it converts
+    the bf16 tensor itself with the same scale."""
+    lib, ops, R = _mods()
+    n, h, cin, cout, coords = case
+    g = torch.Generator().manual_seed(21)
+    cv = cin + (2 if coords else 0)
+    V1 = torch.randn(3, 3, cv, cin, generator=g) / math.sqrt(9 * cv)
+    V2 = torch.randn(3, 3, cv, cout, generator=g) / math.sqrt(9 * cv)
+    l1 = _layer(ops, lib, V1, torch.randn(cin, generator=g) * 0.1, 3, 1, coords, "leaky_relu", dev)
+    l2 = _layer(ops, lib, V2, torch.randn(cout, generator=g) * 0.1, 3, 1, coords, "leaky_relu", dev)
+    x = torch.randn(n, h, h, cin, generator=g).to(torch.bfloat16).to(dev)
+    F = ops.Fp8
+    F.enabled = True
+    producer_was = F.PRODUCER
+    F.PRODUCER = True
+    try:
+        F.next_out_act = lib.ACT_LRELU
+        y0 = ops.conv_forward(x, l1, res=x)                   # first call: records max |act(y)| only
+        assert F.last_out is None
+        F.update()
+        F.next_out_act = lib.ACT_LRELU
+        y = ops.conv_forward(x, l1, res=x)
+        copy = F.last_out
+        assert copy is not None and copy["act"] == lib.ACT_LRELU and copy["t"].shape == y.shape
+        # (y differs from y0 in the last bits: the input's own scale moved from the primed to the recorded maximum)
+        assert_close(y.float(), y0.float(), 5e-2, "second call")
+        scale = float(F.scale[copy["slot"]].cpu())
+        yf = y.float()
+        ya = torch.maximum(yf, 0.2 * yf)
+        y0f = y0.float()
+        assert abs(scale - 448.0 * F.MARGIN / float(torch.maximum(y0f, 0.2 * y0f).abs().max())) <= 1e-5 * scale   # delayed: first call's maximum
+        want = (ya * scale).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+        assert torch.equal(copy["t"], want), "fp8 copy differs from the quantised bf16 tensor in {} bytes".format(int((copy["t"] != want).sum()))
+        # consumer: bytes as they are (two blocks per CU) vs its own conversion of the bf16 tensor with the same scale
+        F.next_in = copy
+        za = ops.conv_forward(y, l2)
+        zb0 = ops.conv_forward(y, l2)                         # primes the layer's own slot from the tensor ...
+        F.scale[l2._cache["f8"]["slot"]] = F.scale[copy["slot"]]      # ... which is then set to the producer's scale
+        zb = ops.conv_forward(y, l2)
+        torch.cuda.synchronize()
+    finally:
+        F.enabled = False
+        F.PRODUCER = producer_was
+        F.next_in = F.next_out_act = F.last_out = None
+    assert_close(za[..., :cout].float(), zb[..., :cout].float(), 1e-6, "consumer of the fp8 copy vs in-kernel conversion")
+    assert float((za[..., :cout].float() - zb0[..., :cout].float()).abs().max()) < 0.1 * float(zb0.float().abs().max())

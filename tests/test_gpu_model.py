@@ -147,7 +147,7 @@ def test_fp8_step_tracks_bf16(dev):
             assert ops.Fp8.count >= 4, "fp8 layers used: {}".format(ops.Fp8.count)
             scales = ops.Fp8.scale[:ops.Fp8.count].cpu()
             assert bool(torch.isfinite(scales).all()) and float(scales.min()) > 0
-            assert all(l._cache["f8"]["version"] == ops.WeightVersion.value for l in ops.Fp8.layers)
+            assert all(l._cache[k]["version"] == ops.WeightVersion.value for l in ops.Fp8.layers for k in ("f8", "f8g") if k in l._cache)
     ops.Fp8.enabled = False
     for step in range(3):
         for k, vb in runs["bf16"][0][step].items():

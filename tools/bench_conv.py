@@ -56,7 +56,9 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--fp8", action="store_true", help="forward of the eligible layers on the e4m3 path (ops.Fp8)")
+    ap.add_argument("--fp8", action="store_true", help="forward / input gradient of the eligible layers on the fp8 path (ops.Fp8)")
+    ap.add_argument("--fp8-copy", action="store_true", help="with --fp8: the forward input arrives as the fp8 copy a producing layer "
+                    "would have written (no conversion in the kernel, two blocks per CU)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ops.Fp8.enabled = args.fp8
@@ -79,7 +81,19 @@ def main():
         gy = torch.randn(y.shape, device=dev).to(T)
         ho = y.shape[1]
         flops = 2.0 * n * ho * ho * k * k * cin_v * cout
-        tf = timeit(lambda: ops.conv_forward(x, lay), args.iters)
+        if args.fp8 and args.fp8_copy and ops.Fp8.eligible(lay, x) and cout > 32:
+            slot = ops.Fp8.slot(dev)
+            xa = x.float()
+            xa = torch.maximum(xa, 0.2 * xa) if act == "leaky_relu" else (torch.relu(xa) if act == "relu" else xa)
+            ops.Fp8.scale[slot] = 224.0 / xa.abs().max()
+            copy = {"t": (xa * ops.Fp8.scale[slot]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8), "act": lay.act_in, "slot": slot}
+
+            def fwd():
+                ops.Fp8.next_in = copy
+                return ops.conv_forward(x, lay)
+            tf = timeit(fwd, args.iters)
+        else:
+            tf = timeit(lambda: ops.conv_forward(x, lay), args.iters)
         td = timeit(lambda: ops.conv_dgrad(gy, x, lay), args.iters)
         tw = timeit(lambda: ops.conv_wgrad(gy, x, lay), args.iters)
         tot[0] += tf; tot[1] += td; tot[2] += tw

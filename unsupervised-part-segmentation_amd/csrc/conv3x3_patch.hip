@@ -50,6 +50,11 @@ struct PatchK {
     // *f8_scale the activation scale of this launch, f8_amax 64 slots that collect max |act(x)| for the next one
     const float* f8_deq; const float* f8_scale; float* f8_amax;
     int f8_e5m2;      // the staged tensor is a gradient: e5m2 operands (ups_conv_desc.f8_e5m2)
+    // fp8 copies between layers (ups_conv_desc.in_f8 / out_f8_*): the consumer reads an already quantised tensor (16 channels per
+    // 16-byte item, no conversion: the same staging registers as bf16, two blocks per CU), the producer's epilogue writes
+    // act(out) * scale as e4m3 / e5m2 next to the bf16 tensor and records max |act(out)|
+    const unsigned char* in_f8; unsigned char* out_f8; const float* out_f8_scale; float* out_f8_amax;
+    int out_f8_act, out_f8_e5m2;
     // depth-to-space output (ups_conv_desc.d2s): GEMM channel ch = (py*2 + px) * (1 << d2s_shift) + c is channel c of output
     // pixel (2y + py, 2x + px) of a [n, 2h, 2w, ld] tensor (res / dact live on that lattice too)
     int d2s, d2s_shift;
@@ -173,13 +178,14 @@ template <> struct PMma<float> {
 // SUB = 16: a tile is a 16x16 window of one image (halo from the neighbouring pixels).  SUB = 8 / 4: the images themselves
 // are 8x8 / 4x4 (encoder bottoms, first decoder levels, VGG block 5) and a tile packs G x G = 4 / 16 whole images, each
 // with its own all-zero halo (the patch grid is G*(SUB+2) wide; halo slots are zeroed once and never written).
-template <typename T, int BN, int OCC, int SUB, int F8 = 0>
+template <typename T, int BN, int OCC, int SUB, int F8 = 0, bool PRE = false>
 __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const PatchK p, const int tiles_x, const int tiles_y,
                                                                  const int ntn, const int kchunks, const int nblocks) {
     constexpr int EPC = Chunk<T>::N;
     constexpr int BK = 4 * EPC;                  // weight-row elements of T per 64-byte row (the fp8 rows are addressed as T too)
     constexpr int BKA = F8 ? 64 : BK;            // input channels per chunk
-    static_assert(!F8 || (sizeof(T) == 2 && SUB == TS && OCC == 1), "fp8 forward: bf16 tensors, one tile per image, one block per CU");
+    static_assert(!F8 || (sizeof(T) == 2 && SUB == TS && (OCC == 1 || PRE)), "fp8 operands: bf16 tensors, one tile per image; two blocks per CU only with a pre-quantised input");
+    static_assert(!PRE || F8, "a pre-quantised input implies fp8 operands");
     constexpr int WN = (BN == 32) ? 1 : 2;
     constexpr int WM = 8 / WN;                   // 4 or 8 waves along the pixels
     constexpr int TM = 256 / WM / 32;            // 2 or 1
@@ -280,6 +286,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     const T* __restrict__ in_o = in + (long long)origin * p.ldi;
     const unsigned* __restrict__ mbits_o = mbits ? mbits + origin : nullptr;
     const unsigned row_b = (unsigned)p.ldi * (unsigned)sizeof(T);
+    const unsigned char* __restrict__ in8_o = PRE ? p.in_f8 + ((long long)img_in * p.h * p.w + origin) * p.ldi : nullptr;
     auto ld_rel = [&](unsigned pk, int koff, uint4& hi) -> uint4 {
         uint4 v = zero4;
         if constexpr (F8) hi = zero4;
@@ -288,9 +295,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         const unsigned rel = pk & 0xffffu;
         if (rel != 0xffffu && koff + cha < p.ci) {
             // scalar base (image + chunk + origin) + 32-bit vector offset addressing
-            const unsigned o = __umul24(rel, row_b) + (unsigned)(cha * (int)sizeof(T));
-            v = *(const uint4*)((const unsigned char*)(in_o + koff) + o);
-            if constexpr (F8) hi = *(const uint4*)((const unsigned char*)(in_o + koff) + o + 16);
+            if constexpr (PRE) {        // pre-quantised tensor: one byte per channel, the item's 16 channels are 16 bytes
+                const unsigned o8 = __umul24(rel, (unsigned)p.ldi) + (unsigned)cha;
+                v = *(const uint4*)(in8_o + koff + o8);
+            } else {
+                const unsigned o = __umul24(rel, row_b) + (unsigned)(cha * (int)sizeof(T));
+                v = *(const uint4*)((const unsigned char*)(in_o + koff) + o);
+                if constexpr (F8) hi = *(const uint4*)((const unsigned char*)(in_o + koff) + o + 16);
+            }
             // part-masked input (model.py:185): the pixel belongs to this block's part image only where its hard-mask bit is set
             if (mbits_o && !((mbits_o[rel] >> part) & 1u)) v = zero4;
         }
@@ -342,7 +354,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         return make_uint4(wd[0], wd[1], wd[2], wd[3]);
     };
     auto store_patch = [&](unsigned char* A) __attribute__((always_inline)) {
-        if constexpr (F8) {
+        if constexpr (PRE) {
+            *(uint4*)(A + (pk0 >> 16)) = ra0;
+            *(uint4*)(A + (pk1 >> 16)) = ra1;
+            if (has2) *(uint4*)(A + (pk2 >> 16)) = ra2;
+        } else if constexpr (F8) {
             *(uint4*)(A + (pk0 >> 16)) = cvt_f8(ra0, rb0);
             *(uint4*)(A + (pk1 >> 16)) = cvt_f8(ra1, rb1);
             if (has2) *(uint4*)(A + (pk2 >> 16)) = cvt_f8(ra2, rb2);
@@ -598,8 +614,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #endif
     if constexpr (F8) {
         // max |act(x)| of the launch (blocks of the first N-tile; 64 slots spread the atomics): next launch's scale
-        const float m = wave_max(f8_amax_t);
-        if (nt == 0 && lane == 0) atomicMax((unsigned*)(p.f8_amax + (bid & 63)), __float_as_uint(m));
+        if constexpr (!PRE) {
+            const float m = wave_max(f8_amax_t);
+            if (nt == 0 && lane == 0) atomicMax((unsigned*)(p.f8_amax + (bid & 63)), __float_as_uint(m));
+        }
         // dequantise: acc = sum (s_a x)(s_w[c] w)  ->  * 1 / (s_a s_w[c])
         const float inv_sa = 1.f / f8_sa;
 #pragma unroll
@@ -614,12 +632,17 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
     T* __restrict__ outT = (T*)p.out;
     float* __restrict__ outF = (float*)p.out;
+    unsigned char* __restrict__ of8 = p.out_f8;
+    float of8_amax = 0.f;
+    const float of8_s = (p.out_f8 && p.out_f8_scale) ? *p.out_f8_scale : 1.f;
+    const float of8_ns = ups_slope_eff(p.out_f8_act, p.act_slope);
     const T* __restrict__ res = (const T*)p.res;
     const T* __restrict__ dact = (const T*)p.dact;
     // the block's first image as uniform (scalar) bases; tile pixel index (ty * 16 + tx) -> 32-bit pixel index from there
     // (the launcher checks that an image group stays below 2^31 bytes in every tensor)
     const long long img_pix = (long long)img_pm * p.h * p.w * (p.d2s ? 4 : 1);
     outT += img_pix * p.ldo; outF += img_pix * p.ldo;
+    if (of8) of8 += img_pix * p.ldo;
     if (res) res += img_pix * p.ldr;
     if (dact) dact += img_pix * p.ldd;
     auto gpix = [&](int q) -> unsigned {
@@ -759,7 +782,45 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
-                if (ch * 8 < c_lim) *(uint4*)(outT + gaddr(px, nt * BN + ch * 8, p.ldo)) = *(const uint4*)(R0 + px * ERS + ch * 16);
+                if (ch * 8 < c_lim) {
+                    const uint4 u = *(const uint4*)(R0 + px * ERS + ch * 16);
+                    const unsigned ga = gaddr(px, nt * BN + ch * 8, p.ldo);
+                    *(uint4*)(outT + ga) = u;
+                    // fp8 copy for the consumer (uniform branch; compiled into the fp8 instances only: the 128-wide bf16 kernel at
+                    // two blocks per CU has no register to spare): act(out) -> max -> * scale -> 8 bytes
+                    if (F8 != 0 && p.out_f8_amax) {
+                        const unsigned wsrc[4] = {u.x, u.y, u.z, u.w};
+                        float f[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            f[2 * e] = __uint_as_float(wsrc[e] << 16); f[2 * e + 1] = __uint_as_float(wsrc[e] & 0xffff0000u);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (p.out_f8_act != UPS_ACT_NONE) f[e] = ups_act_ns(f[e], of8_ns);
+                            of8_amax = fmaxf(of8_amax, fabsf(f[e]));
+                        }
+                        if (p.out_f8) {
+                            int d0 = 0, d1 = 0;
+                            if (p.out_f8_e5m2) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e] * of8_s, -57344.f, 57344.f);
+                                d0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], d0, false); d0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], d0, true);
+                                d1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], d1, false); d1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], d1, true);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e] * of8_s, -448.f, 448.f);
+                                d0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], d0, false); d0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], d0, true);
+                                d1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], d1, false); d1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], d1, true);
+                            }
+                            *(uint2*)(of8 + ga) = make_uint2((unsigned)d0, (unsigned)d1);
+                        }
+                    }
+                }
+            }
+            if (F8 != 0 && p.out_f8_amax) {
+                const float m = wave_max(of8_amax);
+                if (lane == 0) atomicMax((unsigned*)(p.out_f8_amax + (bid & 63)), __float_as_uint(m));
             }
             return;
         }
@@ -817,7 +878,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
 }
 
-template <typename T, int BN, int OCC, int SUB, int F8 = 0>
+template <typename T, int BN, int OCC, int SUB, int F8 = 0, bool PRE = false>
 int launch_bn(const PatchK& k, hipStream_t s) {
     constexpr int EPC = Chunk<T>::N;
     constexpr int G = TS / SUB, PR = G * (SUB + 2), PWPS = (PR + 3) / 4 * 4;
@@ -837,12 +898,12 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     if (epi > shmem) shmem = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB, F8>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(epi > shmem_max ? epi : shmem_max));
         if (e != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC, SUB, F8>), dim3(nblocks), dim3(512), shmem, s, kk, tiles_x, tiles_y, ntn,
+    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE>), dim3(nblocks), dim3(512), shmem, s, kk, tiles_x, tiles_y, ntn,
                        kchunks, nblocks);
     return UPS_OK;
 }
@@ -867,6 +928,17 @@ int launch_t(const PatchK& k, hipStream_t s) {
     if (k.h == 8) return launch_small<T, 8>(k, s);
     if (k.h == 4) return launch_small<T, 4>(k, s);
     if constexpr (sizeof(T) == 2) {
+        if (k.f8_deq && k.in_f8) {      // pre-quantised input: bf16-sized staging, two blocks per CU on large grids
+            const int tiles8 = k.n * (k.w / TS) * (k.h / TS);
+            const bool big128 = patch_occ() == 2 && tiles8 * ups_cdiv(k.co_fill, 128) >= 512;
+            const bool big64 = patch_occ() == 2 && tiles8 * ups_cdiv(k.co_fill, 64) >= 512;
+            if (k.f8_e5m2) {
+                if (k.co_fill > 64) return big128 ? launch_bn<T, 128, 2, TS, 2, true>(k, s) : launch_bn<T, 128, 1, TS, 2, true>(k, s);
+                return big64 ? launch_bn<T, 64, 2, TS, 2, true>(k, s) : launch_bn<T, 64, 1, TS, 2, true>(k, s);
+            }
+            if (k.co_fill > 64) return big128 ? launch_bn<T, 128, 2, TS, 1, true>(k, s) : launch_bn<T, 128, 1, TS, 1, true>(k, s);
+            return big64 ? launch_bn<T, 64, 2, TS, 1, true>(k, s) : launch_bn<T, 64, 1, TS, 1, true>(k, s);
+        }
         if (k.f8_deq) {      // fp8 operands (eligibility checked by the caller): e4m3 activations or e5m2 gradients
             if (k.f8_e5m2) {
                 if (k.co_fill > 64) return launch_bn<T, 128, 1, TS, 2>(k, s);
@@ -934,6 +1006,12 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     PatchK k;
     k.mask = d->mask_bits; k.mask_grad = d->mask_grad; k.mask_view = d->mask_view;
     k.f8_deq = d->f8_deq; k.f8_scale = d->f8_scale; k.f8_amax = d->f8_amax; k.f8_e5m2 = d->f8_e5m2;
+    k.in_f8 = (const unsigned char*)d->in_f8; k.out_f8 = (unsigned char*)d->out_f8; k.out_f8_scale = d->out_f8_scale;
+    k.out_f8_amax = d->out_f8_amax; k.out_f8_act = d->out_f8_act; k.out_f8_e5m2 = d->out_f8_e5m2;
+    if (d->in_f8 && (!d->f8_deq || d->co_fill <= 32)) return 1;
+    if ((d->out_f8 || d->out_f8_amax) && (!d->f8_deq || d->dtype != UPS_BF16 || small || d->out_f32 || (d->ldo & 7) || (d->co_fill & 7) || d->mask_grad ||
+                                          !d->out_f8_amax || (d->out_f8 && !d->out_f8_scale)))
+        return 1;
     k.d2s = 0; k.d2s_shift = 0;
     if (d->d2s) {
         // depth-to-space output: bf16 staged epilogue on 16-aligned lattices, 4 classes of d2s (power of two, >= 8) channels
@@ -946,7 +1024,7 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     }
     if (d->f8_deq) {
         if (d->dtype != UPS_BF16 || small || (d->hi % TS) || (d->wi % TS) || d->ci % 64 || d->mask_bits || d->mask_grad ||
-            !d->f8_scale || !d->f8_amax)
+            !d->f8_scale || (!d->f8_amax && !d->in_f8))
             return 1;
     }
     k.mask_B = 0; k.mask_P = 1;

@@ -35,7 +35,8 @@ class ConvDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("mask_bits", C.c_void_p), ("mask_batch", C.c_int32), ("mask_grad", C.c_void_p), ("mask_view", C.c_void_p),
                 ("f8_deq", C.c_void_p), ("f8_scale", C.c_void_p), ("f8_amax", C.c_void_p), ("f8_e5m2", C.c_int32),
-                ("d2s", C.c_int32)]
+                ("in_f8", C.c_void_p), ("out_f8", C.c_void_p), ("out_f8_scale", C.c_void_p), ("out_f8_amax", C.c_void_p),
+                ("out_f8_act", C.c_int32), ("out_f8_e5m2", C.c_int32), ("d2s", C.c_int32)]
 
 
 class WgradDesc(C.Structure):

@@ -93,12 +93,13 @@ class ParamBank(object):
 
 class Act(object):
     """Activation handle: tensor (None in the shape-only dry run) + logical channel count."""
-    __slots__ = ("t", "n", "h", "w", "c", "mask")
+    __slots__ = ("t", "n", "h", "w", "c", "mask", "f8")
 
-    def __init__(self, t, n, h, w, c, mask=None):
+    def __init__(self, t, n, h, w, c, mask=None, f8=None):
         # mask = (hard, hard_bits, view_f32): `t` is the unmasked view [B,h,w,8] and the handle stands for the n = P*B
         # part images view[b] * hard[b,:,:,p] that the first convolution forms while it loads (ops.conv)
-        self.t, self.n, self.h, self.w, self.c, self.mask = t, n, h, w, c, mask
+        # f8 = the fp8 copy of act(t) its producer wrote (ops.Fp8: {"t", "act", "slot"}) or None
+        self.t, self.n, self.h, self.w, self.c, self.mask, self.f8 = t, n, h, w, c, mask, f8
 
 
 class Scope(object):
@@ -133,8 +134,12 @@ class Scope(object):
         ho, wo = ops.same_geometry(x.h, k, stride)[0], ops.same_geometry(x.w, k, stride)[0]
         if lay is None:
             return Act(None, x.n, ho, wo, cout)
+        if ops.Fp8.enabled:     # hand the input's fp8 copy in, ask for one of the output (consumed with this scope's activation)
+            ops.Fp8.next_in, ops.Fp8.next_out_act, ops.Fp8.last_out = x.f8, self.act, None
         t = ops.conv(x.t, lay, res=None if res is None else res.t, res_self=res_self, out_f32=out_f32, mask=x.mask)
-        return Act(t, x.n, ho, wo, cout)
+        f8 = ops.Fp8.last_out if ops.Fp8.enabled else None
+        ops.Fp8.last_out = None
+        return Act(t, x.n, ho, wo, cout, f8=f8)
 
     def nin(self, x, cout, **kw):
         return self.conv2d(x, cout, k=1, **kw)

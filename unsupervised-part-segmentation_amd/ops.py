@@ -199,6 +199,7 @@ class Fp8(object):
         m = cls.amax[:n].amax(dim=1)
         cls.scale[:n] = torch.where(m > 0, (cls.fmax[:n] * cls.MARGIN) / m.clamp_min(1e-30), cls.scale[:n])
         cls.amax[:n].zero_()
+        cls.steps += 1
 
     @classmethod
     def after_step(cls):
@@ -213,7 +214,36 @@ class Fp8(object):
                     ent["version"] = WeightVersion.value
 
     GRAD = True             # input gradients of the fp8 layers on e5m2 operands (False: bf16 kernels)
+    # fp8 copies handed from layer to layer: the producing convolution's epilogue writes e4m3(act(out) * scale) next to its bf16
+    # output (scale = the delayed scale of that tensor), the consuming convolution stages those bytes without any conversion.
+    # nets.Scope passes the handle along: next_in / next_out_act are set right before ops.conv, last_out is read right after.
+    # Off unless asked for (UPS_F8_PRODUCER=1 / Fp8.PRODUCER = True): in this model nearly every wide convolution reads the output of
+    # a bilinear up-sampling, a stride-2 layer or a pooling, not of another fp8 convolution, so the copies would find no consumer
+    #  -- the kernels and the hand-off are tested and timed on their own (tools/bench_conv.py --fp8 --fp8-copy).
+    PRODUCER = os.environ.get("UPS_F8_PRODUCER", "0") == "1"
+    next_in = None          # {"t": uint8 tensor, "act": UPS_ACT_*, "slot": scale slot} of the coming call's input
+    next_out_act = None     # activation-on-load of the consumer of the coming call's output (None: no copy wanted)
+    last_out = None         # the copy the last call wrote (same dict), or None
+    steps = 0               # update() calls so far (a tensor's copy starts one step after its first maximum was recorded)
+    stats = {"fwd_f8": 0, "fwd_copy_in": 0, "fwd_copy_out": 0, "dgrad_f8": 0, "dgrad_copy_in": 0, "dgrad_copy_out": 0}
     E5M2_MAX = 57344.0
+
+    grad_side = {}          # data_ptr of a gradient tensor -> (weakref to it, its e5m2 copy): dgrad epilogue -> next dgrad
+
+    @classmethod
+    def register_grad_copy(cls, t, copy):
+        import weakref
+        if len(cls.grad_side) > 256:
+            cls.grad_side.clear()
+        cls.grad_side[t.data_ptr()] = (weakref.ref(t), tuple(t.shape), copy)
+
+    @classmethod
+    def grad_copy(cls, g):
+        """The e5m2 copy of exactly this tensor object (the autograd engine hands a single-use gradient on unchanged), or None."""
+        ent = cls.grad_side.pop(g.data_ptr(), None)
+        if ent is None or ent[0]() is not g or ent[1] != tuple(g.shape):
+            return None
+        return ent[2]
 
     @staticmethod
     def eligible_grad(layer, g, x):
@@ -320,7 +350,7 @@ class ConvLayer(object):
             L.call("ups_weight_prep_f8", L.ptr(self.V), self.k * self.k, self.cin_v, self.ci_log, self.co, 1,
                    L.ptr(ent["w"]), L.ptr(ent["deq"]), L.stream())
             ent["version"] = WeightVersion.value
-        if not ent["primed"]:
+        if not ent["primed"] and g is not None:
             m = g[..., :self.co].abs().amax().float()
             Fp8.scale[ent["slot"]] = torch.where(m > 0, (Fp8.E5M2_MAX * Fp8.MARGIN) / m.clamp_min(1e-30), torch.ones_like(m))
             ent["primed"] = True
@@ -342,7 +372,7 @@ class ConvLayer(object):
             L.call("ups_weight_prep_f8", L.ptr(self.V), self.k * self.k, self.cin_v, self.ci_log, self.co, 0,
                    L.ptr(ent["w"]), L.ptr(ent["deq"]), L.stream())
             ent["version"] = WeightVersion.value
-        if not ent["primed"]:       # first launch of the layer: scale from the tensor at hand (|act(x)| <= |x|)
+        if not ent["primed"] and x is not None:       # first launch of the layer: scale from the tensor at hand (|act(x)| <= |x|)
             m = x[..., :self.ci_log].abs().amax().float()
             Fp8.scale[ent["slot"]] = torch.where(m > 0, (448.0 * Fp8.MARGIN) / m.clamp_min(1e-30), torch.ones_like(m))
             ent["primed"] = True
@@ -394,6 +424,7 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
     co_fill = co_fill if co_fill is not None else ldo
     out = torch.empty((n, ho, wo, ldo), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     d = L.ConvDesc()
+    f8_out = None
     d.dtype = dcode
     d.n, d.hi, d.wi, d.ci, d.ldi = n, hi, wi, round8(layer.ci_log), ldi
     d.ho, d.wo, d.co, d.co_fill, d.ldo = ho, wo, layer.co, co_fill, ldo
@@ -413,11 +444,33 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
     if mask is not None:
         d.mask_bits, d.mask_batch = mask[0].data_ptr(), x.shape[0]
     elif Fp8.eligible(layer, x):
-        f8 = layer.prepared_f8(x)
+        src, want_act = Fp8.next_in, Fp8.next_out_act
+        if (src is not None and src["act"] == layer.act_in and tuple(src["t"].shape) == tuple(x.shape) and layer.co > 32
+                and ldi % 16 == 0):
+            f8 = layer.prepared_f8(None)               # the producer quantised act(x) with its tensor's scale
+            Fp8.stats["fwd_copy_in"] += 1
+            d.in_f8 = src["t"].data_ptr()
+            d.f8_scale = Fp8.scale[src["slot"]:].data_ptr()
+        else:
+            f8 = layer.prepared_f8(x)
+            d.f8_scale = Fp8.scale[f8["slot"]:].data_ptr()
+            d.f8_amax = Fp8.amax[f8["slot"]].data_ptr()
         d.w = f8["w"].data_ptr()
         d.f8_deq = f8["deq"].data_ptr()
-        d.f8_scale = Fp8.scale[f8["slot"]:].data_ptr()
-        d.f8_amax = Fp8.amax[f8["slot"]].data_ptr()
+        Fp8.stats["fwd_f8"] += 1
+        if Fp8.PRODUCER and want_act is not None and not out_f32 and ldo % 64 == 0 and co_fill == ldo:
+            eo = layer._cache.get("f8o")
+            if eo is None:
+                eo = layer._cache["f8o"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
+            d.out_f8_amax = Fp8.amax[eo["slot"]].data_ptr()
+            d.out_f8_act = want_act
+            if Fp8.steps > eo["born"]:                 # its delayed scale exists
+                t8 = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
+                d.out_f8, d.out_f8_scale = t8.data_ptr(), Fp8.scale[eo["slot"]:].data_ptr()
+                f8_out = {"t": t8, "act": want_act, "slot": eo["slot"]}
+                Fp8.stats["fwd_copy_out"] += 1
+    Fp8.next_in = Fp8.next_out_act = None
+    Fp8.last_out = f8_out
     _attach_ws(d, x.device)
     assert round8(layer.ci_log) <= ldi, (layer.name, layer.ci_log, ldi)
     if KernelTimer.layer == layer.name and KernelTimer.enabled:
@@ -513,12 +566,32 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
         if mask_view is not None:
             d.mask_grad, d.mask_view, d.mask_batch = g_hard.data_ptr(), mask_view.data_ptr(), n
         elif st == 1 and Fp8.eligible_grad(layer, g, x):
-            f8 = layer.prepared_f8_grad(g)
+            src = Fp8.grad_copy(g)
+            if src is not None and layer.ci_log > 32 and g.shape[-1] % 16 == 0:
+                f8 = layer.prepared_f8_grad(None)          # the layer above wrote e5m2(g * scale) in its dgrad epilogue
+                Fp8.stats["dgrad_copy_in"] += 1
+                d.in_f8 = src["t"].data_ptr()
+                d.f8_scale = Fp8.scale[src["slot"]:].data_ptr()
+            else:
+                f8 = layer.prepared_f8_grad(g)
+                d.f8_scale = Fp8.scale[f8["slot"]:].data_ptr()
+                d.f8_amax = Fp8.amax[f8["slot"]].data_ptr()
             d.w = f8["w"].data_ptr()
             d.f8_deq = f8["deq"].data_ptr()
-            d.f8_scale = Fp8.scale[f8["slot"]:].data_ptr()
-            d.f8_amax = Fp8.amax[f8["slot"]].data_ptr()
             d.f8_e5m2 = 1
+            Fp8.stats["dgrad_f8"] += 1
+            if Fp8.PRODUCER and gx is not None and ldi % 64 == 0 and layer.ci_log == ldi:
+                eo = layer._cache.get("f8go")
+                if eo is None:
+                    eo = layer._cache["f8go"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
+                    Fp8.fmax[eo["slot"]] = Fp8.E5M2_MAX
+                d.out_f8_amax = Fp8.amax[eo["slot"]].data_ptr()
+                d.out_f8_act, d.out_f8_e5m2 = L.ACT_NONE, 1
+                if Fp8.steps > eo["born"]:
+                    t8 = torch.empty(gx.shape, dtype=torch.uint8, device=x.device)
+                    d.out_f8, d.out_f8_scale = t8.data_ptr(), Fp8.scale[eo["slot"]:].data_ptr()
+                    Fp8.register_grad_copy(gx, {"t": t8, "slot": eo["slot"]})
+                    Fp8.stats["dgrad_copy_out"] += 1
         _attach_ws(d, x.device)
         assert round8(layer.co) <= g.shape[-1]
         if KernelTimer.layer == layer.name and KernelTimer.enabled and st == 1:
