@@ -161,7 +161,9 @@ def run_rank(args):
     if rank == 0:
         images = args.batch * world * args.steps
         value = images / dt
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        low = args.precision in ("bf16", "fp8")        # fp8: priced against the bf16 peak too (K = 32 fp8 MFMAs run at the bf16 rate)
+        peak = PEAK_BF16_TFLOPS if low else PEAK_F32_TFLOPS
+        dname = {"bf16": "bf16", "fp8": "fp8"}.get(args.precision, "f32")
         traffic = None
         try:   # HBM bytes per launch of the roofline kernel from the PMC passes committed for this tree (profiles/), not live
             with open(PMC_FILE) as f:
@@ -173,18 +175,20 @@ def run_rank(args):
         out = {"metric": "images/sec training (CUB 128x128, 10 parts)", "value": round(value, 2), "unit": "images/sec",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+               "dtype": dname, "data": "synthetic",
                "config": {"workload": "CUB yaml 128x128 n_parts={} batch {}/GPU, full train step (7 per-key losses, "
                                       "per-key grads, TF-Adam), use_tps False, VGG19-topology perceptual trunk with "
                                       "stand-in weights at native 128x128; bf16 storage / fp32 accumulate (parity bar of this "
                                       "dtype: part-mask IoU >= 0.99 and losses within 5% of the fp64 oracle; the 1e-3 bar is "
-                                      "met by precision=fp32)".format(args.parts, args.batch),
+                                      "met by precision=fp32){}".format(args.parts, args.batch, "; --precision fp8: e4m3 / e5m2 MFMA "
+                                      "operands for the wide 3x3 convolutions whose operand arrives as an fp8 copy (BASELINE config #5 "
+                                      "arithmetic on config #2's workload)" if args.precision == "fp8" else ""),
                           "global_batch": args.batch * world, "parallelism": "dp{}".format(world),
                           "rccl_world_size": rccl_world},
                "model_tflops_per_gpu": round(value * TRAIN_GFLOP_PER_IMAGE / 1e3 / world, 2),
                "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel<{},128,2,16> @ {} (1 forward + 2 input-gradient "
                                                         "launches per step, all timed)".format(
-                                "bf16" if args.precision == "bf16" else "f32", ops.KernelTimer.layer),
+                                dname, ops.KernelTimer.layer),
                             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                             "kernel_ms": round(kms, 4), "kernel_ms_forward": round(ops.KernelTimer.mean_ms("fwd"), 4),
                             "kernel_ms_dgrad": round(ops.KernelTimer.mean_ms("dgrad"), 4),

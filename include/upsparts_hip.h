@@ -203,6 +203,12 @@ int ups_col_sum(const void* dout, int32_t dtype, int64_t rows, int32_t co, int32
  * Legacy TF-1 bilinear x2 (N:834-847, tf.image.resize_images BILINEAR, no half-pixel centres). */
 int ups_bilinear2x_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
 int ups_bilinear2x_bwd(const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+/* The same (bf16) with an fp8 copy of the result for a consuming fp8 convolution (ups_conv_desc.in_f8): max |act(y)| goes to
+ * amax[64]; with y_f8 != NULL also e4m3 (e5m2 != 0: e5m2) of act(y) * *scale, one byte per element, laid out like y. */
+int ups_bilinear2x_fwd_f8(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void* y_f8, const float* scale,
+                          float* amax, int32_t act, float slope, int32_t e5m2, void* stream);
+int ups_bilinear2x_bwd_f8(const void* gy, void* gx, int32_t n, int32_t h, int32_t w, int32_t c, void* gx_f8, const float* scale,
+                          float* amax, int32_t e5m2, void* stream);
 /* activate + global spatial mean (M:50-51): y[n][c] = mean_hw act(x) */
 int ups_act_mean_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t hw, int32_t c, int32_t act, float slope, void* stream);
 int ups_act_mean_bwd(const void* x, const void* gy, void* gx, int32_t dtype, int32_t n, int32_t hw, int32_t c, int32_t act, float slope, void* stream);

@@ -514,7 +514,7 @@ def test_conv_fp8_forward(case, dev):
     x = (torch.randn(n, h, h, cin, generator=g) * 1.5).to(torch.bfloat16)
     lay = _layer(ops, lib, V, b, 3, 1, coords, act, dev)
     xd = x.to(dev)
-    ops.Fp8.enabled = True
+    ops.Fp8.enabled, ops.Fp8.COPY_ONLY = True, False      # (no producer here: the kernel converts its bf16 operand itself)
     try:
         eligible = ops.Fp8.eligible(lay, xd)
         y = ops.conv_forward(xd, lay, res=xd if res_self else None)
@@ -528,7 +528,7 @@ def test_conv_fp8_forward(case, dev):
         s_a = float(ops.Fp8.scale[f8["slot"]].cpu())
         amax_seen = float(ops.Fp8.amax[f8["slot"]].max().cpu())
     finally:
-        ops.Fp8.enabled = False
+        ops.Fp8.enabled, ops.Fp8.COPY_ONLY = False, None
     xf = x.float()
     xa = torch.maximum(xf, 0.2 * xf) if act == "leaky_relu" else (torch.relu(xf) if act == "relu" else xf)
     assert abs(amax_seen - float(xa.abs().max())) <= 1e-6 * amax_seen, "recorded activation maximum"
@@ -570,7 +570,7 @@ def test_conv_fp8_input_gradient(case, dev):
     x = (torch.randn(n, h, h, cin, generator=g0)).to(torch.bfloat16)
     gy = (torch.randn(n, h, h, cout, generator=g0) * 0.02).to(torch.bfloat16)
     lay = _layer(ops, lib, V, b, 3, 1, coords, act, dev)
-    ops.Fp8.enabled = True
+    ops.Fp8.enabled, ops.Fp8.COPY_ONLY = True, False
     try:
         assert ops.Fp8.eligible_grad(lay, gy.to(dev), x.to(dev))
         gx = ops.conv_dgrad(gy.to(dev), x.to(dev), lay)
@@ -579,7 +579,7 @@ def test_conv_fp8_input_gradient(case, dev):
         s_g = float(ops.Fp8.scale[f8["slot"]].cpu())
         amax_seen = float(ops.Fp8.amax[f8["slot"]].max().cpu())
     finally:
-        ops.Fp8.enabled = False
+        ops.Fp8.enabled, ops.Fp8.COPY_ONLY = False, None
     gf = gy.float()
     assert abs(amax_seen - float(gf.abs().max())) <= 1e-6 * amax_seen
     assert abs(s_g - 57344.0 * ops.Fp8.MARGIN / float(gf.abs().max())) <= 1e-5 * s_g
@@ -623,8 +623,8 @@ def test_conv_fp8_copy_handed_from_producer_to_consumer(case, dev):
     x = torch.randn(n, h, h, cin, generator=g).to(torch.bfloat16).to(dev)
     F = ops.Fp8
     F.enabled = True
-    producer_was = F.PRODUCER
-    F.PRODUCER = True
+    producer_was, copy_only_was = F.PRODUCER, F.COPY_ONLY
+    F.PRODUCER, F.COPY_ONLY = True, False          # (the producing layer itself converts its bf16 input in the kernel here)
     try:
         F.next_out_act = lib.ACT_LRELU
         y0 = ops.conv_forward(x, l1, res=x)                   # first call: records max |act(y)| only
@@ -652,7 +652,52 @@ def test_conv_fp8_copy_handed_from_producer_to_consumer(case, dev):
         torch.cuda.synchronize()
     finally:
         F.enabled = False
-        F.PRODUCER = producer_was
+        F.PRODUCER, F.COPY_ONLY = producer_was, copy_only_was
         F.next_in = F.next_out_act = F.last_out = None
     assert_close(za[..., :cout].float(), zb[..., :cout].float(), 1e-6, "consumer of the fp8 copy vs in-kernel conversion")
     assert float((za[..., :cout].float() - zb0[..., :cout].float()).abs().max()) < 0.1 * float(zb0.float().abs().max())
+
+
+def test_bilinear_fp8_copies(dev):
+    """The bilinear x2 kernels as fp8 producers: same bf16 result as the plain kernels, the forward copy = e4m3(lrelu(y) * scale), the
+    backward copy = e5m2(gx * scale), the recorded maxima exact."""
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(3, 16, 24, 128, generator=g) * 2).to(torch.bfloat16).to(dev)
+    gy = (torch.randn(3, 32, 48, 128, generator=g) * 1e-3).to(torch.bfloat16).to(dev)
+    y_ref = ops.BilinearFn.apply(x)
+    F = ops.Fp8
+    F.enabled = True
+    producer_was = F.PRODUCER
+    F.PRODUCER = True
+    try:
+        site = {}
+        xr = x.clone().requires_grad_(True)
+        y0 = ops.BilinearFn.apply(xr, site, lib.ACT_LRELU, 0.2)          # first step: maxima only
+        assert F.last_out is None and torch.equal(y0, y_ref)
+        y0.backward(gy)
+        gx_ref = xr.grad.clone()
+        F.update()
+        xr.grad = None
+        y1 = ops.BilinearFn.apply(xr, site, lib.ACT_LRELU, 0.2)
+        copy = F.last_out
+        assert copy is not None and torch.equal(y1, y_ref)
+        yf = y_ref.float(); ya = torch.maximum(yf, 0.2 * yf)
+        sc = float(F.scale[copy["slot"]].cpu())
+        assert abs(sc - 448.0 * F.MARGIN / float(ya.abs().max())) <= 1e-5 * sc
+        assert torch.equal(copy["t"], (ya * sc).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+        y1.backward(gy)
+        gx = xr.grad
+        assert torch.equal(gx, gx_ref)
+        ent = F.grad_side.get(gx.data_ptr())
+        assert ent is not None, "no e5m2 copy registered for the returned gradient"
+        gcopy = ent[2]
+        sg = float(F.scale[gcopy["slot"]].cpu())
+        assert abs(sg - 57344.0 * F.MARGIN / float(gx_ref.float().abs().max())) <= 1e-5 * sg
+        want = (gx_ref.float() * sg).clamp(-57344, 57344).to(torch.float8_e5m2).view(torch.uint8)
+        assert torch.equal(gcopy["t"], want)
+    finally:
+        F.enabled = False
+        F.PRODUCER = producer_was
+        F.last_out = None
+        F.grad_side.clear()

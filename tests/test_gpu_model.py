@@ -145,6 +145,7 @@ def test_fp8_step_tracks_bf16(dev):
         runs[prec] = (out, trainer._debug["hard"].cpu().clone())
         if prec == "fp8":
             assert ops.Fp8.count >= 4, "fp8 layers used: {}".format(ops.Fp8.count)
+            assert ops.Fp8.stats["fwd_copy_in"] > 0 and ops.Fp8.stats["dgrad_copy_in"] > 0, ops.Fp8.stats    # copies were handed on
             scales = ops.Fp8.scale[:ops.Fp8.count].cpu()
             assert bool(torch.isfinite(scales).all()) and float(scales.min()) > 0
             assert all(l._cache[k]["version"] == ops.WeightVersion.value for l in ops.Fp8.layers for k in ("f8", "f8g") if k in l._cache)

@@ -62,6 +62,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ops.Fp8.enabled = args.fp8
+    ops.Fp8.COPY_ONLY = False        # isolated launches: convert in the kernel unless --fp8-copy supplies the quantised operand
     T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     only = set(args.only.split(",")) if args.only else None
     print("{:10s} {:>9s} {:>8s} {:>9s} {:>8s} {:>9s} {:>8s}".format("layer", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))

@@ -136,4 +136,10 @@ __device__ inline float block_sum_256(float v, float* smem4) {
     return smem4[0] + smem4[1] + smem4[2] + smem4[3];
 }
 
+// running maximum of non-negative floats in a global slot: the slot only grows, so a wave whose value does not exceed what it
+// reads needs no atomic (a stale read only costs a redundant atomic) -- thousands of blocks otherwise serialise on 64 addresses
+__device__ __forceinline__ void ups_amax_slot(float* slot, float m) {
+    if (m > __builtin_nontemporal_load(slot)) atomicMax((unsigned*)slot, __float_as_uint(m));
+}
+
 static inline int ups_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

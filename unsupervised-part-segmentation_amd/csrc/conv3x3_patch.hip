@@ -616,7 +616,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         // max |act(x)| of the launch (blocks of the first N-tile; 64 slots spread the atomics): next launch's scale
         if constexpr (!PRE) {
             const float m = wave_max(f8_amax_t);
-            if (nt == 0 && lane == 0) atomicMax((unsigned*)(p.f8_amax + (bid & 63)), __float_as_uint(m));
+            if (nt == 0 && lane == 0) ups_amax_slot(p.f8_amax + (bid & 63), m);
         }
         // dequantise: acc = sum (s_a x)(s_w[c] w)  ->  * 1 / (s_a s_w[c])
         const float inv_sa = 1.f / f8_sa;
@@ -632,6 +632,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
     T* __restrict__ outT = (T*)p.out;
     float* __restrict__ outF = (float*)p.out;
+    constexpr bool EMITS = F8 != 0 || !(OCC == 2 && BN == 128);      // instances that can write an fp8 copy of their output
     unsigned char* __restrict__ of8 = p.out_f8;
     float of8_amax = 0.f;
     const float of8_s = (p.out_f8 && p.out_f8_scale) ? *p.out_f8_scale : 1.f;
@@ -786,9 +787,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                     const uint4 u = *(const uint4*)(R0 + px * ERS + ch * 16);
                     const unsigned ga = gaddr(px, nt * BN + ch * 8, p.ldo);
                     *(uint4*)(outT + ga) = u;
-                    // fp8 copy for the consumer (uniform branch; compiled into the fp8 instances only: the 128-wide bf16 kernel at
-                    // two blocks per CU has no register to spare): act(out) -> max -> * scale -> 8 bytes
-                    if (F8 != 0 && p.out_f8_amax) {
+                    // fp8 copy for the consumer (uniform branch; not compiled into the 128-wide bf16 kernel at two blocks per CU, which
+                    // has no register to spare -- the launcher keeps producers off it): act(out) -> max -> * scale -> 8 bytes
+                    if (EMITS && p.out_f8_amax) {
                         const unsigned wsrc[4] = {u.x, u.y, u.z, u.w};
                         float f[8];
 #pragma unroll
@@ -818,9 +819,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                     }
                 }
             }
-            if (F8 != 0 && p.out_f8_amax) {
+            if (EMITS && p.out_f8_amax) {
                 const float m = wave_max(of8_amax);
-                if (lane == 0) atomicMax((unsigned*)(p.out_f8_amax + (bid & 63)), __float_as_uint(m));
+                if (lane == 0) ups_amax_slot(p.out_f8_amax + (bid & 63), m);
             }
             return;
         }
@@ -953,7 +954,7 @@ int launch_t(const PatchK& k, hipStream_t s) {
         // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv) use 64-wide tiles and one patch buffer
         const int tiles = k.n * (k.w / TS) * (k.h / TS);
         if (k.co_fill > 64 && k.ci > 32) {
-            if (patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 128) >= 512) return launch_bn<T, 128, 2, TS>(k, s);
+            if (patch_occ() == 2 && !k.out_f8_amax && tiles * ups_cdiv(k.co_fill, 128) >= 512) return launch_bn<T, 128, 2, TS>(k, s);
             // a grid of one 128-wide block per CU: 64-wide tiles put two blocks on every CU instead (4 waves per SIMD)
             static int mid = -1;
             if (mid < 0) { const char* e = getenv("UPS_PATCH_MID"); mid = (e && e[0] == '0') ? 0 : 1; }
@@ -1009,7 +1010,7 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     k.in_f8 = (const unsigned char*)d->in_f8; k.out_f8 = (unsigned char*)d->out_f8; k.out_f8_scale = d->out_f8_scale;
     k.out_f8_amax = d->out_f8_amax; k.out_f8_act = d->out_f8_act; k.out_f8_e5m2 = d->out_f8_e5m2;
     if (d->in_f8 && (!d->f8_deq || d->co_fill <= 32)) return 1;
-    if ((d->out_f8 || d->out_f8_amax) && (!d->f8_deq || d->dtype != UPS_BF16 || small || d->out_f32 || (d->ldo & 7) || (d->co_fill & 7) || d->mask_grad ||
+    if ((d->out_f8 || d->out_f8_amax) && (d->dtype != UPS_BF16 || small || d->out_f32 || (d->ldo & 7) || (d->co_fill & 7) || d->mask_grad ||
                                           !d->out_f8_amax || (d->out_f8 && !d->out_f8_scale)))
         return 1;
     k.d2s = 0; k.d2s_shift = 0;

@@ -15,9 +15,46 @@ template <typename T> struct V16 {
 // out[2i] = in[i]; out[2i+1] = 0.5*(in[i] + in[min(i+1, n-1)])  (rows first, then columns, like the oracle)
 // One thread per INPUT pixel chunk: the four neighbours it needs are loaded once and its 2x2 block of outputs is written
 // (one load per output chunk instead of 2.25; same operation order as before: rows first, then columns).
-template <typename T>
-__global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c) {
+// fp8 copy of a stored bf16 chunk for the consuming convolution (ups_conv_desc.in_f8): act -> running max -> * scale -> 8 bytes
+struct F8Emit {
+    unsigned char* out;      // NULL: record the maximum only
+    const float* scale; float* amax;
+    int act, e5m2; float slope;
+};
+__device__ __forceinline__ void f8_emit_chunk(const F8Emit& q, float sc, float ns, long long elem, const float* v, float& amax) {
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        f[e] = (float)(bf16)v[e];                 // what the bf16 tensor holds
+        if (q.act != UPS_ACT_NONE) f[e] = ups_act_ns(f[e], ns);
+        amax = fmaxf(amax, fabsf(f[e]));
+    }
+    if (q.out) {
+        int d0 = 0, d1 = 0;
+        if (q.e5m2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e] * sc, -57344.f, 57344.f);
+            d0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], d0, false); d0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], d0, true);
+            d1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], d1, false); d1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], d1, true);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e] * sc, -448.f, 448.f);
+            d0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], d0, false); d0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], d0, true);
+            d1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], d1, false); d1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], d1, true);
+        }
+        *(uint2*)(q.out + elem) = make_uint2((unsigned)d0, (unsigned)d1);
+    }
+}
+__device__ __forceinline__ void f8_emit_finish(const F8Emit& q, float amax) {
+    const float m = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) ups_amax_slot(q.amax + (blockIdx.x & 63), m);
+}
+
+template <typename T, bool EMIT = false>
+__global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, F8Emit q = F8Emit()) {
     constexpr int E = V16<T>::N;
+    float amax = 0.f;
+    const float sc = (EMIT && q.out) ? *q.scale : 1.f, ns = EMIT ? ups_slope_eff(q.act, q.slope) : 0.f;
     const int cc = c / E;
     const long long total = (long long)n * h * w * cc;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -37,16 +74,21 @@ __global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y
         T* ob = y + (((long long)b * 2 * h + 2 * y0) * (2 * w) + 2 * x0) * c + k * E;
         const long long orow = (long long)2 * w * c;
         V16<T>::st(ob, a00);                                                        // (2y, 2x)
+        if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob - y, a00, amax);
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = 0.5f * (a00[e] + a01[e]);
         V16<T>::st(ob + c, o);                                                      // (2y, 2x+1)
+        if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob + c - y, o, amax);
 #pragma unroll
         for (int e = 0; e < E; ++e) { a00[e] = 0.5f * (a00[e] + a10[e]); a01[e] = 0.5f * (a01[e] + a11[e]); }
         V16<T>::st(ob + orow, a00);                                                 // (2y+1, 2x)
+        if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob + orow - y, a00, amax);
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = 0.5f * (a00[e] + a01[e]);
         V16<T>::st(ob + orow + c, o);                                               // (2y+1, 2x+1)
+        if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob + orow + c - y, o, amax);
     }
+    if constexpr (EMIT) f8_emit_finish(q, amax);
 }
 
 // gather form of the transpose: 1-D weights of output o on input i: o=2i ->1, o=2i+1 ->.5 (+.5 if i==n-1), o=2i-1 ->.5
@@ -56,9 +98,11 @@ __device__ inline float up_w(int o, int i, int n) {
     return 0.5f;  // o == 2i-1
 }
 
-template <typename T>
-__global__ void bilinear2x_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int n, int h, int w, int c) {
+template <typename T, bool EMIT = false>
+__global__ void bilinear2x_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int n, int h, int w, int c, F8Emit q = F8Emit()) {
     constexpr int E = V16<T>::N;
+    float amax = 0.f;
+    const float sc = (EMIT && q.out) ? *q.scale : 1.f;
     const int cc = c / E;
     const long long total = (long long)n * h * w * cc;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -83,7 +127,9 @@ __global__ void bilinear2x_bwd_kernel(const T* __restrict__ gy, T* __restrict__ 
             }
         }
         V16<T>::st(gx + idx * E, acc);
+        if constexpr (EMIT) f8_emit_chunk(q, sc, 0.f, idx * E, acc, amax);
     }
+    if constexpr (EMIT) f8_emit_finish(q, amax);
 }
 
 // ------------------------------------------------------------------ activate + global mean (model.py:50-51)
@@ -323,6 +369,28 @@ extern "C" int ups_bilinear2x_bwd(const void* gy, void* gx, int32_t dtype, int32
     hipStream_t s = (hipStream_t)stream;
     if (dtype == UPS_F32) hipLaunchKernelGGL(bilinear2x_bwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)gy, (float*)gx, n, h, w, c);
     else hipLaunchKernelGGL(bilinear2x_bwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)gy, (bf16*)gx, n, h, w, c);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+// bf16 bilinear x2 that also hands its output to an fp8 convolution: max |act(y)| into amax[64]; with y_f8 != NULL the e4m3
+// (e5m2 != 0: e5m2) bytes of act(y) * *scale next to y (ups_conv_desc.in_f8 of the consumer)
+extern "C" int ups_bilinear2x_fwd_f8(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void* y_f8,
+                                     const float* scale, float* amax, int32_t act, float slope, int32_t e5m2, void* stream) {
+    UPS_CHECK_ARG(x && y && amax && c % 8 == 0 && (!y_f8 || scale) && slope >= 0.f && slope <= 1.f);
+    const long long work = (long long)n * h * w * (c / 8);
+    F8Emit q; q.out = (unsigned char*)y_f8; q.scale = scale; q.amax = amax; q.act = act; q.e5m2 = e5m2; q.slope = slope;
+    hipLaunchKernelGGL((bilinear2x_fwd_kernel<bf16, true>), dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                       (bf16*)y, n, h, w, c, q);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_bilinear2x_bwd_f8(const void* gy, void* gx, int32_t n, int32_t h, int32_t w, int32_t c, void* gx_f8,
+                                     const float* scale, float* amax, int32_t e5m2, void* stream) {
+    UPS_CHECK_ARG(gy && gx && amax && c % 8 == 0 && (!gx_f8 || scale));
+    const long long work = (long long)n * h * w * (c / 8);
+    F8Emit q; q.out = (unsigned char*)gx_f8; q.scale = scale; q.amax = amax; q.act = UPS_ACT_NONE; q.e5m2 = e5m2; q.slope = 0.f;
+    hipLaunchKernelGGL((bilinear2x_bwd_kernel<bf16, true>), dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const bf16*)gy,
+                       (bf16*)gx, n, h, w, c, q);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

@@ -87,6 +87,8 @@ _SIGS = {
     "ups_col_sum": ([_P, _I, _L, _I, _I, _P, _P, _P], C.c_int),
     "ups_bilinear2x_fwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "ups_bilinear2x_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "ups_bilinear2x_fwd_f8": ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _I, _P], C.c_int),
+    "ups_bilinear2x_bwd_f8": ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "ups_act_mean_fwd": ([_P, _P, _I, _I, _I, _I, _I, _F, _P], C.c_int),
     "ups_act_mean_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _F, _P], C.c_int),
     "ups_maxpool2_fwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),

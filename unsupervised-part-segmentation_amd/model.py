@@ -52,6 +52,8 @@ class TrainModel(object):
         # precision: fp8 (BASELINE config #5) = bf16 tensors, forward and input gradient of the wide 3x3 / stride-1 convolutions
         # with e4m3 / e5m2 MFMA operands and fp32 accumulation (ops.Fp8); weight gradients stay on the bf16 kernels
         ops.Fp8.enabled = prec in ("fp8", "f8", "e4m3")
+        for k in ops.Fp8.stats:
+            ops.Fp8.stats[k] = 0
         self.patch_size = config.get("patch_size", 32)
         self.df = N.is_48c(config)          # DeepFashion SB_model48c variant (two inputs, no rectangles, extra decoders)
         self.nets = N.Nets(config, self.device, seed if seed is not None else config.get("seed", 0))

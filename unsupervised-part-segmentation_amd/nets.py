@@ -162,7 +162,16 @@ class Scope(object):
     def upsample_linear(self, x):
         if x.t is None:
             return Act(None, x.n, 2 * x.h, 2 * x.w, x.c)
-        return Act(ops.BilinearFn.apply(x.t), x.n, 2 * x.h, 2 * x.w, x.c)
+        if not ops.Fp8.enabled:
+            return Act(ops.BilinearFn.apply(x.t), x.n, 2 * x.h, 2 * x.w, x.c)
+        # fp8: the up-sampled tensor feeds this scope's next convolution -- hand it an e4m3 copy of act(y) (and, backwards, the
+        # convolution below an e5m2 copy of the gradient); per-call-site scale slots live with the model
+        sites = self.owner.__dict__.setdefault("f8_sites", {})
+        site = sites.setdefault("{}/upsample@{}".format(self.prefix, self.counter), {})
+        ops.Fp8.last_out = None
+        t = ops.BilinearFn.apply(x.t, site, self.act, 0.2)
+        f8, ops.Fp8.last_out = ops.Fp8.last_out, None
+        return Act(t, x.n, 2 * x.h, 2 * x.w, x.c, f8=f8)
 
     def act_mean(self, x):
         if x.t is None:

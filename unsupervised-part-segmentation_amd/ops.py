@@ -214,13 +214,15 @@ class Fp8(object):
                     ent["version"] = WeightVersion.value
 
     GRAD = True             # input gradients of the fp8 layers on e5m2 operands (False: bf16 kernels)
+    # COPY_ONLY: a layer takes the fp8 kernels only when its operand arrives quantised (a copy written by the producing bilinear /
+    # convolution kernel); layers whose operand would have to be converted inside the kernel (24 staging registers, one block per
+    # CU: slower than bf16) stay on the bf16 kernels.  Follows PRODUCER unless set explicitly.
+    COPY_ONLY = None
     # fp8 copies handed from layer to layer: the producing convolution's epilogue writes e4m3(act(out) * scale) next to its bf16
     # output (scale = the delayed scale of that tensor), the consuming convolution stages those bytes without any conversion.
     # nets.Scope passes the handle along: next_in / next_out_act are set right before ops.conv, last_out is read right after.
-    # Off unless asked for (UPS_F8_PRODUCER=1 / Fp8.PRODUCER = True): in this model nearly every wide convolution reads the output of
-    # a bilinear up-sampling, a stride-2 layer or a pooling, not of another fp8 convolution, so the copies would find no consumer
-    #  -- the kernels and the hand-off are tested and timed on their own (tools/bench_conv.py --fp8 --fp8-copy).
-    PRODUCER = os.environ.get("UPS_F8_PRODUCER", "0") == "1"
+    # UPS_F8_PRODUCER=0 switches the hand-off off (every eligible layer then converts its bf16 operand inside the kernel).
+    PRODUCER = os.environ.get("UPS_F8_PRODUCER", "1") != "0"
     next_in = None          # {"t": uint8 tensor, "act": UPS_ACT_*, "slot": scale slot} of the coming call's input
     next_out_act = None     # activation-on-load of the consumer of the coming call's output (None: no copy wanted)
     last_out = None         # the copy the last call wrote (same dict), or None
@@ -229,6 +231,27 @@ class Fp8(object):
     E5M2_MAX = 57344.0
 
     grad_side = {}          # data_ptr of a gradient tensor -> (weakref to it, its e5m2 copy): dgrad epilogue -> next dgrad
+
+    @staticmethod
+    def wanted(site):
+        """A producer keeps writing its copy only while somebody reads it: after two unread copies the site goes quiet."""
+        return not (site.get("emitted", 0) >= 2 and site.get("used", 0) == 0)
+
+    @staticmethod
+    def mark_used(copy):
+        site = copy.get("site")
+        if site is not None:
+            site["used"] = site.get("used", 0) + 1
+
+    @classmethod
+    def copy_only(cls):
+        return cls.PRODUCER if cls.COPY_ONLY is None else cls.COPY_ONLY
+
+    @staticmethod
+    def usable(src, layer, x, ldi):
+        """src (a producer's fp8 copy handle or None) is this layer's input, quantised with this layer's activation-on-load."""
+        return (src is not None and src.get("t") is not None and src["act"] == layer.act_in and tuple(src["t"].shape) == tuple(x.shape)
+                and layer.co > 32 and ldi % 16 == 0)
 
     @classmethod
     def register_grad_copy(cls, t, copy):
@@ -443,12 +466,12 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
     d.dact = None
     if mask is not None:
         d.mask_bits, d.mask_batch = mask[0].data_ptr(), x.shape[0]
-    elif Fp8.eligible(layer, x):
+    elif Fp8.eligible(layer, x) and (not Fp8.copy_only() or Fp8.usable(Fp8.next_in, layer, x, ldi)):
         src, want_act = Fp8.next_in, Fp8.next_out_act
-        if (src is not None and src["act"] == layer.act_in and tuple(src["t"].shape) == tuple(x.shape) and layer.co > 32
-                and ldi % 16 == 0):
+        if Fp8.usable(src, layer, x, ldi):
             f8 = layer.prepared_f8(None)               # the producer quantised act(x) with its tensor's scale
             Fp8.stats["fwd_copy_in"] += 1
+            Fp8.mark_used(src)
             d.in_f8 = src["t"].data_ptr()
             d.f8_scale = Fp8.scale[src["slot"]:].data_ptr()
         else:
@@ -462,13 +485,15 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
             eo = layer._cache.get("f8o")
             if eo is None:
                 eo = layer._cache["f8o"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
-            d.out_f8_amax = Fp8.amax[eo["slot"]].data_ptr()
-            d.out_f8_act = want_act
-            if Fp8.steps > eo["born"]:                 # its delayed scale exists
-                t8 = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
-                d.out_f8, d.out_f8_scale = t8.data_ptr(), Fp8.scale[eo["slot"]:].data_ptr()
-                f8_out = {"t": t8, "act": want_act, "slot": eo["slot"]}
-                Fp8.stats["fwd_copy_out"] += 1
+            if Fp8.wanted(eo):
+                d.out_f8_amax = Fp8.amax[eo["slot"]].data_ptr()
+                d.out_f8_act = want_act
+                if Fp8.steps > eo["born"]:                 # its delayed scale exists
+                    t8 = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
+                    d.out_f8, d.out_f8_scale = t8.data_ptr(), Fp8.scale[eo["slot"]:].data_ptr()
+                    f8_out = {"t": t8, "act": want_act, "slot": eo["slot"], "site": eo}
+                    eo["emitted"] = eo.get("emitted", 0) + 1
+                    Fp8.stats["fwd_copy_out"] += 1
     Fp8.next_in = Fp8.next_out_act = None
     Fp8.last_out = f8_out
     _attach_ws(d, x.device)
@@ -565,33 +590,43 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
         d.dact = x.data_ptr() if layer.act_in != L.ACT_NONE else None
         if mask_view is not None:
             d.mask_grad, d.mask_view, d.mask_batch = g_hard.data_ptr(), mask_view.data_ptr(), n
-        elif st == 1 and Fp8.eligible_grad(layer, g, x):
+        elif st == 1 and Fp8.enabled and Fp8.GRAD and g.dtype == torch.bfloat16:
             src = Fp8.grad_copy(g)
-            if src is not None and layer.ci_log > 32 and g.shape[-1] % 16 == 0:
-                f8 = layer.prepared_f8_grad(None)          # the layer above wrote e5m2(g * scale) in its dgrad epilogue
-                Fp8.stats["dgrad_copy_in"] += 1
-                d.in_f8 = src["t"].data_ptr()
-                d.f8_scale = Fp8.scale[src["slot"]:].data_ptr()
-            else:
-                f8 = layer.prepared_f8_grad(g)
-                d.f8_scale = Fp8.scale[f8["slot"]:].data_ptr()
-                d.f8_amax = Fp8.amax[f8["slot"]].data_ptr()
-            d.w = f8["w"].data_ptr()
-            d.f8_deq = f8["deq"].data_ptr()
-            d.f8_e5m2 = 1
-            Fp8.stats["dgrad_f8"] += 1
-            if Fp8.PRODUCER and gx is not None and ldi % 64 == 0 and layer.ci_log == ldi:
+            use_f8 = Fp8.eligible_grad(layer, g, x)
+            src_ok = use_f8 and src is not None and layer.ci_log > 32 and g.shape[-1] % 16 == 0
+            emit = False
+            if use_f8 and (src_ok or not Fp8.copy_only()):
+                if src_ok:
+                    f8 = layer.prepared_f8_grad(None)      # the producer wrote e5m2(g * scale) in its epilogue
+                    Fp8.stats["dgrad_copy_in"] += 1
+                    Fp8.mark_used(src)
+                    d.in_f8 = src["t"].data_ptr()
+                    d.f8_scale = Fp8.scale[src["slot"]:].data_ptr()
+                else:
+                    f8 = layer.prepared_f8_grad(g)
+                    d.f8_scale = Fp8.scale[f8["slot"]:].data_ptr()
+                    d.f8_amax = Fp8.amax[f8["slot"]].data_ptr()
+                d.w = f8["w"].data_ptr()
+                d.f8_deq = f8["deq"].data_ptr()
+                d.f8_e5m2 = 1
+                Fp8.stats["dgrad_f8"] += 1
+                emit = True
+            elif layer.k == 3 and round8(layer.co) <= 32 and hi % 16 == 0 and wi % 16 == 0:
+                emit = True     # a bf16 launch off the 128-wide two-blocks-per-CU instance (the P-channel head): it can write the copy
+            if emit and Fp8.PRODUCER and gx is not None and ldi % 64 == 0 and layer.ci_log == ldi:
                 eo = layer._cache.get("f8go")
                 if eo is None:
                     eo = layer._cache["f8go"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
                     Fp8.fmax[eo["slot"]] = Fp8.E5M2_MAX
-                d.out_f8_amax = Fp8.amax[eo["slot"]].data_ptr()
-                d.out_f8_act, d.out_f8_e5m2 = L.ACT_NONE, 1
-                if Fp8.steps > eo["born"]:
-                    t8 = torch.empty(gx.shape, dtype=torch.uint8, device=x.device)
-                    d.out_f8, d.out_f8_scale = t8.data_ptr(), Fp8.scale[eo["slot"]:].data_ptr()
-                    Fp8.register_grad_copy(gx, {"t": t8, "slot": eo["slot"]})
-                    Fp8.stats["dgrad_copy_out"] += 1
+                if Fp8.wanted(eo):
+                    d.out_f8_amax = Fp8.amax[eo["slot"]].data_ptr()
+                    d.out_f8_act, d.out_f8_e5m2 = L.ACT_NONE, 1
+                    if Fp8.steps > eo["born"]:
+                        t8 = torch.empty(gx.shape, dtype=torch.uint8, device=x.device)
+                        d.out_f8, d.out_f8_scale = t8.data_ptr(), Fp8.scale[eo["slot"]:].data_ptr()
+                        Fp8.register_grad_copy(gx, {"t": t8, "slot": eo["slot"], "site": eo})
+                        eo["emitted"] = eo.get("emitted", 0) + 1
+                        Fp8.stats["dgrad_copy_out"] += 1
         _attach_ws(d, x.device)
         assert round8(layer.co) <= g.shape[-1]
         if KernelTimer.layer == layer.name and KernelTimer.enabled and st == 1:
@@ -735,12 +770,29 @@ def masked_conv_eligible(dtype, size, n_parts):
 
 
 class BilinearFn(torch.autograd.Function):
+    """site: per-call-site state (a dict owned by the Scope) when the up-sampling feeds fp8 convolutions: its forward then also
+    writes the e4m3 copy of act(y), its backward the e5m2 copy of the gradient it returns (ops.Fp8 hand-off)."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, site=None, act=0, slope=0.2):
         x = x.contiguous()
         n, h, w, c = x.shape
         y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
-        L.call("ups_bilinear2x_fwd", L.ptr(x), L.ptr(y), L.dt(x), n, h, w, c, L.stream())
+        f8 = site is not None and Fp8.enabled and Fp8.PRODUCER and x.dtype == torch.bfloat16 and c % 64 == 0 and (2 * h) % 16 == 0
+        ctx.site = site if f8 else None
+        f8 = f8 and Fp8.wanted(site.setdefault("fwd", {"slot": Fp8.slot(x.device), "born": Fp8.steps}))
+        if f8:
+            so = site.get("fwd")
+            if so is None:
+                so = site["fwd"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
+            t8 = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if Fp8.steps > so["born"] else None
+            if t8 is not None:
+                so["emitted"] = so.get("emitted", 0) + 1
+            L.call("ups_bilinear2x_fwd_f8", L.ptr(x), L.ptr(y), n, h, w, c, L.ptr(t8) if t8 is not None else None,
+                   L.ptr(Fp8.scale[so["slot"]:]), L.ptr(Fp8.amax[so["slot"]]), act, slope, 0, L.stream())
+            Fp8.last_out = {"t": t8, "act": act, "slot": so["slot"], "site": so} if t8 is not None else None
+        else:
+            L.call("ups_bilinear2x_fwd", L.ptr(x), L.ptr(y), L.dt(x), n, h, w, c, L.stream())
         ctx.shape = (n, h, w, c)
         return y
 
@@ -749,8 +801,26 @@ class BilinearFn(torch.autograd.Function):
         n, h, w, c = ctx.shape
         g = g.contiguous()
         gx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
-        L.call("ups_bilinear2x_bwd", L.ptr(g), L.ptr(gx), L.dt(g), n, h, w, c, L.stream())
-        return gx
+        site = ctx.site
+        so = None
+        if site is not None and Fp8.GRAD and g.dtype == torch.bfloat16 and h % 16 == 0:
+            so = site.get("bwd")
+            if so is None:
+                so = site["bwd"] = {"slot": Fp8.slot(g.device), "born": Fp8.steps}
+                Fp8.fmax[so["slot"]] = Fp8.E5M2_MAX
+            if not Fp8.wanted(so):
+                so = None
+        if so is not None:
+            t8 = torch.empty(gx.shape, dtype=torch.uint8, device=g.device) if Fp8.steps > so["born"] else None
+            if t8 is not None:
+                so["emitted"] = so.get("emitted", 0) + 1
+            L.call("ups_bilinear2x_bwd_f8", L.ptr(g), L.ptr(gx), n, h, w, c, L.ptr(t8) if t8 is not None else None,
+                   L.ptr(Fp8.scale[so["slot"]:]), L.ptr(Fp8.amax[so["slot"]]), 1, L.stream())
+            if t8 is not None:
+                Fp8.register_grad_copy(gx, {"t": t8, "slot": so["slot"], "site": so})
+        else:
+            L.call("ups_bilinear2x_bwd", L.ptr(g), L.ptr(gx), L.dt(g), n, h, w, c, L.stream())
+        return gx, None, None, None
 
 
 class ActMeanFn(torch.autograd.Function):
