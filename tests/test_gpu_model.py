@@ -366,10 +366,14 @@ def test_forty_steps_bf16_and_fp8_track_fp32(dev):
         model = TrainModel(c, device=dev, seed=0)
         trainer = Trainer(c, None, model)
         h = []
+        slots = None
         for step in range(40):
             losses = trainer.train_step(views, noise)
             if step % 5 == 0 or step == 39:
                 h.append({k: float(v) for k, v in losses.items()})
+            if step == 3:
+                slots = ops.Fp8.count
+        assert ops.Fp8.count == slots, "fp8 scale slots keep being allocated: {} -> {}".format(slots, ops.Fp8.count)
         hist[prec] = h
     ops.Fp8.enabled = False
     print("decoder_delta loss, steps 0, 5, ..., 35, 39:", {p: [round(r["decoder_delta"], 2) for r in h] for p, h in hist.items()})

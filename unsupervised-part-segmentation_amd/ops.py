@@ -780,11 +780,11 @@ class BilinearFn(torch.autograd.Function):
         y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
         f8 = site is not None and Fp8.enabled and Fp8.PRODUCER and x.dtype == torch.bfloat16 and c % 64 == 0 and (2 * h) % 16 == 0
         ctx.site = site if f8 else None
-        f8 = f8 and Fp8.wanted(site.setdefault("fwd", {"slot": Fp8.slot(x.device), "born": Fp8.steps}))
+        if f8 and "fwd" not in site:
+            site["fwd"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
+        f8 = f8 and Fp8.wanted(site["fwd"])
         if f8:
-            so = site.get("fwd")
-            if so is None:
-                so = site["fwd"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
+            so = site["fwd"]
             t8 = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if Fp8.steps > so["born"] else None
             if t8 is not None:
                 so["emitted"] = so.get("emitted", 0) + 1
