@@ -379,7 +379,9 @@ class Trainer(object):
         lr = self.learning_rate()
         g["lr"].fill_(lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t))
         sig = self._schedule_signature() + (lr > 0,)
-        if g["eager"] < 2:                       # warm-up: kernel attributes, side streams, allocator pools
+        # warm-up: kernel attributes, side streams, allocator pools; fp8: the copy hand-off settles over four steps (first maxima,
+        # first copies, unread producers going quiet) and the captured graph freezes whatever it sees
+        if g["eager"] < (5 if ops.Fp8.enabled else 2):
             g["eager"] += 1
             out = self._step_impl(g["in"], g["noise"], graph_lr=g["lr"])
             self._after_graph_step()
