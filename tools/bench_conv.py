@@ -15,6 +15,7 @@ from upsparts_amd import ops, lib  # noqa: E402
 CASES = [
     # name, n, h, cin, cout, k, stride, coords, act
     ("dv_rb128", 128, 128, 256, 256, 3, 1, True, "leaky_relu"),
+    ("dv_rb128_noact", 128, 128, 256, 256, 3, 1, True, None),      # the same layer without activation-on-load (cost of the fused lrelu)
     ("dv_rb64", 128, 64, 256, 256, 3, 1, True, "leaky_relu"),
     ("dv_rb32", 128, 32, 256, 256, 3, 1, True, "leaky_relu"),
     ("dv_rb16", 128, 16, 256, 256, 3, 1, True, "leaky_relu"),
