@@ -11,7 +11,7 @@
  *     (caller-owned, no hidden allocation) unless a parameter says "host";
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
  *   - return value: 0 = ok, negative = UPS_E_* (no exceptions cross the ABI);
- *   - activations are NHWC, element type UPS_F32 or UPS_BF16, with a physical
+ *   - activations are NHWC, element type UPS_F32, UPS_BF16 or (forward tensors only) UPS_F16, with a physical
  *     channel count that is a multiple of 8 (16-byte rows); accumulation is fp32;
  *   - thread-compatible: one stream per concurrent caller.
  */
@@ -27,7 +27,11 @@ extern "C" {
 
 #define UPS_ABI_VERSION 1
 
-enum { UPS_F32 = 0, UPS_BF16 = 1 };
+/* UPS_F16 (IEEE half): element type of FORWARD tensors of precision-critical scopes (the mask decoder): ups_conv_igemm,
+ * ups_weight_prep(_batch), ups_bilinear2x_fwd, ups_convert / ups_pad_convert accept it; gradients are never fp16 (range): the
+ * input-gradient call of such a layer is a plain UPS_BF16 call (`dact` only has its sign read, which is the same bit in both
+ * 16-bit formats), its weight-gradient call sets ups_wgrad_desc.in_f16. */
+enum { UPS_F32 = 0, UPS_BF16 = 1, UPS_F16 = 2 };
 enum { UPS_ACT_NONE = 0, UPS_ACT_LRELU = 1, UPS_ACT_RELU = 2 };
 enum { UPS_OK = 0, UPS_E_ARG = -1, UPS_E_UNSUPPORTED = -2, UPS_E_LAUNCH = -3 };
 
@@ -149,6 +153,8 @@ typedef struct {
     float* workspace;                 /* bytes from ups_conv_wgrad_plan */
     const uint32_t* mask_bits;        /* part-masked input, same meaning as in the conv descriptor; bf16 3x3 / stride-1 patch kernel only; or NULL */
     int32_t mask_batch;
+    int32_t in_f16;                   /* dtype UPS_BF16 only: `in` holds fp16 (the forward tensor of a UPS_F16 layer); it is converted to
+                                       * bf16 (after the activation) while it is staged -- dout stays bf16 */
 } ups_wgrad_desc;
 
 int ups_conv_wgrad_plan(const ups_wgrad_desc* d, int32_t* splitk, size_t* workspace_bytes);

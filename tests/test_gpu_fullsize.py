@@ -33,6 +33,8 @@ def _trainer(dev, precision, perceptual_input="native"):
         import make_golden_full as G
         cfg = copy.deepcopy(G.CONFIGS[perceptual_input]())
         perceptual_input = "native"
+    if precision == "bf16-pure":      # bf16 tensors in the mask decoder too (the round-2 configuration)
+        precision, cfg["mask_decoder_dtype"] = "bf16", "bf16"
     cfg["precision"] = precision
     cfg["perceptual_input"] = perceptual_input
     model = TrainModel(cfg, device=dev, seed=0)
@@ -129,16 +131,18 @@ def test_full_width_step_bf16_mask_iou(dev, mode, precision):
         assert abs(lo - lh) <= tol * max(1.0, abs(lo)), "loss {}: oracle {} hip({}) {}".format(k, lo, precision, lh)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32", "fp8"])
+@pytest.mark.parametrize("precision", ["bf16", "bf16-pure", "fp32", "fp8"])
 def test_full_width_confident_masks_iou(dev, precision):
     """Part-mask IoU vs the fp64 oracle on CONFIDENT masks.  At random init the mask decoder's output is nearly flat (noise-free
     argmax decided by ~1e-2 logit gaps, sampled masks decided by the unit noise: the >= 0.99 of the test above is easy there),
     so this fixture scales the last decoder convolution until the mask entropy equals what the reference logs after training
     (tests/golden/make_golden_full.py confident).  The logit FIELD is still the smooth random function of an untrained
     decoder, whose part regions meet along long, shallow boundaries: a relative logit error e flips the pixels whose top-2 gap
-    is below e * |logit|, whatever the scale.  fp32 must reproduce the masks (IoU >= 0.999); bf16 storage through the ~30
-    convolutions of encoder_0 + decoder_visualize (1-2 % relative logit error) must agree on >= 99 % of the pixels; its mean
-    per-part IoU (small parts weigh as much as large ones) is reported and held to >= 0.9 (measured 0.93 - 0.97).
+    is below e * |logit|, whatever the scale.  fp32 must reproduce the masks (IoU >= 0.999).  "bf16" -- the benchmark's
+    precision: bf16 tensors with the mask decoder's forward tensors in fp16 (`mask_decoder_dtype`, nets.Nets) -- must meet
+    north_star's bar on both mask outputs: mean per-part IoU >= 0.99 noise-free (out_parts_hard, M:469-470) AND sampled.
+    "bf16-pure" (bf16 in the mask decoder as well, the round-2 configuration) documents why: 0.7 % logit error after its ~15
+    layers, pixel agreement 0.995 but mean per-part IoU 0.93 - 0.97 (small parts weigh as much as large ones); held to 0.9.
     fp8 (BASELINE config #5's arithmetic at config #2's size: e4m3 forward of the wide 3x3 convolutions) is reported the same
     way and held to the agreement its 2^-4 operand resolution allows (pixels >= 0.95, mean per-part IoU >= 0.8)."""
     import sys
@@ -168,6 +172,8 @@ def test_full_width_confident_masks_iou(dev, precision):
         ops.Fp8.enabled, ops.Fp8.COPY_ONLY = False, None
         assert agree >= 0.95 and iou_mean >= 0.8 and iou_s >= 0.8, (agree, iou_mean, iou_s)     # measured 0.979 / 0.90 / 0.92
     elif precision == "bf16":
+        assert agree >= 0.995 and iou_mean >= 0.99 and iou_s >= 0.99, (agree, iou_mean, iou_s)
+    elif precision == "bf16-pure":
         assert agree >= 0.99 and iou_mean >= 0.9 and iou_s >= 0.9, (agree, iou_mean, iou_s)
     else:
         assert iou_mean >= 0.999 and iou_s >= 0.999, (iou_mean, iou_s)

@@ -142,6 +142,75 @@ def test_conv_fwd_bwd(case, dtype, dev):
     assert_close(gb.float(), bo.grad.float(), tol, "conv bias grad {}".format(case))
 
 
+F16_CASES = [c for c in CONV_CASES if c[6] == 1 and c[8] in (None, "leaky_relu")
+             and c in ((2, 16, 16, 16, 16, 3, 1, True, "leaky_relu", True), (4, 1, 1, 16, 72, 1, 1, True, None, False),
+                       (3, 32, 48, 64, 136, 3, 1, True, "leaky_relu", False), (2, 32, 32, 128, 128, 3, 1, True, "leaky_relu", True),
+                       (5, 16, 32, 24, 40, 3, 1, True, None, False), (16, 64, 64, 136, 136, 3, 1, True, "leaky_relu", True),
+                       (8, 8, 8, 72, 72, 3, 1, True, "leaky_relu", True), (32, 4, 4, 136, 136, 3, 1, True, "leaky_relu", True),
+                       (1536, 4, 4, 16, 136, 3, 1, True, None, False), (8, 128, 128, 256, 256, 3, 1, True, "leaky_relu", True),
+                       (16, 64, 64, 256, 256, 3, 1, True, "leaky_relu", True), (2, 40, 40, 256, 256, 3, 1, True, "leaky_relu", True),
+                       (1, 40, 40, 256, 256, 3, 1, True, "leaky_relu", True))]
+F16_TOL = 2e-3
+
+
+@pytest.mark.parametrize("case", F16_CASES)
+def test_conv_fp16_forward_bf16_gradients(case, dev):
+    """The mask decoder's tensor format (`fmt = UPS_F16`): forward tensors and forward weights are fp16 (in bf16 containers),
+    the gradients and the backward operands bf16.  Forward vs the fp64 oracle on the fp16-rounded operands at 2e-3 (bf16: 2e-2);
+    input / weight gradients at the bf16 bar (their operands are bf16 roundings of the same numbers)."""
+    lib, ops, R = _mods()
+    n, h, w, cin, cout, k, stride, coords, act, res_self = case
+    g = torch.Generator().manual_seed(300 + CONV_CASES.index(case))
+    cin_v = cin + (2 if coords else 0)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.float16).float()
+    V = torch.randn(k, k, cin_v, cout, generator=g) / math.sqrt(cin_v * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    xo = x.double().requires_grad_(True)
+    Vo = V.double().clone()
+    Vo[:, :, :cin] = V[:, :, :cin].to(torch.float16).double()
+    Vo.requires_grad_(True)
+    bo = b.double().requires_grad_(True)
+    yo = _oracle_conv(R, xo, Vo, bo, stride, coords, act, res_self, None)
+    go = torch.randn(yo.shape, generator=g).to(torch.bfloat16).float()
+    yo.backward(go.double())
+    lay = _layer(ops, lib, V, b, k, stride, coords, act, dev)
+    lay.f16 = True
+    xd = x.to(dev, torch.float16).view(torch.bfloat16).requires_grad_(True)
+    y = ops.conv(xd, lay, res_self=res_self, fmt=lib.F16)
+    assert y.dtype == torch.bfloat16 and y.shape[-1] == ops.round8(cout)
+    yf = y.view(torch.float16).float()
+    assert_close(yf[..., :cout], yo.float(), F16_TOL, "fp16 conv fwd {}".format(case))
+    if y.shape[-1] > cout:
+        assert float(yf[..., cout:].abs().max()) == 0.0
+    gd = torch.zeros(y.shape, dtype=torch.bfloat16, device=dev)
+    gd[..., :cout] = go.to(dev, torch.bfloat16)
+    gx, gV, gb = torch.autograd.grad([y], [xd, lay.V, lay.b], grad_outputs=[gd])
+    assert gx.dtype == torch.bfloat16
+    assert_close(gx.float(), xo.grad.float(), BF16_TOL, "fp16-forward conv dgrad {}".format(case))
+    assert_close(gV.float(), Vo.grad.float(), 4 * BF16_TOL, "fp16-forward conv wgrad {}".format(case))
+    assert_close(gb.float(), bo.grad.float(), BF16_TOL, "fp16-forward conv bias grad {}".format(case))
+    # fp32 logits out of an fp16 layer (the decoder's last convolution)
+    if not res_self:
+        y32 = ops.conv(xd, lay, out_f32=True, fmt=lib.F16)
+        assert y32.dtype == torch.float32
+        assert_close(y32[..., :cout], yo.float(), F16_TOL / 2, "fp16 conv fwd, fp32 out {}".format(case))
+
+
+def test_bilinear_fp16(dev):
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(3, 6, 5, 16, generator=g).to(torch.float16).float()
+    yo = R.bilinear_up2(x.double())
+    xd = x.to(dev, torch.float16).view(torch.bfloat16).requires_grad_(True)
+    y = ops.BilinearFn.apply(xd, None, 0, 0.2, lib.F16)
+    assert_close(y.view(torch.float16).float(), yo.float(), 1e-3, "bilinear fp16 fwd")
+    go = torch.randn(yo.shape, generator=g).to(torch.bfloat16)
+    (gx,) = torch.autograd.grad([y], [xd], grad_outputs=[go.to(dev)])
+    xo = x.double().requires_grad_(True)
+    R.bilinear_up2(xo).backward(go.double())
+    assert_close(gx.float(), xo.grad.float(), 1e-2, "bilinear bwd (bf16 gradient of an fp16 tensor)")
+
+
 def test_conv_f32_out_and_padded_input(dev):
     """fp32 output with ldo == co (logits / latent head) and an input whose physical width exceeds Cin."""
     lib, ops, R = _mods()

@@ -8,6 +8,11 @@
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// IEEE half: the forward tensors of precision-critical scopes (the mask decoder) are stored and multiplied as fp16 -- 10
+// mantissa bits instead of bf16's 7 at the same MFMA rate; gradients stay bf16 (range)
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -60,6 +65,35 @@ template <> struct Chunk<bf16> {
     }
 };
 
+template <> struct Chunk<f16> {
+    static constexpr int N = 8;
+    __device__ static inline void unpack(const uint4& u, float* f) {
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            union { unsigned u; f16x2 h; } x; x.u = w[i];
+            f[2 * i] = (float)x.h[0]; f[2 * i + 1] = (float)x.h[1];
+        }
+    }
+    __device__ static inline unsigned pk(float a, float b) {
+        union { f16x2 h; unsigned u; } x;
+        x.h[0] = (f16)a; x.h[1] = (f16)b;     // RNE; overflows to inf beyond 65504
+        return x.u;
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(pk(f[0], f[1]), pk(f[2], f[3]), pk(f[4], f[5]), pk(f[6], f[7]));
+    }
+};
+// two 16-bit elements of a dword as floats, by storage type
+template <typename T> __device__ __forceinline__ void ups_unpack2(unsigned w, float& lo, float& hi);
+template <> __device__ __forceinline__ void ups_unpack2<bf16>(unsigned w, float& lo, float& hi) {
+    lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void ups_unpack2<f16>(unsigned w, float& lo, float& hi) {
+    union { unsigned u; f16x2 h; } x; x.u = w;
+    lo = (float)x.h[0]; hi = (float)x.h[1];
+}
+
 __device__ inline float ups_act(float x, int act, float slope) {
     if (act == UPS_ACT_LRELU) return x > 0.f ? x : slope * x;
     if (act == UPS_ACT_RELU) return x > 0.f ? x : 0.f;
@@ -93,6 +127,34 @@ __device__ __forceinline__ uint4 ups_act_chunk(uint4 u, float s, bf16*) {
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
+// fp16: packed half math (v_pk_mul_f16 + v_pk_max_f16 per pair); slope * x is rounded to fp16 once, as a stored
+// act(x) tensor would be
+template <bool TIGHT = false>
+__device__ __forceinline__ uint4 ups_act_chunk(uint4 u, float s, f16*) {
+    unsigned w[4] = {u.x, u.y, u.z, u.w};
+    const f16x2 sv = {(f16)s, (f16)s};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        union { unsigned u; f16x2 h; } x; x.u = w[i];
+        const f16x2 sx = x.h * sv;
+        x.h = __builtin_elementwise_max(x.h, sx);
+        w[i] = x.u;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+// fp16 tensor -> activation -> bf16 chunk (weight-gradient staging of a layer whose forward input is stored as fp16: the
+// gradient operand is bf16, and an MFMA takes one type)
+__device__ __forceinline__ uint4 ups_act_chunk_f16_to_bf16(uint4 u, float s, bool act) {
+    unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float lo, hi;
+        ups_unpack2<f16>(w[i], lo, hi);
+        if (act) { lo = ups_vmax(lo, s * lo); hi = ups_vmax(hi, s * hi); }
+        w[i] = Chunk<bf16>::pk(lo, hi);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
 template <bool TIGHT = false>
 __device__ __forceinline__ uint4 ups_act_chunk(uint4 u, float s, float*) {
     float f[4];
@@ -111,7 +173,9 @@ __device__ inline float ups_dact(float x, int act, float slope) {
 template <typename T> __device__ inline float ld_as_float(const T* p);
 template <> __device__ inline float ld_as_float<float>(const float* p) { return *p; }
 template <> __device__ inline float ld_as_float<bf16>(const bf16* p) { return (float)*p; }
+template <> __device__ inline float ld_as_float<f16>(const f16* p) { return (float)*p; }
 template <typename T> __device__ inline void st_from_float(T* p, float v);
+template <> __device__ inline void st_from_float<f16>(f16* p, float v) { *p = (f16)v; }
 template <> __device__ inline void st_from_float<float>(float* p, float v) { *p = v; }
 template <> __device__ inline void st_from_float<bf16>(bf16* p, float v) { *p = (bf16)v; }
 

@@ -85,15 +85,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 // ROWB > 0: the wave's tile rows are ROWB bytes apart in the patch image (one image per tile): fragment i is read at an
 // immediate offset i * ROWB from one per-tap lane address (no address arithmetic per read); ROWB == 0: rows from arow[].
 typedef __attribute__((ext_vector_type(2))) long i64x2;
-template <int F8> struct Frag16 { typedef i64x2 type; };
-template <> struct Frag16<0> { typedef bf16x8 type; };
+template <typename T, int F8> struct Frag16 { typedef i64x2 type; };
+template <> struct Frag16<bf16, 0> { typedef bf16x8 type; };
+template <> struct Frag16<f16, 0> { typedef f16x8 type; };
 // F8: a 16-byte fragment holds 16 e4m3 channels -- two v_mfma_f32_16x16x32_fp8_fp8 per fragment pair (low / high 8 bytes:
 // both operands use the same byte -> k mapping), a 64-byte pixel / weight row is a chunk of 64 channels.
-template <int TM16, int TN16, int ROWB, int F8>
+template <typename T, int TM16, int TN16, int ROWB, int F8>
 __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsigned char* B, const int (&arow)[TM16],
                                             int po0, int po1, int po2, int sw0, int sw1, int sw2, int b_tap_stride,
                                             f32x4v (&acc)[TM16][TN16]) {
-    typedef typename Frag16<F8>::type frag_t;
+    typedef typename Frag16<T, F8>::type frag_t;
     frag_t fa[TM16], fb[2][2];
     auto fetch_a = [&](int t) __attribute__((always_inline)) {
         const int po = t == 0 ? po0 : (t == 1 ? po1 : po2);
@@ -134,6 +135,8 @@ __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsign
                     } else if constexpr (F8 == 1) {
                         acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[step & 1][jj][0], fa[i][0], acc[i][2 * jh + jj], 0, 0, 0);
                         acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[step & 1][jj][1], fa[i][1], acc[i][2 * jh + jj], 0, 0, 0);
+                    } else if constexpr (sizeof(T) == 2 && !__is_same(T, bf16)) {      // fp16 forward tensors (mask decoder)
+                        acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[step & 1][jj], fa[i], acc[i][2 * jh + jj], 0, 0, 0);
                     } else {
                         acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[step & 1][jj], fa[i], acc[i][2 * jh + jj], 0, 0, 0);
                     }
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
             const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
             const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
-            bf16_taps16<TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
+            bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
             if (n1 < total && n1 % 3 == 0) {
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
             const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
             const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
-            bf16_taps16<TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
+            bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
 #if !defined(UPS_ABLATE_LSTORE)
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
     T* __restrict__ outT = (T*)p.out;
     float* __restrict__ outF = (float*)p.out;
-    constexpr bool EMITS = F8 != 0 || !(OCC == 2 && BN == 128);      // instances that can write an fp8 copy of their output
+    constexpr bool EMITS = __is_same(T, bf16) && (F8 != 0 || !(OCC == 2 && BN == 128));   // instances that can write an fp8 copy of their output
     unsigned char* __restrict__ of8 = p.out_f8;
     float of8_amax = 0.f;
     const float of8_s = (p.out_f8 && p.out_f8_scale) ? *p.out_f8_scale : 1.f;
@@ -758,19 +761,20 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                     uint2* slot = (uint2*)(R0 + px * ERS + cl * 2);
                     if (res) {
                         const uint2 rv = *slot;
-                        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-                        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+                        float r0, r1, r2, r3;
+                        ups_unpack2<T>(rv.x, r0, r1); ups_unpack2<T>(rv.y, r2, r3);
+                        v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (!cv[e]) v[e] = 0.f;
-                    *slot = make_uint2(Chunk<bf16>::pk(v[0], v[1]), Chunk<bf16>::pk(v[2], v[3]));
+                    *slot = make_uint2(Chunk<T>::pk(v[0], v[1]), Chunk<T>::pk(v[2], v[3]));
                 }
             }
             __syncthreads();
             if (p.mask_grad) {
                 // input gradient of the part-masked convolution, reduced to the hard mask: g_hard[b][y][x][part] =
                 // sum_c gx[c] * view[b][y][x][c] with gx rounded to the activation dtype first (as the tensor it replaces was)
-                if (SUB == TS && tid < 256) {
+                if (SUB == TS && tid < 256 && __is_same(T, bf16)) {
                     const long long pixb = (long long)img * p.h * p.w + (long long)(ty0 + (tid >> 4)) * p.w + tx0 + (tid & 15);
                     const bf16* gv = (const bf16*)(R0 + tid * ERS);
                     const float* vv = p.mask_view + pixb * p.co;
@@ -929,6 +933,7 @@ int launch_t(const PatchK& k, hipStream_t s) {
     if (k.h == 8) return launch_small<T, 8>(k, s);
     if (k.h == 4) return launch_small<T, 4>(k, s);
     if constexpr (sizeof(T) == 2) {
+      if constexpr (__is_same(T, bf16)) {
         if (k.f8_deq && k.in_f8) {      // pre-quantised input: bf16-sized staging, two blocks per CU on large grids
             const int tiles8 = k.n * (k.w / TS) * (k.h / TS);
             const bool big128 = patch_occ() == 2 && tiles8 * ups_cdiv(k.co_fill, 128) >= 512;
@@ -950,6 +955,7 @@ int launch_t(const PatchK& k, hipStream_t s) {
             if (k.co_fill > 32) return launch_bn<T, 64, 1, TS, 1>(k, s);
             return launch_bn<T, 32, 1, TS, 1>(k, s);
         }
+      }
         // two blocks per CU once the grid has at least two blocks for every CU (smaller grids spread over the chip instead);
         // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv) use 64-wide tiles and one patch buffer
         const int tiles = k.n * (k.w / TS) * (k.h / TS);
@@ -1046,6 +1052,7 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
         k.tap_off |= (unsigned long long)(((d->tap_dy[t] + 1) << 2) | (d->tap_dx[t] + 1)) << (4 * t);
         k.tap_wi |= (unsigned long long)d->tap_w[t] << (4 * t);
     }
-    const int rc = (d->dtype == UPS_F32) ? launch_t<float>(k, s) : launch_t<bf16>(k, s);
+    if (d->dtype == UPS_F16 && (d->f8_deq || d->in_f8 || d->out_f8 || d->out_f8_amax || d->mask_bits || d->mask_grad || d->d2s)) return 1;
+    const int rc = (d->dtype == UPS_F32) ? launch_t<float>(k, s) : (d->dtype == UPS_F16 ? launch_t<f16>(k, s) : launch_t<bf16>(k, s));
     return rc == UPS_OK ? 0 : rc;
 }

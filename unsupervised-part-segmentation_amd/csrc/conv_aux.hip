@@ -255,6 +255,9 @@ extern "C" int ups_weight_prep(const float* src, int32_t ntaps, int32_t cin_v, i
     if (dtype == UPS_F32)
         hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(grid), dim3(256), 0, s, src, ntaps, cin_v, ci_log, co,
                            (float*)w_fwd, ci_pad, (float*)w_dgrad, dgrad_rows, dgrad_k);
+    else if (dtype == UPS_F16)
+        hipLaunchKernelGGL(weight_prep_kernel<f16>, dim3(grid), dim3(256), 0, s, src, ntaps, cin_v, ci_log, co,
+                           (f16*)w_fwd, ci_pad, (f16*)w_dgrad, dgrad_rows, dgrad_k);
     else
         hipLaunchKernelGGL(weight_prep_kernel<bf16>, dim3(grid), dim3(256), 0, s, src, ntaps, cin_v, ci_log, co,
                            (bf16*)w_fwd, ci_pad, (bf16*)w_dgrad, dgrad_rows, dgrad_k);
@@ -358,6 +361,9 @@ extern "C" int ups_weight_prep_batch(const ups_prep_item* items, const int64_t* 
     UPS_CHECK_ARG(items && block_prefix && n_items >= 1 && total_blocks >= 1 && total_blocks < 0x7fffffffLL);
     if (dtype == UPS_F32)
         hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                           items, (const long long*)block_prefix, n_items);
+    else if (dtype == UPS_F16)
+        hipLaunchKernelGGL(weight_prep_batch_kernel<f16>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                            items, (const long long*)block_prefix, n_items);
     else
         hipLaunchKernelGGL(weight_prep_batch_kernel<bf16>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,

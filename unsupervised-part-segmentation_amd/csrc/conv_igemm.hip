@@ -45,6 +45,28 @@ template <> struct Mma<bf16> {
     }
 };
 
+template <> struct Mma<f16> {
+    // as bf16 on v_mfma_f32_32x32x16_f16 (same rate, 10 mantissa bits)
+    template <int TM, int TN>
+    __device__ static inline void chunk(const unsigned char* a_base, const unsigned char* b_base, int lane,
+                                        f32x16 (&acc)[TM][TN]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const f16x8*)(a_base + (i * 32 + r) * RS + ks * 32 + h * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *(const f16x8*)(b_base + (j * 32 + r) * RS + ks * 32 + h * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
 template <> struct Mma<float> {
     // one 64-byte K-chunk = 16 floats; lane half h owns k in [8h, 8h+8): 8 x (32x32x2) steps
     template <int TM, int TN>
@@ -436,8 +458,12 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_p
 
 extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d != nullptr);
-    UPS_CHECK_ARG(d->dtype == UPS_F32 || d->dtype == UPS_BF16);
+    UPS_CHECK_ARG(d->dtype == UPS_F32 || d->dtype == UPS_BF16 || d->dtype == UPS_F16);
     UPS_CHECK_ARG(d->in && d->w && (d->out || d->mask_grad));
+    if (d->dtype == UPS_F16 && (d->d2s || d->f8_deq || d->mask_bits || d->mask_grad || d->in_f8 || d->out_f8 || d->out_f8_amax)) {
+        ups_set_error("ups_conv_igemm: UPS_F16 is a forward format: no fp8 copies, part masks or depth-to-space output");
+        return UPS_E_UNSUPPORTED;
+    }
     UPS_CHECK_ARG(d->ci > 0 && d->ci % 8 == 0 && d->ldi % 8 == 0 && d->ci <= d->ldi);
     UPS_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= 9);
     UPS_CHECK_ARG(d->act_slope >= 0.f && d->act_slope <= 1.f);    // activation-on-load is max(x, slope * x)
@@ -465,7 +491,12 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
         ups_set_error("ups_conv_igemm: the part-masked forms need the bf16 3x3 / stride-1 patch kernel (16-aligned images, P <= 32)");
         return UPS_E_UNSUPPORTED;
     }
-    int rc = (d->dtype == UPS_F32) ? launch<float>(*d, (hipStream_t)stream) : launch<bf16>(*d, (hipStream_t)stream);
+    if (d->out_f8 || d->out_f8_amax || d->in_f8) {   // (the generic kernel never writes / reads fp8 copies)
+        ups_set_error("ups_conv_igemm: fp8 copies (in_f8 / out_f8 / out_f8_amax) need the bf16 3x3 / stride-1 patch kernel");
+        return UPS_E_UNSUPPORTED;
+    }
+    int rc = (d->dtype == UPS_F32) ? launch<float>(*d, (hipStream_t)stream)
+             : (d->dtype == UPS_F16 ? launch<f16>(*d, (hipStream_t)stream) : launch<bf16>(*d, (hipStream_t)stream));
     if (rc != UPS_OK) { ups_set_error("ups_conv_igemm: bad problem size"); return rc; }
     UPS_LAUNCH_CHECK();
     return UPS_OK;

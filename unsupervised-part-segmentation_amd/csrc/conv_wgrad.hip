@@ -16,7 +16,7 @@
 namespace {
 
 struct WgK {
-    int n, hi, wi, ci, ldi, ci_log, cin_v, ho, wo, co, ldo, in_sy, in_sx, ntaps, act_in, want_bias;
+    int n, hi, wi, ci, ldi, ci_log, cin_v, ho, wo, co, ldo, in_sy, in_sx, ntaps, act_in, want_bias, in_f16;
     float act_slope;
     unsigned long long tap_off, tap_wi;
     const void* in; const void* dout; float* ws;
@@ -129,6 +129,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int 
         return v;
     };
     auto act_u4 = [&](uint4 u) -> uint4 {
+        if constexpr (__is_same(T, bf16)) {
+            if (p.in_f16) return ups_act_chunk_f16_to_bf16(u, act_ns, p.act_in != UPS_ACT_NONE);
+        }
         if (p.act_in != UPS_ACT_NONE) {
             u = ups_act_chunk(u, act_ns, (T*)nullptr);
         }
@@ -360,6 +363,8 @@ extern "C" int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream) {
     k.n = d->n; k.hi = d->hi; k.wi = d->wi; k.ci = d->ci; k.ldi = d->ldi; k.ci_log = d->ci_log; k.cin_v = d->cin_v;
     k.ho = d->ho; k.wo = d->wo; k.co = d->co; k.ldo = d->ldo; k.in_sy = d->in_sy; k.in_sx = d->in_sx;
     k.ntaps = d->ntaps; k.act_in = d->act_in; k.act_slope = d->act_slope; k.want_bias = d->grad_bias != nullptr;
+    k.in_f16 = d->in_f16;
+    UPS_CHECK_ARG(!d->in_f16 || (d->dtype == UPS_BF16 && !d->mask_bits));
     k.in = d->in; k.dout = d->dout; k.ws = d->workspace;
     k.tap_off = 0; k.tap_wi = 0;
     int max_tw = 0;

@@ -28,6 +28,7 @@ struct Wg3K {
     unsigned long long tap_off, tap_wi;
     const void* in; const void* dout; float* ws;
     const unsigned* mask; int mask_B;     // part-masked input (ups_wgrad_desc.mask_*): in = view [mask_B,h,w,ldi], image = p*mask_B + b
+    int in_f16;                           // `in` is an fp16 tensor (ups_wgrad_desc.in_f16): converted to bf16 while it is staged
 };
 
 __device__ inline int g_dy(unsigned long long off, int t) { return (int)((off >> (4 * t + 2)) & 3) - 1; }
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
             unsigned f = xs[k];
             asm volatile("" : "+v"(f));
             uint4 v = rx[k];
-            if (p.act_in != UPS_ACT_NONE) v = ups_act_chunk(v, act_ns, (bf16*)nullptr);
+            if (p.in_f16) v = ups_act_chunk_f16_to_bf16(v, act_ns, p.act_in != UPS_ACT_NONE);
+            else if (p.act_in != UPS_ACT_NONE) v = ups_act_chunk(v, act_ns, (bf16*)nullptr);
             if (k + 1 < NX || tid + 512 * k < PPIX * CPX) *(uint4*)(X + (f & 0xffffu)) = v;
             __builtin_amdgcn_sched_barrier(0);        // one item at a time (register pressure)
         }
@@ -348,6 +350,7 @@ int ups_wgrad3x3_run(const ups_wgrad_desc* d, hipStream_t s) {
     k.units_per = ups_cdiv(k.units_total, d->splitk);
     k.in = d->in; k.dout = d->dout; k.ws = d->workspace;
     k.mask = d->mask_bits; k.mask_B = d->mask_batch;
+    k.in_f16 = d->in_f16;
     k.tap_off = 0; k.tap_wi = 0;
     for (int t = 0; t < 9; ++t) {
         k.tap_off |= (unsigned long long)(((d->tap_dy[t] + 1) << 2) | (d->tap_dx[t] + 1)) << (4 * t);

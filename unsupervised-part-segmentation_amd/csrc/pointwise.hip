@@ -350,6 +350,7 @@ inline int grid_for(long long work, int cap = 16384) {
     do {                                                                                                  \
         if ((dtype) == UPS_F32) hipLaunchKernelGGL(KERNEL<float>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
         else if ((dtype) == UPS_BF16) hipLaunchKernelGGL(KERNEL<bf16>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else if ((dtype) == UPS_F16) hipLaunchKernelGGL(KERNEL<f16>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
         else { ups_set_error("bad dtype %d", (int)(dtype)); return UPS_E_ARG; }                           \
         UPS_LAUNCH_CHECK();                                                                               \
     } while (0)
@@ -359,6 +360,7 @@ extern "C" int ups_bilinear2x_fwd(const void* x, void* y, int32_t dtype, int32_t
     const long long work = (long long)n * h * w * (c / (dtype == UPS_F32 ? 4 : 8));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == UPS_F32) hipLaunchKernelGGL(bilinear2x_fwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)x, (float*)y, n, h, w, c);
+    else if (dtype == UPS_F16) hipLaunchKernelGGL(bilinear2x_fwd_kernel<f16>, dim3(grid_for(work)), dim3(256), 0, s, (const f16*)x, (f16*)y, n, h, w, c);
     else hipLaunchKernelGGL(bilinear2x_fwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w, c);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
@@ -498,6 +500,8 @@ extern "C" int ups_convert(const void* src, int32_t sd, void* dst, int32_t dd, i
     if (sd == UPS_F32 && dd == UPS_BF16) hipLaunchKernelGGL((convert_kernel<float, bf16>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16*)dst, (long long)count);
     else if (sd == UPS_BF16 && dd == UPS_F32) hipLaunchKernelGGL((convert_kernel<bf16, float>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (float*)dst, (long long)count);
     else if (sd == UPS_F32 && dd == UPS_F32) hipLaunchKernelGGL((convert_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, (long long)count);
+    else if (sd == UPS_F32 && dd == UPS_F16) hipLaunchKernelGGL((convert_kernel<float, f16>), dim3(grid), dim3(256), 0, s, (const float*)src, (f16*)dst, (long long)count);
+    else if (sd == UPS_F16 && dd == UPS_F32) hipLaunchKernelGGL((convert_kernel<f16, float>), dim3(grid), dim3(256), 0, s, (const f16*)src, (float*)dst, (long long)count);
     else if (sd == UPS_BF16 && dd == UPS_BF16) hipLaunchKernelGGL((convert_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, (long long)count);
     else { ups_set_error("ups_convert: bad dtypes"); return UPS_E_ARG; }
     UPS_LAUNCH_CHECK();
@@ -510,6 +514,7 @@ extern "C" int ups_pad_convert(const float* src, int32_t c, void* dst, int32_t d
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for((long long)rows * ldd);
     if (dtype == UPS_F32) hipLaunchKernelGGL(pad_convert_kernel<float>, dim3(grid), dim3(256), 0, s, src, c, (float*)dst, ldd, (long long)rows);
+    else if (dtype == UPS_F16) hipLaunchKernelGGL(pad_convert_kernel<f16>, dim3(grid), dim3(256), 0, s, src, c, (f16*)dst, ldd, (long long)rows);
     else hipLaunchKernelGGL(pad_convert_kernel<bf16>, dim3(grid), dim3(256), 0, s, src, c, (bf16*)dst, ldd, (long long)rows);
     UPS_LAUNCH_CHECK();
     return UPS_OK;

@@ -79,13 +79,20 @@ class TrainModel(object):
             out.update(getattr(self, "_tps", {}))        # model.py:272-279
         return out
 
-    def to_act(self, x_f32):
-        """fp32 [n,H,W,c] -> activation dtype, 8-padded channels."""
+    def to_act(self, x_f32, fmt=None):
+        """fp32 [n,H,W,c] -> activation dtype, 8-padded channels (fmt = L.F16: fp16 in a bf16 container, ops.py)."""
         x_f32 = x_f32.contiguous()
         out = torch.empty(x_f32.shape[:-1] + (ops.round8(x_f32.shape[-1]),), dtype=self.act_dtype, device=x_f32.device)
         rows = x_f32.numel() // x_f32.shape[-1]
-        L.call("ups_pad_convert", L.ptr(x_f32), x_f32.shape[-1], L.ptr(out), L.dt(out), out.shape[-1], rows, L.stream())
+        L.call("ups_pad_convert", L.ptr(x_f32), x_f32.shape[-1], L.ptr(out), L.dt(out) if fmt is None else fmt, out.shape[-1], rows,
+               L.stream())
         return out
+
+    def latent_act(self, z_f32):
+        """A latent sample [n,Z] as the mask decoder's input handle (in the decoder's tensor format)."""
+        n, Z = z_f32.shape
+        fmt = self.nets.scope_fmt.get("decoder_visualize")
+        return Act(self.to_act(z_f32.view(n, 1, 1, Z), fmt), n, 1, 1, Z, fmt=fmt)
 
     def part_images(self, view_act, view_f32, hard, hard_bits):
         """The P*B part images view1[b] * hard1[b,:,:,p] in part-major order (mask_parts + apply_partwise, model.py:176-187,
@@ -114,7 +121,7 @@ class TrainModel(object):
             s0, _ = ops.latent_fwd(pe[:B].contiguous(), noise["eps_pi0"][:1].to(self.device), [1.0], False)
             s1, _ = ops.latent_fwd(pe[B:].contiguous(), noise["eps_pi1"][None].to(self.device), [1.0], False)
             z = torch.cat([s0[0], s1[0]], 0)
-        lm = self.nets.dv(Act(self.to_act(z.view(2 * B, 1, 1, Z)), 2 * B, 1, 1, Z)).t
+        lm = self.nets.dv(self.latent_act(z)).t
         eps = None if noise is None else torch.cat([noise["eps_l0"], noise["eps_l1"]], 0).to(self.device)
         _, m, hard, _, bits = ops.part_softmax(lm, eps, want_bits=P <= 32)
         _, soft, _, amax = ops.part_softmax(lm[:B].contiguous(), None, want_hard=False, want_argmax=True)
@@ -534,8 +541,9 @@ class Trainer(object):
         loss_est, _, acc_est, _ = crit["mi_estimator"]
 
         # ================= B: mask decoder (model.py:411-412)
-        z_leaf = model.to_act(torch.cat([samples0[0], samples1[0]], 0).view(2 * B, 1, 1, Z)).requires_grad_(True)
-        l_mean = nets.dv(Act(z_leaf, 2 * B, 1, 1, Z)).t                   # fp32 [2B,S,S,P], taped
+        z_act = model.latent_act(torch.cat([samples0[0], samples1[0]], 0))
+        z_leaf = z_act.t.requires_grad_(True)
+        l_mean = nets.dv(z_act).t                                         # fp32 [2B,S,S,P], taped
         lm = l_mean.detach()
 
         # ================= part path, untaped (model.py:414-473)

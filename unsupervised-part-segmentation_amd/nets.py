@@ -93,9 +93,11 @@ class ParamBank(object):
 
 class Act(object):
     """Activation handle: tensor (None in the shape-only dry run) + logical channel count."""
-    __slots__ = ("t", "n", "h", "w", "c", "mask", "f8")
+    __slots__ = ("t", "n", "h", "w", "c", "mask", "f8", "fmt")
 
-    def __init__(self, t, n, h, w, c, mask=None, f8=None):
+    def __init__(self, t, n, h, w, c, mask=None, f8=None, fmt=None):
+        # fmt = L.F16: `t` holds fp16 in a bf16 container (ops.py module docstring); None: what t.dtype says
+        self.fmt = fmt
         # mask = (hard, hard_bits, view_f32): `t` is the unmasked view [B,h,w,8] and the handle stands for the n = P*B
         # part images view[b] * hard[b,:,:,p] that the first convolution forms while it loads (ops.conv)
         # f8 = the fp8 copy of act(t) its producer wrote (ops.Fp8: {"t", "act", "slot"}) or None
@@ -105,10 +107,11 @@ class Act(object):
 class Scope(object):
     """One nn.model_arg_scope: fresh counter per template call, variables shared by name."""
 
-    def __init__(self, owner, prefix, activation, coords):
+    def __init__(self, owner, prefix, activation, coords, fmt=None):
         self.owner, self.prefix, self.coords = owner, prefix, coords
         self.act = L.ACT[activation]
         self.counter = 0
+        self.fmt = fmt               # L.F16: every tensor of this scope's forward pass is fp16 (the mask decoder)
 
     def _layer(self, cin, cout, k, stride, act_in):
         name = "{}/conv2d_{}".format(self.prefix, self.counter)
@@ -126,6 +129,7 @@ class Scope(object):
             lay = ConvLayer(name, own.bank.params[name + "/V"], own.bank.params[name + "/b"], k, stride, self.coords, act_in)
             lay.grad_V, lay.grad_b = own.bank.grads[name + "/V"], own.bank.grads[name + "/b"]
             lay.registry = own.prep
+            lay.f16 = self.fmt == L.F16
             own.layers[key] = lay
         return lay
 
@@ -133,13 +137,14 @@ class Scope(object):
         lay = self._layer(x.c, cout, k, stride, act_in)
         ho, wo = ops.same_geometry(x.h, k, stride)[0], ops.same_geometry(x.w, k, stride)[0]
         if lay is None:
-            return Act(None, x.n, ho, wo, cout)
+            return Act(None, x.n, ho, wo, cout, fmt=None if out_f32 else self.fmt)
         if ops.Fp8.enabled:     # hand the input's fp8 copy in, ask for one of the output (consumed with this scope's activation)
             ops.Fp8.next_in, ops.Fp8.next_out_act, ops.Fp8.last_out = x.f8, self.act, None
-        t = ops.conv(x.t, lay, res=None if res is None else res.t, res_self=res_self, out_f32=out_f32, mask=x.mask)
+        assert x.fmt == self.fmt and (res is None or res.fmt == self.fmt), "tensor format does not match the scope's"
+        t = ops.conv(x.t, lay, res=None if res is None else res.t, res_self=res_self, out_f32=out_f32, mask=x.mask, fmt=self.fmt)
         f8 = ops.Fp8.last_out if ops.Fp8.enabled else None
         ops.Fp8.last_out = None
-        return Act(t, x.n, ho, wo, cout, f8=f8)
+        return Act(t, x.n, ho, wo, cout, f8=f8, fmt=None if out_f32 else self.fmt)
 
     def nin(self, x, cout, **kw):
         return self.conv2d(x, cout, k=1, **kw)
@@ -153,17 +158,17 @@ class Scope(object):
             return self.conv2d(x, x.c, k=k, act_in=self.act, res_self=True)
         s = self.nin(skipin, x.c, act_in=self.act)
         if x.t is None:
-            cat = Act(None, x.n, x.h, x.w, 2 * x.c)
+            cat = Act(None, x.n, x.h, x.w, 2 * x.c, fmt=self.fmt)
         else:
             assert x.c % 8 == 0
-            cat = Act(torch.cat([x.t, s.t], dim=-1), x.n, x.h, x.w, 2 * x.c)
+            cat = Act(torch.cat([x.t, s.t], dim=-1), x.n, x.h, x.w, 2 * x.c, fmt=self.fmt)
         return self.conv2d(cat, x.c, act_in=self.act, res=x)
 
     def upsample_linear(self, x):
         if x.t is None:
-            return Act(None, x.n, 2 * x.h, 2 * x.w, x.c)
-        if not ops.Fp8.enabled:
-            return Act(ops.BilinearFn.apply(x.t), x.n, 2 * x.h, 2 * x.w, x.c)
+            return Act(None, x.n, 2 * x.h, 2 * x.w, x.c, fmt=self.fmt)
+        if not ops.Fp8.enabled or self.fmt == L.F16:
+            return Act(ops.BilinearFn.apply(x.t, None, 0, 0.2, self.fmt), x.n, 2 * x.h, 2 * x.w, x.c, fmt=self.fmt)
         # fp8: the up-sampled tensor feeds this scope's next convolution -- hand it an e4m3 copy of act(y) (and, backwards, the
         # convolution below an e5m2 copy of the gradient); per-call-site scale slots live with the model
         sites = self.owner.__dict__.setdefault("f8_sites", {})
@@ -174,6 +179,7 @@ class Scope(object):
         return Act(t, x.n, 2 * x.h, 2 * x.w, x.c, f8=f8)
 
     def act_mean(self, x):
+        assert self.fmt is None, "act_mean has no fp16 form"
         if x.t is None:
             return Act(None, x.n, 1, 1, x.c)
         return Act(ops.ActMeanFn.apply(x.t, self.act, 0.2), x.n, 1, 1, x.c)
@@ -203,9 +209,9 @@ def single_decoder_model(sc, z, n_out, config, upsample_config, out_f32=True):
     h = sc.nin(z, 4 * 4 * c)
     if h.t is not None:
         assert h.t.shape[-1] == 16 * c
-        h = Act(h.t.view(h.n, 4, 4, c), h.n, 4, 4, c)
+        h = Act(h.t.view(h.n, 4, 4, c), h.n, 4, 4, c, fmt=h.fmt)
     else:
-        h = Act(None, h.n, 4, 4, c)
+        h = Act(None, h.n, 4, 4, c, fmt=h.fmt)
     h = sc.conv2d(h, c)
     h = sc.residual_block(h)
     for _nf, _u in zip(config[-2::-1], upsample_config[-1::-1]):
@@ -254,11 +260,20 @@ class Nets(object):
         self.config = config
         self.dry, self.specs, self.layers, self.bank = True, OrderedDict(), {}, None
         self.prep = ops.PrepRegistry()
+        # `mask_decoder_dtype: fp16` (default with precision bf16): decoder_visualize's FORWARD tensors and forward weights are
+        # fp16 -- its logits decide the part masks, and bf16's 2^-9 per operand / per store leaves 0.7 % logit error after
+        # its ~15 layers (mask IoU 0.93-0.97 on confident masks; fp16: 0.09 %, IoU >= 0.998; tests/bf16_emulation_study.py).
+        # Gradients, the encoders, the image decoder and the perceptual trunk stay bf16.
+        prec = str(config.get("precision", "bf16")).lower()
+        md = str(config.get("mask_decoder_dtype", "fp16" if prec in ("bf16", "bfloat16") else "same")).lower()
+        if md in ("fp16", "f16", "half") and prec not in ("bf16", "bfloat16"):
+            raise ValueError("mask_decoder_dtype: fp16 needs precision: bf16")
+        self.scope_fmt = {"decoder_visualize": L.F16} if md in ("fp16", "f16", "half") else {}
         S = config["spatial_size"]
         Z, A, P = config.get("z0_size", 256), config.get("local_app_size", 64), config["n_parts"]
         img = Act(None, 1, S, S, 3)
         self.e_pi(img); self.e_alpha(img)
-        self.dv(Act(None, 1, 1, 1, Z))
+        self.dv(Act(None, 1, 1, 1, Z, fmt=self.scope_fmt.get("decoder_visualize")))
         self.dd(Act(None, 1, S, S, A + P))
         for name in ("mi0_discriminator", "mi1_discriminator", "mi_estimator"):
             self.critic(name, (Act(None, 1, 1, 1, Z), Act(None, 1, 1, 1, A)))
@@ -270,7 +285,7 @@ class Nets(object):
         self.bank = ParamBank(self.specs, device, seed, keys=submodules(config))
 
     def _scope(self, name, kw):
-        return Scope(self, name, kw.get("activation", "relu"), kw.get("coords", False))
+        return Scope(self, name, kw.get("activation", "relu"), kw.get("coords", False), fmt=self.scope_fmt.get(name))
 
     def e_pi(self, x):
         kw = self.config["encoder0"]
@@ -368,7 +383,7 @@ class VggTrunk(object):
             if bi > 0:
                 h = ops.MaxPoolFn.apply(h)     # max-pool commutes with ReLU: pool the pre-activations
             for ci, lay in enumerate(blk):
-                h = ops.ConvFn.apply(h, lay.V, lay.b, None, lay, 0, False, None)
+                h = ops.ConvFn.apply(h, lay.V, lay.b, None, lay, 0, False, None, None, None, None, None)
                 if ci == 1:
                     feats.append((h, lay.co, L.ACT_RELU))
         return feats

@@ -5,6 +5,11 @@ upsample 834-847), SURVEY.md Appendix A.
 
 Activations are NHWC tensors whose last dimension is the PHYSICAL channel count (multiple of 8);
 weights stay fp32 in the TF variable layout HWIO and are re-laid-out / converted once per optimizer step.
+
+fp16 forward tensors (``fmt = L.F16``, the mask decoder: 10 mantissa bits instead of bf16's 7 at the same MFMA rate -- what
+north_star's part-mask IoU >= 0.99 needs, tests/bf16_emulation_study.py) live in torch.bfloat16 CONTAINERS: the autograd engine casts
+every returned gradient to the dtype of the forward tensor, and the gradients of these layers are bf16 (range).  The format
+travels beside the tensor (nets.Act.fmt, ConvFn's ``fmt`` argument); nothing but the HIP kernels reads those bits.
 """
 import ctypes as C
 import os
@@ -129,8 +134,10 @@ class PrepRegistry(object):
             prefix = [0]
             for i, (lay, ent, _, hi, wi) in enumerate(ents):
                 it = arr[i]
-                it.src, it.w_fwd, it.w_dgrad = lay.V.data_ptr(), ent["w_fwd"].data_ptr(), ent["w_dgrad"].data_ptr()
-                it.ctab = ent["ctab"].data_ptr() if lay.coords else None
+                it.src = lay.V.data_ptr()
+                it.w_fwd = ent["w_fwd"].data_ptr() if ent["w_fwd"] is not None else None
+                it.w_dgrad = ent["w_dgrad"].data_ptr() if ent["w_dgrad"] is not None else None
+                it.ctab = ent["ctab"].data_ptr() if ent["ctab"] is not None else None
                 it.ntaps, it.cin_v, it.ci_log, it.co = lay.k * lay.k, lay.cin_v, lay.ci_log, lay.co
                 it.ci_pad, it.dgrad_rows, it.dgrad_k = round8(lay.ci_log), lay.ci_log, round8(lay.co)
                 it.kh = it.kw = lay.k
@@ -297,6 +304,7 @@ class ConvLayer(object):
         self.frozen = False         # frozen weights (perceptual trunk): converted copies survive optimizer steps
         self.after_wgrad = None     # optional callback run right after this layer's weight gradient has been enqueued
         self.registry = None        # PrepRegistry of the owning model (batched refresh) or None (lazy per-layer prep)
+        self.f16 = False            # forward tensors of this layer are fp16 (nets.Scope.fmt)
         self._cache = {}
 
     # ---- converted weights (refreshed when the optimizer has stepped)
@@ -309,17 +317,20 @@ class ConvLayer(object):
         ci_pad = round8(self.ci_log)
         bk = 16 if dtype_code == L.F32 else 32          # blocked-K layout [tap][k-chunk][row][64 B]
         if ent is None:                                 # persistent buffers (pointers stay valid for the batched refresh)
+            # a layer with fp16 forward tensors: forward weights as fp16, input-gradient weights as bf16 (one copy each)
+            want_f = not (self.f16 and dtype_code == L.BF16)
+            want_d = dtype_code != L.F16
             ent = {"version": -1,
-                   "w_fwd": torch.empty((ntaps, -(-ci_pad // bk), self.co, bk), dtype=td, device=dev),
-                   "w_dgrad": torch.empty((ntaps, -(-round8(self.co) // bk), self.ci_log, bk), dtype=td, device=dev),
-                   "ctab": torch.empty((64, 3, self.co), dtype=torch.float32, device=dev) if self.coords else None}
+                   "w_fwd": torch.empty((ntaps, -(-ci_pad // bk), self.co, bk), dtype=td, device=dev) if want_f else None,
+                   "w_dgrad": torch.empty((ntaps, -(-round8(self.co) // bk), self.ci_log, bk), dtype=td, device=dev) if want_d else None,
+                   "ctab": torch.empty((64, 3, self.co), dtype=torch.float32, device=dev) if (self.coords and want_f) else None}
             self._cache[key] = ent
             if self.registry is not None and not self.frozen:
                 self.registry.register(self, ent, dtype_code, hi, wi)
         if ent["version"] != WeightVersion.value and not (self.frozen and ent["version"] >= 0):
             L.call("ups_weight_prep", L.ptr(self.V), ntaps, self.cin_v, self.ci_log, self.co, dtype_code,
                    L.ptr(ent["w_fwd"]), ci_pad, L.ptr(ent["w_dgrad"]), self.ci_log, round8(self.co), L.stream())
-            if self.coords:
+            if ent["ctab"] is not None:
                 dy, dx, _ = self.fwd_taps(hi, wi)
                 ax, ay = 2.0 / max(1, hi - 1), 2.0 / max(1, wi - 1)     # nn.py:2145-2148 (xx / (H-1), yy / (W-1))
                 L.call("ups_coord_table", L.ptr(self.V), self.k, self.k, self.ci_log, self.co,
@@ -433,14 +444,16 @@ def _attach_ws(d, device):
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
 
 
-def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask=None):
+def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask=None, fmt=None):
     """out = conv(act(x) (+coords), V) + b (+ res);  x [n,hi,wi,ldi].
+    fmt = L.F16: x, res and (unless out_f32) out hold fp16 in bf16 containers (module docstring).
     mask = (hard_bits [B,hi,wi] int32, P): x is the UNMASKED view [B,hi,wi,ldi] and the convolution runs on the P*B part images
     x[b] * hard[b,:,:,p] (part-major) without materialising them (model.py:176-187, nn.py:81-113)."""
     n, hi, wi, ldi = x.shape
     if mask is not None:
         n = n * mask[1]
-    dcode = L.dt(x)
+    dcode = L.dt(x) if fmt is None else fmt
+    assert dcode != L.F16 or (x.dtype == torch.bfloat16 and mask is None and layer.f16)
     ho, wo = layer.out_hw(hi, wi)
     ent = layer.prepared(dcode, hi, wi, need_dgrad=False)
     ldo = ldo if ldo is not None else (layer.co if out_f32 else round8(layer.co))
@@ -466,7 +479,7 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
     d.dact = None
     if mask is not None:
         d.mask_bits, d.mask_batch = mask[0].data_ptr(), x.shape[0]
-    elif Fp8.eligible(layer, x) and (not Fp8.copy_only() or Fp8.usable(Fp8.next_in, layer, x, ldi)):
+    elif dcode != L.F16 and Fp8.eligible(layer, x) and (not Fp8.copy_only() or Fp8.usable(Fp8.next_in, layer, x, ldi)):
         src, want_act = Fp8.next_in, Fp8.next_out_act
         if Fp8.usable(src, layer, x, ldi):
             f8 = layer.prepared_f8(None)               # the producer quantised act(x) with its tensor's scale
@@ -641,8 +654,9 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
     return gx if mask_view is None else g_hard
 
 
-def conv_wgrad(g, x, layer, mask=None):
-    """(dV [kh,kw,cin_v,co] fp32, db [co] fp32).  mask = (hard_bits, P): x is the unmasked view of a part-masked convolution."""
+def conv_wgrad(g, x, layer, mask=None, fmt=None):
+    """(dV [kh,kw,cin_v,co] fp32, db [co] fp32).  mask = (hard_bits, P): x is the unmasked view of a part-masked convolution.
+    fmt = L.F16: x holds fp16 (converted to bf16, the gradient's type, while it is staged)."""
     n, hi, wi, ldi = x.shape
     if mask is not None:
         n = n * mask[1]
@@ -664,6 +678,7 @@ def conv_wgrad(g, x, layer, mask=None):
     d.in_, d.dout, d.grad, d.grad_bias = x.data_ptr(), g.data_ptr(), gV.data_ptr(), gb.data_ptr()
     if mask is not None:
         d.mask_bits, d.mask_batch = mask[0].data_ptr(), x.shape[0]
+    d.in_f16 = int(fmt == L.F16)
     L.call("ups_conv_wgrad_plan", C.byref(d), C.byref(sk), C.byref(wsb))
     ws = WORKSPACE.get(wsb.value, dev)
     d.splitk, d.workspace = sk.value, ws.data_ptr()
@@ -710,15 +725,15 @@ class ConvFn(torch.autograd.Function):
     """res_mode 0: plain; 1: out = res + conv(x); 2: out = x + conv(act(x)) (residual_block, nn.py:1042-1056)."""
 
     @staticmethod
-    def forward(ctx, x, V, b, res, layer, res_mode, out_f32, ldo, hard=None, hard_bits=None, view_f32=None):
+    def forward(ctx, x, V, b, res, layer, res_mode, out_f32, ldo, hard=None, hard_bits=None, view_f32=None, fmt=None):
         """hard / hard_bits / view_f32 given: the part-masked convolution (x = the unmasked view in the activation dtype,
         the P*B part images are formed in the kernel's load); the gradient w.r.t. `hard` comes out of the dgrad epilogue."""
         x = x.contiguous()
         r = x if res_mode == 2 else (res.contiguous() if res_mode == 1 else None)
         ctx.mask = None if hard is None else (hard_bits, hard.shape[-1])
-        out = conv_forward(x, layer, res=r, out_f32=out_f32, ldo=ldo, mask=ctx.mask)
+        out = conv_forward(x, layer, res=r, out_f32=out_f32, ldo=ldo, mask=ctx.mask, fmt=fmt)
         ctx.save_for_backward(x, view_f32)
-        ctx.layer, ctx.res_mode = layer, res_mode
+        ctx.layer, ctx.res_mode, ctx.fmt = layer, res_mode, fmt
         return out
 
     @staticmethod
@@ -737,10 +752,10 @@ class ConvFn(torch.autograd.Function):
                 side = Streams.get("wgrad", x.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask)
+                    gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask, fmt=ctx.fmt)
                 Streams.keep(x.device, g, x)      # alive until the launching stream has joined the side stream
             else:
-                gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask)
+                gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask, fmt=ctx.fmt)
             if layer.after_wgrad is not None:
                 layer.after_wgrad()
         if ctx.mask is not None:
@@ -752,16 +767,16 @@ class ConvFn(torch.autograd.Function):
             # the autograd engine may accumulate other branches into the returned tensor IN PLACE; the side stream
             # is still reading g, so hand out a copy in that case
             gres = g.clone() if offloaded else g
-        return gx, gV, gb, gres, None, None, None, None, g_hard, None, None
+        return gx, gV, gb, gres, None, None, None, None, g_hard, None, None, None
 
 
-def conv(x, layer, res=None, res_self=False, out_f32=False, ldo=None, mask=None):
+def conv(x, layer, res=None, res_self=False, out_f32=False, ldo=None, mask=None, fmt=None):
     """mask = (hard [B,H,W,P] fp32 autograd leaf, hard_bits [B,H,W] int32, view_f32 [B,H,W,3]): part-masked convolution."""
     mode = 2 if res_self else (1 if res is not None else 0)
     if mask is None:
-        return ConvFn.apply(x, layer.V, layer.b, res, layer, mode, out_f32, ldo)
+        return ConvFn.apply(x, layer.V, layer.b, res, layer, mode, out_f32, ldo, None, None, None, fmt)
     assert mode == 0
-    return ConvFn.apply(x, layer.V, layer.b, None, layer, 0, out_f32, ldo, mask[0], mask[1], mask[2].contiguous())
+    return ConvFn.apply(x, layer.V, layer.b, None, layer, 0, out_f32, ldo, mask[0], mask[1], mask[2].contiguous(), None)
 
 
 def masked_conv_eligible(dtype, size, n_parts):
@@ -774,11 +789,11 @@ class BilinearFn(torch.autograd.Function):
     writes the e4m3 copy of act(y), its backward the e5m2 copy of the gradient it returns (ops.Fp8 hand-off)."""
 
     @staticmethod
-    def forward(ctx, x, site=None, act=0, slope=0.2):
+    def forward(ctx, x, site=None, act=0, slope=0.2, fmt=None):
         x = x.contiguous()
         n, h, w, c = x.shape
         y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
-        f8 = site is not None and Fp8.enabled and Fp8.PRODUCER and x.dtype == torch.bfloat16 and c % 64 == 0 and (2 * h) % 16 == 0
+        f8 = fmt != L.F16 and site is not None and Fp8.enabled and Fp8.PRODUCER and x.dtype == torch.bfloat16 and c % 64 == 0 and (2 * h) % 16 == 0
         ctx.site = site if f8 else None
         if f8 and "fwd" not in site:
             site["fwd"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
@@ -792,7 +807,7 @@ class BilinearFn(torch.autograd.Function):
                    L.ptr(Fp8.scale[so["slot"]:]), L.ptr(Fp8.amax[so["slot"]]), act, slope, 0, L.stream())
             Fp8.last_out = {"t": t8, "act": act, "slot": so["slot"], "site": so} if t8 is not None else None
         else:
-            L.call("ups_bilinear2x_fwd", L.ptr(x), L.ptr(y), L.dt(x), n, h, w, c, L.stream())
+            L.call("ups_bilinear2x_fwd", L.ptr(x), L.ptr(y), L.dt(x) if fmt is None else fmt, n, h, w, c, L.stream())
         ctx.shape = (n, h, w, c)
         return y
 
@@ -820,7 +835,7 @@ class BilinearFn(torch.autograd.Function):
                 Fp8.register_grad_copy(gx, {"t": t8, "slot": so["slot"], "site": so})
         else:
             L.call("ups_bilinear2x_bwd", L.ptr(g), L.ptr(gx), L.dt(g), n, h, w, c, L.stream())
-        return gx, None, None, None
+        return gx, None, None, None, None
 
 
 class ActMeanFn(torch.autograd.Function):
