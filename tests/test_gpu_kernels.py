@@ -704,7 +704,7 @@ def test_conv_fp8_copy_handed_from_producer_to_consumer(case, dev):
         copy = F.last_out
         assert copy is not None and copy["act"] == lib.ACT_LRELU and copy["t"].shape == y.shape
         # (y differs from y0 in the last bits: the input's own scale moved from the primed to the recorded maximum)
-        assert_close(y.float(), y0.float(), 5e-2, "second call")
+        assert rel_err(y.float(), y0.float()) <= 5e-2, "second call"     # (two fp8 quantisations of the same tensor: a sanity bound)
         scale = float(F.scale[copy["slot"]].cpu())
         yf = y.float()
         ya = torch.maximum(yf, 0.2 * yf)

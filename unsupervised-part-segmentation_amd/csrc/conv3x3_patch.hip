@@ -34,6 +34,8 @@ __device__ __forceinline__ int a_swz(int px) { return (px >> 2) & 3; }
 __device__ __forceinline__ int a_swz16(int px) { return ((px >> 2) & 1) << 1; }
 template <typename T> __device__ __forceinline__ int a_swz_t(int px) { return sizeof(T) == 2 ? a_swz16(px) : a_swz(px); }
 
+template <int V> struct IC { static constexpr int value = V; };
+
 struct PatchK {
     int n, h, w, ci, ldi, co, co_fill, ldo, ldr, ldd, act_in, out_f32, dact_kind, has_ctab;
     float act_slope;
@@ -58,6 +60,7 @@ struct PatchK {
     // depth-to-space output (ups_conv_desc.d2s): GEMM channel ch = (py*2 + px) * (1 << d2s_shift) + c is channel c of output
     // pixel (2y + py, 2x + px) of a [n, 2h, 2w, ld] tensor (res / dact live on that lattice too)
     int d2s, d2s_shift;
+    int taps_static;      // 1: forward order, 2: flipped (input-gradient) order, 0: neither (launcher)
 };
 
 __device__ __forceinline__ int fast_div(int n, int d, unsigned m) {
@@ -181,7 +184,15 @@ template <> struct PMma<float> {
 // SUB = 16: a tile is a 16x16 window of one image (halo from the neighbouring pixels).  SUB = 8 / 4: the images themselves
 // are 8x8 / 4x4 (encoder bottoms, first decoder levels, VGG block 5) and a tile packs G x G = 4 / 16 whole images, each
 // with its own all-zero halo (the patch grid is G*(SUB+2) wide; halo slots are zeroed once and never written).
-template <typename T, int BN, int OCC, int SUB, int F8 = 0, bool PRE = false>
+// TAPS = 1 / 2: the nine taps are in the forward's r-major order (dy = t/3 - 1, dx = t%3 - 1, weight slice t) / in the input
+// gradient's flipped order (dy = 1 - t/3, dx = 1 - t%3, weight slice t), known at compile time: the tap-row loop of the
+// two-blocks-per-CU variant is then unrolled over (tap-row, ring stage) with every LDS offset an immediate and no tap decode
+// on the scalar unit (the generic loop spent ~200 SALU + 18 VALU per 48 MFMAs on it).  TAPS = 0: taps from the descriptor.
+// DMAP: the input needs nothing done to it on the way (act_in none, no part mask, bf16 / fp16, whole 32-channel chunks): the
+// halo patch then arrives by LDS-DMA like the weights -- 23 wave-instructions of 1 KiB per chunk, the swizzle applied on the
+// source side, patch pixels outside the image masked off in EXEC (their slots were zeroed once and are never written) -- with
+// no staging registers, no VALU and no ds_write.  Every input-gradient launch qualifies (its input is the gradient tensor).
+template <typename T, int BN, int OCC, int SUB, int F8 = 0, bool PRE = false, int TAPS = 0, bool DMAP = false>
 __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const PatchK p, const int tiles_x, const int tiles_y,
                                                                  const int ntn, const int kchunks, const int nblocks) {
     constexpr int EPC = Chunk<T>::N;
@@ -264,6 +275,23 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         };
         pa0 = mk(tid, sa0); pa1 = mk(tid + 512, sa1);
         for (int i = tid * 16; i < 2 * ABY; i += 512 * 16) *(uint4*)(Abuf + i) = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+    }
+    // DMAP: piece j = wid + 8 q fills LDS bytes [j * 1024, +1024) of the patch image = pixel slots 16 j .. 16 j + 15
+    unsigned pd_off[3] = {0u, 0u, 0u};
+    unsigned long long pd_mask[3] = {0ull, 0ull, 0ull};
+    if constexpr (DMAP) {
+        static_assert(SUB == TS && OCC == 2 && F8 == 0 && sizeof(T) == 2, "DMA patch: one tile per image, two blocks per CU, 16-bit tensors");
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int pp = (wid + 8 * q) * 16 + (lane >> 2), sl = lane & 3;
+            const int py = pp / PWPS, px = pp - py * PWPS;
+            const int y = ty0 - 1 + py, x = tx0 - 1 + px;
+            const bool ok = py < PW && px < PW && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
+            pd_off[q] = (unsigned)(py * p.w + px) * ((unsigned)p.ldi * 2u) + (unsigned)((sl ^ a_swz16(px)) << 4);
+            pd_mask[q] = __ballot(ok);
+        }
+        for (int i = tid * 16; i < ABY; i += 512 * 16) *(uint4*)(Abuf + i) = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
     }
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
@@ -484,7 +512,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             for (int q = 0; q < NW; ++q) {
                 const int j = (wid + 8 * q) % NJ;
                 // uniform slab base (scalar) + per-lane 32-bit offset
-                const T* slab = w + ((long long)p_w(p.tap_wi, 3 * g + d_tl[q]) * kchunks + cc) * p.co * BK;
+                const int wslice = TAPS != 0 ? 3 * g + d_tl[q] : p_w(p.tap_wi, 3 * g + d_tl[q]);
+                const T* slab = w + ((long long)wslice * kchunks + cc) * p.co * BK;
 #if !defined(UPS_ABLATE_DMA)
                 // issued as inline asm: hipcc's wait-count pass treats the builtin as a FLAT access that may touch LDS
                 // and from then on waits lgkmcnt(0) before every fragment use (no counted waits); hidden from the pass,
@@ -496,8 +525,27 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #endif
             }
         };
-        load_patch(0);
-        store_patch(Abuf);
+        const unsigned char* __restrict__ in_b = (const unsigned char*)(in + (long long)origin * p.ldi);
+        auto dma_patch = [&](int cc) __attribute__((always_inline)) {
+            if constexpr (DMAP) {
+                const unsigned char* base = in_b + cc * 64;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (wid + 8 * q >= (PW * PWPS + 15) / 16) continue;        // piece 23 of 22.5 (wave-uniform)
+                    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((wid + 8 * q) * 1024));
+#if !defined(UPS_ABLATE_GLOAD)
+                    asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
+                                 :: "s"(pd_mask[q]), "s"(lds_dst), "v"(pd_off[q]), "s"(base) : "memory", "m0");
+#endif
+                }
+            }
+        };
+        // lane part of the A fragment address for the three column shifts (static taps: loop invariant)
+        const int swx0 = a_lane16 + ((q16 ^ a_swz16(px_l16 + 0)) << 4);
+        const int swx1 = a_lane16 + ((q16 ^ a_swz16(px_l16 + 1)) << 4);
+        const int swx2 = a_lane16 + ((q16 ^ a_swz16(px_l16 + 2)) << 4);
+        if constexpr (DMAP) dma_patch(0);
+        else { load_patch(0); store_patch(Abuf); }
         dma_w(0);
         if (OCC != 2 && total > 1) dma_w(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -509,11 +557,19 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const int cc = it / 3, g = it - cc * 3;
             const int n1 = it + 1;
             if (n1 < total) {
-                if (n1 % 3 == 0) load_patch(n1 / 3);
+                if constexpr (!DMAP) { if (n1 % 3 == 0) load_patch(n1 / 3); }
                 dma_w(n1);
             }
             const unsigned char* A = Abuf;
             const unsigned char* B = Bst + (it % NST) * BST + (wn * TN * 32) * 64 + boff16;
+            if constexpr (TAPS != 0) {
+                // static tap geometry: tap-row g reads patch rows g .. (forward) / 2-g .. (flipped), its three taps the column
+                // shifts 0, 1, 2 / 2, 1, 0: two scalar operations instead of the tap decode, loop-invariant lane terms
+                const int po0 = ((TAPS == 1 ? g : 2 - g) * PWPS + (TAPS == 1 ? 0 : 2)) * APX;
+                bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po0 + (TAPS == 1 ? APX : -APX),
+                                        po0 + (TAPS == 1 ? 2 * APX : -2 * APX), TAPS == 1 ? swx0 : swx2, swx1, TAPS == 1 ? swx2 : swx0,
+                                        BN * 64, acc16);
+            } else {
             const int dx0 = p_dx(p.tap_off, 3 * g) + 1, dx1 = p_dx(p.tap_off, 3 * g + 1) + 1, dx2 = p_dx(p.tap_off, 3 * g + 2) + 1;
             const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
             const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
@@ -521,12 +577,16 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
+            }
             if (n1 < total && n1 % 3 == 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                 // every wave has read the last tap of this chunk's patch
+                if constexpr (DMAP) dma_patch(n1 / 3);
+                else {
 #if !defined(UPS_ABLATE_LSTORE)
                 store_patch(Abuf);
 #endif
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -883,7 +943,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
 }
 
-template <typename T, int BN, int OCC, int SUB, int F8 = 0, bool PRE = false>
+template <typename T, int BN, int OCC, int SUB, int F8 = 0, bool PRE = false, int TAPS = 0, bool DMAP = false>
 int launch_bn(const PatchK& k, hipStream_t s) {
     constexpr int EPC = Chunk<T>::N;
     constexpr int G = TS / SUB, PR = G * (SUB + 2), PWPS = (PR + 3) / 4 * 4;
@@ -903,14 +963,26 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     if (epi > shmem) shmem = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE, TAPS, DMAP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(epi > shmem_max ? epi : shmem_max));
         if (e != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE>), dim3(nblocks), dim3(512), shmem, s, kk, tiles_x, tiles_y, ntn,
+    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE, TAPS, DMAP>), dim3(nblocks), dim3(512), shmem, s, kk, tiles_x, tiles_y, ntn,
                        kchunks, nblocks);
     return UPS_OK;
+}
+
+static int static_taps_on() {   // UPS_PATCH_STATIC=0: the descriptor-driven tap loop everywhere (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UPS_PATCH_STATIC"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+
+static int dma_patch_on() {   // UPS_PATCH_DMA=0: register-staged patch everywhere (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UPS_PATCH_DMA"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
 }
 
 static int patch_occ() {   // UPS_PATCH_OCC=1 forces the one-block-per-CU configuration (A/B runs)
@@ -960,7 +1032,15 @@ int launch_t(const PatchK& k, hipStream_t s) {
         // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv) use 64-wide tiles and one patch buffer
         const int tiles = k.n * (k.w / TS) * (k.h / TS);
         if (k.co_fill > 64 && k.ci > 32) {
-            if (patch_occ() == 2 && !k.out_f8_amax && tiles * ups_cdiv(k.co_fill, 128) >= 512) return launch_bn<T, 128, 2, TS>(k, s);
+            if (patch_occ() == 2 && !k.out_f8_amax && tiles * ups_cdiv(k.co_fill, 128) >= 512) {
+                const bool dmap = dma_patch_on() && k.act_in == UPS_ACT_NONE && !k.mask && !k.mask_grad && k.ci % 32 == 0;
+                if (k.taps_static == 1 && static_taps_on())
+                    return dmap ? launch_bn<T, 128, 2, TS, 0, false, 1, true>(k, s) : launch_bn<T, 128, 2, TS, 0, false, 1>(k, s);
+                // (flipped order without the DMA patch -- ragged channel counts -- keeps the descriptor-driven loop: its static
+                // form spills)
+                if (k.taps_static == 2 && static_taps_on() && dmap) return launch_bn<T, 128, 2, TS, 0, false, 2, true>(k, s);
+                return launch_bn<T, 128, 2, TS>(k, s);
+            }
             // a grid of one 128-wide block per CU: 64-wide tiles put two blocks on every CU instead (4 waves per SIMD)
             static int mid = -1;
             if (mid < 0) { const char* e = getenv("UPS_PATCH_MID"); mid = (e && e[0] == '0') ? 0 : 1; }
@@ -1053,6 +1133,15 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
         k.tap_wi |= (unsigned long long)d->tap_w[t] << (4 * t);
     }
     if (d->dtype == UPS_F16 && (d->f8_deq || d->in_f8 || d->out_f8 || d->out_f8_amax || d->mask_bits || d->mask_grad || d->d2s)) return 1;
+    {
+        bool fwd = true, flip = true;
+        for (int t = 0; t < 9; ++t) {
+            if (d->tap_w[t] != t) fwd = flip = false;
+            if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1) fwd = false;
+            if (d->tap_dy[t] != 1 - t / 3 || d->tap_dx[t] != 1 - t % 3) flip = false;
+        }
+        k.taps_static = fwd ? 1 : (flip ? 2 : 0);
+    }
     const int rc = (d->dtype == UPS_F32) ? launch_t<float>(k, s) : (d->dtype == UPS_F16 ? launch_t<f16>(k, s) : launch_t<bf16>(k, s));
     return rc == UPS_OK ? 0 : rc;
 }
