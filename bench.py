@@ -10,9 +10,11 @@ N > 1 works both ways the driver may start it:
   * ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``: WORLD_SIZE is already in the
     environment, the process is one rank.
 
-Workload (BASELINE.json configs[1]): CUB yaml, 128x128, n_parts 10, batch 64 per GPU, bf16 activations /
-weights with fp32 accumulation and fp32 master weights, use_tps False, synthetic U(-1,1) views resident in
-HBM before the timed region, noise drawn on device inside the step.  Prints ONE JSON line on rank 0.
+Workload (BASELINE.json configs[1], the default): CUB yaml, 128x128, n_parts 10, batch 64 per GPU, bf16 activations /
+weights (the mask decoder's forward tensors fp16) with fp32 accumulation and fp32 master weights, use_tps False,
+synthetic U(-1,1) views resident in HBM before the timed region, noise drawn on device inside the step.
+``--config deepfashion256p16 | pennaction128 | cub256p20`` runs BASELINE configs #3 / #4 / #5 the same way (their own
+model variant, size, per-GPU batch, algorithmic FLOPs per image and roofline layer).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -24,10 +26,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAIN_GFLOP_PER_IMAGE = 268.9      # BASELINE.md section 3, 128^2, P=10 (F_alg)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (guide)
 PEAK_F32_TFLOPS = 157.3
-PMC_FILE = os.path.join(ROOT, "profiles", "round2_pmc_dv_rb128.json")     # written by tools/profile_round.sh from this tree
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("round3_pmc_dv_rb128.json", "round2_pmc_dv_rb128.json")]   # tools/profile_round.sh
 CPU_THREAD_CAP = 32                # torch-CPU stops scaling on this graph well before the GPU box's core count (see cpu_baseline)
 
 
@@ -36,9 +37,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
-    ap.add_argument("--parts", type=int, default=10)
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--config", default="cub128p10", help="cub128p10 (BASELINE config #2, the headline) | deepfashion256p16 (#3) | "
+                    "pennaction128 (#4) | cub256p20 (#5)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the config's)")
+    ap.add_argument("--parts", type=int, default=0, help="only for cub128p10 (0 = 10)")
+    ap.add_argument("--precision", default="", help="bf16 | fp8 | fp32 (empty = the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="BASELINE config #1: batch 8")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(os.cpu_count(), {})".format(CPU_THREAD_CAP))
@@ -48,18 +51,19 @@ def parse_args():
     return ap.parse_args()
 
 
-def free_port():
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
 def launch_ranks(args):
-    """Launcher side of ``python bench.py --gpus N``: no HIP call is ever made in this process."""
-    port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
+    """Launcher side of ``python bench.py --gpus N``: no HIP call is ever made in this process.  The ranks are fresh child
+    processes; they are supervised: the first one to exit non-zero takes the others down (a rank that died on an import
+    error or a bad device would otherwise leave its siblings in init_process_group / a collective until the RCCL timeout)."""
+    import socket
+    import threading
+    sock = None
+    port = int(os.environ.get("MASTER_PORT", "0"))
+    if not port:       # keep the probe socket open (SO_REUSEADDR) until the ranks have been started: nobody else takes the port
+        sock = socket.socket()
+        sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ)
@@ -67,17 +71,43 @@ def launch_ranks(args):
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         out = subprocess.PIPE if r == 0 else sys.stderr     # rank 0 prints the JSON line; whatever else the ranks print goes to stderr
         procs.append(subprocess.Popen([sys.executable, args.rank_entry] + sys.argv[1:], env=env, stdout=out))
-    line = None
-    for raw in procs[0].stdout:
-        text = raw.decode(errors="replace")
-        if text.lstrip().startswith('{"metric"'):
-            line = text.strip()
-        else:
-            sys.stderr.write(text)
-    codes = [p.wait() for p in procs]
+    if sock is not None:
+        sock.close()
+    found = {"line": None}
+
+    def drain():
+        for raw in procs[0].stdout:
+            text = raw.decode(errors="replace")
+            if text.lstrip().startswith('{"metric"'):
+                found["line"] = text.strip()
+            else:
+                sys.stderr.write(text)
+    th = threading.Thread(target=drain, daemon=True)
+    th.start()
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, pr in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = pr.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, pr in enumerate(procs):           # exact children only (never by pattern)
+                if codes[i] is None:
+                    pr.terminate()
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = pr.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[i] = pr.wait()
+            break
+        time.sleep(0.2)
+    th.join(timeout=5)
+    line = found["line"]
     if any(codes) or line is None:
         sys.stderr.write("bench.py: rank exit codes {} (JSON line {})\n".format(codes, "missing" if line is None else "present"))
-        sys.exit(next((c for c in codes if c), 1))
+        # the code of the rank that failed by itself, not the signal of a sibling this launcher terminated
+        sys.exit(next((c for c in codes if c and c > 0), next((c for c in codes if c), 1)) & 0xff or 1)
     print(line)
     sys.stdout.flush()
 
@@ -129,15 +159,26 @@ def run_rank(args):
     from upsparts_amd import configs, ops
     from upsparts_amd.model import TrainModel, Trainer
 
-    cfg = configs.cub_config(n_parts=args.parts, batch_size=args.batch)
+    if args.config not in configs.BENCH_CONFIGS:
+        raise SystemExit("bench.py: unknown --config {} (one of {})".format(args.config, sorted(configs.BENCH_CONFIGS)))
+    build, S, P, B0, prec0, gflop_img, note = configs.BENCH_CONFIGS[args.config]
+    args.batch = args.batch or B0
+    args.precision = args.precision or prec0
+    if args.config == "cub128p10" and args.parts:
+        P = args.parts
+        cfg = configs.cub_config(n_parts=P, batch_size=args.batch)
+    else:
+        cfg = build(args.batch)
+    args.parts = P
     cfg["precision"] = args.precision
     model = TrainModel(cfg, device=dev, seed=0)
     trainer = Trainer(cfg, None, model, world_size=world, rank=rank)
     g = torch.Generator().manual_seed(1234 + rank)
-    batch = {k: (torch.rand(args.batch, 128, 128, 3, generator=g) * 2 - 1).to(dev)
-             for k in ("view0", "view1", "view0_target")}
+    batch = {k: (torch.rand(args.batch, S, S, 3, generator=g) * 2 - 1).to(dev) for k in model.inputs}
 
-    ops.KernelTimer.layer = "decoder_visualize/conv2d_8"       # the 258->256 3x3 conv at 128x128 (37% of forward FLOPs)
+    # roofline layer: the 258 -> 256 3x3 convolution of the mask decoder at full resolution (its last residual block:
+    # conv2d_0 nin, conv2d_1, conv2d_2, one block per level, then this one) -- 37 % of the forward FLOPs at 128x128
+    ops.KernelTimer.layer = "decoder_visualize/conv2d_{}".format(2 + len(cfg["dv"]["config"]))
     for _ in range(args.warmup):
         trainer.train_step(batch)
     if world > 1:
@@ -165,27 +206,38 @@ def run_rank(args):
         peak = PEAK_BF16_TFLOPS if low else PEAK_F32_TFLOPS
         dname = {"bf16": "bf16", "fp8": "fp8"}.get(args.precision, "f32")
         traffic = None
-        try:   # HBM bytes per launch of the roofline kernel from the PMC passes committed for this tree (profiles/), not live
-            with open(PMC_FILE) as f:
-                traffic = json.load(f)["traffic_bytes_per_launch"] * (args.batch / 64.0) if args.precision == "bf16" else None
-        except Exception:
-            traffic = None
+        pmc_used = None
+        # HBM bytes per launch of the roofline kernel from the PMC passes committed for this tree (profiles/), not live; they were
+        # taken on the headline shape (2 x 64 images of 128x128, 256 channels, bf16): reported for exactly that launch only
+        if args.config == "cub128p10" and args.precision == "bf16" and args.batch == 64:
+            for pf in PMC_FILES:
+                try:
+                    with open(pf) as f:
+                        traffic = json.load(f)["traffic_bytes_per_launch"]
+                    pmc_used = os.path.relpath(pf, ROOT)
+                    break
+                except Exception:
+                    traffic = None
         kms = ops.KernelTimer.mean_ms()
         ach = ops.KernelTimer.flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
-        out = {"metric": "images/sec training (CUB 128x128, 10 parts)", "value": round(value, 2), "unit": "images/sec",
+        metric = "images/sec training (CUB 128x128, 10 parts)" if args.config == "cub128p10" and P == 10 else \
+            "images/sec training ({} {}x{}, {} parts)".format(args.config, S, S, P)
+        out = {"metric": metric, "value": round(value, 2), "unit": "images/sec",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": dname, "data": "synthetic",
-               "config": {"workload": "CUB yaml 128x128 n_parts={} batch {}/GPU, full train step (7 per-key losses, "
+               "config": {"workload": "{}: {} yaml {}x{} n_parts={} batch {}/GPU, full train step (per-key losses, "
                                       "per-key grads, TF-Adam), use_tps False, VGG19-topology perceptual trunk with "
-                                      "stand-in weights at native 128x128; bf16 storage / fp32 accumulate (parity bar of this "
-                                      "dtype: part-mask IoU >= 0.99 and losses within 5% of the fp64 oracle; the 1e-3 bar is "
-                                      "met by precision=fp32){}".format(args.parts, args.batch, "; --precision fp8: e4m3 / e5m2 MFMA "
-                                      "operands for the wide 3x3 convolutions whose operand arrives as an fp8 copy (BASELINE config #5 "
-                                      "arithmetic on config #2's workload)" if args.precision == "fp8" else ""),
+                                      "stand-in weights at native resolution; bf16 storage / fp32 accumulate, the mask decoder's "
+                                      "forward tensors fp16 (parity bar of this dtype: part-mask IoU >= 0.99 and losses within 5% "
+                                      "of the fp64 oracle; the 1e-3 bar is met by precision=fp32){}".format(
+                                          note, args.config, S, S, P, args.batch, "; precision fp8: e4m3 / e5m2 MFMA "
+                                      "operands for the wide 3x3 convolutions whose operand arrives as an fp8 copy, bf16 tensors "
+                                      "everywhere" if args.precision == "fp8" else ""),
+                          "name": args.config,
                           "global_batch": args.batch * world, "parallelism": "dp{}".format(world),
                           "rccl_world_size": rccl_world},
-               "model_tflops_per_gpu": round(value * TRAIN_GFLOP_PER_IMAGE / 1e3 / world, 2),
+               "model_tflops_per_gpu": round(value * gflop_img / 1e3 / world, 2), "train_gflop_per_image": gflop_img,
                "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel<{},128,2,16> @ {} (1 forward + 2 input-gradient "
                                                         "launches per step, all timed)".format(
                                 dname, ops.KernelTimer.layer),
@@ -194,11 +246,13 @@ def run_rank(args):
                             "kernel_ms_dgrad": round(ops.KernelTimer.mean_ms("dgrad"), 4),
                             "launches_timed": len(ops.KernelTimer.events), "traffic": traffic,
                             "traffic_note": "HBM bytes of the forward launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                            "(profiles/round2_pmc_dv_rb128.json); tensor-once algorithmic bytes 2.15e9",
+                                            "({}); tensor-once algorithmic bytes 2.15e9".format(pmc_used) if traffic else
+                                            "no PMC pass committed for this launch shape",
                             "flop_per_launch": ops.KernelTimer.flops}}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, CPU_THREAD_CAP)
-            out["cpu_baseline"] = cpu_baseline(args.parts, args.cpu_batch, threads, args.cpu_budget)
+            if args.config == "cub128p10":      # the CPU leg is BASELINE config #1 (the CUB yaml at batch 8)
+                out["cpu_baseline"] = cpu_baseline(args.parts, args.cpu_batch, threads, args.cpu_budget)
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

@@ -170,7 +170,7 @@ def test_inference_outputs(dev):
 
 def test_runner_end_to_end_with_csv_dataset_and_checkpoint(dev, tmp_path):
     """`python -m upsparts_amd.runner -t <yaml>` (the `edflow -t` work-alike): reference import paths in the yaml, the csv pair
-    dataset, LoggingHook lines at steps 0,1,2,4, a checkpoint every ckpt_freq steps and a lazy restore from it."""
+    dataset, LoggingHook lines at steps 0, 2, 4 (the reference's cadence and alphabetical key order), a checkpoint every ckpt_freq steps and a lazy restore from it."""
     import numpy as np
     import yaml
     from PIL import Image
@@ -195,9 +195,14 @@ def test_runner_end_to_end_with_csv_dataset_and_checkpoint(dev, tmp_path):
     it = runner.main(["-t", str(ypath), "-p", str(root), "--strict-dataset"])
     assert it.global_step == 5
     log = (root / "train" / "log.txt").read_text()
-    for s in (0, 1, 2, 4):
+    for s in (0, 2, 4):
         assert "[INFO] [LoggingHook]: global_step: {}\n".format(s) in log
-    assert "[INFO] [LoggingHook]: global_step: 3\n" not in log and "loss_decoder_visualize" in log
+    for s in (1, 3):                # cub/train/log.txt:221,279,337: 0, 2, 4, 8, ...
+        assert "[INFO] [LoggingHook]: global_step: {}\n".format(s) not in log
+    assert "loss_decoder_visualize" in log
+    first = [ln.split("]: ")[1].split(":")[0] for ln in log.splitlines() if "[LoggingHook]" in ln][:12]
+    assert first[0] == "adversarial_constraint" and first == sorted(first), first      # log.txt:204-215 (alphabetical)
+    assert "[INFO] [LoggingHook]: project root: " in log
     ck = root / "train" / "checkpoints" / "model.ckpt-4"
     assert ck.exists() and (root / "train" / "checkpoints" / "model.ckpt-2").exists()
     assert (root / "train" / "checkpoints" / "model.ckpt-5").exists()          # final state at loop exit

@@ -232,6 +232,8 @@ import torch
 import torch.distributed as dist
 world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
 assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+if os.environ.get("UPS_TEST_DIE_EARLY") == "1" and rank == 1:
+    sys.exit(9)           # dies before the rendezvous: rank 0 would sit in init_process_group until its timeout
 dist.init_process_group("gloo", init_method="env://", world_size=world, rank=rank)
 t = torch.tensor([float(rank + 1)])
 dist.all_reduce(t)
@@ -263,6 +265,11 @@ def test_bench_launcher_spawns_n_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["sum"] == 3.0 and "--steps" in out["argv"]
     bad = subprocess.run(cmd + ["--fail"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert bad.returncode != 0 and not bad.stdout.decode().strip()
+    # a rank that dies before the rendezvous: the launcher takes its siblings down and reports, instead of hanging with them
+    import time
+    t0 = time.time()
+    dead = subprocess.run(cmd, env=dict(env, UPS_TEST_DIE_EARLY="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert dead.returncode == 9 and not dead.stdout.decode().strip() and time.time() - t0 < 120, dead.stderr.decode()[-500:]
 
 
 def test_read_vgg_weights_key_spellings(tmp_path):

@@ -83,3 +83,27 @@ def deepfashion_config(n_parts=16, batch_size=8, spatial_size=128):
     c["dv"] = {"config": dvc, "upsample_config": ["linear"] * levels, "activation": "leaky_relu", "coords": True}
     c["d_single"] = copy.deepcopy(c["dv"])
     return c
+
+
+def cub256_config(n_parts=20, batch_size=8):
+    """BASELINE config #5's model: the CUB yaml at 256x256 -- the mask decoder needs one more level to reach 256 from its 4x4
+    code (only the LENGTH of `dv.config` matters: linear up-sampling ignores the widths, nn.py:834-847) and the rectangle
+    patch scales with the image."""
+    c = cub_config(n_parts, batch_size, 256)
+    c["dv"] = dict(c["dv"], config=[16] + list(c["dv"]["config"]), upsample_config=["linear"] * 6)
+    c["patch_size"] = 64
+    return c
+
+
+# The BASELINE.json configurations as bench.py runs them: name -> (config builder, image size, parts, per-GPU batch, precision,
+# algorithmic training GFLOP per image (BASELINE.md section 3), note).  Config #2 is the headline.
+BENCH_CONFIGS = {
+    "cub128p10": (lambda b: cub_config(10, b), 128, 10, 64, "bf16", 268.9, "BASELINE config #2 (headline)"),
+    "deepfashion256p16": (lambda b: deepfashion_config(16, b, 256), 256, 16, 32, "bf16", 1202.6,
+                          "BASELINE config #3: DeepFashion SB_model48c yaml at 256x256, 16 parts, global batch 256 = 32 per GPU on 8 GPUs"),
+    "pennaction128": (lambda b: pennaction_config(10, b, 128), 128, 10, 32, "bf16", 271.2,
+                      "BASELINE config #4: PennAction yaml (encoder1.coords), 128x128, global batch 128 = 32 per GPU on 4 GPUs; the "
+                      "'equivariance-via-flow loss' is not a reference feature (SURVEY 0.5): timed without it"),
+    "cub256p20": (lambda b: cub256_config(20, b), 256, 20, 16, "fp8", 1287.8,
+                  "BASELINE config #5: CUB yaml at 256x256, 20 parts, fp8 MFMA conv path; BASELINE names no batch: 16 per GPU"),
+}

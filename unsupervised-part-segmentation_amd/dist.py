@@ -50,6 +50,13 @@ def average_scalars(stats, world_size, group=None):
     return stats
 
 
+def sum_flag(flag, world_size, group=None):
+    """flag: 1-element tensor -> sum over ranks (in place): a collective "did any rank fail" decision on log steps."""
+    if world_size > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
+    return flag
+
+
 def shard_seed(base_seed, rank):
     """Rank-offset seeds for data / noise (weights use the SAME seed on every rank)."""
     return int(base_seed) + 7919 * int(rank)

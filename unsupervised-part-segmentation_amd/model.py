@@ -51,9 +51,8 @@ class TrainModel(object):
         self.act_dtype = torch.float32 if prec in ("fp32", "f32", "float32") else torch.bfloat16
         # precision: fp8 (BASELINE config #5) = bf16 tensors, forward and input gradient of the wide 3x3 / stride-1 convolutions
         # with e4m3 / e5m2 MFMA operands and fp32 accumulation (ops.Fp8); weight gradients stay on the bf16 kernels
+        ops.Fp8.reset()                                     # the fp8 state (scale slots, hand-off) is per model
         ops.Fp8.enabled = prec in ("fp8", "f8", "e4m3")
-        for k in ops.Fp8.stats:
-            ops.Fp8.stats[k] = 0
         self.patch_size = config.get("patch_size", 32)
         self.df = N.is_48c(config)          # DeepFashion SB_model48c variant (two inputs, no rectangles, extra decoders)
         self.nets = N.Nets(config, self.device, seed if seed is not None else config.get("seed", 0))
@@ -823,31 +822,51 @@ class Trainer(object):
         return out
 
     def iterate(self, batch_iterator, num_steps=None, log_fn=print):
+        """edflow's session loop with its hooks.  LoggingHook cadence as cub/train/log.txt:221-860 shows it (an IntervalHook whose
+        interval doubles after every trigger up to ``log_freq``): global steps 0, 2, 4, 8, ..., 128, then every ``log_freq``
+        (250, 500, ...); the keys are printed in alphabetical order with ``global_step`` among them (log.txt:204-263), followed
+        by the ``project root`` line."""
         cfg = self.config
         num_steps = num_steps if num_steps is not None else cfg.get("num_steps", 1000000)
         log_freq, ckpt_freq = cfg.get("log_freq", 250), cfg.get("ckpt_freq", 10000)
+        interval = 1
         for batch in batch_iterator:
             if self.global_step >= num_steps:
                 break
             s = self.global_step
             self.train_step(batch)
-            if s % log_freq == 0 or (s & (s - 1)) == 0:      # edflow LoggingHook: steps 0,1,2,4,8,... and every log_freq
-                log_fn("[INFO] [LoggingHook]: global_step: {}".format(s))
+            if s % interval == 0:
+                interval = min(2 * interval, max(1, log_freq))
                 logs = self.fetch_logs()
-                for k, v in logs.items():
-                    log_fn("[INFO] [LoggingHook]: {}: {}".format(k, v))
+                logs["global_step"] = s
+                for k in sorted(logs):
+                    log_fn("[INFO] [LoggingHook]: {}: {}".format(k, logs[k]))
+                if self.root:
+                    log_fn("[INFO] [LoggingHook]: project root: {}".format(os.path.join(self.root, "train")))
+                # failure detection on log steps only (the step itself never synchronises with the host).  Losses are per rank:
+                # the decision is made collective, so that every rank of a data-parallel run leaves together instead of the
+                # healthy ones waiting in the next all-reduce until the RCCL timeout
                 bad = [k for k, v in logs.items() if k.startswith("loss_") and not math.isfinite(v)]
-                if bad:       # failure detection on log steps only (the step itself never synchronises with the host)
-                    raise FloatingPointError("non-finite {} at global step {}".format(", ".join(bad), s))
+                flag = torch.tensor([1.0 if bad else 0.0], dtype=torch.float32, device=self.device)
+                D.sum_flag(flag, self.world_size, self.process_group)
+                if float(flag) > 0:
+                    raise FloatingPointError("non-finite {} at global step {} (on {} rank(s))".format(
+                        ", ".join(bad) if bad else "loss on another rank", s, int(float(flag))))
             # edflow CheckpointHook: the file is named after the global step the restored run continues FROM
             if ckpt_freq and self.global_step % ckpt_freq == 0:
                 self._checkpoint()
         self._checkpoint()                # final state at loop exit
 
     def _checkpoint(self):
+        """model.ckpt-<step> of THIS process's current state: written to a temporary name and renamed, so a file of that name
+        left by an earlier (or diverged) run in the same project root is replaced, never kept."""
         if not self.root or self.rank != 0:
             return
         path = os.path.join(self.root, "train", "checkpoints", "model.ckpt-{}".format(self.global_step))
-        if not os.path.exists(path):
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            self.save_checkpoint(path)
+        if getattr(self, "_last_ckpt", None) == (path, self.global_step):
+            return                        # this very state was just written (loop exit right after a periodic checkpoint)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = path + ".tmp-{}".format(os.getpid())
+        self.save_checkpoint(tmp)
+        os.replace(tmp, path)
+        self._last_ckpt = (path, self.global_step)

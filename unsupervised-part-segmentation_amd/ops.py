@@ -212,6 +212,7 @@ class Fp8(object):
     def after_step(cls):
         """After the optimizer step: new activation scales, e4m3 copies of the updated weights (one launch per layer)."""
         cls.update()
+        cls.grad_side.clear()          # copies nobody read this step are released (they pinned a gradient-sized tensor each)
         for lay in cls.layers:
             for key, tr in (("f8", 0), ("f8g", 1)):
                 ent = lay._cache.get(key)
@@ -265,15 +266,30 @@ class Fp8(object):
         import weakref
         if len(cls.grad_side) > 256:
             cls.grad_side.clear()
-        cls.grad_side[t.data_ptr()] = (weakref.ref(t), tuple(t.shape), copy)
+        # t._version: the autograd engine's InputBuffer accumulates other branches INTO a buffered gradient in place when it
+        # holds the last reference (a weakref does not count as one) -- the same object then arrives holding g1 + g2 while the
+        # copy still holds quantised g1; every in-place add bumps the version counter
+        cls.grad_side[t.data_ptr()] = (weakref.ref(t), tuple(t.shape), copy, t._version)
 
     @classmethod
     def grad_copy(cls, g):
-        """The e5m2 copy of exactly this tensor object (the autograd engine hands a single-use gradient on unchanged), or None."""
+        """The e5m2 copy of exactly this tensor object, unmodified since the copy was written, or None."""
         ent = cls.grad_side.pop(g.data_ptr(), None)
-        if ent is None or ent[0]() is not g or ent[1] != tuple(g.shape):
+        if ent is None or ent[0]() is not g or ent[1] != tuple(g.shape) or ent[3] != g._version:
             return None
         return ent[2]
+
+    @classmethod
+    def reset(cls):
+        """Scale slots, layer list and hand-off state belong to ONE model: a process that builds several (tests, an evaluation
+        sweep) starts each from a clean slate instead of running into MAX_LAYERS or inheriting another model's precision."""
+        cls.amax = cls.scale = cls.fmax = None
+        cls.count, cls.layers, cls.steps = 0, [], 0
+        cls.grad_side.clear()
+        cls.next_in = cls.next_out_act = cls.last_out = None
+        cls.COPY_ONLY = None
+        for k in cls.stats:
+            cls.stats[k] = 0
 
     @staticmethod
     def eligible_grad(layer, g, x):

@@ -5,7 +5,7 @@ reference: requirements.txt:33).  Keeps the surface the shipped configs rely on:
     ``nips19.*`` / ``src.*`` resolve to this package's TrainModel / Trainer, any other path is imported as is;
   * ``Model(config)`` then ``Iterator(config, root, model)``, ``iterator.initialize(checkpoint)``,
     ``iterator.iterate(batches)`` (cub/train/log.txt:1-9, 201-203);
-  * ``[INFO] [LoggingHook]: name: value`` lines at steps 0,1,2,4,8,... and every ``log_freq``; checkpoints every
+  * ``[INFO] [LoggingHook]: name: value`` lines at steps 0, 2, 4, 8, ..., then every ``log_freq`` (keys alphabetical, as cub/train/log.txt:204-279); checkpoints every
     ``ckpt_freq`` under ``<root>/train/checkpoints/model.ckpt-<step>``.
 
 Data: ``dataset: src.data.data.AugmentedPair2`` / ``eddata.stochastic_pair.StochasticPairs`` resolve to the csv pair
