@@ -177,3 +177,47 @@ def test_full_width_confident_masks_iou(dev, precision):
         assert agree >= 0.99 and iou_mean >= 0.9 and iou_s >= 0.9, (agree, iou_mean, iou_s)
     else:
         assert iou_mean >= 0.999 and iou_s >= 0.999, (iou_mean, iou_s)
+
+
+@pytest.mark.parametrize("name,fixture", [("cub128p10", "full_cub128_step.npz"), ("pennaction128", "full_pennaction128_step.npz"),
+                                          ("deepfashion256p16", "full_deepfashion256_step.npz"), ("cub256p20", "full_cub256p20_step.npz")])
+def test_bench_configs_at_full_batch(dev, name, fixture):
+    """Every `bench.py --config` workload at its FULL per-GPU batch and precision (BASELINE configs #2 - #5): one training step,
+    all losses finite, and -- size-independent property: samples are independent in the forward pass -- the leading samples,
+    which carry the fixture's views and noise, reproduce the fixture's part masks (IoU >= 0.99; fp8: >= 0.98) inside the
+    large batch."""
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import configs, ops
+    from upsparts_amd.model import TrainModel, Trainer
+    from oracle import ref_model as R
+    z = np.load(os.path.join(GOLD, fixture))
+    build, S, P, B, prec, _gflop, _note = configs.BENCH_CONFIGS[name]
+    cfg = build(B)
+    cfg["precision"] = prec
+    bf = z["hard0_argmax"].shape[0]
+    cfg_fix = dict(cfg, batch_size=bf)
+    views_f, noise_f = R.synthetic_views(cfg_fix), R.synthetic_noise(cfg_fix)
+    g = torch.Generator().manual_seed(99)
+    model = TrainModel(cfg, device=dev, seed=0)
+    trainer = Trainer(cfg, None, model)
+    views = {k: torch.rand(B, S, S, 3, generator=g) * 2 - 1 for k in model.inputs}
+    noise = {k: torch.randn((v.shape[0], B) + tuple(v.shape[2:]) if k == "eps_pi0" else (B,) + tuple(v.shape[1:]), generator=g)
+             for k, v in noise_f.items()}
+    for k in views:
+        views[k][:bf] = views_f[k]
+    for k, v in noise_f.items():
+        if k == "eps_pi0":
+            noise[k][:, :bf] = v
+        else:
+            noise[k][:bf] = v
+    if prec == "fp8":
+        ops.Fp8.COPY_ONLY = False      # one step: no producer has a delayed scale yet
+    losses = trainer.train_step(views, noise)
+    hard = trainer._debug["hard"]
+    for k, v in losses.items():
+        assert np.isfinite(float(v)), "{}: loss {} = {}".format(name, k, float(v))
+    iou0, iou1 = _iou(hard[:bf], z["hard0_argmax"], P), _iou(hard[B:B + bf], z["hard1_argmax"], P)
+    print("{} B={} {}: part-mask IoU of the fixture samples inside the batch {:.4f} / {:.4f}".format(name, B, prec, iou0, iou1))
+    if prec == "fp8":
+        ops.Fp8.enabled, ops.Fp8.COPY_ONLY = False, None
+    assert min(iou0, iou1) >= (0.98 if prec == "fp8" else 0.99), (iou0, iou1)
