@@ -29,6 +29,7 @@ struct Wg3K {
     const void* in; const void* dout; float* ws;
     const unsigned* mask; int mask_B;     // part-masked input (ups_wgrad_desc.mask_*): in = view [mask_B,h,w,ldi], image = p*mask_B + b
     int in_f16;                           // `in` is an fp16 tensor (ups_wgrad_desc.in_f16): converted to bf16 while it is staged
+    int taps_std;                         // the taps are in the forward's r-major order: dy = t/3 - 1, dx = t%3 - 1 (launcher)
 };
 
 __device__ inline int g_dy(unsigned long long off, int t) { return (int)((off >> (4 * t + 2)) & 3) - 1; }
@@ -74,7 +75,7 @@ __device__ inline bf16x8 tr_frag_d(const unsigned char* tile, int row0, int wco,
     return u.b;
 }
 
-template <int CB, int BN, int TH>
+template <int CB, int BN, int TH, bool SLIDE = false>
 __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const int cit, const int cot, const int nsplit) {
     constexpr int PROWS = TH + 2, PPIX = PWID * PROWS;
     constexpr int WCI = CB / 32, WCO = BN / 32, WK = 8 / (WCI * WCO);
@@ -214,6 +215,33 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
         if (u + 1 < u_end) load_unit(u + 1, buf ^ 1);
         const unsigned char* X = Xbuf + buf * XB;
         const unsigned char* D = Dbuf + buf * DB;
+        if constexpr (WK == 1 && SLIDE) {
+            // Sliding window over the tile rows (a wave that walks EVERY row of the unit, taps in r-major order): the operand of
+            // tap (dy, dx) at row ks is the patch window of patch row ks + dy + 1 shifted by dx -- the same fragment serves
+            // dy = +1 at row ks, dy = 0 at row ks + 1 and dy = -1 at row ks + 2.  Three patch rows x three shifts stay in
+            // registers, every row brings in 3 new fragments + 1 dout fragment: 4 transposing fragment reads per 9 MFMAs
+            // instead of 10 (the LDS reads were what bounded this kernel: 2.19 ms with the staging compiled out).
+            bf16x8 aw[3][3];
+#pragma unroll
+            for (int dxi = 0; dxi < 3; ++dxi) {
+                aw[0][dxi] = tr_frag3(X, RSX, dxi, w_ci * 32, lane);
+                aw[1][dxi] = tr_frag3(X, RSX, PWID + dxi, w_ci * 32, lane);
+            }
+#pragma unroll
+            for (int ks = 0; ks < TH; ++ks) {
+#pragma unroll
+                for (int dxi = 0; dxi < 3; ++dxi) aw[(ks + 2) % 3][dxi] = tr_frag3(X, RSX, (ks + 2) * PWID + dxi, w_ci * 32, lane);
+                const bf16x8 b = tr_frag_d<BN>(D, ks * TW, w_co, lane);
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[(ks + t / 3) % 3][t % 3], b, acc[t], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += (float)b[j];
+                }
+                __builtin_amdgcn_sched_barrier(0);        // rows stay in program order: the scheduler otherwise pulls every
+            }                                             // row's fragment reads to the front (36 -> 100+ live registers)
+        } else
 #pragma unroll 1
         for (int kk = 0; kk < TH / WK; ++kk) {
             const int ks = w_k + kk * WK;                               // tile row handled by this wave
@@ -305,7 +333,7 @@ bool eligible(const ups_wgrad_desc* d) {
     return !(force && force[0] == '1');
 }
 
-template <int CB, int BN, int TH>
+template <int CB, int BN, int TH, bool SLIDE = false>
 int launch3(const Wg3K& k, int cit, int cot, int splitk, hipStream_t s) {
     constexpr int RSX = lds_stride3(CB * 2), RSD = BN * 2;
     constexpr int PPIX = PWID * (TH + 2);
@@ -314,11 +342,11 @@ int launch3(const Wg3K& k, int cit, int cot, int splitk, hipStream_t s) {
     if (shmem < red) shmem = red;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<CB, BN, TH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<CB, BN, TH, SLIDE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shmem) != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wgrad3x3_kernel<CB, BN, TH>), dim3(cit * cot * splitk), dim3(512), shmem, s, k, cit, cot, splitk);
+    hipLaunchKernelGGL((conv_wgrad3x3_kernel<CB, BN, TH, SLIDE>), dim3(cit * cot * splitk), dim3(512), shmem, s, k, cit, cot, splitk);
     return UPS_OK;
 }
 
@@ -351,13 +379,16 @@ int ups_wgrad3x3_run(const ups_wgrad_desc* d, hipStream_t s) {
     k.in = d->in; k.dout = d->dout; k.ws = d->workspace;
     k.mask = d->mask_bits; k.mask_B = d->mask_batch;
     k.in_f16 = d->in_f16;
+    k.taps_std = 1;
+    for (int t = 0; t < 9; ++t) if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1) k.taps_std = 0;
+    { const char* e = getenv("UPS_WGRAD_SLIDE"); if (e && e[0] == '0') k.taps_std = 0; }      // A/B switch
     k.tap_off = 0; k.tap_wi = 0;
     for (int t = 0; t < 9; ++t) {
         k.tap_off |= (unsigned long long)(((d->tap_dy[t] + 1) << 2) | (d->tap_dx[t] + 1)) << (4 * t);
         k.tap_wi |= (unsigned long long)d->tap_w[t] << (4 * t);
     }
     const int cit = ups_cdiv(d->ci, v.cb), cot = ups_cdiv(d->co, v.bn);
-    if (v.cb == 64 && v.bn == 128) return launch3<64, 128, 8>(k, cit, cot, d->splitk, s);
+    if (v.cb == 64 && v.bn == 128) return k.taps_std ? launch3<64, 128, 8, true>(k, cit, cot, d->splitk, s) : launch3<64, 128, 8>(k, cit, cot, d->splitk, s);
     if (v.cb == 64 && v.bn == 64) return launch3<64, 64, 8>(k, cit, cot, d->splitk, s);
     if (v.cb == 64 && v.bn == 32) return launch3<64, 32, 8>(k, cit, cot, d->splitk, s);
     if (v.cb == 32 && v.bn == 128) return launch3<32, 128, 8>(k, cit, cot, d->splitk, s);
