@@ -487,8 +487,9 @@ def vgg_features(vp, x, depths=VGG_DEPTHS):
 def perceptual_loss(vp, target, generated, mode="native", depths=VGG_DEPTHS):
     """sum_l mean|f_l(target) - f_l(generated)| (feature weights 1, gram weight 0: M:608)."""
     if mode == "resize256":
-        assert target.shape[1] == 128, "resize256 is restated for 128^2 inputs only (legacy bilinear x2)"
-        target, generated = bilinear_up2(target), bilinear_up2(generated)
+        assert target.shape[1] in (128, 256), "resize256 is restated for 128^2 (legacy bilinear x2) and 256^2 (identity) inputs"
+        if target.shape[1] == 128:
+            target, generated = bilinear_up2(target), bilinear_up2(generated)
     elif mode != "native":
         raise ValueError(mode)
     ft = vgg_features(vp, target, depths)

@@ -205,7 +205,7 @@ def test_csv_pair_datasets(tmp_path):
         data.AugmentedPair2(dict(cfg, data_augment_shape=True))
 
 
-def test_part_iou_evaluation():
+def test_part_iou_evaluation(tmp_path):
     """evalutil: best-IoU remapping of inferred part ids to ground-truth labels + per-label IoU (eval_01.py:229-383 protocol)."""
     import numpy as np
     import upsparts_amd  # noqa: F401
@@ -224,6 +224,20 @@ def test_part_iou_evaluation():
     assert abs(r["overall"] - 0.5 * (r["iou"][1] + r["iou"][2])) < 1e-12
     same = E.evaluate_parts(gt, gt)
     assert same["overall"] == 1.0
+    # the files of eval_01.py:355-383
+    import pandas as pd
+    df, df_mean = E.write_eval_tables(r, str(tmp_path), 71000, {0: "background", 1: "head", 2: "tail"})
+    back = pd.read_csv(str(tmp_path / "part_ious.csv"))
+    assert list(back.columns) == ["global_step", "batch_idx", "background", "head", "tail"] and len(back) == 2
+    assert abs(back["head"][0] - 16 / 17) < 1e-12 and back["global_step"][1] == 71000 and back["batch_idx"][1] == 1
+    table = (tmp_path / "mean_part_ios.csv").read_text()
+    assert table.startswith("+") and "overall" in table and "{:.6f}".format(r["overall"])[:7] in table
+    assert "3: 1" in (tmp_path / "best_remapping.yml").read_text()
+    # a label missing from one image's ground truth is written as -1 and left out of the mean (eval_01.py:299, 373)
+    gt2 = gt.copy(); gt2[1][gt2[1] == 2] = 0
+    r2 = E.evaluate_parts(pred, gt2)
+    df2, m2 = E.write_eval_tables(r2, str(tmp_path / "b"), 1, {0: "background", 1: "head", 2: "tail"})
+    assert df2["tail"][1] == -1.0 and abs(float(m2["tail"][0]) - df2["tail"][0]) < 1e-12
 
 
 _RANK_STANDIN = '''

@@ -67,3 +67,37 @@ def evaluate_parts(out_parts_hard, gt_segmentation, background_label=0):
     return {"mapping": mapping, "iou": per_label, "per_image": rows,
             "overall": float(np.mean(fg)) if fg else float("nan"),
             "pooled": dict(zip(pl.tolist(), pooled.tolist()))}
+
+
+def write_eval_tables(res, root, global_step, part_names=None, background_label=0):
+    """The files eval_01.py:229-383 leaves in the evaluation directory, from ``evaluate_parts``' result:
+    ``part_ious.csv``     one row per image: global_step, batch_idx, then one IoU column per ground-truth part (-1.0 where the
+                          image's ground truth lacks the part, eval_01.py:299-309, 371)
+    ``mean_part_ios.csv`` (the reference's spelling) the column means over the rows with the -1 entries left out plus
+                          ``overall`` = the mean of the part columns without ``background``, as a psql table (eval_01.py:373-383)
+    ``best_remapping.yml`` inferred part id -> ground-truth label (eval_01.py:254-258).
+    part_names: {ground-truth label: column name} (the sorted keys of the yaml's dp_semantic_remap_dict in the reference);
+    default "background" for `background_label`, "part_<label>" otherwise."""
+    import os
+    import pandas as pd
+    import yaml
+    from tabulate import tabulate
+    labels = sorted(res["iou"])
+    names = {g: ("background" if g == background_label else "part_{}".format(g)) for g in labels}
+    names.update(part_names or {})
+    cols = [names[g] for g in labels]
+    rows = []
+    for i, r in enumerate(res["per_image"]):
+        row = {"global_step": global_step, "batch_idx": i}
+        row.update({names[g]: float(r.get(g, -1.0)) for g in labels})
+        rows.append(row)
+    df = pd.DataFrame(rows, columns=["global_step", "batch_idx"] + cols)
+    os.makedirs(root, exist_ok=True)
+    df.to_csv(os.path.join(root, "part_ious.csv"), index=False, header=True)
+    df_mean = df[df != -1].mean().to_frame().transpose()
+    df_mean["overall"] = df_mean[[c for c in cols if c != "background"]].mean(axis=1)
+    with open(os.path.join(root, "mean_part_ios.csv"), "w") as f:
+        print(tabulate(df_mean, headers="keys", tablefmt="psql", showindex="never"), file=f)
+    with open(os.path.join(root, "best_remapping.yml"), "w") as f:
+        yaml.dump({"best_remapping": {int(k): int(v) for k, v in res["mapping"].items()}}, f, default_flow_style=False)
+    return df, df_mean

@@ -431,13 +431,20 @@ class Trainer(object):
         # the perceptual features of the TARGET depend on the data only: evaluated on a side stream from the start of the step
         # (they fill the bubbles of the small layers at the network ends), joined where the loss needs them
         ft_pre, ft_ready = None, None
+        # `perceptual_input: resize256` (edflow VGG19Features original_scale reading, model.py:610-612): 128x128 inputs are
+        # up-sampled x2 (legacy bilinear), 256x256 inputs already have that size; other sizes have no restatement
+        resize2x = False
         if self.perceptual_input == "resize256":
-            assert S == 128
+            if S not in (128, 256):
+                raise NotImplementedError("perceptual_input: resize256 is restated for 128x128 and 256x256 inputs only (got {})".format(S))
+            resize2x = S == 128
+        elif self.perceptual_input != "native":
+            raise NotImplementedError("perceptual_input: {} (native | resize256)".format(self.perceptual_input))
         if ops.Streams.enabled:
             pre = ops.Streams.get("pre", dev)
             pre.wait_stream(main_stream)
             with torch.cuda.stream(pre), torch.no_grad():
-                tgt_pre = ops.BilinearFn.apply(model.to_act(vt)) if self.perceptual_input == "resize256" else vt
+                tgt_pre = ops.BilinearFn.apply(model.to_act(vt)) if resize2x else vt
                 ft_pre = self.vgg.features(tgt_pre, T)
             ft_ready = pre.record_event()
         if noise is None:
@@ -561,12 +568,12 @@ class Trainer(object):
         feat = yp.float().view(P, B, A).permute(1, 0, 2).contiguous()      # [B,P,A]
         inj = ops.UnpoolFn.apply(hard0, feat, T)
         gen = nets.dd(Act(inj, B, S, S, A + P)).t                          # [B,S,S,8]
-        gen_in = ops.BilinearFn.apply(gen) if self.perceptual_input == "resize256" else gen
+        gen_in = ops.BilinearFn.apply(gen) if resize2x else gen
         if ft_pre is not None:
             main_stream.wait_event(ft_ready)
             rec = self.vgg.loss(None, gen_in, T, target_features=ft_pre)
         else:
-            tgt_in = ops.BilinearFn.apply(model.to_act(vt)) if self.perceptual_input == "resize256" else vt
+            tgt_in = ops.BilinearFn.apply(model.to_act(vt)) if resize2x else vt
             rec = self.vgg.loss(tgt_in, gen_in, T)
         auto_rec = (1e-3 * 0.5 * (S * S * 3)) * rec                        # model.py:613-619
 

@@ -173,6 +173,9 @@ def evaluate(args):
             yaml.safe_dump({"iou": {int(k): float(v) for k, v in res["iou"].items()}, "overall": res["overall"],
                             "pooled_iou": {int(k): float(v) for k, v in res["pooled"].items()},
                             "best_remapping": {int(k): int(v) for k, v in res["mapping"].items()}}, f)
+        # part_ious.csv / mean_part_ios.csv / best_remapping.yml as eval_01.py:355-383 writes them
+        names = cfg.get("part_names")
+        evalutil.write_eval_tables(res, odir, it.global_step, {int(k): str(v) for k, v in names.items()} if names else None)
     print("[INFO] evaluation outputs written to", odir)
     return data
 
