@@ -97,6 +97,49 @@ def test_two_rank_step_matches_sum_of_local_gradients(dev):
         assert err <= 1e-5, "bucket {}: all-reduced gradient vs sum of local gradients, rel err {:.2e}".format(k, err)
 
 
+def _graph_worker(rank, world, port, out, use_graph, steps):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import dist as D
+    from upsparts_amd.model import TrainModel, Trainer
+    D.init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    cfg = _cfg()
+    cfg["hip_graph"] = use_graph
+    model = TrainModel(cfg, device=dev, seed=0)
+    tr = Trainer(cfg, None, model, world_size=world, rank=rank)
+    views, noise = _shard(rank)
+    for _ in range(steps):
+        losses = tr.train_step(views, noise)
+    torch.cuda.synchronize()
+    nseg = len(tr._g["graph"]["graphs"]) if use_graph and tr._g and tr._g["graph"] else 0
+    out[(use_graph, rank)] = {"params": {k: g["flat"]["p"].detach().cpu() for k, g in model.bank.groups.items()},
+                              "state": {k: float(v) for k, v in tr.state.items()}, "segments": nseg,
+                              "losses": {k: float(v) for k, v in losses.items()}, "step": tr.global_step}
+    torch.distributed.destroy_process_group()
+
+
+def test_hip_graph_replay_under_data_parallelism(dev):
+    """`hip_graph: True` with world_size 2: the step is captured as a sequence of HIP graphs cut at the collectives (bucket
+    all-reduces after each backward segment, the averaged Lagrangian scalars) and replayed with the collectives run eagerly in
+    between.  After five steps (two eager warm-up steps, the capture, replays) parameters, Lagrangian / EMA state and losses are
+    bit-identical to the eager two-rank run, on both ranks."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    for use_graph in (False, True):
+        mp.spawn(_graph_worker, args=(2, _free_port(), out, use_graph, 5), nprocs=2, join=True)
+    for rank in range(2):
+        e, g = out[(False, rank)], out[(True, rank)]
+        assert g["segments"] >= 5 and g["step"] == e["step"] == 5, (g["segments"], g["step"])
+        for k in e["params"]:
+            assert torch.equal(e["params"][k], g["params"][k]), "graph replay diverged from the eager DP step: {} (rank {})".format(k, rank)
+        assert e["state"] == g["state"] and e["losses"] == g["losses"]
+    for k in out[(True, 0)]["params"]:
+        assert torch.equal(out[(True, 0)]["params"][k], out[(True, 1)]["params"][k]), "replicas diverged: " + k
+
+
 def test_rccl_call_pattern_at_world_size_one(dev):
     """tools/nccl_trainer_check.py in a child process: a world-size-1 NCCL (= RCCL) group with UPS_FORCE_COLLECTIVES=1 issues
     every bucket all-reduce where the multi-GPU run does (asynchronously, inside backward, early encoder_0 head slice) and

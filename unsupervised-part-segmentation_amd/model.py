@@ -203,6 +203,7 @@ class Trainer(object):
         self._early, self._early_hooked = {}, False
         self._graph_enabled = bool(config.get("hip_graph", os.environ.get("UPS_GRAPH", "0") == "1"))
         self._g = None
+        self._cap = None                # set while the step is being captured into HIP graphs (_capture_step)
 
     # ------------------------------------------------------------------ edflow hook surface
     def loss_keys(self):
@@ -342,9 +343,10 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ one session.run(train_op)
     def train_step(self, batch, noise=None):
-        """One session.run(train_op).  With ``hip_graph: True`` (single GPU) the whole step -- ~2 400 kernel launches on three
-        streams -- is captured once into a HIP graph and replayed; see ``_graph_step``."""
-        if self._graph_enabled and self.world_size == 1 and not self.model.use_tps:
+        """One session.run(train_op).  With ``hip_graph: True`` the whole step -- ~1 000 kernel launches on three streams -- is
+        captured once into HIP graphs and replayed (one graph on a single GPU; under data parallelism a sequence of graphs cut
+        at the collectives); see ``_graph_step`` / ``_capture_step``."""
+        if self._graph_enabled and not self.model.use_tps:
             # one device scalar carries Adam's bias-corrected step size: usable only while every trained key is at the same
             # Adam step (not after restoring a checkpoint whose keys were trained for different numbers of steps)
             ts = set(self.model.bank.groups[k]["t"] for k in self.loss_keys())
@@ -393,14 +395,68 @@ class Trainer(object):
             self._after_graph_step()
             return out
         if g["graph"] is None or g["sig"] != sig:
-            torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._step_impl(g["in"], g["noise"], graph_lr=g["lr"])
-            g["graph"], g["sig"] = graph, sig   # (capturing does not execute: the replay below runs the step)
-        g["graph"].replay()
+            g["graph"], g["sig"] = self._capture_step(g), sig   # (capturing does not execute: the replay below runs the step)
+        self._replay_step(g["graph"])
         self._after_graph_step()
         return self.losses
+
+    # Data parallel: a collective cannot sit inside a captured region on every backend (gloo reduces on the host), and the
+    # buckets should start their all-reduce as early as in the eager step.  The step is therefore captured as a SEQUENCE of
+    # graphs, cut wherever the eager step talks to the other ranks: after the backward segment of each group of optimizer keys
+    # (bucket all-reduce, asynchronous, overlapping the next segments) and before the Lagrangian / EMA update (the averaged
+    # batch-mean scalars).  One python pass records all segments (the tape objects simply live on between them; the graphs
+    # share one memory pool and are always replayed in capture order); at replay the collectives run eagerly in between.
+    def _capture_step(self, g):
+        dev = self.device
+        torch.cuda.synchronize(dev)
+        cap = {"graphs": [], "bounds": [], "pool": torch.cuda.graph_pool_handle(), "stream": torch.cuda.Stream(dev), "cur": None}
+        cap["stream"].wait_stream(torch.cuda.current_stream(dev))
+        self._cap = cap
+        try:
+            with torch.cuda.stream(cap["stream"]):
+                self._segment_begin()
+                self._step_impl(g["in"], g["noise"], graph_lr=g["lr"])
+                self._segment_end()
+        finally:
+            self._cap = None
+        torch.cuda.current_stream(dev).wait_stream(cap["stream"])
+        torch.cuda.synchronize(dev)
+        return cap
+
+    def _segment_begin(self):
+        cap = self._cap
+        cap["cur"] = torch.cuda.CUDAGraph()
+        cap["cur"].capture_begin(pool=cap["pool"])
+
+    def _segment_end(self):
+        cap = self._cap
+        ops.Streams.join(self.device, names=("wgrad", "aux"))      # every forked stream rejoins before the capture ends
+        cap["cur"].capture_end()
+        cap["graphs"].append(cap["cur"])
+        cap["cur"] = None
+
+    def _boundary(self, kind, payload):
+        """Called from inside the step while it is being captured: close the running segment, note what has to happen between
+        it and the next one (kind "grads": all-reduce these keys' buckets; "scalars": average this tensor), open the next."""
+        self._segment_end()
+        self._cap["bounds"].append((kind, payload))
+        self._segment_begin()
+
+    def _replay_step(self, cap):
+        bank = self.model.bank
+        last_grads = max([i for i, (kind, _) in enumerate(cap["bounds"]) if kind == "grads"], default=-1)
+        handles = []
+        for i, graph in enumerate(cap["graphs"]):
+            graph.replay()
+            if i < len(cap["bounds"]):
+                kind, payload = cap["bounds"][i]
+                if kind == "grads":
+                    for k in payload:
+                        handles.append(D.allreduce_bucket(bank.groups[k]["flat"]["g"], self.world_size, self.process_group))
+                    if i == last_grads:
+                        D.wait_all(handles)             # the next segment is the optimizer
+                else:
+                    D.average_scalars(payload, self.world_size, self.process_group)
 
     def _after_graph_step(self):
         # (WeightVersion is not bumped: the step's own batched weight_prep has already refreshed every converted copy)
@@ -671,7 +727,10 @@ class Trainer(object):
 
         # ================= state updates (update_ops; Appendix A.15: losses above used the pre-update state)
         stats = torch.stack([mim.detach(), ind_mim.detach(), acc0, acc1, loss_dis0.detach(), loss_dis1.detach()])
-        D.average_scalars(stats, self.world_size, self.process_group)
+        if getattr(self, "_cap", None) is not None and self.world_size > 1:
+            self._boundary("scalars", stats)             # (the tensor lives in the graphs' pool: same address at every replay)
+        else:
+            D.average_scalars(stats, self.world_size, self.process_group)
         g_mim, g_ind, g_acc0, g_acc1, g_l0, g_l1 = stats.unbind(0)
         ema = lambda old, val: 0.99 * old + (1.0 - 0.99) * val            # model.py:28-35
         new = dict(st)
@@ -770,8 +829,8 @@ class Trainer(object):
         trainer = self
 
         def launch():
-            if "encoder_0" in trainer._early:
-                return
+            if "encoder_0" in trainer._early or getattr(trainer, "_cap", None) is not None:
+                return                      # (graph capture: the whole bucket is reduced at the segment boundary)
             ops.Streams.join(trainer.device, names=("wgrad",))
             h = D.allreduce_bucket(grp["flat"]["g"][off:], trainer.world_size, trainer.process_group)
             trainer._early["encoder_0"] = (off, h)
@@ -785,6 +844,10 @@ class Trainer(object):
         are joined and each key's flat gradient bucket starts its RCCL all-reduce (sum; 1/world is folded into Adam),
         overlapping the backward segments that are still to run.  Returns the work handles."""
         if not key_list:
+            return []
+        if getattr(self, "_cap", None) is not None:      # graph capture under data parallelism: a segment boundary
+            if self.world_size > 1 or D.FORCE_COLLECTIVES:
+                self._boundary("grads", list(key_list))
             return []
         ops.Streams.join(self.device, names=("wgrad",))
         bank = self.model.bank
