@@ -114,6 +114,15 @@ typedef struct {
      * class (py, px) at lattice pixel (y, x) is written to out[n][2y + py][2x + px][c] of a [n, out_h = 2 ho, out_w = 2 wo, ldo]
      * tensor; res / dact are read on that lattice.  `w` = ups_weight_prep_d2s.  bf16 patch kernel only (else UPS_E_UNSUPPORTED). */
     int32_t      d2s;
+    /* Post-activation storage.  A 16-bit (or fp32) tensor whose only convolution consumer applies an activation on load may be
+     * STORED as act(x) instead of x: the consumer then stages it untouched (act_in = UPS_ACT_NONE: the halo patch can arrive by
+     * LDS-DMA, no staging registers, no VALU), its weight gradient reads the operand as it is, its input gradient still takes
+     * the sign for act' from it (sign(act(x)) = sign(x)).
+     *   out_act  activation applied to the finished value (after bias, CoordConv, act', residual) before it is stored;
+     *   res_act  `res` holds act(x) of a leaky-ReLU (slope > 0): it is inverted (r > 0 ? r : r / slope) before it is added --
+     *            the residual stream x + conv(act(x)) of N:1042-1056 with x stored as act(x).  UPS_ACT_LRELU or UPS_ACT_NONE.
+     * Gradients are always with respect to the pre-activation values: nothing changes in the backward calls. */
+    int32_t      out_act, res_act;
 } ups_conv_desc;
 
 int ups_conv_igemm(const ups_conv_desc* d, void* stream);
@@ -209,6 +218,9 @@ int ups_col_sum(const void* dout, int32_t dtype, int64_t rows, int32_t co, int32
  * Legacy TF-1 bilinear x2 (N:834-847, tf.image.resize_images BILINEAR, no half-pixel centres). */
 int ups_bilinear2x_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
 int ups_bilinear2x_bwd(const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+/* y = act(bilinear x2 of x): the up-sampled tensor in post-activation storage (ups_conv_desc.out_act) for a consuming residual block */
+int ups_bilinear2x_fwd_act(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t act, float slope,
+                           void* stream);
 /* The same (bf16) with an fp8 copy of the result for a consuming fp8 convolution (ups_conv_desc.in_f8): max |act(y)| goes to
  * amax[64]; with y_f8 != NULL also e4m3 (e5m2 != 0: e5m2) of act(y) * *scale, one byte per element, laid out like y. */
 int ups_bilinear2x_fwd_f8(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void* y_f8, const float* scale,

@@ -196,6 +196,76 @@ def test_conv_fp16_forward_bf16_gradients(case, dev):
         assert_close(y32[..., :cout], yo.float(), F16_TOL / 2, "fp16 conv fwd, fp32 out {}".format(case))
 
 
+POST_CASES = [
+    # n, h, w, cin, cout, k, stride, coords, res_self, dtype
+    (2, 32, 32, 128, 128, 3, 1, True, True, "bf16"),      # patch kernel, staged epilogue
+    (16, 64, 64, 128, 128, 3, 1, True, True, "bf16"),     # two blocks per CU: LDS-DMA patch on the forward (act_in none)
+    (8, 128, 128, 256, 256, 3, 1, True, True, "bf16"),    # the dominant layer's shape
+    (16, 64, 64, 256, 256, 3, 1, True, True, "f16"),      # mask decoder format
+    (32, 4, 4, 136, 136, 3, 1, True, True, "bf16"),       # whole images packed into a tile
+    (5, 4, 4, 16, 16, 1, 1, False, True, "bf16"),         # 1x1 residual block of the critics (generic kernel)
+    (128, 1, 1, 512, 512, 1, 1, False, True, "bf16"),     # ... at the critics' width (split-K epilogue)
+    (2, 16, 16, 16, 16, 3, 1, True, True, "fp32"),
+    (3, 16, 16, 16, 24, 3, 2, True, False, "bf16"),       # a downsample whose output is stored post-activation
+    (2, 12, 20, 32, 40, 3, 1, False, False, "fp32"),      # generic kernel, per-element epilogue
+]
+
+
+@pytest.mark.parametrize("case", POST_CASES)
+def test_conv_post_activation_storage(case, dev):
+    """ups_conv_desc.out_act / res_act: the input tensor holds a = lrelu(x) (in_post), the residual is recovered from it
+    (x = a > 0 ? a : a / slope), the output is stored as lrelu(y); gradients stay with respect to the pre-activation values."""
+    lib, ops, R = _mods()
+    n, h, w, cin, cout, k, stride, coords, res_self, dtype = case
+    g = torch.Generator().manual_seed(500 + POST_CASES.index(case))
+    cin_v = cin + (2 if coords else 0)
+    T = {"fp32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+    tol = {"fp32": F32_TOL, "bf16": BF16_TOL, "f16": F16_TOL}[dtype]
+    x = torch.randn(n, h, w, cin, generator=g)
+    a = torch.nn.functional.leaky_relu(x, 0.2).to(T).float()          # what the producer stored
+    V = torch.randn(k, k, cin_v, cout, generator=g) / math.sqrt(cin_v * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    Vo = V.double().clone()
+    if dtype != "fp32":
+        Vo[:, :, :cin] = V[:, :, :cin].to(T).double()
+    xo = torch.where(a > 0, a, a / 0.2).double().requires_grad_(True)      # the pre-activation value the stored tensor stands for
+    Vo.requires_grad_(True)
+    bo = b.double().requires_grad_(True)
+    ypre = _oracle_conv(R, xo, Vo, bo, stride, coords, "leaky_relu", res_self, None)
+    go = torch.randn(ypre.shape, generator=g)
+    if dtype != "fp32":
+        go = go.to(torch.bfloat16).float()
+    ypre.backward(go.double())
+    want = torch.nn.functional.leaky_relu(ypre.detach(), 0.2)
+    lay = _layer(ops, lib, V, b, k, stride, coords, "leaky_relu", dev)
+    lay.in_post, lay.out_act, lay.f16 = True, lib.ACT_LRELU, dtype == "f16"
+    fmt = lib.F16 if dtype == "f16" else None
+    xd = (a.to(dev, torch.float16).view(torch.bfloat16) if dtype == "f16" else a.to(dev, T)).requires_grad_(True)
+    y = ops.conv(xd, lay, res_self=res_self, fmt=fmt)
+    yf = y.view(torch.float16).float() if dtype == "f16" else y.float()
+    assert_close(yf[..., :cout], want.float(), tol, "post-activation conv fwd {}".format(case))
+    TG = torch.float32 if dtype == "fp32" else torch.bfloat16
+    gd = torch.zeros(y.shape, dtype=TG, device=dev)
+    gd[..., :cout] = go.to(dev, TG)
+    gx, gV, gb = torch.autograd.grad([y], [xd, lay.V, lay.b], grad_outputs=[gd])
+    btol = F32_TOL if dtype == "fp32" else BF16_TOL
+    assert_close(gx.float(), xo.grad.float(), btol, "post-activation conv dgrad {}".format(case))
+    assert_close(gV.float(), Vo.grad.float(), btol * (1 if dtype == "fp32" else 4), "post-activation conv wgrad {}".format(case))
+    assert_close(gb.float(), bo.grad.float(), btol, "post-activation conv bias grad {}".format(case))
+
+
+def test_bilinear_post_activation_output(dev):
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(16)
+    for T, fmt, tol in ((torch.float32, None, 1e-6), (torch.bfloat16, None, 1e-2), (torch.float16, lib.F16, 1e-3)):
+        x = torch.randn(3, 6, 5, 16, generator=g).to(T).float()
+        want = torch.nn.functional.leaky_relu(R.bilinear_up2(x.double()), 0.2)
+        xd = x.to(dev, T).view(torch.bfloat16) if fmt == lib.F16 else x.to(dev, T)
+        y = ops.BilinearFn.apply(xd, None, 0, 0.2, fmt, lib.ACT_LRELU)
+        yf = y.view(torch.float16).float() if fmt == lib.F16 else y.float()
+        assert_close(yf, want.float(), tol, "bilinear with post-activation output {}".format(T))
+
+
 def test_bilinear_fp16(dev):
     lib, ops, R = _mods()
     g = torch.Generator().manual_seed(15)

@@ -61,6 +61,7 @@ struct PatchK {
     // pixel (2y + py, 2x + px) of a [n, 2h, 2w, ld] tensor (res / dact live on that lattice too)
     int d2s, d2s_shift;
     int taps_static;      // 1: forward order, 2: flipped (input-gradient) order, 0: neither (launcher)
+    int out_act, res_act; // post-activation storage (ups_conv_desc.out_act / res_act)
 };
 
 __device__ __forceinline__ int fast_div(int n, int d, unsigned m) {
@@ -221,6 +222,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values derived from it live in SGPRs
     const float act_ns = ups_slope_eff(p.act_in, p.act_slope);   // branch-free activation-on-load
     const float dact_ns = ups_slope_eff(p.dact_kind, p.act_slope); // act'(x) = x > 0 ? 1 : dact_ns (only used when dact != NULL)
+    const float oact_ns = ups_slope_eff(p.out_act, p.act_slope);   // stored value = max(v, oact_ns * v) when out_act is set
+    const float res_inv = p.res_act ? 1.f / p.act_slope : 1.f;     // residual stored as leaky-ReLU(x): x = r > 0 ? r : r / slope
     // XCD-aware order: consecutive logical tiles (which share halos / the same patch for both N-tiles) stay on
     // one XCD's L2 (blocks are dealt round-robin over the 8 XCDs)
     int bid = blockIdx.x;
@@ -823,7 +826,15 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                         const uint2 rv = *slot;
                         float r0, r1, r2, r3;
                         ups_unpack2<T>(rv.x, r0, r1); ups_unpack2<T>(rv.y, r2, r3);
+                        if (p.res_act) {
+                            r0 = r0 > 0.f ? r0 : r0 * res_inv; r1 = r1 > 0.f ? r1 : r1 * res_inv;
+                            r2 = r2 > 0.f ? r2 : r2 * res_inv; r3 = r3 > 0.f ? r3 : r3 * res_inv;
+                        }
                         v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+                    }
+                    if (p.out_act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ups_vmax(v[e], oact_ns * v[e]);
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (!cv[e]) v[e] = 0.f;
@@ -908,7 +919,12 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 v += tb[0] + (float)x * tb[p.co] + (float)y * tb[2 * p.co];
             }
             if (dact) v *= (ld_as_float<T>(dact + pix * p.ldd + col) > 0.f) ? 1.f : dact_ns;
-            if (res) v += ld_as_float<T>(res + pix * p.ldr + col);
+            if (res) {
+                float r = ld_as_float<T>(res + pix * p.ldr + col);
+                if (p.res_act) r = r > 0.f ? r : r * res_inv;
+                v += r;
+            }
+            if (p.out_act) v = ups_vmax(v, oact_ns * v);
         }
         if (p.out_f32) outF[pix * p.ldo + col] = v;
         else st_from_float<T>(outT + pix * p.ldo + col, v);
@@ -1127,6 +1143,8 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     k.ldo = d->ldo; k.ldr = d->ldr; k.ldd = d->ldd; k.act_in = d->act_in; k.out_f32 = d->out_f32;
     k.dact_kind = d->dact_kind; k.has_ctab = d->coord_tab != nullptr; k.act_slope = d->act_slope;
     k.in = d->in; k.wgt = d->w; k.out = d->out; k.bias = d->bias; k.coord_tab = d->coord_tab; k.res = d->res; k.dact = d->dact;
+    k.out_act = d->out_act; k.res_act = d->res_act;
+    if ((d->out_act || d->res_act) && (d->out_f8 || d->out_f8_amax || d->mask_grad || d->d2s)) return 1;   // (no fp8 copy of a post-activation tensor)
     k.tap_off = 0; k.tap_wi = 0;
     for (int t = 0; t < 9; ++t) {
         k.tap_off |= (unsigned long long)(((d->tap_dy[t] + 1) << 2) | (d->tap_dx[t] + 1)) << (4 * t);

@@ -104,7 +104,7 @@ __device__ inline int tap_w_of(unsigned long long wi, int t) { return (int)((wi 
 // ups_conv_desc without the tap arrays
 struct ConvK {
     int n, hi, wi, ci, ldi, ho, wo, co, co_fill, ldo, out_h, out_w, out_sy, out_sx, out_oy, out_ox, in_sy, in_sx;
-    int ntaps, kh, kw, act_in, out_f32, dact_kind, ldr, ldd;
+    int ntaps, kh, kw, act_in, out_f32, dact_kind, ldr, ldd, out_act, res_act;
     float act_slope;
     unsigned long long tap_off, tap_wi;
     const void* in; const void* w; void* out;
@@ -313,7 +313,12 @@ __global__ __launch_bounds__(256, (CPS == 1 ? 3 : 2)) void conv_igemm_kernel(con
                         v += tb[0] + (float)rowaux[rl * 3 + 1] * tb[p.co] + (float)rowaux[rl * 3 + 2] * tb[2 * p.co];
                     }
                     if (dact) v *= (ld_as_float<T>(dact + pix * p.ldd + col) > 0.f) ? 1.f : dact_ns;
-                    if (res) v += ld_as_float<T>(res + pix * p.ldr + col);
+                    if (res) {
+                        float rr = ld_as_float<T>(res + pix * p.ldr + col);
+                        if (p.res_act) rr = rr > 0.f ? rr : rr / p.act_slope;      // residual stored as leaky-ReLU(x)
+                        v += rr;
+                    }
+                    if (p.out_act) v = ups_vmax(v, ups_slope_eff(p.out_act, p.act_slope) * v);   // post-activation storage
                 }
                 if (p.out_f32) outF[pix * p.ldo + col] = v;
                 else st_from_float<T>(outT + pix * p.ldo + col, v);
@@ -346,7 +351,12 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const ConvK p, cons
             v += tb[0] + (float)j * tb[p.co] + (float)i * tb[2 * p.co];
         }
         if (p.dact) v *= (ld_as_float<T>((const T*)p.dact + pix * p.ldd + col) > 0.f) ? 1.f : ups_slope_eff(p.dact_kind, p.act_slope);
-        if (p.res) v += ld_as_float<T>((const T*)p.res + pix * p.ldr + col);
+        if (p.res) {
+            float rr = ld_as_float<T>((const T*)p.res + pix * p.ldr + col);
+            if (p.res_act) rr = rr > 0.f ? rr : rr / p.act_slope;
+            v += rr;
+        }
+        if (p.out_act) v = ups_vmax(v, ups_slope_eff(p.out_act, p.act_slope) * v);
     } else {
         v = 0.f;
     }
@@ -363,6 +373,7 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
     d.out_sx = dd.out_sx; d.out_oy = dd.out_oy; d.out_ox = dd.out_ox; d.in_sy = dd.in_sy; d.in_sx = dd.in_sx;
     d.ntaps = dd.ntaps; d.kh = dd.kh; d.kw = dd.kw; d.act_in = dd.act_in; d.out_f32 = dd.out_f32;
     d.dact_kind = dd.dact_kind; d.ldr = dd.ldr; d.ldd = dd.ldd; d.act_slope = dd.act_slope;
+    d.out_act = dd.out_act; d.res_act = dd.res_act;
     d.in = dd.in; d.w = dd.w; d.out = dd.out; d.bias = dd.bias; d.coord_tab = dd.coord_tab; d.res = dd.res; d.dact = dd.dact;
     d.tap_off = 0; d.tap_wi = 0;
     for (int t = 0; t < dd.ntaps; ++t) {
@@ -467,6 +478,8 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d->ci > 0 && d->ci % 8 == 0 && d->ldi % 8 == 0 && d->ci <= d->ldi);
     UPS_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= 9);
     UPS_CHECK_ARG(d->act_slope >= 0.f && d->act_slope <= 1.f);    // activation-on-load is max(x, slope * x)
+    UPS_CHECK_ARG(d->out_act >= UPS_ACT_NONE && d->out_act <= UPS_ACT_RELU);
+    UPS_CHECK_ARG(d->res_act == UPS_ACT_NONE || (d->res_act == UPS_ACT_LRELU && d->act_slope > 0.f && d->res));   // invertible only
     UPS_CHECK_ARG(d->co >= 1 && d->co_fill >= d->co && (d->d2s ? d->d2s <= d->ldo : d->co_fill <= d->ldo));
     UPS_CHECK_ARG(d->n > 0 && d->ho > 0 && d->wo > 0 && d->hi > 0 && d->wi > 0);
     UPS_CHECK_ARG(!d->coord_tab || (d->kh * d->kw == d->ntaps && d->kh <= 3 && d->kw <= 3));

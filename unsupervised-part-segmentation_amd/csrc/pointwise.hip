@@ -51,7 +51,20 @@ __device__ __forceinline__ void f8_emit_finish(const F8Emit& q, float amax) {
 }
 
 template <typename T, bool EMIT = false>
-__global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, F8Emit q = F8Emit()) {
+// ons >= 0: the stored value is max(v, ons * v) (post-activation storage of the up-sampled tensor, ups_bilinear2x_fwd_act); the
+// interpolation itself always runs on the un-activated values
+__global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, F8Emit q = F8Emit(),
+                                      float ons = -1.f) {
+    auto stv = [&](T* ptr, const float* v) __attribute__((always_inline)) {
+        if (ons >= 0.f) {
+            float t[V16<T>::N];
+#pragma unroll
+            for (int e = 0; e < V16<T>::N; ++e) t[e] = ups_vmax(v[e], ons * v[e]);
+            V16<T>::st(ptr, t);
+        } else {
+            V16<T>::st(ptr, v);
+        }
+    };
     constexpr int E = V16<T>::N;
     float amax = 0.f;
     const float sc = (EMIT && q.out) ? *q.scale : 1.f, ns = EMIT ? ups_slope_eff(q.act, q.slope) : 0.f;
@@ -73,19 +86,19 @@ __global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y
         V16<T>::ld(base + ((long long)y1 * w + x1) * c, a11);
         T* ob = y + (((long long)b * 2 * h + 2 * y0) * (2 * w) + 2 * x0) * c + k * E;
         const long long orow = (long long)2 * w * c;
-        V16<T>::st(ob, a00);                                                        // (2y, 2x)
+        stv(ob, a00);                                                        // (2y, 2x)
         if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob - y, a00, amax);
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = 0.5f * (a00[e] + a01[e]);
-        V16<T>::st(ob + c, o);                                                      // (2y, 2x+1)
+        stv(ob + c, o);                                                      // (2y, 2x+1)
         if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob + c - y, o, amax);
 #pragma unroll
         for (int e = 0; e < E; ++e) { a00[e] = 0.5f * (a00[e] + a10[e]); a01[e] = 0.5f * (a01[e] + a11[e]); }
-        V16<T>::st(ob + orow, a00);                                                 // (2y+1, 2x)
+        stv(ob + orow, a00);                                                 // (2y+1, 2x)
         if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob + orow - y, a00, amax);
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = 0.5f * (a00[e] + a01[e]);
-        V16<T>::st(ob + orow + c, o);                                               // (2y+1, 2x+1)
+        stv(ob + orow + c, o);                                               // (2y+1, 2x+1)
         if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob + orow + c - y, o, amax);
     }
     if constexpr (EMIT) f8_emit_finish(q, amax);
@@ -362,6 +375,18 @@ extern "C" int ups_bilinear2x_fwd(const void* x, void* y, int32_t dtype, int32_t
     if (dtype == UPS_F32) hipLaunchKernelGGL(bilinear2x_fwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)x, (float*)y, n, h, w, c);
     else if (dtype == UPS_F16) hipLaunchKernelGGL(bilinear2x_fwd_kernel<f16>, dim3(grid_for(work)), dim3(256), 0, s, (const f16*)x, (f16*)y, n, h, w, c);
     else hipLaunchKernelGGL(bilinear2x_fwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w, c);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_bilinear2x_fwd_act(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t act,
+                                      float slope, void* stream) {
+    UPS_CHECK_ARG(x && y && c % 8 == 0 && slope >= 0.f && slope <= 1.f && act >= UPS_ACT_NONE && act <= UPS_ACT_RELU);
+    const long long work = (long long)n * h * w * (c / (dtype == UPS_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    const float ons = act == UPS_ACT_NONE ? -1.f : (act == UPS_ACT_LRELU ? slope : 0.f);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(bilinear2x_fwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)x, (float*)y, n, h, w, c, F8Emit(), ons);
+    else if (dtype == UPS_F16) hipLaunchKernelGGL(bilinear2x_fwd_kernel<f16>, dim3(grid_for(work)), dim3(256), 0, s, (const f16*)x, (f16*)y, n, h, w, c, F8Emit(), ons);
+    else hipLaunchKernelGGL(bilinear2x_fwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w, c, F8Emit(), ons);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

@@ -36,7 +36,8 @@ class ConvDesc(C.Structure):
                 ("mask_bits", C.c_void_p), ("mask_batch", C.c_int32), ("mask_grad", C.c_void_p), ("mask_view", C.c_void_p),
                 ("f8_deq", C.c_void_p), ("f8_scale", C.c_void_p), ("f8_amax", C.c_void_p), ("f8_e5m2", C.c_int32),
                 ("in_f8", C.c_void_p), ("out_f8", C.c_void_p), ("out_f8_scale", C.c_void_p), ("out_f8_amax", C.c_void_p),
-                ("out_f8_act", C.c_int32), ("out_f8_e5m2", C.c_int32), ("d2s", C.c_int32)]
+                ("out_f8_act", C.c_int32), ("out_f8_e5m2", C.c_int32), ("d2s", C.c_int32),
+                ("out_act", C.c_int32), ("res_act", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -87,6 +88,7 @@ _SIGS = {
     "ups_col_sum": ([_P, _I, _L, _I, _I, _P, _P, _P], C.c_int),
     "ups_bilinear2x_fwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "ups_bilinear2x_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "ups_bilinear2x_fwd_act": ([_P, _P, _I, _I, _I, _I, _I, _I, _F, _P], C.c_int),
     "ups_bilinear2x_fwd_f8": ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _I, _P], C.c_int),
     "ups_bilinear2x_bwd_f8": ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "ups_act_mean_fwd": ([_P, _P, _I, _I, _I, _I, _I, _F, _P], C.c_int),

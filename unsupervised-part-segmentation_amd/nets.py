@@ -7,6 +7,7 @@ every ``activate`` is folded into the load of the consuming convolution and Coor
 affine epilogue, so no activated / coordinate-augmented tensor is ever written to HBM.
 """
 import math
+import os
 import zlib
 from collections import OrderedDict
 
@@ -93,11 +94,12 @@ class ParamBank(object):
 
 class Act(object):
     """Activation handle: tensor (None in the shape-only dry run) + logical channel count."""
-    __slots__ = ("t", "n", "h", "w", "c", "mask", "f8", "fmt")
+    __slots__ = ("t", "n", "h", "w", "c", "mask", "f8", "fmt", "post")
 
-    def __init__(self, t, n, h, w, c, mask=None, f8=None, fmt=None):
+    def __init__(self, t, n, h, w, c, mask=None, f8=None, fmt=None, post=False):
         # fmt = L.F16: `t` holds fp16 in a bf16 container (ops.py module docstring); None: what t.dtype says
-        self.fmt = fmt
+        # post: `t` holds act(x) of its scope's activation instead of x (post-activation storage, ops.ConvLayer.in_post)
+        self.fmt, self.post = fmt, post
         # mask = (hard, hard_bits, view_f32): `t` is the unmasked view [B,h,w,8] and the handle stands for the n = P*B
         # part images view[b] * hard[b,:,:,p] that the first convolution forms while it loads (ops.conv)
         # f8 = the fp8 copy of act(t) its producer wrote (ops.Fp8: {"t", "act", "slot"}) or None
@@ -113,7 +115,7 @@ class Scope(object):
         self.counter = 0
         self.fmt = fmt               # L.F16: every tensor of this scope's forward pass is fp16 (the mask decoder)
 
-    def _layer(self, cin, cout, k, stride, act_in):
+    def _layer(self, cin, cout, k, stride, act_in, in_post=False, out_act=L.ACT_NONE):
         name = "{}/conv2d_{}".format(self.prefix, self.counter)
         self.counter += 1
         own = self.owner
@@ -123,52 +125,69 @@ class Scope(object):
             own.specs[name + "/V"] = ((k, k, cin_v, cout), bound)
             own.specs[name + "/b"] = ((cout,), bound)
             return None
-        key = (name, act_in)
+        key = (name, act_in, in_post, out_act)
         lay = own.layers.get(key)
         if lay is None:
             lay = ConvLayer(name, own.bank.params[name + "/V"], own.bank.params[name + "/b"], k, stride, self.coords, act_in)
             lay.grad_V, lay.grad_b = own.bank.grads[name + "/V"], own.bank.grads[name + "/b"]
             lay.registry = own.prep
             lay.f16 = self.fmt == L.F16
+            lay.in_post, lay.out_act = in_post, out_act
             own.layers[key] = lay
         return lay
 
-    def conv2d(self, x, cout, k=3, stride=1, act_in=L.ACT_NONE, res=None, res_self=False, out_f32=False):
-        lay = self._layer(x.c, cout, k, stride, act_in)
+    def post_ok(self):
+        """Post-activation storage is used for leaky-ReLU scopes (the residual must be recoverable from act(x)); not in fp8 mode
+        (its producers quantise act(out) themselves) and not when switched off (`post_activation_storage: False`, A/B runs)."""
+        return self.act == L.ACT_LRELU and not ops.Fp8.enabled and self.owner.post_storage
+
+    def conv2d(self, x, cout, k=3, stride=1, act_in=L.ACT_NONE, res=None, res_self=False, out_f32=False, post=False):
+        """post: store the output as act(out) -- its only convolution consumer is a residual block / an activated nin of THIS
+        scope (the builders below say so); the consumer then runs with the activation already applied."""
+        post = bool(post) and self.post_ok() and not out_f32
+        in_post = bool(x.post)
+        if in_post and act_in != self.act:
+            raise L.UpsError("{}: a post-activation tensor feeds a convolution that wants {}".format(self.prefix, act_in))
+        lay = self._layer(x.c, cout, k, stride, act_in, in_post, self.act if post else L.ACT_NONE)
         ho, wo = ops.same_geometry(x.h, k, stride)[0], ops.same_geometry(x.w, k, stride)[0]
         if lay is None:
-            return Act(None, x.n, ho, wo, cout, fmt=None if out_f32 else self.fmt)
+            return Act(None, x.n, ho, wo, cout, fmt=None if out_f32 else self.fmt, post=post)
         if ops.Fp8.enabled:     # hand the input's fp8 copy in, ask for one of the output (consumed with this scope's activation)
             ops.Fp8.next_in, ops.Fp8.next_out_act, ops.Fp8.last_out = x.f8, self.act, None
         assert x.fmt == self.fmt and (res is None or res.fmt == self.fmt), "tensor format does not match the scope's"
-        t = ops.conv(x.t, lay, res=None if res is None else res.t, res_self=res_self, out_f32=out_f32, mask=x.mask, fmt=self.fmt)
+        t = ops.conv(x.t, lay, res=None if res is None else res.t, res_self=res_self, out_f32=out_f32, mask=x.mask, fmt=self.fmt,
+                     res_post=bool(res is not None and res.post))
         f8 = ops.Fp8.last_out if ops.Fp8.enabled else None
         ops.Fp8.last_out = None
-        return Act(t, x.n, ho, wo, cout, f8=f8, fmt=None if out_f32 else self.fmt)
+        return Act(t, x.n, ho, wo, cout, f8=f8, fmt=None if out_f32 else self.fmt, post=post)
 
     def nin(self, x, cout, **kw):
         return self.conv2d(x, cout, k=1, **kw)
 
-    def downsample(self, x, cout):
-        return self.conv2d(x, cout, k=3, stride=2)
+    def downsample(self, x, cout, post=False):
+        return self.conv2d(x, cout, k=3, stride=2, post=post)
 
-    def residual_block(self, x, skipin=None, k=3):
-        """x + conv(act(x [++ nin(act(skip))]))  (nn.py:1042-1056, dropout keep_prob = 1)."""
+    def residual_block(self, x, skipin=None, k=3, post=False):
+        """x + conv(act(x [++ nin(act(skip))]))  (nn.py:1042-1056, dropout keep_prob = 1).  post: see conv2d."""
         if skipin is None:
-            return self.conv2d(x, x.c, k=k, act_in=self.act, res_self=True)
-        s = self.nin(skipin, x.c, act_in=self.act)
+            return self.conv2d(x, x.c, k=k, act_in=self.act, res_self=True, post=post)
+        s = self.nin(skipin, x.c, act_in=self.act, post=x.post)        # the concatenated operand is in ONE storage form
         if x.t is None:
-            cat = Act(None, x.n, x.h, x.w, 2 * x.c, fmt=self.fmt)
+            cat = Act(None, x.n, x.h, x.w, 2 * x.c, fmt=self.fmt, post=x.post)
         else:
-            assert x.c % 8 == 0
-            cat = Act(torch.cat([x.t, s.t], dim=-1), x.n, x.h, x.w, 2 * x.c, fmt=self.fmt)
-        return self.conv2d(cat, x.c, act_in=self.act, res=x)
+            assert x.c % 8 == 0 and s.post == x.post
+            cat = Act(torch.cat([x.t, s.t], dim=-1), x.n, x.h, x.w, 2 * x.c, fmt=self.fmt, post=x.post)
+        return self.conv2d(cat, x.c, act_in=self.act, res=x, post=post)
 
-    def upsample_linear(self, x):
+    def upsample_linear(self, x, post=False):
+        post = bool(post) and self.post_ok()
+        if x.post:
+            raise L.UpsError("{}: bilinear up-sampling of a post-activation tensor".format(self.prefix))
         if x.t is None:
-            return Act(None, x.n, 2 * x.h, 2 * x.w, x.c, fmt=self.fmt)
+            return Act(None, x.n, 2 * x.h, 2 * x.w, x.c, fmt=self.fmt, post=post)
         if not ops.Fp8.enabled or self.fmt == L.F16:
-            return Act(ops.BilinearFn.apply(x.t, None, 0, 0.2, self.fmt), x.n, 2 * x.h, 2 * x.w, x.c, fmt=self.fmt)
+            return Act(ops.BilinearFn.apply(x.t, None, 0, 0.2, self.fmt, self.act if post else 0), x.n, 2 * x.h, 2 * x.w, x.c,
+                       fmt=self.fmt, post=post)
         # fp8: the up-sampled tensor feeds this scope's next convolution -- hand it an e4m3 copy of act(y) (and, backwards, the
         # convolution below an e5m2 copy of the gradient); per-call-site scale slots live with the model
         sites = self.owner.__dict__.setdefault("f8_sites", {})
@@ -182,18 +201,20 @@ class Scope(object):
         assert self.fmt is None, "act_mean has no fp16 form"
         if x.t is None:
             return Act(None, x.n, 1, 1, x.c)
-        return Act(ops.ActMeanFn.apply(x.t, self.act, 0.2), x.n, 1, 1, x.c)
+        return Act(ops.ActMeanFn.apply(x.t, self.act, 0.2, bool(x.post)), x.n, 1, 1, x.c)
 
 
 def encoder_model(sc, x, out_size, config, extra_resnets, out_f32=False):
-    """model.py:38-54."""
-    h = sc.conv2d(x, config[0])
-    h = sc.residual_block(h)
-    for nf in config[1:]:
-        h = sc.downsample(h, nf)
-        h = sc.residual_block(h)
+    """model.py:38-54.  (`post=True`: the tensor's only convolution consumer is an activated one of this scope -- a residual
+    block or the activate + mean at the end -- so it is stored post-activation, Scope.conv2d.)"""
+    h = sc.conv2d(x, config[0], post=True)
+    last = len(config) == 1
+    h = sc.residual_block(h, post=last)                       # feeds a downsample (plain) unless it is the last level
+    for li, nf in enumerate(config[1:]):
+        h = sc.downsample(h, nf, post=True)
+        h = sc.residual_block(h, post=li == len(config) - 2)
     for _ in range(extra_resnets):
-        h = sc.residual_block(h)
+        h = sc.residual_block(h, post=True)
     h = sc.act_mean(h)
     return sc.nin(h, out_size, out_f32=out_f32)
 
@@ -212,12 +233,12 @@ def single_decoder_model(sc, z, n_out, config, upsample_config, out_f32=True):
         h = Act(h.t.view(h.n, 4, 4, c), h.n, 4, 4, c, fmt=h.fmt)
     else:
         h = Act(None, h.n, 4, 4, c, fmt=h.fmt)
-    h = sc.conv2d(h, c)
-    h = sc.residual_block(h)
+    h = sc.conv2d(h, c, post=True)
+    h = sc.residual_block(h, post=True)                       # next: a residual block in either case
     for _nf, _u in zip(config[-2::-1], upsample_config[-1::-1]):
-        h = sc.residual_block(h)
-        h = sc.upsample_linear(h)
-    h = sc.residual_block(h)
+        h = sc.residual_block(h)                              # next: the (linear) up-sampling
+        h = sc.upsample_linear(h, post=True)
+    h = sc.residual_block(h)                                  # next: the plain output convolution
     return sc.conv2d(h, n_out, out_f32=out_f32)
 
 
@@ -226,17 +247,18 @@ def hourglass_model(sc, x, config, extra_resnets, n_out=3, upsample_method="subp
     if upsample_method != "linear":
         raise NotImplementedError("only upsample method 'linear' is on the shipped path")
     hs = []
-    h = sc.conv2d(x, config[0])
-    h = sc.residual_block(h)
-    for nf in config[1:]:
-        h = sc.downsample(h, nf)
-        h = sc.residual_block(h)
+    h = sc.conv2d(x, config[0], post=True)
+    # (a block's output that also feeds a downsample keeps the plain form; the skip nin then activates on load)
+    h = sc.residual_block(h, post=len(config) == 1)
+    for li, nf in enumerate(config[1:]):
+        h = sc.downsample(h, nf, post=True)
+        h = sc.residual_block(h, post=li == len(config) - 2)
         hs.append(h)
     for _ in range(extra_resnets):
-        h = sc.residual_block(h)
+        h = sc.residual_block(h, post=True)
     for i, _nf in enumerate(config[-2::-1]):
         h = sc.residual_block(h, skipin=hs[-(i + 1)])
-        h = sc.upsample_linear(h)
+        h = sc.upsample_linear(h, post=True)
     h = sc.residual_block(h)
     return sc.conv2d(h, n_out)
 
@@ -245,9 +267,9 @@ def discriminator_towers(sc, pair):
     """model.py:159-173 up to the two 512-d embeddings (the dot product is done by the caller)."""
     outs = []
     for z in pair:
-        h = sc.nin(z, DSIZE)
+        h = sc.nin(z, DSIZE, post=True)
         for _ in range(4):
-            h = sc.residual_block(h, k=1)
+            h = sc.residual_block(h, k=1, post=True)
         h = sc.nin(h, DSIZE, act_in=sc.act)
         outs.append(h)
     return outs
@@ -269,6 +291,9 @@ class Nets(object):
         if md in ("fp16", "f16", "half") and prec not in ("bf16", "bfloat16"):
             raise ValueError("mask_decoder_dtype: fp16 needs precision: bf16")
         self.scope_fmt = {"decoder_visualize": L.F16} if md in ("fp16", "f16", "half") else {}
+        # `post_activation_storage` (default on): tensors whose only convolution consumer activates them are stored as act(x)
+        # (Scope.conv2d); False restores activation-on-load everywhere (A/B runs, debugging)
+        self.post_storage = bool(config.get("post_activation_storage", os.environ.get("UPS_POST_ACT", "1") != "0"))
         S = config["spatial_size"]
         Z, A, P = config.get("z0_size", 256), config.get("local_app_size", 64), config["n_parts"]
         img = Act(None, 1, S, S, 3)
@@ -343,7 +368,7 @@ class VggTrunk(object):
     the ImageNet weights are not obtainable offline, so He-normal stand-ins are generated per name --
     ``load`` accepts real Keras kernels in HWIO)."""
 
-    def __init__(self, device, seed=7, widths=VGG_WIDTHS, depths=VGG_DEPTHS):
+    def __init__(self, device, seed=7, widths=VGG_WIDTHS, depths=VGG_DEPTHS, post_storage=True):
         self.depths = depths
         self.layers = []
         cin = 3
@@ -357,6 +382,9 @@ class VggTrunk(object):
                 first = bi == 0 and ci == 0
                 lay = ConvLayer(name, V, b, 3, 1, False, L.ACT_NONE if first else L.ACT_RELU)
                 lay.frozen = True
+                if post_storage:     # every feature map is stored as relu(y): the next convolution stages it untouched (LDS-DMA
+                    lay.out_act = L.ACT_RELU          # patch); the 2x2 max-pool commutes with ReLU, the L1 terms re-apply it
+                    lay.in_post = not first           # (idempotent), act' is read off the sign either way
                 blk.append(lay)
                 cin = wd
             self.layers.append(blk)

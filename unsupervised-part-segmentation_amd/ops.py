@@ -321,6 +321,11 @@ class ConvLayer(object):
         self.after_wgrad = None     # optional callback run right after this layer's weight gradient has been enqueued
         self.registry = None        # PrepRegistry of the owning model (batched refresh) or None (lazy per-layer prep)
         self.f16 = False            # forward tensors of this layer are fp16 (nets.Scope.fmt)
+        # post-activation storage (ups_conv_desc.out_act / res_act): in_post = the input tensor already holds act_in(x) -- the
+        # forward and the weight gradient stage it as it is (LDS-DMA patch), the input gradient still reads act' off its sign;
+        # out_act = the output is stored as out_act(y) because its consumer would apply that activation on load
+        self.in_post = False
+        self.out_act = L.ACT_NONE
         self._cache = {}
 
     # ---- converted weights (refreshed when the optimizer has stepped)
@@ -460,7 +465,7 @@ def _attach_ws(d, device):
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
 
 
-def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask=None, fmt=None):
+def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask=None, fmt=None, res_post=False):
     """out = conv(act(x) (+coords), V) + b (+ res);  x [n,hi,wi,ldi].
     fmt = L.F16: x, res and (unless out_f32) out hold fp16 in bf16 containers (module docstring).
     mask = (hard_bits [B,hi,wi] int32, P): x is the UNMASKED view [B,hi,wi,ldi] and the convolution runs on the P*B part images
@@ -485,7 +490,10 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
     dy, dx, tw = layer.fwd_taps(hi, wi)
     _fill_taps(d, dy, dx, tw, layer.k * layer.k)
     d.kh = d.kw = layer.k
-    d.act_in, d.act_slope, d.out_f32, d.dact_kind = layer.act_in, layer.slope, int(out_f32), 0
+    d.act_in, d.act_slope, d.out_f32, d.dact_kind = (L.ACT_NONE if layer.in_post else layer.act_in), layer.slope, int(out_f32), 0
+    d.out_act = layer.out_act
+    d.res_act = layer.act_in if (res is not None and res_post) else L.ACT_NONE       # residual stored as act(x): inverted in the epilogue
+    assert not (d.res_act and layer.act_in != L.ACT_LRELU), "only a leaky-ReLU residual can be stored post-activation"
     d.ldr = res.shape[-1] if res is not None else 0
     d.ldd = 0
     d.in_, d.w, d.out = x.data_ptr(), ent["w_fwd"].data_ptr(), out.data_ptr()
@@ -689,7 +697,7 @@ def conv_wgrad(g, x, layer, mask=None, fmt=None):
     d.in_sy = d.in_sx = layer.stride
     dy, dx, tw = layer.fwd_taps(hi, wi)
     _fill_taps(d, dy, dx, tw, layer.k * layer.k)
-    d.act_in, d.act_slope = layer.act_in, layer.slope
+    d.act_in, d.act_slope = (L.ACT_NONE if layer.in_post else layer.act_in), layer.slope
     sk, wsb = C.c_int32(0), C.c_size_t(0)
     d.in_, d.dout, d.grad, d.grad_bias = x.data_ptr(), g.data_ptr(), gV.data_ptr(), gb.data_ptr()
     if mask is not None:
@@ -741,13 +749,15 @@ class ConvFn(torch.autograd.Function):
     """res_mode 0: plain; 1: out = res + conv(x); 2: out = x + conv(act(x)) (residual_block, nn.py:1042-1056)."""
 
     @staticmethod
-    def forward(ctx, x, V, b, res, layer, res_mode, out_f32, ldo, hard=None, hard_bits=None, view_f32=None, fmt=None):
+    def forward(ctx, x, V, b, res, layer, res_mode, out_f32, ldo, hard=None, hard_bits=None, view_f32=None, fmt=None, res_post=False):
         """hard / hard_bits / view_f32 given: the part-masked convolution (x = the unmasked view in the activation dtype,
         the P*B part images are formed in the kernel's load); the gradient w.r.t. `hard` comes out of the dgrad epilogue."""
         x = x.contiguous()
         r = x if res_mode == 2 else (res.contiguous() if res_mode == 1 else None)
         ctx.mask = None if hard is None else (hard_bits, hard.shape[-1])
-        out = conv_forward(x, layer, res=r, out_f32=out_f32, ldo=ldo, mask=ctx.mask, fmt=fmt)
+        # res_mode 2: the residual is the input itself -- stored post-activation exactly when the layer's input is
+        out = conv_forward(x, layer, res=r, out_f32=out_f32, ldo=ldo, mask=ctx.mask, fmt=fmt,
+                           res_post=layer.in_post if res_mode == 2 else bool(res_post))
         ctx.save_for_backward(x, view_f32)
         ctx.layer, ctx.res_mode, ctx.fmt = layer, res_mode, fmt
         return out
@@ -783,16 +793,17 @@ class ConvFn(torch.autograd.Function):
             # the autograd engine may accumulate other branches into the returned tensor IN PLACE; the side stream
             # is still reading g, so hand out a copy in that case
             gres = g.clone() if offloaded else g
-        return gx, gV, gb, gres, None, None, None, None, g_hard, None, None, None
+        return gx, gV, gb, gres, None, None, None, None, g_hard, None, None, None, None
 
 
-def conv(x, layer, res=None, res_self=False, out_f32=False, ldo=None, mask=None, fmt=None):
-    """mask = (hard [B,H,W,P] fp32 autograd leaf, hard_bits [B,H,W] int32, view_f32 [B,H,W,3]): part-masked convolution."""
+def conv(x, layer, res=None, res_self=False, out_f32=False, ldo=None, mask=None, fmt=None, res_post=False):
+    """mask = (hard [B,H,W,P] fp32 autograd leaf, hard_bits [B,H,W] int32, view_f32 [B,H,W,3]): part-masked convolution.
+    res_post: `res` is stored post-activation (ups_conv_desc.res_act)."""
     mode = 2 if res_self else (1 if res is not None else 0)
     if mask is None:
-        return ConvFn.apply(x, layer.V, layer.b, res, layer, mode, out_f32, ldo, None, None, None, fmt)
+        return ConvFn.apply(x, layer.V, layer.b, res, layer, mode, out_f32, ldo, None, None, None, fmt, res_post)
     assert mode == 0
-    return ConvFn.apply(x, layer.V, layer.b, None, layer, 0, out_f32, ldo, mask[0], mask[1], mask[2].contiguous(), None)
+    return ConvFn.apply(x, layer.V, layer.b, None, layer, 0, out_f32, ldo, mask[0], mask[1], mask[2].contiguous(), None, False)
 
 
 def masked_conv_eligible(dtype, size, n_parts):
@@ -805,10 +816,17 @@ class BilinearFn(torch.autograd.Function):
     writes the e4m3 copy of act(y), its backward the e5m2 copy of the gradient it returns (ops.Fp8 hand-off)."""
 
     @staticmethod
-    def forward(ctx, x, site=None, act=0, slope=0.2, fmt=None):
+    def forward(ctx, x, site=None, act=0, slope=0.2, fmt=None, out_act=0):
+        """out_act: the result is stored as out_act(y) (post-activation storage for a consuming residual block; gradients stay
+        with respect to y, so the backward is unchanged)."""
         x = x.contiguous()
         n, h, w, c = x.shape
         y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+        if out_act:
+            assert site is None or not Fp8.enabled
+            L.call("ups_bilinear2x_fwd_act", L.ptr(x), L.ptr(y), L.dt(x) if fmt is None else fmt, n, h, w, c, out_act, slope, L.stream())
+            ctx.site, ctx.shape = None, (n, h, w, c)
+            return y
         f8 = fmt != L.F16 and site is not None and Fp8.enabled and Fp8.PRODUCER and x.dtype == torch.bfloat16 and c % 64 == 0 and (2 * h) % 16 == 0
         ctx.site = site if f8 else None
         if f8 and "fwd" not in site:
@@ -851,16 +869,17 @@ class BilinearFn(torch.autograd.Function):
                 Fp8.register_grad_copy(gx, {"t": t8, "slot": so["slot"], "site": so})
         else:
             L.call("ups_bilinear2x_bwd", L.ptr(g), L.ptr(gx), L.dt(g), n, h, w, c, L.stream())
-        return gx, None, None, None, None
+        return gx, None, None, None, None, None
 
 
 class ActMeanFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, act, slope):
+    def forward(ctx, x, act, slope, post=False):
+        """post: x already holds act(x) (post-activation storage): plain mean forward, act' from its sign backward."""
         x = x.contiguous()
         n, h, w, c = x.shape
         y = torch.empty((n, 1, 1, c), dtype=x.dtype, device=x.device)
-        L.call("ups_act_mean_fwd", L.ptr(x), L.ptr(y), L.dt(x), n, h * w, c, act, slope, L.stream())
+        L.call("ups_act_mean_fwd", L.ptr(x), L.ptr(y), L.dt(x), n, h * w, c, L.ACT_NONE if post else act, slope, L.stream())
         ctx.save_for_backward(x)
         ctx.act, ctx.slope = act, slope
         return y
@@ -872,7 +891,7 @@ class ActMeanFn(torch.autograd.Function):
         g = g.contiguous()
         gx = torch.empty_like(x)
         L.call("ups_act_mean_bwd", L.ptr(x), L.ptr(g), L.ptr(gx), L.dt(x), n, h * w, c, ctx.act, ctx.slope, L.stream())
-        return gx, None, None
+        return gx, None, None, None
 
 
 class MaxPoolFn(torch.autograd.Function):
