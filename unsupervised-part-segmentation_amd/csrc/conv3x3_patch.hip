@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     unsigned pd_off[3] = {0u, 0u, 0u};
     unsigned long long pd_mask[3] = {0ull, 0ull, 0ull};
     if constexpr (DMAP) {
-        static_assert(SUB == TS && OCC == 2 && F8 == 0 && sizeof(T) == 2, "DMA patch: one tile per image, two blocks per CU, 16-bit tensors");
+        static_assert(SUB == TS && F8 == 0 && sizeof(T) == 2, "DMA patch: one tile per image, 16-bit tensors");
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int pp = (wid + 8 * q) * 16 + (lane >> 2), sl = lane & 3;
@@ -294,8 +294,12 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             pd_off[q] = (unsigned)(py * p.w + px) * ((unsigned)p.ldi * 2u) + (unsigned)((sl ^ a_swz16(px)) << 4);
             pd_mask[q] = __ballot(ok);
         }
-        for (int i = tid * 16; i < ABY; i += 512 * 16) *(uint4*)(Abuf + i) = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
+        // halo slots outside the image are never written by the DMA: zero the patch buffer(s) once, on border tiles only
+        if (ty0 == 0 || tx0 == 0 || ty0 + TS >= p.h || tx0 + TS >= p.w) {
+            const int nab = (kchunks == 1 || OCC == 2) ? 1 : 2;
+            for (int i = tid * 16; i < nab * ABY; i += 512 * 16) *(uint4*)(Abuf + i) = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+        }
     }
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     uint4 ra0, ra1, ra2;
@@ -529,13 +533,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             }
         };
         const unsigned char* __restrict__ in_b = (const unsigned char*)(in + (long long)origin * p.ldi);
-        auto dma_patch = [&](int cc) __attribute__((always_inline)) {
+        auto dma_patch = [&](int cc, int boff = 0) __attribute__((always_inline)) {
             if constexpr (DMAP) {
                 const unsigned char* base = in_b + cc * 64;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     if (wid + 8 * q >= (PW * PWPS + 15) / 16) continue;        // piece 23 of 22.5 (wave-uniform)
-                    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((wid + 8 * q) * 1024));
+                    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(boff + (wid + 8 * q) * 1024));
 #if !defined(UPS_ABLATE_GLOAD)
                     asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
                                  :: "s"(pd_mask[q]), "s"(lds_dst), "v"(pd_off[q]), "s"(base) : "memory", "m0");
@@ -600,11 +604,22 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const int cc = it / 3, g = it - cc * 3;
             const int n2 = it + 2, n1 = it + 1;
             if (n2 < total) {
-                if (n2 % 3 == 0) load_patch(n2 / 3);     // register loads first: they stay OLDER than this tap-row's DMAs
+                // the patch first (register loads, or DMA pieces straight into the buffer chunk n2/3 will be read from -- free
+                // since chunk n2/3 - 2): it stays OLDER than this tap-row's weight DMAs, so the counted wait below covers it
+                if (n2 % 3 == 0) {
+                    if constexpr (DMAP) dma_patch(n2 / 3, ((n2 / 3) & 1) * ABY);
+                    else load_patch(n2 / 3);
+                }
                 dma_w(n2);
             }
             const unsigned char* A = Abuf + (cc & 1) * ABY;
             const unsigned char* B = Bst + (it % 3) * BST + (wn * TN * 32) * 64 + boff16;
+            if constexpr (TAPS != 0) {
+                const int po0 = ((TAPS == 1 ? g : 2 - g) * PWPS + (TAPS == 1 ? 0 : 2)) * APX;
+                bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po0 + (TAPS == 1 ? APX : -APX),
+                                        po0 + (TAPS == 1 ? 2 * APX : -2 * APX), TAPS == 1 ? swx0 : swx2, swx1, TAPS == 1 ? swx2 : swx0,
+                                        BN * 64, acc16);
+            } else {
             const int dx0 = p_dx(p.tap_off, 3 * g) + 1, dx1 = p_dx(p.tap_off, 3 * g + 1) + 1, dx2 = p_dx(p.tap_off, 3 * g + 2) + 1;
             const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
             const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
@@ -612,10 +627,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
+            }
 #if !defined(UPS_ABLATE_LSTORE)
             // (the activation patch goes through registers for the fused activation / zero padding; hipcc waits
             // vmcnt(0) for it, which also drains the DMAs once per channel chunk -- measured cost ~0.2 ms of 3.2 ms)
-            if (n1 < total && n1 % 3 == 0) store_patch(Abuf + ((n1 / 3) & 1) * ABY);
+            if constexpr (!DMAP) { if (n1 < total && n1 % 3 == 0) store_patch(Abuf + ((n1 / 3) & 1) * ABY); }
 #endif
             // the weights of tap-row it+1 must have landed; the NW DMAs of tap-row it+2 may stay in flight
             if (n2 < total) {
@@ -1016,6 +1032,20 @@ int launch_small(const PatchK& k, hipStream_t s) {
     return launch_bn<T, 32, 1, SUB>(k, s);
 }
 
+// one tile per image, bf16 / fp16, no fp8: the variant with the static tap geometry and, where the input needs nothing done to it
+// on the way (no activation-on-load, no part mask, whole 32-channel chunks), the halo patch by LDS-DMA
+template <typename T, int BN, int OCC>
+int launch_v(const PatchK& k, hipStream_t s) {
+    const bool dmap = dma_patch_on() && k.act_in == UPS_ACT_NONE && !k.mask && !k.mask_grad && k.ci % 32 == 0;
+    if (static_taps_on() && dmap) {
+        if (k.taps_static == 1) return launch_bn<T, BN, OCC, TS, 0, false, 1, true>(k, s);
+        if (k.taps_static == 2) return launch_bn<T, BN, OCC, TS, 0, false, 2, true>(k, s);
+    }
+    // (without the DMA patch only the forward order of the widest two-blocks-per-CU instance has a static form: the others spill)
+    if (static_taps_on() && k.taps_static == 1 && BN == 128 && OCC == 2) return launch_bn<T, BN, OCC, TS, 0, false, (BN == 128 && OCC == 2) ? 1 : 0>(k, s);
+    return launch_bn<T, BN, OCC, TS>(k, s);
+}
+
 template <typename T>
 int launch_t(const PatchK& k, hipStream_t s) {
     if (k.h == 8) return launch_small<T, 8>(k, s);
@@ -1048,25 +1078,17 @@ int launch_t(const PatchK& k, hipStream_t s) {
         // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv) use 64-wide tiles and one patch buffer
         const int tiles = k.n * (k.w / TS) * (k.h / TS);
         if (k.co_fill > 64 && k.ci > 32) {
-            if (patch_occ() == 2 && !k.out_f8_amax && tiles * ups_cdiv(k.co_fill, 128) >= 512) {
-                const bool dmap = dma_patch_on() && k.act_in == UPS_ACT_NONE && !k.mask && !k.mask_grad && k.ci % 32 == 0;
-                if (k.taps_static == 1 && static_taps_on())
-                    return dmap ? launch_bn<T, 128, 2, TS, 0, false, 1, true>(k, s) : launch_bn<T, 128, 2, TS, 0, false, 1>(k, s);
-                // (flipped order without the DMA patch -- ragged channel counts -- keeps the descriptor-driven loop: its static
-                // form spills)
-                if (k.taps_static == 2 && static_taps_on() && dmap) return launch_bn<T, 128, 2, TS, 0, false, 2, true>(k, s);
-                return launch_bn<T, 128, 2, TS>(k, s);
-            }
+            if (patch_occ() == 2 && !k.out_f8_amax && tiles * ups_cdiv(k.co_fill, 128) >= 512) return launch_v<T, 128, 2>(k, s);
             // a grid of one 128-wide block per CU: 64-wide tiles put two blocks on every CU instead (4 waves per SIMD)
             static int mid = -1;
             if (mid < 0) { const char* e = getenv("UPS_PATCH_MID"); mid = (e && e[0] == '0') ? 0 : 1; }
-            if (mid && patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 64) >= 512) return launch_bn<T, 64, 2, TS>(k, s);
-            return launch_bn<T, 128, 1, TS>(k, s);
+            if (mid && patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 64) >= 512) return launch_v<T, 64, 2>(k, s);
+            return launch_v<T, 128, 1>(k, s);
         }
         if (k.co_fill > 32)
-            return (patch_occ() == 2 && k.ci > 32 && tiles * ups_cdiv(k.co_fill, 64) >= 512) ? launch_bn<T, 64, 2, TS>(k, s)
-                                                                                              : launch_bn<T, 64, 1, TS>(k, s);
-        return launch_bn<T, 32, 1, TS>(k, s);
+            return (patch_occ() == 2 && k.ci > 32 && tiles * ups_cdiv(k.co_fill, 64) >= 512) ? launch_v<T, 64, 2>(k, s)
+                                                                                              : launch_v<T, 64, 1>(k, s);
+        return launch_v<T, 32, 1>(k, s);
     } else {
         if (k.co_fill > 64) return launch_bn<T, 128, 1, TS>(k, s);
         if (k.co_fill > 32) return launch_bn<T, 64, 1, TS>(k, s);
