@@ -836,8 +836,8 @@ class Trainer(object):
             h = D.allreduce_bucket(grp["flat"]["g"][off:], trainer.world_size, trainer.process_group)
             trainer._early["encoder_0"] = (off, h)
 
-        for (name, _act), lay in self.model.nets.layers.items():
-            if name == prefix:
+        for key, lay in self.model.nets.layers.items():
+            if key[0] == prefix:
                 lay.after_wgrad = launch
 
     def _launch_reduce(self, key_list):
