@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--f16", action="store_true", help="fp16 forward tensors (the mask decoder's format): forward in fp16, gradients bf16")
+    ap.add_argument("--post", action="store_true", help="post-activation storage: the input holds act(x), the output is stored as act(y) "
+                    "(layers with an activation only)")
     ap.add_argument("--fp8", action="store_true", help="forward / input gradient of the eligible layers on the fp8 path (ops.Fp8)")
     ap.add_argument("--fp8-copy", action="store_true", help="with --fp8: the forward input arrives as the fp8 copy a producing layer "
                     "would have written (no conversion in the kernel, two blocks per CU)")
@@ -76,10 +79,18 @@ def main():
         V = (torch.randn(k, k, cin_v, cout, generator=g) / math.sqrt(cin_v * k * k)).to(dev)
         b = torch.randn(cout, generator=g).to(dev)
         lay = ops.ConvLayer(name + "/conv2d_0", V, b, k, stride, coords, act)
+        fmt = lib.F16 if (args.f16 and k == 3) else None
+        lay.f16 = fmt == lib.F16
+        if args.post and act == "leaky_relu":
+            lay.in_post, lay.out_act = True, lib.ACT_LRELU
         x = torch.randn(n, h, h, ops.round8(cin), device=dev).to(T)
         if ops.round8(cin) > cin:
             x[..., cin:] = 0
-        y = ops.conv_forward(x, lay)
+        if fmt == lib.F16:
+            x = x.to(torch.float16).view(torch.bfloat16)
+        res_self = act is not None and stride == 1 and cin == cout      # the residual blocks of the model
+        _fwd = lambda: ops.conv_forward(x, lay, res=x if res_self else None, fmt=fmt, res_post=lay.in_post)
+        y = _fwd()
         gy = torch.randn(y.shape, device=dev).to(T)
         ho = y.shape[1]
         flops = 2.0 * n * ho * ho * k * k * cin_v * cout
@@ -95,9 +106,11 @@ def main():
                 return ops.conv_forward(x, lay)
             tf = timeit(fwd, args.iters)
         else:
-            tf = timeit(lambda: ops.conv_forward(x, lay), args.iters)
-        td = timeit(lambda: ops.conv_dgrad(gy, x, lay), args.iters)
-        tw = timeit(lambda: ops.conv_wgrad(gy, x, lay), args.iters)
+            tf = timeit(_fwd, args.iters)
+        if fmt == lib.F16:
+            gy = torch.randn(y.shape, device=dev).to(T)
+        td = timeit(lambda: ops.conv_dgrad(gy, x, lay, res=gy if res_self else None), args.iters)
+        tw = timeit(lambda: ops.conv_wgrad(gy, x, lay, fmt=fmt), args.iters)
         tot[0] += tf; tot[1] += td; tot[2] += tw
         print("{:10s} {:9.3f} {:8.1f} {:9.3f} {:8.1f} {:9.3f} {:8.1f}".format(
             name, tf, flops / tf / 1e9, td, flops / td / 1e9, tw, flops / tw / 1e9))

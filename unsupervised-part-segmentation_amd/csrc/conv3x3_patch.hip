@@ -62,6 +62,11 @@ struct PatchK {
     int d2s, d2s_shift;
     int taps_static;      // 1: forward order, 2: flipped (input-gradient) order, 0: neither (launcher)
     int out_act, res_act; // post-activation storage (ups_conv_desc.out_act / res_act)
+    // the residual IS the input tensor (residual block, nn.py:1042-1056: res == in, same channel count): the 16x16 centre of
+    // the halo patch of channel chunk c holds exactly the residual values of output channels 32c .. 32c+31, so each wave adds
+    // its share into its accumulators straight from LDS while that chunk is resident -- the residual tensor is never read a
+    // second time from global memory and the epilogue needs no residual tile (launcher sets it; 16-bit, SUB == TS)
+    int res_patch;
 };
 
 __device__ __forceinline__ int fast_div(int n, int d, unsigned m) {
@@ -551,6 +556,38 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         const int swx0 = a_lane16 + ((q16 ^ a_swz16(px_l16 + 0)) << 4);
         const int swx1 = a_lane16 + ((q16 ^ a_swz16(px_l16 + 1)) << 4);
         const int swx2 = a_lane16 + ((q16 ^ a_swz16(px_l16 + 2)) << 4);
+        // residual from the resident patch (PatchK.res_patch): chunk cc = the output channels 32 (cc - c_first) .. +31 of this
+        // N-tile; wave wn owns CPW = TN16 / 2 of the tile's chunks; lane (p16, q16) adds the 4 channels 4 q16 .. of accumulator
+        // block (i, j) = pixel (tile row wm*TM16 + i, column p16): 8 bytes at patch pixel (row + 1, p16 + 1)
+        constexpr int CPW = TN16 / 2 > 0 ? TN16 / 2 : 1;
+        const int rp_first = nt * (BN / 32) + wn * CPW;
+        const int rp_lane = ((px_l16 + 1) * APX) + ((((q16 >> 1)) ^ a_swz16(px_l16 + 1)) << 4) + (q16 & 1) * 8;   // jj = 0; jj = 1: slot ^ 2
+        auto add_res_patch = [&](const unsigned char* A, int cc) __attribute__((always_inline)) {
+            if constexpr (DMAP && SUB == TS && TN16 >= 2) {     // (the conditions of res_patch are those of the DMA patch)
+                const int c2 = cc - rp_first;
+                if (p.res_patch && c2 >= 0 && c2 < CPW) {
+#pragma unroll
+                    for (int jh = 0; jh < CPW; ++jh) {
+                        if (jh != c2) continue;
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+                            for (int i = 0; i < TM16; ++i) {
+                                const uint2 rv = *(const uint2*)(A + (wm * TM16 + i + 1) * (PWPS * APX) + (rp_lane ^ (jj << 5)));
+                                float r0, r1, r2, r3;
+                                ups_unpack2<T>(rv.x, r0, r1); ups_unpack2<T>(rv.y, r2, r3);
+                                if (p.res_act) {
+                                    r0 = r0 > 0.f ? r0 : r0 * res_inv; r1 = r1 > 0.f ? r1 : r1 * res_inv;
+                                    r2 = r2 > 0.f ? r2 : r2 * res_inv; r3 = r3 > 0.f ? r3 : r3 * res_inv;
+                                }
+                                acc16[i][2 * jh + jj][0] += r0; acc16[i][2 * jh + jj][1] += r1;
+                                acc16[i][2 * jh + jj][2] += r2; acc16[i][2 * jh + jj][3] += r3;
+                            }
+                        }
+                    }
+                }
+            }
+        };
         if constexpr (DMAP) dma_patch(0);
         else { load_patch(0); store_patch(Abuf); }
         dma_w(0);
@@ -569,6 +606,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             }
             const unsigned char* A = Abuf;
             const unsigned char* B = Bst + (it % NST) * BST + (wn * TN * 32) * 64 + boff16;
+            if (g == 0) add_res_patch(A, cc);
             if constexpr (TAPS != 0) {
                 // static tap geometry: tap-row g reads patch rows g .. (forward) / 2-g .. (flipped), its three taps the column
                 // shifts 0, 1, 2 / 2, 1, 0: two scalar operations instead of the tap decode, loop-invariant lane terms
@@ -614,6 +652,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             }
             const unsigned char* A = Abuf + (cc & 1) * ABY;
             const unsigned char* B = Bst + (it % 3) * BST + (wn * TN * 32) * 64 + boff16;
+            if (g == 0) add_res_patch(A, cc);
             if constexpr (TAPS != 0) {
                 const int po0 = ((TAPS == 1 ? g : 2 - g) * PWPS + (TAPS == 1 ? 0 : 2)) * APX;
                 bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po0 + (TAPS == 1 ? APX : -APX),
@@ -719,7 +758,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     float of8_amax = 0.f;
     const float of8_s = (p.out_f8 && p.out_f8_scale) ? *p.out_f8_scale : 1.f;
     const float of8_ns = ups_slope_eff(p.out_f8_act, p.act_slope);
-    const T* __restrict__ res = (const T*)p.res;
+    const T* __restrict__ res = (DMAP && p.res_patch) ? nullptr : (const T*)p.res;
     const T* __restrict__ dact = (const T*)p.dact;
     // the block's first image as uniform (scalar) bases; tile pixel index (ty * 16 + tx) -> 32-bit pixel index from there
     // (the launcher checks that an image group stays below 2^31 bytes in every tensor)
@@ -1165,16 +1204,8 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     k.ldo = d->ldo; k.ldr = d->ldr; k.ldd = d->ldd; k.act_in = d->act_in; k.out_f32 = d->out_f32;
     k.dact_kind = d->dact_kind; k.has_ctab = d->coord_tab != nullptr; k.act_slope = d->act_slope;
     k.in = d->in; k.wgt = d->w; k.out = d->out; k.bias = d->bias; k.coord_tab = d->coord_tab; k.res = d->res; k.dact = d->dact;
-    k.out_act = d->out_act; k.res_act = d->res_act;
-    if ((d->out_act || d->res_act) && (d->out_f8 || d->out_f8_amax || d->mask_grad || d->d2s)) return 1;   // (no fp8 copy of a post-activation tensor)
-    k.tap_off = 0; k.tap_wi = 0;
-    for (int t = 0; t < 9; ++t) {
-        k.tap_off |= (unsigned long long)(((d->tap_dy[t] + 1) << 2) | (d->tap_dx[t] + 1)) << (4 * t);
-        k.tap_wi |= (unsigned long long)d->tap_w[t] << (4 * t);
-    }
-    if (d->dtype == UPS_F16 && (d->f8_deq || d->in_f8 || d->out_f8 || d->out_f8_amax || d->mask_bits || d->mask_grad || d->d2s)) return 1;
+    bool fwd = true, flip = true;
     {
-        bool fwd = true, flip = true;
         for (int t = 0; t < 9; ++t) {
             if (d->tap_w[t] != t) fwd = flip = false;
             if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1) fwd = false;
@@ -1182,6 +1213,24 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
         }
         k.taps_static = fwd ? 1 : (flip ? 2 : 0);
     }
+    k.out_act = d->out_act; k.res_act = d->res_act;
+    {   // residual block: res == in, channel chunk c <-> output channels 32c.. (no CoordConv channels are part of `in`), whole chunks,
+        // 16-bit, one tile per image, an N-tile of at least two 16-channel blocks per wave (BN >= 64 in launch_t's choice below)
+        static int rp_on = -1;
+        if (rp_on < 0) { const char* e = getenv("UPS_RES_PATCH"); rp_on = (e && e[0] == '0') ? 0 : 1; }
+        k.res_patch = rp_on && d->res && d->res == d->in && d->ldr == d->ldi && d->ci == d->co_fill && d->co == d->co_fill && d->ci % 32 == 0 &&
+                      d->dtype != UPS_F32 && !small && !d->dact && !d->mask_bits && !d->mask_grad && !d->d2s && !d->f8_deq && !d->out_f32 &&
+                      d->act_in == UPS_ACT_NONE &&    // (with activation-on-load the patch holds act(x), the residual wants x)
+                      dma_patch_on() && static_taps_on() && (fwd || flip);       // ... and only the DMA-patch instances implement it
+    }
+    if ((d->out_act || d->res_act) && (d->out_f8 || d->out_f8_amax || d->mask_grad || d->d2s)) return 1;   // (no fp8 copy of a post-activation tensor)
+    k.tap_off = 0; k.tap_wi = 0;
+    for (int t = 0; t < 9; ++t) {
+        k.tap_off |= (unsigned long long)(((d->tap_dy[t] + 1) << 2) | (d->tap_dx[t] + 1)) << (4 * t);
+        k.tap_wi |= (unsigned long long)d->tap_w[t] << (4 * t);
+    }
+    if (d->dtype == UPS_F16 && (d->f8_deq || d->in_f8 || d->out_f8 || d->out_f8_amax || d->mask_bits || d->mask_grad || d->d2s)) return 1;
+
     const int rc = (d->dtype == UPS_F32) ? launch_t<float>(k, s) : (d->dtype == UPS_F16 ? launch_t<f16>(k, s) : launch_t<bf16>(k, s));
     return rc == UPS_OK ? 0 : rc;
 }
