@@ -592,8 +592,36 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         else { load_patch(0); store_patch(Abuf); }
         dma_w(0);
         if (OCC != 2 && total > 1) dma_w(1);
+        // a single channel chunk on the 3-stage ring: all nine taps' weights fit the ring at once -- everything is requested
+        // up front, ONE wait + barrier, then the three tap-rows run back to back (the thin 128x128 layers of encoder_1 on the
+        // part images and the heads' input gradients are chains of load -> barrier round trips otherwise)
+        const bool one_shot = OCC != 2 && kchunks == 1;
+        if (one_shot) dma_w(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (one_shot) {
+            add_res_patch(Abuf, 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const unsigned char* B = Bst + g * BST + (wn * TN * 32) * 64 + boff16;
+                if constexpr (TAPS != 0) {
+                    const int po0 = ((TAPS == 1 ? g : 2 - g) * PWPS + (TAPS == 1 ? 0 : 2)) * APX;
+                    bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(Abuf, B, arow16, po0, po0 + (TAPS == 1 ? APX : -APX),
+                                            po0 + (TAPS == 1 ? 2 * APX : -2 * APX), TAPS == 1 ? swx0 : swx2, swx1, TAPS == 1 ? swx2 : swx0,
+                                            BN * 64, acc16);
+                } else {
+                    const int dx0 = p_dx(p.tap_off, 3 * g) + 1, dx1 = p_dx(p.tap_off, 3 * g + 1) + 1, dx2 = p_dx(p.tap_off, 3 * g + 2) + 1;
+                    const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
+                    const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
+                    const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
+                    bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(Abuf, B, arow16, po0, po1, po2,
+                                            a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4), a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
+                                            a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // (the epilogue reuses the buffers)
+        } else
         if constexpr (OCC == 2) {
         // two blocks per CU: prefetch distance 1 on a 2-stage ring, one patch buffer (re-staged behind an extra barrier at
         // each channel-chunk boundary); the stalls this exposes are covered by the other block's waves
