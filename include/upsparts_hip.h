@@ -257,6 +257,14 @@ int ups_sum_scale(const float* partial, int32_t n, float scale, float* out, int3
  * the compact form the part-masked convolution reads).  eps, hard, argmax, hard_bits may be NULL.  All fp32, [pixels][P]. */
 int ups_part_softmax_fwd(const float* mean, const float* eps, float* l, float* m, float* hard, int64_t* argmax,
                          uint32_t* hard_bits, int64_t pixels, int32_t P, void* stream);
+/* The same plus, from the same pass, the spatial soft-max moments of gamma * hard (the one-hot map has them in closed form from
+ * per-part integer sums of the hard pixels' coordinates): stats [n][P][8] as ups_spatial_moments(hard, gamma, no rectangle) writes
+ * them (M:437-440: the input of the rectangle centres).  mean is [n,h,w,P]; h*w must be a multiple of the kernel's pixel tile
+ * (else UPS_E_ARG: call ups_part_softmax_fwd + ups_spatial_moments); scratch: ups_part_softmax_moments_ints(n*h*w, P) int32. */
+size_t ups_part_softmax_moments_ints(int64_t pixels, int32_t P);
+int ups_part_softmax_moments_fwd(const float* mean, const float* eps, float* l, float* m, float* hard, int64_t* argmax,
+                                 uint32_t* hard_bits, int32_t n, int32_t h, int32_t w, int32_t P, float gamma, float* stats,
+                                 int32_t* scratch, void* stream);
 /* spatial soft-max moments (N:65-71, N:1541-1587) of gamma*x per (n,p) over H*W, optionally masked by
  * (1 - rect) with integer rectangle centres `rect_c` [n*P][2] (y,x) and half sizes:
  * stats[n][p] = {max, Z, sum e*k, sum e*k*gy, sum e*k*gx, sum e*k*(gy^2+gx^2), sum e*k*gy^2, 0},  e = exp(gamma*x - max) */

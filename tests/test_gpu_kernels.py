@@ -266,6 +266,35 @@ def test_bilinear_post_activation_output(dev):
         assert_close(yf, want.float(), tol, "bilinear with post-activation output {}".format(T))
 
 
+@pytest.mark.parametrize("shape", [(3, 16, 16, 3), (2, 32, 32, 10), (2, 128, 128, 25), (4, 64, 64, 10)])
+def test_hard_mask_moments_from_the_softmax_pass(shape, dev):
+    """ups_part_softmax_moments_fwd: the spatial soft-max moments of gamma * hard (the rectangle centres' input, M:437-441) in
+    closed form from integer sums taken while the hard mask is produced == ups_spatial_moments on the hard map (to fp32
+    rounding), identical integer centres, and the same l / m / hard / bit sets as the plain call."""
+    lib, ops, R = _mods()
+    n, h, w, P = shape
+    g = torch.Generator().manual_seed(31 + P)
+    mean = (torch.randn(n, h, w, P, generator=g) * 2).to(dev)
+    mean[0, :, :, P - 1] = -50.0                      # a part that owns no pixel in image 0
+    eps = torch.randn(n, h, w, P, generator=g).to(dev)
+    l0, m0, h0, _, b0 = ops.part_softmax(mean, eps, want_bits=True)
+    l1, m1, h1, _, b1, stats = ops.part_softmax(mean, eps, want_bits=True, moments_gamma=10.0)
+    assert stats is not None
+    assert torch.equal(l0, l1) and torch.equal(m0, m1) and torch.equal(h0, h1) and torch.equal(b0, b1)
+    ref = ops.spatial_moments(h0, 10.0)
+    for k in (1, 2, 3, 4, 5, 6):
+        assert_close(stats[..., k], ref[..., k], 1e-3, "hard-mask moment {} (vs the fp32 summation kernel)".format(k), elementwise=False)
+    # (a part that owns no pixel has its centre of mass exactly on the pixel border h/2: the closed form gives exactly 0, a
+    # summation a rounding error of either sign -- the truncated centre of such a part is not defined to better than one pixel)
+    dk = (ops.moments_to_px(stats, h) - ops.moments_to_px(ref, h)).abs()
+    owned = (h0.sum(dim=(1, 2)) > 0)
+    assert int(dk[owned].max()) == 0 and int(dk.max()) <= 1
+    # against the oracle's centres (fp64; a centre of mass within fp32 rounding of a pixel border may truncate the other way)
+    _, rc = R.patch_mask(h0.double().cpu(), 10.0, 6)
+    d = (ops.moments_to_px(stats, h).cpu().long() - rc).abs()
+    assert int(d.max()) <= 1 and float((d == 0).float().mean()) >= 0.9, (int(d.max()), float((d == 0).float().mean()))
+
+
 def test_bilinear_fp16(dev):
     lib, ops, R = _mods()
     g = torch.Generator().manual_seed(15)

@@ -58,9 +58,10 @@ def main():
     mean = torch.randn(n2, S, S, P, device=dev, generator=g)
     eps = torch.randn(n2, S, S, P, device=dev, generator=g)
     map_b = mean.numel() * 4
-    add("part_softmax (l, m, hard)", 5 * map_b, lambda: ops.part_softmax(mean, eps), "2 reads + 3 writes of a [2B,S,S,P] fp32 map")
+    add("part_softmax (l, m, hard) + hard-mask moments", 5 * map_b, lambda: ops.part_softmax(mean, eps, moments_gamma=10.0),
+        "2 reads + 3 writes of a [2B,S,S,P] fp32 map; the spatial soft-max moments of the hard map come out of the same pass "
+        "(round 2: a separate 0.068 ms pass over the hard map at 15 % of the roof)")
     l, m, hard, _ = ops.part_softmax(mean, eps)
-    add("spatial_moments", map_b, lambda: ops.spatial_moments(hard, 10.0), "1 read of the map")
     px = ops.moments_to_px(ops.spatial_moments(hard, 10.0), S)
     l0, m0, h0, lm0, px0 = l[:B].contiguous(), m[:B].contiguous(), hard[:B].contiguous(), mean[:B].contiguous(), px[:B].contiguous()
     nfl = L.load().ups_prior_sums_floats(B, P)

@@ -17,14 +17,21 @@ struct TileSign { __device__ float operator()(float v) const { return (__float_a
 
 // thread = pixel: the P values of the pixel are walked in LDS (odd pixel pitch: conflict-free), no cross-lane traffic at all
 // (a lane-per-part layout spends 16 ds_bpermute per 4 pixels on the max / sum / arg-max reductions: LDS-issue bound)
+// mom (optional, [blocks][P][5] int32): per part the pixel count and the sums of iy, ix, iy^2, ix^2 over the tile's hard-mask
+// pixels (integer: exact and order-independent, so the block's LDS atomics keep the result reproducible) -- the spatial soft-max
+// moments of the ONE-HOT hard map have a closed form in these (hard_moments_finalize_kernel), which spares the separate
+// pass over the 40-byte-per-pixel map that ups_spatial_moments(hard) was.
 __global__ __launch_bounds__(256) void part_softmax_kernel(const float* __restrict__ mean, const float* __restrict__ eps,
                                                            float* __restrict__ l, float* __restrict__ m, float* __restrict__ hard,
                                                            long long* __restrict__ amax, unsigned* __restrict__ bits,
-                                                           long long pixels, int P, int tpx) {
-    extern __shared__ __attribute__((aligned(16))) float ts[];          // [tpx][PP]
+                                                           long long pixels, int P, int tpx, int* __restrict__ mom, int img_w,
+                                                           int img_hw) {
+    extern __shared__ __attribute__((aligned(16))) float ts[];          // [tpx][PP] (+ [P][5] ints when mom)
     const int PP = tile_pitch(P);
     const long long pix0 = (long long)blockIdx.x * tpx;
     const int cnt = (int)min((long long)tpx, pixels - pix0);
+    int* red = (int*)(ts + (size_t)tpx * PP);
+    if (mom) { for (int i = threadIdx.x; i < P * 5; i += 256) red[i] = 0; }
     tile_load_f32(mean + pix0 * P, cnt, P, PP, ts, eps ? eps + pix0 * P : nullptr, (eps && l) ? l + pix0 * P : nullptr);
     __syncthreads();
     for (int px = threadIdx.x; px < cnt; px += 256) {
@@ -47,8 +54,16 @@ __global__ __launch_bounds__(256) void part_softmax_kernel(const float* __restri
         }
         if (amax) amax[pix0 + px] = first;
         if (bits) bits[pix0 + px] = bm;
+        if (mom) {
+            const int q = (int)((pix0 + px) % img_hw), iy = q / img_w, ix = q - iy * img_w;
+            for (unsigned b = bm; b; b &= b - 1) {
+                int* r = red + 5 * (__ffs(b) - 1);
+                atomicAdd(r, 1); atomicAdd(r + 1, iy); atomicAdd(r + 2, ix); atomicAdd(r + 3, iy * iy); atomicAdd(r + 4, ix * ix);
+            }
+        }
     }
     __syncthreads();
+    if (mom) { for (int i = threadIdx.x; i < P * 5; i += 256) mom[(long long)blockIdx.x * P * 5 + i] = red[i]; }
     tile_store_f32(m + pix0 * P, cnt, P, PP, ts, TileAbs());
     if (hard) tile_store_f32(hard + pix0 * P, cnt, P, PP, ts, TileSign());
 }
@@ -120,6 +135,36 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
         dst[0] = M;
         for (int k = 0; k < 6; ++k) dst[1 + k] = o[k];
         dst[7] = 0.f;
+    }
+}
+
+// stats[n][p] = {max, Z, S0, Sy, Sx, Q, Qy, 0} of spatial_softmax(gamma * hard) (no rectangle) from the integer sums of the
+// hard pixels: e = 1 on them, exp(-gamma) elsewhere (all e = 1 when the part owns no pixel); grid sums of the linspace(-1, 1)
+// coordinates in closed form (sum g = 0, sum g^2 = n (n + 1) / (3 (n - 1)))
+__global__ void hard_moments_finalize_kernel(const int* __restrict__ mom, int count_n, int blocks_per_img, int P, int h, int w,
+                                             float gamma, float* __restrict__ stats) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count_n * P) return;
+    const int n = idx / P, c = idx - n * P;
+    long long a[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < blocks_per_img; ++b) {
+        const int* r = mom + ((long long)(n * blocks_per_img + b) * P + c) * 5;
+        for (int k = 0; k < 5; ++k) a[k] += r[k];
+    }
+    const double N = (double)h * w, N1 = (double)a[0];
+    const double sy = h > 1 ? 2.0 / (h - 1) : 0.0, sx = w > 1 ? 2.0 / (w - 1) : 0.0;
+    const double hy = -N1 + sy * a[1], hx = -N1 + sx * a[2];                                   // sum over the hard pixels of gy, gx
+    const double hyy = N1 - 2.0 * sy * a[1] + sy * sy * a[3], hxx = N1 - 2.0 * sx * a[2] + sx * sx * a[4];
+    const double ayy = h > 1 ? (double)w * h * (h + 1.0) / (3.0 * (h - 1.0)) : N;                // sum over ALL pixels of gy^2
+    const double axx = w > 1 ? (double)h * w * (w + 1.0) / (3.0 * (w - 1.0)) : N;
+    float* d = stats + (long long)idx * 8;
+    if (a[0] > 0) {
+        const double e = exp(-(double)gamma), Z = N1 + e * (N - N1);
+        const double Qy = (1.0 - e) * hyy + e * ayy, Qx = (1.0 - e) * hxx + e * axx;
+        d[0] = gamma; d[1] = (float)Z; d[2] = (float)Z; d[3] = (float)((1.0 - e) * hy); d[4] = (float)((1.0 - e) * hx);
+        d[5] = (float)(Qy + Qx); d[6] = (float)Qy; d[7] = 0.f;
+    } else {
+        d[0] = 0.f; d[1] = (float)N; d[2] = (float)N; d[3] = 0.f; d[4] = 0.f; d[5] = (float)(ayy + axx); d[6] = (float)ayy; d[7] = 0.f;
     }
 }
 
@@ -381,7 +426,30 @@ extern "C" int ups_part_softmax_fwd(const float* mean, const float* eps, float* 
     const int grid = ups_cdiv(pixels, tpx);
     const size_t shm = (size_t)tpx * (P | 1) * sizeof(float);
     hipLaunchKernelGGL(part_softmax_kernel, dim3(grid), dim3(256), shm, s, mean, eps, l, m, hard, (long long*)argmax,
-                       (unsigned*)hard_bits, (long long)pixels, P, tpx);
+                       (unsigned*)hard_bits, (long long)pixels, P, tpx, (int*)nullptr, 1, 1);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" size_t ups_part_softmax_moments_ints(int64_t pixels, int32_t P) {
+    return (size_t)ups_cdiv(pixels, tile_pixels(P, 1, 24 * 1024)) * P * 5;
+}
+
+extern "C" int ups_part_softmax_moments_fwd(const float* mean, const float* eps, float* l, float* m, float* hard, int64_t* argmax,
+                                            uint32_t* hard_bits, int32_t n, int32_t h, int32_t w, int32_t P, float gamma,
+                                            float* stats, int32_t* scratch, void* stream) {
+    UPS_CHECK_ARG(mean && m && stats && scratch && n > 0 && h > 0 && w > 0 && P >= 1 && P <= 32 && gamma > 0.f);
+    hipStream_t s = (hipStream_t)stream;
+    const long long pixels = (long long)n * h * w;
+    const int tpx = tile_pixels(P, 1, 24 * 1024);
+    UPS_CHECK_ARG((h * w) % tpx == 0);           // a tile never straddles two images
+    const int grid = ups_cdiv(pixels, tpx);
+    const size_t shm = (size_t)tpx * (P | 1) * sizeof(float) + (size_t)P * 5 * sizeof(int);
+    hipLaunchKernelGGL(part_softmax_kernel, dim3(grid), dim3(256), shm, s, mean, eps, l, m, hard, (long long*)argmax,
+                       (unsigned*)hard_bits, pixels, P, tpx, (int*)scratch, w, h * w);
+    UPS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hard_moments_finalize_kernel, dim3(ups_cdiv((long long)n * P, 64)), dim3(64), 0, s, (const int*)scratch, n,
+                       (h * w) / tpx, P, h, w, gamma, stats);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

@@ -103,6 +103,8 @@ _SIGS = {
     "ups_l1_bwd": ([_P, _P, _P, _I, _L, _I, _I, _I, _P, _F, _P], C.c_int),
     "ups_sum_scale": ([_P, _I, _F, _P, _I, _P], C.c_int),
     "ups_part_softmax_fwd": ([_P, _P, _P, _P, _P, _P, _P, _L, _I, _P], C.c_int),
+    "ups_part_softmax_moments_ints": ([_L, _I], _Z),
+    "ups_part_softmax_moments_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P], C.c_int),
     "ups_spatial_moments": ([_P, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P], C.c_int),
     "ups_spatial_moments_floats": ([_I, _I], _Z),
     "ups_moments_to_px": ([_P, _I, _I, _I, _P, _P], C.c_int),

@@ -613,9 +613,19 @@ class Trainer(object):
         # model.py:420-421 / nn.py:1427-1433: l = mean + eps unless `stochastic_l: False` (default: not test_mode)
         stochastic_l = cfg.get("stochastic_l", not cfg.get("test_mode", False))
         eps_l = torch.cat([noise["eps_l0"], noise["eps_l1"]], 0) if stochastic_l else None
-        l, m, hard, _, hbits = ops.part_softmax(lm, eps_l, want_bits=P <= 32)
+        # (the moments of gamma * hard -- the input of the rectangle centres, model.py:437-440 -- come out of the same pass)
+        if df:
+            l, m, hard, _, hbits = ops.part_softmax(lm, eps_l, want_bits=P <= 32)
+            hstats = None
+        else:
+            l, m, hard, _, hbits, hstats = ops.part_softmax(lm, eps_l, want_bits=P <= 32, moments_gamma=gamma)
         # [2B,P,2] rectangle centres (stop-gradient); SB_model48c has no rectangles
-        px = None if df else ops.moments_to_px(ops.spatial_moments(hard, gamma), S, cfg.get("rect_order", "xy"))
+        if df:
+            px = None
+        else:
+            if hstats is None:
+                hstats = ops.spatial_moments(hard, gamma)
+            px = ops.moments_to_px(hstats, S, cfg.get("rect_order", "xy"))
         hard0 = hard[:B].detach().requires_grad_(True)
         hard1 = hard[B:].detach().requires_grad_(True)
 

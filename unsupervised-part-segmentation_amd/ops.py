@@ -1017,9 +1017,11 @@ class UnpoolFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- raw (non-autograd) part-path / latent calls
-def part_softmax(mean, eps=None, want_hard=True, want_argmax=False, want_bits=None):
+def part_softmax(mean, eps=None, want_hard=True, want_argmax=False, want_bits=None, moments_gamma=None):
     """-> (l, m, hard, argmax), or (l, m, hard, argmax, hard_bits) when `want_bits` is given (True / False):
-    hard_bits [..] int32 = the hard mask as a bit set per pixel (P <= 32; None when not wanted)."""
+    hard_bits [..] int32 = the hard mask as a bit set per pixel (P <= 32; None when not wanted).
+    moments_gamma (mean [n,h,w,P]): additionally returns, as the last element, the spatial soft-max moments of
+    gamma * hard -- what spatial_moments(hard, gamma) computes -- from the same pass (None when the shape does not allow it)."""
     mean = mean.contiguous()
     pixels, P = mean.numel() // mean.shape[-1], mean.shape[-1]
     l = torch.empty_like(mean) if eps is not None else mean
@@ -1027,9 +1029,22 @@ def part_softmax(mean, eps=None, want_hard=True, want_argmax=False, want_bits=No
     hard = torch.empty_like(mean) if want_hard else None
     am = torch.empty(mean.shape[:-1], dtype=torch.int64, device=mean.device) if want_argmax else None
     bits = torch.empty(mean.shape[:-1], dtype=torch.int32, device=mean.device) if want_bits else None
-    L.call("ups_part_softmax_fwd", L.ptr(mean), L.ptr(eps.contiguous()) if eps is not None else None,
-           L.ptr(l) if eps is not None else None, L.ptr(m), L.ptr(hard), L.ptr(am), L.ptr(bits), pixels, P, L.stream())
-    return (l, m, hard, am) if want_bits is None else (l, m, hard, am, bits)
+    stats = None
+    if moments_gamma is not None and mean.dim() == 4 and P <= 32 and want_hard:
+        n, h, w, _ = mean.shape
+        nint = L.load().ups_part_softmax_moments_ints(pixels, P)
+        blocks = nint // (P * 5)                                     # = ceil(pixels / tile): whole tiles <=> pixels % blocks == 0
+        if pixels % blocks == 0 and (h * w) % (pixels // blocks) == 0:    # ... and no tile straddles two images
+            stats = torch.empty((n, P, 8), dtype=torch.float32, device=mean.device)
+            scratch = torch.empty(nint, dtype=torch.int32, device=mean.device)
+            L.call("ups_part_softmax_moments_fwd", L.ptr(mean), L.ptr(eps.contiguous()) if eps is not None else None,
+                   L.ptr(l) if eps is not None else None, L.ptr(m), L.ptr(hard), L.ptr(am), L.ptr(bits), n, h, w, P,
+                   float(moments_gamma), L.ptr(stats), L.ptr(scratch), L.stream())
+    if stats is None:
+        L.call("ups_part_softmax_fwd", L.ptr(mean), L.ptr(eps.contiguous()) if eps is not None else None,
+               L.ptr(l) if eps is not None else None, L.ptr(m), L.ptr(hard), L.ptr(am), L.ptr(bits), pixels, P, L.stream())
+    out = (l, m, hard, am) if want_bits is None else (l, m, hard, am, bits)
+    return out + (stats,) if moments_gamma is not None else out
 
 
 def spatial_moments(x, gamma, rect_px=None, half=0):
