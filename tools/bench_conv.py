@@ -121,7 +121,7 @@ def main():
             elif act == "relu":
                 xa = torch.relu(xa)
             Vq = V.clone()
-            Vq[:, :, :cin] = V[:, :, :cin].to(T).float()
+            Vq[:, :, :cin] = V[:, :, :cin].to(torch.float16 if fmt == lib.F16 else T).float()
             if coords:
                 col = torch.arange(h, device=dev, dtype=torch.float32) / max(1, h - 1) * 2 - 1
                 xx = col.view(1, 1, h, 1).expand(n, h, h, 1); yy = col.view(1, h, 1, 1).expand(n, h, h, 1)
@@ -129,7 +129,18 @@ def main():
             oh = -(-h // stride); pt = max((oh - 1) * stride + k - h, 0)
             xp = torch.nn.functional.pad(xa.permute(0, 3, 1, 2), (pt // 2, pt - pt // 2, pt // 2, pt - pt // 2))
             ref = torch.nn.functional.conv2d(xp[:8], Vq.permute(3, 2, 0, 1), b, stride=stride).permute(0, 2, 3, 1)
-            err = float((y[:8, ..., :cout].float() - ref).abs().max() / ref.abs().max())
+            xin = (x.view(torch.float16) if fmt == lib.F16 else x).float()[:8, ..., :cin]
+            if lay.in_post:        # the stored tensor is act(x): the reference operand is the tensor itself, the residual its inverse
+                xa8 = xin
+                xp = torch.nn.functional.pad(torch.cat([xa8, xa[:8, ..., cin:]], -1).permute(0, 3, 1, 2), (pt // 2, pt - pt // 2, pt // 2, pt - pt // 2))
+                ref = torch.nn.functional.conv2d(xp, Vq.permute(3, 2, 0, 1), b, stride=stride).permute(0, 2, 3, 1)
+                xin = torch.where(xin > 0, xin, xin / 0.2)
+            if res_self:
+                ref = ref + xin
+            if lay.out_act:
+                ref = torch.nn.functional.leaky_relu(ref, 0.2)
+            yf = (y.view(torch.float16) if fmt == lib.F16 else y).float()
+            err = float((yf[:8, ..., :cout] - ref).abs().max() / ref.abs().max())
             print("           fwd max-rel err vs torch fp32 (first 8 images): {:.2e}".format(err))
     print("{:10s} {:9.3f} {:8s} {:9.3f} {:8s} {:9.3f}".format("sum", tot[0], "", tot[1], "", tot[2]))
 

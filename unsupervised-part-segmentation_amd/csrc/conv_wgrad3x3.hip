@@ -75,6 +75,12 @@ __device__ inline bf16x8 tr_frag_d(const unsigned char* tile, int row0, int wco,
     return u.b;
 }
 
+#if defined(UPS_WGRAD_NO_PIPE)
+constexpr bool PIPE_X = false;
+#else
+constexpr bool PIPE_X = true;
+#endif
+
 template <int CB, int BN, int TH, bool SLIDE = false>
 __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const int cit, const int cot, const int nsplit) {
     constexpr int PROWS = TH + 2, PPIX = PWID * PROWS;
@@ -145,6 +151,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
     const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
 
     uint4 rx[NX];
+    uint4 rxn[NX];            // pipelined SLIDE variant: the X items of the unit after next
+    bool rxok[NX];
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 
     auto unit_origin = [&](int u, int& img, int& y0, int& x0) {
@@ -154,6 +162,51 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
         const int ty = t % p.tiles_y;
         img = t / p.tiles_y;
         y0 = ty * 16 + half * TH; x0 = tx * TW;
+    };
+    // X loads of unit u into registers, UNCONDITIONALLY (lanes whose item lies outside the image read the tensor's first bytes and
+    // drop them): the number of vector-memory operations per wave is then static, and a counted s_waitcnt can leave exactly
+    // these loads in flight across a barrier (pipelined SLIDE variant below)
+    auto load_x = [&](int u) __attribute__((always_inline)) {
+        int img, y0, x0;
+        unit_origin(u, img, y0, x0);
+        const unsigned edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.h ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == p.w ? 8u : 0u) | 16u;
+        const long long org = ((long long)img * p.h + (y0 - 1)) * p.w + (x0 - 1);
+        const unsigned char* xb = (const unsigned char*)(in + org * p.ldi);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            unsigned r = xr[k], f = xs[k];
+            asm volatile("" : "+v"(r), "+v"(f));
+            const bool ok = ((f >> 16) & edge) == 0u;
+            const unsigned char* src = ok ? xb + (__umul24(r, x_rowb) + x_chb) : (const unsigned char*)in;
+            uint4 v;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(src) : "memory");
+            rxn[k] = v;
+            rxok[k] = ok;
+        }
+    };
+    auto dma_d = [&](int u, int buf) __attribute__((always_inline)) {
+        int img, y0, x0;
+        unit_origin(u, img, y0, x0);
+        const unsigned char* db = (const unsigned char*)(dout + (((long long)img * p.h + y0) * p.w + x0) * p.ldo);
+#pragma unroll
+        for (int q = 0; q < NWD; ++q) {
+            const unsigned lds_dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(2 * XB + buf * DB + (wid + 8 * q) * 1024));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(lds_dst), "v"(dd[q]), "s"(db) : "memory", "m0");
+        }
+    };
+    auto store_xn = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* X = Xbuf + buf * XB;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            unsigned f = xs[k];
+            asm volatile("" : "+v"(f));
+            uint4 v = rxok[k] ? rxn[k] : zero4;
+            if (p.in_f16) v = ups_act_chunk_f16_to_bf16(v, act_ns, p.act_in != UPS_ACT_NONE);
+            else if (p.act_in != UPS_ACT_NONE) v = ups_act_chunk(v, act_ns, (bf16*)nullptr);
+            if (k + 1 < NX || tid + 512 * k < PPIX * CPX) *(uint4*)(X + (f & 0xffffu)) = v;
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     // global loads of unit u: X into registers, dout straight into D buffer `buf`
     auto load_unit = [&](int u, int buf) __attribute__((always_inline)) {
@@ -207,6 +260,78 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     float bsum = 0.f;        // bias gradient: column sums straight from the dout fragments (k = 8*(lane>>5)+j, col = lane&31)
 
+    if constexpr (WK == 1 && SLIDE) {
+      if (!p.mask && PIPE_X) {
+        // Software-pipelined staging: the X items of unit u+1 are converted and written to LDS in the MIDDLE of unit u's MFMAs
+        // (they were requested during unit u-1), the loads of unit u+2 are issued right behind and stay in flight across the
+        // barrier (counted wait: only the dout DMA of unit u+1, issued first, has to have landed).  One block per CU runs its
+        // eight waves in lock-step between barriers, so a load -> wait -> convert -> ds_write phase at the end of every unit
+        // left the matrix pipe idle for its whole length.
+        static_assert(NX == 3 && (NWD == 4 || NWD == 2 || NWD == 1), "pipelined staging: item / DMA piece counts");
+#define UPS_WAIT_X(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(rxn[0].x), "+v"(rxn[0].y), "+v"(rxn[0].z), "+v"(rxn[0].w), \
+                                   "+v"(rxn[1].x), "+v"(rxn[1].y), "+v"(rxn[1].z), "+v"(rxn[1].w), "+v"(rxn[2].x), "+v"(rxn[2].y), \
+                                   "+v"(rxn[2].z), "+v"(rxn[2].w) :: "memory")
+        if (u_begin < u_end) {
+            load_x(u_begin); dma_d(u_begin, 0);
+            UPS_WAIT_X(0);
+            store_xn(0);
+            if (u_begin + 1 < u_end) load_x(u_begin + 1);
+        }
+        UPS_WAIT_X(0);
+        __syncthreads();
+        for (int u = u_begin; u < u_end; ++u) {
+            const int buf = (u - u_begin) & 1;
+            if (u + 1 < u_end) dma_d(u + 1, buf ^ 1);
+            const unsigned char* X = Xbuf + buf * XB;
+            const unsigned char* D = Dbuf + buf * DB;
+            bf16x8 aw[3][3];
+#pragma unroll
+            for (int dxi = 0; dxi < 3; ++dxi) {
+                aw[0][dxi] = tr_frag3(X, RSX, dxi, w_ci * 32, lane);
+                aw[1][dxi] = tr_frag3(X, RSX, PWID + dxi, w_ci * 32, lane);
+            }
+            bf16x8 bcur = tr_frag_d<BN>(D, 0, w_co, lane);
+#pragma unroll
+            for (int ks = 0; ks < TH; ++ks) {
+                if (ks == TH / 2) {
+                    if (u + 1 < u_end) {
+                        // the X items of unit u+1 (requested half a unit ago or earlier) are older than this unit's NWD dout DMA
+                        // pieces; the registers are operands of the wait so that no use of them is scheduled above it (the
+                        // loads are inline asm: the compiler's own wait-count bookkeeping does not see them)
+                        if (NWD == 4) UPS_WAIT_X(4); else if (NWD == 2) UPS_WAIT_X(2); else UPS_WAIT_X(1);
+                        store_xn(buf ^ 1);
+                    }
+                    if (u + 2 < u_end) load_x(u + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int dxi = 0; dxi < 3; ++dxi) aw[(ks + 2) % 3][dxi] = tr_frag3(X, RSX, (ks + 2) * PWID + dxi, w_ci * 32, lane);
+                // the dout fragment of the NEXT row is requested now: all nine MFMAs of a row wait for theirs
+                const bf16x8 bnext = tr_frag_d<BN>(D, (ks + 1 < TH ? ks + 1 : ks) * TW, w_co, lane);
+                const bf16x8 b = bcur;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[(ks + t / 3) % 3][t % 3], b, acc[t], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += (float)b[j];
+                }
+                bcur = bnext;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the dout DMA of unit u+1 (older than the NX loads of unit u+2) must have landed; those loads stay in flight
+            if (u + 2 < u_end) {
+                if (NX == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        goto reduce_parts;
+      }
+    }
     if (u_begin < u_end) { load_unit(u_begin, 0); store_unit(0); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -262,6 +387,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
         __syncthreads();
     }
 
+reduce_parts:
     // ---- reduce the WK K-parts of the block through LDS (tap by tap), then the w_k == 0 waves write the block's slab
     bsum += __shfl_xor(bsum, 32, 64);                                  // the two lane halves own k = 0..7 / 8..15
     if (WK > 1) {
