@@ -1152,9 +1152,15 @@ int launch_t(const PatchK& k, hipStream_t s) {
             if (mid && patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 64) >= 512) return launch_v<T, 64, 2>(k, s);
             return launch_v<T, 128, 1>(k, s);
         }
-        if (k.co_fill > 32)
+        if (k.co_fill > 32) {
+            // a single input chunk with many outputs (the input gradient of the P-channel logit convolution: 16 -> 256 channels,
+            // a store-bound launch): 128-wide tiles halve the number of blocks and patch loads (0.55 -> 0.48 ms; UPS_PATCH_THIN128=0: off)
+            static int thin128 = -1;
+            if (thin128 < 0) { const char* e = getenv("UPS_PATCH_THIN128"); thin128 = (e && e[0] == '0') ? 0 : 1; }
+            if (thin128 && k.co_fill > 64 && patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 128) >= 512) return launch_v<T, 128, 2>(k, s);
             return (patch_occ() == 2 && k.ci > 32 && tiles * ups_cdiv(k.co_fill, 64) >= 512) ? launch_v<T, 64, 2>(k, s)
                                                                                               : launch_v<T, 64, 1>(k, s);
+        }
         return launch_v<T, 32, 1>(k, s);
     } else {
         if (k.co_fill > 64) return launch_bn<T, 128, 1, TS>(k, s);
