@@ -151,6 +151,37 @@ def mask2rgb(mask):
     return col[mask.argmax(dim=3)]
 
 
+class _LazyLosses(object):
+    """What train_step returns: the per-key losses of the step just run, computed when first read (Trainer.losses)."""
+
+    def __init__(self, trainer):
+        self._t = trainer
+
+    def _d(self):
+        return self._t.losses
+
+    def __getitem__(self, k):
+        return self._d()[k]
+
+    def __iter__(self):
+        return iter(self._d())
+
+    def __len__(self):
+        return len(self._d())
+
+    def __contains__(self, k):
+        return k in self._d()
+
+    def keys(self):
+        return self._d().keys()
+
+    def values(self):
+        return self._d().values()
+
+    def items(self):
+        return self._d().items()
+
+
 class Trainer(object):
     """Mirror of model.py:570-1068 plus the pieces edflow's TFBaseTrainer supplied (session loop,
     one Adam per loss key over the variables whose name contains the key, logging cadence)."""
@@ -160,7 +191,7 @@ class Trainer(object):
         self.device = model.device
         self.logger = kwargs.get("logger")
         self.global_step = 0
-        self.log_ops, self.img_ops, self.update_ops = OrderedDict(), OrderedDict(), []
+        self._log_ops, self.img_ops, self.update_ops = OrderedDict(), OrderedDict(), []
         self.world_size = kwargs.get("world_size", 1)
         self.rank = kwargs.get("rank", 0)
         self.process_group = kwargs.get("process_group")
@@ -200,11 +231,35 @@ class Trainer(object):
                       "avg_mim": _scalar(0.0, d), "avg_independent_mim": _scalar(0.0, d)}
         self._gen = torch.Generator(device=d)
         self._gen.manual_seed(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))
-        self.losses = OrderedDict((k, None) for k in self.loss_keys())
+        self._lazy_logs = None
+        self._losses = OrderedDict((k, None) for k in self.loss_keys())
         self._early, self._early_hooked = {}, False
         self._graph_enabled = bool(config.get("hip_graph", os.environ.get("UPS_GRAPH", "0") == "1"))
         self._g = None
         self._cap = None                # set while the step is being captured into HIP graphs (_capture_step)
+
+    # ------------------------------------------------------------------ losses / log scalars, materialised on first use
+    def _set_logs(self, losses, log):
+        self._losses, self._log_ops, self._lazy_logs = losses, log, None
+
+    def _materialize(self):
+        if self._lazy_logs is not None:
+            thunk, self._lazy_logs = self._lazy_logs, None
+            self._losses, self._log_ops = thunk()
+
+    @property
+    def losses(self):
+        self._materialize()
+        return self._losses
+
+    @property
+    def log_ops(self):
+        self._materialize()
+        return self._log_ops
+
+    @log_ops.setter
+    def log_ops(self, value):
+        self._log_ops = value
 
     # ------------------------------------------------------------------ edflow hook surface
     def loss_keys(self):
@@ -399,7 +454,7 @@ class Trainer(object):
             g["graph"], g["sig"] = self._capture_step(g), sig   # (capturing does not execute: the replay below runs the step)
         self._replay_step(g["graph"])
         self._after_graph_step()
-        return self.losses
+        return _LazyLosses(self)
 
     # Data parallel: a collective cannot sit inside a captured region on every backend (gloo reduces on the host), and the
     # buckets should start their all-reduce as early as in the eager step.  The step is therefore captured as a SEQUENCE of
@@ -530,7 +585,6 @@ class Trainer(object):
             levels0 += [1.0, 1.0]                                         # SB_model48c:492,502: two more draws of z_00
         samples0, kl_rows = ops.latent_fwd(pe_v0, noise["eps_pi0"], levels0, True)
         samples1, _ = ops.latent_fwd(pe_v1, noise["eps_pi1"][None], [1.0], False)
-        bottleneck = kl_rows.sum(dim=1).mean()                            # nn.py:1196-1208
 
         # ================= D: critics (model.py:502-521, 800-866) -- they depend on the latent samples and on the appearance
         # code of the whole views only, and the main path needs them again at the encoder_0 backward: the whole block
@@ -671,25 +725,6 @@ class Trainer(object):
         self._prior(1, B, S, P, l1, None, m1, None, px1, None, sums1, wp)
         # variance moments (model.py:683-707; SB_model48c:750-756: no gamma, no rectangle)
         stats_v = ops.spatial_moments(m1.contiguous(), 1.0 if df else gamma, rect_px=px1, half=half)
-        npx = float(B * S * S)
-        prior_gmrf = sums0[3] / B
-        mask0_kl = (sums0[0] + sums1[0]) / npx
-        weakly = sums0[1] / npx
-        patch_loss = sums0[2] / B
-        p_ms = w_ms * sums0[4] / B
-        area_cost = 1.0e-12 * sums0[5] / B
-        Zs = stats_v[..., 1]
-        if df:       # SB_model48c:757-776: squared diagonal variances of the (already normalised) maps
-            s00 = stats_v[..., 6] / Zs - (stats_v[..., 3] / Zs) ** 2
-            s11 = (stats_v[..., 5] - stats_v[..., 6]) / Zs - (stats_v[..., 4] / Zs) ** 2
-            variances = (s00 ** 2 + s11 ** 2).sum(dim=1).mean()
-            prior_ms = sums0[2] / B                                   # variant 1: the patch slot holds sum min(alpha g, lambda)
-            prior_total = w_gmrf * prior_gmrf + prior_ms * w_ms + w_kl * mask0_kl + weakly * w_weak + w_var * variances
-        else:
-            variances = (stats_v[..., 5] / Zs - (stats_v[..., 3] / Zs) ** 2 - (stats_v[..., 4] / Zs) ** 2).sum(dim=1).mean()
-            prior_total = (w_gmrf * prior_gmrf + w_kl * mask0_kl + weakly * w_weak + w_var * variances + p_ms + area_cost
-                           + patch_loss * w_patch)
-
         dl_tot = torch.empty_like(lm)
         dl_rec = torch.empty_like(lm)
         # one launch per view emits both d(rec + priors)/dl (decoder_visualize key) and d(rec)/dl (what encoder_0 sees)
@@ -710,13 +745,11 @@ class Trainer(object):
                                         if k in keys])
 
         # ================= A backward (model.py:739, 909, 930)
-        bw = None
         beta_0 = cfg.get("beta_0", 1.0)
         var_reg = cfg.get("variational_regularization", True)
         if var_reg:
             assert not cfg.get("test_mode", False)
             explor = torch.exp(st["lor"])
-            bw = beta_0 * explor * bottleneck
         if "encoder_0" in keys:
             g_s0 = torch.zeros((len(levels0), B, Z), dtype=torch.float32, device=dev)
             g_s0[0] = gz[:B]
@@ -755,73 +788,108 @@ class Trainer(object):
             new["lor"] = torch.clamp(st["lor"] + mi.get("lor_lr", 0.05) * (g_ind - MI_TARGET), mi.get("lor_min", 1.0),
                                      mi.get("lor_max", 7.5))
 
-        # ================= losses per key + log ops (model.py:648-966; same names as the reference)
-        Ls = OrderedDict()
-        Ls["encoder_0"] = auto_rec + (adv if adv is not None else 0.0) + (bw if bw is not None else 0.0)
-        Ls["encoder_1"] = auto_rec
-        Ls["decoder_delta"] = auto_rec
-        Ls["decoder_visualize"] = auto_rec if pretrain else auto_rec + prior_total
-        Ls["mi0_discriminator"], Ls["mi1_discriminator"], Ls["mi_estimator"] = loss_dis0, loss_dis1, loss_est
-        if df:       # SB_model48c:809-815 (the global term has no gradient path to the encoders: stop_gradient inputs)
-            Ls["encoder_0"] = Ls["encoder_0"] + crit["d_single"][0].detach()
-            Ls["encoder_1"] = Ls["encoder_1"] + crit["d_single"][0].detach()
-            for k in N.EXTRA_48C:
-                Ls[k] = crit[k][0]
-        self.losses = OrderedDict((k, Ls[k].detach()) for k in keys)
-        avg_mim = torch.clamp(st["avg_mim"], min=0.0); avg_ind = torch.clamp(st["avg_independent_mim"], min=0.0)
-        loo = torch.clamp((avg_ind - avg_mim) / (avg_ind + 1e-6), 0.0, 1.0)
-        log.update({"prior_gmrf": prior_gmrf, "prior_gmrf_weight": w_gmrf, "prior_gmrf_weighted": w_gmrf * prior_gmrf,
-                    "mask0_kl_weight": w_kl, "mask0_kl": mask0_kl, "mask0_kl_weighted": w_kl * mask0_kl,
-                    "variance_loss_weighted": w_var * variances, "variance_loss": variances, "variance_weight": w_var,
-                    "weakly_superv_loss_weight_p": w_weak, "weakly_superv_loss_p": weakly,
-                    "weakly_superv_loss_p_weighted": weakly * w_weak,
-                    "patch_loss": patch_loss, "patch_loss_weight": w_patch, "patch_loss_weighted": patch_loss * w_patch,
-                    "mumford_sha_lambda": make_var(step, cfg["mumford_sha_lambda"]),
-                    "mumford_sha_alpha": make_var(step, cfg["mumford_sha_alpha"]),
-                    "avg_acc_error": st["avg_acc_error"], "avg_mim": avg_mim, "avg_independent_mim": avg_ind,
-                    "loo": loo, "lon_gain": -loo + 0.025, "model_lon": st["lon"]})
-        if df:
-            for k in ("patch_loss", "patch_loss_weight", "patch_loss_weighted"):
-                log.pop(k)
-        for k in Ls:
-            log["loss_" + k] = Ls[k].detach()
-        log.update({"dis0_accuracy": acc0, "dis1_accuracy": acc1, "avg_dis0_accuracy": st["avg_acc0"],
-                    "avg_dis1_accuracy": st["avg_acc1"], "avg_loss_dis0": st["avg_loss_dis0"],
-                    "avg_loss_dis1": st["avg_loss_dis1"], "est_accuracy": acc_est,
-                    "mi_constraint": mim.detach(), "independent_mi_constraint": ind_mim.detach()})
-        if adv is not None:
-            log.update({"adversarial_weight": st["loa"], "adversarial_constraint": mim.detach(),
-                        "adversarial_weighted_loss": adv.detach(), "loa": st["loa"],
-                        "loa_gain": (mim - (1.0 - MI_SLACK) * MI_TARGET).detach()})
-        if bw is not None:
-            log.update({"bottleneck_weight": st["lor"], "bottleneck_loss": bottleneck, "bottleneck_weighted_loss": bw,
-                        "lor": st["lor"], "explor": beta_0 * torch.exp(st["lor"]), "lor_gain": (ind_mim - MI_TARGET).detach()})
-        if df:
-            log.update({"prior_mumford_sha": prior_ms, "prior_mumford_sha_weight": w_ms, "prior_mumford_sha_weighted": prior_ms * w_ms,
-                        "perceptual": rec.detach(), "lr": self.learning_rate()})
-            for i in range(P):
-                log["sigma1_{:02d}".format(i)] = s00[0, i]
-                log["sigma2_{:02d}".format(i)] = s11[0, i]
-        else:
-            log.update({"zr_mumford_sha": p_ms, "z_mumford_sha_smoothness_cost": sums0[6] / B,
-                        "z_mumford_sha_contour_cost": sums0[7] / B, "z_area_cost": area_cost,
-                        "prior_mumford_sha_weight": w_ms, "perceptual": rec.detach(), "lr": self.learning_rate()})
+        # ================= losses per key + log ops (model.py:648-966; same names as the reference).  Everything below is
+        # REPORTING: ~150 scalar launches that no gradient depends on (the per-key gradients were taken from the pieces above).
+        # In the eager trainer it is deferred until somebody reads `losses` / `log_ops` (log steps, tests); the closure keeps
+        # only detached scalars and the small reduction buffers alive.  Inside a captured HIP graph it runs with the step.
+        auto_rec, rec = auto_rec.detach(), rec.detach()
+        adv = adv.detach() if adv is not None else None
+        loss_dis0, loss_dis1, loss_est = loss_dis0.detach(), loss_dis1.detach(), loss_est.detach()
+        mim, ind_mim = mim.detach(), ind_mim.detach()
+        crit_d = {k: crit[k][0].detach() for k in N.EXTRA_48C} if df else {}
+
+        lr_now = self.learning_rate()          # (of THIS step: the counters have moved on when the logs are read)
+        def build_logs():
+            bottleneck = kl_rows.sum(dim=1).mean()                            # nn.py:1196-1208
+            bw = beta_0 * torch.exp(st["lor"]) * bottleneck if var_reg else None
+            npx = float(B * S * S)
+            prior_gmrf = sums0[3] / B
+            mask0_kl = (sums0[0] + sums1[0]) / npx
+            weakly = sums0[1] / npx
+            patch_loss = sums0[2] / B
+            p_ms = w_ms * sums0[4] / B
+            area_cost = 1.0e-12 * sums0[5] / B
+            Zs = stats_v[..., 1]
+            if df:       # SB_model48c:757-776: squared diagonal variances of the (already normalised) maps
+                s00 = stats_v[..., 6] / Zs - (stats_v[..., 3] / Zs) ** 2
+                s11 = (stats_v[..., 5] - stats_v[..., 6]) / Zs - (stats_v[..., 4] / Zs) ** 2
+                variances = (s00 ** 2 + s11 ** 2).sum(dim=1).mean()
+                prior_ms = sums0[2] / B                                   # variant 1: the patch slot holds sum min(alpha g, lambda)
+                prior_total = w_gmrf * prior_gmrf + prior_ms * w_ms + w_kl * mask0_kl + weakly * w_weak + w_var * variances
+            else:
+                variances = (stats_v[..., 5] / Zs - (stats_v[..., 3] / Zs) ** 2 - (stats_v[..., 4] / Zs) ** 2).sum(dim=1).mean()
+                prior_total = (w_gmrf * prior_gmrf + w_kl * mask0_kl + weakly * w_weak + w_var * variances + p_ms + area_cost
+                               + patch_loss * w_patch)
+
+            Ls = OrderedDict()
+            Ls["encoder_0"] = auto_rec + (adv if adv is not None else 0.0) + (bw if bw is not None else 0.0)
+            Ls["encoder_1"] = auto_rec
+            Ls["decoder_delta"] = auto_rec
+            Ls["decoder_visualize"] = auto_rec if pretrain else auto_rec + prior_total
+            Ls["mi0_discriminator"], Ls["mi1_discriminator"], Ls["mi_estimator"] = loss_dis0, loss_dis1, loss_est
+            if df:       # SB_model48c:809-815 (the global term has no gradient path to the encoders: stop_gradient inputs)
+                Ls["encoder_0"] = Ls["encoder_0"] + crit_d["d_single"]
+                Ls["encoder_1"] = Ls["encoder_1"] + crit_d["d_single"]
+                for k in N.EXTRA_48C:
+                    Ls[k] = crit_d[k]
+            losses_d = OrderedDict((k, Ls[k].detach()) for k in keys)
+            avg_mim = torch.clamp(st["avg_mim"], min=0.0); avg_ind = torch.clamp(st["avg_independent_mim"], min=0.0)
+            loo = torch.clamp((avg_ind - avg_mim) / (avg_ind + 1e-6), 0.0, 1.0)
+            log.update({"prior_gmrf": prior_gmrf, "prior_gmrf_weight": w_gmrf, "prior_gmrf_weighted": w_gmrf * prior_gmrf,
+                        "mask0_kl_weight": w_kl, "mask0_kl": mask0_kl, "mask0_kl_weighted": w_kl * mask0_kl,
+                        "variance_loss_weighted": w_var * variances, "variance_loss": variances, "variance_weight": w_var,
+                        "weakly_superv_loss_weight_p": w_weak, "weakly_superv_loss_p": weakly,
+                        "weakly_superv_loss_p_weighted": weakly * w_weak,
+                        "patch_loss": patch_loss, "patch_loss_weight": w_patch, "patch_loss_weighted": patch_loss * w_patch,
+                        "mumford_sha_lambda": make_var(step, cfg["mumford_sha_lambda"]),
+                        "mumford_sha_alpha": make_var(step, cfg["mumford_sha_alpha"]),
+                        "avg_acc_error": st["avg_acc_error"], "avg_mim": avg_mim, "avg_independent_mim": avg_ind,
+                        "loo": loo, "lon_gain": -loo + 0.025, "model_lon": st["lon"]})
+            if df:
+                for k in ("patch_loss", "patch_loss_weight", "patch_loss_weighted"):
+                    log.pop(k)
+            for k in Ls:
+                log["loss_" + k] = Ls[k].detach()
+            log.update({"dis0_accuracy": acc0, "dis1_accuracy": acc1, "avg_dis0_accuracy": st["avg_acc0"],
+                        "avg_dis1_accuracy": st["avg_acc1"], "avg_loss_dis0": st["avg_loss_dis0"],
+                        "avg_loss_dis1": st["avg_loss_dis1"], "est_accuracy": acc_est,
+                        "mi_constraint": mim.detach(), "independent_mi_constraint": ind_mim.detach()})
+            if adv is not None:
+                log.update({"adversarial_weight": st["loa"], "adversarial_constraint": mim.detach(),
+                            "adversarial_weighted_loss": adv.detach(), "loa": st["loa"],
+                            "loa_gain": (mim - (1.0 - MI_SLACK) * MI_TARGET).detach()})
+            if bw is not None:
+                log.update({"bottleneck_weight": st["lor"], "bottleneck_loss": bottleneck, "bottleneck_weighted_loss": bw,
+                            "lor": st["lor"], "explor": beta_0 * torch.exp(st["lor"]), "lor_gain": (ind_mim - MI_TARGET).detach()})
+            if df:
+                log.update({"prior_mumford_sha": prior_ms, "prior_mumford_sha_weight": w_ms, "prior_mumford_sha_weighted": prior_ms * w_ms,
+                            "perceptual": rec.detach(), "lr": lr_now})
+                for i in range(P):
+                    log["sigma1_{:02d}".format(i)] = s00[0, i]
+                    log["sigma2_{:02d}".format(i)] = s11[0, i]
+            else:
+                log.update({"zr_mumford_sha": p_ms, "z_mumford_sha_smoothness_cost": sums0[6] / B,
+                            "z_mumford_sha_contour_cost": sums0[7] / B, "z_area_cost": area_cost,
+                            "prior_mumford_sha_weight": w_ms, "perceptual": rec.detach(), "lr": lr_now})
+            return losses_d, log
+
         if graph_lr is not None:        # graph mode: state lives in fixed device scalars, python counters advance outside
+            losses_now, log = build_logs()
             # the logged state is the PRE-update value in both modes: snapshot before the in-place update below
             for k, v in list(log.items()):
                 if torch.is_tensor(v) and any(v is sv for sv in st.values()):
                     log[k] = v.clone()
-        self.log_ops = log
-        if graph_lr is not None:
+            self._set_logs(losses_now, log)
             for k in st:
                 if new[k] is not st[k]:
                     st[k].copy_(new[k])
         else:
+            self._lazy_logs = build_logs        # (the closure holds the PRE-update state dict `st`: self.state is replaced, not modified)
             self.state = new
             self.global_step += 1
         self._debug = {"l_mean": lm, "l": l, "m": m, "hard": hard, "px": px, "generated": gen.detach(), "feat": feat.detach(),
                        "dl_tot": dl_tot, "dl_rec": dl_rec, "g_hard0": g_hard0, "g_hard1": g_hard1, "pe": pe2}
-        return self.losses
+        return _LazyLosses(self)
 
     def _hook_early_reduce(self):
         """The 1x1 head of encoder_0 (258 x 33152 weights = 34 of the key's 54.6 MB) is the FIRST weight gradient of the
