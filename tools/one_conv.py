@@ -1,5 +1,7 @@
 """Runs one convolution a few times: target for rocprofv3 --pmc (tools/pmc_conv.sh).
-Usage: python tools/one_conv.py [fwd|dgrad|wgrad] [case of tools/bench_conv.py, default dv_rb128 with the residual add]"""
+Usage: python tools/one_conv.py [fwd|dgrad|wgrad] [case of tools/bench_conv.py, default dv_rb128] [plain]
+The launch is issued the way the model issues it: residual block (res = in), for a 3x3 layer with an activation the input in
+post-activation storage and -- the mask decoder's layers (dv_*) -- fp16 forward tensors; `plain`: bf16, activation-on-load."""
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -15,16 +17,24 @@ g = torch.Generator().manual_seed(1)
 cin_v = cin + (2 if coords else 0)
 V = (torch.randn(k, k, cin_v, cout, generator=g) / math.sqrt(k * k * cin_v)).to(dev)
 b = torch.randn(cout, generator=g).to(dev)
+from upsparts_amd import lib
 lay = ops.ConvLayer("x/conv2d_0", V, b, k, stride, coords, act)
+plain = len(sys.argv) > 3 and sys.argv[3] == "plain"
+fmt = lib.F16 if (not plain and case.startswith("dv_") and k == 3) else None
+lay.f16 = fmt == lib.F16
+if not plain and act == "leaky_relu":
+    lay.in_post, lay.out_act = True, lib.ACT_LRELU
 x = torch.randn(n, h, h, ops.round8(cin), device=dev).to(torch.bfloat16)
-res = x if (cin == cout and stride == 1) else None
-y = ops.conv_forward(x, lay, res=res)
+if fmt == lib.F16:
+    x = x.to(torch.float16).view(torch.bfloat16)
+res = x if (cin == cout and stride == 1 and act is not None) else None
+y = ops.conv_forward(x, lay, res=res, fmt=fmt, res_post=lay.in_post)
 gy = torch.randn(y.shape, device=dev).to(torch.bfloat16)
 for _ in range(3):
     if mode == "fwd":
-        ops.conv_forward(x, lay, res=res)
+        ops.conv_forward(x, lay, res=res, fmt=fmt, res_post=lay.in_post)
     elif mode == "dgrad":
-        ops.conv_dgrad(gy, x, lay)
+        ops.conv_dgrad(gy, x, lay, res=gy if res is not None else None)
     elif mode == "wgrad":
-        ops.conv_wgrad(gy, x, lay)
+        ops.conv_wgrad(gy, x, lay, fmt=fmt)
 torch.cuda.synchronize()

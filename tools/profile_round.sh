@@ -10,7 +10,7 @@
 # Everything lands in gpurun_out/profiles_<tag>/ on the box (merged back); copy what is to be judged into profiles/.
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-round2}
+TAG=${1:-round3}
 cd $R
 O=$R/gpurun_out/profiles_$TAG
 rm -rf $O; mkdir -p $O
@@ -45,9 +45,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals[c] = v
 rd = 2 * 1024 * sum(vals["FETCH_SIZE"]) / max(1, len(vals["FETCH_SIZE"]))
 wr = 1024 * sum(vals["WRITE_SIZE"]) / max(1, len(vals["WRITE_SIZE"]))
-alg = {"input (also the residual: counted once)": 1073741824, "weights": 1179648, "output": 1073741824}
-json.dump({"kernel": "conv3x3_patch_kernel<bf16,128,2>",
-           "launch": "decoder_visualize res-block conv, forward with residual: n=128 images, 128x128, 256(+2 CoordConv)->256, bf16 (tools/one_conv.py fwd)",
+alg = {"input (also the residual: read once)": 1073741824, "weights": 1179648, "output": 1073741824}
+json.dump({"kernel": "conv3x3_patch_kernel<f16,128,2,16,0,false,1,true>",
+           "launch": "decoder_visualize res-block conv as the model issues it: n=128 images, 128x128, 256(+2 CoordConv)->256, fp16 forward tensors in post-activation storage, LDS-DMA patch, residual taken from the resident patch (tools/one_conv.py fwd)",
            "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --output-format csv -- python3 tools/one_conv.py fwd",
            "FETCH_SIZE_kb_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_kb_per_launch": vals["WRITE_SIZE"],
            "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE exact",
@@ -62,7 +62,7 @@ for m in fwd dgrad wgrad; do
   (echo "== $m"; cat $R/gpurun_out/pmc_${TAG}_sq_$m.txt) >> $O/${TAG}_sq_dv_rb128.txt 2>/dev/null
   rm -rf $R/gpurun_out/pmc_${TAG}_sq_$m $R/gpurun_out/pmc_${TAG}_sq_$m.txt
 done
-python3 tools/bench_conv.py --iters 10 > $O/${TAG}_bench_conv.txt 2>&1
+(echo "== bf16, activation-on-load (round-2 form)"; python3 tools/bench_conv.py --iters 10; echo "== the model form: post-activation storage; fp16 forward tensors for the 3x3 layers"; python3 tools/bench_conv.py --iters 10 --post --f16) > $O/${TAG}_bench_conv.txt 2>&1
 python3 tools/bench_conv.py --fp8 --iters 10 --only dv_rb128,dv_rb64,dv_rb32,dv_rb16,ea_rb2,vgg3_2,vgg4_2 > $O/${TAG}_bench_conv_fp8.txt 2>&1
 python3 tools/hbm_roofline.py --json $O/${TAG}_hbm_kernels.json > $O/${TAG}_hbm_kernels.txt 2>&1
 cat $O/${TAG}_bench_b64.json | cut -c1-300; cat $O/${TAG}_bench_b64_nooverlap.json | cut -c1-200
