@@ -99,13 +99,17 @@ template <> struct Frag16<bf16, 0> { typedef bf16x8 type; };
 template <> struct Frag16<f16, 0> { typedef f16x8 type; };
 // F8: a 16-byte fragment holds 16 e4m3 channels -- two v_mfma_f32_16x16x32_fp8_fp8 per fragment pair (low / high 8 bytes:
 // both operands use the same byte -> k mapping), a 64-byte pixel / weight row is a chunk of 64 channels.
-template <typename T, int TM16, int TN16, int ROWB, int F8>
+// A2: the A fragments of the NEXT tap are requested at the start of the current one (a second register set: the instances
+// whose patch arrives by LDS-DMA have the 16 VGPRs to spare) instead of behind its last MFMAs, where their LDS latency sat
+// in front of every tap.
+template <typename T, int TM16, int TN16, int ROWB, int F8, bool A2 = false>
 __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsigned char* B, const int (&arow)[TM16],
                                             int po0, int po1, int po2, int sw0, int sw1, int sw2, int b_tap_stride,
                                             f32x4v (&acc)[TM16][TN16]) {
     typedef typename Frag16<T, F8>::type frag_t;
-    frag_t fa[TM16], fb[2][2];
+    frag_t fa2[A2 ? 2 : 1][TM16], fb[2][2];
     auto fetch_a = [&](int t) __attribute__((always_inline)) {
+        frag_t (&fa)[TM16] = fa2[A2 ? (t & 1) : 0];
         const int po = t == 0 ? po0 : (t == 1 ? po1 : po2);
         const int sw = t == 0 ? sw0 : (t == 1 ? sw1 : sw2);
         if constexpr (ROWB > 0) {
@@ -132,6 +136,8 @@ __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsign
             // the next B pair is requested before this pair's MFMAs (second register slot), the next tap's A fragments behind
             // the last MFMAs that read the current ones
             if (step + 1 < 3 * NP) fetch_b((step + 1) / NP, (step + 1) % NP, (step + 1) & 1);
+            if constexpr (A2) { if (jh == 0 && t + 1 < 3) fetch_a(t + 1); }
+            frag_t (&fa)[TM16] = fa2[A2 ? (t & 1) : 0];
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM16; ++i)
@@ -150,7 +156,7 @@ __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsign
                         acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[step & 1][jj], fa[i], acc[i][2 * jh + jj], 0, 0, 0);
                     }
             __builtin_amdgcn_s_setprio(0);
-            if (jh + 1 == NP && t + 1 < 3) fetch_a(t + 1);
+            if constexpr (!A2) { if (jh + 1 == NP && t + 1 < 3) fetch_a(t + 1); }
         }
     }
 }
@@ -202,6 +208,11 @@ template <typename T, int BN, int OCC, int SUB, int F8 = 0, bool PRE = false, in
 __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const PatchK p, const int tiles_x, const int tiles_y,
                                                                  const int ntn, const int kchunks, const int nblocks) {
     constexpr int EPC = Chunk<T>::N;
+#if defined(UPS_PATCH_A2)
+    constexpr bool A2FR = DMAP;                  // second A-fragment register set (bf16_taps16): measured SLOWER (round 3: the 128-wide
+#else                                            // two-blocks-per-CU instances spill at 128 VGPRs: dgrad 2.28 -> 3.07 ms), off by default
+    constexpr bool A2FR = false;
+#endif
     constexpr int BK = 4 * EPC;                  // weight-row elements of T per 64-byte row (the fp8 rows are addressed as T too)
     constexpr int BKA = F8 ? 64 : BK;            // input channels per chunk
     static_assert(!F8 || (sizeof(T) == 2 && SUB == TS && (OCC == 1 || PRE)), "fp8 operands: bf16 tensors, one tile per image; two blocks per CU only with a pre-quantised input");
@@ -606,7 +617,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 const unsigned char* B = Bst + g * BST + (wn * TN * 32) * 64 + boff16;
                 if constexpr (TAPS != 0) {
                     const int po0 = ((TAPS == 1 ? g : 2 - g) * PWPS + (TAPS == 1 ? 0 : 2)) * APX;
-                    bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(Abuf, B, arow16, po0, po0 + (TAPS == 1 ? APX : -APX),
+                    bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8, A2FR>(Abuf, B, arow16, po0, po0 + (TAPS == 1 ? APX : -APX),
                                             po0 + (TAPS == 1 ? 2 * APX : -2 * APX), TAPS == 1 ? swx0 : swx2, swx1, TAPS == 1 ? swx2 : swx0,
                                             BN * 64, acc16);
                 } else {
@@ -614,7 +625,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                     const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
                     const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
                     const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
-                    bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(Abuf, B, arow16, po0, po1, po2,
+                    bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8, A2FR>(Abuf, B, arow16, po0, po1, po2,
                                             a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4), a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                             a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
                 }
@@ -639,7 +650,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 // static tap geometry: tap-row g reads patch rows g .. (forward) / 2-g .. (flipped), its three taps the column
                 // shifts 0, 1, 2 / 2, 1, 0: two scalar operations instead of the tap decode, loop-invariant lane terms
                 const int po0 = ((TAPS == 1 ? g : 2 - g) * PWPS + (TAPS == 1 ? 0 : 2)) * APX;
-                bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po0 + (TAPS == 1 ? APX : -APX),
+                bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8, A2FR>(A, B, arow16, po0, po0 + (TAPS == 1 ? APX : -APX),
                                         po0 + (TAPS == 1 ? 2 * APX : -2 * APX), TAPS == 1 ? swx0 : swx2, swx1, TAPS == 1 ? swx2 : swx0,
                                         BN * 64, acc16);
             } else {
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
             const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
             const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
-            bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
+            bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8, A2FR>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
             }
@@ -683,7 +694,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             if (g == 0) add_res_patch(A, cc);
             if constexpr (TAPS != 0) {
                 const int po0 = ((TAPS == 1 ? g : 2 - g) * PWPS + (TAPS == 1 ? 0 : 2)) * APX;
-                bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po0 + (TAPS == 1 ? APX : -APX),
+                bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8, A2FR>(A, B, arow16, po0, po0 + (TAPS == 1 ? APX : -APX),
                                         po0 + (TAPS == 1 ? 2 * APX : -2 * APX), TAPS == 1 ? swx0 : swx2, swx1, TAPS == 1 ? swx2 : swx0,
                                         BN * 64, acc16);
             } else {
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
             const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
             const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
-            bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
+            bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8, A2FR>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
             }

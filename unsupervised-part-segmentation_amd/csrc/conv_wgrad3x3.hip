@@ -373,7 +373,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_kernel(const Wg3K p, const 
             const bf16x8 b = tr_frag_d<BN>(D, ks * TW, w_co, lane);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int row0 = (ks + g_dy(p.tap_off, t) + 1) * PWID + g_dx(p.tap_off, t) + 1;
+                // SLIDE instances are only launched for the r-major tap order: the window offsets are then immediates
+                const int row0 = SLIDE ? (ks + t / 3) * PWID + t % 3 : (ks + g_dy(p.tap_off, t) + 1) * PWID + g_dx(p.tap_off, t) + 1;
                 const bf16x8 a = tr_frag3(X, RSX, row0, w_ci * 32, lane);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
             }
@@ -515,9 +516,10 @@ int ups_wgrad3x3_run(const ups_wgrad_desc* d, hipStream_t s) {
     }
     const int cit = ups_cdiv(d->ci, v.cb), cot = ups_cdiv(d->co, v.bn);
     if (v.cb == 64 && v.bn == 128) return k.taps_std ? launch3<64, 128, 8, true>(k, cit, cot, d->splitk, s) : launch3<64, 128, 8>(k, cit, cot, d->splitk, s);
-    if (v.cb == 64 && v.bn == 64) return launch3<64, 64, 8>(k, cit, cot, d->splitk, s);
-    if (v.cb == 64 && v.bn == 32) return launch3<64, 32, 8>(k, cit, cot, d->splitk, s);
-    if (v.cb == 32 && v.bn == 128) return launch3<32, 128, 8>(k, cit, cot, d->splitk, s);
-    if (v.cb == 32 && v.bn == 64) return launch3<32, 64, 16>(k, cit, cot, d->splitk, s);
-    return launch3<32, 32, 16>(k, cit, cot, d->splitk, s);
+    // (SLIDE on the variants whose waves do not walk every row = the r-major tap order known at compile time, nothing else)
+    if (v.cb == 64 && v.bn == 64) return k.taps_std ? launch3<64, 64, 8, true>(k, cit, cot, d->splitk, s) : launch3<64, 64, 8>(k, cit, cot, d->splitk, s);
+    if (v.cb == 64 && v.bn == 32) return k.taps_std ? launch3<64, 32, 8, true>(k, cit, cot, d->splitk, s) : launch3<64, 32, 8>(k, cit, cot, d->splitk, s);
+    if (v.cb == 32 && v.bn == 128) return k.taps_std ? launch3<32, 128, 8, true>(k, cit, cot, d->splitk, s) : launch3<32, 128, 8>(k, cit, cot, d->splitk, s);
+    if (v.cb == 32 && v.bn == 64) return k.taps_std ? launch3<32, 64, 16, true>(k, cit, cot, d->splitk, s) : launch3<32, 64, 16>(k, cit, cot, d->splitk, s);
+    return k.taps_std ? launch3<32, 32, 16, true>(k, cit, cot, d->splitk, s) : launch3<32, 32, 16>(k, cit, cot, d->splitk, s);
 }
