@@ -337,6 +337,19 @@ class Trainer(object):
             self.logger.info("Lazily restored {} of {} variables from the TensorFlow checkpoint {}".format(
                 len(loaded), len(bank.params), prefix))
         self.restored_from_tf = sorted(loaded)
+        # what slim.assign_from_checkpoint would ALSO have restored but cannot be matched here: the reference's unnamed
+        # non-trainable scalars (Lagrangian multipliers, EMAs) and the optimizers' beta powers.  Say so instead of silently
+        # restarting them (the multipliers / EMAs start from their yaml initial values, Adam's step count from the file name).
+        self.not_restored_from_tf = sorted(n for n in _other if n != "global_step")
+        if self.not_restored_from_tf:
+            msg = ("TensorFlow checkpoint {}: {} non-trainable / optimizer scalars are NOT restored (unnamed in the reference's graph: "
+                   "{} ...): lon / loa / lor and the EMAs restart from their initial values, Adam's bias correction from step {}"
+                   .format(prefix, len(self.not_restored_from_tf), ", ".join(self.not_restored_from_tf[:4]), self.global_step))
+            if self.logger:
+                self.logger.warning(msg)
+            else:
+                import sys
+                sys.stderr.write("[WARNING] " + msg + "\n")
 
     def export_tf_checkpoint(self, prefix):
         """Write the trainable variables (+ Adam slots) as a TensorFlow tensor bundle the reference's graph can restore."""

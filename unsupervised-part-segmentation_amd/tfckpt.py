@@ -289,8 +289,10 @@ def write_bundle(prefix, tensors, block_bytes=4096, with_crc=True):
 def to_trainer_state(bundle):
     """Split a TF checkpoint's variables into this package's checkpoint pieces: parameters by name, Adam slots
     (``<var>/Adam`` = m, ``<var>/Adam_1`` = v: tf.train.AdamOptimizer slot names; one optimizer per loss key adds ``_k``
-    suffixes to the later optimizers' slots of shared names only, which this model does not have), the global step and the
-    non-trainable Lagrangian / EMA scalars where present."""
+    suffixes to the later optimizers' slots of shared names only, which this model does not have) and everything else
+    (``other``: the global step, the optimizers' ``beta1_power`` / ``beta2_power`` scalars and the reference's UNNAMED
+    non-trainable variables -- ``Variable``, ``Variable_1``, ...: the Lagrangian multipliers lon / loa / lor and the seven EMAs,
+    model.py:503, 829-834, 890, 921 -- which cannot be told apart by name; the caller reports them as not restored)."""
     params, m, v, other = {}, {}, {}, {}
     for name, arr in bundle.items():
         if name.endswith("/Adam"):
