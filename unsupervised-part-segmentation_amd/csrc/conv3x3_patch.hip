@@ -1268,7 +1268,9 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
                       d->act_in == UPS_ACT_NONE &&    // (with activation-on-load the patch holds act(x), the residual wants x)
                       dma_patch_on() && static_taps_on() && (fwd || flip);       // ... and only the DMA-patch instances implement it
     }
-    if ((d->out_act || d->res_act) && (d->out_f8 || d->out_f8_amax || d->mask_grad || d->d2s)) return 1;   // (no fp8 copy of a post-activation tensor)
+    if ((d->out_act || d->res_act) && (d->mask_grad || d->d2s)) return 1;
+    // an fp8 copy of a post-activation output is the quantisation of the stored value: no second activation
+    if (d->out_act && (d->out_f8 || d->out_f8_amax) && d->out_f8_act != UPS_ACT_NONE) return 1;
     k.tap_off = 0; k.tap_wi = 0;
     for (int t = 0; t < 9; ++t) {
         k.tap_off |= (unsigned long long)(((d->tap_dy[t] + 1) << 2) | (d->tap_dx[t] + 1)) << (4 * t);

@@ -205,7 +205,7 @@ class Trainer(object):
             raise NotImplementedError("the 'pretty' image discriminator (model.py:190-212) is not used by the shipped configs")
         vw = config.get("vgg_widths", N.VGG_WIDTHS)
         self.vgg = N.VggTrunk(self.device, seed=config.get("vgg_seed", 7), widths=tuple(vw),
-                              post_storage=model.nets.post_storage and not ops.Fp8.enabled)
+                              post_storage=model.nets.post_storage)
         # `vgg_weights`: npz / torch file with the Keras VGG19 ImageNet kernels in HWIO (edflow downloads them at run time;
         # they are not obtainable offline).  Without it the perceptual loss runs on seeded He-normal stand-ins: fine for
         # timing and parity, NOT for training a model that should match the reference's part quality -- say so loudly.

@@ -137,9 +137,10 @@ class Scope(object):
         return lay
 
     def post_ok(self):
-        """Post-activation storage is used for leaky-ReLU scopes (the residual must be recoverable from act(x)); not in fp8 mode
-        (its producers quantise act(out) themselves) and not when switched off (`post_activation_storage: False`, A/B runs)."""
-        return self.act == L.ACT_LRELU and not ops.Fp8.enabled and self.owner.post_storage
+        """Post-activation storage is used for leaky-ReLU scopes (the residual must be recoverable from act(x)), unless switched
+        off (`post_activation_storage: False`, A/B runs).  In fp8 mode a producer's fp8 copy of such a tensor is the plain
+        quantisation of what it stores (ops.conv_forward)."""
+        return self.act == L.ACT_LRELU and self.owner.post_storage
 
     def conv2d(self, x, cout, k=3, stride=1, act_in=L.ACT_NONE, res=None, res_self=False, out_f32=False, post=False):
         """post: store the output as act(out) -- its only convolution consumer is a residual block / an activated nin of THIS

@@ -524,7 +524,9 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
                 eo = layer._cache["f8o"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
             if Fp8.wanted(eo):
                 d.out_f8_amax = Fp8.amax[eo["slot"]].data_ptr()
-                d.out_f8_act = want_act
+                # a post-activation output already holds want_act(out): its copy is the quantisation of the stored value
+                assert not layer.out_act or layer.out_act == want_act
+                d.out_f8_act = L.ACT_NONE if layer.out_act else want_act
                 if Fp8.steps > eo["born"]:                 # its delayed scale exists
                     t8 = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
                     d.out_f8, d.out_f8_scale = t8.data_ptr(), Fp8.scale[eo["slot"]:].data_ptr()
