@@ -201,8 +201,62 @@ def test_csv_pair_datasets(tmp_path):
     assert ex["gt_segmentation"].shape == (16, 16) and ex["gt_segmentation"].dtype == np.int64 and ex["gt_segmentation"].max() <= 4
     pair = data.StochasticPairs(dict(cfg, data_flip_h=True))
     assert set(pair.get_example(0)) == {"view0", "view1"}
-    with pytest.raises(NotImplementedError):
-        data.AugmentedPair2(dict(cfg, data_augment_shape=True))
+    # the augmentation switches of the yaml (data.py:56-57, 166-173): reproducible, in range, and with the reference's sync rules
+    aug = dict(cfg, data_augment_shape=True, data_augment_appearance=True, spatial_size=32)
+    e1, e2 = data.AugmentedPair2(aug).get_example(1), data.AugmentedPair2(aug).get_example(1)
+    for k in ("view0", "view1", "view0_target"):
+        assert np.array_equal(e1[k], e2[k]) and e1[k].shape == (32, 32, 3) and e1[k].dtype == np.float32
+        assert -1.0 <= e1[k].min() and e1[k].max() <= 1.0
+    geo = data.AugmentedPair2(dict(aug, data_augment_appearance=False))
+    changed = 0
+    for i in range(7):
+        for _ in range(3):
+            ex = geo.get_example(i)
+            # shape-only: view0 and its target went through one geometric realisation of the same image -> identical
+            assert np.array_equal(ex["view0"], ex["view0_target"])
+            changed += int(not np.allclose(ex["view0"], data.AugmentedPair2(dict(cfg, spatial_size=32)).get_example(i)["view0"], atol=1e-2))
+    assert changed > 0
+
+
+def test_augmentation_pipelines():
+    """augment.py, the numpy restatement of cub/code/data/data.py:64-117: every transform alone, and the pipelines' sync rule
+    (one realisation for all images of a call)."""
+    import numpy as np
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import augment as A
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (24, 20, 3)).astype(np.uint8)
+    # HSV round trip through the cv2 uint8 convention (H halved): within the quantisation of H (2 degrees)
+    back = A.hsv_to_rgb_u8(A.rgb_to_hsv_u8(img)).astype(int)
+    assert np.abs(back - img.astype(int)).max() <= 12 and np.abs(back - img.astype(int)).mean() < 2.5
+    gray = np.repeat(img[..., :1], 3, -1)
+    assert np.array_equal(A.hsv_to_rgb_u8(A.rgb_to_hsv_u8(gray)), gray)            # no hue, no saturation: exact
+    assert np.array_equal(A._brightness_contrast(img, 1.0, 0.0), img) and A._brightness_contrast(img, 1.2, 0.2).min() >= 51
+    assert np.array_equal(A._rgb_shift(img, [0, 0, 0]), img) and np.array_equal(A._hue_sat_val(gray, 0, 0, 0), gray)
+    g = A._to_gray(img)
+    assert np.array_equal(g[..., 0], g[..., 1]) and np.array_equal(g[..., 1], g[..., 2])
+    const = np.full((24, 20, 3), 77, np.uint8)
+    assert np.array_equal(A._box3(const), const) and np.array_equal(A._median3(const), const)
+    # geometric transforms keep the shape, replicate the border (a constant image stays constant) and move something
+    for make in (A._shift_scale_rotate, A._piecewise_affine, A._elastic):
+        op = make(np.random.RandomState(3), 24, 20)
+        assert np.array_equal(op(const), const) and op(img).shape == img.shape and not np.array_equal(op(img), img)
+    # identity shift/scale/rotate parameters give the identity map
+    class Zero(object):
+        def uniform(self, a, b, *s):
+            return np.zeros(s) if s else 0.0
+    assert np.array_equal(A._shift_scale_rotate(Zero(), 24, 20)(img), img)
+    # one realisation per call: two copies of an image stay equal through either pipeline, over many draws; some draws change it
+    f = img.astype(np.float32) / 127.5 - 1.0
+    moved = 0
+    for seed in range(40):
+        r = np.random.RandomState(seed)
+        a, b = A.stochastic_appearance_augmentation(r, f, f.copy())
+        c, d = A.stochastic_shape_augmentation(r, f, f.copy())
+        assert np.array_equal(a, b) and np.array_equal(c, d) and a.dtype == np.float32 and c.shape == f.shape
+        assert -1.0 <= min(a.min(), c.min()) and max(a.max(), c.max()) <= 1.0
+        moved += int(not np.allclose(a, f, atol=1e-2)) + int(not np.allclose(c, f, atol=1e-2))
+    assert 20 < moved < 80                       # p = 0.9 x the inner probabilities: most draws do something, not all
 
 
 def test_part_iou_evaluation(tmp_path):

@@ -5,8 +5,9 @@
     the same character_id), both resized to ``spatial_size`` and scaled to [-1, 1]; ``data_avoid_identity`` excludes
     j = i when the character has more than one image; ``data_flip_h`` / ``data_flip_v`` flip BOTH views together.
   * ``AugmentedPair2``   -- cub/code/data/data.py:52-175 on top of it: adds ``view0_target`` (a copy of view0).  The
-    albumentations appearance / shape augmentations (data_augment_appearance / data_augment_shape, both False in the
-    shipped yaml) are not reproduced and raise when requested.
+    appearance / shape augmentations (data_augment_appearance / data_augment_shape, both False in the shipped yaml) are the
+    numpy restatement of the albumentations pipelines in ``augment.py`` (same transforms, defaults and sync rules; the
+    sample stream is not albumentations').
 
 The exact resize filter / cropping of eddata's ``preprocess_image`` is not visible in the reference tree: bilinear resize
 of the whole image is used (UNVERIFIED).  ``batches`` turns a dataset into the ``{"view0", "view1"[, "view0_target"]}``
@@ -104,13 +105,23 @@ class AugmentedPair2(StochasticPairs):
 
     def __init__(self, config):
         super(AugmentedPair2, self).__init__(config)
-        if config.get("data_augment_appearance", False) or config.get("data_augment_shape", False):
-            raise NotImplementedError("albumentations appearance / shape augmentation (cub/code/data/data.py:57-117) is not "
-                                      "reproduced; the shipped yaml keeps both off")
+        self.use_appearance_augmentation = config.get("data_augment_appearance", False)       # data.py:56-57
+        self.use_shape_augmentation = config.get("data_augment_shape", False)
 
     def get_example(self, i):
+        from . import augment
         ex = super(AugmentedPair2, self).get_example(i)
-        ex["view0_target"] = ex["view0"].copy()         # data.py:164
+        view0, view1 = ex["view0"], ex["view1"]
+        target = view0.copy()                           # data.py:164
+        if self.use_appearance_augmentation or self.use_shape_augmentation:
+            rng = np.random.RandomState([self.seed & 0x7fffffff, int(i), self.draws[int(i)], 7])
+            if self.use_appearance_augmentation:        # data.py:167-169: view1 and the target share one realisation
+                view0, = augment.stochastic_appearance_augmentation(rng, view0)
+                view1, target = augment.stochastic_appearance_augmentation(rng, view1, target)
+            if self.use_shape_augmentation:             # data.py:171-173: view0 and the target share one realisation
+                view0, target = augment.stochastic_shape_augmentation(rng, view0, target)
+                view1, = augment.stochastic_shape_augmentation(rng, view1)
+        ex.update(view0=view0, view1=view1, view0_target=target)
         return ex
 
 
