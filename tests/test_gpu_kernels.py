@@ -826,6 +826,83 @@ def test_conv_fp8_copy_handed_from_producer_to_consumer(case, dev):
     assert float((za[..., :cout].float() - zb0[..., :cout].float()).abs().max()) < 0.1 * float(zb0.float().abs().max())
 
 
+@pytest.mark.parametrize("case", [
+    # n, h, cin, cout, coords, res_self      (grids of >= 512 blocks with whole 128-channel double chunks)
+    (8, 128, 128, 128, True, True),          # one double chunk, 128-wide N-tile
+    (4, 128, 256, 256, True, True),          # the dominant decoder layer's shape: two double chunks, two N-tiles
+    (32, 64, 128, 64, False, False),         # 64-wide N-tile
+    (2, 128, 256, 256, True, True),          # small grid: stays on the K = 32 path (same expectation)
+])
+def test_conv_fp8_block_scaled_mfma(case, dev):
+    """The block-scaled K = 128 MFMA path (v_mfma_scale_f32_16x16x128_f8f6f4, conv3x3_patch.hip f8s_tap): a consumer of a
+    pre-quantised e4m3 copy (forward) / e5m2 copy (input gradient) on a grid of two blocks per CU, against the same arithmetic
+    restated in torch from the very bytes the kernel reads (exact products, fp64 accumulation; the kernel accumulates in fp32),
+    and against the unquantised convolution at the fp8 error level."""
+    lib, ops, R = _mods()
+    n, h, cin, cout, coords, res_self = case
+    g0 = torch.Generator().manual_seed(31)
+    cv = cin + (2 if coords else 0)
+    V = torch.randn(3, 3, cv, cout, generator=g0) / math.sqrt(9 * cv)
+    V[..., : cout // 3] *= 4.0
+    V[:, :, : cin // 2] *= 2.0
+    b = torch.randn(cout, generator=g0) * 0.1
+    x = (torch.randn(n, h, h, cin, generator=g0) * 1.5).to(torch.bfloat16)
+    gy = (torch.randn(n, h, h, cout, generator=g0) * 0.02).to(torch.bfloat16)
+    lay = _layer(ops, lib, V, b, 3, 1, coords, "leaky_relu", dev)
+    xd, gd = x.to(dev), gy.to(dev)
+    F = ops.Fp8
+    F.reset()
+    F.enabled = True
+    try:
+        # ---- forward: e4m3(lrelu(x) * s_a) handed in as a producer's copy
+        xa = torch.maximum(x.float(), 0.2 * x.float())
+        s_a = 448.0 * F.MARGIN / float(xa.abs().max())
+        sl = F.slot(dev)
+        F.scale[sl] = s_a
+        xq8 = (xa * s_a).clamp(-448, 448).to(torch.float8_e4m3fn)
+        F.next_in = {"t": xq8.view(torch.uint8).to(dev), "slot": sl, "act": lib.ACT_LRELU, "site": None}
+        y = ops.conv_forward(xd, lay, res=xd if res_self else None)
+        assert F.stats["fwd_copy_in"] == 1
+        # ---- input gradient: e5m2(gy * s_g) registered as the copy of exactly this gradient tensor
+        s_g = 57344.0 * F.MARGIN / float(gy.float().abs().max())
+        sg = F.slot(dev)
+        F.scale[sg] = s_g
+        gq8 = (gy.float() * s_g).clamp(-57344, 57344).to(torch.float8_e5m2)
+        F.register_grad_copy(gd, {"t": gq8.view(torch.uint8).to(dev), "slot": sg, "site": None})
+        gx = ops.conv_dgrad(gd, xd, lay)
+        assert F.stats["dgrad_copy_in"] == 1
+        torch.cuda.synchronize()
+    finally:
+        F.enabled = False
+        F.next_in = F.next_out_act = F.last_out = None
+        F.reset()
+    # forward expectation
+    wmax = V[:, :, :cin].abs().amax(dim=(0, 1, 2))
+    wq = (V[:, :, :cin] * (448.0 / wmax)).clamp(-448, 448).to(torch.float8_e4m3fn).double()
+    acc = R.conv2d_same(xq8.double(), wq, torch.zeros(cout, dtype=torch.float64), 1) * (wmax.double() / 448.0) / s_a
+    extra = b.double().view(1, 1, 1, -1).expand_as(acc).clone()
+    if coords:
+        Vc = V.double().clone(); Vc[:, :, :cin] = 0
+        extra = extra + R.conv2d_same(R.Scope.add_coordinates(torch.zeros(n, h, h, cin, dtype=torch.float64)), Vc,
+                                      torch.zeros(cout, dtype=torch.float64), 1)
+    ref_q = acc + extra + (x.double() if res_self else 0)
+    got = y[..., :cout].float().cpu()
+    assert_close(got, ref_q.float(), 1e-2, "block-scaled fp8 forward vs e4m3 emulation")      # (bf16 output rounding)
+    ref = _oracle_conv(R, x.double(), V.double(), b.double(), 1, coords, "leaky_relu", res_self, None)
+    err = float((got.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert err < 0.05, "fp8 forward vs unquantised convolution: rel RMS {:.3g}".format(err)
+    # input-gradient expectation
+    wmax_i = V[:, :, :cin].abs().amax(dim=(0, 1, 3))
+    wqi = (V[:, :, :cin] * (448.0 / wmax_i).view(1, 1, -1, 1)).clamp(-448, 448).to(torch.float8_e4m3fn).double()
+    z = torch.zeros(n, h, h, cin, dtype=torch.float64, requires_grad=True)
+    yz = R.conv2d_same(z, wqi, torch.zeros(cout, dtype=torch.float64), 1)
+    ref_g, = torch.autograd.grad((yz * gq8.double()).sum(), z)
+    ref_g = ref_g * (wmax_i.double() / 448.0) / s_g
+    xf = x.double()
+    ref_g = ref_g * torch.where(xf > 0, torch.ones_like(xf), torch.full_like(xf, 0.2))
+    assert_close(gx[..., :cin].float().cpu(), ref_g.float(), 1e-2, "block-scaled fp8 input gradient vs e5m2 / e4m3 emulation")
+
+
 def test_bilinear_fp8_copies(dev):
     """The bilinear x2 kernels as fp8 producers: same bf16 result as the plain kernels, the forward copy = e4m3(lrelu(y) * scale), the
     backward copy = e5m2(gx * scale), the recorded maxima exact."""

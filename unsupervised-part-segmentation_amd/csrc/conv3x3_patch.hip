@@ -161,6 +161,49 @@ __device__ __forceinline__ void bf16_taps16(const unsigned char* A, const unsign
     }
 }
 
+// fp8, block-scaled (F8 = 3 / 4): ONE tap of a 128-channel double chunk on v_mfma_scale_f32_16x16x128_f8f6f4 (E8M0 scales 1.0:
+// the tensors carry per-tensor / per-channel scales applied in the epilogue).  The instruction takes 32 bytes per lane and
+// operand -- lane (row l & 15, k-block l >> 4) holds k = 32 (l >> 4) .. + 31 of BOTH operands (tools/probes/mfma_scale_probe.hip)
+// -- and the order of k is free as long as both operands agree: the lane's 32 bytes are the SAME 16-byte slot of two resident
+// 64-byte chunk images (channels 16 q .. of chunk 2c and of chunk 2c + 1), so patch layout, swizzle and weight layout are those
+// of the K = 32 path.  4x the K of the bf16 MFMA in 2x its cycles (measured 4.4 PFLOP/s against 1.5 for 16x16x32_fp8_fp8).
+typedef __attribute__((ext_vector_type(8))) int i32x8v;
+template <int TM16, int TN16, int ROWB, int ABYTES, int BHALF, bool E5M2, int BBUFS>
+__device__ __forceinline__ void f8s_tap(const unsigned char* A, const unsigned char* B, int at, f32x4v (&acc)[TM16][TN16]) {
+    typedef __attribute__((ext_vector_type(4))) int i32x4v;
+    i32x8v fa[TM16], fb[BBUFS];      // (BBUFS = 1 at 64 accumulator registers: the second B slot does not fit 128 VGPRs)
+    auto cat = [](i32x4v lo, i32x4v hi) __attribute__((always_inline)) -> i32x8v {
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto fetch_b = [&](int j, int slot) __attribute__((always_inline)) {
+        fb[slot] = cat(*(const i32x4v*)(B + j * (16 * 64)), *(const i32x4v*)(B + BHALF + j * (16 * 64)));
+    };
+    fetch_b(0, 0);
+#pragma unroll
+    for (int i = 0; i < TM16; ++i) fa[i] = cat(*(const i32x4v*)(A + at + i * ROWB), *(const i32x4v*)(A + ABYTES + at + i * ROWB));
+#pragma unroll
+    for (int j = 0; j < TN16; ++j) {
+        if (BBUFS == 2 && j + 1 < TN16) fetch_b(j + 1, (j + 1) & 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM16; ++i)      // weights as the row operand (e4m3), pixels e4m3 (activations) or e5m2 (gradients)
+#if defined(UPS_ABLATE_MFMA)
+            acc[i][j][0] += __int_as_float(fb[BBUFS == 2 ? (j & 1) : 0][i] ^ fa[i][j & 7]);
+#else
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[BBUFS == 2 ? (j & 1) : 0], fa[i], acc[i][j], 0, E5M2 ? 1 : 0,
+                                                                          0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#endif
+        __builtin_amdgcn_s_setprio(0);
+        // no hoisting of later fetches above these MFMAs (the scheduler otherwise requests every B fragment up front and
+        // spills accumulators to hold them)
+#pragma unroll
+        for (int i = 0; i < TM16; ++i) asm volatile("" : "+v"(acc[i][j]));      // pins the MFMAs here (they are sunk to the loop end otherwise)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (BBUFS == 1 && j + 1 < TN16) fetch_b(j + 1, 0);
+    }
+}
+
 template <> struct PMma<float> {
     template <int TM, int TN, int PITCH>
     __device__ static inline void tap(const unsigned char* a_pix, int hh, int v, const unsigned char* b_lane, f32x16 (&acc)[TM][TN]) {
@@ -215,9 +258,18 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #endif
     constexpr int BK = 4 * EPC;                  // weight-row elements of T per 64-byte row (the fp8 rows are addressed as T too)
     constexpr int BKA = F8 ? 64 : BK;            // input channels per chunk
+    constexpr bool F8S = F8 >= 3;                // block-scaled K = 128 MFMA over pairs of 64-channel chunks (f8s_tap)
+    constexpr int F8K = F8S ? F8 - 2 : F8;       // 1: e4m3 pixels (activations), 2: e5m2 pixels (gradients)
     static_assert(!F8 || (sizeof(T) == 2 && SUB == TS && (OCC == 1 || PRE)), "fp8 operands: bf16 tensors, one tile per image; two blocks per CU only with a pre-quantised input");
+    static_assert(!F8S || (PRE && OCC == 2 && BN >= 64 && TAPS == 0 && !DMAP), "block-scaled fp8: pre-quantised input, two blocks per CU");
     static_assert(!PRE || F8, "a pre-quantised input implies fp8 operands");
+#if defined(UPS_F8S_WN1)
+    // (block-scaled fp8, alternative wave tile: 2 tile rows x ALL the N-tile's channels -- 16 A registers resident, the B fragments
+    // stream through two slots; 20 instead of 16 fragment reads per step and an epilogue that spills: not the default)
+    constexpr int WN = (BN == 32 || F8 >= 3) ? 1 : 2;
+#else
     constexpr int WN = (BN == 32) ? 1 : 2;
+#endif
     constexpr int WM = 8 / WN;                   // 4 or 8 waves along the pixels
     constexpr int TM = 256 / WM / 32;            // 2 or 1
     constexpr int TN = BN / WN / 32;             // 2, 1, 1
@@ -299,20 +351,21 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     // DMAP: piece j = wid + 8 q fills LDS bytes [j * 1024, +1024) of the patch image = pixel slots 16 j .. 16 j + 15
     unsigned pd_off[3] = {0u, 0u, 0u};
     unsigned long long pd_mask[3] = {0ull, 0ull, 0ull};
-    if constexpr (DMAP) {
-        static_assert(SUB == TS && F8 == 0 && sizeof(T) == 2, "DMA patch: one tile per image, 16-bit tensors");
+    if constexpr (DMAP || F8S) {
+        // (F8S: the pre-quantised tensor has one byte per channel -- a pixel's 64-byte chunk is the same four 16-byte slots)
+        static_assert(SUB == TS && (F8 == 0 || F8S) && sizeof(T) == 2, "DMA patch: one tile per image, 16-bit tensors or an fp8 copy");
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int pp = (wid + 8 * q) * 16 + (lane >> 2), sl = lane & 3;
             const int py = pp / PWPS, px = pp - py * PWPS;
             const int y = ty0 - 1 + py, x = tx0 - 1 + px;
             const bool ok = py < PW && px < PW && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
-            pd_off[q] = (unsigned)(py * p.w + px) * ((unsigned)p.ldi * 2u) + (unsigned)((sl ^ a_swz16(px)) << 4);
+            pd_off[q] = (unsigned)(py * p.w + px) * ((unsigned)p.ldi * (F8S ? 1u : 2u)) + (unsigned)((sl ^ a_swz16(px)) << 4);
             pd_mask[q] = __ballot(ok);
         }
         // halo slots outside the image are never written by the DMA: zero the patch buffer(s) once, on border tiles only
         if (ty0 == 0 || tx0 == 0 || ty0 + TS >= p.h || tx0 + TS >= p.w) {
-            const int nab = (kchunks == 1 || OCC == 2) ? 1 : 2;
+            const int nab = F8S ? 2 : ((kchunks == 1 || OCC == 2) ? 1 : 2);
             for (int i = tid * 16; i < nab * ABY; i += 512 * 16) *(uint4*)(Abuf + i) = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();
         }
@@ -392,11 +445,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             for (int e = 0; e < 4; ++e) {
                 if (p.act_in != UPS_ACT_NONE) f[e] = ups_act_ns(f[e], act_ns);
                 f8_amax_t = fmaxf(f8_amax_t, fabsf(f[e]));
-                constexpr float FMAX = F8 == 2 ? 57344.f : 448.f;      // e5m2 / e4m3 largest normal
+                constexpr float FMAX = F8K == 2 ? 57344.f : 448.f;      // e5m2 / e4m3 largest normal
                 f[e] = __builtin_amdgcn_fmed3f(f[e] * f8_sa, -FMAX, FMAX);
             }
             int d = 0;
-            if constexpr (F8 == 2) {
+            if constexpr (F8K == 2) {
                 d = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], d, false);
                 d = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], d, true);
             } else {
@@ -599,6 +652,74 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 }
             }
         };
+        if constexpr (F8S) {
+        // ===== block-scaled fp8: a step is ONE tap of a double chunk (128 channels): 16 MFMAs of 32 cycles per wave.  Two patch
+        // images (chunks 2c, 2c + 1: 2 x 22.5 KB) filled by LDS-DMA from the pre-quantised copy, a 2-stage ring of per-tap weight
+        // stages [2 chunk halves][BN rows][64 B] (2 x 16 KB at BN = 128) -- 77 KB, two blocks per CU; prefetch distance 1, the
+        // patch pair re-filled behind an extra barrier at each double-chunk boundary (covered by the other block's waves).
+        constexpr int BST8 = 2 * BN * 64;
+        constexpr int NJ8 = BST8 / 1024;                 // DMA wave-instructions per stage: 16 / 8
+        constexpr int NW8 = NJ8 / 8;                     // per wave: 2 / 1
+        unsigned char* Bst8 = smem + 2 * ABY;
+        const unsigned char* __restrict__ w8 = (const unsigned char*)p.wgt;
+        unsigned d8_off[NW8];
+#pragma unroll
+        for (int q = 0; q < NW8; ++q) {
+            const int j = wid + 8 * q;
+            const int pos = j * 64 + lane, row = pos >> 2, slot = pos & 3;
+            const int half = (j * 16) / BN, rl = row - half * BN;          // a wave-instruction's 16 rows lie in one half
+            const int c = min(nt * BN + rl, p.co - 1);
+            d8_off[q] = (unsigned)(half * p.co + c) * 64u + (unsigned)((slot ^ a_swz16(row)) << 4);   // halves = consecutive k-chunks
+        }
+        const int steps = (kchunks >> 1) * 9;
+        auto dma_w8 = [&](int st) __attribute__((always_inline)) {
+            const int dc = st / 9, tp = st - dc * 9;
+            const unsigned char* slab = w8 + ((long long)p_w(p.tap_wi, tp) * kchunks + 2 * dc) * p.co * 64;
+#pragma unroll
+            for (int q = 0; q < NW8; ++q) {
+                const unsigned lds_dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(2 * ABY + (st & 1) * BST8 + (wid + 8 * q) * 1024));
+#if !defined(UPS_ABLATE_DMA)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                             :: "s"(lds_dst), "v"(d8_off[q]), "s"(slab) : "memory", "m0");
+#endif
+            }
+        };
+        auto dma_patch8 = [&](int dc) __attribute__((always_inline)) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const unsigned char* base = in8_o + (2 * dc + half) * 64;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (wid + 8 * q >= (PW * PWPS + 15) / 16) continue;        // piece 23 of 22.5 (wave-uniform)
+                    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(half * ABY + (wid + 8 * q) * 1024));
+#if !defined(UPS_ABLATE_GLOAD)
+                    asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
+                                 :: "s"(pd_mask[q]), "s"(lds_dst), "v"(pd_off[q]), "s"(base) : "memory", "m0");
+#endif
+                }
+            }
+        };
+        dma_patch8(0);
+        dma_w8(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int st = 0; st < steps; ++st) {
+            const int n1 = st + 1;
+            if (n1 < steps) dma_w8(n1);
+            const int tp = st % 9;
+            const int dx1 = p_dx(p.tap_off, tp) + 1;
+            const int at = arow16[0] + ((p_dy(p.tap_off, tp) + 1) * PWPS + dx1) * APX + a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4);
+            f8s_tap<TM16, TN16, PWPS * APX, (int)ABY, BN * 64, F8K == 2, (TM16 * TN16 == 16 && TM16 == 4 ? 1 : 2)>(Abuf, Bst8 + (st & 1) * BST8 + (wn * TN * 32) * 64 + boff16, at, acc16);
+            if (n1 < steps && n1 % 9 == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                 // every wave has read the last tap of this patch pair
+                dma_patch8(n1 / 9);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        } else {
         if constexpr (DMAP) dma_patch(0);
         else { load_patch(0); store_patch(Abuf); }
         dma_w(0);
@@ -723,6 +844,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             __builtin_amdgcn_s_barrier();
         }
         }
+        }       // (!F8S)
     } else {
     // ===== fp32 (parity mode): register-staged weights, prefetch distance 2, one barrier per tap-row
     load_patch(0); load_w(ws0, 0, 0);
@@ -1068,7 +1190,8 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     constexpr size_t BST = 3 * (size_t)BN * 64;
     const int nabuf = (sizeof(T) == 2 && SUB == TS && (kchunks == 1 || OCC == 2)) ? 1 : 2;
     size_t shmem = sizeof(T) == 2 ? nabuf * ABY + (OCC == 2 ? 2 : 3) * BST : 2 * ABY + 2 * 3 * BN * RS;
-    const size_t shmem_max = sizeof(T) == 2 ? (OCC == 2 ? 1 : 2) * ABY + (OCC == 2 ? 2 : 3) * BST : shmem;
+    size_t shmem_max = sizeof(T) == 2 ? (OCC == 2 ? 1 : 2) * ABY + (OCC == 2 ? 2 : 3) * BST : shmem;
+    if (F8 >= 3) shmem = shmem_max = 2 * ABY + 2 * (2 * (size_t)BN * 64);      // block-scaled fp8: two patch images, two per-tap stages
     const size_t epi = sizeof(T) == 2 ? 256 * (size_t)(BN * 2 + 16) + 256 * (size_t)(BN / 8) : 0;   // staged bf16 epilogue
     if (epi > shmem) shmem = epi;
     static bool attr_set = false;
@@ -1134,6 +1257,13 @@ int launch_t(const PatchK& k, hipStream_t s) {
             const int tiles8 = k.n * (k.w / TS) * (k.h / TS);
             const bool big128 = patch_occ() == 2 && tiles8 * ups_cdiv(k.co_fill, 128) >= 512;
             const bool big64 = patch_occ() == 2 && tiles8 * ups_cdiv(k.co_fill, 64) >= 512;
+            // whole 128-channel double chunks on a grid of two blocks per CU: the block-scaled K = 128 MFMA (UPS_F8_SCALED=0: off)
+            static int scaled = -1;
+            if (scaled < 0) { const char* e = getenv("UPS_F8_SCALED"); scaled = (e && e[0] == '0') ? 0 : 1; }
+            if (scaled && k.ci % 128 == 0) {
+                if (k.co_fill > 64 && big128) return k.f8_e5m2 ? launch_bn<T, 128, 2, TS, 4, true>(k, s) : launch_bn<T, 128, 2, TS, 3, true>(k, s);
+                if (k.co_fill <= 64 && big64) return k.f8_e5m2 ? launch_bn<T, 64, 2, TS, 4, true>(k, s) : launch_bn<T, 64, 2, TS, 3, true>(k, s);
+            }
             if (k.f8_e5m2) {
                 if (k.co_fill > 64) return big128 ? launch_bn<T, 128, 2, TS, 2, true>(k, s) : launch_bn<T, 128, 1, TS, 2, true>(k, s);
                 return big64 ? launch_bn<T, 64, 2, TS, 2, true>(k, s) : launch_bn<T, 64, 1, TS, 2, true>(k, s);
