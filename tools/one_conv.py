@@ -1,7 +1,8 @@
 """Runs one convolution a few times: target for rocprofv3 --pmc (tools/pmc_conv.sh).
 Usage: python tools/one_conv.py [fwd|dgrad|wgrad] [case of tools/bench_conv.py, default dv_rb128] [plain]
 The launch is issued the way the model issues it: residual block (res = in), for a 3x3 layer with an activation the input in
-post-activation storage and -- the mask decoder's layers (dv_*) -- fp16 forward tensors; `plain`: bf16, activation-on-load."""
+post-activation storage and -- the mask decoder's layers (dv_*) -- fp16 forward tensors; `plain`: bf16, activation-on-load;
+`f8`: the fp8 mode's launch -- the operand arrives as a producer's e4m3 (forward) / e5m2 (input gradient) copy."""
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +21,8 @@ b = torch.randn(cout, generator=g).to(dev)
 from upsparts_amd import lib
 lay = ops.ConvLayer("x/conv2d_0", V, b, k, stride, coords, act)
 plain = len(sys.argv) > 3 and sys.argv[3] == "plain"
-fmt = lib.F16 if (not plain and case.startswith("dv_") and k == 3) else None
+f8 = len(sys.argv) > 3 and sys.argv[3] == "f8"
+fmt = lib.F16 if (not plain and not f8 and case.startswith("dv_") and k == 3) else None
 lay.f16 = fmt == lib.F16
 if not plain and act == "leaky_relu":
     lay.in_post, lay.out_act = True, lib.ACT_LRELU
@@ -28,13 +30,28 @@ x = torch.randn(n, h, h, ops.round8(cin), device=dev).to(torch.bfloat16)
 if fmt == lib.F16:
     x = x.to(torch.float16).view(torch.bfloat16)
 res = x if (cin == cout and stride == 1 and act is not None) else None
+F = ops.Fp8
+if f8:
+    F.reset(); F.enabled = True
+    sx, sg = F.slot(dev), F.slot(dev)
+    F.scale[sx] = 448.0 * F.MARGIN / float(x.float().abs().max()); F.scale[sg] = 57344.0 * F.MARGIN / 6.0
+    x8 = (x.float() * F.scale[sx]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    F.next_in = {"t": x8, "slot": sx, "act": lay.act_in, "site": None}
 y = ops.conv_forward(x, lay, res=res, fmt=fmt, res_post=lay.in_post)
 gy = torch.randn(y.shape, device=dev).to(torch.bfloat16)
+if f8:
+    g8 = (gy.float() * F.scale[sg]).clamp(-57344, 57344).to(torch.float8_e5m2).view(torch.uint8)
 for _ in range(3):
     if mode == "fwd":
+        if f8:
+            F.next_in = {"t": x8, "slot": sx, "act": lay.act_in, "site": None}
         ops.conv_forward(x, lay, res=res, fmt=fmt, res_post=lay.in_post)
     elif mode == "dgrad":
+        if f8:
+            F.register_grad_copy(gy, {"t": g8, "slot": sg, "site": None})
         ops.conv_dgrad(gy, x, lay, res=gy if res is not None else None)
     elif mode == "wgrad":
         ops.conv_wgrad(gy, x, lay, fmt=fmt)
 torch.cuda.synchronize()
+if f8:
+    print(F.stats)
