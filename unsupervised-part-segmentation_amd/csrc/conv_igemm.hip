@@ -466,6 +466,7 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
 }  // namespace
 
 int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_patch.hip
+int ups_conv3x3_first_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_first.hip
 
 extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d != nullptr);
@@ -488,6 +489,8 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     // 3x3 / stride-1 problems on 16-aligned images go to the patch-tiled kernel (halo reuse across the 9 taps)
     const char* force = getenv("UPS_FORCE_GENERIC_CONV");
     if (!(force && force[0] == '1')) {
+        // first layers (<= 8 input channels, 32 / 64 outputs): the im2col-in-the-fragment kernel, an output-write stream
+        if (ups_conv3x3_first_try(d, (hipStream_t)stream) == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
         const int pr = ups_conv3x3_patch_try(d, (hipStream_t)stream);
         if (pr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
         if (pr < 0) { ups_set_error("ups_conv_igemm: patch kernel launch setup failed"); return pr; }
