@@ -617,6 +617,51 @@ def test_integration_stub_runs(dev):
     assert_close(out.float(), yo.float(), BF16_TOL, "INTEGRATION.md stub")
 
 
+@pytest.mark.parametrize("case", [
+    # n, h, w, cout, coords, parts, post
+    (4, 64, 48, 32, True, 10, True),         # encoder_1's first convolution: part-masked, CoordConv, stored as lrelu(y)
+    (5, 32, 64, 64, False, 0, False),        # VGG block1_conv1 form: 3 -> 64
+    (3, 16, 16, 24, True, 0, False),         # all-border tile, ragged channel tail
+])
+def test_first_layer_kernel(case, dev, monkeypatch):
+    """conv3x3_first.hip (im2col in the MFMA fragment addressing, every part image of a tile from one read of the view) against
+    the patch kernel on the same operands and against the fp64 oracle on the materialised part images."""
+    lib, ops, R = _mods()
+    n, h, w, cout, coords, parts, post = case
+    g0 = torch.Generator().manual_seed(5)
+    cv = 3 + (2 if coords else 0)
+    V = torch.randn(3, 3, cv, cout, generator=g0) / math.sqrt(9 * cv)
+    b = torch.randn(cout, generator=g0) * 0.1
+    x = torch.zeros(n, h, w, 8, dtype=torch.bfloat16)
+    x[..., :3] = torch.randn(n, h, w, 3, generator=g0).to(torch.bfloat16)
+    mask, hard = None, None
+    if parts:
+        owner = torch.randint(0, parts, (n, h, w), generator=g0)
+        bits = (1 << owner).to(torch.int32)
+        bits[0, :3, :3] = 0b101                               # several parts own a pixel / (below) nobody does
+        bits[0, 5, 5] = 0
+        mask = (bits.to(dev), parts)
+        hard = ((bits.unsqueeze(-1) >> torch.arange(parts)) & 1).double()
+    out = {}
+    for first in ("1", "0"):
+        monkeypatch.setenv("UPS_FIRST_LAYER", first)
+        lay = _layer(ops, lib, V, b, 3, 1, coords, None, dev)
+        if post:
+            lay.out_act = lib.ACT_LRELU
+        out[first] = ops.conv_forward(x.to(dev), lay, mask=mask).float().cpu()
+    assert_close(out["1"], out["0"], BF16_TOL, "first-layer kernel vs patch kernel")
+    assert float((out["1"] - out["0"]).abs().max()) <= 2.0 ** -6 * float(out["0"].abs().max())      # at most a bf16 rounding flip
+    xo = x[..., :3].double()
+    if parts:
+        xo = (xo.unsqueeze(3) * hard.unsqueeze(-1)).permute(3, 0, 1, 2, 4).reshape(parts * n, h, w, 3)
+    ref = _oracle_conv(R, xo, V.double(), b.double(), 1, coords, None, False, None)
+    if post:
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    assert_close(out["1"][..., :cout], ref.float(), BF16_TOL, "first-layer kernel vs oracle")
+    if cout < out["1"].shape[-1]:
+        assert float(out["1"][..., cout:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("P,B,S,coords", [(10, 3, 32, False), (25, 2, 48, True), (3, 5, 16, False)])
 def test_part_masked_convolution_matches_the_materialised_path(P, B, S, coords, dev):
     """mask_parts fused into encoder_1's first convolution (model.py:176-187, nn.py:81-113): forward, weight gradient and the

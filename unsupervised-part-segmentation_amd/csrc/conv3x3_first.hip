@@ -162,9 +162,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const FirstK p) {
 
 // Internal entry of ups_conv_igemm's dispatcher.  Returns 1 if the problem is not a first-layer problem, 0 when launched.
 int ups_conv3x3_first_try(const ups_conv_desc* d, hipStream_t s) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("UPS_FIRST_LAYER"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on) return 1;
+    { const char* e = getenv("UPS_FIRST_LAYER"); if (e && e[0] == '0') return 1; }     // (read per call: the parity test toggles it)
     if (d->dtype != UPS_BF16 || d->ntaps != 9 || d->ci != 8 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 ||
         d->out_oy || d->out_ox || d->hi != d->ho || d->wi != d->wo || d->out_h != d->ho || d->out_w != d->wo)
         return 1;
@@ -192,3 +190,4 @@ int ups_conv3x3_first_try(const ups_conv_desc* d, hipStream_t s) {
     else hipLaunchKernelGGL((conv3x3_first_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, k);
     return 0;
 }
+
