@@ -28,7 +28,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (guide)
 PEAK_F32_TFLOPS = 157.3
+PEAK_FP8_TFLOPS = 5000.0           # dense fp8 on the block-scaled K = 128 MFMA (guide); the K = 32 fp8 forms run at the bf16 rate
 PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("round3_pmc_dv_rb128.json", "round2_pmc_dv_rb128.json")]   # tools/profile_round.sh
+PMC_FILES_FP8 = [os.path.join(ROOT, "profiles", "round3_pmc_dv_rb128_fp8.json")]
 CPU_THREAD_CAP = 32                # torch-CPU stops scaling on this graph well before the GPU box's core count (see cpu_baseline)
 
 
@@ -202,15 +204,16 @@ def run_rank(args):
     if rank == 0:
         images = args.batch * world * args.steps
         value = images / dt
-        low = args.precision in ("bf16", "fp8")        # fp8: priced against the bf16 peak too (K = 32 fp8 MFMAs run at the bf16 rate)
-        peak = PEAK_BF16_TFLOPS if low else PEAK_F32_TFLOPS
+        # fp8: the roofline launches run on the block-scaled K = 128 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4): priced against the
+        # dense fp8 peak (MI355X_MICROARCH.md: ~5 PFLOP/s)
+        peak = {"bf16": PEAK_BF16_TFLOPS, "fp8": PEAK_FP8_TFLOPS}.get(args.precision, PEAK_F32_TFLOPS)
         dname = {"bf16": "bf16", "fp8": "fp8"}.get(args.precision, "f32")
         traffic = None
         pmc_used = None
         # HBM bytes per launch of the roofline kernel from the PMC passes committed for this tree (profiles/), not live; they were
         # taken on the headline shape (2 x 64 images of 128x128, 256 channels, bf16): reported for exactly that launch only
-        if args.config == "cub128p10" and args.precision == "bf16" and args.batch == 64:
-            for pf in PMC_FILES:
+        if args.config == "cub128p10" and args.precision in ("bf16", "fp8") and args.batch == 64:
+            for pf in (PMC_FILES_FP8 if args.precision == "fp8" else PMC_FILES):
                 try:
                     with open(pf) as f:
                         traffic = json.load(f)["traffic_bytes_per_launch"]
@@ -240,13 +243,14 @@ def run_rank(args):
                "model_tflops_per_gpu": round(value * gflop_img / 1e3 / world, 2), "train_gflop_per_image": gflop_img,
                "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel<{},128,2,16> @ {} (1 forward + 2 input-gradient "
                                                         "launches per step, all timed)".format(
-                                dname, ops.KernelTimer.layer),
+                                "bf16 tensors, block-scaled fp8 MFMA" if args.precision == "fp8" else dname, ops.KernelTimer.layer),
                             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                             "kernel_ms": round(kms, 4), "kernel_ms_forward": round(ops.KernelTimer.mean_ms("fwd"), 4),
                             "kernel_ms_dgrad": round(ops.KernelTimer.mean_ms("dgrad"), 4),
                             "launches_timed": len(ops.KernelTimer.events), "traffic": traffic,
                             "traffic_note": "HBM bytes of the forward launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                            "({}); tensor-once algorithmic bytes 2.15e9".format(pmc_used) if traffic else
+                                            "({}); tensor-once algorithmic bytes {}".format(
+                                                pmc_used, "2.69e9 (e4m3 copy in, bf16 residual in, bf16 out)" if args.precision == "fp8" else "2.15e9") if traffic else
                                             "no PMC pass committed for this launch shape",
                             "flop_per_launch": ops.KernelTimer.flops}}
         if world == 1 and not args.no_cpu_baseline:

@@ -57,13 +57,54 @@ json.dump({"kernel": "conv3x3_patch_kernel<f16,128,2,16,0,false,1,true>",
           open(O + "/%s_pmc_dv_rb128.json" % tag, "w"), indent=1)
 PY
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+# the same two passes on the fp8 mode's launch of that layer (operand = a producer's e4m3 copy, block-scaled K = 128 MFMA)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc8_$c -- python3 tools/one_conv.py fwd dv_rb128 f8 > /dev/null 2>&1
+done
+python3 - $O $TAG <<'PY'
+import csv, glob, json, sys
+O, tag = sys.argv[1], sys.argv[2]
+vals = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    v = []
+    for f in glob.glob(O + "/pmc8_%s/*/*counter_collection.csv" % c):
+        for r in csv.DictReader(open(f)):
+            if "conv3x3_patch" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                v.append(float(r["Counter_Value"]))
+    vals[c] = v
+rd = 2 * 1024 * sum(vals["FETCH_SIZE"]) / max(1, len(vals["FETCH_SIZE"]))
+wr = 1024 * sum(vals["WRITE_SIZE"]) / max(1, len(vals["WRITE_SIZE"]))
+alg = {"e4m3 copy of the input": 536870912, "bf16 residual (the input tensor)": 1073741824, "weights (e4m3)": 589824, "output (bf16)": 1073741824}
+json.dump({"kernel": "conv3x3_patch_kernel<bf16,128,2,16,F8=3,PRE>",
+           "launch": "decoder_visualize res-block conv in fp8 mode: n=128 images, 128x128, 256->256, the operand arrives as a producer's e4m3 copy, v_mfma_scale_f32_16x16x128_f8f6f4 (tools/one_conv.py fwd dv_rb128 f8)",
+           "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --output-format csv -- python3 tools/one_conv.py fwd dv_rb128 f8",
+           "FETCH_SIZE_kb_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_kb_per_launch": vals["WRITE_SIZE"],
+           "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE exact",
+           "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr,
+           "algorithmic_bytes_per_launch_tensor_once": alg, "algorithmic_total": sum(alg.values()),
+           "traffic_over_algorithmic": (rd + wr) / sum(alg.values())},
+          open(O + "/%s_pmc_dv_rb128_fp8.json" % tag, "w"), indent=1)
+PY
+rm -rf $O/pmc8_FETCH_SIZE $O/pmc8_WRITE_SIZE
 for m in fwd dgrad wgrad; do
   bash tools/pmc_conv.sh ${TAG}_sq_$m $m > /dev/null 2>&1
   (echo "== $m"; cat $R/gpurun_out/pmc_${TAG}_sq_$m.txt) >> $O/${TAG}_sq_dv_rb128.txt 2>/dev/null
   rm -rf $R/gpurun_out/pmc_${TAG}_sq_$m $R/gpurun_out/pmc_${TAG}_sq_$m.txt
 done
+for m in fwd dgrad; do          # fp8 mode's launches of the same layer
+  bash tools/pmc_conv.sh ${TAG}_sq8_$m $m dv_rb128 f8 > /dev/null 2>&1
+  (echo "== $m, fp8 copy in, block-scaled MFMA"; cat $R/gpurun_out/pmc_${TAG}_sq8_$m.txt) >> $O/${TAG}_sq_dv_rb128_fp8.txt 2>/dev/null
+  rm -rf $R/gpurun_out/pmc_${TAG}_sq8_$m $R/gpurun_out/pmc_${TAG}_sq8_$m.txt
+done
 (echo "== bf16, activation-on-load (round-2 form)"; python3 tools/bench_conv.py --iters 10; echo "== the model form: post-activation storage; fp16 forward tensors for the 3x3 layers"; python3 tools/bench_conv.py --iters 10 --post --f16) > $O/${TAG}_bench_conv.txt 2>&1
 python3 tools/bench_conv.py --fp8 --iters 10 --only dv_rb128,dv_rb64,dv_rb32,dv_rb16,ea_rb2,vgg3_2,vgg4_2 > $O/${TAG}_bench_conv_fp8.txt 2>&1
+(echo "== forward operand arrives as an e4m3 copy: block-scaled K = 128 MFMA"; python3 tools/bench_conv.py --fp8 --fp8-copy --iters 10 --only dv_rb128,dv_rb64,dv_rb32,dv_rb16,ea_rb2,vgg3_2,vgg4_2; echo "== the same with UPS_F8_SCALED=0 (K = 32 fp8 MFMA)"; UPS_F8_SCALED=0 python3 tools/bench_conv.py --fp8 --fp8-copy --iters 10 --only dv_rb128,dv_rb64,dv_rb32,dv_rb16,ea_rb2,vgg3_2,vgg4_2) > $O/${TAG}_bench_conv_fp8_copy.txt 2>&1
+python3 tools/bench_first.py > $O/${TAG}_bench_first.txt 2>&1
+# fp8 mode: one-stream kernel trace grouped by (kernel, grid)
+UPS_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats8 -- python3 bench.py --precision fp8 --no-cpu-baseline --steps 10 --warmup 6 > $O/bench_fp8_nooverlap.log 2>&1
+grep '"metric"' $O/bench_fp8_nooverlap.log > $O/${TAG}_bench_b64_fp8_nooverlap.json
+python3 tools/by_grid.py $(find $O/stats8 -name "*kernel_trace.csv" | head -1) 16 0.1 > $O/${TAG}_by_kernel_and_grid_fp8_nooverlap.txt
+rm -rf $O/stats8
 python3 tools/hbm_roofline.py --json $O/${TAG}_hbm_kernels.json > $O/${TAG}_hbm_kernels.txt 2>&1
 cat $O/${TAG}_bench_b64.json | cut -c1-300; cat $O/${TAG}_bench_b64_nooverlap.json | cut -c1-200
 head -14 $O/${TAG}_bench_b64_kernel_stats.csv | cut -c1-160
