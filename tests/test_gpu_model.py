@@ -284,10 +284,19 @@ def test_tensorflow_checkpoint_import_export(dev, tmp_path):
     model3 = TrainModel(cfg3, device=dev, seed=9)
     tr3 = Trainer(cfg3, None, model3)
     tr3.initialize(prefix)
-    tr3.train_step(views, noise)          # (the Lagrangian scalars are unnamed tf.Variables: not in the bundle, tr3 starts them afresh)
-    for n in model.variables:
-        if "mi" not in n and "encoder_0" not in n:                   # keys whose losses do not involve the Lagrangian state
-            assert torch.allclose(model.variables[n], model3.variables[n], atol=1e-7), n
+    # the Lagrangian scalars travel as the reference's unnamed tf.Variables (`Variable`, `Variable_1`, ... by creation order)
+    assert tr3.state_from_tf["lon"] == "Variable" and tr3.state_from_tf["lor"] == "Variable_9" and not tr3.not_restored_from_tf
+    bundle = tfckpt.read_bundle(prefix)
+    assert abs(float(bundle["Variable_9"]) - float(tr3.state["lor"])) < 1e-7 and float(bundle["Variable_4"]) != 1.0     # avg_loss_dis0 moved
+    tr3.train_step(views, noise)
+    for n in model.variables:              # every key continues exactly, the ones whose losses involve the Lagrangian state included
+        assert torch.allclose(model.variables[n], model3.variables[n], atol=1e-7), n
+    # a bundle without (all of) them: reported, not guessed
+    t2 = {k: v for k, v in bundle.items() if k != "Variable_3"}
+    tfckpt.write_bundle(str(tmp_path / "part.ckpt-3"), t2)
+    tr4 = Trainer(cfg3, None, TrainModel(cfg3, device=dev, seed=9))
+    tr4.initialize(str(tmp_path / "part.ckpt-3"))
+    assert not tr4.state_from_tf and "Variable_9" in tr4.not_restored_from_tf
 
 
 def test_fix_weights_and_pretrain_keys(dev):

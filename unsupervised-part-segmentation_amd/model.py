@@ -310,6 +310,9 @@ class Trainer(object):
         if self.logger:
             self.logger.info("Lazily restored from {}".format(checkpoint_path))
 
+    TF_UNNAMED_ORDER = ("lon", "avg_acc0", "avg_acc1", "avg_acc_error", "avg_loss_dis0", "avg_loss_dis1", "avg_mim",
+                        "avg_independent_mim", "loa", "lor")
+
     def _initialize_from_tf(self, prefix):
         """A TensorFlow-1.x checkpoint of the reference (``model.ckpt-<step>.index`` + ``.data-*``): variables are matched by
         name exactly as slim.assign_from_checkpoint(ignore_missing_vars=True) does (model.py:597-601), Adam slots
@@ -340,6 +343,25 @@ class Trainer(object):
         # what slim.assign_from_checkpoint would ALSO have restored but cannot be matched here: the reference's unnamed
         # non-trainable scalars (Lagrangian multipliers, EMAs) and the optimizers' beta powers.  Say so instead of silently
         # restarting them (the multipliers / EMAs start from their yaml initial values, Adam's step count from the file name).
+        # The reference's graph creates exactly ten unnamed scalar tf.Variables, which TensorFlow names by creation order:
+        # `Variable` = lon (define_graph, model.py:503), `Variable_1..5` = the EMAs of make_loss_ops in source order
+        # (model.py:829-834: avg_acc0, avg_acc1, avg_acc_error, avg_loss_dis0, avg_loss_dis1), `_6`, `_7` = the EMAs of the two MI
+        # constraints (model.py:862, 865), `_8` = loa (890), `_9` = lor (921).  A bundle that holds exactly these ten scalars is
+        # mapped in that order (UNVERIFIED against a real checkpoint: the shipped ones are Git-LFS stubs); anything else is
+        # reported below instead of guessed.
+        unnamed = ["Variable"] + ["Variable_{}".format(i) for i in range(1, 10)]
+        order = self.TF_UNNAMED_ORDER
+        found = [n for n in _other if n == "Variable" or n.startswith("Variable_")]
+        self.state_from_tf = {}
+        if sorted(found) == sorted(unnamed) and all(np.asarray(_other[n]).size == 1 for n in unnamed):
+            for key, n in zip(order, unnamed):
+                if key in self.state:
+                    self.state[key].fill_(float(np.asarray(_other[n]).reshape(-1)[0]))
+                    self.state_from_tf[key] = n
+                _other.pop(n)
+            if self.logger:
+                self.logger.info("Lagrangian state restored from the checkpoint's unnamed variables by creation order: {}".format(
+                    ", ".join("{}<-{}".format(k, v) for k, v in self.state_from_tf.items())))
         self.not_restored_from_tf = sorted(n for n in _other if n != "global_step")
         if self.not_restored_from_tf:
             msg = ("TensorFlow checkpoint {}: {} non-trainable / optimizer scalars are NOT restored (unnamed in the reference's graph: "
@@ -362,6 +384,11 @@ class Trainer(object):
             tensors[n + "/Adam"] = bank.adam_m[n].detach().cpu().numpy()
             tensors[n + "/Adam_1"] = bank.adam_v[n].detach().cpu().numpy()
         tensors["global_step"] = np.asarray(self.global_step, dtype=np.int64)
+        # the Lagrangian state under the names TensorFlow gives the reference's ten unnamed scalar variables (creation order:
+        # see _initialize_from_tf)
+        for i, key in enumerate(self.TF_UNNAMED_ORDER):
+            if key in self.state:
+                tensors["Variable" if i == 0 else "Variable_{}".format(i)] = np.asarray(float(self.state[key]), dtype=np.float32)
         tfckpt.write_bundle(prefix, tensors)
 
     def save_checkpoint(self, path):

@@ -292,7 +292,8 @@ def to_trainer_state(bundle):
     suffixes to the later optimizers' slots of shared names only, which this model does not have) and everything else
     (``other``: the global step, the optimizers' ``beta1_power`` / ``beta2_power`` scalars and the reference's UNNAMED
     non-trainable variables -- ``Variable``, ``Variable_1``, ...: the Lagrangian multipliers lon / loa / lor and the seven EMAs,
-    model.py:503, 829-834, 890, 921 -- which cannot be told apart by name; the caller reports them as not restored)."""
+    model.py:503, 829-834, 862-865, 890, 921 -- which carry no name of their own: Trainer._initialize_from_tf maps them by creation
+    order when exactly those ten are present and reports them as not restored otherwise)."""
     params, m, v, other = {}, {}, {}, {}
     for name, arr in bundle.items():
         if name.endswith("/Adam"):
