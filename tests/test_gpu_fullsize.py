@@ -221,3 +221,37 @@ def test_bench_configs_at_full_batch(dev, name, fixture):
     if prec == "fp8":
         ops.Fp8.enabled, ops.Fp8.COPY_ONLY = False, None
     assert min(iou0, iou1) >= (0.98 if prec == "fp8" else 0.99), (iou0, iou1)
+
+
+@pytest.mark.parametrize("batch", [8])
+def test_fp8_hand_off_stays_finite_over_steps(dev, batch):
+    """fp8 mode at the benchmark's widths over several steps: the copies start flowing at the SECOND step (the first only records
+    maxima), so a producer that is asked for a copy and does not write it (round 3: the logit convolution's input gradient routed to
+    an instance without the emitting store loop) poisons the consumer from step 1 on -- one-step fixtures cannot see that.  Every
+    loss, every variable and every scale slot must stay finite, the copies must be in use, and the run must track the bf16 run."""
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import configs, ops
+    from upsparts_amd.model import TrainModel, Trainer
+    g = torch.Generator().manual_seed(3)
+    views = {k: (torch.rand(batch, 128, 128, 3, generator=g) * 2 - 1).to(dev) for k in ("view0", "view1", "view0_target")}
+    traj = {}
+    for precision in ("fp8", "bf16"):
+        cfg = copy.deepcopy(configs.cub_config(n_parts=10, batch_size=batch))
+        cfg["precision"] = precision
+        model = TrainModel(cfg, device=dev, seed=0)
+        tr = Trainer(cfg, None, model)
+        traj[precision] = []
+        for step in range(5):
+            losses = {k: float(v) for k, v in tr.train_step(views).items()}
+            assert all(np.isfinite(v) for v in losses.values()), (precision, step, losses)
+            traj[precision].append(losses)
+        for n, p in model.variables.items():
+            assert bool(torch.isfinite(p).all()), (precision, n)
+        if precision == "fp8":
+            F = ops.Fp8
+            sc = F.scale[:F.count]
+            assert bool(torch.isfinite(sc).all()) and float(sc.min()) > 0.0, "a scale slot went to zero / inf: some tensor held inf"
+            assert F.stats["fwd_copy_in"] > 0 and F.stats["dgrad_copy_in"] > 0 and F.stats["dgrad_copy_out"] > 0, F.stats
+    for a, b in zip(traj["fp8"], traj["bf16"]):
+        for k in b:
+            assert abs(a[k] - b[k]) <= 0.1 * max(1.0, abs(b[k])), (k, a[k], b[k])

@@ -1180,6 +1180,10 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     constexpr int EPC = Chunk<T>::N;
     constexpr int G = TS / SUB, PR = G * (SUB + 2), PWPS = (PR + 3) / 4 * 4;
     constexpr size_t ABY = (size_t)PR * PWPS * APX;
+    // an fp8 copy of the output can only be written by the instances that compile the emitting store loop (EMITS in the kernel):
+    // a launch that asks for one must never land on another instance and leave the copy unwritten
+    constexpr bool emits = __is_same(T, bf16) && (F8 != 0 || !(OCC == 2 && BN == 128));
+    if ((k.out_f8 || k.out_f8_amax) && !emits) return UPS_E_UNSUPPORTED;
     const int tiles_x = SUB == TS ? k.w / TS : 1, tiles_y = SUB == TS ? k.h / TS : 1;
     const int ntn = ups_cdiv(k.co_fill, BN);
     const int kchunks = ups_cdiv(k.ci, F8 ? 64 : 4 * EPC);
@@ -1298,7 +1302,8 @@ int launch_t(const PatchK& k, hipStream_t s) {
             // a store-bound launch): 128-wide tiles halve the number of blocks and patch loads (0.55 -> 0.48 ms; UPS_PATCH_THIN128=0: off)
             static int thin128 = -1;
             if (thin128 < 0) { const char* e = getenv("UPS_PATCH_THIN128"); thin128 = (e && e[0] == '0') ? 0 : 1; }
-            if (thin128 && k.co_fill > 64 && patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 128) >= 512) return launch_v<T, 128, 2>(k, s);
+            // (not when the launch has to write an fp8 copy of its output: the 128-wide two-blocks-per-CU instance cannot -- EMITS)
+            if (thin128 && !k.out_f8_amax && k.co_fill > 64 && patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 128) >= 512) return launch_v<T, 128, 2>(k, s);
             return (patch_occ() == 2 && k.ci > 32 && tiles * ups_cdiv(k.co_fill, 64) >= 512) ? launch_v<T, 64, 2>(k, s)
                                                                                               : launch_v<T, 64, 1>(k, s);
         }
