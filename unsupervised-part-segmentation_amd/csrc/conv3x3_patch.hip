@@ -914,7 +914,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
     T* __restrict__ outT = (T*)p.out;
     float* __restrict__ outF = (float*)p.out;
-    constexpr bool EMITS = __is_same(T, bf16) && (F8 != 0 || !(OCC == 2 && BN == 128));   // instances that can write an fp8 copy of their output
+    // instances that can write an fp8 copy of their output: all but the 128-wide two-blocks-per-CU ones with static taps / DMA patch
+    // (the hot layers' instances, at their register limit); the descriptor-tap form of that shape emits -- it serves the thin
+    // single-chunk launches (the logit convolution's input gradient, a store-bound launch whose copy feeds the dominant layer)
+    constexpr bool EMITS = __is_same(T, bf16) && (F8 != 0 || !(OCC == 2 && BN == 128) || (TAPS == 0 && !DMAP));
     unsigned char* __restrict__ of8 = p.out_f8;
     float of8_amax = 0.f;
     const float of8_s = (p.out_f8 && p.out_f8_scale) ? *p.out_f8_scale : 1.f;
@@ -1182,7 +1185,7 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     constexpr size_t ABY = (size_t)PR * PWPS * APX;
     // an fp8 copy of the output can only be written by the instances that compile the emitting store loop (EMITS in the kernel):
     // a launch that asks for one must never land on another instance and leave the copy unwritten
-    constexpr bool emits = __is_same(T, bf16) && (F8 != 0 || !(OCC == 2 && BN == 128));
+    constexpr bool emits = __is_same(T, bf16) && (F8 != 0 || !(OCC == 2 && BN == 128) || (TAPS == 0 && !DMAP));
     if ((k.out_f8 || k.out_f8_amax) && !emits) return UPS_E_UNSUPPORTED;
     const int tiles_x = SUB == TS ? k.w / TS : 1, tiles_y = SUB == TS ? k.h / TS : 1;
     const int ntn = ups_cdiv(k.co_fill, BN);
@@ -1303,7 +1306,11 @@ int launch_t(const PatchK& k, hipStream_t s) {
             static int thin128 = -1;
             if (thin128 < 0) { const char* e = getenv("UPS_PATCH_THIN128"); thin128 = (e && e[0] == '0') ? 0 : 1; }
             // (not when the launch has to write an fp8 copy of its output: the 128-wide two-blocks-per-CU instance cannot -- EMITS)
-            if (thin128 && !k.out_f8_amax && k.co_fill > 64 && patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 128) >= 512) return launch_v<T, 128, 2>(k, s);
+            if (thin128 && k.co_fill > 64 && patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 128) >= 512) {
+                // a launch that writes an fp8 copy takes the descriptor-tap form of the 128-wide instance (the one that emits)
+                if (k.out_f8_amax) return launch_bn<T, 128, 2, TS>(k, s);
+                return launch_v<T, 128, 2>(k, s);
+            }
             return (patch_occ() == 2 && k.ci > 32 && tiles * ups_cdiv(k.co_fill, 64) >= 512) ? launch_v<T, 64, 2>(k, s)
                                                                                               : launch_v<T, 64, 1>(k, s);
         }
