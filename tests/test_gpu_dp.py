@@ -145,10 +145,17 @@ def test_rccl_call_pattern_at_world_size_one(dev):
     every bucket all-reduce where the multi-GPU run does (asynchronously, inside backward, early encoder_0 head slice) and
     must leave the parameters bit-identical to a run without collectives."""
     import subprocess
-    env = dict(os.environ, UPS_FORCE_COLLECTIVES="1", MASTER_PORT=str(_free_port()))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_trainer_check.py")], env=env, capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0 and "nccl trainer check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for attempt in range(2):
+        env = dict(os.environ, UPS_FORCE_COLLECTIVES="1", MASTER_PORT=str(_free_port()))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_trainer_check.py")], env=env, capture_output=True,
+                           text=True, timeout=600)
+        if r.returncode == 0 and "nccl trainer check ok" in r.stdout:
+            return
+        # a numerical mismatch (the script's own asserts) is a failure at once; a rendezvous / RCCL start-up hiccup of the child
+        # process (seen once in ~10 full-suite runs on the pool's boxes) gets one more try on a fresh port
+        if "AssertionError" in r.stderr or attempt == 1:
+            break
+    assert False, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_bench_two_ranks_over_rccl():
