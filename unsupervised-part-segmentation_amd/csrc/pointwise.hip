@@ -21,28 +21,50 @@ struct F8Emit {
     const float* scale; float* amax;
     int act, e5m2; float slope;
 };
-__device__ __forceinline__ void f8_emit_chunk(const F8Emit& q, float sc, float ns, long long elem, const float* v, float& amax) {
-    float f[8];
+// u = the 8 bf16 values as they are stored (the copy is the quantisation of the STORED tensor): unpacked with a shift / a mask per
+// pair, activation and scale on packed pairs (v_pk_mul_f32), the running maximum two values at a time (v_max3_f32)
+__device__ __forceinline__ void f8_emit_words(const F8Emit& q, float sc, float ns, long long elem, uint4 u, float& amax) {
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+    ups_f32x2 f[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        f[e] = (float)(bf16)v[e];                 // what the bf16 tensor holds
-        if (q.act != UPS_ACT_NONE) f[e] = ups_act_ns(f[e], ns);
-        amax = fmaxf(amax, fabsf(f[e]));
+    for (int k = 0; k < 4; ++k) {
+        f[k] = (ups_f32x2){__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xffff0000u)};
+        if (q.act != UPS_ACT_NONE) {
+            const ups_f32x2 sx = f[k] * ns;
+            f[k] = (ups_f32x2){ups_vmax(f[k][0], sx[0]), ups_vmax(f[k][1], sx[1])};
+        }
+        amax = fmaxf(fmaxf(amax, fabsf(f[k][0])), fabsf(f[k][1]));
     }
     if (q.out) {
         int d0 = 0, d1 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[k] = f[k] * sc;
         if (q.e5m2) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e] * sc, -57344.f, 57344.f);
-            d0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], d0, false); d0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], d0, true);
-            d1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], d1, false); d1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], d1, true);
+            for (int k = 0; k < 4; ++k)
+                f[k] = (ups_f32x2){__builtin_amdgcn_fmed3f(f[k][0], -57344.f, 57344.f), __builtin_amdgcn_fmed3f(f[k][1], -57344.f, 57344.f)};
+            d0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[0][0], f[0][1], d0, false); d0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[1][0], f[1][1], d0, true);
+            d1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[2][0], f[2][1], d1, false); d1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[3][0], f[3][1], d1, true);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e] * sc, -448.f, 448.f);
-            d0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], d0, false); d0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], d0, true);
-            d1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], d1, false); d1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], d1, true);
+            for (int k = 0; k < 4; ++k)
+                f[k] = (ups_f32x2){__builtin_amdgcn_fmed3f(f[k][0], -448.f, 448.f), __builtin_amdgcn_fmed3f(f[k][1], -448.f, 448.f)};
+            d0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0][0], f[0][1], d0, false); d0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[1][0], f[1][1], d0, true);
+            d1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2][0], f[2][1], d1, false); d1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[3][0], f[3][1], d1, true);
         }
         *(uint2*)(q.out + elem) = make_uint2((unsigned)d0, (unsigned)d1);
+    }
+}
+// store the chunk as T and (EMIT instances: T = bf16) hand the stored words to the fp8 copy
+template <typename T, bool EMIT>
+__device__ __forceinline__ void st_emit(T* ptr, const float* v, const F8Emit& q, float sc, float ns, long long elem, float& amax) {
+    if constexpr (EMIT) {
+        static_assert(sizeof(T) == 2, "fp8 copies accompany bf16 tensors");
+        const uint4 u = Chunk<T>::pack(v);
+        *(uint4*)ptr = u;
+        f8_emit_words(q, sc, ns, elem, u, amax);
+    } else {
+        V16<T>::st(ptr, v);
     }
 }
 __device__ __forceinline__ void f8_emit_finish(const F8Emit& q, float amax) {
@@ -86,20 +108,16 @@ __global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y
         V16<T>::ld(base + ((long long)y1 * w + x1) * c, a11);
         T* ob = y + (((long long)b * 2 * h + 2 * y0) * (2 * w) + 2 * x0) * c + k * E;
         const long long orow = (long long)2 * w * c;
-        stv(ob, a00);                                                        // (2y, 2x)
-        if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob - y, a00, amax);
+        if constexpr (EMIT) st_emit<T, true>(ob, a00, q, sc, ns, ob - y, amax); else stv(ob, a00);               // (2y, 2x)
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = 0.5f * (a00[e] + a01[e]);
-        stv(ob + c, o);                                                      // (2y, 2x+1)
-        if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob + c - y, o, amax);
+        if constexpr (EMIT) st_emit<T, true>(ob + c, o, q, sc, ns, ob + c - y, amax); else stv(ob + c, o);       // (2y, 2x+1)
 #pragma unroll
         for (int e = 0; e < E; ++e) { a00[e] = 0.5f * (a00[e] + a10[e]); a01[e] = 0.5f * (a01[e] + a11[e]); }
-        stv(ob + orow, a00);                                                 // (2y+1, 2x)
-        if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob + orow - y, a00, amax);
+        if constexpr (EMIT) st_emit<T, true>(ob + orow, a00, q, sc, ns, ob + orow - y, amax); else stv(ob + orow, a00);   // (2y+1, 2x)
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = 0.5f * (a00[e] + a01[e]);
-        stv(ob + orow + c, o);                                               // (2y+1, 2x+1)
-        if constexpr (EMIT) f8_emit_chunk(q, sc, ns, ob + orow + c - y, o, amax);
+        if constexpr (EMIT) st_emit<T, true>(ob + orow + c, o, q, sc, ns, ob + orow + c - y, amax); else stv(ob + orow + c, o);   // (2y+1, 2x+1)
     }
     if constexpr (EMIT) f8_emit_finish(q, amax);
 }
@@ -139,8 +157,7 @@ __global__ void bilinear2x_bwd_kernel(const T* __restrict__ gy, T* __restrict__ 
                 for (int e = 0; e < E; ++e) acc[e] += ww * g[e];
             }
         }
-        V16<T>::st(gx + idx * E, acc);
-        if constexpr (EMIT) f8_emit_chunk(q, sc, 0.f, idx * E, acc, amax);
+        st_emit<T, EMIT>(gx + idx * E, acc, q, sc, 0.f, idx * E, amax);
     }
     if constexpr (EMIT) f8_emit_finish(q, amax);
 }
