@@ -622,6 +622,7 @@ def test_integration_stub_runs(dev):
     (4, 64, 48, 32, True, 10, True),         # encoder_1's first convolution: part-masked, CoordConv, stored as lrelu(y)
     (5, 32, 64, 64, False, 0, False),        # VGG block1_conv1 form: 3 -> 64
     (3, 16, 16, 24, True, 0, False),         # all-border tile, ragged channel tail
+    (1, 48, 32, 64, True, 32, True),         # the most parts a mask word holds, 64 output channels
 ])
 def test_first_layer_kernel(case, dev, monkeypatch):
     """conv3x3_first.hip (im2col in the MFMA fragment addressing, every part image of a tile from one read of the view) against
@@ -654,7 +655,9 @@ def test_first_layer_kernel(case, dev, monkeypatch):
     xo = x[..., :3].double()
     if parts:
         xo = (xo.unsqueeze(3) * hard.unsqueeze(-1)).permute(3, 0, 1, 2, 4).reshape(parts * n, h, w, 3)
-    ref = _oracle_conv(R, xo, V.double(), b.double(), 1, coords, None, False, None)
+    Vo = V.double().clone()
+    Vo[:, :, :3] = V[:, :, :3].to(torch.bfloat16).double()          # the image rows of the kernel's weights are bf16 (CoordConv rows fp32)
+    ref = _oracle_conv(R, xo, Vo, b.double(), 1, coords, None, False, None)
     if post:
         ref = torch.nn.functional.leaky_relu(ref, 0.2)
     assert_close(out["1"][..., :cout], ref.float(), BF16_TOL, "first-layer kernel vs oracle")
@@ -877,6 +880,7 @@ def test_conv_fp8_copy_handed_from_producer_to_consumer(case, dev):
     (4, 128, 256, 256, True, True),          # the dominant decoder layer's shape: two double chunks, two N-tiles
     (32, 64, 128, 64, False, False),         # 64-wide N-tile
     (2, 128, 256, 256, True, True),          # small grid: stays on the K = 32 path (same expectation)
+    (6, 112, 384, 192, False, False),        # three double chunks, a ragged second N-tile (192 = 128 + 64), 7x7 tiles per image
 ])
 def test_conv_fp8_block_scaled_mfma(case, dev):
     """The block-scaled K = 128 MFMA path (v_mfma_scale_f32_16x16x128_f8f6f4, conv3x3_patch.hip f8s_tap): a consumer of a
