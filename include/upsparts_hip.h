@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define UPS_ABI_VERSION 1
+/* 2: ups_conv_desc grew by out_act / res_act, ups_wgrad_desc by in_f16, UPS_F16 was added (round 3) -- a stale library
+ * built against the older structs ignores those fields silently, so the loader also compares ups_struct_sizes(). */
+#define UPS_ABI_VERSION 2
 
 /* UPS_F16 (IEEE half): element type of FORWARD tensors of precision-critical scopes (the mask decoder): ups_conv_igemm,
  * ups_weight_prep(_batch), ups_bilinear2x_fwd, ups_convert / ups_pad_convert accept it; gradients are never fp16 (range): the
@@ -36,6 +38,9 @@ enum { UPS_ACT_NONE = 0, UPS_ACT_LRELU = 1, UPS_ACT_RELU = 2 };
 enum { UPS_OK = 0, UPS_E_ARG = -1, UPS_E_UNSUPPORTED = -2, UPS_E_LAUNCH = -3 };
 
 int ups_abi_version(void);
+/* sizeof of the descriptor structs AS THE LIBRARY WAS COMPILED: out[0] ups_conv_desc, [1] ups_wgrad_desc, [2] ups_prior_desc,
+ * [3] ups_prep_item.  A binding compares them with its own struct sizes at load time. */
+void ups_struct_sizes(int64_t out[4]);
 /* human readable description of the last error on this thread (host string) */
 const char* ups_last_error(void);
 
@@ -218,6 +223,14 @@ int ups_col_sum(const void* dout, int32_t dtype, int64_t rows, int32_t co, int32
  * Legacy TF-1 bilinear x2 (N:834-847, tf.image.resize_images BILINEAR, no half-pixel centres). */
 int ups_bilinear2x_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
 int ups_bilinear2x_bwd(const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+/* The ho x wo window of x [n,h,w,c] whose corner (oy, ox) = yx_dev[0..1] is read ON THE DEVICE (int32; clamped to the image):
+ * the random 224x224 window of edflow VGG19Features(original_scale=True).make_loss_op as `perceptual_input: resize256_crop224`
+ * reads it (M:610-618; UNVERIFIED), one window per step for the whole batch.  bwd: gx [n,h,w,c] = gy inside the window, 0
+ * elsewhere.  16-bit dtypes are copied as raw bits (UPS_BF16 and UPS_F16 alike). */
+int ups_crop_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo,
+                 const int32_t* yx_dev, void* stream);
+int ups_crop_bwd(const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo,
+                 const int32_t* yx_dev, void* stream);
 /* y = act(bilinear x2 of x): the up-sampled tensor in post-activation storage (ups_conv_desc.out_act) for a consuming residual block */
 int ups_bilinear2x_fwd_act(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t act, float slope,
                            void* stream);
@@ -260,7 +273,9 @@ int ups_part_softmax_fwd(const float* mean, const float* eps, float* l, float* m
 /* The same plus, from the same pass, the spatial soft-max moments of gamma * hard (the one-hot map has them in closed form from
  * per-part integer sums of the hard pixels' coordinates): stats [n][P][8] as ups_spatial_moments(hard, gamma, no rectangle) writes
  * them (M:437-440: the input of the rectangle centres).  mean is [n,h,w,P]; h*w must be a multiple of the kernel's pixel tile
- * (else UPS_E_ARG: call ups_part_softmax_fwd + ups_spatial_moments); scratch: ups_part_softmax_moments_ints(n*h*w, P) int32. */
+ * = ups_part_softmax_moments_tile(P) (else UPS_E_ARG: call ups_part_softmax_fwd + ups_spatial_moments); scratch:
+ * ups_part_softmax_moments_ints(n*h*w, P) int32. */
+int32_t ups_part_softmax_moments_tile(int32_t P);
 size_t ups_part_softmax_moments_ints(int64_t pixels, int32_t P);
 int ups_part_softmax_moments_fwd(const float* mean, const float* eps, float* l, float* m, float* hard, int64_t* argmax,
                                  uint32_t* hard_bits, int32_t n, int32_t h, int32_t w, int32_t P, float gamma, float* stats,

@@ -430,6 +430,7 @@ def forward(params, config, views, noise, lon=1.0, dtype=torch.float32, seed=Non
     o["dd_input"] = inj
     o["generated"] = nets.dd(inj)                            # M:485
     o["target"] = vt
+    o["crop_yx"] = noise.get("crop_yx")                      # window corner of perceptual mode "resize256_crop224"
 
     # critics (M:502-521)
     def smp(i, level=1.0):
@@ -484,12 +485,20 @@ def vgg_features(vp, x, depths=VGG_DEPTHS):
     return feats
 
 
-def perceptual_loss(vp, target, generated, mode="native", depths=VGG_DEPTHS):
-    """sum_l mean|f_l(target) - f_l(generated)| (feature weights 1, gram weight 0: M:608)."""
-    if mode == "resize256":
+def perceptual_loss(vp, target, generated, mode="native", depths=VGG_DEPTHS, crop=None):
+    """sum_l mean|f_l(target) - f_l(generated)| (feature weights 1, gram weight 0: M:608).
+    mode: the three readings of edflow's `VGG19Features(original_scale=True)` (M:610-612; edflow source absent, UNVERIFIED):
+    "native" (images as they are), "resize256" (bilinear to 256x256), "resize256_crop224" (bilinear to 256x256, then ONE random
+    224x224 window for the whole batch and for both images -- tf.random_crop of the concatenated tensor; the window's corner
+    `crop` = (y, x) in [0, 32] is an explicit noise input, like every other random draw of the step)."""
+    if mode in ("resize256", "resize256_crop224"):
         assert target.shape[1] in (128, 256), "resize256 is restated for 128^2 (legacy bilinear x2) and 256^2 (identity) inputs"
         if target.shape[1] == 128:
             target, generated = bilinear_up2(target), bilinear_up2(generated)
+        if mode == "resize256_crop224":
+            oy, ox = int(crop[0]), int(crop[1])
+            assert 0 <= oy <= 32 and 0 <= ox <= 32
+            target, generated = target[:, oy:oy + 224, ox:ox + 224], generated[:, oy:oy + 224, ox:ox + 224]
     elif mode != "native":
         raise ValueError(mode)
     ft = vgg_features(vp, target, depths)
@@ -540,7 +549,7 @@ def losses(o, config, state, step, vp, perceptual_mode="native", vgg_depths=VGG_
     H = o["l0"].shape[1]
     dim = H * H * 3                                           # M:613
     df = is_48c(config)
-    rec = perceptual_loss(vp, o["target"], o["generated"], perceptual_mode, vgg_depths)
+    rec = perceptual_loss(vp, o["target"], o["generated"], perceptual_mode, vgg_depths, crop=o.get("crop_yx"))
     auto_rec_loss = 1e-3 * 0.5 * dim * rec                    # M:614-619
     log["perceptual"] = rec
     if df:      # DF:672-684
@@ -831,4 +840,5 @@ def synthetic_noise(config, seed=4321, batch=None):
     if config.get("use_tps", False):
         from . import tps as TPS
         out["tps_u"] = torch.rand(2 * B, TPS.N_UNIFORMS, generator=g)
+    out["crop_yx"] = torch.randint(0, 33, (2,), generator=g)      # drawn last: the earlier draws keep their values
     return out

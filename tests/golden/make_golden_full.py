@@ -2,7 +2,9 @@
 widths of train_cub_subset_tps.yaml:147-182, VGG19-topology trunk at its real widths with the seeded stand-in weights) from
 the fp64 CPU oracle -- scalars, per-variable gradient norms, a few small summaries and the hard-mask argmax maps only (< 1 MB).
 With `resize256` as argument: the same step with `perceptual_input: resize256` (edflow's original_scale reading) ->
-full_cub128_step_resize256.npz.  Inputs are regenerated from seeds by the test (R.synthetic_views / R.synthetic_noise).
+full_cub128_step_resize256.npz; `resize256_crop224`: the third reading (one random 224x224 window of the resized images, its
+corner an explicit noise input `crop_yx`) -> full_cub128_step_resize256_crop224.npz.  Inputs are regenerated from seeds by
+the test (R.synthetic_views / R.synthetic_noise).
 
 With `confident`: forward only, with the last convolution of the mask decoder scaled by CONFIDENT_SCALE so that the masks
 are as confident as the reference's after training: its log reports mask0_kl 6.18 at step ~71k (cub/train/log.txt:20385-20442;
@@ -14,7 +16,7 @@ With a config name of CONFIGS (the other BASELINE.json configs at their full wid
     deepfashion256 DeepFashion SB_model48c yaml, 256x256, 16 parts, batch 1                    (config #3's model and size)
     cub256p20      CUB yaml at 256x256, 20 parts, batch 1, one more decoder level, patch 64    (config #5's model and size)
 
-    python tests/golden/make_golden_full.py [native|resize256|confident|pennaction128|deepfashion256|cub256p20]
+    python tests/golden/make_golden_full.py [native|resize256|resize256_crop224|confident|pennaction128|deepfashion256|cub256p20]
 """
 import os
 import sys
@@ -26,6 +28,24 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import configs, ref_model as R  # noqa: E402
+
+
+N_PROJ = 16                       # seeded random projections <g, r_k> per variable (round 4: gradient DIRECTION, not only norms)
+
+
+def projection_vectors(name, shape, k=N_PROJ):
+    """r_0..r_{k-1} ~ N(0, 1) for one variable, fp32, seeded by the variable's name (the GPU test regenerates them)."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(("proj/" + name).encode()))
+    return torch.randn((k,) + tuple(shape), generator=g, dtype=torch.float32)
+
+
+def gradient_projections(grads, names):
+    out = np.zeros((len(names), N_PROJ))
+    for i, n in enumerate(names):
+        r = projection_vectors(n, grads[n].shape).double()
+        out[i] = (r.reshape(N_PROJ, -1) @ grads[n].double().reshape(-1)).numpy()
+    return out
 
 
 CONFIDENT_SCALE = 100.0
@@ -94,6 +114,7 @@ def main(mode="native"):
     out["grad_names"] = np.array(names)
     out["grad_norms"] = np.array([float(grads[n].norm()) for n in names])
     out["grad_sums"] = np.array([float(grads[n].sum()) for n in names])
+    out["grad_proj"] = gradient_projections(grads, names)
     out["hard0_argmax"] = R.hard_max(o["m0"]).argmax(-1).numpy().astype(np.uint8)
     out["hard1_argmax"] = R.hard_max(o["m1"]).argmax(-1).numpy().astype(np.uint8)
     out["out_parts_hard"] = o["out_parts_hard"].numpy().astype(np.uint8)
@@ -109,6 +130,7 @@ def main(mode="native"):
     out["feat_norm"] = np.float64(float(o["local_app_features1"].norm()))
     for k, v in new_state.items():
         out["state_" + k] = np.float64(v)
+    out["crop_yx"] = noise["crop_yx"].numpy().astype(np.int32)
     fname = "full_{}_step.npz".format(mode) if mode in CONFIGS else (
         "full_cub128_step.npz" if mode == "native" else "full_cub128_step_{}.npz".format(mode))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), fname)

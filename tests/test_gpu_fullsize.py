@@ -15,18 +15,19 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 FIXTURES = {"native": "full_cub128_step.npz", "resize256": "full_cub128_step_resize256.npz",
+            "resize256_crop224": "full_cub128_step_resize256_crop224.npz",
             # the other BASELINE.json configs at their full widths (tests/golden/make_golden_full.py CONFIGS)
             "pennaction128": "full_pennaction128_step.npz", "deepfashion256": "full_deepfashion256_step.npz",
             "cub256p20": "full_cub256p20_step.npz"}
 
 
-def _trainer(dev, precision, perceptual_input="native"):
+def _trainer(dev, precision, perceptual_input="native", **extra):
     import sys
     import upsparts_amd  # noqa: F401
     from upsparts_amd import configs
     from upsparts_amd.model import TrainModel, Trainer
     from oracle import ref_model as R
-    if perceptual_input in ("native", "resize256"):
+    if perceptual_input in ("native", "resize256", "resize256_crop224"):
         cfg = copy.deepcopy(configs.cub_config(n_parts=10, batch_size=2))
     else:
         sys.path.insert(0, GOLD)
@@ -37,9 +38,44 @@ def _trainer(dev, precision, perceptual_input="native"):
         precision, cfg["mask_decoder_dtype"] = "bf16", "bf16"
     cfg["precision"] = precision
     cfg["perceptual_input"] = perceptual_input
+    cfg.update(extra)
     model = TrainModel(cfg, device=dev, seed=0)
     trainer = Trainer(cfg, None, model)
     return cfg, model, trainer, R.synthetic_views(cfg), R.synthetic_noise(cfg)
+
+
+def _gradient_report(model, z):
+    """Per optimizer key, from the fixture's per-variable gradient norms and seeded random projections <g, r_k>
+    (tests/golden/make_golden_full.py): (norm of the HIP gradient / norm of the oracle's, relative error ||g_hip - g_or|| /
+    ||g_or|| ESTIMATED from the projections -- <e, r_k> ~ N(0, ||e||^2) for unit-normal r_k, so mean_k of the squared
+    projection differences estimates ||e||^2 (16 directions per variable: +-35 % on the estimate) --, cosine of the angle
+    between the two gradients that follows from the three lengths, worst single-variable |projection difference| / ||g_or||)."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_golden_full as G
+    names, norms, proj = [str(n) for n in z["grad_names"]], z["grad_norms"], z["grad_proj"]
+    rep = {}
+    for key, grp in model.bank.groups.items():
+        n2o = n2h = 0.0
+        dk = np.zeros(proj.shape[1])
+        worst = 0.0
+        for n, gn, pr in zip(names, norms, proj):
+            if n not in grp["names"]:
+                continue
+            g = model.bank.grads[n].double()
+            r = G.projection_vectors(n, g.shape, proj.shape[1]).to(g.device).double()
+            ph = (r.reshape(proj.shape[1], -1) @ g.reshape(-1)).cpu().numpy()
+            dk += ph - pr
+            n2o += gn ** 2
+            n2h += float(g.norm()) ** 2
+            if gn > 1e-12:
+                worst = max(worst, float(np.abs(ph - pr).max() / gn))
+        if n2o <= 0.0:
+            continue
+        e2 = float(np.mean(dk ** 2))
+        cos = (n2o + n2h - e2) / (2.0 * np.sqrt(n2o * n2h) + 1e-300)
+        rep[key] = (np.sqrt(n2h / n2o), np.sqrt(e2 / n2o), cos, worst)
+    return rep
 
 
 def _iou(hard, gold_argmax, P):
@@ -54,7 +90,7 @@ def _iou(hard, gold_argmax, P):
     return float(np.mean(ious))
 
 
-@pytest.mark.parametrize("mode", ["native", "resize256", "pennaction128", "deepfashion256", "cub256p20"])
+@pytest.mark.parametrize("mode", ["native", "resize256", "resize256_crop224", "pennaction128", "deepfashion256", "cub256p20"])
 def test_full_width_step_fp32_matches_oracle_fixture(dev, mode):
     z = np.load(os.path.join(GOLD, FIXTURES[mode]))
     cfg, model, trainer, views, noise = _trainer(dev, "fp32", mode)
@@ -97,6 +133,11 @@ def test_full_width_step_fp32_matches_oracle_fixture(dev, mode):
         if gn > 1e-12 and e > worst[1]:
             worst = (str(n), e)
     assert worst[1] <= 2e-3, "gradient norm of {}: rel err {:.3e}".format(*worst)
+    # direction, not only length (round 4): 16 seeded random projections per variable; every single projection within 2e-3 of the
+    # variable's gradient norm, and per optimizer key the projection-estimated relative error within 2e-3
+    for key, (ratio, rel, cos, worst_p) in _gradient_report(model, z).items():
+        assert abs(ratio - 1.0) <= 2e-3 and rel <= 2e-3 and worst_p <= 2e-3, \
+            "gradient of key {}: norm ratio {:.5f}, projected rel. error {:.2e}, worst projection {:.2e}".format(key, ratio, rel, worst_p)
     for k in ("loa", "lor", "avg_mim", "avg_independent_mim", "avg_acc0", "avg_loss_dis1"):
         if "state_" + k not in z.files:
             continue
@@ -111,24 +152,29 @@ def test_full_width_step_bf16_mask_iou(dev, mode, precision):
     256x256, 20 parts) also with the fp8 forward: part-mask IoU vs the fp64 oracle >= 0.99 (north_star), losses within 5 %
     (fp8: IoU >= 0.98, losses within 10 %)."""
     z = np.load(os.path.join(GOLD, FIXTURES[mode]))
-    cfg, model, trainer, views, noise = _trainer(dev, precision, mode)
-    if precision == "fp8":      # one step only: no producer has a delayed scale yet, so let every eligible layer convert in the kernel
-        from upsparts_amd import ops
-        ops.Fp8.COPY_ONLY = False
+    # fp8, one step only: no producer has a delayed scale yet, so let every eligible layer convert in the kernel
+    cfg, model, trainer, views, noise = _trainer(dev, precision, mode, **({"fp8_copy_only": False} if precision == "fp8" else {}))
     losses = trainer.train_step(views, noise)
     B, P = cfg["batch_size"], cfg["n_parts"]
     hard = trainer._debug["hard"]
     iou0, iou1 = _iou(hard[:B], z["hard0_argmax"], P), _iou(hard[B:], z["hard1_argmax"], P)
     print("{} {}: part-mask IoU vs oracle {:.4f} / {:.4f}".format(mode, precision, iou0, iou1))
     if precision == "fp8":
-        from upsparts_amd import ops
-        assert ops.Fp8.count > 0 and ops.Fp8.stats["fwd_f8"] > 0 and ops.Fp8.stats["dgrad_f8"] > 0
-        ops.Fp8.enabled, ops.Fp8.COPY_ONLY = False, None
+        assert model.fp8.count > 0 and model.fp8.stats["fwd_f8"] > 0 and model.fp8.stats["dgrad_f8"] > 0
     bar, tol = (0.98, 0.10) if precision == "fp8" else (0.99, 0.05)
     assert min(iou0, iou1) >= bar, "{} part-mask IoU vs oracle: {} / {}".format(precision, iou0, iou1)
     for k in losses:
         lo, lh = float(z["loss_" + k]), float(losses[k])
         assert abs(lo - lh) <= tol * max(1.0, abs(lo)), "loss {}: oracle {} hip({}) {}".format(k, lo, precision, lh)
+    # whole-step GRADIENTS in the headline dtype against the fp64 oracle (round 4): per optimizer key the gradient norm within
+    # 3 % and the cosine to the oracle's gradient >= 0.999 (fp8: 10 % / 0.99), from the fixture's norms and random projections
+    nbar, cbar = (0.10, 0.99) if precision == "fp8" else (0.03, 0.999)
+    rep = _gradient_report(model, z)
+    for key, (ratio, rel, cos, _w) in rep.items():
+        print("  {} {} gradient of {}: norm ratio {:.4f}, projected rel. error {:.4f}, cosine {:.5f}".format(mode, precision, key, ratio, rel, cos))
+    for key, (ratio, rel, cos, _w) in rep.items():
+        assert abs(ratio - 1.0) <= nbar and cos >= cbar, "{} gradient of key {}: norm ratio {:.4f}, cosine {:.5f} (bars {} / {})".format(
+            precision, key, ratio, cos, nbar, cbar)
 
 
 @pytest.mark.parametrize("precision", ["bf16", "bf16-pure", "fp32", "fp8"])
@@ -149,14 +195,13 @@ def test_full_width_confident_masks_iou(dev, precision):
     sys.path.insert(0, GOLD)
     import make_golden_full as G
     z = np.load(os.path.join(GOLD, "full_cub128_confident.npz"))
-    cfg, model, trainer, views, noise = _trainer(dev, precision)
+    # (fp8, a single forward: in-kernel conversion, the same quantisation the copies carry)
+    cfg, model, trainer, views, noise = _trainer(dev, precision, **({"fp8_copy_only": False} if precision == "fp8" else {}))
     with torch.no_grad():
         for suf in ("/V", "/b"):
             model.variables[G.CONFIDENT_LAYER + suf].mul_(G.CONFIDENT_SCALE)
     from upsparts_amd import ops
     ops.WeightVersion.value += 1
-    if precision == "fp8":
-        ops.Fp8.COPY_ONLY = False      # (a single forward: in-kernel conversion, the same quantisation the copies carry)
     B, P = cfg["batch_size"], cfg["n_parts"]
     out = model.forward(views, noise)
     a = out["out_parts_hard"].cpu().numpy()
@@ -168,8 +213,7 @@ def test_full_width_confident_masks_iou(dev, precision):
     print("{} full width, confident logits: out_parts_hard IoU {:.4f} (pixel agreement {:.4f}), sampled-mask IoU {:.4f}".format(
         precision, iou_mean, agree, iou_s))
     if precision == "fp8":
-        assert ops.Fp8.count > 0 and ops.Fp8.stats["fwd_f8"] > 0, "no layer took the fp8 path"
-        ops.Fp8.enabled, ops.Fp8.COPY_ONLY = False, None
+        assert model.fp8.count > 0 and model.fp8.stats["fwd_f8"] > 0, "no layer took the fp8 path"
         assert agree >= 0.95 and iou_mean >= 0.8 and iou_s >= 0.8, (agree, iou_mean, iou_s)     # measured 0.979 / 0.90 / 0.92
     elif precision == "bf16":
         assert agree >= 0.995 and iou_mean >= 0.99 and iou_s >= 0.99, (agree, iou_mean, iou_s)
@@ -194,6 +238,8 @@ def test_bench_configs_at_full_batch(dev, name, fixture):
     build, S, P, B, prec, _gflop, _note = configs.BENCH_CONFIGS[name]
     cfg = build(B)
     cfg["precision"] = prec
+    if prec == "fp8":
+        cfg["fp8_copy_only"] = False      # one step: no producer has a delayed scale yet
     bf = z["hard0_argmax"].shape[0]
     cfg_fix = dict(cfg, batch_size=bf)
     views_f, noise_f = R.synthetic_views(cfg_fix), R.synthetic_noise(cfg_fix)
@@ -210,16 +256,12 @@ def test_bench_configs_at_full_batch(dev, name, fixture):
             noise[k][:, :bf] = v
         else:
             noise[k][:bf] = v
-    if prec == "fp8":
-        ops.Fp8.COPY_ONLY = False      # one step: no producer has a delayed scale yet
     losses = trainer.train_step(views, noise)
     hard = trainer._debug["hard"]
     for k, v in losses.items():
         assert np.isfinite(float(v)), "{}: loss {} = {}".format(name, k, float(v))
     iou0, iou1 = _iou(hard[:bf], z["hard0_argmax"], P), _iou(hard[B:B + bf], z["hard1_argmax"], P)
     print("{} B={} {}: part-mask IoU of the fixture samples inside the batch {:.4f} / {:.4f}".format(name, B, prec, iou0, iou1))
-    if prec == "fp8":
-        ops.Fp8.enabled, ops.Fp8.COPY_ONLY = False, None
     assert min(iou0, iou1) >= (0.98 if prec == "fp8" else 0.99), (iou0, iou1)
 
 
@@ -248,7 +290,7 @@ def test_fp8_hand_off_stays_finite_over_steps(dev, batch):
         for n, p in model.variables.items():
             assert bool(torch.isfinite(p).all()), (precision, n)
         if precision == "fp8":
-            F = ops.Fp8
+            F = model.fp8
             sc = F.scale[:F.count]
             assert bool(torch.isfinite(sc).all()) and float(sc.min()) > 0.0, "a scale slot went to zero / inf: some tensor held inf"
             assert F.stats["fwd_copy_in"] > 0 and F.stats["dgrad_copy_in"] > 0 and F.stats["dgrad_copy_out"] > 0, F.stats

@@ -480,6 +480,147 @@ def test_part_path(P, dev):
     assert_close(v, v_o.float(), 1e-4, "variance per part")
 
 
+def _prior_oracle(R, variant, lm0, eps0, lm1, eps1, px_order, gamma, patch, w, g_hard0, g_hard1, entropy_func, ms_alpha, ms_lambda):
+    """The mask priors of Trainer.make_loss_ops in torch fp64 from the oracle's own building blocks (M:652-797, N:1366-1451;
+    variant 1: deepfashion/code/SB_model48c/model.py:719-776) + the straight-through term <g_hard, ste(hard, m)> that carries the
+    reconstruction gradient.  Returns (dict of the logged forward quantities, total view 0, total view 1, rec-only v0, v1)."""
+    B, S, _, P = lm0.shape
+    l0, l1 = lm0 + eps0, lm1 + eps1
+    m0, m1 = torch.softmax(l0, -1), torch.softmax(l1, -1)
+    h0, h1 = R.ste(R.hard_max(m0), m0), R.ste(R.hard_max(m1), m1)
+    q = {}
+    kl0 = (m0 * torch.log(P * m0 + 1e-20)).sum(-1).mean()
+    kl1 = (m1 * torch.log(P * m1 + 1e-20)).sum(-1).mean()
+    q["mask0_kl"] = kl0 + kl1
+    p_labels = torch.softmax(l0, -1)
+    labels = R.ste(R.hard_max(p_labels), p_labels) if (variant == 1 or entropy_func == "cross_entropy") else p_labels
+    q["weakly"] = (-(labels * torch.log_softmax(l0, -1)).sum(-1)).mean()
+    dy, dx = lm0[:, 1:] - lm0[:, :-1], lm0[:, :, 1:] - lm0[:, :, :-1]
+    q["gmrf"] = 0.5 * ((dy ** 2).sum(dim=(1, 2, 3)) + (dx ** 2).sum(dim=(1, 2, 3))).mean()
+    sq = lambda t: (t.sum(dim=(1, 2)) ** 2).sum(dim=1).mean()
+    if variant == 0:
+        rect0, _ = R.patch_mask(h0, gamma, patch, px_order)
+        rect1, _ = R.patch_mask(h1, gamma, patch, px_order)
+        g = R.squared_grad(m0)
+        r = torch.clamp(g, max=1.0e-2)
+        q["ms"], q["area"] = sq(r), sq(m0)
+        q["smooth"] = sq(torch.where(g < 1.0e-2, r, torch.zeros_like(r)))
+        q["contour"] = sq(torch.where(g >= 1.0e-2, r, torch.zeros_like(r)))
+        q["patch"] = (h0 * (1 - rect0).detach()).sum(dim=(1, 2, 3)).mean()
+        c1 = R.spatial_softmax(torch.softmax(l1, -1) * gamma) * (1 - rect1).detach()
+        _, sig = R.probs_to_mu_sigma(c1)
+        q["var"] = (sig[:, :, 0, 0] + sig[:, :, 1, 1]).sum(dim=1).mean()
+        t0 = (w["kl"] * kl0 + w["entropy"] * q["weakly"] + w["ms"] * q["ms"] + w["area"] * q["area"] + w["patch"] * q["patch"]
+              + w["gmrf"] * q["gmrf"])
+    else:
+        q["msl"] = torch.clamp(ms_alpha * R.squared_grad(lm0), max=ms_lambda).sum(dim=(1, 2, 3)).mean()
+        c1 = R.spatial_softmax(torch.softmax(l1, -1))
+        c1 = c1 / c1.sum(dim=(1, 2), keepdim=True)
+        _, sig = R.probs_to_mu_sigma(c1)
+        q["var"] = (sig[:, :, 0, 0] ** 2 + sig[:, :, 1, 1] ** 2).sum(dim=1).mean()
+        t0 = w["kl"] * kl0 + w["entropy"] * q["weakly"] + w["gmrf"] * q["gmrf"] + w["msl"] * q["msl"]
+    t1 = w["kl"] * kl1 + w["var"] * q["var"]
+    r0, r1 = (g_hard0 * h0).sum(), (g_hard1 * h1).sum()
+    return q, t0 + r0, t1 + r1, r0, r1
+
+
+@pytest.mark.parametrize("variant,P,S,entropy_func", [(0, 10, 32, "entropy"), (0, 25, 32, "cross_entropy"), (0, 10, 20, "entropy"),
+                                                      (1, 10, 32, "cross_entropy"), (1, 25, 32, "cross_entropy"), (0, 3, 48, "entropy")])
+def test_mask_priors_forward_and_backward(variant, P, S, entropy_func, dev):
+    """ups_prior_fwd / ups_prior_bwd ALONE (8a-12; until round 4 only covered through the whole-step tests): every logged prior
+    and the fused analytic d/d logits -- total (`dl`, the decoder_visualize key) and reconstruction-only (`dl_rec`, what
+    encoder_0 sees) -- for both views and both model variants against torch-fp64 autograd over the oracle's restatement, with
+    non-trivial weights on EVERY term (the shipped schedules make area / Mumford-Shah ~1e-5 of the total, where an error in
+    their backward would hide).  The forward sums are cross-checked against the independent NumPy restatement too."""
+    import types
+    lib, ops, R = _mods()
+    from oracle import np_ops
+    from upsparts_amd.model import Trainer
+    g = torch.Generator().manual_seed(100 * variant + P + S)
+    B, gamma, patch = 3, 10.0, 8
+    # logits with spatial structure (so that rectangles, Mumford-Shah contours and moments are non-degenerate) + unit noise
+    low = torch.randn(2 * B, P, S // 4, S // 4, generator=g, dtype=torch.float64)
+    lm = 2.0 * torch.nn.functional.interpolate(low, size=(S, S), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
+    eps = torch.randn(2 * B, S, S, P, generator=g, dtype=torch.float64)
+    g_hard = torch.randn(2 * B, S, S, P, generator=g, dtype=torch.float64)
+    w = {"kl": 0.7, "entropy": 1.3, "ms": 0.05, "area": 2.0e-3, "patch": 0.02, "gmrf": 0.3, "var": 1.7, "msl": 0.4}
+    ms_alpha, ms_lambda = (1.0, 1.0e-2) if variant == 0 else (1.5, 0.05)
+    lm0 = lm[:B].clone().requires_grad_(True)
+    lm1 = lm[B:].clone().requires_grad_(True)
+    q, t0, t1, r0, r1 = _prior_oracle(R, variant, lm0, eps[:B], lm1, eps[B:], "xy", gamma, patch, w, g_hard[:B], g_hard[B:],
+                                      entropy_func, ms_alpha, ms_lambda)
+    d_tot0, = torch.autograd.grad(t0, lm0, retain_graph=True)
+    d_tot1, = torch.autograd.grad(t1, lm1, retain_graph=True)
+    d_rec0, = torch.autograd.grad(r0, lm0, retain_graph=True)
+    d_rec1, = torch.autograd.grad(r1, lm1)
+
+    # ---- HIP: the product's own descriptor filling (Trainer._prior) on a stand-in trainer
+    cfg = {"entropy_func": entropy_func, "gamma": gamma,
+           "mumford_sha_alpha": {"var_type": "staircase", "options": {"start": 0, "start_value": ms_alpha, "step_size": 1, "stair_factor": 1.0,
+                                                                      "clip_min": ms_alpha, "clip_max": ms_alpha}},
+           "mumford_sha_lambda": {"var_type": "staircase", "options": {"start": 0, "start_value": ms_lambda, "step_size": 1, "stair_factor": 1.0,
+                                                                       "clip_min": ms_lambda, "clip_max": ms_lambda}}}
+    fake = types.SimpleNamespace(model=types.SimpleNamespace(patch_size=patch, df=variant == 1), config=cfg, global_step=0)
+    lmd, epsd = lm.float().to(dev), eps.float().to(dev)
+    if variant == 0:
+        l, m, hard, _, _bits, hstats = ops.part_softmax(lmd, epsd, want_bits=True, moments_gamma=gamma)
+        if hstats is None:
+            hstats = ops.spatial_moments(hard, gamma)
+        px = ops.moments_to_px(hstats, S, "xy")
+        px0, px1 = px[:B].contiguous(), px[B:].contiguous()
+    else:
+        l, m, hard, _ = ops.part_softmax(lmd, epsd)
+        px0 = px1 = None
+    nfl = lib.load().ups_prior_sums_floats(B, P)
+    sums0 = torch.empty(nfl, dtype=torch.float32, device=dev)
+    sums1 = torch.empty(nfl, dtype=torch.float32, device=dev)
+    per_np0 = torch.empty((B, P, 8), dtype=torch.float32, device=dev)
+    l0, l1, m0, m1 = l[:B].contiguous(), l[B:].contiguous(), m[:B].contiguous(), m[B:].contiguous()
+    h0 = hard[:B].contiguous()
+    Trainer._prior(fake, 0, B, S, P, l0, lmd[:B].contiguous(), m0, h0, px0, per_np0, sums0, w)
+    Trainer._prior(fake, 1, B, S, P, l1, None, m1, None, px1, None, sums1, w)
+    stats_v = ops.spatial_moments(m1, 1.0 if variant == 1 else gamma, rect_px=px1, half=patch // 2)
+    dl_tot = torch.empty_like(lmd)
+    dl_rec = torch.empty_like(lmd)
+    gh = g_hard.float().to(dev)
+    Trainer._prior(fake, 0, B, S, P, l0, lmd[:B].contiguous(), m0, h0, px0, per_np0, sums0, w, gh[:B].contiguous(), dl_tot[:B],
+                   bwd=True, dl_rec=dl_rec[:B])
+    Trainer._prior(fake, 1, B, S, P, l1, None, m1, None, px1, stats_v, sums1, w, gh[B:].contiguous(), dl_tot[B:], bwd=True,
+                   dl_rec=dl_rec[B:])
+
+    # ---- forward quantities, exactly as Trainer.build_logs derives them from the sums
+    npx = float(B * S * S)
+    s0, s1 = sums0.double().cpu(), sums1.double().cpu()
+    got = {"mask0_kl": (s0[0] + s1[0]) / npx, "weakly": s0[1] / npx, "gmrf": s0[3] / B}
+    Zs = stats_v.double().cpu()[..., 1]
+    sv = stats_v.double().cpu()
+    if variant == 0:
+        got.update({"patch": s0[2] / B, "ms": s0[4] / B, "area": s0[5] / B, "smooth": s0[6] / B, "contour": s0[7] / B,
+                    "var": (sv[..., 5] / Zs - (sv[..., 3] / Zs) ** 2 - (sv[..., 4] / Zs) ** 2).sum(dim=1).mean()})
+    else:
+        s00 = sv[..., 6] / Zs - (sv[..., 3] / Zs) ** 2
+        s11 = (sv[..., 5] - sv[..., 6]) / Zs - (sv[..., 4] / Zs) ** 2
+        got.update({"msl": s0[2] / B, "var": (s00 ** 2 + s11 ** 2).sum(dim=1).mean()})
+    for k, v in got.items():
+        ref = float(q[k])
+        assert abs(float(v) - ref) <= 2e-4 * max(abs(ref), 1e-6), "prior {} (variant {}, P {}): oracle {} hip {}".format(k, variant, P, ref, float(v))
+    # independent NumPy restatement of the forward terms (oracle/np_ops.py)
+    m0n = torch.softmax(lm[:B] + eps[:B], -1).numpy()
+    m1n = torch.softmax(lm[B:] + eps[B:], -1).numpy()
+    assert abs(np_ops.categorical_kl(m0n) + np_ops.categorical_kl(m1n) - float(q["mask0_kl"])) <= 1e-9 * max(1.0, abs(float(q["mask0_kl"])))
+    assert abs(np_ops.kl_improper_gmrf(lm[:B].numpy()) - float(q["gmrf"])) <= 1e-9 * abs(float(q["gmrf"]))
+    if variant == 0:
+        r_np = np_ops.mumford_shah(m0n, 1.0, 1.0e-2)
+        r_np = r_np[0] if isinstance(r_np, tuple) else r_np
+        assert abs(float(((r_np.sum(axis=(1, 2)) ** 2).sum(axis=1)).mean()) - float(q["ms"])) <= 1e-9 * abs(float(q["ms"]))
+
+    # ---- backward: d total / d logits (decoder_visualize) and d rec / d logits (encoder_0)
+    assert_close(dl_tot[:B], d_tot0.float(), 1e-3, "prior_bwd view 0 dl (variant {}, P {})".format(variant, P))
+    assert_close(dl_tot[B:], d_tot1.float(), 1e-3, "prior_bwd view 1 dl")
+    assert_close(dl_rec[:B], d_rec0.float(), 1e-3, "prior_bwd view 0 dl_rec")
+    assert_close(dl_rec[B:], d_rec1.float(), 1e-3, "prior_bwd view 1 dl_rec")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_mask_parts_unpool(dtype, dev):
     lib, ops, R = _mods()
@@ -730,7 +871,7 @@ def test_conv_fp8_forward(case, dev):
     x = (torch.randn(n, h, h, cin, generator=g) * 1.5).to(torch.bfloat16)
     lay = _layer(ops, lib, V, b, 3, 1, coords, act, dev)
     xd = x.to(dev)
-    ops.Fp8.enabled, ops.Fp8.COPY_ONLY = True, False      # (no producer here: the kernel converts its bf16 operand itself)
+    ops.Fp8.activate(ops.Fp8State(True, copy_only=False))      # (no producer here: the kernel converts its bf16 operand itself)
     try:
         eligible = ops.Fp8.eligible(lay, xd)
         y = ops.conv_forward(xd, lay, res=xd if res_self else None)
@@ -744,7 +885,7 @@ def test_conv_fp8_forward(case, dev):
         s_a = float(ops.Fp8.scale[f8["slot"]].cpu())
         amax_seen = float(ops.Fp8.amax[f8["slot"]].max().cpu())
     finally:
-        ops.Fp8.enabled, ops.Fp8.COPY_ONLY = False, None
+        ops.Fp8.activate(ops.Fp8State(False))
     xf = x.float()
     xa = torch.maximum(xf, 0.2 * xf) if act == "leaky_relu" else (torch.relu(xf) if act == "relu" else xf)
     assert abs(amax_seen - float(xa.abs().max())) <= 1e-6 * amax_seen, "recorded activation maximum"
@@ -786,7 +927,7 @@ def test_conv_fp8_input_gradient(case, dev):
     x = (torch.randn(n, h, h, cin, generator=g0)).to(torch.bfloat16)
     gy = (torch.randn(n, h, h, cout, generator=g0) * 0.02).to(torch.bfloat16)
     lay = _layer(ops, lib, V, b, 3, 1, coords, act, dev)
-    ops.Fp8.enabled, ops.Fp8.COPY_ONLY = True, False
+    ops.Fp8.activate(ops.Fp8State(True, copy_only=False))
     try:
         assert ops.Fp8.eligible_grad(lay, gy.to(dev), x.to(dev))
         gx = ops.conv_dgrad(gy.to(dev), x.to(dev), lay)
@@ -795,7 +936,7 @@ def test_conv_fp8_input_gradient(case, dev):
         s_g = float(ops.Fp8.scale[f8["slot"]].cpu())
         amax_seen = float(ops.Fp8.amax[f8["slot"]].max().cpu())
     finally:
-        ops.Fp8.enabled, ops.Fp8.COPY_ONLY = False, None
+        ops.Fp8.activate(ops.Fp8State(False))
     gf = gy.float()
     assert abs(amax_seen - float(gf.abs().max())) <= 1e-6 * amax_seen
     assert abs(s_g - 57344.0 * ops.Fp8.MARGIN / float(gf.abs().max())) <= 1e-5 * s_g
@@ -837,8 +978,7 @@ def test_conv_fp8_copy_handed_from_producer_to_consumer(case, dev):
     l1 = _layer(ops, lib, V1, torch.randn(cin, generator=g) * 0.1, 3, 1, coords, "leaky_relu", dev)
     l2 = _layer(ops, lib, V2, torch.randn(cout, generator=g) * 0.1, 3, 1, coords, "leaky_relu", dev)
     x = torch.randn(n, h, h, cin, generator=g).to(torch.bfloat16).to(dev)
-    F = ops.Fp8
-    F.enabled = True
+    F = ops.Fp8.activate(ops.Fp8State(True))          # a fresh state for this test (scale slots, hand-off, counters)
     producer_was, copy_only_was = F.PRODUCER, F.COPY_ONLY
     F.PRODUCER, F.COPY_ONLY = True, False          # (the producing layer itself converts its bf16 input in the kernel here)
     try:
@@ -867,7 +1007,7 @@ def test_conv_fp8_copy_handed_from_producer_to_consumer(case, dev):
         zb = ops.conv_forward(y, l2)
         torch.cuda.synchronize()
     finally:
-        F.enabled = False
+        ops.Fp8.activate(ops.Fp8State(False))
         F.PRODUCER, F.COPY_ONLY = producer_was, copy_only_was
         F.next_in = F.next_out_act = F.last_out = None
     assert_close(za[..., :cout].float(), zb[..., :cout].float(), 1e-6, "consumer of the fp8 copy vs in-kernel conversion")
@@ -899,9 +1039,7 @@ def test_conv_fp8_block_scaled_mfma(case, dev):
     gy = (torch.randn(n, h, h, cout, generator=g0) * 0.02).to(torch.bfloat16)
     lay = _layer(ops, lib, V, b, 3, 1, coords, "leaky_relu", dev)
     xd, gd = x.to(dev), gy.to(dev)
-    F = ops.Fp8
-    F.reset()
-    F.enabled = True
+    F = ops.Fp8.activate(ops.Fp8State(True))          # a fresh state for this test (scale slots, hand-off, counters)
     try:
         # ---- forward: e4m3(lrelu(x) * s_a) handed in as a producer's copy
         xa = torch.maximum(x.float(), 0.2 * x.float())
@@ -922,9 +1060,7 @@ def test_conv_fp8_block_scaled_mfma(case, dev):
         assert F.stats["dgrad_copy_in"] == 1
         torch.cuda.synchronize()
     finally:
-        F.enabled = False
-        F.next_in = F.next_out_act = F.last_out = None
-        F.reset()
+        ops.Fp8.activate(ops.Fp8State(False))
     # forward expectation
     wmax = V[:, :, :cin].abs().amax(dim=(0, 1, 2))
     wq = (V[:, :, :cin] * (448.0 / wmax)).clamp(-448, 448).to(torch.float8_e4m3fn).double()
@@ -960,8 +1096,7 @@ def test_bilinear_fp8_copies(dev):
     x = (torch.randn(3, 16, 24, 128, generator=g) * 2).to(torch.bfloat16).to(dev)
     gy = (torch.randn(3, 32, 48, 128, generator=g) * 1e-3).to(torch.bfloat16).to(dev)
     y_ref = ops.BilinearFn.apply(x)
-    F = ops.Fp8
-    F.enabled = True
+    F = ops.Fp8.activate(ops.Fp8State(True))          # a fresh state for this test (scale slots, hand-off, counters)
     producer_was = F.PRODUCER
     F.PRODUCER = True
     try:
@@ -991,7 +1126,7 @@ def test_bilinear_fp8_copies(dev):
         want = (gx_ref.float() * sg).clamp(-57344, 57344).to(torch.float8_e5m2).view(torch.uint8)
         assert torch.equal(gcopy["t"], want)
     finally:
-        F.enabled = False
+        ops.Fp8.activate(ops.Fp8State(False))
         F.PRODUCER = producer_was
         F.last_out = None
         F.grad_side.clear()

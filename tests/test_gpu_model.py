@@ -83,12 +83,8 @@ def test_train_step_fp32_matches_oracle(dev, variant, size):
         for k in log_keys:
             lo = float(log[k])
             assert abs(lo - logs[k]) <= 1e-3 * max(1e-6, abs(lo)) + 1e-9, "log {}: oracle {} hip {}".format(k, lo, logs[k])
-        worst = ("", 0.0)
-        for n, g in grads.items():
-            e = rel_err(model.bank.grads[n], g.float())
-            if e > worst[1]:
-                worst = (n, e)
-        assert worst[1] <= 2e-3, "gradient {} rel err {:.3e} (step {})".format(worst[0], worst[1], step)
+        for n, g in grads.items():        # three bars each: max-norm, RMS and element-wise on the channel's own scale (util.py)
+            assert_close(model.bank.grads[n], g.float(), 2e-3, "gradient {} (step {})".format(n, step))
         # Adam normalises the gradient (m / (sqrt(v) + eps)), so an element whose gradient is ~0 can move by up to
         # +-lr_t with either sign: compare updates in units of the learning rate, not relative to |param|.
         lr = cfg["lr"]
@@ -144,12 +140,12 @@ def test_fp8_step_tracks_bf16(dev):
             out.append({k: float(v) for k, v in losses.items()})
         runs[prec] = (out, trainer._debug["hard"].cpu().clone())
         if prec == "fp8":
-            assert ops.Fp8.count >= 4, "fp8 layers used: {}".format(ops.Fp8.count)
-            assert ops.Fp8.stats["fwd_copy_in"] > 0 and ops.Fp8.stats["dgrad_copy_in"] > 0, ops.Fp8.stats    # copies were handed on
-            scales = ops.Fp8.scale[:ops.Fp8.count].cpu()
+            F = model.fp8
+            assert F.count >= 4, "fp8 layers used: {}".format(F.count)
+            assert F.stats["fwd_copy_in"] > 0 and F.stats["dgrad_copy_in"] > 0, F.stats    # copies were handed on
+            scales = F.scale[:F.count].cpu()
             assert bool(torch.isfinite(scales).all()) and float(scales.min()) > 0
-            assert all(l._cache[k]["version"] == ops.WeightVersion.value for l in ops.Fp8.layers for k in ("f8", "f8g") if k in l._cache)
-    ops.Fp8.enabled = False
+            assert all(l._cache[k]["version"] == ops.WeightVersion.value for l in F.layers for k in ("f8", "f8g") if k in l._cache)
     for step in range(3):
         for k, vb in runs["bf16"][0][step].items():
             vf = runs["fp8"][0][step][k]
@@ -386,10 +382,9 @@ def test_forty_steps_bf16_and_fp8_track_fp32(dev):
             if step % 5 == 0 or step == 39:
                 h.append({k: float(v) for k, v in losses.items()})
             if step == 3:
-                slots = ops.Fp8.count
-        assert ops.Fp8.count == slots, "fp8 scale slots keep being allocated: {} -> {}".format(slots, ops.Fp8.count)
+                slots = model.fp8.count
+        assert model.fp8.count == slots, "fp8 scale slots keep being allocated: {} -> {}".format(slots, model.fp8.count)
         hist[prec] = h
-    ops.Fp8.enabled = False
     print("decoder_delta loss, steps 0, 5, ..., 35, 39:", {p: [round(r["decoder_delta"], 2) for r in h] for p, h in hist.items()})
     for prec, h in hist.items():
         for row in h:

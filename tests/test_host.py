@@ -29,7 +29,12 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), "libupsparts_hip.so lacks " + name
     assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
-    assert handle.ups_abi_version() == 1
+    assert handle.ups_abi_version() == lib.ABI_VERSION == int(re.search(r"#define UPS_ABI_VERSION (\d+)", hdr).group(1))
+    # the descriptor structs of the ctypes binding are byte-compatible with what the library was compiled against
+    import ctypes as C
+    sizes = (C.c_int64 * 4)()
+    handle.ups_struct_sizes(sizes)
+    assert list(sizes) == [C.sizeof(lib.ConvDesc), C.sizeof(lib.WgradDesc), C.sizeof(lib.PriorDesc), C.sizeof(lib.PrepItem)]
 
 
 def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch):

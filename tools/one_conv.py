@@ -32,7 +32,7 @@ if fmt == lib.F16:
 res = x if (cin == cout and stride == 1 and act is not None) else None
 F = ops.Fp8
 if f8:
-    F.reset(); F.enabled = True
+    F = ops.Fp8.activate(ops.Fp8State(True))
     sx, sg = F.slot(dev), F.slot(dev)
     F.scale[sx] = 448.0 * F.MARGIN / float(x.float().abs().max()); F.scale[sg] = 57344.0 * F.MARGIN / 6.0
     x8 = (x.float() * F.scale[sx]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)

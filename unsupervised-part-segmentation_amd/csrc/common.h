@@ -76,8 +76,10 @@ template <> struct Chunk<f16> {
         }
     }
     __device__ static inline unsigned pk(float a, float b) {
+        // RNE; SATURATING at +-65504 (v_med3_f32; NaN stays NaN): a residual stream or a restored checkpoint that leaves the
+        // fp16 range clips instead of turning into inf / NaN that nothing notices before the next log step
         union { f16x2 h; unsigned u; } x;
-        x.h[0] = (f16)a; x.h[1] = (f16)b;     // RNE; overflows to inf beyond 65504
+        x.h[0] = (f16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f); x.h[1] = (f16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
         return x.u;
     }
     __device__ static inline uint4 pack(const float* f) {
@@ -175,7 +177,7 @@ template <> __device__ inline float ld_as_float<float>(const float* p) { return 
 template <> __device__ inline float ld_as_float<bf16>(const bf16* p) { return (float)*p; }
 template <> __device__ inline float ld_as_float<f16>(const f16* p) { return (float)*p; }
 template <typename T> __device__ inline void st_from_float(T* p, float v);
-template <> __device__ inline void st_from_float<f16>(f16* p, float v) { *p = (f16)v; }
+template <> __device__ inline void st_from_float<f16>(f16* p, float v) { *p = (f16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
 template <> __device__ inline void st_from_float<float>(float* p, float v) { *p = v; }
 template <> __device__ inline void st_from_float<bf16>(bf16* p, float v) { *p = (bf16)v; }
 

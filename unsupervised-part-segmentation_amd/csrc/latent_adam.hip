@@ -15,6 +15,10 @@ void ups_set_error(const char* fmt, ...) {
 }
 extern "C" const char* ups_last_error(void) { return g_err; }
 extern "C" int ups_abi_version(void) { return UPS_ABI_VERSION; }
+extern "C" void ups_struct_sizes(int64_t out[4]) {
+    out[0] = (int64_t)sizeof(ups_conv_desc); out[1] = (int64_t)sizeof(ups_wgrad_desc);
+    out[2] = (int64_t)sizeof(ups_prior_desc); out[3] = (int64_t)sizeof(ups_prep_item);
+}
 
 namespace {
 

@@ -431,6 +431,8 @@ extern "C" int ups_part_softmax_fwd(const float* mean, const float* eps, float* 
     return UPS_OK;
 }
 
+extern "C" int32_t ups_part_softmax_moments_tile(int32_t P) { return tile_pixels(P, 1, 24 * 1024); }
+
 extern "C" size_t ups_part_softmax_moments_ints(int64_t pixels, int32_t P) {
     return (size_t)ups_cdiv(pixels, tile_pixels(P, 1, 24 * 1024)) * P * 5;
 }

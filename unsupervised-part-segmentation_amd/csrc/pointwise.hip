@@ -271,6 +271,34 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, int lds, T* __re
     }
 }
 
+// ------------------------------------------------------------------ crop window (perceptual_input: resize256_crop224)
+// fwd: y[n, i, j, :] = x[n, oy + i, ox + j, :] for the ho x wo window whose corner (oy, ox) is READ ON THE DEVICE (one random
+// window per step for the whole batch, tf.random_crop; a device scalar keeps the launch valid inside a captured HIP graph);
+// bwd: gx = gy inside the window, zero elsewhere.  One thread per 16-byte chunk of the result.
+template <typename T>
+__global__ void crop_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w, int c, int ho, int wo,
+                            const int* __restrict__ yx, int bwd) {
+    constexpr int E = V16<T>::N;
+    const int cc = c / E;
+    const int oy = min(max(yx[0], 0), h - ho), ox = min(max(yx[1], 0), w - wo);
+    const int rh = bwd ? h : ho, rw = bwd ? w : wo;            // shape of the result
+    const long long total = (long long)n * rh * rw * cc;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % cc);
+        long long r = idx / cc;
+        const int j = (int)(r % rw); r /= rw;
+        const int i = (int)(r % rh);
+        const int img = (int)(r / rh);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (!bwd) {
+            v = *(const uint4*)(src + (((long long)img * h + oy + i) * w + ox + j) * c + k * E);
+        } else if ((unsigned)(i - oy) < (unsigned)ho && (unsigned)(j - ox) < (unsigned)wo) {
+            v = *(const uint4*)(src + (((long long)img * ho + i - oy) * wo + j - ox) * c + k * E);
+        }
+        *(uint4*)(dst + idx * E) = v;
+    }
+}
+
 // ------------------------------------------------------------------ VGG pre-processing (edflow VGG19Features, UNVERIFIED)
 // y[pix] = {b*127.5+127.5-103.939, g*..-116.779, r*..-123.68, 0,0,0,0,0}
 template <typename T, typename TX>
@@ -437,6 +465,26 @@ extern "C" int ups_bilinear2x_bwd_f8(const void* gy, void* gx, int32_t n, int32_
                        (bf16*)gx, n, h, w, c, q);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
+}
+static int crop_launch(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo,
+                       const int32_t* yx_dev, int bwd, void* stream) {
+    UPS_CHECK_ARG(src && dst && yx_dev && n > 0 && ho > 0 && wo > 0 && ho <= h && wo <= w && c % 8 == 0);
+    const long long work = (long long)n * (bwd ? h : ho) * (bwd ? w : wo) * (c / (dtype == UPS_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(crop_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)src, (float*)dst, n, h, w, c, ho, wo, yx_dev, bwd);
+    else if (dtype == UPS_BF16 || dtype == UPS_F16)
+        hipLaunchKernelGGL(crop_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, n, h, w, c, ho, wo, yx_dev, bwd);
+    else { ups_set_error("bad dtype %d", (int)dtype); return UPS_E_ARG; }
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_crop_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo,
+                            const int32_t* yx_dev, void* stream) {
+    return crop_launch(x, y, dtype, n, h, w, c, ho, wo, yx_dev, 0, stream);
+}
+extern "C" int ups_crop_bwd(const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo,
+                            const int32_t* yx_dev, void* stream) {
+    return crop_launch(gy, gx, dtype, n, h, w, c, ho, wo, yx_dev, 1, stream);
 }
 extern "C" int ups_act_mean_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t hw, int32_t c, int32_t act, float slope, void* stream) {
     UPS_CHECK_ARG(x && y);

@@ -12,6 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UPS_LIB", os.path.join(_HERE, "csrc", "libupsparts_hip.so"))   # UPS_LIB: A/B builds
 
+ABI_VERSION = 2               # include/upsparts_hip.h UPS_ABI_VERSION
 F32, BF16, F16 = 0, 1, 2      # F16: forward tensors of precision-critical scopes (held in torch.bfloat16 containers, see ops.py)
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 ACT = {None: ACT_NONE, "leaky_relu": ACT_LRELU, "relu": ACT_RELU}
@@ -74,6 +75,7 @@ _lib = None
 _I, _L, _F, _P, _Z = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 _SIGS = {
     "ups_abi_version": ([], C.c_int),
+    "ups_struct_sizes": ([C.POINTER(C.c_int64)], None),
     "ups_conv_igemm": ([C.POINTER(ConvDesc), _P], C.c_int),
     "ups_conv_wgrad_plan": ([C.POINTER(WgradDesc), C.POINTER(_I), C.POINTER(_Z)], C.c_int),
     "ups_conv_wgrad": ([C.POINTER(WgradDesc), _P], C.c_int),
@@ -88,6 +90,8 @@ _SIGS = {
     "ups_col_sum": ([_P, _I, _L, _I, _I, _P, _P, _P], C.c_int),
     "ups_bilinear2x_fwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "ups_bilinear2x_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "ups_crop_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
+    "ups_crop_bwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "ups_bilinear2x_fwd_act": ([_P, _P, _I, _I, _I, _I, _I, _I, _F, _P], C.c_int),
     "ups_bilinear2x_fwd_f8": ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _I, _P], C.c_int),
     "ups_bilinear2x_bwd_f8": ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
@@ -103,6 +107,7 @@ _SIGS = {
     "ups_l1_bwd": ([_P, _P, _P, _I, _L, _I, _I, _I, _P, _F, _P], C.c_int),
     "ups_sum_scale": ([_P, _I, _F, _P, _I, _P], C.c_int),
     "ups_part_softmax_fwd": ([_P, _P, _P, _P, _P, _P, _P, _L, _I, _P], C.c_int),
+    "ups_part_softmax_moments_tile": ([_I], _I),
     "ups_part_softmax_moments_ints": ([_L, _I], _Z),
     "ups_part_softmax_moments_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P], C.c_int),
     "ups_spatial_moments": ([_P, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P], C.c_int),
@@ -145,8 +150,14 @@ def load():
         fn.restype = res
     lib.ups_last_error.argtypes = []
     lib.ups_last_error.restype = C.c_char_p
-    if lib.ups_abi_version() != 1:
-        raise UpsError("ABI version mismatch")
+    if lib.ups_abi_version() != ABI_VERSION:
+        raise UpsError("{}: ABI version {} (this binding speaks {}): rebuild with __graft_entry__.build()".format(
+            LIB_PATH, lib.ups_abi_version(), ABI_VERSION))
+    sizes = (C.c_int64 * 4)()
+    lib.ups_struct_sizes(sizes)
+    mine = [C.sizeof(ConvDesc), C.sizeof(WgradDesc), C.sizeof(PriorDesc), C.sizeof(PrepItem)]
+    if list(sizes) != mine:
+        raise UpsError("{}: descriptor struct sizes {} differ from this binding's {} (stale library?)".format(LIB_PATH, list(sizes), mine))
     _lib = lib
     return lib
 

@@ -18,6 +18,7 @@ import ctypes as C
 import math
 import os
 from collections import OrderedDict
+from collections.abc import Mapping
 
 import torch
 
@@ -28,6 +29,9 @@ from . import dist as D
 from . import tps as TPS
 from .nets import Act
 from .schedules import make_var, make_linear_var
+
+
+PERCEPTUAL_INPUTS = ("native", "resize256", "resize256_crop224")
 
 
 def _scalar(v, device):
@@ -51,8 +55,9 @@ class TrainModel(object):
         self.act_dtype = torch.float32 if prec in ("fp32", "f32", "float32") else torch.bfloat16
         # precision: fp8 (BASELINE config #5) = bf16 tensors, forward and input gradient of the wide 3x3 / stride-1 convolutions
         # with e4m3 / e5m2 MFMA operands and fp32 accumulation (ops.Fp8); weight gradients stay on the bf16 kernels
-        ops.Fp8.reset()                                     # the fp8 state (scale slots, hand-off) is per model
-        ops.Fp8.enabled = prec in ("fp8", "f8", "e4m3")
+        # the fp8 state (scale slots, hand-off, switches, counters) is an object of THIS model; `fp8_copy_only: False` lets every
+        # eligible layer convert its operand in the kernel (one-step runs: no producer has a delayed scale yet)
+        self.fp8 = ops.Fp8.activate(ops.Fp8State(prec in ("fp8", "f8", "e4m3"), config.get("fp8_copy_only")))
         self.patch_size = config.get("patch_size", 32)
         self.df = N.is_48c(config)          # DeepFashion SB_model48c variant (two inputs, no rectangles, extra decoders)
         self.nets = N.Nets(config, self.device, seed if seed is not None else config.get("seed", 0))
@@ -108,6 +113,7 @@ class TrainModel(object):
     def forward(self, batch, noise=None):
         """Inference graph (test_mode semantics when ``noise`` is None): fills ``outputs``."""
         cfg = self.config
+        ops.Fp8.activate(self.fp8)
         v0 = batch["view0"].to(self.device, torch.float32)
         v1 = batch["view1"].to(self.device, torch.float32)
         B, S = v0.shape[0], v0.shape[1]
@@ -151,14 +157,31 @@ def mask2rgb(mask):
     return col[mask.argmax(dim=3)]
 
 
-class _LazyLosses(object):
-    """What train_step returns: the per-key losses of the step just run, computed when first read (Trainer.losses)."""
+class _Step(object):
+    """The tensors and constants of one training step, handed from segment to segment (Trainer._step_begin ... _log_thunk)."""
+
+
+class _LazyLosses(Mapping):
+    """What train_step returns: the per-key losses OF THAT STEP, computed when first read and cached (the object keeps the step's
+    own thunk, so reading it after later steps still yields this step's values).  A read-only Mapping (dict(x), json via
+    dict(x), isinstance(x, Mapping) work)."""
 
     def __init__(self, trainer):
-        self._t = trainer
+        self._t, self._thunk = trainer, trainer._lazy_logs
+        # (HIP-graph mode computes the values with the step, into buffers every replay overwrites: nothing to defer)
+        self._vals = trainer._losses if self._thunk is None else None
 
     def _d(self):
-        return self._t.losses
+        if self._vals is None:
+            t = self._t
+            if t._lazy_logs is self._thunk:
+                self._vals = t.losses                   # still the trainer's latest step: materialise there (log_ops share it)
+            elif t._done_thunk is self._thunk:
+                self._vals = t._losses                  # ... which somebody has already done
+            else:
+                self._vals = self._thunk()[0]           # later steps have replaced the trainer's view: evaluate this step's own
+            self._thunk = None
+        return self._vals
 
     def __getitem__(self, k):
         return self._d()[k]
@@ -168,18 +191,6 @@ class _LazyLosses(object):
 
     def __len__(self):
         return len(self._d())
-
-    def __contains__(self, k):
-        return k in self._d()
-
-    def keys(self):
-        return self._d().keys()
-
-    def values(self):
-        return self._d().values()
-
-    def items(self):
-        return self._d().items()
 
 
 class Trainer(object):
@@ -231,7 +242,7 @@ class Trainer(object):
                       "avg_mim": _scalar(0.0, d), "avg_independent_mim": _scalar(0.0, d)}
         self._gen = torch.Generator(device=d)
         self._gen.manual_seed(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))
-        self._lazy_logs = None
+        self._lazy_logs, self._done_thunk = None, None
         self._losses = OrderedDict((k, None) for k in self.loss_keys())
         self._early, self._early_hooked = {}, False
         self._graph_enabled = bool(config.get("hip_graph", os.environ.get("UPS_GRAPH", "0") == "1"))
@@ -246,6 +257,7 @@ class Trainer(object):
         if self._lazy_logs is not None:
             thunk, self._lazy_logs = self._lazy_logs, None
             self._losses, self._log_ops = thunk()
+            self._done_thunk = thunk
 
     @property
     def losses(self):
@@ -313,6 +325,17 @@ class Trainer(object):
     TF_UNNAMED_ORDER = ("lon", "avg_acc0", "avg_acc1", "avg_acc_error", "avg_loss_dis0", "avg_loss_dis1", "avg_mim",
                         "avg_independent_mim", "loa", "lor")
 
+    def tf_unnamed_order(self):
+        """The state scalars the REFERENCE graph creates for this config, in creation order (TensorFlow names unnamed variables
+        `Variable`, `Variable_1`, ... by it): `loa` exists only under adversarial_regularization (model.py:886-890), `lor` only
+        under variational_regularization (model.py:913-921); with one of them off the later names shift down."""
+        skip = set()
+        if not self.config.get("adversarial_regularization", True):
+            skip.add("loa")
+        if not self.config.get("variational_regularization", True):
+            skip.add("lor")
+        return tuple(k for k in self.TF_UNNAMED_ORDER if k not in skip)
+
     def _initialize_from_tf(self, prefix):
         """A TensorFlow-1.x checkpoint of the reference (``model.ckpt-<step>.index`` + ``.data-*``): variables are matched by
         name exactly as slim.assign_from_checkpoint(ignore_missing_vars=True) does (model.py:597-601), Adam slots
@@ -343,14 +366,15 @@ class Trainer(object):
         # what slim.assign_from_checkpoint would ALSO have restored but cannot be matched here: the reference's unnamed
         # non-trainable scalars (Lagrangian multipliers, EMAs) and the optimizers' beta powers.  Say so instead of silently
         # restarting them (the multipliers / EMAs start from their yaml initial values, Adam's step count from the file name).
-        # The reference's graph creates exactly ten unnamed scalar tf.Variables, which TensorFlow names by creation order:
+        # The reference's graph creates ten unnamed scalar tf.Variables (eight / nine with a regulariser off, tf_unnamed_order),
+        # which TensorFlow names by creation order:
         # `Variable` = lon (define_graph, model.py:503), `Variable_1..5` = the EMAs of make_loss_ops in source order
         # (model.py:829-834: avg_acc0, avg_acc1, avg_acc_error, avg_loss_dis0, avg_loss_dis1), `_6`, `_7` = the EMAs of the two MI
         # constraints (model.py:862, 865), `_8` = loa (890), `_9` = lor (921).  A bundle that holds exactly these ten scalars is
         # mapped in that order (UNVERIFIED against a real checkpoint: the shipped ones are Git-LFS stubs); anything else is
         # reported below instead of guessed.
-        unnamed = ["Variable"] + ["Variable_{}".format(i) for i in range(1, 10)]
-        order = self.TF_UNNAMED_ORDER
+        order = self.tf_unnamed_order()
+        unnamed = ["Variable"] + ["Variable_{}".format(i) for i in range(1, len(order))]
         found = [n for n in _other if n == "Variable" or n.startswith("Variable_")]
         self.state_from_tf = {}
         if sorted(found) == sorted(unnamed) and all(np.asarray(_other[n]).size == 1 for n in unnamed):
@@ -386,7 +410,7 @@ class Trainer(object):
         tensors["global_step"] = np.asarray(self.global_step, dtype=np.int64)
         # the Lagrangian state under the names TensorFlow gives the reference's ten unnamed scalar variables (creation order:
         # see _initialize_from_tf)
-        for i, key in enumerate(self.TF_UNNAMED_ORDER):
+        for i, key in enumerate(self.tf_unnamed_order()):
             if key in self.state:
                 tensors["Variable" if i == 0 else "Variable_{}".format(i)] = np.asarray(float(self.state[key]), dtype=np.float32)
         tfckpt.write_bundle(prefix, tensors)
@@ -403,8 +427,11 @@ class Trainer(object):
         cfg = self.config
         S, P, Z = cfg["spatial_size"], self.model.n_parts, cfg.get("z0_size", 256)
         r = lambda *s: torch.randn(*s, generator=self._gen, device=self.device, dtype=torch.float32)
-        return {"eps_pi0": r(9 if self.model.df else 7, B, Z), "eps_pi1": r(B, Z), "eps_l0": r(B, S, S, P),
-                "eps_l1": r(B, S, S, P)}
+        out = {"eps_pi0": r(9 if self.model.df else 7, B, Z), "eps_pi1": r(B, Z), "eps_l0": r(B, S, S, P),
+               "eps_l1": r(B, S, S, P)}
+        if self.perceptual_input == "resize256_crop224":     # corner of the step's 224x224 window of the 256x256 images
+            out["crop_yx"] = torch.randint(0, 33, (2,), generator=self._gen, device=self.device, dtype=torch.int32)
+        return out
 
     def learning_rate(self):
         cfg = self.config
@@ -442,6 +469,7 @@ class Trainer(object):
         """One session.run(train_op).  With ``hip_graph: True`` the whole step -- ~1 000 kernel launches on three streams -- is
         captured once into HIP graphs and replayed (one graph on a single GPU; under data parallelism a sequence of graphs cut
         at the collectives); see ``_graph_step`` / ``_capture_step``."""
+        ops.Fp8.activate(self.model.fp8)
         if self._graph_enabled and not self.model.use_tps:
             # one device scalar carries Adam's bias-corrected step size: usable only while every trained key is at the same
             # Adam step (not after restoring a checkpoint whose keys were trained for different numbers of steps)
@@ -476,7 +504,10 @@ class Trainer(object):
             buf.copy_(batch[k], non_blocking=True)
         for k, buf in g["noise"].items():
             if noise is None:
-                buf.normal_(generator=self._gen)
+                if k == "crop_yx":
+                    buf.random_(0, 33, generator=self._gen)
+                else:
+                    buf.normal_(generator=self._gen)
             else:
                 buf.copy_(noise[k], non_blocking=True)
         t = self.model.bank.groups[self.loss_keys()[0]]["t"] + 1
@@ -513,6 +544,18 @@ class Trainer(object):
                 self._segment_begin()
                 self._step_impl(g["in"], g["noise"], graph_lr=g["lr"])
                 self._segment_end()
+        except BaseException:
+            # leave the stream usable for the eager trainer: end the open capture (its graph is discarded), rejoin the side
+            # streams, and stop trying to capture
+            try:
+                with torch.cuda.stream(cap["stream"]):
+                    if cap["cur"] is not None:
+                        ops.Streams.join(dev, names=("wgrad", "aux", "pre"))
+                        cap["cur"].capture_end()
+            except Exception:
+                pass
+            self._graph_enabled, self._g = False, None
+            raise
         finally:
             self._cap = None
         torch.cuda.current_stream(dev).wait_stream(cap["stream"])
@@ -560,14 +603,17 @@ class Trainer(object):
             self.model.bank.groups[k]["t"] += 1
         self.global_step += 1
 
-    def _step_impl(self, batch, noise=None, graph_lr=None):
-        cfg, model, nets, bank = self.config, self.model, self.model.nets, self.model.bank
-        dev, T = self.device, model.act_dtype
-        step = self.global_step
-        keys = self.loss_keys()
+    # ------------------------------------------------------------------ the step, segment by segment.  `c` (a _Step) carries the
+    # step's tensors from one segment to the next; the order of the calls in _step_impl IS the order of the launches.
+    def _step_begin(self, batch, noise):
+        """Inputs (+ in-graph TPS, model.py:334-337), noise, schedule constants; starts the perceptual features of the TARGET on
+        the "pre" stream (they depend on the data only and fill the bubbles of the small layers at the network ends)."""
+        cfg, model, dev = self.config, self.model, self.device
+        c = _Step()
+        c.keys, c.step, c.df, c.T = self.loss_keys(), self.global_step, model.df, model.act_dtype
+        df = c.df
         v0 = batch["view0"].to(dev, torch.float32).contiguous()
         v1 = batch["view1"].to(dev, torch.float32).contiguous()
-        df = model.df
         vt = v0 if df else batch["view0_target"].to(dev, torch.float32).contiguous()    # SB_model48c:669: target = view0
         if model.use_tps:           # model.py:334-337, 282-311
             tu = None if noise is None or "tps_u" not in noise else noise["tps_u"].to(dev, torch.float32)
@@ -575,242 +621,263 @@ class Trainer(object):
             v0, v1 = aug[0], aug[1]
             vt = v0 if df else aug[2]
             model._tps = {"tps_view0": v0, "tps_view1": v1, "tps_view0_target": vt}
-        B, S = v0.shape[0], v0.shape[1]
-        Z, A, P = cfg.get("z0_size", 256), cfg.get("local_app_size", 64), model.n_parts
-        gamma = float(cfg.get("gamma", 3.0))
-        half = model.patch_size // 2
-        main_stream = torch.cuda.current_stream(dev)
-        # the perceptual features of the TARGET depend on the data only: evaluated on a side stream from the start of the step
-        # (they fill the bubbles of the small layers at the network ends), joined where the loss needs them
-        ft_pre, ft_ready = None, None
-        # `perceptual_input: resize256` (edflow VGG19Features original_scale reading, model.py:610-612): 128x128 inputs are
-        # up-sampled x2 (legacy bilinear), 256x256 inputs already have that size; other sizes have no restatement
-        resize2x = False
-        if self.perceptual_input == "resize256":
-            if S not in (128, 256):
-                raise NotImplementedError("perceptual_input: resize256 is restated for 128x128 and 256x256 inputs only (got {})".format(S))
-            resize2x = S == 128
-        elif self.perceptual_input != "native":
-            raise NotImplementedError("perceptual_input: {} (native | resize256)".format(self.perceptual_input))
+        c.v0, c.v1, c.vt = v0, v1, vt
+        c.B, c.S = v0.shape[0], v0.shape[1]
+        c.Z, c.A, c.P = cfg.get("z0_size", 256), cfg.get("local_app_size", 64), model.n_parts
+        c.gamma = float(cfg.get("gamma", 3.0))
+        c.half = model.patch_size // 2
+        c.main_stream = torch.cuda.current_stream(dev)
+        # `perceptual_input` (the three readings of edflow VGG19Features(original_scale=True), model.py:610-612, UNVERIFIED):
+        # native | resize256 (128x128 inputs are up-sampled x2 with the legacy bilinear kernel, 256x256 inputs already have that
+        # size) | resize256_crop224 (then ONE random 224x224 window for the whole batch, target and reconstruction alike;
+        # its corner is the explicit noise input `crop_yx`, int32 [2] on the device)
+        c.pmode = self.perceptual_input
+        if c.pmode not in PERCEPTUAL_INPUTS:
+            raise NotImplementedError("perceptual_input: {} ({})".format(c.pmode, " | ".join(PERCEPTUAL_INPUTS)))
+        c.resize2x = False
+        if c.pmode != "native":
+            if c.S not in (128, 256):
+                raise NotImplementedError("perceptual_input: {} is restated for 128x128 and 256x256 inputs only (got {})".format(c.pmode, c.S))
+            c.resize2x = c.S == 128
+        if noise is None:
+            noise = self.draw_noise(c.B)
+        c.crop_yx = None
+        if c.pmode == "resize256_crop224":
+            if df:
+                raise NotImplementedError("perceptual_input: resize256_crop224 is restated for the SB_model48i variants only")
+            c.crop_yx = noise["crop_yx"].to(dev, torch.int32).contiguous()
+        c.ft_pre, c.ft_ready = None, None
         if ops.Streams.enabled:
             pre = ops.Streams.get("pre", dev)
-            pre.wait_stream(main_stream)
+            pre.wait_stream(c.main_stream)
             with torch.cuda.stream(pre), torch.no_grad():
-                tgt_pre = ops.BilinearFn.apply(model.to_act(vt)) if resize2x else vt
-                ft_pre = self.vgg.features(tgt_pre, T)
-            ft_ready = pre.record_event()
-        if noise is None:
-            noise = self.draw_noise(B)
-        noise = {k: v.to(dev, torch.float32).contiguous() for k, v in noise.items()}
-        st = self.state
-        log = OrderedDict()
-
+                tgt_pre = vt if c.pmode == "native" else self._perceptual_view(c, model.to_act(vt))
+                c.ft_pre = self.vgg.features(tgt_pre, c.T)
+            c.ft_ready = pre.record_event()
+        c.noise = {k: v.to(dev, torch.float32).contiguous() for k, v in noise.items() if k != "crop_yx"}
+        c.st = self.state
         # ---- schedule constants of this step (model.py:621-646, 709-726, 774-779)
-        w_gmrf = make_var(step, cfg["prior_gmrf_weight"])
-        w_ms = make_var(step, cfg["prior_mumford_sha_weight"])
-        w_kl = make_linear_var(step, **cfg["kl_weight"])
-        w_var = make_var(step, cfg["variance_weight"])
-        w_weak = make_var(step, cfg["weakly_superv_loss_weight_p"])
-        w_patch = 0.0 if df else make_var(step, cfg["patch_loss_weight"])
-        pretrain = bool(cfg.get("pretrain", False))
-
-        # ================= A: pose encoder + latent (model.py:382-409)
-        img01 = model.to_act(torch.cat([v0, v1], 0))
-        pe = nets.e_pi(Act(img01, 2 * B, S, S, 3)).t                    # fp32 [2B,1,1,NP], taped
-        pe2 = pe.detach().view(2 * B, -1)
-        pe_v0, pe_v1 = pe2[:B].contiguous(), pe2[B:].contiguous()
-        lon = 1.0                                                         # LON_ADAPTIVE = False (model.py:842): lon stays 1
-        levels0 = [1.0, lon, lon, 1.0, 1.0, 1.0, 1.0]                     # draw order model.py:406,506,509,512,514,518,520
-        if df:
-            levels0 += [1.0, 1.0]                                         # SB_model48c:492,502: two more draws of z_00
-        samples0, kl_rows = ops.latent_fwd(pe_v0, noise["eps_pi0"], levels0, True)
-        samples1, _ = ops.latent_fwd(pe_v1, noise["eps_pi1"][None], [1.0], False)
-
-        # ================= D: critics (model.py:502-521, 800-866) -- they depend on the latent samples and on the appearance
-        # code of the whole views only, and the main path needs them again at the encoder_0 backward: the whole block
-        # (72 tiny GEMMs that cannot fill the chip) runs on the "aux" stream beside segments B and C.
+        step = c.step
+        c.w_gmrf = make_var(step, cfg["prior_gmrf_weight"])
+        c.w_ms = make_var(step, cfg["prior_mumford_sha_weight"])
+        c.w_kl = make_linear_var(step, **cfg["kl_weight"])
+        c.w_var = make_var(step, cfg["variance_weight"])
+        c.w_weak = make_var(step, cfg["weakly_superv_loss_weight_p"])
+        c.w_patch = 0.0 if df else make_var(step, cfg["patch_loss_weight"])
+        c.pretrain = bool(cfg.get("pretrain", False))
         mi = cfg["MI"]
-        MI_TARGET, MI_SLACK = mi.get("mi_target", 0.125), mi.get("mi_slack", 0.05)
+        c.mi, c.MI_TARGET, c.MI_SLACK = mi, mi.get("mi_target", 0.125), mi.get("mi_slack", 0.05)
+        c.beta_0 = cfg.get("beta_0", 1.0)
+        c.var_reg = cfg.get("variational_regularization", True)
+        return c
 
-        def critic_block():
-            # appearance of the whole views feeds the critics only -> forward only (model.py:394-397)
-            with torch.no_grad():
-                alpha = nets.e_alpha(Act(img01, 2 * B, S, S, 3)).t            # [2B,1,1,A]
-                alpha_in = torch.cat([alpha[B:], torch.flip(alpha[:B], dims=[0])], 0).contiguous()
-            crit = {}
-            for ci, name in enumerate(("mi0_discriminator", "mi1_discriminator", "mi_estimator")):
-                pi_in = model.to_act(torch.cat([samples0[1 + 2 * ci], samples0[2 + 2 * ci]], 0).view(2 * B, 1, 1, Z))
-                pi_in.requires_grad_(name == "mi0_discriminator")
-                h_pi, h_al = nets.critic(name, (Act(pi_in, 2 * B, 1, 1, Z), Act(alpha_in, 2 * B, 1, 1, A)))
-                logits = (h_pi.t.float() * h_al.t.float()).sum(dim=(1, 2, 3))
-                joint, marg = logits[:B], logits[B:]
-                loss = 0.5 * (torch.nn.functional.softplus(-joint).mean() + torch.nn.functional.softplus(marg).mean())
-                acc = ((joint > 0).sum() + (marg < 0).sum()).float() / (2 * B)
-                crit[name] = (loss, joint, acc, pi_in)
-            loss_dis0, joint0, acc0, pi_leaf0 = crit["mi0_discriminator"]
-            loss_dis1, joint1, acc1, _ = crit["mi1_discriminator"]
-            loss_est, _, acc_est, _ = crit["mi_estimator"]
-            mim = joint0.mean()                                                # logit_constraint(real=False), model.py:855
-            ind_mim = joint1.mean()
+    def _perceptual_view(self, c, x_act):
+        """What the perceptual trunk sees of an image in the activation layout [n,S,S,8] (`perceptual_input`)."""
+        if c.resize2x:
+            x_act = ops.BilinearFn.apply(x_act)
+        if c.crop_yx is not None:
+            x_act = ops.CropFn.apply(x_act, c.crop_yx, 224, 224)
+        return x_act
 
-            adv = None
-            g_adv = None
-            if cfg.get("adversarial_regularization", True):                   # model.py:886-909
-                loa, loa_lr = st["loa"], mi.get("loa_lr", 4.0)
-                loa_gain = mim - (1.0 - MI_SLACK) * MI_TARGET
-                if mi.get("loa_adaptive", True):
-                    active = (loa_lr * loa_gain.detach() >= -loa).float()
-                    adv = active * (loa * loa_gain + loa_lr / 2.0 * loa_gain ** 2)
-                else:
-                    adv = loa * loa_gain
-                if "encoder_0" in keys:
-                    with ops.skip_wgrad():
-                        g_adv = torch.autograd.grad([adv], [pi_leaf0], retain_graph=True)[0].float().view(2 * B, Z)[:B]
-            for name in ("mi0_discriminator", "mi1_discriminator", "mi_estimator"):
+    def _fwd_pose(self, c):
+        """A forward: pose encoder + full-covariance latent (model.py:382-409); nine / seven draws of z_0, one of z_1."""
+        model, nets = self.model, self.model.nets
+        B, S = c.B, c.S
+        c.img01 = model.to_act(torch.cat([c.v0, c.v1], 0))
+        c.pe = nets.e_pi(Act(c.img01, 2 * B, S, S, 3)).t                  # fp32 [2B,1,1,NP], taped
+        c.pe2 = c.pe.detach().view(2 * B, -1)
+        c.pe_v0, c.pe_v1 = c.pe2[:B].contiguous(), c.pe2[B:].contiguous()
+        lon = 1.0                                                         # LON_ADAPTIVE = False (model.py:842): lon stays 1
+        c.levels0 = [1.0, lon, lon, 1.0, 1.0, 1.0, 1.0]                   # draw order model.py:406,506,509,512,514,518,520
+        if c.df:
+            c.levels0 += [1.0, 1.0]                                       # SB_model48c:492,502: two more draws of z_00
+        c.samples0, c.kl_rows = ops.latent_fwd(c.pe_v0, c.noise["eps_pi0"], c.levels0, True)
+        c.samples1, _ = ops.latent_fwd(c.pe_v1, c.noise["eps_pi1"][None], [1.0], False)
+
+    def _critics(self, c):
+        """D: the three critics (model.py:502-521, 800-866), their own gradients, the adversarial gradient d adv / d z_joint0 for
+        encoder_0 (model.py:886-909) and, for SB_model48c, the three single-sample decoders.  They depend on the latent samples
+        and on the appearance code of the whole views only, and the main path needs them again at the encoder_0 backward: the
+        whole block (72 tiny GEMMs that cannot fill the chip) runs on the "aux" stream beside segments B and C."""
+        cfg, model, nets, bank = self.config, self.model, self.model.nets, self.model.bank
+        B, S, Z, A, keys, st, mi = c.B, c.S, c.Z, c.A, c.keys, c.st, c.mi
+        # appearance of the whole views feeds the critics only -> forward only (model.py:394-397)
+        with torch.no_grad():
+            alpha = nets.e_alpha(Act(c.img01, 2 * B, S, S, 3)).t            # [2B,1,1,A]
+            alpha_in = torch.cat([alpha[B:], torch.flip(alpha[:B], dims=[0])], 0).contiguous()
+        crit = {}
+        for ci, name in enumerate(("mi0_discriminator", "mi1_discriminator", "mi_estimator")):
+            pi_in = model.to_act(torch.cat([c.samples0[1 + 2 * ci], c.samples0[2 + 2 * ci]], 0).view(2 * B, 1, 1, Z))
+            pi_in.requires_grad_(name == "mi0_discriminator")
+            h_pi, h_al = nets.critic(name, (Act(pi_in, 2 * B, 1, 1, Z), Act(alpha_in, 2 * B, 1, 1, A)))
+            logits = (h_pi.t.float() * h_al.t.float()).sum(dim=(1, 2, 3))
+            joint, marg = logits[:B], logits[B:]
+            loss = 0.5 * (torch.nn.functional.softplus(-joint).mean() + torch.nn.functional.softplus(marg).mean())
+            acc = ((joint > 0).sum() + (marg < 0).sum()).float() / (2 * B)
+            crit[name] = (loss, joint, acc, pi_in)
+        _, joint0, _, pi_leaf0 = crit["mi0_discriminator"]
+        _, joint1, _, _ = crit["mi1_discriminator"]
+        c.mim = joint0.mean()                                                # logit_constraint(real=False), model.py:855
+        c.ind_mim = joint1.mean()
+        c.adv, c.g_adv = None, None
+        if cfg.get("adversarial_regularization", True):                   # model.py:886-909
+            loa, loa_lr = st["loa"], mi.get("loa_lr", 4.0)
+            loa_gain = c.mim - (1.0 - c.MI_SLACK) * c.MI_TARGET
+            if mi.get("loa_adaptive", True):
+                active = (loa_lr * loa_gain.detach() >= -loa).float()
+                c.adv = active * (loa * loa_gain + loa_lr / 2.0 * loa_gain ** 2)
+            else:
+                c.adv = loa * loa_gain
+            if "encoder_0" in keys:
+                with ops.skip_wgrad():
+                    c.g_adv = torch.autograd.grad([c.adv], [pi_leaf0], retain_graph=True)[0].float().view(2 * B, Z)[:B]
+        for name in ("mi0_discriminator", "mi1_discriminator", "mi_estimator"):
+            if name in keys:
+                ps = [bank.params[n] for n in bank.groups[name]["names"]]
+                torch.autograd.grad([crit[name][0]], ps)
+        if c.df:
+            # SB_model48c:491-505, 672-684, 812-814: three single-sample decoders on batch item 0 (inputs under
+            # stop_gradient), each with its own perceptual loss and optimizer key
+            scale = 1e-3 * 0.5 * (S * S * 3)
+            a1 = alpha[B:B + 1, ..., :A].float().reshape(1, A)
+            ins = {"d_single": (torch.cat([c.samples0[7][:1], a1], 1), c.v0[:1], Z + A),
+                   "d_alpha": (a1, c.v1[:1], A), "d_pi": (c.samples0[8][:1], c.v0[:1], Z)}
+            for name, (zin, tgt, cz) in ins.items():
+                g_img = nets.dsingle(name, Act(model.to_act(zin.view(1, 1, 1, cz)), 1, 1, 1, cz)).t
+                lss = scale * self.vgg.loss(tgt.contiguous(), g_img, c.T)
+                crit[name] = (lss, g_img)
                 if name in keys:
-                    ps = [bank.params[n] for n in bank.groups[name]["names"]]
-                    torch.autograd.grad([crit[name][0]], ps)
+                    torch.autograd.grad([lss], [bank.params[n] for n in bank.groups[name]["names"]])
+        c.crit = crit
+        c.loss_dis0, _, c.acc0, _ = crit["mi0_discriminator"]
+        c.loss_dis1, _, c.acc1, _ = crit["mi1_discriminator"]
+        c.loss_est, _, c.acc_est, _ = crit["mi_estimator"]
 
-            if df:
-                # SB_model48c:491-505, 672-684, 812-814: three single-sample decoders on batch item 0 (inputs under
-                # stop_gradient), each with its own perceptual loss and optimizer key
-                scale = 1e-3 * 0.5 * (S * S * 3)
-                a1 = alpha[B:B + 1, ..., :A].float().reshape(1, A)
-                ins = {"d_single": (torch.cat([samples0[7][:1], a1], 1), v0[:1], Z + A),
-                       "d_alpha": (a1, v1[:1], A), "d_pi": (samples0[8][:1], v0[:1], Z)}
-                for name, (zin, tgt, cz) in ins.items():
-                    g_img = nets.dsingle(name, Act(model.to_act(zin.view(1, 1, 1, cz)), 1, 1, 1, cz)).t
-                    lss = scale * self.vgg.loss(tgt.contiguous(), g_img, T)
-                    crit[name] = (lss, g_img)
-                    if name in keys:
-                        torch.autograd.grad([lss], [bank.params[n] for n in bank.groups[name]["names"]])
-            return crit, adv, g_adv, mim, ind_mim
-
-        if ops.Streams.enabled:
-            aux = ops.Streams.get("aux", dev)
-            aux.wait_stream(main_stream)
-            with torch.cuda.stream(aux):
-                crit, adv, g_adv, mim, ind_mim = critic_block()
-        else:
-            crit, adv, g_adv, mim, ind_mim = critic_block()
-        loss_dis0, joint0, acc0, _ = crit["mi0_discriminator"]
-        loss_dis1, joint1, acc1, _ = crit["mi1_discriminator"]
-        loss_est, _, acc_est, _ = crit["mi_estimator"]
-
-        # ================= B: mask decoder (model.py:411-412)
-        z_act = model.latent_act(torch.cat([samples0[0], samples1[0]], 0))
-        z_leaf = z_act.t.requires_grad_(True)
-        l_mean = nets.dv(z_act).t                                         # fp32 [2B,S,S,P], taped
-        lm = l_mean.detach()
-
-        # ================= part path, untaped (model.py:414-473)
+    def _fwd_masks(self, c):
+        """B forward: mask decoder z -> logits (model.py:411-412), then the un-taped part path (model.py:414-473): l = mean + eps,
+        soft-max, hard max, the moments of gamma * hard and the rectangle centres."""
+        cfg, model, nets = self.config, self.model, self.model.nets
+        B, S, P = c.B, c.S, c.P
+        z_act = model.latent_act(torch.cat([c.samples0[0], c.samples1[0]], 0))
+        c.z_leaf = z_act.t.requires_grad_(True)
+        c.l_mean = nets.dv(z_act).t                                       # fp32 [2B,S,S,P], taped
+        c.lm = c.l_mean.detach()
         # model.py:420-421 / nn.py:1427-1433: l = mean + eps unless `stochastic_l: False` (default: not test_mode)
         stochastic_l = cfg.get("stochastic_l", not cfg.get("test_mode", False))
-        eps_l = torch.cat([noise["eps_l0"], noise["eps_l1"]], 0) if stochastic_l else None
+        eps_l = torch.cat([c.noise["eps_l0"], c.noise["eps_l1"]], 0) if stochastic_l else None
         # (the moments of gamma * hard -- the input of the rectangle centres, model.py:437-440 -- come out of the same pass)
-        if df:
-            l, m, hard, _, hbits = ops.part_softmax(lm, eps_l, want_bits=P <= 32)
+        if c.df:
+            c.l, c.m, c.hard, _, c.hbits = ops.part_softmax(c.lm, eps_l, want_bits=P <= 32)
             hstats = None
         else:
-            l, m, hard, _, hbits, hstats = ops.part_softmax(lm, eps_l, want_bits=P <= 32, moments_gamma=gamma)
+            c.l, c.m, c.hard, _, c.hbits, hstats = ops.part_softmax(c.lm, eps_l, want_bits=P <= 32, moments_gamma=c.gamma)
         # [2B,P,2] rectangle centres (stop-gradient); SB_model48c has no rectangles
-        if df:
-            px = None
+        if c.df:
+            c.px = None
         else:
             if hstats is None:
-                hstats = ops.spatial_moments(hard, gamma)
-            px = ops.moments_to_px(hstats, S, cfg.get("rect_order", "xy"))
-        hard0 = hard[:B].detach().requires_grad_(True)
-        hard1 = hard[B:].detach().requires_grad_(True)
+                hstats = ops.spatial_moments(c.hard, c.gamma)
+            c.px = ops.moments_to_px(hstats, S, cfg.get("rect_order", "xy"))
+        c.hard0 = c.hard[:B].detach().requires_grad_(True)
+        c.hard1 = c.hard[B:].detach().requires_grad_(True)
 
-        # ================= C: part-wise appearance -> unpool -> image decoder -> perceptual loss (model.py:478-485, 607-619)
-        parts = model.part_images(img01[B:], v1, hard1, None if hbits is None else hbits[B:].contiguous())
+    def _fwd_reconstruction(self, c):
+        """C forward: part-wise appearance -> unpool -> image decoder -> perceptual loss (model.py:478-485, 607-619)."""
+        model, nets = self.model, self.model.nets
+        B, S, A, P, T = c.B, c.S, c.A, c.P, c.T
+        parts = model.part_images(c.img01[B:], c.v1, c.hard1, None if c.hbits is None else c.hbits[B:].contiguous())
         yp = nets.e_alpha(parts).t                                         # [P*B,1,1,A]
-        feat = yp.float().view(P, B, A).permute(1, 0, 2).contiguous()      # [B,P,A]
-        inj = ops.UnpoolFn.apply(hard0, feat, T)
-        gen = nets.dd(Act(inj, B, S, S, A + P)).t                          # [B,S,S,8]
-        gen_in = ops.BilinearFn.apply(gen) if resize2x else gen
-        if ft_pre is not None:
-            main_stream.wait_event(ft_ready)
-            rec = self.vgg.loss(None, gen_in, T, target_features=ft_pre)
+        c.feat = yp.float().view(P, B, A).permute(1, 0, 2).contiguous()    # [B,P,A]
+        inj = ops.UnpoolFn.apply(c.hard0, c.feat, T)
+        c.gen = nets.dd(Act(inj, B, S, S, A + P)).t                        # [B,S,S,8]
+        gen_in = self._perceptual_view(c, c.gen)
+        if c.ft_pre is not None:
+            c.main_stream.wait_event(c.ft_ready)
+            c.rec = self.vgg.loss(None, gen_in, T, target_features=c.ft_pre)
         else:
-            tgt_in = ops.BilinearFn.apply(model.to_act(vt)) if resize2x else vt
-            rec = self.vgg.loss(tgt_in, gen_in, T)
-        auto_rec = (1e-3 * 0.5 * (S * S * 3)) * rec                        # model.py:613-619
+            tgt_in = c.vt if c.pmode == "native" else self._perceptual_view(c, model.to_act(c.vt))
+            c.rec = self.vgg.loss(tgt_in, gen_in, T)
+        c.auto_rec = (1e-3 * 0.5 * (S * S * 3)) * c.rec                    # model.py:613-619
 
-        rec_params = []
-        for k in ("encoder_1", "decoder_delta"):
-            if k in keys:
-                rec_params += [bank.params[n] for n in bank.groups[k]["names"]]
-        gr = torch.autograd.grad([auto_rec], [hard0, hard1] + rec_params)  # conv wgrads land in bank.grads
-        g_hard0, g_hard1 = gr[0].contiguous(), gr[1].contiguous()
-        pending = self._launch_reduce([k for k in ("encoder_1", "decoder_delta") if k in keys])
+    def _bwd_reconstruction(self, c):
+        """C backward: encoder_1 / decoder_delta weight gradients (they land in the flat buckets) and d rec / d hard masks."""
+        bank = self.model.bank
+        rec_keys = [k for k in ("encoder_1", "decoder_delta") if k in c.keys]
+        rec_params = [bank.params[n] for k in rec_keys for n in bank.groups[k]["names"]]
+        gr = torch.autograd.grad([c.auto_rec], [c.hard0, c.hard1] + rec_params)
+        c.g_hard0, c.g_hard1 = gr[0].contiguous(), gr[1].contiguous()
+        return self._launch_reduce(rec_keys)
 
-        # ================= mask priors: fused forward sums + fused backward (model.py:652-797)
+    def _priors(self, c):
+        """Mask priors: fused forward sums + fused analytic backward (model.py:652-797).  One backward launch per view emits both
+        d(rec + priors)/dl (what the decoder_visualize key sees) and d(rec)/dl (what encoder_0 sees)."""
+        dev = self.device
+        B, S, P, df = c.B, c.S, c.P, c.df
         nfl = L.load().ups_prior_sums_floats(B, P)
-        sums0 = torch.empty(nfl, dtype=torch.float32, device=dev)
-        sums1 = torch.empty(nfl, dtype=torch.float32, device=dev)
+        c.sums0 = torch.empty(nfl, dtype=torch.float32, device=dev)
+        c.sums1 = torch.empty(nfl, dtype=torch.float32, device=dev)
         per_np0 = torch.empty((B, P, 8), dtype=torch.float32, device=dev)
-        l0, l1, m0, m1 = l[:B], l[B:], m[:B], m[B:]
-        px0, px1 = (None, None) if df else (px[:B].contiguous(), px[B:].contiguous())
+        l0, l1, m0, m1 = c.l[:B], c.l[B:], c.m[:B], c.m[B:]
+        px0, px1 = (None, None) if df else (c.px[:B].contiguous(), c.px[B:].contiguous())
         wz = {"kl": 0.0, "entropy": 0.0, "ms": 0.0, "area": 0.0, "patch": 0.0, "gmrf": 0.0, "var": 0.0, "msl": 0.0}
-        if pretrain:
+        if c.pretrain:
             wp = dict(wz)
         elif df:     # SB_model48c:830-838
-            wp = {"kl": w_kl, "entropy": w_weak, "ms": 0.0, "area": 0.0, "patch": 0.0, "gmrf": w_gmrf, "var": w_var, "msl": w_ms}
+            wp = {"kl": c.w_kl, "entropy": c.w_weak, "ms": 0.0, "area": 0.0, "patch": 0.0, "gmrf": c.w_gmrf, "var": c.w_var, "msl": c.w_ms}
         else:
-            wp = {"kl": w_kl, "entropy": w_weak, "ms": w_ms, "area": 1.0e-12, "patch": w_patch, "gmrf": w_gmrf, "var": w_var,
+            wp = {"kl": c.w_kl, "entropy": c.w_weak, "ms": c.w_ms, "area": 1.0e-12, "patch": c.w_patch, "gmrf": c.w_gmrf, "var": c.w_var,
                   "msl": 0.0}
-        self._prior(0, B, S, P, l0, lm[:B], m0, hard[:B], px0, per_np0, sums0, wp)
-        self._prior(1, B, S, P, l1, None, m1, None, px1, None, sums1, wp)
+        self._prior(0, B, S, P, l0, c.lm[:B], m0, c.hard[:B], px0, per_np0, c.sums0, wp)
+        self._prior(1, B, S, P, l1, None, m1, None, px1, None, c.sums1, wp)
         # variance moments (model.py:683-707; SB_model48c:750-756: no gamma, no rectangle)
-        stats_v = ops.spatial_moments(m1.contiguous(), 1.0 if df else gamma, rect_px=px1, half=half)
-        dl_tot = torch.empty_like(lm)
-        dl_rec = torch.empty_like(lm)
-        # one launch per view emits both d(rec + priors)/dl (decoder_visualize key) and d(rec)/dl (what encoder_0 sees)
-        self._prior(0, B, S, P, l0, lm[:B], m0, hard[:B], px0, per_np0, sums0, wp, g_hard0, dl_tot[:B], bwd=True, dl_rec=dl_rec[:B])
-        self._prior(1, B, S, P, l1, None, m1, None, px1, stats_v, sums1, wp, g_hard1, dl_tot[B:], bwd=True, dl_rec=dl_rec[B:])
+        c.stats_v = ops.spatial_moments(m1.contiguous(), 1.0 if df else c.gamma, rect_px=px1, half=c.half)
+        c.dl_tot = torch.empty_like(c.lm)
+        c.dl_rec = torch.empty_like(c.lm)
+        self._prior(0, B, S, P, l0, c.lm[:B], m0, c.hard[:B], px0, per_np0, c.sums0, wp, c.g_hard0, c.dl_tot[:B], bwd=True,
+                    dl_rec=c.dl_rec[:B])
+        self._prior(1, B, S, P, l1, None, m1, None, px1, c.stats_v, c.sums1, wp, c.g_hard1, c.dl_tot[B:], bwd=True, dl_rec=c.dl_rec[B:])
 
-        # ---- B backward: weights see rec + priors, the latent sees rec only
-        if "decoder_visualize" in keys:
+    def _bwd_mask_decoder(self, c):
+        """B backward: the weights see rec + priors, the latent sees rec only (one extra input-gradient pass)."""
+        bank = self.model.bank
+        if "decoder_visualize" in c.keys:
             dv_params = [bank.params[n] for n in bank.groups["decoder_visualize"]["names"]]
-            torch.autograd.grad([l_mean], dv_params, grad_outputs=[dl_tot], retain_graph=True)
-        pending += self._launch_reduce([k for k in ("decoder_visualize",) if k in keys])
+            torch.autograd.grad([c.l_mean], dv_params, grad_outputs=[c.dl_tot], retain_graph=True)
+        pending = self._launch_reduce([k for k in ("decoder_visualize",) if k in c.keys])
         with ops.skip_wgrad():
-            gz = torch.autograd.grad([l_mean], [z_leaf], grad_outputs=[dl_rec])[0].float().view(2 * B, Z)
+            c.gz = torch.autograd.grad([c.l_mean], [c.z_leaf], grad_outputs=[c.dl_rec])[0].float().view(2 * c.B, c.Z)
+        return pending
 
-        # the critics' block (aux stream) must be complete from here on: g_adv, the critic losses and their gradients
-        ops.Streams.join(dev, names=("aux",))
-        pending += self._launch_reduce([k for k in ("mi0_discriminator", "mi1_discriminator", "mi_estimator") + N.EXTRA_48C
-                                        if k in keys])
+    def _bwd_pose(self, c):
+        """A backward (model.py:739, 909, 930): d rec / d z (from B), the adversarial gradient on the joint sample of mi0 and the
+        bottleneck beta_0 * exp(lor) * KL."""
+        dev, bank = self.device, self.model.bank
+        B, Z = c.B, c.Z
+        if c.var_reg:
+            assert not self.config.get("test_mode", False)
+            explor = torch.exp(c.st["lor"])
+        if "encoder_0" not in c.keys:
+            return
+        g_s0 = torch.zeros((len(c.levels0), B, Z), dtype=torch.float32, device=dev)
+        g_s0[0] = c.gz[:B]
+        if c.g_adv is not None:
+            g_s0[1] = c.g_adv
+        gp0 = ops.latent_bwd(c.pe_v0, c.noise["eps_pi0"], c.levels0, g_s0, explor.reshape(1) if c.var_reg else None,
+                             c.beta_0 / B if c.var_reg else 0.0)
+        gp1 = ops.latent_bwd(c.pe_v1, c.noise["eps_pi1"][None], [1.0], c.gz[B:].contiguous()[None], None, 0.0)
+        g_pe = torch.cat([gp0, gp1], 0).view_as(c.pe)
+        e0_params = [bank.params[n] for n in bank.groups["encoder_0"]["names"]]
+        if (self.world_size > 1 or D.FORCE_COLLECTIVES) and not self._early_hooked:      # layers exist once the first forward has run
+            self._hook_early_reduce()
+            self._early_hooked = True
+        torch.autograd.grad([c.pe], e0_params, grad_outputs=[g_pe])
 
-        # ================= A backward (model.py:739, 909, 930)
-        beta_0 = cfg.get("beta_0", 1.0)
-        var_reg = cfg.get("variational_regularization", True)
-        if var_reg:
-            assert not cfg.get("test_mode", False)
-            explor = torch.exp(st["lor"])
-        if "encoder_0" in keys:
-            g_s0 = torch.zeros((len(levels0), B, Z), dtype=torch.float32, device=dev)
-            g_s0[0] = gz[:B]
-            if g_adv is not None:
-                g_s0[1] = g_adv
-            gp0 = ops.latent_bwd(pe_v0, noise["eps_pi0"], levels0, g_s0, explor.reshape(1) if var_reg else None,
-                                 beta_0 / B if var_reg else 0.0)
-            gp1 = ops.latent_bwd(pe_v1, noise["eps_pi1"][None], [1.0], gz[B:].contiguous()[None], None, 0.0)
-            g_pe = torch.cat([gp0, gp1], 0).view_as(pe)
-            e0_params = [bank.params[n] for n in bank.groups["encoder_0"]["names"]]
-            if (self.world_size > 1 or D.FORCE_COLLECTIVES) and not self._early_hooked:      # layers exist once the first forward has run
-                self._hook_early_reduce()
-                self._early_hooked = True
-            torch.autograd.grad([pe], e0_params, grad_outputs=[g_pe])
-
-        # ================= gradient all-reduce (data parallel) + TF Adam per key
-        pending += self._launch_reduce([k for k in ("encoder_0",) if k in keys])
-        self._finish_step(keys, pending, graph_lr)
-
-        # ================= state updates (update_ops; Appendix A.15: losses above used the pre-update state)
-        stats = torch.stack([mim.detach(), ind_mim.detach(), acc0, acc1, loss_dis0.detach(), loss_dis1.detach()])
+    def _next_state(self, c):
+        """update_ops (model.py:28-35, 829-834, 861-866, 890-909, 921-930): EMAs and the two multipliers from the batch-mean
+        scalars -- averaged over the ranks first, so that every replica holds the same state.  Appendix A.15: the losses of this
+        step used the pre-update state."""
+        cfg, st, mi = self.config, c.st, c.mi
+        stats = torch.stack([c.mim.detach(), c.ind_mim.detach(), c.acc0, c.acc1, c.loss_dis0.detach(), c.loss_dis1.detach()])
         if getattr(self, "_cap", None) is not None and self.world_size > 1:
             self._boundary("scalars", stats)             # (the tensor lives in the graphs' pool: same address at every replay)
         else:
@@ -823,22 +890,31 @@ class Trainer(object):
         new["avg_loss_dis0"] = ema(st["avg_loss_dis0"], g_l0); new["avg_loss_dis1"] = ema(st["avg_loss_dis1"], g_l1)
         new["avg_mim"] = ema(st["avg_mim"], g_mim); new["avg_independent_mim"] = ema(st["avg_independent_mim"], g_ind)
         if cfg.get("adversarial_regularization", True) and mi.get("loa_adaptive", True):
-            new["loa"] = torch.clamp(st["loa"] + mi.get("loa_lr", 4.0) * (g_mim - (1.0 - MI_SLACK) * MI_TARGET), min=0.0)
-        if var_reg and mi.get("lor_adaptive", True):
-            new["lor"] = torch.clamp(st["lor"] + mi.get("lor_lr", 0.05) * (g_ind - MI_TARGET), mi.get("lor_min", 1.0),
+            new["loa"] = torch.clamp(st["loa"] + mi.get("loa_lr", 4.0) * (g_mim - (1.0 - c.MI_SLACK) * c.MI_TARGET), min=0.0)
+        if c.var_reg and mi.get("lor_adaptive", True):
+            new["lor"] = torch.clamp(st["lor"] + mi.get("lor_lr", 0.05) * (g_ind - c.MI_TARGET), mi.get("lor_min", 1.0),
                                      mi.get("lor_max", 7.5))
+        return new
 
-        # ================= losses per key + log ops (model.py:648-966; same names as the reference).  Everything below is
-        # REPORTING: ~150 scalar launches that no gradient depends on (the per-key gradients were taken from the pieces above).
-        # In the eager trainer it is deferred until somebody reads `losses` / `log_ops` (log steps, tests); the closure keeps
-        # only detached scalars and the small reduction buffers alive.  Inside a captured HIP graph it runs with the step.
-        auto_rec, rec = auto_rec.detach(), rec.detach()
-        adv = adv.detach() if adv is not None else None
-        loss_dis0, loss_dis1, loss_est = loss_dis0.detach(), loss_dis1.detach(), loss_est.detach()
-        mim, ind_mim = mim.detach(), ind_mim.detach()
-        crit_d = {k: crit[k][0].detach() for k in N.EXTRA_48C} if df else {}
-
+    def _log_thunk(self, c):
+        """Losses per key + log ops (model.py:648-966; same names as the reference).  REPORTING only: ~150 scalar launches that no
+        gradient depends on (the per-key gradients were taken from the pieces above).  In the eager trainer the returned closure is
+        evaluated when somebody reads `losses` / `log_ops` (log steps, tests) and keeps only detached scalars and the small
+        reduction buffers alive; inside a captured HIP graph it runs with the step."""
+        cfg, st = self.config, c.st
+        B, S, P, df, keys, step = c.B, c.S, c.P, c.df, c.keys, c.step
+        w_gmrf, w_ms, w_kl, w_var, w_weak, w_patch, pretrain = c.w_gmrf, c.w_ms, c.w_kl, c.w_var, c.w_weak, c.w_patch, c.pretrain
+        beta_0, var_reg, MI_TARGET, MI_SLACK = c.beta_0, c.var_reg, c.MI_TARGET, c.MI_SLACK
+        sums0, sums1, stats_v, kl_rows = c.sums0, c.sums1, c.stats_v, c.kl_rows
+        auto_rec, rec = c.auto_rec.detach(), c.rec.detach()
+        adv = c.adv.detach() if c.adv is not None else None
+        loss_dis0, loss_dis1, loss_est = c.loss_dis0.detach(), c.loss_dis1.detach(), c.loss_est.detach()
+        acc0, acc1, acc_est = c.acc0, c.acc1, c.acc_est
+        mim, ind_mim = c.mim.detach(), c.ind_mim.detach()
+        crit_d = {k: c.crit[k][0].detach() for k in N.EXTRA_48C} if df else {}
         lr_now = self.learning_rate()          # (of THIS step: the counters have moved on when the logs are read)
+        log = OrderedDict()
+
         def build_logs():
             bottleneck = kl_rows.sum(dim=1).mean()                            # nn.py:1196-1208
             bw = beta_0 * torch.exp(st["lor"]) * bottleneck if var_reg else None
@@ -893,26 +969,56 @@ class Trainer(object):
             log.update({"dis0_accuracy": acc0, "dis1_accuracy": acc1, "avg_dis0_accuracy": st["avg_acc0"],
                         "avg_dis1_accuracy": st["avg_acc1"], "avg_loss_dis0": st["avg_loss_dis0"],
                         "avg_loss_dis1": st["avg_loss_dis1"], "est_accuracy": acc_est,
-                        "mi_constraint": mim.detach(), "independent_mi_constraint": ind_mim.detach()})
+                        "mi_constraint": mim, "independent_mi_constraint": ind_mim})
             if adv is not None:
-                log.update({"adversarial_weight": st["loa"], "adversarial_constraint": mim.detach(),
-                            "adversarial_weighted_loss": adv.detach(), "loa": st["loa"],
-                            "loa_gain": (mim - (1.0 - MI_SLACK) * MI_TARGET).detach()})
+                log.update({"adversarial_weight": st["loa"], "adversarial_constraint": mim,
+                            "adversarial_weighted_loss": adv, "loa": st["loa"],
+                            "loa_gain": mim - (1.0 - MI_SLACK) * MI_TARGET})
             if bw is not None:
                 log.update({"bottleneck_weight": st["lor"], "bottleneck_loss": bottleneck, "bottleneck_weighted_loss": bw,
-                            "lor": st["lor"], "explor": beta_0 * torch.exp(st["lor"]), "lor_gain": (ind_mim - MI_TARGET).detach()})
+                            "lor": st["lor"], "explor": beta_0 * torch.exp(st["lor"]), "lor_gain": ind_mim - MI_TARGET})
             if df:
                 log.update({"prior_mumford_sha": prior_ms, "prior_mumford_sha_weight": w_ms, "prior_mumford_sha_weighted": prior_ms * w_ms,
-                            "perceptual": rec.detach(), "lr": lr_now})
+                            "perceptual": rec, "lr": lr_now})
                 for i in range(P):
                     log["sigma1_{:02d}".format(i)] = s00[0, i]
                     log["sigma2_{:02d}".format(i)] = s11[0, i]
             else:
                 log.update({"zr_mumford_sha": p_ms, "z_mumford_sha_smoothness_cost": sums0[6] / B,
                             "z_mumford_sha_contour_cost": sums0[7] / B, "z_area_cost": area_cost,
-                            "prior_mumford_sha_weight": w_ms, "perceptual": rec.detach(), "lr": lr_now})
+                            "prior_mumford_sha_weight": w_ms, "perceptual": rec, "lr": lr_now})
             return losses_d, log
+        return build_logs
 
+    def _step_impl(self, batch, noise=None, graph_lr=None):
+        """One training step on the launching stream (+ the "pre", "aux" and "wgrad" side streams): forward A -> D (aux) -> B ->
+        C, backward C -> priors -> B -> A, each optimizer key's bucket reduced as soon as its segment is complete, Adam, state."""
+        dev = self.device
+        c = self._step_begin(batch, noise)
+        self._fwd_pose(c)
+        if ops.Streams.enabled:
+            aux = ops.Streams.get("aux", dev)
+            aux.wait_stream(c.main_stream)
+            with torch.cuda.stream(aux):
+                self._critics(c)
+        else:
+            self._critics(c)
+        self._fwd_masks(c)
+        self._fwd_reconstruction(c)
+        pending = self._bwd_reconstruction(c)
+        self._priors(c)
+        pending += self._bwd_mask_decoder(c)
+        # the critics' block (aux stream) must be complete from here on: g_adv, the critic losses and their gradients
+        ops.Streams.join(dev, names=("aux",))
+        pending += self._launch_reduce([k for k in ("mi0_discriminator", "mi1_discriminator", "mi_estimator") + N.EXTRA_48C
+                                        if k in c.keys])
+        self._bwd_pose(c)
+        # ---- gradient all-reduce (data parallel) + TF Adam per key
+        pending += self._launch_reduce([k for k in ("encoder_0",) if k in c.keys])
+        self._finish_step(c.keys, pending, graph_lr)
+        new = self._next_state(c)
+        build_logs = self._log_thunk(c)
+        st = c.st
         if graph_lr is not None:        # graph mode: state lives in fixed device scalars, python counters advance outside
             losses_now, log = build_logs()
             # the logged state is the PRE-update value in both modes: snapshot before the in-place update below
@@ -927,8 +1033,9 @@ class Trainer(object):
             self._lazy_logs = build_logs        # (the closure holds the PRE-update state dict `st`: self.state is replaced, not modified)
             self.state = new
             self.global_step += 1
-        self._debug = {"l_mean": lm, "l": l, "m": m, "hard": hard, "px": px, "generated": gen.detach(), "feat": feat.detach(),
-                       "dl_tot": dl_tot, "dl_rec": dl_rec, "g_hard0": g_hard0, "g_hard1": g_hard1, "pe": pe2}
+        self._debug = {"l_mean": c.lm, "l": c.l, "m": c.m, "hard": c.hard, "px": c.px, "generated": c.gen.detach(),
+                       "feat": c.feat.detach(), "dl_tot": c.dl_tot, "dl_rec": c.dl_rec, "g_hard0": c.g_hard0, "g_hard1": c.g_hard1,
+                       "pe": c.pe2}
         return _LazyLosses(self)
 
     def _hook_early_reduce(self):

@@ -168,77 +168,86 @@ class PrepRegistry(object):
             fn()
 
 
-class Fp8(object):
+class Fp8State(object):
     """fp8 forward of the wide 3x3 / stride-1 convolutions (BASELINE config #5: e4m3 MFMA operands, fp32 accumulate, bf16
     tensors; ``precision: fp8`` in the config).  Weights are scaled per output channel when they are converted; activations
     use delayed per-tensor scaling: every launch records max |act(x)| (kernel epilogue, 64 atomic slots per layer) and
     ``update()`` -- once per step, three tiny launches for all layers -- turns it into the next step's scale
-    448 * MARGIN / amax.  A layer's first launch scales from the tensor at hand."""
-    enabled = False
+    448 * MARGIN / amax.  A layer's first launch scales from the tensor at hand.
+
+    One instance per model (``TrainModel.fp8``): scale slots, layer list, hand-off state, switches and counters.  The operators
+    reach the state of the model that is running through the module-level ``Fp8`` proxy; ``TrainModel`` / ``Trainer`` activate
+    their own instance before they touch a layer, so two models alive in one process (a trainer plus an evaluation model, a
+    test sweep) never share slots.  Layers cache slot numbers of THEIR model's state (``generation`` guards against a layer
+    being driven under a foreign state)."""
     MARGIN = 0.5            # headroom for the step-to-step growth of amax (e4m3 max normal = 448)
     MAX_LAYERS = 512
-    amax = None             # [MAX_LAYERS, 64] fp32
-    scale = None            # [MAX_LAYERS] fp32
-    fmax = None             # [MAX_LAYERS] fp32: largest normal of the slot's format
-    count = 0
-    layers = []             # trainable layers with e4m3 weights (re-converted by after_step)
+    E5M2_MAX = 57344.0
+    _generations = 0
 
-    @classmethod
-    def slot(cls, device):
-        if cls.amax is None or cls.amax.device != device:
-            cls.amax = torch.zeros((cls.MAX_LAYERS, 64), dtype=torch.float32, device=device)
-            cls.scale = torch.ones((cls.MAX_LAYERS,), dtype=torch.float32, device=device)
-            cls.fmax = torch.full((cls.MAX_LAYERS,), 448.0, dtype=torch.float32, device=device)   # e4m3; gradient slots: e5m2
-            cls.count = 0
-            cls.layers = []
-        i = cls.count
-        cls.count += 1
-        if i >= cls.MAX_LAYERS:
-            raise L.UpsError("more than {} fp8 layers".format(cls.MAX_LAYERS))
+    def __init__(self, enabled=False, copy_only=None):
+        Fp8State._generations += 1
+        self.generation = Fp8State._generations
+        self.enabled = bool(enabled)
+        self.amax = None            # [MAX_LAYERS, 64] fp32
+        self.scale = None           # [MAX_LAYERS] fp32
+        self.fmax = None            # [MAX_LAYERS] fp32: largest normal of the slot's format
+        self.count = 0
+        self.layers = []            # trainable layers with e4m3 weights (re-converted by after_step)
+        self.GRAD = True            # input gradients of the fp8 layers on e5m2 operands (False: bf16 kernels)
+        # COPY_ONLY: a layer takes the fp8 kernels only when its operand arrives quantised (a copy written by the producing
+        # bilinear / convolution kernel); layers whose operand would have to be converted inside the kernel (24 staging
+        # registers, one block per CU: slower than bf16, DESIGN 3b) stay on the bf16 kernels.  None: follows PRODUCER.
+        # (config key `fp8_copy_only`)
+        self.COPY_ONLY = copy_only
+        # fp8 copies handed from layer to layer: the producing convolution's epilogue writes e4m3(act(out) * scale) next to its
+        # bf16 output (scale = the delayed scale of that tensor), the consuming convolution stages those bytes without any
+        # conversion.  nets.Scope passes the handle along: next_in / next_out_act are set right before ops.conv, last_out is
+        # read right after.  UPS_F8_PRODUCER=0 switches the hand-off off (every eligible layer then converts its bf16 operand
+        # inside the kernel).
+        self.PRODUCER = os.environ.get("UPS_F8_PRODUCER", "1") != "0"
+        self.next_in = None         # {"t": uint8 tensor, "act": UPS_ACT_*, "slot": scale slot} of the coming call's input
+        self.next_out_act = None    # activation-on-load of the consumer of the coming call's output (None: no copy wanted)
+        self.last_out = None        # the copy the last call wrote (same dict), or None
+        self.steps = 0              # update() calls so far (a tensor's copy starts one step after its first maximum was recorded)
+        self.stats = {"fwd_f8": 0, "fwd_copy_in": 0, "fwd_copy_out": 0, "dgrad_f8": 0, "dgrad_copy_in": 0, "dgrad_copy_out": 0,
+                      "wgrad_f8": 0}
+        self.grad_side = {}         # data_ptr of a gradient tensor -> (weakref to it, its e5m2 copy): dgrad epilogue -> next dgrad
+
+    def slot(self, device):
+        if self.amax is None or self.amax.device != device:
+            self.amax = torch.zeros((self.MAX_LAYERS, 64), dtype=torch.float32, device=device)
+            self.scale = torch.ones((self.MAX_LAYERS,), dtype=torch.float32, device=device)
+            self.fmax = torch.full((self.MAX_LAYERS,), 448.0, dtype=torch.float32, device=device)   # e4m3; gradient slots: e5m2
+            self.count = 0
+            self.layers = []
+        i = self.count
+        self.count += 1
+        if i >= self.MAX_LAYERS:
+            raise L.UpsError("more than {} fp8 layers".format(self.MAX_LAYERS))
         return i
 
-    @classmethod
-    def update(cls):
+    def update(self):
         """Next step's activation scales from this step's maxima (layers that did not run keep theirs)."""
-        if cls.amax is None or cls.count == 0:
+        if self.amax is None or self.count == 0:
             return
-        n = cls.count
-        m = cls.amax[:n].amax(dim=1)
-        cls.scale[:n] = torch.where(m > 0, (cls.fmax[:n] * cls.MARGIN) / m.clamp_min(1e-30), cls.scale[:n])
-        cls.amax[:n].zero_()
-        cls.steps += 1
+        n = self.count
+        m = self.amax[:n].amax(dim=1)
+        self.scale[:n] = torch.where(m > 0, (self.fmax[:n] * self.MARGIN) / m.clamp_min(1e-30), self.scale[:n])
+        self.amax[:n].zero_()
+        self.steps += 1
 
-    @classmethod
-    def after_step(cls):
+    def after_step(self):
         """After the optimizer step: new activation scales, e4m3 copies of the updated weights (one launch per layer)."""
-        cls.update()
-        cls.grad_side.clear()          # copies nobody read this step are released (they pinned a gradient-sized tensor each)
-        for lay in cls.layers:
+        self.update()
+        self.grad_side.clear()          # copies nobody read this step are released (they pinned a gradient-sized tensor each)
+        for lay in self.layers:
             for key, tr in (("f8", 0), ("f8g", 1)):
                 ent = lay._cache.get(key)
                 if ent is not None:
                     L.call("ups_weight_prep_f8", L.ptr(lay.V), lay.k * lay.k, lay.cin_v, lay.ci_log, lay.co, tr,
                            L.ptr(ent["w"]), L.ptr(ent["deq"]), L.stream())
                     ent["version"] = WeightVersion.value
-
-    GRAD = True             # input gradients of the fp8 layers on e5m2 operands (False: bf16 kernels)
-    # COPY_ONLY: a layer takes the fp8 kernels only when its operand arrives quantised (a copy written by the producing bilinear /
-    # convolution kernel); layers whose operand would have to be converted inside the kernel (24 staging registers, one block per
-    # CU: slower than bf16, DESIGN 3b) stay on the bf16 kernels.  Follows PRODUCER unless set explicitly.
-    COPY_ONLY = None
-    # fp8 copies handed from layer to layer: the producing convolution's epilogue writes e4m3(act(out) * scale) next to its bf16
-    # output (scale = the delayed scale of that tensor), the consuming convolution stages those bytes without any conversion.
-    # nets.Scope passes the handle along: next_in / next_out_act are set right before ops.conv, last_out is read right after.
-    # UPS_F8_PRODUCER=0 switches the hand-off off (every eligible layer then converts its bf16 operand inside the kernel).
-    PRODUCER = os.environ.get("UPS_F8_PRODUCER", "1") != "0"
-    next_in = None          # {"t": uint8 tensor, "act": UPS_ACT_*, "slot": scale slot} of the coming call's input
-    next_out_act = None     # activation-on-load of the consumer of the coming call's output (None: no copy wanted)
-    last_out = None         # the copy the last call wrote (same dict), or None
-    steps = 0               # update() calls so far (a tensor's copy starts one step after its first maximum was recorded)
-    stats = {"fwd_f8": 0, "fwd_copy_in": 0, "fwd_copy_out": 0, "dgrad_f8": 0, "dgrad_copy_in": 0, "dgrad_copy_out": 0}
-    E5M2_MAX = 57344.0
-
-    grad_side = {}          # data_ptr of a gradient tensor -> (weakref to it, its e5m2 copy): dgrad epilogue -> next dgrad
 
     @staticmethod
     def wanted(site):
@@ -251,9 +260,8 @@ class Fp8(object):
         if site is not None:
             site["used"] = site.get("used", 0) + 1
 
-    @classmethod
-    def copy_only(cls):
-        return cls.PRODUCER if cls.COPY_ONLY is None else cls.COPY_ONLY
+    def copy_only(self):
+        return self.PRODUCER if self.COPY_ONLY is None else self.COPY_ONLY
 
     @staticmethod
     def usable(src, layer, x, ldi):
@@ -261,47 +269,78 @@ class Fp8(object):
         return (src is not None and src.get("t") is not None and src["act"] == layer.act_in and tuple(src["t"].shape) == tuple(x.shape)
                 and layer.co > 32 and ldi % 16 == 0)
 
-    @classmethod
-    def register_grad_copy(cls, t, copy):
+    def register_grad_copy(self, t, copy):
         import weakref
-        if len(cls.grad_side) > 256:
-            cls.grad_side.clear()
+        if len(self.grad_side) > 256:
+            self.grad_side.clear()
         # t._version: the autograd engine's InputBuffer accumulates other branches INTO a buffered gradient in place when it
         # holds the last reference (a weakref does not count as one) -- the same object then arrives holding g1 + g2 while the
         # copy still holds quantised g1; every in-place add bumps the version counter
-        cls.grad_side[t.data_ptr()] = (weakref.ref(t), tuple(t.shape), copy, t._version)
+        self.grad_side[t.data_ptr()] = (weakref.ref(t), tuple(t.shape), copy, t._version)
 
-    @classmethod
-    def grad_copy(cls, g):
+    def grad_copy(self, g):
         """The e5m2 copy of exactly this tensor object, unmodified since the copy was written, or None."""
-        ent = cls.grad_side.pop(g.data_ptr(), None)
+        ent = self.grad_side.pop(g.data_ptr(), None)
         if ent is None or ent[0]() is not g or ent[1] != tuple(g.shape) or ent[3] != g._version:
             return None
         return ent[2]
 
-    @classmethod
-    def reset(cls):
-        """Scale slots, layer list and hand-off state belong to ONE model: a process that builds several (tests, an evaluation
-        sweep) starts each from a clean slate instead of running into MAX_LAYERS or inheriting another model's precision."""
-        cls.amax = cls.scale = cls.fmax = None
-        cls.count, cls.layers, cls.steps = 0, [], 0
-        cls.grad_side.clear()
-        cls.next_in = cls.next_out_act = cls.last_out = None
-        cls.COPY_ONLY = None
-        for k in cls.stats:
-            cls.stats[k] = 0
+    def layer_entry(self, layer, key):
+        """A layer's cached fp8 entry (slot numbers, converted weights) -- only if it was made under THIS state."""
+        ent = layer._cache.get(key)
+        if ent is not None and ent.get("gen") != self.generation:
+            raise L.UpsError("{}: fp8 entry '{}' belongs to another model's Fp8State (generation {} != {}): a layer is being "
+                             "driven while a different model's state is active".format(layer.name, key, ent.get("gen"), self.generation))
+        return ent
 
-    @staticmethod
-    def eligible_grad(layer, g, x):
+    def eligible_grad(self, layer, g, x):
         """Input gradient of a stride-1 3x3 layer on fp8 operands: K = output channels of the forward."""
-        return (Fp8.enabled and Fp8.GRAD and g.dtype == torch.bfloat16 and layer.k == 3 and layer.stride == 1
+        return (self.enabled and self.GRAD and g.dtype == torch.bfloat16 and layer.k == 3 and layer.stride == 1
                 and x.shape[1] % 16 == 0 and x.shape[2] % 16 == 0 and round8(layer.co) % 64 == 0 and layer.ci_log >= 64
                 and g.shape[-1] >= round8(layer.co))
 
-    @staticmethod
-    def eligible(layer, x):
-        return (Fp8.enabled and x.dtype == torch.bfloat16 and layer.k == 3 and layer.stride == 1
+    def eligible(self, layer, x):
+        return (self.enabled and x.dtype == torch.bfloat16 and layer.k == 3 and layer.stride == 1
                 and x.shape[1] % 16 == 0 and x.shape[2] % 16 == 0 and round8(layer.ci_log) % 64 == 0 and layer.co >= 64)
+
+
+class _Fp8Proxy(object):
+    """``ops.Fp8``: attribute access goes to the ACTIVE Fp8State (the running model's; a disabled default otherwise)."""
+
+    def __init__(self):
+        object.__setattr__(self, "_cur", Fp8State(False))
+
+    def activate(self, state):
+        object.__setattr__(self, "_cur", state)
+        return state
+
+    @property
+    def current(self):
+        return object.__getattribute__(self, "_cur")
+
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, "_cur"), name)
+
+    def __setattr__(self, name, value):
+        setattr(object.__getattribute__(self, "_cur"), name, value)
+
+
+Fp8 = _Fp8Proxy()
+
+
+class fp8_scope(object):
+    """``with ops.fp8_scope(enabled=True, copy_only=False) as F:`` -- a fresh Fp8State active inside the block (kernel-level tests,
+    tools), the previous one restored afterwards."""
+
+    def __init__(self, enabled=True, copy_only=None):
+        self.state = Fp8State(enabled, copy_only)
+
+    def __enter__(self):
+        self.prev = Fp8.current
+        return Fp8.activate(self.state)
+
+    def __exit__(self, *a):
+        Fp8.activate(self.prev)
 
 
 class ConvLayer(object):
@@ -390,11 +429,11 @@ class ConvLayer(object):
 
     def prepared_f8_grad(self, g):
         """e4m3 weights of the input-gradient GEMM (rows = input channels, scaled per row) + the gradient tensor's e5m2 scale slot."""
-        ent = self._cache.get("f8g")
+        ent = Fp8.layer_entry(self, "f8g")
         dev = self.V.device
         if ent is None:
             kc = -(-self.co // 64)
-            ent = {"version": -1, "slot": Fp8.slot(dev), "primed": False,
+            ent = {"version": -1, "slot": Fp8.slot(dev), "primed": False, "gen": Fp8.generation,
                    "w": torch.empty((self.k * self.k, kc, self.ci_log, 64), dtype=torch.uint8, device=dev),
                    "deq": torch.empty((self.ci_log,), dtype=torch.float32, device=dev)}
             self._cache["f8g"] = ent
@@ -413,11 +452,11 @@ class ConvLayer(object):
 
     def prepared_f8(self, x):
         """e4m3 weights + per-channel dequantisation factors + this layer's activation-scale slot."""
-        ent = self._cache.get("f8")
+        ent = Fp8.layer_entry(self, "f8")
         dev = self.V.device
         if ent is None:
             kc = -(-self.ci_log // 64)
-            ent = {"version": -1, "slot": Fp8.slot(dev), "primed": False,
+            ent = {"version": -1, "slot": Fp8.slot(dev), "primed": False, "gen": Fp8.generation,
                    "w": torch.empty((self.k * self.k, kc, self.co, 64), dtype=torch.uint8, device=dev),
                    "deq": torch.empty((self.co,), dtype=torch.float32, device=dev)}
             self._cache["f8"] = ent
@@ -519,9 +558,9 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
         d.f8_deq = f8["deq"].data_ptr()
         Fp8.stats["fwd_f8"] += 1
         if Fp8.PRODUCER and want_act is not None and not out_f32 and ldo % 64 == 0 and co_fill == ldo:
-            eo = layer._cache.get("f8o")
+            eo = Fp8.layer_entry(layer, "f8o")
             if eo is None:
-                eo = layer._cache["f8o"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
+                eo = layer._cache["f8o"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps, "gen": Fp8.generation}
             if Fp8.wanted(eo):
                 d.out_f8_amax = Fp8.amax[eo["slot"]].data_ptr()
                 # a post-activation output already holds want_act(out): its copy is the quantisation of the stored value
@@ -653,9 +692,9 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
             elif layer.k == 3 and round8(layer.co) <= 32 and hi % 16 == 0 and wi % 16 == 0:
                 emit = True     # a bf16 launch off the 128-wide two-blocks-per-CU instance (the P-channel head): it can write the copy
             if emit and Fp8.PRODUCER and gx is not None and ldi % 64 == 0 and layer.ci_log == ldi:
-                eo = layer._cache.get("f8go")
+                eo = Fp8.layer_entry(layer, "f8go")
                 if eo is None:
-                    eo = layer._cache["f8go"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
+                    eo = layer._cache["f8go"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps, "gen": Fp8.generation}
                     Fp8.fmax[eo["slot"]] = Fp8.E5M2_MAX
                 if Fp8.wanted(eo):
                     d.out_f8_amax = Fp8.amax[eo["slot"]].data_ptr()
@@ -874,6 +913,31 @@ class BilinearFn(torch.autograd.Function):
         return gx, None, None, None, None, None
 
 
+class CropFn(torch.autograd.Function):
+    """The ho x wo window of an NHWC tensor at the corner held in `yx` (int32 [2] ON THE DEVICE: no host sync, valid inside a
+    captured HIP graph) -- `perceptual_input: resize256_crop224` (Trainer)."""
+
+    @staticmethod
+    def forward(ctx, x, yx, ho, wo):
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        assert yx.dtype == torch.int32 and yx.numel() == 2 and yx.is_cuda
+        y = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+        L.call("ups_crop_fwd", L.ptr(x), L.ptr(y), L.dt(x), n, h, w, c, ho, wo, L.ptr(yx), L.stream())
+        ctx.save_for_backward(yx)
+        ctx.shape = (n, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (yx,) = ctx.saved_tensors
+        n, h, w, c = ctx.shape
+        g = g.contiguous()
+        gx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+        L.call("ups_crop_bwd", L.ptr(g), L.ptr(gx), L.dt(g), n, h, w, c, g.shape[1], g.shape[2], L.ptr(yx), L.stream())
+        return gx, None, None, None
+
+
 class ActMeanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act, slope, post=False):
@@ -1034,9 +1098,9 @@ def part_softmax(mean, eps=None, want_hard=True, want_argmax=False, want_bits=No
     stats = None
     if moments_gamma is not None and mean.dim() == 4 and P <= 32 and want_hard:
         n, h, w, _ = mean.shape
-        nint = L.load().ups_part_softmax_moments_ints(pixels, P)
-        blocks = nint // (P * 5)                                     # = ceil(pixels / tile): whole tiles <=> pixels % blocks == 0
-        if pixels % blocks == 0 and (h * w) % (pixels // blocks) == 0:    # ... and no tile straddles two images
+        # the fused form needs whole pixel tiles that do not straddle two images: the library says what its tile is
+        if (h * w) % L.load().ups_part_softmax_moments_tile(P) == 0:
+            nint = L.load().ups_part_softmax_moments_ints(pixels, P)
             stats = torch.empty((n, P, 8), dtype=torch.float32, device=mean.device)
             scratch = torch.empty(nint, dtype=torch.int32, device=mean.device)
             L.call("ups_part_softmax_moments_fwd", L.ptr(mean), L.ptr(eps.contiguous()) if eps is not None else None,
