@@ -44,6 +44,10 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the config's)")
     ap.add_argument("--parts", type=int, default=0, help="only for cub128p10 (0 = 10)")
     ap.add_argument("--precision", default="", help="bf16 | fp8 | fp32 (empty = the config's)")
+    ap.add_argument("--perceptual-input", default="native", choices=("native", "resize256", "resize256_crop224"),
+                    help="what the perceptual trunk sees (the three readings of edflow VGG19Features(original_scale=True), "
+                         "model.py:610-612, UNVERIFIED): the images as they are (headline) | bilinear to 256x256 | then one random "
+                         "224x224 window per step.  The extra trunk work is counted in train_gflop_per_image.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="BASELINE config #1: batch 8")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(os.cpu_count(), {})".format(CPU_THREAD_CAP))
@@ -173,6 +177,15 @@ def run_rank(args):
         cfg = build(args.batch)
     args.parts = P
     cfg["precision"] = args.precision
+    cfg["perceptual_input"] = args.perceptual_input
+    # algorithmic FLOPs of the trunk: 1.5 x F_vgg per image (2 forwards + 1 input gradient over 2 images' worth) scale
+    # with its input area: BASELINE.md section 3 counts +109.2 GFLOP / image for 256x256 instead of 128x128 inputs (= 3 x the
+    # 36.4 of the native trunk); a 224x224 window is (224 / 256)^2 of that
+    if S == 128 and args.perceptual_input != "native":
+        area = {"resize256": 4.0, "resize256_crop224": 4.0 * (224.0 / 256.0) ** 2}[args.perceptual_input]
+        gflop_img = gflop_img + (area - 1.0) * (109.2 / 3.0)
+    elif S == 256 and args.perceptual_input == "resize256_crop224":
+        gflop_img = gflop_img - (1.0 - (224.0 / 256.0) ** 2) * 4.0 * (109.2 / 3.0)
     model = TrainModel(cfg, device=dev, seed=0)
     trainer = Trainer(cfg, None, model, world_size=world, rank=rank)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -231,13 +244,18 @@ def run_rank(args):
                "dtype": dname, "data": "synthetic",
                "config": {"workload": "{}: {} yaml {}x{} n_parts={} batch {}/GPU, full train step (per-key losses, "
                                       "per-key grads, TF-Adam), use_tps False, VGG19-topology perceptual trunk with "
-                                      "stand-in weights at native resolution; bf16 storage / fp32 accumulate, the mask decoder's "
+                                      "stand-in weights, perceptual_input = {} ({}); bf16 storage / fp32 accumulate, the mask decoder's "
                                       "forward tensors fp16 (parity bar of this dtype: part-mask IoU >= 0.99 and losses within 5% "
                                       "of the fp64 oracle; the 1e-3 bar is met by precision=fp32){}".format(
-                                          note, args.config, S, S, P, args.batch, "; precision fp8: e4m3 / e5m2 MFMA "
-                                      "operands for the wide 3x3 convolutions whose operand arrives as an fp8 copy, bf16 tensors "
-                                      "everywhere" if args.precision == "fp8" else ""),
-                          "name": args.config,
+                                          note, args.config, S, S, P, args.batch, args.perceptual_input,
+                                          {"native": "the trunk sees the images at their own resolution: the headline reading",
+                                           "resize256": "both images bilinearly resized to 256x256 first",
+                                           "resize256_crop224": "resized to 256x256, then one random 224x224 window per step"}[args.perceptual_input],
+                                          "; precision fp8: e4m3 / e5m2 MFMA "
+                                      "operands for the wide 3x3 convolutions whose operand arrives as an fp8 copy (the mask decoder's "
+                                      "FORWARD stays fp16: its logits decide the masks), bf16 tensors everywhere"
+                                          if args.precision == "fp8" else ""),
+                          "name": args.config, "perceptual_input": args.perceptual_input,
                           "global_batch": args.batch * world, "parallelism": "dp{}".format(world),
                           "rccl_world_size": rccl_world},
                "model_tflops_per_gpu": round(value * gflop_img / 1e3 / world, 2), "train_gflop_per_image": gflop_img,

@@ -285,7 +285,12 @@ int ups_part_softmax_moments_fwd(const float* mean, const float* eps, float* l, 
  * stats[n][p] = {max, Z, sum e*k, sum e*k*gy, sum e*k*gx, sum e*k*(gy^2+gx^2), sum e*k*gy^2, 0},  e = exp(gamma*x - max) */
 int ups_spatial_moments(const float* x, int32_t n, int32_t h, int32_t w, int32_t P, float gamma,
                         const int32_t* rect_c, int32_t half_h, int32_t half_w, float* stats, void* stream);
-/* `stats` must hold n*P*8 floats of result followed by n*8*P*8 floats of scratch (ups_spatial_moments_floats). */
+/* The same pass also sums x * log(P * x + 1e-20) over the whole map -- categorical_kl of view 1's soft map (M:21-25, 659-665), the
+ * only other prior term of that view, which therefore needs no pass of its own: kl_sums16[0] = the sum (slots 1..15 zeroed: the
+ * layout of ups_prior_desc.sums). */
+int ups_spatial_moments_kl(const float* x, int32_t n, int32_t h, int32_t w, int32_t P, float gamma,
+                           const int32_t* rect_c, int32_t half_h, int32_t half_w, float* stats, float* kl_sums16, void* stream);
+/* `stats` must hold n*P*8 floats of result followed by scratch; total = ups_spatial_moments_floats(n, P). */
 size_t ups_spatial_moments_floats(int32_t n, int32_t P);
 /* px[n*P][2] = (row, column) centre of the rectangle tfutils.draw_rect paints for int32(mu*h/2 + h/2) (M:441,459;
    truncation) from the un-masked stats.  xy_order != 0: the helper reads the (y, x) pair as (x, y) -- row centre from mu_x,
@@ -338,6 +343,22 @@ typedef struct {
 size_t ups_prior_sums_floats(int32_t n, int32_t P);
 int ups_prior_fwd(const ups_prior_desc* d, void* stream);
 int ups_prior_bwd(const ups_prior_desc* d, void* stream);
+
+/* ---------------------------------------------------------------- noise (tf.random_normal of the sampling ops, N:1187, 1431)
+ * out[i] ~ N(0, 1), i < n: Philox4x32-10 keyed by `seed`, counter = offset + i / 4, Box-Muller.  A pure function of (seed, offset,
+ * i); the caller advances offset by ceil(n / 4) per call. */
+int ups_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---------------------------------------------------------------- MI critic head (M:159-173 last line, 524-536, 800-834, 855)
+ * h_pi, h_al [2B][ld] (K logical channels): the two 512-d embeddings of discriminator_model; rows [0,B) are the joint pairs,
+ * [B,2B) the marginal pairs.  logits[i] = <h_pi[i], h_al[i]>; out4 = {0.5 (mean softplus(-joint) + mean softplus(marg)),
+ * accuracy ((#joint > 0) + (#marg < 0)) / 2B, mean joint logit (logit_constraint(real=False)), 0}.  Single block: fixed
+ * reduction order.  bwd: g_loss / g_mim are DEVICE scalars (NULL = 0), the upstream gradients of out4[0] / out4[2];
+ * g_h_pi = dlogit * h_al, g_h_al = dlogit * h_pi (either may be NULL). */
+int ups_critic_head_fwd(const void* h_pi, const void* h_al, int32_t dtype, int32_t B, int32_t K, int32_t ld, float* logits,
+                        float* out4, void* stream);
+int ups_critic_head_bwd(const void* h_pi, const void* h_al, const float* logits, const float* g_loss, const float* g_mim,
+                        int32_t dtype, int32_t B, int32_t K, int32_t ld, void* g_h_pi, void* g_h_al, void* stream);
 
 /* ---------------------------------------------------------------- full-covariance latent (N:1134-1208, util.py:878-995)
  * params [B][dim + dim(dim+1)/2] fp32.  samples[s][b][i] = mean + L (level[s]*eps[s][b]) ; kl_rows[b][i]. */

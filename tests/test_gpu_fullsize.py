@@ -149,8 +149,9 @@ def test_full_width_step_fp32_matches_oracle_fixture(dev, mode):
                                             ("cub256p20", "bf16"), ("cub256p20", "fp8")])
 def test_full_width_step_bf16_mask_iou(dev, mode, precision):
     """The benchmark's dtype at the benchmark's widths -- and at the widths / sizes of the other BASELINE configs; config #5 (CUB
-    256x256, 20 parts) also with the fp8 forward: part-mask IoU vs the fp64 oracle >= 0.99 (north_star), losses within 5 %
-    (fp8: IoU >= 0.98, losses within 10 %)."""
+    256x256, 20 parts) also in fp8 mode: part-mask IoU vs the fp64 oracle >= 0.99 (north_star) in EVERY mode -- since round 4 the
+    mask decoder's forward stays fp16 under `precision: fp8` (nets.Nets), so the masks are the bf16 mode's --, losses within 5 %
+    (fp8: 10 %: decoder_delta's forward runs on e4m3 operands)."""
     z = np.load(os.path.join(GOLD, FIXTURES[mode]))
     # fp8, one step only: no producer has a delayed scale yet, so let every eligible layer convert in the kernel
     cfg, model, trainer, views, noise = _trainer(dev, precision, mode, **({"fp8_copy_only": False} if precision == "fp8" else {}))
@@ -161,7 +162,7 @@ def test_full_width_step_bf16_mask_iou(dev, mode, precision):
     print("{} {}: part-mask IoU vs oracle {:.4f} / {:.4f}".format(mode, precision, iou0, iou1))
     if precision == "fp8":
         assert model.fp8.count > 0 and model.fp8.stats["fwd_f8"] > 0 and model.fp8.stats["dgrad_f8"] > 0
-    bar, tol = (0.98, 0.10) if precision == "fp8" else (0.99, 0.05)
+    bar, tol = (0.99, 0.10) if precision == "fp8" else (0.99, 0.05)
     assert min(iou0, iou1) >= bar, "{} part-mask IoU vs oracle: {} / {}".format(precision, iou0, iou1)
     for k in losses:
         lo, lh = float(z["loss_" + k]), float(losses[k])
@@ -189,8 +190,8 @@ def test_full_width_confident_masks_iou(dev, precision):
     north_star's bar on both mask outputs: mean per-part IoU >= 0.99 noise-free (out_parts_hard, M:469-470) AND sampled.
     "bf16-pure" (bf16 in the mask decoder as well, the round-2 configuration) documents why: 0.7 % logit error after its ~15
     layers, pixel agreement 0.995 but mean per-part IoU 0.93 - 0.97 (small parts weigh as much as large ones); held to 0.9.
-    fp8 (BASELINE config #5's arithmetic at config #2's size: e4m3 forward of the wide 3x3 convolutions) is reported the same
-    way and held to the agreement its 2^-4 operand resolution allows (pixels >= 0.95, mean per-part IoU >= 0.8)."""
+    fp8 (BASELINE config #5's arithmetic at config #2's size) is held to the SAME bars as bf16 since round 4: its mask decoder's
+    forward is fp16 too (round 3 ran it on e4m3 operands: pixels 0.979, IoU 0.90), fp8 operands go where error is tolerated."""
     import sys
     sys.path.insert(0, GOLD)
     import make_golden_full as G
@@ -214,7 +215,7 @@ def test_full_width_confident_masks_iou(dev, precision):
         precision, iou_mean, agree, iou_s))
     if precision == "fp8":
         assert model.fp8.count > 0 and model.fp8.stats["fwd_f8"] > 0, "no layer took the fp8 path"
-        assert agree >= 0.95 and iou_mean >= 0.8 and iou_s >= 0.8, (agree, iou_mean, iou_s)     # measured 0.979 / 0.90 / 0.92
+        assert agree >= 0.995 and iou_mean >= 0.99 and iou_s >= 0.99, (agree, iou_mean, iou_s)
     elif precision == "bf16":
         assert agree >= 0.995 and iou_mean >= 0.99 and iou_s >= 0.99, (agree, iou_mean, iou_s)
     elif precision == "bf16-pure":
@@ -228,7 +229,7 @@ def test_full_width_confident_masks_iou(dev, precision):
 def test_bench_configs_at_full_batch(dev, name, fixture):
     """Every `bench.py --config` workload at its FULL per-GPU batch and precision (BASELINE configs #2 - #5): one training step,
     all losses finite, and -- size-independent property: samples are independent in the forward pass -- the leading samples,
-    which carry the fixture's views and noise, reproduce the fixture's part masks (IoU >= 0.99; fp8: >= 0.98) inside the
+    which carry the fixture's views and noise, reproduce the fixture's part masks (IoU >= 0.99, fp8 mode included) inside the
     large batch."""
     import upsparts_amd  # noqa: F401
     from upsparts_amd import configs, ops
@@ -247,6 +248,7 @@ def test_bench_configs_at_full_batch(dev, name, fixture):
     model = TrainModel(cfg, device=dev, seed=0)
     trainer = Trainer(cfg, None, model)
     views = {k: torch.rand(B, S, S, 3, generator=g) * 2 - 1 for k in model.inputs}
+    noise_f = {k: v for k, v in noise_f.items() if k != "crop_yx"}      # (per-step window corner of one perceptual mode: not per sample)
     noise = {k: torch.randn((v.shape[0], B) + tuple(v.shape[2:]) if k == "eps_pi0" else (B,) + tuple(v.shape[1:]), generator=g)
              for k, v in noise_f.items()}
     for k in views:
@@ -262,7 +264,7 @@ def test_bench_configs_at_full_batch(dev, name, fixture):
         assert np.isfinite(float(v)), "{}: loss {} = {}".format(name, k, float(v))
     iou0, iou1 = _iou(hard[:bf], z["hard0_argmax"], P), _iou(hard[B:B + bf], z["hard1_argmax"], P)
     print("{} B={} {}: part-mask IoU of the fixture samples inside the batch {:.4f} / {:.4f}".format(name, B, prec, iou0, iou1))
-    assert min(iou0, iou1) >= (0.98 if prec == "fp8" else 0.99), (iou0, iou1)
+    assert min(iou0, iou1) >= 0.99, (iou0, iou1)
 
 
 @pytest.mark.parametrize("batch", [8])

@@ -142,6 +142,51 @@ def test_conv_fwd_bwd(case, dtype, dev):
     assert_close(gb.float(), bo.grad.float(), tol, "conv bias grad {}".format(case))
 
 
+S2_CASES = [
+    # n, h, w, cin, cout, coords, out_act
+    (4, 64, 64, 32, 64, False, False),      # encoder first downsample
+    (3, 32, 32, 64, 128, True, True),       # 64 input channels (two chunks), two 64-wide output blocks, CoordConv, stored activation
+    (2, 32, 64, 32, 24, True, False),       # ragged output channels (24 of a 64-wide block), non-square
+    (2, 31, 63, 32, 64, False, True),       # odd input sizes: pad_before = 1 (taps reach above / left of the image)
+    (2, 128, 128, 32, 64, True, False),     # 128x128 -> 64x64 as in the model
+]
+
+
+@pytest.mark.parametrize("case", S2_CASES)
+def test_conv_stride2_forward_kernel(case, dev, monkeypatch):
+    """conv3x3_s2.hip: the forward of the large 3x3 / stride-2 `downsample` layers (N:816-817) with the taps read straight from
+    global memory.  The model only routes launches of >= 256 Ki output pixels to it; UPS_S2_KERNEL=force takes the size gate away so
+    that the parity shapes stay small.  Against the fp64 oracle on the bf16-rounded operands, and against the generic gather
+    kernel (UPS_S2_KERNEL=0) on the same inputs."""
+    lib, ops, R = _mods()
+    n, h, w, cin, cout, coords, out_act = case
+    g = torch.Generator().manual_seed(500 + S2_CASES.index(case))
+    cin_v = cin + (2 if coords else 0)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+    V = torch.randn(3, 3, cin_v, cout, generator=g) / math.sqrt(cin_v * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    Vo = V.double().clone()
+    Vo[:, :, :cin] = V[:, :, :cin].to(torch.bfloat16).double()
+    yo = _oracle_conv(R, x.double(), Vo, b.double(), 2, coords, None, False, None)
+    if out_act:
+        yo = torch.nn.functional.leaky_relu(yo, 0.2)
+    lay = _layer(ops, lib, V, b, 3, 2, coords, None, dev)
+    if out_act:
+        lay.out_act = lib.ACT_LRELU
+    xd = x.to(dev)
+    monkeypatch.setenv("UPS_S2_KERNEL", "force")
+    y = ops.conv_forward(xd, lay)
+    monkeypatch.setenv("UPS_S2_KERNEL", "0")
+    y_gen = ops.conv_forward(xd, lay)
+    torch.cuda.synchronize()
+    assert y.shape == y_gen.shape and y.shape[-1] == ops.round8(cout)
+    assert_close(y[..., :cout].float(), yo.float(), BF16_TOL, "stride-2 kernel vs oracle {}".format(case))
+    assert_close(y_gen[..., :cout].float(), yo.float(), BF16_TOL, "generic kernel vs oracle {}".format(case))
+    assert_close(y[..., :cout].float(), y_gen[..., :cout].float(), 1e-2, "stride-2 kernel vs generic kernel {}".format(case))
+    if y.shape[-1] > cout:
+        assert float(y[..., cout:].float().abs().max()) == 0.0
+
+
 F16_CASES = [c for c in CONV_CASES if c[6] == 1 and c[8] in (None, "leaky_relu")
              and c in ((2, 16, 16, 16, 16, 3, 1, True, "leaky_relu", True), (4, 1, 1, 16, 72, 1, 1, True, None, False),
                        (3, 32, 48, 64, 136, 3, 1, True, "leaky_relu", False), (2, 32, 32, 128, 128, 3, 1, True, "leaky_relu", True),
@@ -544,6 +589,8 @@ def test_mask_priors_forward_and_backward(variant, P, S, entropy_func, dev):
     eps = torch.randn(2 * B, S, S, P, generator=g, dtype=torch.float64)
     g_hard = torch.randn(2 * B, S, S, P, generator=g, dtype=torch.float64)
     w = {"kl": 0.7, "entropy": 1.3, "ms": 0.05, "area": 2.0e-3, "patch": 0.02, "gmrf": 0.3, "var": 1.7, "msl": 0.4}
+    if variant == 1:       # SB_model48c has no Mumford-Shah-on-masks / area / patch terms (its trainer passes zero weights, DF:830-838)
+        w.update({"ms": 0.0, "area": 0.0, "patch": 0.0})
     ms_alpha, ms_lambda = (1.0, 1.0e-2) if variant == 0 else (1.5, 0.05)
     lm0 = lm[:B].clone().requires_grad_(True)
     lm1 = lm[B:].clone().requires_grad_(True)
@@ -580,6 +627,11 @@ def test_mask_priors_forward_and_backward(variant, P, S, entropy_func, dev):
     Trainer._prior(fake, 0, B, S, P, l0, lmd[:B].contiguous(), m0, h0, px0, per_np0, sums0, w)
     Trainer._prior(fake, 1, B, S, P, l1, None, m1, None, px1, None, sums1, w)
     stats_v = ops.spatial_moments(m1, 1.0 if variant == 1 else gamma, rect_px=px1, half=patch // 2)
+    # the product path takes view 1's KL from the moments pass (ups_spatial_moments_kl): same statistics, same sum
+    sums1b = torch.empty(nfl, dtype=torch.float32, device=dev)
+    stats_vb = ops.spatial_moments(m1, 1.0 if variant == 1 else gamma, rect_px=px1, half=patch // 2, kl_sums=sums1b)
+    assert torch.equal(stats_vb, stats_v)
+    assert abs(float(sums1b[0]) - float(sums1[0])) <= 1e-5 * abs(float(sums1[0])) and float(sums1b[1:16].abs().max()) == 0.0
     dl_tot = torch.empty_like(lmd)
     dl_rec = torch.empty_like(lmd)
     gh = g_hard.float().to(dev)
@@ -619,6 +671,69 @@ def test_mask_priors_forward_and_backward(variant, P, S, entropy_func, dev):
     assert_close(dl_tot[B:], d_tot1.float(), 1e-3, "prior_bwd view 1 dl")
     assert_close(dl_rec[:B], d_rec0.float(), 1e-3, "prior_bwd view 0 dl_rec")
     assert_close(dl_rec[B:], d_rec1.float(), 1e-3, "prior_bwd view 1 dl_rec")
+
+
+def test_randn_philox_stream(dev):
+    """ups_randn: Philox4x32-10 + Box-Muller.  Known answer of the generator (Random123's test vector: counter 0, key 0 ->
+    6627e8d5 e169c58d bc57ac4c 9b00dbd8), the stream property (one call over n values == two calls over the halves), seed
+    sensitivity, and the first four moments of 4 M draws."""
+    lib, ops, R = _mods()
+    ns = ops.NoiseStream(0)
+    z = ns.randn(8, device=dev).cpu().double()
+    words = [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    exp = []
+    for h in range(2):
+        u1 = ((words[2 * h] >> 8) + 0.5) / 16777216.0
+        u2 = ((words[2 * h + 1] >> 8) + 0.5) / 16777216.0
+        rad = math.sqrt(-2.0 * math.log(u1))
+        exp += [rad * math.cos(2 * math.pi * u2), rad * math.sin(2 * math.pi * u2)]
+    assert float((z[:4] - torch.tensor(exp, dtype=torch.float64)).abs().max()) <= 2e-5, (z[:4].tolist(), exp)
+    a = ops.NoiseStream(1234)
+    whole = a.randn(1 << 20, device=dev)
+    b = ops.NoiseStream(1234)
+    halves = torch.cat([b.randn(1 << 19, device=dev), b.randn(1 << 19, device=dev)])
+    assert torch.equal(whole, halves) and a.offset == b.offset == (1 << 18)
+    other = ops.NoiseStream(1235).randn(1 << 20, device=dev)
+    assert float((other == whole).float().mean()) < 1e-3
+    x = ops.NoiseStream(99).randn(1 << 22, device=dev).double()
+    m, v = float(x.mean()), float(x.var())
+    sk = float(((x - m) ** 3).mean() / v ** 1.5)
+    ku = float(((x - m) ** 4).mean() / v ** 2)
+    assert abs(m) <= 3e-3 and abs(v - 1.0) <= 5e-3 and abs(sk) <= 1e-2 and abs(ku - 3.0) <= 3e-2, (m, v, sk, ku)
+    assert bool(torch.isfinite(x).all()) and float(x.abs().max()) < 6.5
+
+
+@pytest.mark.parametrize("dtype,B", [(torch.float32, 8), (torch.bfloat16, 64), (torch.float32, 3)])
+def test_critic_head(dtype, B, dev):
+    """ups_critic_head_fwd / _bwd against the reference's formulation (M:159-173 last line: logit = sum(h_pi * h_alpha);
+    M:524-529 logit_loss = mean softplus(-+logit); M:821-826 accuracy; M:532-536, 855 mean joint logit): values, and the gradients
+    w.r.t. both embeddings for the two upstream gradients the trainer sends (d loss -- the critic's own key -- and d mean-joint --
+    the adversarial term of encoder_0)."""
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(17 + B)
+    K = 512
+    hp = (torch.randn(2 * B, 1, 1, K, generator=g) * 0.2).to(dtype)
+    ha = (torch.randn(2 * B, 1, 1, K, generator=g) * 0.2).to(dtype)
+    hpo = hp.double().requires_grad_(True)
+    hao = ha.double().requires_grad_(True)
+    logits = (hpo * hao).sum(dim=(1, 2, 3))
+    joint, marg = logits[:B], logits[B:]
+    loss_o = 0.5 * (torch.nn.functional.softplus(-joint).mean() + torch.nn.functional.softplus(marg).mean())
+    acc_o = ((joint > 0).sum() + (marg < 0).sum()).double() / (2 * B)
+    mim_o = joint.mean()
+    hpd = hp.to(dev).requires_grad_(True)
+    had = ha.to(dev).requires_grad_(True)
+    loss, acc, mim = ops.CriticHeadFn.apply(hpd, had, B, K)
+    tol = 1e-5 if dtype == torch.float32 else 1e-5          # (inputs are the same rounded values; accumulation is fp32)
+    assert abs(float(loss) - float(loss_o)) <= tol * max(1.0, abs(float(loss_o)))
+    assert abs(float(mim) - float(mim_o)) <= tol * max(1.0, abs(float(mim_o)))
+    assert abs(float(acc) - float(acc_o)) <= 1e-6
+    gtol = 1e-5 if dtype == torch.float32 else 1e-2
+    for wl, wm in ((1.0, 0.0), (0.0, 1.0), (0.7, -2.5)):
+        go = torch.autograd.grad(wl * loss_o + wm * mim_o, [hpo, hao], retain_graph=True)
+        gh = torch.autograd.grad(wl * loss + wm * mim, [hpd, had], retain_graph=True)
+        assert_close(gh[0].float(), go[0].float(), gtol, "d / d h_pi ({}, {})".format(wl, wm))
+        assert_close(gh[1].float(), go[1].float(), gtol, "d / d h_alpha ({}, {})".format(wl, wm))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -83,8 +83,12 @@ def test_train_step_fp32_matches_oracle(dev, variant, size):
         for k in log_keys:
             lo = float(log[k])
             assert abs(lo - logs[k]) <= 1e-3 * max(1e-6, abs(lo)) + 1e-9, "log {}: oracle {} hip {}".format(k, lo, logs[k])
-        for n, g in grads.items():        # three bars each: max-norm, RMS and element-wise on the channel's own scale (util.py)
-            assert_close(model.bank.grads[n], g.float(), 2e-3, "gradient {} (step {})".format(n, step))
+        # three bars each: max-norm, RMS and element-wise on the channel's own scale (util.py).  The element-wise bar holds for the
+        # FIRST step (identical weights on both sides); after an Adam update the two sides' weights differ by up to +-lr on elements
+        # whose gradient is ~0 (Adam normalises it: see the parameter check below), which the second step's gradients inherit
+        # element by element -- there the max-norm and RMS bars stand
+        for n, g in grads.items():
+            assert_close(model.bank.grads[n], g.float(), 2e-3, "gradient {} (step {})".format(n, step), elementwise=step == 0)
         # Adam normalises the gradient (m / (sqrt(v) + eps)), so an element whose gradient is ~0 can move by up to
         # +-lr_t with either sign: compare updates in units of the learning rate, not relative to |param|.
         lr = cfg["lr"]
@@ -115,10 +119,13 @@ def test_train_step_bf16_close_to_oracle(dev, variant, size):
         assert abs(lo - lh) <= 5e-2 * max(1.0, abs(lo)), "loss {}: oracle {} hip(bf16) {}".format(k, lo, lh)
 
 
-def test_fp8_step_tracks_bf16(dev):
-    """precision: fp8 (BASELINE config #5): forward of the wide 3x3 / stride-1 convolutions on e4m3 MFMA operands with delayed
-    activation scaling.  Three training steps from the same initial weights as a bf16 run: every loss stays within 10 % and the
-    sampled part masks agree on >= 95 % of the pixels; the fp8 layers are re-quantised after each optimizer step."""
+@pytest.mark.parametrize("mask_decoder", ["fp16", "same"])
+def test_fp8_step_tracks_bf16(dev, mask_decoder):
+    """precision: fp8 (BASELINE config #5): wide 3x3 / stride-1 convolutions on e4m3 / e5m2 MFMA operands with delayed scaling.
+    Three training steps from the same initial weights as a bf16 run: every loss stays within 10 % and the sampled part masks
+    agree on >= 95 % of the pixels; the fp8 layers are re-quantised after each optimizer step.  "fp16" = the mode's default since
+    round 4 (the mask decoder's FORWARD stays fp16, its two input-gradient passes run on e5m2 copies: masks as in bf16 mode);
+    "same" = the round-3 form (that forward on e4m3 copies too), which keeps the forward hand-off covered."""
     import upsparts_amd  # noqa: F401
     from upsparts_amd import ops
     from upsparts_amd.model import TrainModel, Trainer
@@ -132,6 +139,7 @@ def test_fp8_step_tracks_bf16(dev):
     for prec in ("bf16", "fp8"):
         c = copy.deepcopy(cfg)
         c["precision"] = prec
+        c["mask_decoder_dtype"] = mask_decoder
         model = TrainModel(c, device=dev, seed=0)
         trainer = Trainer(c, None, model)
         out = []
@@ -142,7 +150,9 @@ def test_fp8_step_tracks_bf16(dev):
         if prec == "fp8":
             F = model.fp8
             assert F.count >= 4, "fp8 layers used: {}".format(F.count)
-            assert F.stats["fwd_copy_in"] > 0 and F.stats["dgrad_copy_in"] > 0, F.stats    # copies were handed on
+            assert F.stats["dgrad_copy_in"] > 0 and F.stats["dgrad_f8"] > 0, F.stats                  # gradient copies were handed on
+            if mask_decoder == "same":
+                assert F.stats["fwd_copy_in"] > 0, F.stats                                            # ... and forward copies
             scales = F.scale[:F.count].cpu()
             assert bool(torch.isfinite(scales).all()) and float(scales.min()) > 0
             assert all(l._cache[k]["version"] == ops.WeightVersion.value for l in F.layers for k in ("f8", "f8g") if k in l._cache)
@@ -151,7 +161,7 @@ def test_fp8_step_tracks_bf16(dev):
             vf = runs["fp8"][0][step][k]
             assert abs(vb - vf) <= 0.1 * max(1.0, abs(vb)), "step {} loss {}: bf16 {} fp8 {}".format(step, k, vb, vf)
     agree = float(((runs["bf16"][1] > 0) == (runs["fp8"][1] > 0)).float().mean())
-    assert agree >= 0.95, agree
+    assert agree >= (0.99 if mask_decoder == "fp16" else 0.95), agree
 
 
 def test_inference_outputs(dev):
@@ -443,3 +453,62 @@ def test_reference_log_state_trajectory(dev):
             pad = 0.006 if k != "lor" else 0.06
             print("{} @ step {}: reference {:.5f}, restatement [{:.5f}, {:.5f}]".format(k, s, want, lo, hi))
             assert lo - pad <= want <= hi + pad, "{} at step {}: reference {} outside [{}, {}] +- {}".format(k, s, want, lo, hi, pad)
+
+
+def test_reference_log_mask_statistics_conditional_pin(dev):
+    """Round 4 (tools/pin_log.py, profiles/round4_pin_log_*.txt).  The reference's log holds the mask
+    statistics at their random-init values through global step 32; the restated trainer moves them within two steps.  The sweep
+    over what the log does not record -- one image for all three views (the logged csv setting) vs independent views, smooth /
+    i.i.d. / 1-over-f textures, TPS on / off, the g vs g - 1 alignment of the logged state -- closes NONE of it (`mask0_kl` >= 2.5
+    at steps 2-4 in all 24 cells), and neither does removing the reconstruction term from decoder_visualize's gradient (the priors
+    alone drive it).  ONE thing does: decoder_visualize stepping 10-30x slower than Adam(lr) moves it.  This test states that
+    finding as an executable fact -- with the mask decoder's step scaled by 0.03 on the logged run's data setting, EVERY quantity
+    the log prints at global steps 2, 4, 8, 16, 32 lies in a window around the logged value:
+      mask0_kl, weakly_superv_loss_p, patch_loss, variance_loss: inside the logged run's own range over steps 0..32 (+- its spread);
+      prior_gmrf: inside [100, 360] (logged 115 ... 344);
+      bottleneck_loss (encoder_0's KL: an independent check of the encoder's optimizer wiring): within 25 % at steps 2-16 (the
+      seeds' own spread at step 8 is +-20 %; their mean tracks the log to 3 %).
+    It is a CONDITIONAL pin: it says the rest of the restated graph / optimizer reproduces the log once the mask decoder is slow,
+    not why the reference's was (gradient-magnitude intermittency on real images under Adam's second-moment estimate, or an
+    edflow optimizer detail: the source is absent).  The product path keeps plain Adam(lr) on every key."""
+    import importlib.util
+    import os
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import configs, ops
+    from upsparts_amd.model import TrainModel, Trainer
+    spec = importlib.util.spec_from_file_location("pin_log", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                          "tools", "pin_log.py"))
+    pin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin)
+    steps = (2, 4, 8, 16, 32)
+    idx = {s: pin.STEPS.index(s) for s in steps}
+    windows = {"mask0_kl": (0.85, 1.15), "weakly_superv_loss_p": (2.60, 2.80), "patch_loss": (15050.0, 15350.0),
+               "variance_loss": (16.3, 17.0), "prior_gmrf": (100.0, 360.0)}
+    for k, (lo, hi) in windows.items():          # the windows contain the reference's own values at these steps
+        assert all(lo <= pin.REF[k][idx[s]] <= hi for s in steps), k
+    orig_adam = ops.adam_step
+    try:
+        for seed in range(3):
+            cfg = copy.deepcopy(configs.cub_config(n_parts=25, batch_size=8, use_tps=True))
+            cfg.update({"precision": "bf16", "noise_seed": 4321 + seed})
+            model = TrainModel(cfg, device=dev, seed=seed)
+            tr = Trainer(cfg, None, model)
+            dv_p = model.bank.groups["decoder_visualize"]["flat"]["p"]
+
+            def adam(p, g, m, v, lr_t, *a, _dv=dv_p, **kw):
+                return orig_adam(p, g, m, v, lr_t * 0.03 if p.data_ptr() == _dv.data_ptr() else lr_t, *a, **kw)
+            ops.adam_step = adam
+            for s in range(32):
+                batch = {k: v.to(dev) for k, v in pin.make_views("same", "pink", 8, 128, 1000 * seed + s).items()}
+                tr.train_step(batch)
+                g_step = s + 1                       # the logged state at global step g carries g - 1 updates (DESIGN section 5)
+                if g_step in steps:
+                    lg = tr.fetch_logs()
+                    for k, (lo, hi) in windows.items():
+                        assert lo <= lg[k] <= hi, "seed {} global step {}: {} = {} outside [{}, {}] (logged {})".format(
+                            seed, g_step, k, lg[k], lo, hi, pin.REF[k][idx[g_step]])
+                    if g_step <= 16:
+                        want = pin.REF["bottleneck_loss"][idx[g_step]]
+                        assert abs(lg["bottleneck_loss"] - want) <= 0.25 * want, (seed, g_step, lg["bottleneck_loss"], want)
+    finally:
+        ops.adam_step = orig_adam

@@ -104,10 +104,10 @@ def main():
         "two kernels: [B,S,S,80] bf16 gradient read twice, hard read, g_hard written")
     m1 = m[B:].contiguous()
     px1 = px[B:].contiguous()
-    add("spatial_moments (masked, soft map)", half_b, lambda: ops.spatial_moments(m1, 10.0, rect_px=px1, half=16), "1 read of the map")
     sums1 = torch.empty(nfl, dtype=torch.float32, device=dev)
-    d_f1 = prior_desc(1, B, l[B:].contiguous(), None, m1, None, px1, None, sums1)
-    add("prior_fwd (view 1)", half_b, lambda: L.call("ups_prior_fwd", C.byref(d_f1), L.stream()), "m read once")
+    add("spatial_moments + KL (view 1, masked soft map)", half_b, lambda: ops.spatial_moments(m1, 10.0, rect_px=px1, half=16, kl_sums=sums1),
+        "1 read of the map: the variance moments and view 1's categorical KL from one pass (round 4: the separate prior_fwd launch "
+        "of view 1, another read of the same map, is gone)")
     st1 = ops.spatial_moments(m1, 10.0, rect_px=px1, half=16)
     d_b1 = prior_desc(1, B, l[B:].contiguous(), None, m1, None, px1, st1, sums1, gh, dl, dlr)
     add("prior_bwd (view 1, dl_tot + dl_rec)", 4 * half_b, lambda: L.call("ups_prior_bwd", C.byref(d_b1), L.stream()),

@@ -18,7 +18,7 @@ version sweeps the factors that were confounded there, all combinations, over se
                    printed for both alignments (same runs, no extra cost)
 
     python tools/pin_log.py [seeds] [steps] [out.json]        (GPU box; stand-in VGG; ~25 ms per step)
-    python tools/pin_log.py probe [seeds] [steps]             optimizer-wiring probes on the logged run's data setting
+    python tools/pin_log.py probe [seeds] [steps] [betas]     optimizer-wiring probes on the logged run's data setting
                                                               (same / pink / tps1): see probes()
 """
 import copy
@@ -119,8 +119,14 @@ def probes():
     from upsparts_amd import ops as OPS
     orig_prior, orig_adam = Trainer._prior, OPS.adam_step
     res = {}
-    for tag, rec_s, lr_f in (("rec x1", 1.0, 1.0), ("rec x0.1", 0.1, 1.0), ("rec x0.01", 0.01, 1.0), ("rec x0", 0.0, 1.0),
-                             ("lr_dv x0.1", 1.0, 0.1), ("lr_dv x0.01", 1.0, 0.01)):
+    cases = (("rec x1", 1.0, 1.0, (0.5, 0.9)), ("rec x0.1", 0.1, 1.0, (0.5, 0.9)), ("rec x0.01", 0.01, 1.0, (0.5, 0.9)),
+             ("rec x0", 0.0, 1.0, (0.5, 0.9)), ("lr_dv x0.1", 1.0, 0.1, (0.5, 0.9)), ("lr_dv x0.01", 1.0, 0.01, (0.5, 0.9)))
+    if len(sys.argv) > 4 and sys.argv[4] == "betas":
+        # second round: with decoder_visualize slowed down (the one setting that keeps the mask statistics where the log has them)
+        # the OTHER sub-networks' trajectories -- bottleneck_loss = encoder_0's KL -- can tell edflow's Adam betas from TensorFlow's
+        cases = (("lr_dv x0.03", 1.0, 0.03, (0.5, 0.9)), ("lr_dv x0.1", 1.0, 0.1, (0.5, 0.9)),
+                 ("lr_dv x0.03 tf", 1.0, 0.03, (0.9, 0.999)), ("lr_dv x0.1 tf", 1.0, 0.1, (0.9, 0.999)))
+    for tag, rec_s, lr_f, betas in cases:
         def patched(self, view, n, S, P, l, lm, m, hard, px, per_np, sums, w, g_hard=None, dl=None, bwd=False, dl_rec=None, _s=rec_s):
             orig_prior(self, view, n, S, P, l, lm, m, hard, px, per_np, sums, w, g_hard, dl, bwd, dl_rec)
             if bwd and _s != 1.0:
@@ -129,7 +135,7 @@ def probes():
         runs = []
         for sd in range(seeds):
             cfg = copy.deepcopy(configs.cub_config(n_parts=25, batch_size=8, use_tps=True))
-            cfg.update({"precision": "bf16", "noise_seed": 4321 + sd})
+            cfg.update({"precision": "bf16", "noise_seed": 4321 + sd, "beta1": betas[0], "beta2": betas[1]})
             dev = torch.device("cuda:0")
             model = TrainModel(cfg, device=dev, seed=sd)
             tr = Trainer(cfg, None, model)
@@ -148,7 +154,7 @@ def probes():
         res[tag] = runs
         sys.stderr.write("done {}\n".format(tag))
     Trainer._prior, OPS.adam_step = orig_prior, orig_adam
-    for k in MASK_KEYS + ("loss_decoder_delta", "bottleneck_loss"):
+    for k in MASK_KEYS + ("loss_decoder_delta", "bottleneck_loss", "lor", "avg_loss_dis0", "avg_loss_dis1"):
         print("== " + k)
         for tag, runs in res.items():
             row = "  {:12s}".format(tag)

@@ -467,6 +467,7 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
 
 int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_patch.hip
 int ups_conv3x3_first_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_first.hip
+int ups_conv3x3_s2_try(const ups_conv_desc* d, hipStream_t s);      // conv3x3_s2.hip
 
 extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d != nullptr);
@@ -491,6 +492,12 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     if (!(force && force[0] == '1')) {
         // first layers (<= 8 input channels, 32 / 64 outputs): the im2col-in-the-fragment kernel, an output-write stream
         if (ups_conv3x3_first_try(d, (hipStream_t)stream) == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
+        // the large 3x3 / stride-2 `downsample` forwards (32 / 64 input channels): taps straight from global memory, no gather
+        {
+            const int sr = ups_conv3x3_s2_try(d, (hipStream_t)stream);
+            if (sr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
+            if (sr < 0) { ups_set_error("ups_conv_igemm: stride-2 kernel launch setup failed"); return sr; }
+        }
         const int pr = ups_conv3x3_patch_try(d, (hipStream_t)stream);
         if (pr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
         if (pr < 0) { ups_set_error("ups_conv_igemm: patch kernel launch setup failed"); return pr; }

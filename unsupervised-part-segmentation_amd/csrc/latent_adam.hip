@@ -149,7 +149,51 @@ __global__ void gauss_hm3_kernel(const float* __restrict__ mu, const float* __re
     out[idx] = expf(-0.5f * (z0 * z0 + z1 * z1)) / (6.283185307179586f * fabsf(l4[0] * l4[3]));
 }
 
+
+// ------------------------------------------------------------------ standard-normal noise (tf.random_normal, nn.py:1187,1431)
+// Philox4x32-10 (Salmon et al. 2011) keyed by `seed`, counter = offset + index of the 4-value group; the four 32-bit words of a
+// group -> two Box-Muller pairs.  A pure function of (seed, offset, element index): the same stream under any launch geometry
+// and under HIP-graph replay (the trainer advances `offset` by ceil(n / 4) per call).
+__device__ inline void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__global__ void randn_kernel(float* __restrict__ out, long long n, unsigned long long seed, unsigned long long offset) {
+    const long long groups = (n + 3) >> 2;
+    for (long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x; gidx < groups; gidx += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long ctr = offset + (unsigned long long)gidx;
+        unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);          // (0, 1): 24 bits, never 0
+            const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float rad = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            z[2 * h] = rad * cs; z[2 * h + 1] = rad * sn;
+        }
+        const long long e = gidx << 2;
+        if (e + 3 < n && ((((unsigned long long)out) & 15ull) == 0)) *(float4*)(out + e) = make_float4(z[0], z[1], z[2], z[3]);
+        else for (int k = 0; k < 4 && e + k < n; ++k) out[e + k] = z[k];
+    }
+}
+
 }  // namespace
+
+extern "C" int ups_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+    UPS_CHECK_ARG(out && n > 0);
+    long long grid = ((n + 3) / 4 + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(randn_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, out, (long long)n, (unsigned long long)seed,
+                       (unsigned long long)offset);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
 
 extern "C" int ups_latent_fwd(const float* params, const float* eps, const float* level, int32_t S, int32_t B, int32_t dim,
                               float* samples, float* kl_rows, void* stream) {

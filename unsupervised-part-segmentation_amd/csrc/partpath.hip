@@ -72,13 +72,18 @@ __global__ __launch_bounds__(256) void part_softmax_kernel(const float* __restri
 // partial[n][slab][p][8] = {max, Z, S0, Sy, Sx, Q, Qy, -} relative to the slab max (Q = sum e*k*(gy^2+gx^2), Qy = sum e*k*gy^2)
 // threads = (part c, sub-lane s) with NS = 256 / P sub-lanes per part (250 of 256 lanes busy at P = 10, against 160 with a
 // power-of-two lane group); each walks the column c of the staged tile with its pixel coordinates advanced incrementally.
+// kl_partial (optional, [n][nslab]): sum over the slab of x * log(P * x + 1e-20) -- the categorical KL of the map itself
+// (model.py:21-25): view 1's only other prior term, so its separate pass over the map (prior_fwd, view 1) is not needed.
 __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ x, int h, int w, int P, float gamma,
                                                               const int* __restrict__ rc, int hh, int hw_half,
-                                                              int rows_per_slab, int tpx, float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float ts[];          // [tpx][PP], then red[NS][P][7]
+                                                              int rows_per_slab, int tpx, float* __restrict__ partial,
+                                                              float* __restrict__ kl_partial) {
+    extern __shared__ __attribute__((aligned(16))) float ts[];          // [tpx][PP], then red[NS][P][7], then 4 floats
     const int PP = tile_pitch(P);
     const int NS = 256 / P;
     float* red = ts + (size_t)tpx * PP;
+    float* red4 = red + (size_t)NS * P * 7;
+    float kl = 0.f;
     const int n = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
     const int c = threadIdx.x % P, sl = threadIdx.x / P;
     const bool act = sl < NS;
@@ -90,15 +95,20 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
     const int q0 = y0 * w, q1 = max(y1, y0) * w;
     const float* img = x + (long long)n * h * w * P;
     const int dyy = NS / w, dxx = NS - dyy * w;                         // pixel step NS in (row, column) form
+    TileReq<3> rq;                            // the next tile's pieces are in flight while this one is summed (tile.h)
+    if (q0 < q1) tile_request(rq, img + (long long)q0 * P, min(tpx, q1 - q0), P);
     for (int t0 = q0; t0 < q1; t0 += tpx) {
         const int cnt = min(tpx, q1 - t0);
         __syncthreads();                      // the previous tile has been consumed
-        tile_load_f32(img + (long long)t0 * P, cnt, P, PP, ts);
+        tile_commit(rq, img + (long long)t0 * P, cnt, P, PP, ts);
+        if (t0 + tpx < q1) tile_request(rq, img + (long long)(t0 + tpx) * P, min(tpx, q1 - t0 - tpx), P);
         __syncthreads();
         if (act) {
             int yy = (t0 + sl) / w, xx = (t0 + sl) - yy * w;
             for (int px = sl; px < cnt; px += NS) {
-                const float v = gamma * ts[px * PP + c];
+                const float xv = ts[px * PP + c];
+                if (kl_partial) kl += xv * logf((float)P * xv + 1e-20f);
+                const float v = gamma * xv;
                 if (v > mx) {
                     const float sc = expf(mx - v);  // exp(-inf) = 0 on the first element
                     Z *= sc; S0 *= sc; Sy *= sc; Sx *= sc; Q *= sc; Qy *= sc;
@@ -136,21 +146,33 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
         for (int k = 0; k < 6; ++k) dst[1 + k] = o[k];
         dst[7] = 0.f;
     }
+    if (kl_partial) {
+        const float v = block_sum_256(kl, red4);
+        if (threadIdx.x == 0) kl_partial[(long long)n * nslab + slab] = v;
+    }
 }
 
 // stats[n][p] = {max, Z, S0, Sy, Sx, Q, Qy, 0} of spatial_softmax(gamma * hard) (no rectangle) from the integer sums of the
 // hard pixels: e = 1 on them, exp(-gamma) elsewhere (all e = 1 when the part owns no pixel); grid sums of the linspace(-1, 1)
 // coordinates in closed form (sum g = 0, sum g^2 = n (n + 1) / (3 (n - 1)))
-__global__ void hard_moments_finalize_kernel(const int* __restrict__ mom, int count_n, int blocks_per_img, int P, int h, int w,
-                                             float gamma, float* __restrict__ stats) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// (one WAVE per (image, part): lane b sums the tiles b, b + 64, ... and a shuffle tree adds the lanes -- a thread per (image, part)
+// walking all tiles serially made this tail 28 us behind a 95 us soft-max pass)
+__global__ __launch_bounds__(256) void hard_moments_finalize_kernel(const int* __restrict__ mom, int count_n, int blocks_per_img, int P,
+                                                                    int h, int w, float gamma, float* __restrict__ stats) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (idx >= count_n * P) return;
     const int n = idx / P, c = idx - n * P;
     long long a[5] = {0, 0, 0, 0, 0};
-    for (int b = 0; b < blocks_per_img; ++b) {
+    for (int b = lane; b < blocks_per_img; b += 64) {
         const int* r = mom + ((long long)(n * blocks_per_img + b) * P + c) * 5;
         for (int k = 0; k < 5; ++k) a[k] += r[k];
     }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[k] += __shfl_xor(a[k], o, 64);
+    if (lane != 0) return;
     const double N = (double)h * w, N1 = (double)a[0];
     const double sy = h > 1 ? 2.0 / (h - 1) : 0.0, sx = w > 1 ? 2.0 / (w - 1) : 0.0;
     const double hy = -N1 + sy * a[1], hx = -N1 + sx * a[2];                                   // sum over the hard pixels of gy, gx
@@ -168,18 +190,35 @@ __global__ void hard_moments_finalize_kernel(const int* __restrict__ mom, int co
     }
 }
 
-__global__ void moments_combine_kernel(const float* __restrict__ partial, int count_n, int nslab, int P, float* __restrict__ stats) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// (grid: ceil(n * P / 4) blocks -- four waves, one (image, part) each -- + one more that sums the KL partials in a fixed order)
+__global__ __launch_bounds__(256) void moments_combine_kernel(const float* __restrict__ partial, int count_n, int nslab, int P,
+                                                              float* __restrict__ stats, const float* __restrict__ kl_partial,
+                                                              float* __restrict__ kl_sum) {
+    if (blockIdx.x == gridDim.x - 1 && kl_sum) {
+        __shared__ float red4[4];
+        float a = 0.f;
+        for (int i = threadIdx.x; i < count_n * nslab; i += 256) a += kl_partial[i];
+        const float v = block_sum_256(a, red4);
+        if (threadIdx.x == 0) { kl_sum[0] = v; for (int k = 1; k < 16; ++k) kl_sum[k] = 0.f; }
+        return;
+    }
+    // one wave per (image, part): lane s holds slab s (, s + 64, ...), shuffle trees for the max and the rescaled sums
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (idx >= count_n * P) return;
     const int n = idx / P, c = idx - n * P;
     float M = -INFINITY;
-    for (int s = 0; s < nslab; ++s) M = fmaxf(M, partial[(((long long)n * nslab + s) * P + c) * 8]);
+    for (int s = lane; s < nslab; s += 64) M = fmaxf(M, partial[(((long long)n * nslab + s) * P + c) * 8]);
+    M = wave_max(M);
     float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < nslab; ++s) {
+    for (int s = lane; s < nslab; s += 64) {
         const float* src = partial + (((long long)n * nslab + s) * P + c) * 8;
         const float sc = (src[0] == -INFINITY) ? 0.f : expf(src[0] - M);
         for (int k = 0; k < 6; ++k) o[k] += sc * src[1 + k];
     }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = wave_sum(o[k]);
+    if (lane != 0) return;
     float* d = stats + (long long)idx * 8;
     d[0] = M; d[1] = o[0]; d[2] = o[1]; d[3] = o[2]; d[4] = o[3]; d[5] = o[4]; d[6] = o[5]; d[7] = 0.f;
 }
@@ -273,6 +312,17 @@ __global__ __launch_bounds__(256) void unpool_fwd_kernel(const float* __restrict
     const long long pix0 = (long long)b * hw + q0;
     tile_load_f32(hard + pix0 * P, cnt, P, PP, ts);
     for (int i = threadIdx.x; i < P * F; i += 256) fs[i] = feat[(long long)b * P * F + i];
+    int* act = (int*)(fs + P * F);                        // per pixel: its single active part, -1 (none) or -2 (several: ties)
+    __syncthreads();
+    // the hard mask is one-hot except at ties: find each pixel's active part ONCE (every 16-byte output item walked all P parts
+    // before: 100 LDS reads per pixel at P = 10 for ~10 useful ones)
+    for (int px = threadIdx.x; px < cnt; px += 256) {
+        const float* hrow = ts + px * PP;
+        int a = -1;
+        for (int p = 0; p < P; ++p)
+            if (hrow[p] != 0.f) a = a == -1 ? p : -2;
+        act[px] = a;
+    }
     __syncthreads();
     const int cpp = ldo / 8;
     for (int i = threadIdx.x; i < cnt * cpp; i += 256) {
@@ -280,12 +330,20 @@ __global__ __launch_bounds__(256) void unpool_fwd_kernel(const float* __restrict
         float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* hrow = ts + px * PP;
         if (k * 8 < F) {
-            for (int p = 0; p < P; ++p) {
-                const float hm = hrow[p];
-                if (hm != 0.f) {
-                    const float* fr = fs + p * F + k * 8;
+            const int a = act[px];
+            if (a >= 0) {
+                const float hm = hrow[a];
+                const float* fr = fs + a * F + k * 8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] += hm * fr[e];
+                for (int e = 0; e < 8; ++e) f[e] = hm * fr[e];
+            } else if (a == -2) {
+                for (int p = 0; p < P; ++p) {
+                    const float hm = hrow[p];
+                    if (hm != 0.f) {
+                        const float* fr = fs + p * F + k * 8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += hm * fr[e];
+                    }
                 }
             }
         } else {
@@ -301,80 +359,90 @@ __global__ __launch_bounds__(256) void unpool_fwd_kernel(const float* __restrict
     }
 }
 
-// g_hard[b][px][p] = sum_f g[b][px][f] * feat[b][p][f] + g[b][px][F+p]
-// block = tpx consecutive pixels of one image: their gradient rows (16-byte loads) and feat[b] (odd row stride) sit in LDS;
-// GP adjacent lanes own the parts of one pixel; the result tile goes out with 16-byte stores.
-template <typename T, int GP>
-__global__ __launch_bounds__(256) void unpool_bwd_hard_kernel(const float* __restrict__ feat, const T* __restrict__ g,
-                                                              float* __restrict__ gh, long long hw, int P, int F, int ldo,
-                                                              int tpx) {
-    extern __shared__ __attribute__((aligned(16))) float ts[];          // out [tpx][PP], feat [P][F+1], g [tpx][ldo] (T)
-    const int PP = tile_pitch(P);
-    float* fs = ts + (size_t)tpx * PP;
-    T* gs = (T*)(fs + ((P * (F + 1) + 3) & ~3));
-    const int b = blockIdx.y;
-    const long long q0 = (long long)blockIdx.x * tpx;
-    const int cnt = (int)min((long long)tpx, hw - q0);
-    const long long pix0 = (long long)b * hw + q0;
-    for (int i = threadIdx.x; i < P * F; i += 256) fs[(i / F) * (F + 1) + (i % F)] = feat[(long long)b * P * F + i];
-    {
-        const uint4* src = (const uint4*)(g + pix0 * ldo);
-        const int nv = (int)((size_t)cnt * ldo * sizeof(T) / 16);
-        for (int i = threadIdx.x; i < nv; i += 256) ((uint4*)gs)[i] = src[i];
-    }
-    __syncthreads();
-    const int c = threadIdx.x % GP, pl = threadIdx.x / GP;
-    constexpr int PL = 256 / GP;
-    if (c < P) {
-        const float* fr = fs + c * (F + 1);
-        for (int px = pl; px < cnt; px += PL) {
-            const T* row = gs + (size_t)px * ldo;
-            float acc = ld_as_float<T>(row + F + c);
-            for (int f = 0; f < F; f += 8) {
-                float v[8];
-                if (sizeof(T) == 2) { uint4 u = *(const uint4*)(row + f); Chunk<bf16>::unpack(u, v); }
-                else {
-                    uint4 u0 = *(const uint4*)(row + f), u1 = *(const uint4*)((const float*)(row + f) + 4);
-                    Chunk<float>::unpack(u0, v); Chunk<float>::unpack(u1, v + 4);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc += v[e] * fr[f + e];
-            }
-            ts[px * PP + c] = acc;
-        }
-    }
-    __syncthreads();
-    tile_store_f32(gh + pix0 * P, cnt, P, PP, ts);
-}
-
-// g_feat partials: lane = feature; each wave walks the pixels of the staged tile (gradient rows + hard rows in LDS) and adds
-// the gradient row into the LDS column of the (usually single) active part; partial[b][slab][p][f]
+// Backward of unpool_features + concat in ONE pass over the gradient (round 4; it was two kernels, each reading g):
+//   g_hard[b][px][p]  = sum_f g[b][px][f] * feat[b][p][f] + g[b][px][F+p]
+//   g_feat[b][p][f]   = sum_px hard[b][px][p] * g[b][px][f]          (per-slab partials, reduced by unpool_feat_reduce_kernel)
+// block = (image b, slab of the image's pixels), walked in tiles of tpx pixels: the hard tile (odd pitch) and the gradient rows
+// (raw 16-byte pieces) of a tile are requested together and the NEXT tile's pieces are in flight while this one is computed
+// (tile.h).  Phase 1: thread = (part, pixel lane) -> g_hard tile, stored with 16-byte accesses.  Phase 2:
+// lane = feature, each wave walks the tile's pixels and adds the gradient row into the LDS column of the (usually single)
+// active part.
 template <typename T>
-__global__ __launch_bounds__(256) void unpool_bwd_feat_kernel(const float* __restrict__ hard, const T* __restrict__ g,
-                                                              float* __restrict__ gfeat_partial, long long hw, int P, int F,
-                                                              int ldo, int slab_px, int tpx) {
-    extern __shared__ __attribute__((aligned(16))) float ts[];  // acc [4][P][64], hard [tpx][PP], g [tpx][ldo] (T)
+__global__ __launch_bounds__(256) void unpool_bwd_kernel(const float* __restrict__ hard, const float* __restrict__ feat,
+                                                         const T* __restrict__ g, float* __restrict__ gh,
+                                                         float* __restrict__ gfeat_partial, long long hw, int P, int F, int ldo,
+                                                         int slab_px, int tpx) {
+    extern __shared__ __attribute__((aligned(16))) float ts[];  // acc [4][P][64], out [tpx][PP], hard [tpx][PP], feat [P][F+1], g [tpx][ldo] (T)
     const int PP = tile_pitch(P);
     float* acc = ts;
-    float* hs = acc + 4 * P * 64;
-    T* gs = (T*)(hs + (((size_t)tpx * PP + 3) & ~(size_t)3));
+    float* os = acc + 4 * P * 64;
+    float* hs = os + (((size_t)tpx * PP + 3) & ~(size_t)3);
+    float* fs = hs + (((size_t)tpx * PP + 3) & ~(size_t)3);
+    T* gs = (T*)(fs + (((size_t)P * (F + 1) + 3) & ~(size_t)3));
     const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
     const int f = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    // phase-1 role: thread = (part c, pixel lane pg), 256 / P pixel lanes (250 of 256 threads busy at P = 10)
+    const int PL = 256 / P;
+    const int pg = threadIdx.x / P;
+    const int c = pg < PL ? threadIdx.x - pg * P : P;           // c == P: idle
+    constexpr int KG = 5;                                       // 16-byte pieces of a gradient tile per thread (128 px x 80 ch bf16)
     for (int i = threadIdx.x; i < 4 * P * 64; i += 256) acc[i] = 0.f;
-    const long long p0 = (long long)slab * slab_px, p1 = min(hw, p0 + slab_px);
+    for (int i = threadIdx.x; i < P * F; i += 256) fs[(i / F) * (F + 1) + (i % F)] = feat[(long long)b * P * F + i];
+    const long long p0 = (long long)slab * slab_px, p1 = min(hw, p0 + (long long)slab_px);
     float* my = acc + (long long)pl * P * 64;
+    TileReq<2> rh;
+    uint4 rg[KG];
+    auto request = [&](long long t0) {
+        const int cnt = (int)min((long long)tpx, p1 - t0);
+        const long long pix0 = (long long)b * hw + t0;
+        tile_request(rh, hard + pix0 * P, cnt, P);
+        const uint4* src = (const uint4*)(g + pix0 * ldo);
+        const int nv = (int)((size_t)cnt * ldo * sizeof(T) / 16);
+#pragma unroll
+        for (int k = 0; k < KG; ++k) { const int i = k * 256 + threadIdx.x; rg[k] = i < nv ? src[i] : make_uint4(0u, 0u, 0u, 0u); }
+    };
+    if (p0 < p1) request(p0);
+    // feat[b][c][:] of this thread's part in registers: the inner product of phase 1 then costs 8 LDS reads (the gradient row) per
+    // (pixel, part) instead of 72 -- the launch was LDS-issue bound on those scalar reads
+    float frr[64];
+    __syncthreads();                                              // (fs is complete)
+#pragma unroll
+    for (int k = 0; k < 64; ++k) frr[k] = (c < P && k < F) ? fs[c * (F + 1) + k] : 0.f;
     for (long long t0 = p0; t0 < p1; t0 += tpx) {
         const int cnt = (int)min((long long)tpx, p1 - t0);
         const long long pix0 = (long long)b * hw + t0;
-        __syncthreads();
-        tile_load_f32(hard + pix0 * P, cnt, P, PP, hs);
+        __syncthreads();                                          // the previous tile has been consumed (and stored)
+        tile_commit(rh, hard + pix0 * P, cnt, P, PP, hs);
         {
             const uint4* src = (const uint4*)(g + pix0 * ldo);
             const int nv = (int)((size_t)cnt * ldo * sizeof(T) / 16);
-            for (int i = threadIdx.x; i < nv; i += 256) ((uint4*)gs)[i] = src[i];
+#pragma unroll
+            for (int k = 0; k < KG; ++k) { const int i = k * 256 + threadIdx.x; if (i < nv) ((uint4*)gs)[i] = rg[k]; }
+            for (int i = KG * 256 + threadIdx.x; i < nv; i += 256) ((uint4*)gs)[i] = src[i];
         }
+        if (t0 + tpx < p1) request(t0 + tpx);
         __syncthreads();
-        for (int px = pl; px < cnt; px += 4) {
+        if (c < P) {                                              // phase 1: d / d hard (the part's feature row sits in registers)
+            for (int px = pg; px < cnt; px += PL) {
+                const T* row = gs + (size_t)px * ldo;
+                float a = ld_as_float<T>(row + F + c);
+#pragma unroll
+                for (int ff = 0; ff < 64; ff += 8) {
+                    if (ff < F) {
+                        float v[8];
+                        if (sizeof(T) == 2) { uint4 u = *(const uint4*)(row + ff); Chunk<bf16>::unpack(u, v); }
+                        else {
+                            uint4 u0 = *(const uint4*)(row + ff), u1 = *(const uint4*)((const float*)(row + ff) + 4);
+                            Chunk<float>::unpack(u0, v); Chunk<float>::unpack(u1, v + 4);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a += v[e] * frr[ff + e];
+                    }
+                }
+                os[px * PP + c] = a;
+            }
+        }
+        for (int px = pl; px < cnt; px += 4) {                    // phase 2: d / d feat
             const float gf = (f < F) ? ld_as_float<T>(gs + (size_t)px * ldo + f) : 0.f;
             const float hv = (f < P) ? hs[px * PP + f] : 0.f;
             unsigned long long m = __ballot(hv != 0.f);
@@ -384,6 +452,8 @@ __global__ __launch_bounds__(256) void unpool_bwd_feat_kernel(const float* __res
                 my[pp * 64 + f] += __shfl(hv, pp, 64) * gf;
             }
         }
+        __syncthreads();
+        tile_store_f32(gh + pix0 * P, cnt, P, PP, os);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < P * 64; i += 256) {
@@ -403,7 +473,7 @@ __global__ void unpool_feat_reduce_kernel(const float* __restrict__ partial, int
     gfeat[idx] = s;
 }
 
-constexpr int UNPOOL_SLABS = 16;
+constexpr int UNPOOL_SLABS = 32;
 
 // kernels whose LDS images can exceed the 64 KB default at P = 64: raise the limit once per kernel
 template <typename K>
@@ -450,32 +520,49 @@ extern "C" int ups_part_softmax_moments_fwd(const float* mean, const float* eps,
     hipLaunchKernelGGL(part_softmax_kernel, dim3(grid), dim3(256), shm, s, mean, eps, l, m, hard, (long long*)argmax,
                        (unsigned*)hard_bits, pixels, P, tpx, (int*)scratch, w, h * w);
     UPS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(hard_moments_finalize_kernel, dim3(ups_cdiv((long long)n * P, 64)), dim3(64), 0, s, (const int*)scratch, n,
+    hipLaunchKernelGGL(hard_moments_finalize_kernel, dim3(ups_cdiv((long long)n * P, 4)), dim3(256), 0, s, (const int*)scratch, n,
                        (h * w) / tpx, P, h, w, gamma, stats);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+constexpr int MOMENT_SLABS = 32;      // row slabs per image (n x 32 blocks: 2 048 at B = 64; two 256-pixel tiles each at 128x128)
+
+static int spatial_moments_launch(const float* x, int32_t n, int32_t h, int32_t w, int32_t P, float gamma, const int32_t* rect_c,
+                                  int32_t half_h, int32_t half_w, float* stats, float* kl_sum, void* stream) {
+    UPS_CHECK_ARG(x && stats && n > 0 && P >= 1 && P <= 64);
+    hipStream_t s = (hipStream_t)stream;
+    // the stats buffer doubles as the workspace: n*P*8 floats of result, then n*MOMENT_SLABS*P*8 floats of per-slab partials and
+    // n*MOMENT_SLABS floats of KL partials (ups_spatial_moments_floats)
+    const int nslab = MOMENT_SLABS;
+    float* partial = stats + (long long)n * P * 8;
+    float* klp = kl_sum ? partial + (long long)n * nslab * P * 8 : nullptr;
+    const int rows = ups_cdiv(h, nslab);
+    const int tpx = tile_pixels(P, 1, 24 * 1024);
+    const size_t shm = ((size_t)tpx * (P | 1) + (size_t)(256 / P) * P * 7 + 4) * sizeof(float);
+    hipLaunchKernelGGL(moments_partial_kernel, dim3(n, nslab), dim3(256), shm, s, x, h, w, P, gamma, rect_c, half_h, half_w, rows, tpx,
+                       partial, klp);
+    UPS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(moments_combine_kernel, dim3(ups_cdiv(n * P, 4) + 1), dim3(256), 0, s, partial, n, nslab, P, stats, klp, kl_sum);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }
 
 extern "C" int ups_spatial_moments(const float* x, int32_t n, int32_t h, int32_t w, int32_t P, float gamma,
                                    const int32_t* rect_c, int32_t half_h, int32_t half_w, float* stats, void* stream) {
-    UPS_CHECK_ARG(x && stats && n > 0 && P >= 1 && P <= 64);
-    hipStream_t s = (hipStream_t)stream;
-    // stats buffer doubles as the partial buffer: caller provides n*P*8 floats for stats followed by workspace
-    // n*NSLAB*P*6 floats (documented in the Python wrapper) -> keep it simple: workspace sits right after stats.
-    const int nslab = 8;
-    float* partial = stats + (long long)n * P * 8;
-    const int rows = ups_cdiv(h, nslab);
-    const int tpx = tile_pixels(P, 1, 24 * 1024);
-    const size_t shm = ((size_t)tpx * (P | 1) + (size_t)(256 / P) * P * 7) * sizeof(float);
-    hipLaunchKernelGGL(moments_partial_kernel, dim3(n, nslab), dim3(256), shm, s, x, h, w, P, gamma, rect_c, half_h, half_w, rows, tpx,
-                       partial);
-    UPS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(moments_combine_kernel, dim3(ups_cdiv(n * P, 256)), dim3(256), 0, s, partial, n, nslab, P, stats);
-    UPS_LAUNCH_CHECK();
-    return UPS_OK;
+    return spatial_moments_launch(x, n, h, w, P, gamma, rect_c, half_h, half_w, stats, nullptr, stream);
 }
 
-extern "C" size_t ups_spatial_moments_floats(int32_t n, int32_t P) { return (size_t)n * P * 8 + (size_t)n * 8 * P * 8; }
+extern "C" int ups_spatial_moments_kl(const float* x, int32_t n, int32_t h, int32_t w, int32_t P, float gamma,
+                                      const int32_t* rect_c, int32_t half_h, int32_t half_w, float* stats, float* kl_sums16,
+                                      void* stream) {
+    UPS_CHECK_ARG(kl_sums16);
+    return spatial_moments_launch(x, n, h, w, P, gamma, rect_c, half_h, half_w, stats, kl_sums16, stream);
+}
+
+extern "C" size_t ups_spatial_moments_floats(int32_t n, int32_t P) {
+    return (size_t)n * P * 8 + (size_t)n * MOMENT_SLABS * P * 8 + (size_t)n * MOMENT_SLABS;
+}
 extern "C" size_t ups_unpool_bwd_floats(int32_t B, int32_t P, int32_t F) { return (size_t)B * P * F * (1 + UNPOOL_SLABS); }
 
 extern "C" int ups_moments_to_px(const float* stats, int32_t count, int32_t h, int32_t xy_order, int32_t* px, void* stream) {
@@ -521,7 +608,7 @@ extern "C" int ups_unpool_fwd(const float* hard, const float* feat, void* out, i
                               int32_t F, int32_t ldo, void* stream) {
     UPS_CHECK_ARG(hard && feat && out && F % 8 == 0 && ldo % 8 == 0 && ldo >= F + P && P >= 1 && P <= 64);
     const dim3 grid(ups_cdiv(hw, 256), B);
-    const size_t shm = ((size_t)256 * (P | 1) + (size_t)P * F) * sizeof(float);
+    const size_t shm = ((size_t)256 * (P | 1) + (size_t)P * F + 256) * sizeof(float);
     static bool a0 = false, a1 = false;
     if (!allow_big_lds(unpool_fwd_kernel<float>, a0) || !allow_big_lds(unpool_fwd_kernel<bf16>, a1)) return UPS_E_LAUNCH;
     if (dtype == UPS_F32) hipLaunchKernelGGL(unpool_fwd_kernel<float>, grid, dim3(256), shm, (hipStream_t)stream, hard, feat, (float*)out, (long long)hw, P, F, ldo);
@@ -533,36 +620,31 @@ extern "C" int ups_unpool_fwd(const float* hard, const float* feat, void* out, i
 // g_feat: caller provides B*P*F floats followed by B*UNPOOL_SLABS*P*F floats of workspace.
 extern "C" int ups_unpool_bwd(const float* hard, const float* feat, const void* g, float* g_hard, float* g_feat, int32_t dtype,
                               int32_t B, int64_t hw, int32_t P, int32_t F, int32_t ldo, void* stream) {
-    UPS_CHECK_ARG(hard && feat && g && g_hard && g_feat && F <= 64 && F % 8 == 0 && P <= 64 && ldo >= F + P);
+    UPS_CHECK_ARG(hard && feat && g && g_hard && g_feat && F <= 64 && F % 8 == 0 && P <= 64 && ldo >= F + P && ldo % 8 == 0);
     hipStream_t s = (hipStream_t)stream;
     float* partial = g_feat + (long long)B * P * F;
-    const int slab_px = ups_cdiv(hw, UNPOOL_SLABS);
     const size_t esz = dtype == UPS_F32 ? 4 : 2;
-    const int tpx = 128;
-    const size_t shmem = ((size_t)4 * P * 64 + (((size_t)tpx * (P | 1) + 3) & ~(size_t)3)) * sizeof(float) + (size_t)tpx * ldo * esz;
-    static bool af0 = false, af1 = false;
-    if (!allow_big_lds(unpool_bwd_feat_kernel<float>, af0) || !allow_big_lds(unpool_bwd_feat_kernel<bf16>, af1)) return UPS_E_LAUNCH;
+    int tpx = 128;
+    auto lds_bytes = [&](int t) {
+        return ((size_t)4 * P * 64 + 2 * (((size_t)t * (P | 1) + 3) & ~(size_t)3) + (((size_t)P * (F + 1) + 3) & ~(size_t)3)) * sizeof(float)
+               + (size_t)t * ldo * esz;
+    };
+    while (tpx > 32 && lds_bytes(tpx) > 52 * 1024) tpx >>= 1;
+    // whole tiles per slab, so that every tile's first pixel (and its 16-byte pieces) is aligned
+    const int slab_px = ups_cdiv(ups_cdiv(hw, UNPOOL_SLABS), tpx) * tpx;
+    const size_t shmem = lds_bytes(tpx);
     UPS_CHECK_ARG(shmem <= 160 * 1024);
-    if (dtype == UPS_F32) hipLaunchKernelGGL(unpool_bwd_feat_kernel<float>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, (const float*)g, partial, (long long)hw, P, F, ldo, slab_px, tpx);
-    else hipLaunchKernelGGL(unpool_bwd_feat_kernel<bf16>, dim3(B, UNPOOL_SLABS), dim3(256), shmem, s, hard, (const bf16*)g, partial, (long long)hw, P, F, ldo, slab_px, tpx);
+    const dim3 grid(B, UNPOOL_SLABS);
+    static bool ah0 = false, ah1 = false;
+    if (!allow_big_lds(unpool_bwd_kernel<float>, ah0) || !allow_big_lds(unpool_bwd_kernel<bf16>, ah1)) return UPS_E_LAUNCH;
+    if (dtype == UPS_F32)
+        hipLaunchKernelGGL(unpool_bwd_kernel<float>, grid, dim3(256), shmem, s, hard, feat, (const float*)g, g_hard, partial, (long long)hw,
+                           P, F, ldo, slab_px, tpx);
+    else
+        hipLaunchKernelGGL(unpool_bwd_kernel<bf16>, grid, dim3(256), shmem, s, hard, feat, (const bf16*)g, g_hard, partial, (long long)hw,
+                           P, F, ldo, slab_px, tpx);
     UPS_LAUNCH_CHECK();
     hipLaunchKernelGGL(unpool_feat_reduce_kernel, dim3(ups_cdiv(B * P * F, 256)), dim3(256), 0, s, partial, B, UNPOOL_SLABS, P * F, g_feat);
-    UPS_LAUNCH_CHECK();
-    int gp = 2;
-    while (gp < P) gp *= 2;
-    const int ppb = 128;                                     // pixels per block (one staged tile)
-    const dim3 grid(ups_cdiv(hw, ppb), B);
-    const size_t sh2 = ((size_t)ppb * (P | 1) + (((size_t)P * (F + 1) + 3) & ~(size_t)3)) * sizeof(float) + (size_t)ppb * ldo * esz;
-    UPS_CHECK_ARG(sh2 <= 160 * 1024);
-#define UPS_UH(TT, G) do { static bool ah = false; if (!allow_big_lds(unpool_bwd_hard_kernel<TT, G>, ah)) return UPS_E_LAUNCH; \
-        hipLaunchKernelGGL((unpool_bwd_hard_kernel<TT, G>), grid, dim3(256), sh2, s, feat, (const TT*)g, g_hard, (long long)hw, P, F, ldo, ppb); } while (0)
-#define UPS_UHD(G) do { if (dtype == UPS_F32) UPS_UH(float, G); else UPS_UH(bf16, G); } while (0)
-    switch (gp) {
-        case 2: UPS_UHD(2); break; case 4: UPS_UHD(4); break; case 8: UPS_UHD(8); break;
-        case 16: UPS_UHD(16); break; case 32: UPS_UHD(32); break; default: UPS_UHD(64); break;
-    }
-#undef UPS_UHD
-#undef UPS_UH
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

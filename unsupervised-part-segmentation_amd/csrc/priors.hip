@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int NSLAB = 32;     // row slabs per image in the forward pass (n x NSLAB blocks: 2 048 at B = 64)
+constexpr int NSLAB = 64;     // row slabs per image in the forward pass (n x NSLAB blocks: 4 096 at B = 64, two tiles each at 128x128)
 
 struct PriorK {
     int n, h, w, P, view, entropy_ce, half_h, half_w, variant;
@@ -30,6 +30,14 @@ struct PriorK {
     const float* l; const float* l_mean; const float* m; const float* hard; const int* px;
     float* per_np; float* sums; const float* g_hard; float* dl; float* ws; float* dl_rec;
 };
+
+// Logical block index for a 1-D grid whose consecutive logical blocks share halo rows: hardware block b runs on XCD b % 8, so
+// logical = (b % 8) * (total / 8) + b / 8 puts a run of consecutive logical blocks on ONE XCD (its L2 then serves the rows that
+// neighbouring tiles re-read; with the identity order every halo row came from HBM / Infinity Cache once per XCD that needed it).
+__device__ __forceinline__ int xcd_logical_block() {
+    const int total = gridDim.x, b = blockIdx.x;
+    return (total & 7) == 0 ? (b & 7) * (total >> 3) + (b >> 3) : b;
+}
 
 template <int GP>
 __device__ inline float gsum(float v) {
@@ -58,7 +66,7 @@ __device__ inline float tval(const float* t, int PP, int hp, int dq, int c, int 
 // for view 0, l_mean (same), l and hard; phase 1: one thread per pixel walks its parts (log-soft-max, entropy / CE, patch,
 // GMRF and the Mumford-Shah term r, which it leaves in the hard slot with the sign marking the contour branch); phase 2:
 // threads = (part, sub-lane) sum the columns of the staged tile into the per-part accumulators S, R, Rsmooth, Rcontour.
-__global__ __launch_bounds__(256) void prior_fwd_kernel(const PriorK p, int rows_per_slab, int tpx) {
+__global__ __launch_bounds__(256, 3) void prior_fwd_kernel(const PriorK p, int rows_per_slab, int tpx) {
     extern __shared__ __attribute__((aligned(16))) float ts[];
     const int P = p.P, PP = tile_pitch(P);
     const int halo = p.view == 0 ? p.w + 1 : 0;
@@ -70,7 +78,9 @@ __global__ __launch_bounds__(256) void prior_fwd_kernel(const PriorK p, int rows
     const int NS = 256 / P;                                           // sub-lanes per part in phase 2
     float* red4 = scratch + (size_t)NS * P * 4;
     int* cpx = (int*)(red4 + 4);                                      // rectangle centres of this image [P][2]
-    const int n = blockIdx.x, slab = blockIdx.y;
+    float* pst = (float*)(cpx + 2 * P);                               // per-pixel log-sum-exp of the tile [tpx]
+    const int lb = xcd_logical_block();
+    const int n = lb / NSLAB, slab = lb - n * NSLAB;
     if (p.view == 0 && p.px)
         for (int i = threadIdx.x; i < 2 * P; i += 256) cpx[i] = p.px[(long long)n * P * 2 + i];
     const int y0 = slab * rows_per_slab, y1 = max(y0, min(p.h, y0 + rows_per_slab));
@@ -80,55 +90,74 @@ __global__ __launch_bounds__(256) void prior_fwd_kernel(const PriorK p, int rows
     float S = 0.f, R = 0.f, Rs = 0.f, Rc = 0.f;
     const int c2 = threadIdx.x % P, s2 = threadIdx.x / P;            // phase-2 role
     const int q0 = y0 * p.w, q1 = y1 * p.w;
+    // software pipeline over the slab's tiles: all maps of a tile are requested at once (one HBM round trip, tile.h) and the NEXT
+    // tile's pieces are in flight while the current one is computed
+    TileReq<3> rm, rlm;         // (P <= 11 at 128-wide images: everything in one round trip; larger P: the rest synchronously)
+    TileReq<2> rl, rh;
+    auto request = [&](int t0) {
+        const int cnt = min(tpx, q1 - t0), cnt_h = min(cnt + halo, hw - t0);
+        tile_request(rm, p.m + (img + t0) * P, cnt_h, P);
+        if (p.view == 0) {
+            tile_request(rlm, p.l_mean + (img + t0) * P, cnt_h, P);
+            tile_request(rl, p.l + (img + t0) * P, cnt, P);
+            tile_request(rh, p.hard + (img + t0) * P, cnt, P);
+        }
+    };
+    if (q0 < q1) request(q0);
     for (int t0 = q0; t0 < q1; t0 += tpx) {
         const int cnt = min(tpx, q1 - t0);
         const int cnt_h = min(cnt + halo, hw - t0);
         __syncthreads();
-        tile_load_f32(p.m + (img + t0) * P, cnt_h, P, PP, tm);
+        tile_commit(rm, p.m + (img + t0) * P, cnt_h, P, PP, tm);
         if (p.view == 0) {
-            tile_load_f32(p.l_mean + (img + t0) * P, cnt_h, P, PP, tlm);
-            tile_load_f32(p.l + (img + t0) * P, cnt, P, PP, tl);
-            tile_load_f32(p.hard + (img + t0) * P, cnt, P, PP, th);
+            tile_commit(rlm, p.l_mean + (img + t0) * P, cnt_h, P, PP, tlm);
+            tile_commit(rl, p.l + (img + t0) * P, cnt, P, PP, tl);
+            tile_commit(rh, p.hard + (img + t0) * P, cnt, P, PP, th);
         }
+        if (t0 + tpx < q1) request(t0 + tpx);
         __syncthreads();
-        for (int px = threadIdx.x; px < cnt; px += 256) {
-            const int q = t0 + px;
-            const int yy = q / p.w, xx = q - yy * p.w;
-            const float* mrow = tm + px * PP;
-            for (int c = 0; c < P; ++c) { const float mc = mrow[c]; kl += mc * logf((float)P * mc + 1e-20f); }
-            if (p.view == 0) {
+        // element-wise work on ITEMS (pixel, part) over all 256 threads; only the log-sum-exp stays per pixel (see prior_bwd_kernel)
+        if (p.view == 0) {
+            for (int px = threadIdx.x; px < cnt; px += 256) {
                 const float* lrow = tl + px * PP;
-                float* hrow = th + px * PP;
                 float mx = -INFINITY;
                 for (int c = 0; c < P; ++c) mx = fmaxf(mx, lrow[c]);
                 float se = 0.f;
                 for (int c = 0; c < P; ++c) se += expf(lrow[c] - mx);
-                const float lse = mx + logf(se);
-                for (int c = 0; c < P; ++c) {
-                    const float mc = mrow[c];
-                    const float sl = lrow[c] - lse;
-                    const float hv = hrow[c];
-                    ent += -(p.entropy_ce ? hv : mc) * sl;
-                    const float lm = tlm[px * PP + c];
-                    if (p.variant == 0) {
-                        const bool in_rect = abs(yy - cpx[2 * c]) <= p.half_h && abs(xx - cpx[2 * c + 1]) <= p.half_w;
-                        patch += hv * (in_rect ? 0.f : 1.f);
-                    } else {
-                        // SB_model48c: Mumford-Shah on the noise-free logits, min(alpha * g, lambda) summed (patch slot)
-                        const float lr = tval(tlm, PP, px, 1, c, yy, xx + 1, p.h, p.w);
-                        const float ld = tval(tlm, PP, px, p.w, c, yy + 1, xx, p.h, p.w);
-                        const float gw = 0.25f * (lm - lr), gh = 0.25f * (lm - ld);
-                        patch += fminf(p.ms_alpha * (gw * gw + gh * gh), p.ms_lambda);
-                    }
-                    if (yy + 1 < p.h) { const float d = tlm[(px + p.w) * PP + c] - lm; gmrf += 0.5f * d * d; }
-                    if (xx + 1 < p.w) { const float d = tlm[(px + 1) * PP + c] - lm; gmrf += 0.5f * d * d; }
-                    const float mr = tval(tm, PP, px, 1, c, yy, xx + 1, p.h, p.w);
-                    const float md = tval(tm, PP, px, p.w, c, yy + 1, xx, p.h, p.w);
-                    const float gw = 0.25f * (mc - mr), gh = 0.25f * (mc - md);
-                    const float g = p.ms_alpha * (gw * gw + gh * gh);
-                    const float r = fminf(g, p.ms_lambda);
-                    hrow[c] = (g < p.ms_lambda) ? r : -r;            // sign = contour branch (r = lambda > 0 there)
+                pst[px] = mx + logf(se);
+            }
+            __syncthreads();
+        }
+        const int items = cnt * P;
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int px = it / P, c = it - px * P;
+            const float mc = tm[px * PP + c];
+            kl += mc * logf((float)P * mc + 1e-20f);
+            if (p.view == 0) {
+                const int q = t0 + px;
+                const int yy = q / p.w, xx = q - yy * p.w;
+                const float sl = tl[px * PP + c] - pst[px];
+                const float hv = th[px * PP + c];
+                ent += -(p.entropy_ce ? hv : mc) * sl;
+                const float lm = tlm[px * PP + c];
+                if (p.variant == 0) {
+                    const bool in_rect = abs(yy - cpx[2 * c]) <= p.half_h && abs(xx - cpx[2 * c + 1]) <= p.half_w;
+                    patch += hv * (in_rect ? 0.f : 1.f);
+                } else {
+                    // SB_model48c: Mumford-Shah on the noise-free logits, min(alpha * g, lambda) summed (patch slot)
+                    const float lr = tval(tlm, PP, px, 1, c, yy, xx + 1, p.h, p.w);
+                    const float ld = tval(tlm, PP, px, p.w, c, yy + 1, xx, p.h, p.w);
+                    const float gw = 0.25f * (lm - lr), gh = 0.25f * (lm - ld);
+                    patch += fminf(p.ms_alpha * (gw * gw + gh * gh), p.ms_lambda);
                 }
+                if (yy + 1 < p.h) { const float d = tlm[(px + p.w) * PP + c] - lm; gmrf += 0.5f * d * d; }
+                if (xx + 1 < p.w) { const float d = tlm[(px + 1) * PP + c] - lm; gmrf += 0.5f * d * d; }
+                const float mr = tval(tm, PP, px, 1, c, yy, xx + 1, p.h, p.w);
+                const float md = tval(tm, PP, px, p.w, c, yy + 1, xx, p.h, p.w);
+                const float gw = 0.25f * (mc - mr), gh = 0.25f * (mc - md);
+                const float g = p.ms_alpha * (gw * gw + gh * gh);
+                const float r = fminf(g, p.ms_lambda);
+                th[px * PP + c] = (g < p.ms_lambda) ? r : -r;            // sign = contour branch (r = lambda > 0 there)
             }
         }
         if (p.view == 0) {
@@ -167,32 +196,53 @@ __global__ __launch_bounds__(256) void prior_fwd_kernel(const PriorK p, int rows
     v = block_sum_256(gmrf, red4); if (threadIdx.x == 0) gp[3] = v;
 }
 
-__global__ __launch_bounds__(256) void prior_finalize_kernel(const PriorK p) {
+// Two short stages instead of one single-block pass (which walked n * NSLAB * (1 + P) partial records serially per thread: 16 us
+// behind a 120 us forward pass).  Stage 1, one block per image: the image's slab partials -> per_np[n][P][8] and the image's eight
+// sums (4 pixel sums, 4 sums of squares over its parts), every reduction in a fixed order.  Stage 2, one block: the images.
+__global__ __launch_bounds__(256) void prior_finalize_img_kernel(const PriorK p) {
     __shared__ float red4[4];
-    const float* gpart = p.ws;
-    const float* np_partial = p.ws + (long long)p.n * NSLAB * 4;
+    const int n = blockIdx.x;
+    const float* gpart = p.ws + (long long)n * NSLAB * 4;
+    const float* np_partial = p.ws + (long long)p.n * NSLAB * 4 + (long long)n * NSLAB * p.P * 4;
+    float* img_part = p.ws + (long long)p.n * NSLAB * 4 + (long long)p.n * NSLAB * p.P * 4 + (long long)n * 8;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < p.n * NSLAB; i += 256)
-        for (int k = 0; k < 4; ++k) a[k] += gpart[(long long)i * 4 + k];
+    for (int i = threadIdx.x; i < NSLAB; i += 256)
+        for (int k = 0; k < 4; ++k) a[k] += gpart[i * 4 + k];
     float sq[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.view == 0) {
-        for (int i = threadIdx.x; i < p.n * p.P; i += 256) {
-            const int n = i / p.P, c = i - n * p.P;
+        // wave per part: lanes over the slabs
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int c = wv; c < p.P; c += 4) {
             float o[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < NSLAB; ++s)
-                for (int k = 0; k < 4; ++k) o[k] += np_partial[(((long long)n * NSLAB + s) * p.P + c) * 4 + k];
-            float* d = p.per_np + (long long)i * 8;
-            d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3]; d[4] = d[5] = d[6] = d[7] = 0.f;
-            sq[0] += o[1] * o[1]; sq[1] += o[0] * o[0]; sq[2] += o[2] * o[2]; sq[3] += o[3] * o[3];
+            for (int s = lane; s < NSLAB; s += 64)
+                for (int k = 0; k < 4; ++k) o[k] += np_partial[((long long)s * p.P + c) * 4 + k];
+            for (int k = 0; k < 4; ++k) o[k] = wave_sum(o[k]);
+            if (lane == 0) {
+                float* d = p.per_np + ((long long)n * p.P + c) * 8;
+                d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3]; d[4] = d[5] = d[6] = d[7] = 0.f;
+                sq[0] += o[1] * o[1]; sq[1] += o[0] * o[0]; sq[2] += o[2] * o[2]; sq[3] += o[3] * o[3];
+            }
         }
     }
     for (int k = 0; k < 4; ++k) {
         const float v = block_sum_256(a[k], red4);
-        if (threadIdx.x == 0) p.sums[k] = v;
+        if (threadIdx.x == 0) img_part[k] = v;
     }
     for (int k = 0; k < 4; ++k) {
         const float v = block_sum_256(sq[k], red4);
-        if (threadIdx.x == 0) p.sums[4 + k] = v;
+        if (threadIdx.x == 0) img_part[4 + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void prior_finalize_kernel(const PriorK p) {
+    __shared__ float red4[4];
+    const float* img_part = p.ws + (long long)p.n * NSLAB * 4 + (long long)p.n * NSLAB * p.P * 4;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < p.n; i += 256)
+        for (int k = 0; k < 8; ++k) a[k] += img_part[(long long)i * 8 + k];
+    for (int k = 0; k < 8; ++k) {
+        const float v = block_sum_256(a[k], red4);
+        if (threadIdx.x == 0) p.sums[k] = v;
     }
     if (threadIdx.x == 0) for (int k = 8; k < 16; ++k) p.sums[k] = 0.f;
 }
@@ -203,9 +253,11 @@ __global__ __launch_bounds__(256) void prior_finalize_kernel(const PriorK p) {
 __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p, int tpx) {
     extern __shared__ __attribute__((aligned(16))) float ts[];
     const int P = p.P, PP = tile_pitch(P);
-    const int n = blockIdx.y;
     const int hw = p.h * p.w;
-    const int t0 = blockIdx.x * tpx;
+    const int tiles = (hw + tpx - 1) / tpx;
+    const int lb = xcd_logical_block();
+    const int n = lb / tiles;
+    const int t0 = (lb - n * tiles) * tpx;
     const int cnt = min(tpx, hw - t0);
     const int halo = p.view == 0 ? p.w : 0;
     const int lo = max(0, t0 - halo), hi = min(hw, t0 + cnt + halo);
@@ -217,13 +269,24 @@ __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p, int tpx)
     float* tg = th + (size_t)tpx * PP;                                          // g_hard -> dl_rec
     float* cst = tg + (size_t)tpx * PP;                                         // [P][8]: per-part constants of this image
     const long long img = (long long)n * hw;
-    tile_load_f32(p.m + (img + lo) * P, hi - lo, P, PP, tm);
-    if (p.view == 0) {
-        tile_load_f32(p.l_mean + (img + lo) * P, hi - lo, P, PP, tlm);
-        tile_load_f32(p.l + (img + t0) * P, cnt, P, PP, tl);
-        tile_load_f32(p.hard + (img + t0) * P, cnt, P, PP, th);
+    {   // every map's pieces are requested before any of them is waited for: one HBM round trip per block instead of five
+        TileReq<4> rm, rlm;
+        TileReq<2> rl, rh, rg;
+        tile_request(rm, p.m + (img + lo) * P, hi - lo, P);
+        if (p.view == 0) {
+            tile_request(rlm, p.l_mean + (img + lo) * P, hi - lo, P);
+            tile_request(rl, p.l + (img + t0) * P, cnt, P);
+            tile_request(rh, p.hard + (img + t0) * P, cnt, P);
+        }
+        if (p.g_hard) tile_request(rg, p.g_hard + (img + t0) * P, cnt, P);
+        tile_commit(rm, p.m + (img + lo) * P, hi - lo, P, PP, tm);
+        if (p.view == 0) {
+            tile_commit(rlm, p.l_mean + (img + lo) * P, hi - lo, P, PP, tlm);
+            tile_commit(rl, p.l + (img + t0) * P, cnt, P, PP, tl);
+            tile_commit(rh, p.hard + (img + t0) * P, cnt, P, PP, th);
+        }
+        if (p.g_hard) tile_commit(rg, p.g_hard + (img + t0) * P, cnt, P, PP, tg);
     }
-    if (p.g_hard) tile_load_f32(p.g_hard + (img + t0) * P, cnt, P, PP, tg);
     for (int c = threadIdx.x; c < P; c += 256) {
         float* k = cst + c * 8;
         const float* np = p.per_np + ((long long)n * P + c) * 8;
@@ -240,16 +303,17 @@ __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p, int tpx)
     const float inv_pix = 1.f / (float)npix_total, inv_n = 1.f / (float)p.n;
     const float a8 = p.ms_alpha * 0.125f, a16 = p.ms_alpha * 0.0625f;
     const float sy = p.h > 1 ? 2.f / (float)(p.h - 1) : 0.f, sx = p.w > 1 ? 2.f / (float)(p.w - 1) : 0.f;
-    for (int px = threadIdx.x; px < cnt; px += 256) {
-        const int q = t0 + px;
-        const int yy = q / p.w, xx = q - yy * p.w;
-        const int hp = px + off;
-        const float* mrow = tm + hp * PP;
-        float* lrow = tl + px * PP;
-        float* hrow = th + px * PP;
-        float* grow = tg + px * PP;
-        float dot = 0.f, dot_r = 0.f;
-        if (p.view == 0) {
+    // Compute in four short phases (round 4).  The per-pixel form (one thread walks the P parts of its pixel: a serial chain of
+    // ~150 dependent instructions per part with half the block idle at 128-pixel tiles) bounded the launch, not its bytes: the
+    // element-wise work now runs on ITEMS (pixel, part) spread over all 256 threads (independent items per thread), only the
+    // per-pixel reductions (log-sum-exp, the soft-max Jacobian's dot products) stay per pixel.
+    float* pst = cst + P * 8;                                   // [tpx][4]: lse, qs, labsum | dot, dot_r
+    const int items = cnt * P;
+    if (p.view == 0) {
+        for (int px = threadIdx.x; px < cnt; px += 256) {       // A: per-pixel log-sum-exp, sum m * log-soft-max, sum of labels
+            const float* mrow = tm + (px + off) * PP;
+            const float* lrow = tl + px * PP;
+            const float* hrow = th + px * PP;
             float mx = -INFINITY;
             for (int c = 0; c < P; ++c) mx = fmaxf(mx, lrow[c]);
             float se = 0.f;
@@ -257,119 +321,136 @@ __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p, int tpx)
             const float lse = mx + logf(se);
             float qs = 0.f, labsum = 0.f;
             for (int c = 0; c < P; ++c) { qs += mrow[c] * (lrow[c] - lse); labsum += hrow[c]; }
-            for (int c = 0; c < P; ++c) {
-                const float mc = mrow[c];
-                const float sl = lrow[c] - lse;
-                const float hv = hrow[c];
-                const float gh = p.g_hard ? grow[c] : 0.f;
-                const float pm = (float)P * mc;
-                float gm = p.w_kl * inv_pix * (logf(pm + 1e-20f) + pm / (pm + 1e-20f)) + gh;
-                float direct = p.w_entropy * inv_pix * (-mc * (sl - qs));
-                if (p.entropy_ce) direct += p.w_entropy * inv_pix * (-(hv - mc * labsum));
-                const float* k = cst + c * 8;
-                if (p.variant == 0) {      // patch (STE)
-                    const bool in_rect = abs(yy - (int)k[0]) <= p.half_h && abs(xx - (int)k[1]) <= p.half_w;
-                    gm += p.w_patch * inv_n * (in_rect ? 0.f : 1.f);
-                }
-                // area + mumford-shah
-                gm += p.w_area * inv_n * 2.f * k[2];
-                const float m_r = tval(tm, PP, hp, 1, c, yy, xx + 1, p.h, p.w);
-                const float m_d = tval(tm, PP, hp, p.w, c, yy + 1, xx, p.h, p.w);
-                float dR = 0.f;
-                {   // own cell
-                    const float g = a16 * ((mc - m_r) * (mc - m_r) + (mc - m_d) * (mc - m_d));
-                    if (g <= p.ms_lambda) dR += a8 * ((mc - m_r) + (mc - m_d));
-                }
-                if (xx > 0) {   // left neighbour's cell: its right value is me
-                    const float m_l = tval(tm, PP, hp, -1, c, yy, xx - 1, p.h, p.w);
-                    const float m_ld = tval(tm, PP, hp, p.w - 1, c, yy + 1, xx - 1, p.h, p.w);
-                    const float g = a16 * ((m_l - mc) * (m_l - mc) + (m_l - m_ld) * (m_l - m_ld));
-                    if (g <= p.ms_lambda) dR -= a8 * (m_l - mc);
-                }
-                if (yy > 0) {   // upper neighbour's cell: its down value is me
-                    const float m_u = tval(tm, PP, hp, -p.w, c, yy - 1, xx, p.h, p.w);
-                    const float m_ur = tval(tm, PP, hp, -p.w + 1, c, yy - 1, xx + 1, p.h, p.w);
-                    const float g = a16 * ((m_u - m_ur) * (m_u - m_ur) + (m_u - mc) * (m_u - mc));
-                    if (g <= p.ms_lambda) dR -= a8 * (m_u - mc);
-                }
-                gm += p.w_ms * inv_n * 2.f * k[3] * dR;
-                // gmrf on the noise-free logits (same tensor path: l = l_mean + eps)
-                const float lm = tlm[hp * PP + c];
-                if (p.variant == 1) {
-                    // SB_model48c: d/d l_mean of sum min(alpha * g(l_mean), lambda): the stencil above applied to the logits
-                    const float l_r = tval(tlm, PP, hp, 1, c, yy, xx + 1, p.h, p.w);
-                    const float l_d = tval(tlm, PP, hp, p.w, c, yy + 1, xx, p.h, p.w);
-                    float dL = 0.f;
-                    {
-                        const float g = a16 * ((lm - l_r) * (lm - l_r) + (lm - l_d) * (lm - l_d));
-                        if (g <= p.ms_lambda) dL += a8 * ((lm - l_r) + (lm - l_d));
-                    }
-                    if (xx > 0) {
-                        const float l_l = tval(tlm, PP, hp, -1, c, yy, xx - 1, p.h, p.w);
-                        const float l_ld = tval(tlm, PP, hp, p.w - 1, c, yy + 1, xx - 1, p.h, p.w);
-                        const float g = a16 * ((l_l - lm) * (l_l - lm) + (l_l - l_ld) * (l_l - l_ld));
-                        if (g <= p.ms_lambda) dL -= a8 * (l_l - lm);
-                    }
-                    if (yy > 0) {
-                        const float l_u = tval(tlm, PP, hp, -p.w, c, yy - 1, xx, p.h, p.w);
-                        const float l_ur = tval(tlm, PP, hp, -p.w + 1, c, yy - 1, xx + 1, p.h, p.w);
-                        const float g = a16 * ((l_u - l_ur) * (l_u - l_ur) + (l_u - lm) * (l_u - lm));
-                        if (g <= p.ms_lambda) dL -= a8 * (l_u - lm);
-                    }
-                    direct += p.w_msl * inv_n * dL;
-                }
-                float gg = 0.f;
-                if (yy > 0) gg += lm - tlm[(hp - p.w) * PP + c];
-                if (yy + 1 < p.h) gg -= tlm[(hp + p.w) * PP + c] - lm;
-                if (xx > 0) gg += lm - tlm[(hp - 1) * PP + c];
-                if (xx + 1 < p.w) gg -= tlm[(hp + 1) * PP + c] - lm;
-                direct += p.w_gmrf * inv_n * gg;
-                dot += mc * gm; dot_r += mc * gh;
-                hrow[c] = gm; lrow[c] = direct;
-            }
-            for (int c = 0; c < P; ++c) {
-                const float mc = mrow[c];
-                const float gh = p.g_hard ? grow[c] : 0.f;
-                lrow[c] = mc * (hrow[c] - dot) + lrow[c];
-                // the same launch also emits the gradient of the reconstruction loss alone (all prior weights zero)
-                grow[c] = mc * (gh - dot_r);
-            }
-        } else {
-            const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
-            for (int c = 0; c < P; ++c) {
-                const float mc = mrow[c];
-                const float gh = p.g_hard ? grow[c] : 0.f;
-                const float pm = (float)P * mc;
-                float gm = p.w_kl * inv_pix * (logf(pm + 1e-20f) + pm / (pm + 1e-20f)) + gh;
-                const float* k = cst + c * 8;
-                const float Z = k[3], muy = k[4], mux = k[5];
-                const float sq = expf(p.gamma * mc - k[2]) / Z;
-                if (p.variant == 1) {
-                    // SB_model48c variance (DF:750-776): v_np = S00^2 + S11^2 of c = softmax_hw(gamma*m) (no rectangle,
-                    // renormalised), S00 = Qy/Z - muy^2, S11 = Qx/Z - mux^2
-                    const float Qyn = k[7], Qxn = k[6] - k[7];
-                    const float S00 = Qyn - muy * muy, S11 = Qxn - mux * mux;
-                    const float ay = gy * gy - 2.f * muy * gy - (Qyn - 2.f * muy * muy);
-                    const float ax = gx * gx - 2.f * mux * gx - (Qxn - 2.f * mux * mux);
-                    gm += p.w_var * inv_n * p.gamma * sq * 2.f * (S00 * ay + S11 * ax);
-                } else {
-                    // variance: v_np = Q/Z - muy^2 - mux^2 over c = softmax_hw(gamma*m) * (1-rect)
-                    const float Qn = k[6];
-                    const float T = Qn - 2.f * muy * muy - 2.f * mux * mux;
-                    const float kk = (abs(yy - (int)k[0]) <= p.half_h && abs(xx - (int)k[1]) <= p.half_w) ? 0.f : 1.f;
-                    const float a = gy * gy + gx * gx - 2.f * muy * gy - 2.f * mux * gx;
-                    gm += p.w_var * inv_n * p.gamma * sq * (a * kk - T);
-                }
-                dot += mc * gm; dot_r += mc * gh;
-                lrow[c] = gm;
-            }
-            for (int c = 0; c < P; ++c) {
-                const float mc = mrow[c];
-                const float gh = p.g_hard ? grow[c] : 0.f;
-                lrow[c] = mc * (lrow[c] - dot);
-                grow[c] = mc * (gh - dot_r);
-            }
+            pst[px * 4] = lse; pst[px * 4 + 1] = qs; pst[px * 4 + 2] = labsum;
         }
+        __syncthreads();
+        for (int it = threadIdx.x; it < items; it += 256) {     // B: d loss / d m (-> hard slot) and the direct term (-> l slot)
+            const int px = it / P, c = it - px * P;
+            const int q = t0 + px;
+            const int yy = q / p.w, xx = q - yy * p.w;
+            const int hp = px + off;
+            const float mc = tm[hp * PP + c];
+            const float lse = pst[px * 4], qs = pst[px * 4 + 1], labsum = pst[px * 4 + 2];
+            const float sl = tl[px * PP + c] - lse;
+            const float hv = th[px * PP + c];
+            const float gh = p.g_hard ? tg[px * PP + c] : 0.f;
+            const float pm = (float)P * mc;
+            float gm = p.w_kl * inv_pix * (logf(pm + 1e-20f) + pm / (pm + 1e-20f)) + gh;
+            float direct = p.w_entropy * inv_pix * (-mc * (sl - qs));
+            if (p.entropy_ce) direct += p.w_entropy * inv_pix * (-(hv - mc * labsum));
+            const float* k = cst + c * 8;
+            if (p.variant == 0) {      // patch (STE)
+                const bool in_rect = abs(yy - (int)k[0]) <= p.half_h && abs(xx - (int)k[1]) <= p.half_w;
+                gm += p.w_patch * inv_n * (in_rect ? 0.f : 1.f);
+            }
+            // area + mumford-shah
+            gm += p.w_area * inv_n * 2.f * k[2];
+            const float m_r = tval(tm, PP, hp, 1, c, yy, xx + 1, p.h, p.w);
+            const float m_d = tval(tm, PP, hp, p.w, c, yy + 1, xx, p.h, p.w);
+            float dR = 0.f;
+            {   // own cell
+                const float g = a16 * ((mc - m_r) * (mc - m_r) + (mc - m_d) * (mc - m_d));
+                if (g <= p.ms_lambda) dR += a8 * ((mc - m_r) + (mc - m_d));
+            }
+            if (xx > 0) {   // left neighbour's cell: its right value is me
+                const float m_l = tval(tm, PP, hp, -1, c, yy, xx - 1, p.h, p.w);
+                const float m_ld = tval(tm, PP, hp, p.w - 1, c, yy + 1, xx - 1, p.h, p.w);
+                const float g = a16 * ((m_l - mc) * (m_l - mc) + (m_l - m_ld) * (m_l - m_ld));
+                if (g <= p.ms_lambda) dR -= a8 * (m_l - mc);
+            }
+            if (yy > 0) {   // upper neighbour's cell: its down value is me
+                const float m_u = tval(tm, PP, hp, -p.w, c, yy - 1, xx, p.h, p.w);
+                const float m_ur = tval(tm, PP, hp, -p.w + 1, c, yy - 1, xx + 1, p.h, p.w);
+                const float g = a16 * ((m_u - m_ur) * (m_u - m_ur) + (m_u - mc) * (m_u - mc));
+                if (g <= p.ms_lambda) dR -= a8 * (m_u - mc);
+            }
+            gm += p.w_ms * inv_n * 2.f * k[3] * dR;
+            // gmrf on the noise-free logits (same tensor path: l = l_mean + eps)
+            const float lm = tlm[hp * PP + c];
+            if (p.variant == 1) {
+                // SB_model48c: d/d l_mean of sum min(alpha * g(l_mean), lambda): the stencil above applied to the logits
+                const float l_r = tval(tlm, PP, hp, 1, c, yy, xx + 1, p.h, p.w);
+                const float l_d = tval(tlm, PP, hp, p.w, c, yy + 1, xx, p.h, p.w);
+                float dL = 0.f;
+                {
+                    const float g = a16 * ((lm - l_r) * (lm - l_r) + (lm - l_d) * (lm - l_d));
+                    if (g <= p.ms_lambda) dL += a8 * ((lm - l_r) + (lm - l_d));
+                }
+                if (xx > 0) {
+                    const float l_l = tval(tlm, PP, hp, -1, c, yy, xx - 1, p.h, p.w);
+                    const float l_ld = tval(tlm, PP, hp, p.w - 1, c, yy + 1, xx - 1, p.h, p.w);
+                    const float g = a16 * ((l_l - lm) * (l_l - lm) + (l_l - l_ld) * (l_l - l_ld));
+                    if (g <= p.ms_lambda) dL -= a8 * (l_l - lm);
+                }
+                if (yy > 0) {
+                    const float l_u = tval(tlm, PP, hp, -p.w, c, yy - 1, xx, p.h, p.w);
+                    const float l_ur = tval(tlm, PP, hp, -p.w + 1, c, yy - 1, xx + 1, p.h, p.w);
+                    const float g = a16 * ((l_u - l_ur) * (l_u - l_ur) + (l_u - lm) * (l_u - lm));
+                    if (g <= p.ms_lambda) dL -= a8 * (l_u - lm);
+                }
+                direct += p.w_msl * inv_n * dL;
+            }
+            float gg = 0.f;
+            if (yy > 0) gg += lm - tlm[(hp - p.w) * PP + c];
+            if (yy + 1 < p.h) gg -= tlm[(hp + p.w) * PP + c] - lm;
+            if (xx > 0) gg += lm - tlm[(hp - 1) * PP + c];
+            if (xx + 1 < p.w) gg -= tlm[(hp + 1) * PP + c] - lm;
+            direct += p.w_gmrf * inv_n * gg;
+            th[px * PP + c] = gm; tl[px * PP + c] = direct;
+        }
+    } else {
+        for (int it = threadIdx.x; it < items; it += 256) {     // B (view 1): d loss / d m -> l slot
+            const int px = it / P, c = it - px * P;
+            const int q = t0 + px;
+            const int yy = q / p.w, xx = q - yy * p.w;
+            const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
+            const float mc = tm[(px + off) * PP + c];
+            const float gh = p.g_hard ? tg[px * PP + c] : 0.f;
+            const float pm = (float)P * mc;
+            float gm = p.w_kl * inv_pix * (logf(pm + 1e-20f) + pm / (pm + 1e-20f)) + gh;
+            const float* k = cst + c * 8;
+            const float Z = k[3], muy = k[4], mux = k[5];
+            const float sq = expf(p.gamma * mc - k[2]) / Z;
+            if (p.variant == 1) {
+                // SB_model48c variance (DF:750-776): v_np = S00^2 + S11^2 of c = softmax_hw(gamma*m) (no rectangle,
+                // renormalised), S00 = Qy/Z - muy^2, S11 = Qx/Z - mux^2
+                const float Qyn = k[7], Qxn = k[6] - k[7];
+                const float S00 = Qyn - muy * muy, S11 = Qxn - mux * mux;
+                const float ay = gy * gy - 2.f * muy * gy - (Qyn - 2.f * muy * muy);
+                const float ax = gx * gx - 2.f * mux * gx - (Qxn - 2.f * mux * mux);
+                gm += p.w_var * inv_n * p.gamma * sq * 2.f * (S00 * ay + S11 * ax);
+            } else {
+                // variance: v_np = Q/Z - muy^2 - mux^2 over c = softmax_hw(gamma*m) * (1-rect)
+                const float Qn = k[6];
+                const float T = Qn - 2.f * muy * muy - 2.f * mux * mux;
+                const float kk = (abs(yy - (int)k[0]) <= p.half_h && abs(xx - (int)k[1]) <= p.half_w) ? 0.f : 1.f;
+                const float a = gy * gy + gx * gx - 2.f * muy * gy - 2.f * mux * gx;
+                gm += p.w_var * inv_n * p.gamma * sq * (a * kk - T);
+            }
+            tl[px * PP + c] = gm;
+        }
+    }
+    __syncthreads();
+    const float* gms = p.view == 0 ? th : tl;                   // where phase B left d loss / d m
+    for (int px = threadIdx.x; px < cnt; px += 256) {           // C: the soft-max Jacobian's dot products per pixel
+        const float* mrow = tm + (px + off) * PP;
+        float dot = 0.f, dot_r = 0.f;
+        for (int c = 0; c < P; ++c) {
+            const float mc = mrow[c];
+            dot += mc * gms[px * PP + c];
+            if (p.g_hard) dot_r += mc * tg[px * PP + c];
+        }
+        pst[px * 4] = dot; pst[px * 4 + 1] = dot_r;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < items; it += 256) {         // D: dl (l slot) and the reconstruction-only dl_rec (g_hard slot)
+        const int px = it / P, c = it - px * P;
+        const float mc = tm[(px + off) * PP + c];
+        const float gh = p.g_hard ? tg[px * PP + c] : 0.f;
+        const float gm = gms[px * PP + c];
+        const float direct = p.view == 0 ? tl[px * PP + c] : 0.f;
+        tl[px * PP + c] = mc * (gm - pst[px * 4]) + direct;
+        tg[px * PP + c] = mc * (gh - pst[px * 4 + 1]);
     }
     __syncthreads();
     tile_store_f32(p.dl + (img + t0) * P, cnt, P, PP, tl);
@@ -391,9 +472,9 @@ PriorK to_k(const ups_prior_desc* d, float* ws) {
 
 }  // namespace
 
-extern "C" size_t ups_prior_sums_floats(int32_t n, int32_t P) { return 16 + (size_t)n * NSLAB * 4 + (size_t)n * NSLAB * P * 4; }
+extern "C" size_t ups_prior_sums_floats(int32_t n, int32_t P) { return 16 + (size_t)n * NSLAB * 4 + (size_t)n * NSLAB * P * 4 + (size_t)n * 8; }
 
-// workspace convention: `sums` points at 16 floats followed by n*NSLAB*4 + n*NSLAB*P*4 floats of scratch.
+// workspace convention: `sums` points at 16 floats followed by n*NSLAB*4 + n*NSLAB*P*4 + n*8 floats of scratch.
 extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
     UPS_CHECK_ARG(d && d->m && d->sums && d->P >= 1 && d->P <= 64 && d->n > 0);
     UPS_CHECK_ARG(d->view == 1 || (d->l && d->l_mean && d->hard && (d->px || d->variant == 1) && d->per_np));
@@ -402,7 +483,7 @@ extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
     const int rows = ups_cdiv(d->h, NSLAB);
     const int PP = d->P | 1, NS = 256 / d->P;
     auto lds_fl = [&](int t) {
-        return (d->view == 0 ? (size_t)(4 * t + 2 * (d->w + 1)) : (size_t)t) * PP + (size_t)NS * d->P * 4 + 4 + 2 * d->P;
+        return (d->view == 0 ? (size_t)(4 * t + 2 * (d->w + 1)) : (size_t)t) * PP + (size_t)NS * d->P * 4 + 4 + 2 * d->P + (size_t)t;
     };
     int tpx = 256;
     while (tpx > 32 && lds_fl(tpx) * 4 > 48 * 1024) tpx >>= 1;
@@ -414,7 +495,9 @@ extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
             return UPS_E_LAUNCH;
         attr = true;
     }
-    hipLaunchKernelGGL(prior_fwd_kernel, dim3(d->n, NSLAB), dim3(256), shm, s, k, rows, tpx);
+    hipLaunchKernelGGL(prior_fwd_kernel, dim3(d->n * NSLAB), dim3(256), shm, s, k, rows, tpx);
+    UPS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(prior_finalize_img_kernel, dim3(d->n), dim3(256), 0, s, k);
     UPS_LAUNCH_CHECK();
     hipLaunchKernelGGL(prior_finalize_kernel, dim3(1), dim3(256), 0, s, k);
     UPS_LAUNCH_CHECK();
@@ -427,7 +510,7 @@ extern "C" int ups_prior_bwd(const ups_prior_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     PriorK k = to_k(d, nullptr);
     const int PP = d->P | 1;
-    auto lds_fl = [&](int t) { return ((d->view == 0 ? (size_t)(5 * t + 4 * d->w) : (size_t)(4 * t)) * PP + (size_t)d->P * 8); };
+    auto lds_fl = [&](int t) { return ((d->view == 0 ? (size_t)(5 * t + 4 * d->w) : (size_t)(4 * t)) * PP + (size_t)d->P * 8 + (size_t)t * 4); };
     int tpx = 256;
     while (tpx > 32 && lds_fl(tpx) * 4 > 56 * 1024) tpx >>= 1;
     const size_t shm = lds_fl(tpx) * sizeof(float);
@@ -438,7 +521,7 @@ extern "C" int ups_prior_bwd(const ups_prior_desc* d, void* stream) {
             return UPS_E_LAUNCH;
         attr = true;
     }
-    const dim3 grid(ups_cdiv((long long)d->h * d->w, tpx), d->n);
+    const dim3 grid(ups_cdiv((long long)d->h * d->w, tpx) * d->n);
     hipLaunchKernelGGL(prior_bwd_kernel, grid, dim3(256), shm, s, k, tpx);
     UPS_LAUNCH_CHECK();
     return UPS_OK;

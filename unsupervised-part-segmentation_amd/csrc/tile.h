@@ -69,6 +69,62 @@ __device__ inline void tile_load_f32(const float* __restrict__ src, int count, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Two-phase staging (round 4).  tile_load_f32 requests a map's pieces and waits for them before it scatters them into LDS: a
+// block that stages five maps pays five dependent HBM round trips (~2.5 us each) before its first pixel is computed -- that, not
+// bytes or arithmetic, is what held the prior / moment / un-pool kernels at 12-34 % of the HBM roof.  Here a block first REQUESTS
+// the 16-byte pieces of every map it needs (K per thread and map, all in flight at once), then commits them to LDS; inside a tile
+// loop the next tile is requested before the current one is computed.
+template <int K>
+struct TileReq {
+    float4 u[K];
+    int nv;                  // 16-byte pieces of the tile (0: unaligned source, everything goes through the scalar tail)
+};
+
+template <int K>
+__device__ __forceinline__ void tile_request(TileReq<K>& r, const float* __restrict__ src, int count, int P) {
+    const int nfl = count * P;
+    r.nv = ((((unsigned long long)src) & 15ull) == 0 && src != nullptr) ? (nfl >> 2) : 0;
+    const float4* __restrict__ s4 = (const float4*)src;
+    const int tid = threadIdx.x, nt = blockDim.x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = k * nt + tid;
+        r.u[k] = i < r.nv ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__device__ __forceinline__ void tile_scatter4(float* __restrict__ lds, int i, int P, int PP, const float4& v) {
+    const int e = 4 * i;
+    int px = e / P, c = e - px * P;
+    const float w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        lds[px * PP + c] = w[j];
+        if (++c == P) { c = 0; ++px; }
+    }
+}
+
+// pieces [0, K * blockDim) come out of the request registers; whatever the tile has beyond them (large P), its last < 4 floats
+// and an unaligned source are fetched here
+template <int K>
+__device__ __forceinline__ void tile_commit(const TileReq<K>& r, const float* __restrict__ src, int count, int P, int PP,
+                                            float* __restrict__ lds) {
+    const int nfl = count * P;
+    const int tid = threadIdx.x, nt = blockDim.x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = k * nt + tid;
+        if (i < r.nv) tile_scatter4(lds, i, P, PP, r.u[k]);
+    }
+    const float4* __restrict__ s4 = (const float4*)src;
+    for (int i = K * nt + tid; i < r.nv; i += nt) tile_scatter4(lds, i, P, PP, s4[i]);
+    for (int e = (r.nv << 2) + tid; e < nfl; e += nt) {
+        const int px = e / P, c = e - px * P;
+        lds[px * PP + c] = src[e];
+    }
+}
+
 // lds[px * PP + c] -> HBM [count][P]; `f` maps the staged value to the stored one
 struct TileIdent { __device__ float operator()(float v) const { return v; } };
 template <typename F = TileIdent>

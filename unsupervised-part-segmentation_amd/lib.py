@@ -111,6 +111,7 @@ _SIGS = {
     "ups_part_softmax_moments_ints": ([_L, _I], _Z),
     "ups_part_softmax_moments_fwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P], C.c_int),
     "ups_spatial_moments": ([_P, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P], C.c_int),
+    "ups_spatial_moments_kl": ([_P, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P, _P], C.c_int),
     "ups_spatial_moments_floats": ([_I, _I], _Z),
     "ups_moments_to_px": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "ups_draw_rect": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
@@ -122,6 +123,9 @@ _SIGS = {
     "ups_prior_sums_floats": ([_I, _I], _Z),
     "ups_prior_fwd": ([C.POINTER(PriorDesc), _P], C.c_int),
     "ups_prior_bwd": ([C.POINTER(PriorDesc), _P], C.c_int),
+    "ups_randn": ([_P, _L, C.c_uint64, C.c_uint64, _P], C.c_int),
+    "ups_critic_head_fwd": ([_P, _P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "ups_critic_head_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "ups_latent_fwd": ([_P, _P, C.POINTER(_F), _I, _I, _I, _P, _P, _P], C.c_int),
     "ups_latent_bwd": ([_P, _P, C.POINTER(_F), _P, _P, _F, _I, _I, _I, _P, _P], C.c_int),
     "ups_adam": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P], C.c_int),

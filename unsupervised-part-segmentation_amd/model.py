@@ -83,10 +83,13 @@ class TrainModel(object):
             out.update(getattr(self, "_tps", {}))        # model.py:272-279
         return out
 
-    def to_act(self, x_f32, fmt=None):
-        """fp32 [n,H,W,c] -> activation dtype, 8-padded channels (fmt = L.F16: fp16 in a bf16 container, ops.py)."""
+    def to_act(self, x_f32, fmt=None, out=None):
+        """fp32 [n,H,W,c] -> activation dtype, 8-padded channels (fmt = L.F16: fp16 in a bf16 container, ops.py).
+        out: a contiguous destination of that shape (e.g. one half of a batch that two calls fill: no torch.cat)."""
         x_f32 = x_f32.contiguous()
-        out = torch.empty(x_f32.shape[:-1] + (ops.round8(x_f32.shape[-1]),), dtype=self.act_dtype, device=x_f32.device)
+        if out is None:
+            out = torch.empty(x_f32.shape[:-1] + (ops.round8(x_f32.shape[-1]),), dtype=self.act_dtype, device=x_f32.device)
+        assert out.is_contiguous() and out.shape[:-1] == x_f32.shape[:-1] and out.shape[-1] == ops.round8(x_f32.shape[-1])
         rows = x_f32.numel() // x_f32.shape[-1]
         L.call("ups_pad_convert", L.ptr(x_f32), x_f32.shape[-1], L.ptr(out), L.dt(out) if fmt is None else fmt, out.shape[-1], rows,
                L.stream())
@@ -241,7 +244,8 @@ class Trainer(object):
                       "avg_loss_dis0": _scalar(1.0, d), "avg_loss_dis1": _scalar(1.0, d),
                       "avg_mim": _scalar(0.0, d), "avg_independent_mim": _scalar(0.0, d)}
         self._gen = torch.Generator(device=d)
-        self._gen.manual_seed(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))
+        self._gen.manual_seed(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))      # TPS uniforms, crop window
+        self._noise = ops.NoiseStream(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))  # the sampling noise
         self._lazy_logs, self._done_thunk = None, None
         self._losses = OrderedDict((k, None) for k in self.loss_keys())
         self._early, self._early_hooked = {}, False
@@ -426,9 +430,10 @@ class Trainer(object):
     def draw_noise(self, B):
         cfg = self.config
         S, P, Z = cfg["spatial_size"], self.model.n_parts, cfg.get("z0_size", 256)
-        r = lambda *s: torch.randn(*s, generator=self._gen, device=self.device, dtype=torch.float32)
-        out = {"eps_pi0": r(9 if self.model.df else 7, B, Z), "eps_pi1": r(B, Z), "eps_l0": r(B, S, S, P),
-               "eps_l1": r(B, S, S, P)}
+        r = lambda *s: self._noise.randn(*s, device=self.device)      # the library's own Philox kernel (ops.NoiseStream)
+        # (the mask noise of both views as ONE [2B,S,S,P] tensor: what part_softmax takes -- two tensors would be concatenated,
+        # 168 MB of copies at B = 64; explicit noise may still come as eps_l0 / eps_l1, the fixtures' form)
+        out = {"eps_pi0": r(9 if self.model.df else 7, B, Z), "eps_pi1": r(B, Z), "eps_l": r(2 * B, S, S, P)}
         if self.perceptual_input == "resize256_crop224":     # corner of the step's 224x224 window of the 256x256 images
             out["crop_yx"] = torch.randint(0, 33, (2,), generator=self._gen, device=self.device, dtype=torch.int32)
         return out
@@ -507,7 +512,10 @@ class Trainer(object):
                 if k == "crop_yx":
                     buf.random_(0, 33, generator=self._gen)
                 else:
-                    buf.normal_(generator=self._gen)
+                    self._noise.fill(buf)
+            elif k == "eps_l" and "eps_l" not in noise:          # explicit noise in the fixtures' two-tensor form
+                buf[:B].copy_(noise["eps_l0"], non_blocking=True)
+                buf[B:].copy_(noise["eps_l1"], non_blocking=True)
             else:
                 buf.copy_(noise[k], non_blocking=True)
         t = self.model.bank.groups[self.loss_keys()[0]]["t"] + 1
@@ -683,7 +691,9 @@ class Trainer(object):
         """A forward: pose encoder + full-covariance latent (model.py:382-409); nine / seven draws of z_0, one of z_1."""
         model, nets = self.model, self.model.nets
         B, S = c.B, c.S
-        c.img01 = model.to_act(torch.cat([c.v0, c.v1], 0))
+        c.img01 = torch.empty((2 * B, S, S, 8), dtype=c.T, device=self.device)     # both views, each converted into its half
+        model.to_act(c.v0, out=c.img01[:B])
+        model.to_act(c.v1, out=c.img01[B:])
         c.pe = nets.e_pi(Act(c.img01, 2 * B, S, S, 3)).t                  # fp32 [2B,1,1,NP], taped
         c.pe2 = c.pe.detach().view(2 * B, -1)
         c.pe_v0, c.pe_v1 = c.pe2[:B].contiguous(), c.pe2[B:].contiguous()
@@ -710,15 +720,11 @@ class Trainer(object):
             pi_in = model.to_act(torch.cat([c.samples0[1 + 2 * ci], c.samples0[2 + 2 * ci]], 0).view(2 * B, 1, 1, Z))
             pi_in.requires_grad_(name == "mi0_discriminator")
             h_pi, h_al = nets.critic(name, (Act(pi_in, 2 * B, 1, 1, Z), Act(alpha_in, 2 * B, 1, 1, A)))
-            logits = (h_pi.t.float() * h_al.t.float()).sum(dim=(1, 2, 3))
-            joint, marg = logits[:B], logits[B:]
-            loss = 0.5 * (torch.nn.functional.softplus(-joint).mean() + torch.nn.functional.softplus(marg).mean())
-            acc = ((joint > 0).sum() + (marg < 0).sum()).float() / (2 * B)
-            crit[name] = (loss, joint, acc, pi_in)
-        _, joint0, _, pi_leaf0 = crit["mi0_discriminator"]
-        _, joint1, _, _ = crit["mi1_discriminator"]
-        c.mim = joint0.mean()                                                # logit_constraint(real=False), model.py:855
-        c.ind_mim = joint1.mean()
+            # dot product of the two embeddings, logistic losses, accuracy and the mean joint logit: one launch (+ one backward)
+            loss, acc, mean_joint = ops.CriticHeadFn.apply(h_pi.t, h_al.t, B, N.DSIZE)
+            crit[name] = (loss, mean_joint, acc, pi_in)
+        _, c.mim, _, pi_leaf0 = crit["mi0_discriminator"]                    # logit_constraint(real=False), model.py:855
+        _, c.ind_mim, _, _ = crit["mi1_discriminator"]
         c.adv, c.g_adv = None, None
         if cfg.get("adversarial_regularization", True):                   # model.py:886-909
             loa, loa_lr = st["loa"], mi.get("loa_lr", 4.0)
@@ -764,7 +770,9 @@ class Trainer(object):
         c.lm = c.l_mean.detach()
         # model.py:420-421 / nn.py:1427-1433: l = mean + eps unless `stochastic_l: False` (default: not test_mode)
         stochastic_l = cfg.get("stochastic_l", not cfg.get("test_mode", False))
-        eps_l = torch.cat([c.noise["eps_l0"], c.noise["eps_l1"]], 0) if stochastic_l else None
+        eps_l = None
+        if stochastic_l:
+            eps_l = c.noise["eps_l"] if "eps_l" in c.noise else torch.cat([c.noise["eps_l0"], c.noise["eps_l1"]], 0)
         # (the moments of gamma * hard -- the input of the rectangle centres, model.py:437-440 -- come out of the same pass)
         if c.df:
             c.l, c.m, c.hard, _, c.hbits = ops.part_softmax(c.lm, eps_l, want_bits=P <= 32)
@@ -828,9 +836,9 @@ class Trainer(object):
             wp = {"kl": c.w_kl, "entropy": c.w_weak, "ms": c.w_ms, "area": 1.0e-12, "patch": c.w_patch, "gmrf": c.w_gmrf, "var": c.w_var,
                   "msl": 0.0}
         self._prior(0, B, S, P, l0, c.lm[:B], m0, c.hard[:B], px0, per_np0, c.sums0, wp)
-        self._prior(1, B, S, P, l1, None, m1, None, px1, None, c.sums1, wp)
-        # variance moments (model.py:683-707; SB_model48c:750-756: no gamma, no rectangle)
-        c.stats_v = ops.spatial_moments(m1.contiguous(), 1.0 if df else c.gamma, rect_px=px1, half=c.half)
+        # view 1: variance moments (model.py:683-707; SB_model48c:750-756: no gamma, no rectangle) and, from the same pass over the
+        # map, its categorical KL (sums1[0]) -- the separate forward launch of view 1 is gone
+        c.stats_v = ops.spatial_moments(m1.contiguous(), 1.0 if df else c.gamma, rect_px=px1, half=c.half, kl_sums=c.sums1)
         c.dl_tot = torch.empty_like(c.lm)
         c.dl_rec = torch.empty_like(c.lm)
         self._prior(0, B, S, P, l0, c.lm[:B], m0, c.hard[:B], px0, per_np0, c.sums0, wp, c.g_hard0, c.dl_tot[:B], bwd=True,

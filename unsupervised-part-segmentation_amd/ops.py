@@ -859,17 +859,17 @@ class BilinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, site=None, act=0, slope=0.2, fmt=None, out_act=0):
         """out_act: the result is stored as out_act(y) (post-activation storage for a consuming residual block; gradients stay
-        with respect to y, so the backward is unchanged)."""
+        with respect to y, so the backward is unchanged).  `site` with an fp16 / post-activation forward (the mask decoder in fp8
+        mode: its forward stays fp16, round 4): only the BACKWARD hands an e5m2 copy of the gradient on."""
         x = x.contiguous()
         n, h, w, c = x.shape
         y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+        f8_site = site is not None and Fp8.enabled and Fp8.PRODUCER and x.dtype == torch.bfloat16 and c % 64 == 0 and (2 * h) % 16 == 0
+        ctx.site, ctx.shape = (site if f8_site else None), (n, h, w, c)
         if out_act:
-            assert site is None or not Fp8.enabled
             L.call("ups_bilinear2x_fwd_act", L.ptr(x), L.ptr(y), L.dt(x) if fmt is None else fmt, n, h, w, c, out_act, slope, L.stream())
-            ctx.site, ctx.shape = None, (n, h, w, c)
             return y
-        f8 = fmt != L.F16 and site is not None and Fp8.enabled and Fp8.PRODUCER and x.dtype == torch.bfloat16 and c % 64 == 0 and (2 * h) % 16 == 0
-        ctx.site = site if f8 else None
+        f8 = f8_site and fmt != L.F16
         if f8 and "fwd" not in site:
             site["fwd"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
         f8 = f8 and Fp8.wanted(site["fwd"])
@@ -883,7 +883,6 @@ class BilinearFn(torch.autograd.Function):
             Fp8.last_out = {"t": t8, "act": act, "slot": so["slot"], "site": so} if t8 is not None else None
         else:
             L.call("ups_bilinear2x_fwd", L.ptr(x), L.ptr(y), L.dt(x) if fmt is None else fmt, n, h, w, c, L.stream())
-        ctx.shape = (n, h, w, c)
         return y
 
     @staticmethod
@@ -1032,6 +1031,39 @@ class L1MeanFn(torch.autograd.Function):
         return None, gb, None, None
 
 
+class CriticHeadFn(torch.autograd.Function):
+    """Head of a separable MI critic (model.py:159-173 last line, 524-536, 821-826, 855): (h_pi [2B,..,K], h_al [2B,..,K]) ->
+    (loss, accuracy, mean joint logit) as three device scalars, rows [0,B) = joint pairs, [B,2B) = marginal pairs.  One launch
+    forward, one backward (ups_critic_head_*); the gradient arguments are device scalars -- no host synchronisation."""
+
+    @staticmethod
+    def forward(ctx, h_pi, h_al, B, K):
+        h_pi, h_al = h_pi.contiguous(), h_al.contiguous()
+        ld = h_pi.shape[-1]
+        assert h_pi.numel() == 2 * B * ld and h_al.shape == h_pi.shape
+        logits = torch.empty(2 * B, dtype=torch.float32, device=h_pi.device)
+        out = torch.empty(4, dtype=torch.float32, device=h_pi.device)
+        L.call("ups_critic_head_fwd", L.ptr(h_pi), L.ptr(h_al), L.dt(h_pi), B, K, ld, L.ptr(logits), L.ptr(out), L.stream())
+        ctx.save_for_backward(h_pi, h_al, logits)
+        ctx.B, ctx.K = B, K
+        loss, acc, mim = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc, mim
+
+    @staticmethod
+    def backward(ctx, g_loss, g_acc, g_mim):
+        h_pi, h_al, logits = ctx.saved_tensors
+        ld = h_pi.shape[-1]
+        gl = g_loss.contiguous().float() if g_loss is not None else None
+        gm = g_mim.contiguous().float() if g_mim is not None else None
+        gp = torch.empty_like(h_pi) if ctx.needs_input_grad[0] else None
+        ga = torch.empty_like(h_al) if ctx.needs_input_grad[1] else None
+        if gp is not None or ga is not None:
+            L.call("ups_critic_head_bwd", L.ptr(h_pi), L.ptr(h_al), L.ptr(logits), L.ptr(gl), L.ptr(gm), L.dt(h_pi), ctx.B, ctx.K, ld,
+                   L.ptr(gp), L.ptr(ga), L.stream())
+        return gp, ga, None, None
+
+
 class MaskPartsFn(torch.autograd.Function):
     """mask_parts + part-major transpose (model.py:176-187, nn.py:97-103): -> [P*B,H,W,8]."""
 
@@ -1113,11 +1145,17 @@ def part_softmax(mean, eps=None, want_hard=True, want_argmax=False, want_bits=No
     return out + (stats,) if moments_gamma is not None else out
 
 
-def spatial_moments(x, gamma, rect_px=None, half=0):
+def spatial_moments(x, gamma, rect_px=None, half=0, kl_sums=None):
+    """kl_sums (fp32 [>= 16] device buffer): the same pass also writes sum x * log(P x + 1e-20) -- the categorical KL of the map,
+    view 1's other prior term -- to kl_sums[0] (ups_spatial_moments_kl)."""
     n, h, w, P = x.shape
     nfl = L.load().ups_spatial_moments_floats(n, P)
     buf = torch.empty(nfl, dtype=torch.float32, device=x.device)
-    L.call("ups_spatial_moments", L.ptr(x), n, h, w, P, float(gamma), L.ptr(rect_px), half, half, L.ptr(buf), L.stream())
+    if kl_sums is not None:
+        L.call("ups_spatial_moments_kl", L.ptr(x), n, h, w, P, float(gamma), L.ptr(rect_px), half, half, L.ptr(buf), L.ptr(kl_sums),
+               L.stream())
+    else:
+        L.call("ups_spatial_moments", L.ptr(x), n, h, w, P, float(gamma), L.ptr(rect_px), half, half, L.ptr(buf), L.stream())
     return buf[:n * P * 8].view(n, P, 8)
 
 
@@ -1152,6 +1190,24 @@ def latent_bwd(params, eps, levels, g_samples, g_kl_dev, g_kl_scale):
     L.call("ups_latent_bwd", L.ptr(params), L.ptr(eps.contiguous()), (C.c_float * S)(*levels),
            L.ptr(g_samples.contiguous()), L.ptr(g_kl_dev), float(g_kl_scale), S, B, Z, L.ptr(gp), L.stream())
     return gp
+
+
+class NoiseStream(object):
+    """Standard-normal noise from the library's own Philox4x32-10 kernel (ups_randn): a (seed, offset) counter stream -- the
+    values are a pure function of the seed and of how many values were drawn before, on any launch geometry."""
+
+    def __init__(self, seed):
+        self.seed, self.offset = int(seed) & ((1 << 64) - 1), 0
+
+    def fill(self, out):
+        assert out.dtype == torch.float32 and out.is_contiguous()
+        n = out.numel()
+        L.call("ups_randn", L.ptr(out), n, self.seed, self.offset, L.stream())
+        self.offset += (n + 3) // 4
+        return out
+
+    def randn(self, *shape, device=None):
+        return self.fill(torch.empty(*shape, dtype=torch.float32, device=device))
 
 
 def adam_step(p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0):
