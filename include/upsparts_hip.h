@@ -223,6 +223,13 @@ int ups_col_sum(const void* dout, int32_t dtype, int64_t rows, int32_t co, int32
  * Legacy TF-1 bilinear x2 (N:834-847, tf.image.resize_images BILINEAR, no half-pixel centres). */
 int ups_bilinear2x_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
 int ups_bilinear2x_bwd(const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+/* The other up-sampling methods of nn.upsample (N:820-849).  "subpixel" = a convolution to 4 C channels (ups_conv_igemm) followed by
+ * tf.depth_to_space(x, 2): y[b, 2i+di, 2j+dj, c] = x[b, i, j, (2 di + dj) C + c]; x is [n,h,w,ldx] (4 C logical channels), y is
+ * [n,2h,2w,ldy] (C logical channels, pad channels written as zero).  bwd != 0: src = the gradient w.r.t. y, dst = w.r.t. x.
+ * "nearest_neighbor": y[b, 2i+di, 2j+dj, :] = x[b, i, j, :]; bwd != 0: src = gradient [n,2h,2w,c], dst [n,h,w,c] = the sum of the four. */
+int ups_depth_to_space(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t C, int32_t ldx, int32_t ldy,
+                       int32_t bwd, void* stream);
+int ups_nearest2x(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t bwd, void* stream);
 /* The ho x wo window of x [n,h,w,c] whose corner (oy, ox) = yx_dev[0..1] is read ON THE DEVICE (int32; clamped to the image):
  * the random 224x224 window of edflow VGG19Features(original_scale=True).make_loss_op as `perceptual_input: resize256_crop224`
  * reads it (M:610-618; UNVERIFIED), one window per step for the whole batch.  bwd: gx [n,h,w,c] = gy inside the window, 0

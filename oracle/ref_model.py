@@ -106,6 +106,21 @@ class Scope(object):
     def upsample_linear(x):           # N:834-847: num_units is ignored for method "linear"
         return bilinear_up2(x)
 
+    def upsample(self, x, num_units, method="subpixel"):
+        """N:820-849.  "subpixel": conv2d to 4 * num_units (a variable of this scope, CoordConv included) + tf.depth_to_space(2):
+        out[b, 2h+i, 2w+j, c] = y[b, h, w, (2i + j) * C + c]; "nearest_neighbor": every pixel repeated 2x2; "linear" ignores
+        num_units.  ("conv_transposed" -- weight-normalised deconv2d, N:938-1039 -- is not restated.)"""
+        if method == "linear":
+            return bilinear_up2(x)
+        if method == "nearest_neighbor":
+            return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+        if method == "subpixel":
+            y = self.conv2d(x, 4 * num_units)
+            n, h, w, _ = y.shape
+            y = y.reshape(n, h, w, 2, 2, num_units).permute(0, 1, 3, 2, 4, 5)
+            return y.reshape(n, 2 * h, 2 * w, num_units)
+        raise NotImplementedError(method)
+
 
 def conv2d_same(x, V, b, stride=1):
     """tf.nn.conv2d(x, V, [1,s,s,1], 'SAME') + b, NHWC/HWIO (Appendix A.1)."""
@@ -153,21 +168,19 @@ def single_decoder_model(sc, h, n_out, config, upsample_config):
     if isinstance(upsample_config, str):
         upsample_config = [upsample_config] * (len(config) - 1)
     assert len(upsample_config) == len(config) - 1
-    assert all(u == "linear" for u in upsample_config), "only 'linear' is on the shipped path"
     h = sc.nin(h, 4 * 4 * config[-1])
     h = h.reshape(-1, 4, 4, config[-1])
     h = sc.conv2d(h, config[-1])
     h = sc.residual_block(h)
-    for _nf, _u in zip(config[-2::-1], upsample_config[-1::-1]):
+    for nf, u in zip(config[-2::-1], upsample_config[-1::-1]):
         h = sc.residual_block(h)
-        h = sc.upsample_linear(h)
+        h = sc.upsample(h, nf, u)
     h = sc.residual_block(h)
     return sc.conv2d(h, n_out)
 
 
 def hourglass_model(sc, x, config, extra_resnets, n_out=3, upsample_method="linear"):
     """M:80-131 with alpha = pi = None (M:91-92)."""
-    assert upsample_method == "linear"
     hs = []
     h = sc.conv2d(x, config[0])
     h = sc.residual_block(h)
@@ -177,9 +190,9 @@ def hourglass_model(sc, x, config, extra_resnets, n_out=3, upsample_method="line
         hs.append(h)
     for _ in range(extra_resnets):
         h = sc.residual_block(h)
-    for i, _nf in enumerate(config[-2::-1]):
+    for i, nf in enumerate(config[-2::-1]):
         h = sc.residual_block(h, skipin=hs[-(i + 1)])
-        h = sc.upsample_linear(h)
+        h = sc.upsample(h, nf, upsample_method)
     h = sc.residual_block(h)
     return sc.conv2d(h, n_out)
 

@@ -24,6 +24,14 @@ def _setup(precision, dev, variant="cub", size="tiny"):
         cfg["use_tps"] = True
         cfg.setdefault("tps_parameters", {"scal": 0.8, "tps_scal": 0.15, "rot_scal": 0.2, "off_scal": 0.2, "scal_var": 0.1,
                                           "augm_scal": 1.0})
+    elif size == "tiny_subpixel":   # nn.upsample(method="subpixel") -- the reference signatures' default (M:135, M:87): conv to 4 C + depth_to_space
+        cfg = configs.tiny_config(variant=variant)
+        cfg["dv"]["upsample_config"] = ["subpixel", "subpixel"]
+        cfg["final_hour"]["upsample_method"] = "subpixel"
+    elif size == "tiny_nearest":    # nearest-neighbour up-sampling in the hourglass and one level of the mask decoder
+        cfg = configs.tiny_config(variant=variant)
+        cfg["dv"]["upsample_config"] = ["nearest_neighbor", "linear"]
+        cfg["final_hour"]["upsample_method"] = "nearest_neighbor"
     elif size == "tiny25":        # 25 parts (the shipped yamls' part count), odd batch: ragged lane groups / fallback conv paths
         cfg = configs.tiny_config(n_parts=25, batch_size=3, variant=variant)
     else:
@@ -47,7 +55,8 @@ def _setup(precision, dev, variant="cub", size="tiny"):
 
 
 CASES = [("cub", "tiny"), ("pennaction", "tiny"), ("deepfashion", "tiny"), ("cub", "small"), ("deepfashion", "small"),
-         ("cub", "tiny25"), ("deepfashion", "tiny25"), ("cub", "tiny_tps"), ("cub", "tiny_det")]
+         ("cub", "tiny25"), ("deepfashion", "tiny25"), ("cub", "tiny_tps"), ("cub", "tiny_det"), ("cub", "tiny_subpixel"),
+         ("cub", "tiny_nearest")]
 
 
 @pytest.mark.parametrize("variant,size", CASES)

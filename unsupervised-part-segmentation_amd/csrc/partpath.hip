@@ -12,6 +12,7 @@ namespace {
 // One block = one tile of `tpx` consecutive pixels: l = mean (+ eps) is staged (and echoed to `l`) with 16-byte accesses,
 // GP lanes per pixel reduce over the parts, the tile then holds +m / -m (sign = hard-max flag: m of a maximum is >= 1/P > 0)
 // and goes out as the two maps m and hard.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 struct TileAbs { __device__ float operator()(float v) const { return fabsf(v); } };
 struct TileSign { __device__ float operator()(float v) const { return (__float_as_uint(v) >> 31) ? 1.f : 0.f; } };
 
@@ -107,14 +108,14 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
             int yy = (t0 + sl) / w, xx = (t0 + sl) - yy * w;
             for (int px = sl; px < cnt; px += NS) {
                 const float xv = ts[px * PP + c];
-                if (kl_partial) kl += xv * logf((float)P * xv + 1e-20f);
+                if (kl_partial) kl += xv * __logf((float)P * xv + 1e-20f);
                 const float v = gamma * xv;
                 if (v > mx) {
-                    const float sc = expf(mx - v);  // exp(-inf) = 0 on the first element
+                    const float sc = __expf(mx - v);  // exp(-inf) = 0 on the first element
                     Z *= sc; S0 *= sc; Sy *= sc; Sx *= sc; Q *= sc; Qy *= sc;
                     mx = v;
                 }
-                const float e = expf(v - mx);
+                const float e = __expf(v - mx);
                 Z += e;
                 float k = 1.f;
                 if (rc && abs(yy - cy) <= hh && abs(xx - cx) <= hw_half) k = 0.f;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
         float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int q = 0; q < NS; ++q) {
             const float* r = red + ((size_t)q * P + c) * 7;
-            const float sc = (r[0] == -INFINITY) ? 0.f : expf(r[0] - M);
+            const float sc = (r[0] == -INFINITY) ? 0.f : __expf(r[0] - M);
             for (int k = 0; k < 6; ++k) o[k] += sc * r[1 + k];
         }
         float* dst = partial + (((long long)n * nslab + slab) * P + c) * 8;
@@ -404,10 +405,20 @@ __global__ __launch_bounds__(256) void unpool_bwd_kernel(const float* __restrict
     if (p0 < p1) request(p0);
     // feat[b][c][:] of this thread's part in registers: the inner product of phase 1 then costs 8 LDS reads (the gradient row) per
     // (pixel, part) instead of 72 -- the launch was LDS-issue bound on those scalar reads
-    float frr[64];
+    // 16-bit gradients: the row as PACKED bf16 pairs, contracted with v_dot2c_f32_bf16 (two MACs per instruction, no unpacking of
+    // the gradient; the launch was VALU-bound on 64 conversions + 64 FMAs per (pixel, part)).  In bf16 mode feat is the float view of
+    // a bf16 tensor, so the packing is exact; an fp32 feat given with bf16 gradients is rounded to bf16 here.
+    float frr[sizeof(T) == 2 ? 1 : 64];
+    unsigned fpk[sizeof(T) == 2 ? 32 : 1];
     __syncthreads();                                              // (fs is complete)
+    if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int k = 0; k < 64; ++k) frr[k] = (c < P && k < F) ? fs[c * (F + 1) + k] : 0.f;
+        for (int k = 0; k < 32; ++k)
+            fpk[k] = (c < P && 2 * k + 1 < F) ? Chunk<bf16>::pk(fs[c * (F + 1) + 2 * k], fs[c * (F + 1) + 2 * k + 1]) : 0u;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) frr[k] = (c < P && k < F) ? fs[c * (F + 1) + k] : 0.f;
+    }
     for (long long t0 = p0; t0 < p1; t0 += tpx) {
         const int cnt = (int)min((long long)tpx, p1 - t0);
         const long long pix0 = (long long)b * hw + t0;
@@ -429,14 +440,22 @@ __global__ __launch_bounds__(256) void unpool_bwd_kernel(const float* __restrict
 #pragma unroll
                 for (int ff = 0; ff < 64; ff += 8) {
                     if (ff < F) {
-                        float v[8];
-                        if (sizeof(T) == 2) { uint4 u = *(const uint4*)(row + ff); Chunk<bf16>::unpack(u, v); }
-                        else {
+                        if constexpr (sizeof(T) == 2) {
+                            const uint4 u = *(const uint4*)(row + ff);
+                            const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                bf16x2_t gv, fv;
+                                __builtin_memcpy(&gv, &w4[e], 4); __builtin_memcpy(&fv, &fpk[ff / 2 + e], 4);
+                                a = __builtin_amdgcn_fdot2_f32_bf16(gv, fv, a, false);
+                            }
+                        } else {
+                            float v[8];
                             uint4 u0 = *(const uint4*)(row + ff), u1 = *(const uint4*)((const float*)(row + ff) + 4);
                             Chunk<float>::unpack(u0, v); Chunk<float>::unpack(u1, v + 4);
-                        }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) a += v[e] * frr[ff + e];
+                            for (int e = 0; e < 8; ++e) a += v[e] * frr[ff + e];
+                        }
                     }
                 }
                 os[px * PP + c] = a;

@@ -271,6 +271,70 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, int lds, T* __re
     }
 }
 
+// ------------------------------------------------------------------ the other up-sampling methods of nn.upsample (N:820-849)
+// "subpixel": tf.depth_to_space(x, 2) of a [n,h,w,4C] convolution output: y[b, 2i+di, 2j+dj, c] = x[b, i, j, (2 di + dj) C + c].
+// C need not be a multiple of 8 (physical widths ldx / ldy are): element-wise, one thread per element of the RESULT; pad channels
+// are written as zero.  bwd = the inverse gather (space_to_depth of the gradient).
+template <typename T>
+__global__ void depth_to_space_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w, int C, int ldx, int ldy, int bwd) {
+    const long long total = bwd ? (long long)n * h * w * ldx : (long long)n * 4 * h * w * ldy;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (!bwd) {                       // dst = y [n, 2h, 2w, ldy]
+            const int c = (int)(idx % ldy);
+            long long r = idx / ldy;
+            const int x2 = (int)(r % (2 * w)); r /= 2 * w;
+            const int y2 = (int)(r % (2 * h));
+            const int b = (int)(r / (2 * h));
+            if (c < C) v = ld_as_float<T>(src + (((long long)b * h + (y2 >> 1)) * w + (x2 >> 1)) * ldx + ((y2 & 1) * 2 + (x2 & 1)) * C + c);
+        } else {                          // dst = gx [n, h, w, ldx], src = gy [n, 2h, 2w, ldy]
+            const int k = (int)(idx % ldx);
+            long long r = idx / ldx;
+            const int j = (int)(r % w); r /= w;
+            const int i = (int)(r % h);
+            const int b = (int)(r / h);
+            if (k < 4 * C) {
+                const int q = k / C, c = k - q * C;
+                v = ld_as_float<T>(src + (((long long)b * 2 * h + 2 * i + (q >> 1)) * (2 * w) + 2 * j + (q & 1)) * ldy + c);
+            }
+        }
+        st_from_float<T>(dst + idx, v);
+    }
+}
+// "nearest_neighbor": y[b, 2i+di, 2j+dj, :] = x[b, i, j, :]; bwd: gx = the sum of the four.  One thread per 16-byte chunk of x / gx.
+template <typename T>
+__global__ void nearest2x_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w, int c, int bwd) {
+    constexpr int E = V16<T>::N;
+    const int cc = c / E;
+    const long long total = (long long)n * h * w * cc;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % cc);
+        long long r = idx / cc;
+        const int j = (int)(r % w); r /= w;
+        const int i = (int)(r % h);
+        const int b = (int)(r / h);
+        const long long big = (((long long)b * 2 * h + 2 * i) * (2 * w) + 2 * j) * c + k * E;        // element (2i, 2j) of the 2x tensor
+        if (!bwd) {
+            const uint4 u = *(const uint4*)(src + idx * E);
+            *(uint4*)(dst + big) = u; *(uint4*)(dst + big + c) = u;
+            *(uint4*)(dst + big + (long long)2 * w * c) = u; *(uint4*)(dst + big + (long long)2 * w * c + c) = u;
+        } else {
+            float a[E], t[E];
+            V16<T>::ld(src + big, a);
+            V16<T>::ld(src + big + c, t);
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] += t[e];
+            V16<T>::ld(src + big + (long long)2 * w * c, t);
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] += t[e];
+            V16<T>::ld(src + big + (long long)2 * w * c + c, t);
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] += t[e];
+            V16<T>::st(dst + idx * E, a);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ crop window (perceptual_input: resize256_crop224)
 // fwd: y[n, i, j, :] = x[n, oy + i, ox + j, :] for the ho x wo window whose corner (oy, ox) is READ ON THE DEVICE (one random
 // window per step for the whole batch, tf.random_crop; a device scalar keeps the launch valid inside a captured HIP graph);
@@ -463,6 +527,29 @@ extern "C" int ups_bilinear2x_bwd_f8(const void* gy, void* gx, int32_t n, int32_
     F8Emit q; q.out = (unsigned char*)gx_f8; q.scale = scale; q.amax = amax; q.act = UPS_ACT_NONE; q.e5m2 = e5m2; q.slope = 0.f;
     hipLaunchKernelGGL((bilinear2x_bwd_kernel<bf16, true>), dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const bf16*)gy,
                        (bf16*)gx, n, h, w, c, q);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_depth_to_space(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t C, int32_t ldx,
+                                  int32_t ldy, int32_t bwd, void* stream) {
+    UPS_CHECK_ARG(src && dst && n > 0 && h > 0 && w > 0 && C > 0 && 4 * C <= ldx && C <= ldy);
+    const long long work = bwd ? (long long)n * h * w * ldx : (long long)n * 4 * h * w * ldy;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(depth_to_space_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)src, (float*)dst, n, h, w, C, ldx, ldy, bwd);
+    else if (dtype == UPS_BF16) hipLaunchKernelGGL(depth_to_space_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, n, h, w, C, ldx, ldy, bwd);
+    else if (dtype == UPS_F16) hipLaunchKernelGGL(depth_to_space_kernel<f16>, dim3(grid_for(work)), dim3(256), 0, s, (const f16*)src, (f16*)dst, n, h, w, C, ldx, ldy, bwd);
+    else { ups_set_error("bad dtype %d", (int)dtype); return UPS_E_ARG; }
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_nearest2x(const void* src, void* dst, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t bwd, void* stream) {
+    UPS_CHECK_ARG(src && dst && n > 0 && h > 0 && w > 0 && c % 8 == 0);
+    const long long work = (long long)n * h * w * (c / (dtype == UPS_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(nearest2x_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)src, (float*)dst, n, h, w, c, bwd);
+    else if (dtype == UPS_BF16) hipLaunchKernelGGL(nearest2x_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, n, h, w, c, bwd);
+    else if (dtype == UPS_F16 && !bwd) hipLaunchKernelGGL(nearest2x_kernel<f16>, dim3(grid_for(work)), dim3(256), 0, s, (const f16*)src, (f16*)dst, n, h, w, c, bwd);
+    else { ups_set_error("bad dtype %d", (int)dtype); return UPS_E_ARG; }
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

@@ -66,10 +66,17 @@ __device__ inline float tval(const float* t, int PP, int hp, int dq, int c, int 
 // for view 0, l_mean (same), l and hard; phase 1: one thread per pixel walks its parts (log-soft-max, entropy / CE, patch,
 // GMRF and the Mumford-Shah term r, which it leaves in the hard slot with the sign marking the contour branch); phase 2:
 // threads = (part, sub-lane) sum the columns of the staged tile into the per-part accumulators S, R, Rsmooth, Rcontour.
+// PC / LW: the part count and log2 of the image width as compile-time constants for the common shapes (0 / -1: run-time values).
+// (__logf / __expf / __fdividef: the hardware's log2 / exp2 / rcp, ~1e-7 relative -- two orders below the 1e-3 parity bar; the
+// libm forms are 15-20 VALU instructions each.)
+// These launches are VALU-bound (SQ counters, profiles/round4_pmc_part_kernels.txt: the vector ALU busy 60-80 % of the CU-busy
+// cycles): the item index -> (pixel, part) and pixel -> (row, column) divisions by run-time values were a third of the instructions.
+template <int PC, int LW>
 __global__ __launch_bounds__(256, 3) void prior_fwd_kernel(const PriorK p, int rows_per_slab, int tpx) {
     extern __shared__ __attribute__((aligned(16))) float ts[];
-    const int P = p.P, PP = tile_pitch(P);
-    const int halo = p.view == 0 ? p.w + 1 : 0;
+    const int P = PC > 0 ? PC : p.P, PP = tile_pitch(P);
+    const int W = LW >= 0 ? (1 << (LW >= 0 ? LW : 0)) : p.w;
+    const int halo = p.view == 0 ? W + 1 : 0;
     float* tm = ts;
     float* tlm = tm + (size_t)(tpx + halo) * PP;
     float* tl = tlm + (p.view == 0 ? (size_t)(tpx + halo) * PP : 0);
@@ -84,12 +91,12 @@ __global__ __launch_bounds__(256, 3) void prior_fwd_kernel(const PriorK p, int r
     if (p.view == 0 && p.px)
         for (int i = threadIdx.x; i < 2 * P; i += 256) cpx[i] = p.px[(long long)n * P * 2 + i];
     const int y0 = slab * rows_per_slab, y1 = max(y0, min(p.h, y0 + rows_per_slab));
-    const int hw = p.h * p.w;
+    const int hw = p.h * W;
     const long long img = (long long)n * hw;
     float kl = 0.f, ent = 0.f, patch = 0.f, gmrf = 0.f;
     float S = 0.f, R = 0.f, Rs = 0.f, Rc = 0.f;
     const int c2 = threadIdx.x % P, s2 = threadIdx.x / P;            // phase-2 role
-    const int q0 = y0 * p.w, q1 = y1 * p.w;
+    const int q0 = y0 * W, q1 = y1 * W;
     // software pipeline over the slab's tiles: all maps of a tile are requested at once (one HBM round trip, tile.h) and the NEXT
     // tile's pieces are in flight while the current one is computed
     TileReq<3> rm, rlm;         // (P <= 11 at 128-wide images: everything in one round trip; larger P: the rest synchronously)
@@ -123,37 +130,40 @@ __global__ __launch_bounds__(256, 3) void prior_fwd_kernel(const PriorK p, int r
                 float mx = -INFINITY;
                 for (int c = 0; c < P; ++c) mx = fmaxf(mx, lrow[c]);
                 float se = 0.f;
-                for (int c = 0; c < P; ++c) se += expf(lrow[c] - mx);
-                pst[px] = mx + logf(se);
+                for (int c = 0; c < P; ++c) se += __expf(lrow[c] - mx);
+                pst[px] = mx + __logf(se);
             }
             __syncthreads();
         }
+        // (items over all 256 threads -- exactly cnt * P / 256 each; the (part, pixel lane) form of the backward kernel measured
+        // 19 % slower here: 250 busy threads with 5 or 6 pixels each)
         const int items = cnt * P;
         for (int it = threadIdx.x; it < items; it += 256) {
             const int px = it / P, c = it - px * P;
-            const float mc = tm[px * PP + c];
-            kl += mc * logf((float)P * mc + 1e-20f);
+            const float* tmc = tm + px * PP + c;
+            const float mc = tmc[0];
+            kl += mc * __logf((float)P * mc + 1e-20f);
             if (p.view == 0) {
                 const int q = t0 + px;
-                const int yy = q / p.w, xx = q - yy * p.w;
+                const int yy = q / W, xx = q - yy * W;
+                const bool vr = xx + 1 < W, vd = yy + 1 < p.h;
                 const float sl = tl[px * PP + c] - pst[px];
                 const float hv = th[px * PP + c];
                 ent += -(p.entropy_ce ? hv : mc) * sl;
-                const float lm = tlm[px * PP + c];
+                const float* tlc = tlm + px * PP + c;
+                const float lm = tlc[0];
+                const float lr = vr ? tlc[PP] : 0.f, ld = vd ? tlc[W * PP] : 0.f;
                 if (p.variant == 0) {
                     const bool in_rect = abs(yy - cpx[2 * c]) <= p.half_h && abs(xx - cpx[2 * c + 1]) <= p.half_w;
                     patch += hv * (in_rect ? 0.f : 1.f);
                 } else {
                     // SB_model48c: Mumford-Shah on the noise-free logits, min(alpha * g, lambda) summed (patch slot)
-                    const float lr = tval(tlm, PP, px, 1, c, yy, xx + 1, p.h, p.w);
-                    const float ld = tval(tlm, PP, px, p.w, c, yy + 1, xx, p.h, p.w);
                     const float gw = 0.25f * (lm - lr), gh = 0.25f * (lm - ld);
                     patch += fminf(p.ms_alpha * (gw * gw + gh * gh), p.ms_lambda);
                 }
-                if (yy + 1 < p.h) { const float d = tlm[(px + p.w) * PP + c] - lm; gmrf += 0.5f * d * d; }
-                if (xx + 1 < p.w) { const float d = tlm[(px + 1) * PP + c] - lm; gmrf += 0.5f * d * d; }
-                const float mr = tval(tm, PP, px, 1, c, yy, xx + 1, p.h, p.w);
-                const float md = tval(tm, PP, px, p.w, c, yy + 1, xx, p.h, p.w);
+                if (vd) { const float d = ld - lm; gmrf += 0.5f * d * d; }
+                if (vr) { const float d = lr - lm; gmrf += 0.5f * d * d; }
+                const float mr = vr ? tmc[PP] : 0.f, md = vd ? tmc[W * PP] : 0.f;
                 const float gw = 0.25f * (mc - mr), gh = 0.25f * (mc - md);
                 const float g = p.ms_alpha * (gw * gw + gh * gh);
                 const float r = fminf(g, p.ms_lambda);
@@ -250,16 +260,18 @@ __global__ __launch_bounds__(256) void prior_finalize_kernel(const PriorK p) {
 // One block = one tile of tpx (<= 256) consecutive pixels of image blockIdx.y.  LDS: m and (view 0) l_mean with w pixels of
 // halo on either side, l / hard / g_hard own pixels only, the per-part constants of the image; the result tiles dl (in the l
 // slot) and dl_rec (in the g_hard slot) go back out with 16-byte stores.
+template <int PC, int LW>
 __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p, int tpx) {
     extern __shared__ __attribute__((aligned(16))) float ts[];
-    const int P = p.P, PP = tile_pitch(P);
-    const int hw = p.h * p.w;
+    const int P = PC > 0 ? PC : p.P, PP = tile_pitch(P);
+    const int W = LW >= 0 ? (1 << (LW >= 0 ? LW : 0)) : p.w;
+    const int hw = p.h * W;
     const int tiles = (hw + tpx - 1) / tpx;
     const int lb = xcd_logical_block();
     const int n = lb / tiles;
     const int t0 = (lb - n * tiles) * tpx;
     const int cnt = min(tpx, hw - t0);
-    const int halo = p.view == 0 ? p.w : 0;
+    const int halo = p.view == 0 ? W : 0;
     const int lo = max(0, t0 - halo), hi = min(hw, t0 + cnt + halo);
     const int off = t0 - lo;                       // tile pixel px sits at staged pixel px + off of the halo maps
     float* tm = ts;
@@ -302,13 +314,16 @@ __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p, int tpx)
     const long long npix_total = (long long)p.n * hw;
     const float inv_pix = 1.f / (float)npix_total, inv_n = 1.f / (float)p.n;
     const float a8 = p.ms_alpha * 0.125f, a16 = p.ms_alpha * 0.0625f;
-    const float sy = p.h > 1 ? 2.f / (float)(p.h - 1) : 0.f, sx = p.w > 1 ? 2.f / (float)(p.w - 1) : 0.f;
+    const float sy = p.h > 1 ? 2.f / (float)(p.h - 1) : 0.f, sx = W > 1 ? 2.f / (float)(W - 1) : 0.f;
     // Compute in four short phases (round 4).  The per-pixel form (one thread walks the P parts of its pixel: a serial chain of
     // ~150 dependent instructions per part with half the block idle at 128-pixel tiles) bounded the launch, not its bytes: the
     // element-wise work now runs on ITEMS (pixel, part) spread over all 256 threads (independent items per thread), only the
     // per-pixel reductions (log-sum-exp, the soft-max Jacobian's dot products) stay per pixel.
     float* pst = cst + P * 8;                                   // [tpx][4]: lse, qs, labsum | dot, dot_r
     const int items = cnt * P;
+    const int NS = 256 / P;                                     // pixel lanes of the (part, pixel lane) phases
+    const int s2 = threadIdx.x / P, c2 = threadIdx.x - s2 * P;
+    const int dyy = NS / W, dxx = NS - dyy * W;                 // pixel step NS in (row, column) form
     if (p.view == 0) {
         for (int px = threadIdx.x; px < cnt; px += 256) {       // A: per-pixel log-sum-exp, sum m * log-soft-max, sum of labels
             const float* mrow = tm + (px + off) * PP;
@@ -317,117 +332,130 @@ __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p, int tpx)
             float mx = -INFINITY;
             for (int c = 0; c < P; ++c) mx = fmaxf(mx, lrow[c]);
             float se = 0.f;
-            for (int c = 0; c < P; ++c) se += expf(lrow[c] - mx);
-            const float lse = mx + logf(se);
+            for (int c = 0; c < P; ++c) se += __expf(lrow[c] - mx);
+            const float lse = mx + __logf(se);
             float qs = 0.f, labsum = 0.f;
             for (int c = 0; c < P; ++c) { qs += mrow[c] * (lrow[c] - lse); labsum += hrow[c]; }
             pst[px * 4] = lse; pst[px * 4 + 1] = qs; pst[px * 4 + 2] = labsum;
         }
         __syncthreads();
-        for (int it = threadIdx.x; it < items; it += 256) {     // B: d loss / d m (-> hard slot) and the direct term (-> l slot)
-            const int px = it / P, c = it - px * P;
-            const int q = t0 + px;
-            const int yy = q / p.w, xx = q - yy * p.w;
-            const int hp = px + off;
-            const float mc = tm[hp * PP + c];
-            const float lse = pst[px * 4], qs = pst[px * 4 + 1], labsum = pst[px * 4 + 2];
-            const float sl = tl[px * PP + c] - lse;
-            const float hv = th[px * PP + c];
-            const float gh = p.g_hard ? tg[px * PP + c] : 0.f;
-            const float pm = (float)P * mc;
-            float gm = p.w_kl * inv_pix * (logf(pm + 1e-20f) + pm / (pm + 1e-20f)) + gh;
-            float direct = p.w_entropy * inv_pix * (-mc * (sl - qs));
-            if (p.entropy_ce) direct += p.w_entropy * inv_pix * (-(hv - mc * labsum));
-            const float* k = cst + c * 8;
-            if (p.variant == 0) {      // patch (STE)
-                const bool in_rect = abs(yy - (int)k[0]) <= p.half_h && abs(xx - (int)k[1]) <= p.half_w;
-                gm += p.w_patch * inv_n * (in_rect ? 0.f : 1.f);
-            }
-            // area + mumford-shah
-            gm += p.w_area * inv_n * 2.f * k[2];
-            const float m_r = tval(tm, PP, hp, 1, c, yy, xx + 1, p.h, p.w);
-            const float m_d = tval(tm, PP, hp, p.w, c, yy + 1, xx, p.h, p.w);
-            float dR = 0.f;
-            {   // own cell
-                const float g = a16 * ((mc - m_r) * (mc - m_r) + (mc - m_d) * (mc - m_d));
-                if (g <= p.ms_lambda) dR += a8 * ((mc - m_r) + (mc - m_d));
-            }
-            if (xx > 0) {   // left neighbour's cell: its right value is me
-                const float m_l = tval(tm, PP, hp, -1, c, yy, xx - 1, p.h, p.w);
-                const float m_ld = tval(tm, PP, hp, p.w - 1, c, yy + 1, xx - 1, p.h, p.w);
-                const float g = a16 * ((m_l - mc) * (m_l - mc) + (m_l - m_ld) * (m_l - m_ld));
-                if (g <= p.ms_lambda) dR -= a8 * (m_l - mc);
-            }
-            if (yy > 0) {   // upper neighbour's cell: its down value is me
-                const float m_u = tval(tm, PP, hp, -p.w, c, yy - 1, xx, p.h, p.w);
-                const float m_ur = tval(tm, PP, hp, -p.w + 1, c, yy - 1, xx + 1, p.h, p.w);
-                const float g = a16 * ((m_u - m_ur) * (m_u - m_ur) + (m_u - mc) * (m_u - mc));
-                if (g <= p.ms_lambda) dR -= a8 * (m_u - mc);
-            }
-            gm += p.w_ms * inv_n * 2.f * k[3] * dR;
-            // gmrf on the noise-free logits (same tensor path: l = l_mean + eps)
-            const float lm = tlm[hp * PP + c];
-            if (p.variant == 1) {
-                // SB_model48c: d/d l_mean of sum min(alpha * g(l_mean), lambda): the stencil above applied to the logits
-                const float l_r = tval(tlm, PP, hp, 1, c, yy, xx + 1, p.h, p.w);
-                const float l_d = tval(tlm, PP, hp, p.w, c, yy + 1, xx, p.h, p.w);
-                float dL = 0.f;
+        // B: d loss / d m (-> hard slot) and the direct term (-> l slot).  Thread = (part c, pixel lane): the part is FIXED per thread
+        // (its constants sit in registers, no item -> (pixel, part) division), the pixel coordinates advance incrementally, and the
+        // validity of the stencil neighbours is four flags per pixel instead of two range tests per tap.
+        if (s2 < NS) {
+            const float* kc = cst + c2 * 8;
+            const int rcy = (int)kc[0], rcx = (int)kc[1];
+            const float kS = kc[2], kR = kc[3];
+            int yy = (t0 + s2) / W, xx = (t0 + s2) - yy * W;
+            for (int px = s2; px < cnt; px += NS) {
+                const int c = c2;
+                const int hp = px + off;
+                const bool vr = xx + 1 < W, vd = yy + 1 < p.h, vl = xx > 0, vu = yy > 0;
+                const float* tmc = tm + hp * PP + c;
+                const float mc = tmc[0];
+                const float lse = pst[px * 4], qs = pst[px * 4 + 1], labsum = pst[px * 4 + 2];
+                const float sl = tl[px * PP + c] - lse;
+                const float hv = th[px * PP + c];
+                const float gh = p.g_hard ? tg[px * PP + c] : 0.f;
+                const float pm = (float)P * mc;
+                float gm = p.w_kl * inv_pix * (__logf(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh;
+                float direct = p.w_entropy * inv_pix * (-mc * (sl - qs));
+                if (p.entropy_ce) direct += p.w_entropy * inv_pix * (-(hv - mc * labsum));
+                if (p.variant == 0) {      // patch (STE)
+                    const bool in_rect = abs(yy - rcy) <= p.half_h && abs(xx - rcx) <= p.half_w;
+                    gm += p.w_patch * inv_n * (in_rect ? 0.f : 1.f);
+                }
+                // area + mumford-shah (cells: own, left neighbour's -- its right value is me --, upper neighbour's -- its down value is me)
+                gm += p.w_area * inv_n * 2.f * kS;
+                const float m_r = vr ? tmc[PP] : 0.f;
+                const float m_d = vd ? tmc[W * PP] : 0.f;
+                float dR = 0.f;
                 {
-                    const float g = a16 * ((lm - l_r) * (lm - l_r) + (lm - l_d) * (lm - l_d));
-                    if (g <= p.ms_lambda) dL += a8 * ((lm - l_r) + (lm - l_d));
+                    const float g = a16 * ((mc - m_r) * (mc - m_r) + (mc - m_d) * (mc - m_d));
+                    if (g <= p.ms_lambda) dR += a8 * ((mc - m_r) + (mc - m_d));
                 }
-                if (xx > 0) {
-                    const float l_l = tval(tlm, PP, hp, -1, c, yy, xx - 1, p.h, p.w);
-                    const float l_ld = tval(tlm, PP, hp, p.w - 1, c, yy + 1, xx - 1, p.h, p.w);
-                    const float g = a16 * ((l_l - lm) * (l_l - lm) + (l_l - l_ld) * (l_l - l_ld));
-                    if (g <= p.ms_lambda) dL -= a8 * (l_l - lm);
+                if (vl) {
+                    const float m_l = tmc[-PP];
+                    const float m_ld = vd ? tmc[(W - 1) * PP] : 0.f;
+                    const float g = a16 * ((m_l - mc) * (m_l - mc) + (m_l - m_ld) * (m_l - m_ld));
+                    if (g <= p.ms_lambda) dR -= a8 * (m_l - mc);
                 }
-                if (yy > 0) {
-                    const float l_u = tval(tlm, PP, hp, -p.w, c, yy - 1, xx, p.h, p.w);
-                    const float l_ur = tval(tlm, PP, hp, -p.w + 1, c, yy - 1, xx + 1, p.h, p.w);
-                    const float g = a16 * ((l_u - l_ur) * (l_u - l_ur) + (l_u - lm) * (l_u - lm));
-                    if (g <= p.ms_lambda) dL -= a8 * (l_u - lm);
+                if (vu) {
+                    const float m_u = tmc[-W * PP];
+                    const float m_ur = vr ? tmc[(1 - W) * PP] : 0.f;
+                    const float g = a16 * ((m_u - m_ur) * (m_u - m_ur) + (m_u - mc) * (m_u - mc));
+                    if (g <= p.ms_lambda) dR -= a8 * (m_u - mc);
                 }
-                direct += p.w_msl * inv_n * dL;
+                gm += p.w_ms * inv_n * 2.f * kR * dR;
+                // gmrf on the noise-free logits (same tensor path: l = l_mean + eps)
+                const float* tlc = tlm + hp * PP + c;
+                const float lm = tlc[0];
+                if (p.variant == 1) {
+                    // SB_model48c: d/d l_mean of sum min(alpha * g(l_mean), lambda): the stencil above applied to the logits
+                    const float l_r = vr ? tlc[PP] : 0.f;
+                    const float l_d = vd ? tlc[W * PP] : 0.f;
+                    float dL = 0.f;
+                    {
+                        const float g = a16 * ((lm - l_r) * (lm - l_r) + (lm - l_d) * (lm - l_d));
+                        if (g <= p.ms_lambda) dL += a8 * ((lm - l_r) + (lm - l_d));
+                    }
+                    if (vl) {
+                        const float l_l = tlc[-PP];
+                        const float l_ld = vd ? tlc[(W - 1) * PP] : 0.f;
+                        const float g = a16 * ((l_l - lm) * (l_l - lm) + (l_l - l_ld) * (l_l - l_ld));
+                        if (g <= p.ms_lambda) dL -= a8 * (l_l - lm);
+                    }
+                    if (vu) {
+                        const float l_u = tlc[-W * PP];
+                        const float l_ur = vr ? tlc[(1 - W) * PP] : 0.f;
+                        const float g = a16 * ((l_u - l_ur) * (l_u - l_ur) + (l_u - lm) * (l_u - lm));
+                        if (g <= p.ms_lambda) dL -= a8 * (l_u - lm);
+                    }
+                    direct += p.w_msl * inv_n * dL;
+                }
+                float gg = 0.f;
+                if (vu) gg += lm - tlc[-W * PP];
+                if (vd) gg -= tlc[W * PP] - lm;
+                if (vl) gg += lm - tlc[-PP];
+                if (vr) gg -= tlc[PP] - lm;
+                direct += p.w_gmrf * inv_n * gg;
+                th[px * PP + c] = gm; tl[px * PP + c] = direct;
+                xx += dxx; yy += dyy;
+                if (xx >= W) { xx -= W; ++yy; }
             }
-            float gg = 0.f;
-            if (yy > 0) gg += lm - tlm[(hp - p.w) * PP + c];
-            if (yy + 1 < p.h) gg -= tlm[(hp + p.w) * PP + c] - lm;
-            if (xx > 0) gg += lm - tlm[(hp - 1) * PP + c];
-            if (xx + 1 < p.w) gg -= tlm[(hp + 1) * PP + c] - lm;
-            direct += p.w_gmrf * inv_n * gg;
-            th[px * PP + c] = gm; tl[px * PP + c] = direct;
         }
     } else {
-        for (int it = threadIdx.x; it < items; it += 256) {     // B (view 1): d loss / d m -> l slot
-            const int px = it / P, c = it - px * P;
-            const int q = t0 + px;
-            const int yy = q / p.w, xx = q - yy * p.w;
-            const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
-            const float mc = tm[(px + off) * PP + c];
-            const float gh = p.g_hard ? tg[px * PP + c] : 0.f;
-            const float pm = (float)P * mc;
-            float gm = p.w_kl * inv_pix * (logf(pm + 1e-20f) + pm / (pm + 1e-20f)) + gh;
-            const float* k = cst + c * 8;
-            const float Z = k[3], muy = k[4], mux = k[5];
-            const float sq = expf(p.gamma * mc - k[2]) / Z;
-            if (p.variant == 1) {
-                // SB_model48c variance (DF:750-776): v_np = S00^2 + S11^2 of c = softmax_hw(gamma*m) (no rectangle,
-                // renormalised), S00 = Qy/Z - muy^2, S11 = Qx/Z - mux^2
-                const float Qyn = k[7], Qxn = k[6] - k[7];
-                const float S00 = Qyn - muy * muy, S11 = Qxn - mux * mux;
-                const float ay = gy * gy - 2.f * muy * gy - (Qyn - 2.f * muy * muy);
-                const float ax = gx * gx - 2.f * mux * gx - (Qxn - 2.f * mux * mux);
-                gm += p.w_var * inv_n * p.gamma * sq * 2.f * (S00 * ay + S11 * ax);
-            } else {
-                // variance: v_np = Q/Z - muy^2 - mux^2 over c = softmax_hw(gamma*m) * (1-rect)
-                const float Qn = k[6];
-                const float T = Qn - 2.f * muy * muy - 2.f * mux * mux;
-                const float kk = (abs(yy - (int)k[0]) <= p.half_h && abs(xx - (int)k[1]) <= p.half_w) ? 0.f : 1.f;
-                const float a = gy * gy + gx * gx - 2.f * muy * gy - 2.f * mux * gx;
-                gm += p.w_var * inv_n * p.gamma * sq * (a * kk - T);
+        if (s2 < NS) {                                          // B (view 1): d loss / d m -> l slot; thread = (part, pixel lane)
+            const float* kc = cst + c2 * 8;
+            const int rcy = (int)kc[0], rcx = (int)kc[1];
+            const float kmax = kc[2], rZ = __fdividef(1.f, kc[3]), muy = kc[4], mux = kc[5], k6 = kc[6], k7 = kc[7];
+            // SB_model48c variance (DF:750-776): v_np = S00^2 + S11^2 of c = softmax_hw(gamma*m) (no rectangle, renormalised),
+            // S00 = Qy/Z - muy^2, S11 = Qx/Z - mux^2;  SB_model48i: v_np = Q/Z - muy^2 - mux^2 over softmax_hw(gamma*m) * (1-rect)
+            const float Qyn = k7, Qxn = k6 - k7;
+            const float S00 = Qyn - muy * muy, S11 = Qxn - mux * mux;
+            const float T = k6 - 2.f * muy * muy - 2.f * mux * mux;
+            const float wv = p.w_var * inv_n * p.gamma * rZ;
+            int yy = (t0 + s2) / W, xx = (t0 + s2) - yy * W;
+            for (int px = s2; px < cnt; px += NS) {
+                const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
+                const float mc = tm[(px + off) * PP + c2];
+                const float gh = p.g_hard ? tg[px * PP + c2] : 0.f;
+                const float pm = (float)P * mc;
+                float gm = p.w_kl * inv_pix * (__logf(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh;
+                const float sq = __expf(p.gamma * mc - kmax);
+                if (p.variant == 1) {
+                    const float ay = gy * gy - 2.f * muy * gy - (Qyn - 2.f * muy * muy);
+                    const float ax = gx * gx - 2.f * mux * gx - (Qxn - 2.f * mux * mux);
+                    gm += wv * sq * 2.f * (S00 * ay + S11 * ax);
+                } else {
+                    const float kk = (abs(yy - rcy) <= p.half_h && abs(xx - rcx) <= p.half_w) ? 0.f : 1.f;
+                    const float a = gy * gy + gx * gx - 2.f * muy * gy - 2.f * mux * gx;
+                    gm += wv * sq * (a * kk - T);
+                }
+                tl[px * PP + c2] = gm;
+                xx += dxx; yy += dyy;
+                if (xx >= W) { xx -= W; ++yy; }
             }
-            tl[px * PP + c] = gm;
         }
     }
     __syncthreads();
@@ -472,6 +500,37 @@ PriorK to_k(const ups_prior_desc* d, float* ws) {
 
 }  // namespace
 
+// Launch KERNEL<PC, LW> for the descriptor's (P, w): specialised instances for the part counts of the shipped / benchmark configs and
+// 128- / 256-wide images, the generic <0, -1> instance otherwise.  (Every instance may need more than the 64 KB default of LDS.)
+template <typename K, typename... A>
+static int prior_launch_one(K kernel, bool& attr, dim3 grid, size_t shm, hipStream_t s, A... args) {
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return UPS_E_LAUNCH;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(256), shm, s, args...);
+    return UPS_OK;
+}
+#define UPS_PRIOR_CASE(KERNEL, PCV, LWV, ...)                                                            \
+    do { static bool at_ = false; const int rc_ = prior_launch_one(KERNEL<PCV, LWV>, at_, __VA_ARGS__); if (rc_ != UPS_OK) return rc_; } while (0)
+#define UPS_PRIOR_DISPATCH(KERNEL, grid, shm, ...)                                                       \
+    do {                                                                                                 \
+        const int lw_ = d->w == 128 ? 7 : (d->w == 256 ? 8 : -1);                                        \
+        const int pc_ = (d->P == 10 || d->P == 16 || d->P == 20 || d->P == 25) ? d->P : 0;              \
+        if (lw_ < 0 || pc_ == 0) UPS_PRIOR_CASE(KERNEL, 0, -1, grid, shm, s, __VA_ARGS__);               \
+        else if (lw_ == 7) {                                                                             \
+            if (pc_ == 10) UPS_PRIOR_CASE(KERNEL, 10, 7, grid, shm, s, __VA_ARGS__);                     \
+            else if (pc_ == 16) UPS_PRIOR_CASE(KERNEL, 16, 7, grid, shm, s, __VA_ARGS__);                \
+            else if (pc_ == 20) UPS_PRIOR_CASE(KERNEL, 20, 7, grid, shm, s, __VA_ARGS__);                \
+            else UPS_PRIOR_CASE(KERNEL, 25, 7, grid, shm, s, __VA_ARGS__);                               \
+        } else {                                                                                         \
+            if (pc_ == 10) UPS_PRIOR_CASE(KERNEL, 10, 8, grid, shm, s, __VA_ARGS__);                     \
+            else if (pc_ == 16) UPS_PRIOR_CASE(KERNEL, 16, 8, grid, shm, s, __VA_ARGS__);                \
+            else if (pc_ == 20) UPS_PRIOR_CASE(KERNEL, 20, 8, grid, shm, s, __VA_ARGS__);                \
+            else UPS_PRIOR_CASE(KERNEL, 25, 8, grid, shm, s, __VA_ARGS__);                               \
+        }                                                                                                \
+    } while (0)
+
 extern "C" size_t ups_prior_sums_floats(int32_t n, int32_t P) { return 16 + (size_t)n * NSLAB * 4 + (size_t)n * NSLAB * P * 4 + (size_t)n * 8; }
 
 // workspace convention: `sums` points at 16 floats followed by n*NSLAB*4 + n*NSLAB*P*4 + n*8 floats of scratch.
@@ -489,13 +548,7 @@ extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
     while (tpx > 32 && lds_fl(tpx) * 4 > 48 * 1024) tpx >>= 1;
     const size_t shm = lds_fl(tpx) * sizeof(float);
     UPS_CHECK_ARG(shm <= 160 * 1024);
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)prior_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return UPS_E_LAUNCH;
-        attr = true;
-    }
-    hipLaunchKernelGGL(prior_fwd_kernel, dim3(d->n * NSLAB), dim3(256), shm, s, k, rows, tpx);
+    UPS_PRIOR_DISPATCH(prior_fwd_kernel, dim3(d->n * NSLAB), shm, k, rows, tpx);
     UPS_LAUNCH_CHECK();
     hipLaunchKernelGGL(prior_finalize_img_kernel, dim3(d->n), dim3(256), 0, s, k);
     UPS_LAUNCH_CHECK();
@@ -515,14 +568,8 @@ extern "C" int ups_prior_bwd(const ups_prior_desc* d, void* stream) {
     while (tpx > 32 && lds_fl(tpx) * 4 > 56 * 1024) tpx >>= 1;
     const size_t shm = lds_fl(tpx) * sizeof(float);
     UPS_CHECK_ARG(shm <= 160 * 1024);
-    static bool attr = false;
-    if (!attr) {      // wide images (large w * P) can need more than the 64 KB default
-        if (hipFuncSetAttribute((const void*)prior_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return UPS_E_LAUNCH;
-        attr = true;
-    }
     const dim3 grid(ups_cdiv((long long)d->h * d->w, tpx) * d->n);
-    hipLaunchKernelGGL(prior_bwd_kernel, grid, dim3(256), shm, s, k, tpx);
+    UPS_PRIOR_DISPATCH(prior_bwd_kernel, grid, shm, k, tpx);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

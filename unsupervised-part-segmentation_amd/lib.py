@@ -90,6 +90,8 @@ _SIGS = {
     "ups_col_sum": ([_P, _I, _L, _I, _I, _P, _P, _P], C.c_int),
     "ups_bilinear2x_fwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "ups_bilinear2x_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "ups_depth_to_space": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], C.c_int),
+    "ups_nearest2x": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], C.c_int),
     "ups_crop_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "ups_crop_bwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "ups_bilinear2x_fwd_act": ([_P, _P, _I, _I, _I, _I, _I, _I, _F, _P], C.c_int),

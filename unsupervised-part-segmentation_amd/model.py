@@ -32,6 +32,7 @@ from .schedules import make_var, make_linear_var
 
 
 PERCEPTUAL_INPUTS = ("native", "resize256", "resize256_crop224")
+LATE_JOIN = os.environ.get("UPS_LATE_JOIN", "1") != "0"      # A/B switch: single rank joins the weight-gradient stream only before Adam
 
 
 def _scalar(v, device):
@@ -1082,6 +1083,11 @@ class Trainer(object):
         if getattr(self, "_cap", None) is not None:      # graph capture under data parallelism: a segment boundary
             if self.world_size > 1 or D.FORCE_COLLECTIVES:
                 self._boundary("grads", list(key_list))
+            return []
+        if self.world_size == 1 and not D.FORCE_COLLECTIVES and LATE_JOIN:
+            # a single rank has nothing to reduce: the launching stream need not wait for the weight-gradient stream here (it
+            # would idle whenever that stream lags); both meet before Adam (_finish_step).  The tensors the side stream reads
+            # stay referenced until then (ops.Streams.keep).
             return []
         ops.Streams.join(self.device, names=("wgrad",))
         bank = self.model.bank

@@ -203,6 +203,24 @@ class Scope(object):
         f8, ops.Fp8.last_out = ops.Fp8.last_out, None
         return Act(t, x.n, 2 * x.h, 2 * x.w, x.c, f8=f8)
 
+    def upsample(self, x, num_units, method="subpixel", post=False):
+        """nn.upsample (nn.py:820-849): "linear" (ignores num_units), "subpixel" (conv2d to 4 * num_units + depth_to_space),
+        "nearest_neighbor".  ("conv_transposed" -- the weight-normalised deconv2d of nn.py:938-1039 -- is not built.)"""
+        if method == "linear":
+            return self.upsample_linear(x, post=post)
+        if x.post:
+            raise L.UpsError("{}: up-sampling of a post-activation tensor".format(self.prefix))
+        if method == "subpixel":
+            y = self.conv2d(x, 4 * num_units)            # a variable of this scope (CoordConv included), no activation
+            if y.t is None:
+                return Act(None, x.n, 2 * x.h, 2 * x.w, num_units, fmt=self.fmt)
+            return Act(ops.DepthToSpaceFn.apply(y.t, num_units, self.fmt), x.n, 2 * x.h, 2 * x.w, num_units, fmt=self.fmt)
+        if method == "nearest_neighbor":
+            if x.t is None:
+                return Act(None, x.n, 2 * x.h, 2 * x.w, x.c, fmt=self.fmt)
+            return Act(ops.Nearest2xFn.apply(x.t, self.fmt), x.n, 2 * x.h, 2 * x.w, x.c, fmt=self.fmt)
+        raise NotImplementedError("upsample method '{}' (linear | subpixel | nearest_neighbor)".format(method))
+
     def act_mean(self, x):
         assert self.fmt is None, "act_mean has no fp16 form"
         if x.t is None:
@@ -230,8 +248,6 @@ def single_decoder_model(sc, z, n_out, config, upsample_config, out_f32=True):
     if isinstance(upsample_config, str):
         upsample_config = [upsample_config] * (len(config) - 1)
     assert len(upsample_config) == len(config) - 1
-    if any(u != "linear" for u in upsample_config):
-        raise NotImplementedError("only upsample method 'linear' is on the shipped path")
     c = config[-1]
     h = sc.nin(z, 4 * 4 * c)
     if h.t is not None:
@@ -241,17 +257,15 @@ def single_decoder_model(sc, z, n_out, config, upsample_config, out_f32=True):
         h = Act(None, h.n, 4, 4, c, fmt=h.fmt)
     h = sc.conv2d(h, c, post=True)
     h = sc.residual_block(h, post=True)                       # next: a residual block in either case
-    for _nf, _u in zip(config[-2::-1], upsample_config[-1::-1]):
-        h = sc.residual_block(h)                              # next: the (linear) up-sampling
-        h = sc.upsample_linear(h, post=True)
+    for nf, u in zip(config[-2::-1], upsample_config[-1::-1]):
+        h = sc.residual_block(h)                              # next: the up-sampling (plain input)
+        h = sc.upsample(h, nf, u, post=True)
     h = sc.residual_block(h)                                  # next: the plain output convolution
     return sc.conv2d(h, n_out, out_f32=out_f32)
 
 
 def hourglass_model(sc, x, config, extra_resnets, n_out=3, upsample_method="subpixel"):
     """model.py:80-131 with alpha = pi = None (model.py:91-92)."""
-    if upsample_method != "linear":
-        raise NotImplementedError("only upsample method 'linear' is on the shipped path")
     hs = []
     h = sc.conv2d(x, config[0], post=True)
     # (a block's output that also feeds a downsample keeps the plain form; the skip nin then activates on load)
@@ -262,9 +276,9 @@ def hourglass_model(sc, x, config, extra_resnets, n_out=3, upsample_method="subp
         hs.append(h)
     for _ in range(extra_resnets):
         h = sc.residual_block(h, post=True)
-    for i, _nf in enumerate(config[-2::-1]):
+    for i, nf in enumerate(config[-2::-1]):
         h = sc.residual_block(h, skipin=hs[-(i + 1)])
-        h = sc.upsample_linear(h, post=True)
+        h = sc.upsample(h, nf, upsample_method, post=True)
     h = sc.residual_block(h)
     return sc.conv2d(h, n_out)
 

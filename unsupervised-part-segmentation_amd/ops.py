@@ -912,6 +912,48 @@ class BilinearFn(torch.autograd.Function):
         return gx, None, None, None, None, None
 
 
+class DepthToSpaceFn(torch.autograd.Function):
+    """tf.depth_to_space(x, 2) of the "subpixel" up-sampling (nn.py:824-827): [n,h,w,ld(4C)] -> [n,2h,2w,round8(C)]."""
+
+    @staticmethod
+    def forward(ctx, x, C, fmt=None):
+        x = x.contiguous()
+        n, h, w, ldx = x.shape
+        y = torch.empty((n, 2 * h, 2 * w, round8(C)), dtype=x.dtype, device=x.device)
+        L.call("ups_depth_to_space", L.ptr(x), L.ptr(y), L.dt(x) if fmt is None else fmt, n, h, w, C, ldx, y.shape[-1], 0, L.stream())
+        ctx.dims = (n, h, w, C, ldx)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, C, ldx = ctx.dims
+        g = g.contiguous()
+        gx = torch.empty((n, h, w, ldx), dtype=g.dtype, device=g.device)
+        L.call("ups_depth_to_space", L.ptr(g), L.ptr(gx), L.dt(g), n, h, w, C, ldx, g.shape[-1], 1, L.stream())
+        return gx, None, None
+
+
+class Nearest2xFn(torch.autograd.Function):
+    """tf.image.resize_images(NEAREST_NEIGHBOR) to twice the size (nn.py:828-833): every pixel repeated 2x2."""
+
+    @staticmethod
+    def forward(ctx, x, fmt=None):
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+        L.call("ups_nearest2x", L.ptr(x), L.ptr(y), L.dt(x) if fmt is None else fmt, n, h, w, c, 0, L.stream())
+        ctx.dims = (n, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c = ctx.dims
+        g = g.contiguous()
+        gx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+        L.call("ups_nearest2x", L.ptr(g), L.ptr(gx), L.dt(g), n, h, w, c, 1, L.stream())
+        return gx, None
+
+
 class CropFn(torch.autograd.Function):
     """The ho x wo window of an NHWC tensor at the corner held in `yx` (int32 [2] ON THE DEVICE: no host sync, valid inside a
     captured HIP graph) -- `perceptual_input: resize256_crop224` (Trainer)."""
