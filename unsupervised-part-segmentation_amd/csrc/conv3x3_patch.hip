@@ -1314,6 +1314,14 @@ int launch_t(const PatchK& k, hipStream_t s) {
             return (patch_occ() == 2 && k.ci > 32 && tiles * ups_cdiv(k.co_fill, 64) >= 512) ? launch_v<T, 64, 2>(k, s)
                                                                                               : launch_v<T, 64, 1>(k, s);
         }
+        {   // few outputs over many input chunks (the P-channel logit convolution: 256 -> 10 at 128x128): the 32-wide instance keeps one
+            // block per CU busy with one exposed patch round trip per chunk; UPS_PATCH_THINOUT=64 / 128 tries the two-blocks-per-CU
+            // instances on it (three quarters / seven eighths of their MFMA columns idle, but the launch is latency-bound)
+            static int thinout = -1;
+            if (thinout < 0) { const char* e = getenv("UPS_PATCH_THINOUT"); thinout = e ? atoi(e) : 0; }
+            if (thinout == 64 && k.ci > 32 && patch_occ() == 2 && tiles >= 512) return launch_v<T, 64, 2>(k, s);
+            if (thinout == 128 && k.ci > 32 && patch_occ() == 2 && tiles >= 512 && !k.out_f8_amax) return launch_v<T, 128, 2>(k, s);
+        }
         return launch_v<T, 32, 1>(k, s);
     } else {
         if (k.co_fill > 64) return launch_bn<T, 128, 1, TS>(k, s);

@@ -33,6 +33,7 @@ from .schedules import make_var, make_linear_var
 
 PERCEPTUAL_INPUTS = ("native", "resize256", "resize256_crop224")
 LATE_JOIN = os.environ.get("UPS_LATE_JOIN", "1") != "0"      # A/B switch: single rank joins the weight-gradient stream only before Adam
+EARLY_ADAM = os.environ.get("UPS_EARLY_ADAM", "1") != "0"    # A/B switch: ... and queues each key's Adam behind its weight gradients
 
 
 def _scalar(v, device):
@@ -248,6 +249,7 @@ class Trainer(object):
         self._gen.manual_seed(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))      # TPS uniforms, crop window
         self._noise = ops.NoiseStream(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))  # the sampling noise
         self._lazy_logs, self._done_thunk = None, None
+        self._adam_done, self._step_graph_lr = set(), None
         self._losses = OrderedDict((k, None) for k in self.loss_keys())
         self._early, self._early_hooked = {}, False
         self._graph_enabled = bool(config.get("hip_graph", os.environ.get("UPS_GRAPH", "0") == "1"))
@@ -1003,6 +1005,7 @@ class Trainer(object):
         """One training step on the launching stream (+ the "pre", "aux" and "wgrad" side streams): forward A -> D (aux) -> B ->
         C, backward C -> priors -> B -> A, each optimizer key's bucket reduced as soon as its segment is complete, Adam, state."""
         dev = self.device
+        self._step_graph_lr, self._adam_done = graph_lr, set()
         c = self._step_begin(batch, noise)
         self._fwd_pose(c)
         if ops.Streams.enabled:
@@ -1086,8 +1089,18 @@ class Trainer(object):
             return []
         if self.world_size == 1 and not D.FORCE_COLLECTIVES and LATE_JOIN:
             # a single rank has nothing to reduce: the launching stream need not wait for the weight-gradient stream here (it
-            # would idle whenever that stream lags); both meet before Adam (_finish_step).  The tensors the side stream reads
-            # stay referenced until then (ops.Streams.keep).
+            # would idle whenever that stream lags); both meet before the end of the step (_finish_step).  The tensors the side
+            # stream reads stay referenced until then (ops.Streams.keep).  The keys' Adam updates are queued right BEHIND their
+            # weight gradients on that stream (EARLY_ADAM): the fp32 master weights are not read again this step -- every
+            # convolution works on the converted copies, refreshed once all keys have stepped -- so the 0.9 GB optimizer stream
+            # runs in the shadow of the remaining backward pass instead of on an otherwise empty chip at the end.
+            if EARLY_ADAM and ops.Streams.enabled and self._step_graph_lr is None:
+                side = ops.Streams.get("wgrad", self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))     # (critics: their gradients were taken on "aux", joined by now)
+                side.wait_stream(ops.Streams.get("wgrad2", self.device))     # (the CoordConv rows of these keys' weight gradients)
+                with torch.cuda.stream(side):
+                    self._adam(key_list, None)
+                self._adam_done.update(key_list)
             return []
         ops.Streams.join(self.device, names=("wgrad",))
         bank = self.model.bank
@@ -1101,12 +1114,9 @@ class Trainer(object):
             handles.append(D.allreduce_bucket(g, self.world_size, self.process_group))
         return handles
 
-    def _finish_step(self, keys, handles, graph_lr=None):
-        """Wait for the buckets, then one fused Adam launch per key (tf.train.AdamOptimizer semantics, Appendix A.12).
-        graph_lr: device scalar holding lr_t (HIP-graph mode; the python step counters then advance outside)."""
+    def _adam(self, keys, graph_lr):
+        """One fused TF-Adam launch per key on the current stream (Appendix A.12); advances the keys' step counters (eager mode)."""
         bank = self.model.bank
-        ops.Streams.join(self.device)
-        D.wait_all(handles)
         lr = self.learning_rate()
         for k in keys:
             grp = bank.groups[k]
@@ -1118,6 +1128,14 @@ class Trainer(object):
                 t = grp["t"]
                 lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
             ops.adam_step(f["p"], f["g"], f["m"], f["v"], lr_t, self.beta1, self.beta2, self.adam_eps, 1.0 / self.world_size)
+
+    def _finish_step(self, keys, handles, graph_lr=None):
+        """Wait for the buckets, then one fused Adam launch per key (tf.train.AdamOptimizer semantics, Appendix A.12).
+        graph_lr: device scalar holding lr_t (HIP-graph mode; the python step counters then advance outside)."""
+        ops.Streams.join(self.device)
+        D.wait_all(handles)
+        self._adam([k for k in keys if k not in self._adam_done], graph_lr)
+        self._adam_done = set()
         if graph_lr is None:
             ops.WeightVersion.value += 1
         self.model.nets.prep.refresh()          # one launch: every layer's converted weights + CoordConv tables

@@ -85,6 +85,8 @@ class Streams(object):
         if not cls.enabled:
             return
         cur = torch.cuda.current_stream(device)
+        if "wgrad" in names:
+            names = tuple(names) + ("wgrad2",)          # the CoordConv rows of the weight gradients (conv_wgrad) belong to it
         for n in names:
             st = cls._pool.get((n, torch.device(device).index))
             if st is not None and st != cur:
@@ -719,9 +721,16 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
     return gx if mask_view is None else g_hard
 
 
-def conv_wgrad(g, x, layer, mask=None, fmt=None):
+COORD_STREAM = os.environ.get("UPS_COORD_STREAM", "1") != "0"     # A/B switch: CoordConv rows of the weight gradients on their own stream
+
+
+def conv_wgrad(g, x, layer, mask=None, fmt=None, launch_stream=None):
     """(dV [kh,kw,cin_v,co] fp32, db [co] fp32).  mask = (hard_bits, P): x is the unmasked view of a part-masked convolution.
-    fmt = L.F16: x holds fp16 (converted to bf16, the gradient's type, while it is staged)."""
+    fmt = L.F16: x holds fp16 (converted to bf16, the gradient's type, while it is staged).
+    launch_stream: the stream whose position marks "g and x are ready" when the call itself runs on the weight-gradient side stream:
+    the CoordConv rows (batch sum of g + two small kernels: they write rows of dV the main kernel does not touch) then go to a
+    second side stream, beside the layer's main weight-gradient kernel instead of behind it -- the weight-gradient stream is a
+    serial chain that ends the step (tools/timeline.py), and these ~40 small launches were 1 ms of it."""
     n, hi, wi, ldi = x.shape
     if mask is not None:
         n = n * mask[1]
@@ -749,13 +758,21 @@ def conv_wgrad(g, x, layer, mask=None, fmt=None):
     d.splitk, d.workspace = sk.value, ws.data_ptr()
     L.call("ups_conv_wgrad", C.byref(d), L.stream())        # dV (main channels) + db from the same dout tiles
     if layer.coords:
-        gsum = torch.empty((ho * wo, layer.co), dtype=torch.float32, device=dev)
-        L.call("ups_batch_sum", L.ptr(g), dcode, n, ho * wo, layer.co, g.shape[-1], L.ptr(gsum), L.stream())
-        ax, ay = 2.0 / max(1, hi - 1), 2.0 / max(1, wi - 1)
-        scratch = COLSUM_WS.get((layer.k + 1) * 2 * wo * layer.co * 4, dev)
-        L.call("ups_coord_wgrad", L.ptr(gsum), hi, wi, ho, wo, layer.co, layer.k, layer.k,
-               (C.c_int32 * 9)(*dy), (C.c_int32 * 9)(*dx), layer.stride, layer.stride, ax, ay,
-               layer.ci_log, L.ptr(gV), None, L.ptr(scratch), L.stream())
+        def coord_rows():
+            gsum = torch.empty((ho * wo, layer.co), dtype=torch.float32, device=dev)
+            L.call("ups_batch_sum", L.ptr(g), dcode, n, ho * wo, layer.co, g.shape[-1], L.ptr(gsum), L.stream())
+            ax, ay = 2.0 / max(1, hi - 1), 2.0 / max(1, wi - 1)
+            scratch = COLSUM_WS.get((layer.k + 1) * 2 * wo * layer.co * 4, dev)
+            L.call("ups_coord_wgrad", L.ptr(gsum), hi, wi, ho, wo, layer.co, layer.k, layer.k,
+                   (C.c_int32 * 9)(*dy), (C.c_int32 * 9)(*dx), layer.stride, layer.stride, ax, ay,
+                   layer.ci_log, L.ptr(gV), None, L.ptr(scratch), L.stream())
+        if launch_stream is not None and COORD_STREAM and Streams.enabled:
+            s2 = Streams.get("wgrad2", dev)
+            s2.wait_stream(launch_stream)
+            with torch.cuda.stream(s2):
+                coord_rows()
+        else:
+            coord_rows()
     return gV, gb
 
 
@@ -819,8 +836,8 @@ class ConvFn(torch.autograd.Function):
                 side = Streams.get("wgrad", x.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask, fmt=ctx.fmt)
-                Streams.keep(x.device, g, x)      # alive until the launching stream has joined the side stream
+                    gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask, fmt=ctx.fmt, launch_stream=cur)
+                Streams.keep(x.device, g, x)      # alive until the launching stream has joined the side stream(s)
             else:
                 gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask, fmt=ctx.fmt)
             if layer.after_wgrad is not None:
