@@ -23,6 +23,13 @@ tfutils are absent and there is no network), so:
 Four externals are restated from their published behaviour and flagged
 UNVERIFIED where used: edflow ``VGG19Features`` (perceptual loss),
 ``tfutils.draw_rect``, the edflow per-key Adam wiring and ``eddata.utils.tps``
-(``tps.py``).  The DeepFashion variant (deepfashion/code/SB_model48c/model.py) is
+(``tps.py``).
+
+Open difference against the one log the reference ships (cub/train/log.txt:237-544; DESIGN.md section 5,
+``tools/pin_log.py``, profiles/round4_pin_log_*.txt): the restated trainer's mask statistics leave the logged windows after two
+Adam steps (``mask0_kl`` 3.9 against 0.92-1.08) for every data / TPS / step-alignment setting tried; scaling the mask decoder's
+learning rate by 0.03-0.1 reproduces all of them, ``bottleneck_loss`` included.  The optimizer wiring of
+cub/code/SB_model48i/model.py:739-742,786-815 as restated here (which variables each optimizer owns, the effective step size of the
+``decoder_visualize`` key) is therefore the SUSPECT, not the graph.  The DeepFashion variant (deepfashion/code/SB_model48c/model.py) is
 restated in the same module behind ``is_48c(config)``.
 """

@@ -13,6 +13,18 @@
 
 #include "common.h"
 
+#if defined(UPS_PHASE_TIMING)
+// debug build (tools/probes/phase_timing.sh): thread 0 of each block records the 100 MHz wall clock at phase boundaries and the
+// slot it ran in (HW_ID: CU / SE, XCC_ID, LDS base) -- where a block's life goes, which XCD ends when
+__device__ unsigned long long ups_phase_t[8 * 65536];
+extern "C" int ups_phase_dump(unsigned long long* host, int nblocks) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ups_phase_t), sizeof(unsigned long long) * 8 * (size_t)nblocks, 0, hipMemcpyDeviceToHost);
+}
+#define UPS_PHASE(k) do { if (threadIdx.x == 0 && blockIdx.x < 65536) ups_phase_t[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define UPS_PHASE(k)
+#endif
+
 namespace {
 
 constexpr int TS = 16;                 // tile side
@@ -288,6 +300,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values derived from it live in SGPRs
+    UPS_PHASE(0);
+#if defined(UPS_PHASE_TIMING)
+    if (threadIdx.x == 0 && blockIdx.x < 65536) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        const unsigned lb = __builtin_amdgcn_s_getreg((7 << 11) | 6);
+        ups_phase_t[blockIdx.x * 8 + 7] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)lb << 40);
+    }
+#endif
     const float act_ns = ups_slope_eff(p.act_in, p.act_slope);   // branch-free activation-on-load
     const float dact_ns = ups_slope_eff(p.dact_kind, p.act_slope); // act'(x) = x > 0 ? 1 : dact_ns (only used when dact != NULL)
     const float oact_ns = ups_slope_eff(p.out_act, p.act_slope);   // stored value = max(v, oact_ns * v) when out_act is set
@@ -720,6 +740,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             __builtin_amdgcn_s_barrier();
         }
         } else {
+        UPS_PHASE(1);
         if constexpr (DMAP) dma_patch(0);
         else { load_patch(0); store_patch(Abuf); }
         dma_w(0);
@@ -731,6 +752,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         if (one_shot) dma_w(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        UPS_PHASE(2);
         if (one_shot) {
             add_res_patch(Abuf, 0);
 #pragma unroll
@@ -880,6 +902,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
     }
 
+    UPS_PHASE(3);
     // ---- epilogue
 #if defined(UPS_ABLATE_EPI)
     {   // ablation build: keep the accumulators alive, write (almost) nothing
@@ -979,6 +1002,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 }
                 __syncthreads();
             }
+            UPS_PHASE(4);
             // Accumulator element e of acc16[i][j], lane (p16 = lane & 15, q16 = lane >> 4), is tile pixel (row wm*TM16 + i,
             // column p16), channel (wn*TN16 + j)*16 + 4*q16 + e of the N-tile: 4 consecutive channels per lane, so the
             // residual comes in and the result goes out with one 8-byte LDS access per (i, j).  The CoordConv term of an
@@ -986,6 +1010,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             // channel, the y part is one multiply-add; only tiles that touch the image border look the class table up, and
             // only for their border pixels.
             // (multi-image tiles: every pixel takes the class-table path; the folded terms are then unused)
+            const bool epi_vec = (p.co & 3) == 0 && ((((unsigned long long)p.bias) | ((unsigned long long)p.coord_tab)) & 15ull) == 0;
             const bool border_tile = p.coord_tab && (SUB < TS || ty0 == 0 || ty0 + TS >= p.h || tx0 == 0 || tx0 + TS >= p.w);
             const float xf = (float)(tx0 + p16);
             const int xq = xcoord(p16);
@@ -997,6 +1022,21 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 if (col >= p.co_fill) continue;          // co_fill is a multiple of 8: the 4 channels go together
                 float xs[4], t2v[4];
                 bool cv[4];
+                if (epi_vec) {
+                    // the lane's four channels are consecutive and 16-byte aligned in the bias vector and in every row of the class
+                    // table: one 16-byte load each instead of four (the 128-wide instances issued 64 dword loads per lane here)
+                    const bool ok = col < p.co;
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), t04 = b4, t14 = b4, t24 = b4;
+                    if (ok && p.bias) b4 = *(const float4*)(p.bias + col);
+                    if (ok && p.coord_tab) {
+                        const float* tb = p.coord_tab + (long long)63 * 3 * p.co + col;
+                        t04 = *(const float4*)tb; t14 = *(const float4*)(tb + p.co); t24 = *(const float4*)(tb + 2 * p.co);
+                    }
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, a0[4] = {t04.x, t04.y, t04.z, t04.w};
+                    const float a1[4] = {t14.x, t14.y, t14.z, t14.w}, a2[4] = {t24.x, t24.y, t24.z, t24.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { cv[e] = ok; t2v[e] = a2[e]; xs[e] = fmaf(xf, a1[e], bb[e] + a0[e]); }
+                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     cv[e] = col + e < p.co;
@@ -1008,6 +1048,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                         t0 = tb[0]; t1 = tb[p.co]; t2v[e] = tb[2 * p.co];
                     }
                     xs[e] = fmaf(xf, t1, bias + t0);
+                }
                 }
                 const int dsh = cl & 4;                  // the lane's 4 sign bits inside the tile's derivative byte
 #pragma unroll
@@ -1061,6 +1102,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 }
             }
             __syncthreads();
+            UPS_PHASE(5);
             if (p.mask_grad) {
                 // input gradient of the part-masked convolution, reduced to the hard mask: g_hard[b][y][x][part] =
                 // sum_c gx[c] * view[b][y][x][c] with gx rounded to the activation dtype first (as the tensor it replaces was)
@@ -1117,6 +1159,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 const float m = wave_max(of8_amax);
                 if (lane == 0) ups_amax_slot(p.out_f8_amax + (bid & 63), m);
             }
+            UPS_PHASE(6);
             return;
         }
     }
