@@ -160,52 +160,80 @@ __global__ void batch_sum_kernel(const T* __restrict__ d, int n, long long pix, 
 //   stage 1 (rows):  A[r][j][c] = sum_i valid_y(i,r) g[i][j][c],  B[r][j][c] = sum_i valid_y(i,r) (ay*y-1) g[i][j][c]
 //                    (r = kh: all rows, used for the bias)
 //   stage 2 (cols):  dVx[r][s][c] = sum_j valid_x(j,s) (ax*x-1) A[r][j][c],  dVy[r][s][c] = sum_j valid_x(j,s) B[r][j][c]
-__global__ void coord_rows_kernel(const float* __restrict__ g, int hi, int ho, int wo, int co, int kh, Taps3 tp, int in_sy,
-                                  float ay, float* __restrict__ scratch) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)wo * co) return;
-    float A[4] = {0.f, 0.f, 0.f, 0.f}, B[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < ho; ++i) {
-        const float v = g[(long long)i * wo * co + idx];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            if (r < kh) {
-                const int y = i * in_sy + (r == 0 ? tp.dy[0] : (r == 1 ? tp.dy[1] : tp.dy[2]));
-                if ((unsigned)y < (unsigned)hi) { A[r] += v; B[r] += (ay * (float)y - 1.f) * v; }
-            }
-        }
-        A[3] += v;
-    }
+// (round 4: both kernels ran one thread per output with a serial loop over the 128 rows / columns -- 16 blocks, 48 + 36 us per layer at
+// 128x128, and on the weight-gradient queue's tail at the end of the step nothing hides them.  Now 8 / 4 row groups per output,
+// combined through LDS in a fixed order: deterministic, 128 blocks, loads of a group independent of each other.)
+__global__ __launch_bounds__(256) void coord_rows_kernel(const float* __restrict__ g, int hi, int ho, int wo, int co, int kh, Taps3 tp,
+                                                         int in_sy, float ay, float* __restrict__ scratch) {
+    __shared__ float red[8][7][32];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const long long plane = (long long)wo * co;
+    const long long idx = (long long)blockIdx.x * 32 + o;
+    const bool ok = idx < plane;
+    float A[4] = {0.f, 0.f, 0.f, 0.f}, B[3] = {0.f, 0.f, 0.f};
+    if (ok) {
+#pragma unroll 4
+        for (int i = grp; i < ho; i += 8) {
+            const float v = g[(long long)i * plane + idx];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-        if (r < kh) { scratch[(2 * r) * plane + idx] = A[r]; scratch[(2 * r + 1) * plane + idx] = B[r]; }
-    scratch[(2 * kh) * plane + idx] = A[3];
+            for (int r = 0; r < 3; ++r) {
+                if (r < kh) {
+                    const int y = i * in_sy + (r == 0 ? tp.dy[0] : (r == 1 ? tp.dy[1] : tp.dy[2]));
+                    if ((unsigned)y < (unsigned)hi) { A[r] += v; B[r] += (ay * (float)y - 1.f) * v; }
+                }
+            }
+            A[3] += v;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { red[grp][2 * r][o] = A[r]; red[grp][2 * r + 1][o] = B[r]; }
+    red[grp][6][o] = A[3];
+    __syncthreads();
+    if (grp == 0 && ok) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            float t = red[0][q][o];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t += red[k][q][o];
+            if (q < 6) { if ((q >> 1) < kh) scratch[(long long)q * plane + idx] = t; }
+            else scratch[(2 * kh) * plane + idx] = t;
+        }
+    }
 }
 
-__global__ void coord_cols_kernel(const float* __restrict__ scratch, int wi, int wo, int co, int kh, int kw, Taps3 tp,
-                                  int in_sx, float ax, int ci_log, float* __restrict__ gV, float* __restrict__ gb) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void coord_cols_kernel(const float* __restrict__ scratch, int wi, int wo, int co, int kh, int kw, Taps3 tp,
+                                                         int in_sx, float ax, int ci_log, float* __restrict__ gV, float* __restrict__ gb) {
+    __shared__ float red[4][2][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const int tap = blockIdx.y;                  // kh*kw taps, then one extra block row for the bias
-    if (c >= co) return;
     const long long plane = (long long)wo * co;
-    if (tap == kh * kw) {
-        if (!gb) return;
-        float s = 0.f;
-        for (int j = 0; j < wo; ++j) s += scratch[(2 * kh) * plane + (long long)j * co + c];
-        gb[c] = s;
-        return;
-    }
-    const int r = tap / kw, s_ = tap % kw;
-    const int dxs = s_ == 0 ? tp.dx[0] : (s_ == 1 ? tp.dx[1] : tp.dx[2]);
+    const bool ok = c < co;
     float sx = 0.f, sy = 0.f;
-    for (int j = 0; j < wo; ++j) {
-        const int x = j * in_sx + dxs;
-        if ((unsigned)x < (unsigned)wi) {
-            sx += (ax * (float)x - 1.f) * scratch[(2 * r) * plane + (long long)j * co + c];
-            sy += scratch[(2 * r + 1) * plane + (long long)j * co + c];
+    if (tap == kh * kw) {
+        if (!gb) return;                         // (uniform)
+        if (ok) {
+#pragma unroll 4
+            for (int j = grp; j < wo; j += 4) sx += scratch[(2 * kh) * plane + (long long)j * co + c];
+        }
+    } else if (ok) {
+        const int r = tap / kw, s_ = tap % kw;
+        const int dxs = s_ == 0 ? tp.dx[0] : (s_ == 1 ? tp.dx[1] : tp.dx[2]);
+#pragma unroll 4
+        for (int j = grp; j < wo; j += 4) {
+            const int x = j * in_sx + dxs;
+            if ((unsigned)x < (unsigned)wi) {
+                sx += (ax * (float)x - 1.f) * scratch[(2 * r) * plane + (long long)j * co + c];
+                sy += scratch[(2 * r + 1) * plane + (long long)j * co + c];
+            }
         }
     }
+    red[grp][0][cl] = sx; red[grp][1][cl] = sy;
+    __syncthreads();
+    if (grp != 0 || !ok) return;
+    sx = (red[0][0][cl] + red[1][0][cl]) + (red[2][0][cl] + red[3][0][cl]);
+    sy = (red[0][1][cl] + red[1][1][cl]) + (red[2][1][cl] + red[3][1][cl]);
+    if (tap == kh * kw) { gb[c] = sx; return; }
     const int cin_v = ci_log + 2;
     gV[((long long)tap * cin_v + ci_log) * co + c] = sx;
     gV[((long long)tap * cin_v + ci_log + 1) * co + c] = sy;
@@ -413,10 +441,10 @@ extern "C" int ups_coord_wgrad(const float* gsum, int32_t hi, int32_t wi, int32_
     UPS_CHECK_ARG(gsum && gradV && scratch && kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3);
     const Taps3 tp = make_taps3(kh, kw, tap_dy, tap_dx);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(coord_rows_kernel, dim3(ups_cdiv((long long)wo * co, 256)), dim3(256), 0, s, gsum, hi, ho, wo, co, kh,
+    hipLaunchKernelGGL(coord_rows_kernel, dim3(ups_cdiv((long long)wo * co, 32)), dim3(256), 0, s, gsum, hi, ho, wo, co, kh,
                        tp, in_sy, ay, scratch);
     UPS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(coord_cols_kernel, dim3(ups_cdiv(co, 64), kh * kw + 1), dim3(64), 0, s, scratch, wi, wo, co, kh, kw,
+    hipLaunchKernelGGL(coord_cols_kernel, dim3(ups_cdiv(co, 64), kh * kw + 1), dim3(256), 0, s, scratch, wi, wo, co, kh, kw,
                        tp, in_sx, ax, ci_log, gradV, grad_bias);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
