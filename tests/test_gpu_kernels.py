@@ -187,6 +187,69 @@ def test_conv_stride2_forward_kernel(case, dev, monkeypatch):
         assert float(y[..., cout:].float().abs().max()) == 0.0
 
 
+ROWS_CASES = [
+    # n, h (= w for 64, w = 128 for 32 channels), channels, fmt
+    (3, 128, 32, "bf16"),       # encoder_1's first residual block on the part images (N:1042-1056 at 32 channels, 128x128)
+    (3, 64, 64, "bf16"),        # its second (64 channels, 64x64: two 32-channel planes, two output groups)
+    (2, 128, 32, "f16"),
+    (2, 64, 64, "f16"),
+]
+
+
+@pytest.mark.parametrize("case", ROWS_CASES)
+def test_conv_rows_kernel(case, dev, monkeypatch):
+    """conv3x3_rows.hip: the thin residual blocks as row streams (whole input rows by LDS-DMA into a ring, weights in registers).
+    The model routes only launches of >= 1024 row bands to it; UPS_ROWS_KERNEL=force takes the size gate away so that the parity
+    shapes stay small.  Forward (post-activation storage, residual from the resident centre row, stored activation) and input
+    gradient (flipped taps, act' from the stored forward input, residual gradient) against the fp64 oracle's autograd on the
+    rounded operands, and against the patch kernel (UPS_ROWS_KERNEL=0) on the same inputs."""
+    lib, ops, R = _mods()
+    n, h, c, fmt_name = case
+    w = 128 if c == 32 else 64
+    g = torch.Generator().manual_seed(700 + ROWS_CASES.index(case))
+    f16 = fmt_name == "f16"
+    TF = torch.float16 if f16 else torch.bfloat16
+    V = torch.randn(3, 3, c, c, generator=g) / math.sqrt(c * 9)
+    b = torch.randn(c, generator=g) * 0.1
+    lay = _layer(ops, lib, V, b, 3, 1, False, "leaky_relu", dev)
+    lay.f16 = f16
+    lay.in_post, lay.out_act = True, lib.ACT_LRELU
+    fmt = lib.F16 if f16 else None
+    xs = torch.nn.functional.leaky_relu(torch.randn(n, h, w, c, generator=g), 0.2).to(TF)      # the stored tensor: act(x)
+    xd = xs.to(dev).view(torch.bfloat16) if f16 else xs.to(dev)
+    gy = torch.randn(n, h, w, c, generator=g).to(torch.bfloat16)
+    gyd = gy.to(dev)
+
+    def run():
+        y = ops.conv_forward(xd, lay, res=xd, fmt=fmt, res_post=True)
+        gx = ops.conv_dgrad(gyd, xd, lay, res=gyd)
+        torch.cuda.synchronize()
+        return (y.view(torch.float16) if f16 else y).float().cpu(), gx.float().cpu()
+    monkeypatch.setenv("UPS_ROWS_KERNEL", "force")
+    y1, g1 = run()
+    y2, g2 = run()
+    monkeypatch.setenv("UPS_ROWS_KERNEL", "0")
+    y0, g0 = run()
+    assert torch.equal(y1, y2) and torch.equal(g1, g2), "not reproducible {}".format(case)
+    # oracle: out = act(conv(act(x)) + b + x) with x = act^-1(stored); gx = d<out_pre, gy>/dx
+    xo = xs.double()
+    xpre = torch.where(xo > 0, xo, xo / 0.2).requires_grad_(True)
+    Vo = V.to(TF).double()
+    pre = _oracle_conv(R, torch.nn.functional.leaky_relu(xpre, 0.2), Vo, b.double(), 1, False, None, False, None) + xpre
+    yo = torch.nn.functional.leaky_relu(pre, 0.2).detach()
+    # the input gradient's weights are the bf16 rounding of V in either format
+    xpre2 = xpre.detach().clone().requires_grad_(True)
+    pre2 = _oracle_conv(R, torch.nn.functional.leaky_relu(xpre2, 0.2), V.to(torch.bfloat16).double(), b.double(), 1, False, None, False, None) + xpre2
+    go, = torch.autograd.grad([pre2], [xpre2], grad_outputs=[gy.double()])
+    tol = F16_TOL if f16 else BF16_TOL
+    assert_close(y1, yo.float(), tol, "rows kernel forward vs oracle {}".format(case))
+    assert_close(y0, yo.float(), tol, "patch kernel forward vs oracle {}".format(case))
+    assert_close(g1, go.float(), BF16_TOL, "rows kernel input gradient vs oracle {}".format(case))
+    assert_close(g0, go.float(), BF16_TOL, "patch kernel input gradient vs oracle {}".format(case))
+    assert_close(y1, y0, 1e-2, "rows vs patch kernel forward {}".format(case))
+    assert_close(g1, g0, 1e-2, "rows vs patch kernel input gradient {}".format(case))
+
+
 F16_CASES = [c for c in CONV_CASES if c[6] == 1 and c[8] in (None, "leaky_relu")
              and c in ((2, 16, 16, 16, 16, 3, 1, True, "leaky_relu", True), (4, 1, 1, 16, 72, 1, 1, True, None, False),
                        (3, 32, 48, 64, 136, 3, 1, True, "leaky_relu", False), (2, 32, 32, 128, 128, 3, 1, True, "leaky_relu", True),

@@ -1,0 +1,288 @@
+// Row-streaming 3x3 / stride-1 'SAME' convolution for the THIN residual blocks of the encoders on large image batches
+// (cub/code/nn.py:1042-1056 at 32 / 64 channels: encoder_1 runs them on the P x B part images, 1.3 GB of tensor per launch for
+// 0.19 TFLOP -- HBM streams).  gfx950 only, 16-bit tensors.
+//
+// The patch-tiled kernel (conv3x3_patch.hip) runs these layers at 2.5 TB/s: a 16x16 tile is one block with its own prologue, its
+// own copy of the 3x3 weight set through LDS, one dependent HBM round trip for its halo patch and an epilogue -- 9.5 us of block
+// life for 0.5 us of MFMA work, 470 vector instructions per wave (tools/probes/phase_timing.py).  Here a block owns a band of 32
+// full-width image rows and streams them:
+//   * every input row is fetched ONCE, whole, by LDS-DMA (one 1 KiB global_load_lds_dwordx4 per wave and row) into a ring of NR row
+//     buffers [32-channel plane][pixel slot = x + 1][64 B] (slots 0 and W + 1 stay zero: the horizontal padding); the swizzle of the
+//     patch kernel is applied on the source side; rows are requested four (or eight) ahead of their use and waited for with a
+//     counted s_waitcnt -- the only block barrier is one per two output rows;
+//   * the wave's weights stay in REGISTERS for the whole band (9 taps x CI / 32 chunks x two 16-channel blocks: 72 / 144 VGPRs):
+//     no weight traffic and no B-fragment reads inside the loop;
+//   * a wave owns 16 columns x 32 output channels; per iteration it computes two output rows from four input rows: 12 A-fragment
+//     reads (ds_read_b128, conflict-free) for 36 MFMAs per 32-channel chunk (v_mfma_f32_16x16x32, weights as the row operand);
+//   * epilogue per row: bias, the residual from the resident centre row (res == in, stored post-activation: inverted on the way),
+//     the stored activation, 16-bit pack, a wave-private 1.25 KB LDS stage, one 1 KiB coalesced store per wave and row.
+// Input gradient of the same layers (DG): the operand is the gradient tensor, the taps are flipped, and the epilogue multiplies
+// by act'(x) -- the sign of the stored forward input, fetched row by row into a second small ring by the same DMA -- before the
+// residual gradient is added.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "../../include/upsparts_hip.h"
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+template <typename T> struct RFrag;
+template <> struct RFrag<bf16> { typedef bf16x8 type; };
+template <> struct RFrag<f16> { typedef f16x8 type; };
+
+struct RowsK {
+    const unsigned char* in; const unsigned char* w; unsigned char* out;
+    const float* bias; const unsigned char* dact;
+    int n, h, ldi, ldo, ldd, co_tot, band_rows, bands, res_self, res_act, out_act;
+    float slope, dact_ns;
+};
+
+// a row of zeros in global memory: input rows above / below the image are "fetched" from here, so that the loop has no row tests and
+// the number of DMAs per iteration is static (W * ldi * 2 <= 64 KiB is checked by the launcher)
+__device__ unsigned char ups_rows_zero[65536];
+
+__device__ __forceinline__ int r_swz(int P) { return ((P >> 2) & 1) << 1; }     // (g, g^2, g, g^2): conv3x3_patch.hip a_swz16
+
+// CI input channels (32 / 64), image width 1 << LW (128 / 64): 8 waves = (W / 16 column tiles) x (8 / (W / 16) groups of 32 outputs),
+// i.e. 32 outputs at W = 128, 64 at W = 64.  NR ring rows.  FLIP: the input gradient's tap order (dy = 1 - t / 3, dx = 1 - t % 3).
+template <typename T, int CI, int LW, int NR, bool FLIP, bool DG>
+__global__ __launch_bounds__(512, (CI == 32 && !DG && NR <= 8) ? 4 : 2) void conv3x3_rows_kernel(const RowsK p) {
+    constexpr int W = 1 << LW, KC = CI / 32, NCT = W / 16;
+    constexpr int PL = (W + 2) * 64;            // bytes of one 32-channel plane of a row
+    constexpr int RB = KC * PL;                 // bytes of a row buffer
+    constexpr int ST = 16 * 80;                 // wave-private output stage: 16 pixels x (64 + 16) bytes
+    constexpr int L = (NR - 4) / 2;             // iterations of lead of the row requests (NR = 2 L + 4)
+    constexpr int DR = DG ? 2 * L + 2 : 0;      // ring rows of the act' operand (W pixels x 64 B x output-channel planes; no halo)
+    constexpr int GS = DG ? 4 : 2;              // DMA instructions a wave issues per iteration
+    constexpr int NCG = 8 / NCT;                // output-channel groups of 32 = planes of the output / act' rows
+    constexpr int DRB = NCG * W * 64;
+    static_assert(KC * NCT == 8 && NCG * NCT == 8, "one DMA piece per wave and row");
+    typedef typename RFrag<T>::type frag_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;                              // NR x RB
+    unsigned char* dring = smem + NR * RB;                   // DR x DRB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* stage = smem + NR * RB + DR * DRB + wid * ST;
+    float* biasL = (float*)(smem + NR * RB + DR * DRB + 8 * ST);          // 64 floats
+    const int p16 = lane & 15, q16 = lane >> 4;
+    const int ct = wid % NCT, cg = wid / NCT;                // column tile, output-channel group (also: DMA segment, plane)
+    const int band = blockIdx.x % p.bands, img = blockIdx.x / p.bands;
+    const int y0 = band * p.band_rows;
+    const int y1 = min(p.h, y0 + p.band_rows);
+
+    // the halo slots of every ring row are zero for the whole kernel (the DMA never writes them)
+    for (int i = tid * 16; i < NR * RB; i += 512 * 16) *(uint4*)(ring + i) = make_uint4(0u, 0u, 0u, 0u);
+
+    // ---- weights into registers: fragment (tap t, chunk kc, block j) = rows cg * 32 + 16 j + p16 of slice t, 16-byte piece q16
+    frag_t wb[9][KC][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                wb[t][kc][j] = *(const frag_t*)(p.w + ((long long)(t * KC + kc) * p.co_tot + cg * 32 + 16 * j + p16) * 64 + q16 * 16);
+    if (tid < 64) biasL[tid] = (p.bias && tid < p.co_tot) ? p.bias[tid] : 0.f;
+    __syncthreads();
+
+    // ---- row DMA: wave (segment ct, plane cg) moves 16 pixels x 64 B of input row k (k = y - (y0 - 1)) into ring slot k % NR
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int Pd = 1 + 16 * ct + (lane >> 2);
+    const unsigned d_off = (unsigned)((16 * ct + (lane >> 2)) * p.ldi * 2 + cg * 64 + (((lane & 3) ^ r_swz(Pd)) << 4));
+    const unsigned char* in_img = p.in + (long long)img * p.h * W * p.ldi * 2;
+    const unsigned row_bytes = (unsigned)(W * p.ldi * 2);
+    // act' operand (DG): wave (segment ct, plane cg) moves 16 pixels x 64 B of row y of the forward input (no halo, no swizzle
+    // needed: the epilogue reads 8 bytes per lane at a 64-byte pixel pitch -- 2-way conflicts on a 4-instruction read)
+    const unsigned dd_off = (unsigned)((16 * ct + (lane >> 2)) * p.ldd * 2 + cg * 64 + ((lane & 3) << 4));
+    const unsigned char* da_img = DG ? p.dact + (long long)img * p.h * W * p.ldd * 2 : nullptr;
+    auto issue_row = [&](int k) __attribute__((always_inline)) {
+        const int y = y0 - 1 + k;
+        const unsigned char* src = (unsigned)y < (unsigned)p.h ? in_img + (long long)y * row_bytes : ups_rows_zero;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((k % NR) * RB + cg * PL + (1 + 16 * ct) * 64));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(d_off), "s"(src) : "memory", "m0");
+    };
+    auto issue_drow = [&](int ko) __attribute__((always_inline)) {          // ko = output row index inside the band
+        if constexpr (DG) {
+            const int y = min(y0 + ko, p.h - 1);
+            const unsigned char* src = da_img + (long long)y * (unsigned)(W * p.ldd * 2);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(NR * RB + (ko % DR) * DRB + cg * (W * 64) + 16 * ct * 64));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(dd_off), "s"(src) : "memory", "m0");
+        }
+    };
+    // prologue: what iterations -L .. -1 would have requested (iteration it requests the rows iteration it + L ends on)
+    issue_row(0); issue_row(1);
+#pragma unroll
+    for (int i = 0; i < L; ++i) { issue_row(2 * i + 2); issue_row(2 * i + 3); issue_drow(2 * i); issue_drow(2 * i + 1); }
+
+    const float oact_ns = ups_slope_eff(p.out_act, p.slope);
+    const float res_inv = p.res_act ? 1.f / p.slope : 1.f;
+    const int a_lane = (16 * ct + p16) * 64;            // + dx * 64 + swizzled piece
+    const int iters = (y1 - y0 + 1) >> 1;
+    unsigned char* out_img = p.out + (long long)img * p.h * W * p.ldo * 2;
+
+    for (int it = 0; it < iters; ++it) {
+        // The requests of iteration it - L (input rows up to 2 it + 3, act' rows 2 it, 2 it + 1) must have landed.  Younger operations
+        // that may stay in flight: the requests of iterations it - L + 1 .. it - 1 (GS each) and, from the first real iteration on,
+        // their two stores each (counted once: a lower bound that holds for every it >= 1)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS + 2) : "memory");
+        __builtin_amdgcn_s_barrier();
+        // the ring slots of input rows 2 it - 2, 2 it - 1 (and of the act' rows of iteration it - 1) are free now
+        issue_row(2 * it + 2 * L + 2);
+        issue_row(2 * it + 2 * L + 3);
+        issue_drow(2 * (it + L)); issue_drow(2 * (it + L) + 1);
+
+        f32x4v acc[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4v b4 = *(const f32x4v*)(biasL + cg * 32 + 16 * j + 4 * q16);
+            acc[0][j] = b4; acc[1][j] = b4;
+        }
+        const int yb = y0 + 2 * it;                       // first output row of the iteration; input row of ring index r4 = yb - 1 + r4
+        const unsigned char* rowp[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) rowp[r4] = ring + ((2 * it + r4) % NR) * RB;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int P = 16 * ct + p16 + dx;
+            const int aoff = a_lane + dx * 64 + ((q16 ^ r_swz(P)) << 4);
+            frag_t a[4][KC];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) a[r4][kc] = *(const frag_t*)(rowp[r4] + kc * PL + aoff);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int dyi = 0; dyi < 3; ++dyi) {
+                    const int t = FLIP ? (2 - dyi) * 3 + (2 - dx) : dyi * 3 + dx;
+#pragma unroll
+                    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            if constexpr (__is_same(T, bf16))
+                                acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[t][kc][j], a[r + dyi][kc], acc[r][j], 0, 0, 0);
+                            else
+                                acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][kc][j], a[r + dyi][kc], acc[r][j], 0, 0, 0);
+                        }
+                }
+        }
+        // ---- epilogue: lane (p16, q16) holds channels cg * 32 + 16 j + 4 q16 + e of pixel (row, 16 ct + p16)
+        const int Pc = 16 * ct + p16 + 1;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = yb + r;
+            if (y >= y1) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[r][j][e];
+                if constexpr (DG) {
+                    if (p.dact) {
+                        const uint2 dv = *(const uint2*)(dring + ((2 * it + r) % DR) * DRB + cg * (W * 64) + (16 * ct + p16) * 64 + (16 * j + 4 * q16) * 2);
+                        float d0, d1, d2, d3;
+                        ups_unpack2<T>(dv.x, d0, d1); ups_unpack2<T>(dv.y, d2, d3);
+                        v[0] *= d0 > 0.f ? 1.f : p.dact_ns; v[1] *= d1 > 0.f ? 1.f : p.dact_ns;
+                        v[2] *= d2 > 0.f ? 1.f : p.dact_ns; v[3] *= d3 > 0.f ? 1.f : p.dact_ns;
+                    }
+                }
+                if (p.res_self) {
+                    const int c32 = 16 * j + 4 * q16;
+                    const uint2 rr = *(const uint2*)(rowp[1 + r] + cg * PL + Pc * 64 + (((c32 >> 3) ^ r_swz(Pc)) << 4) + (q16 & 1) * 8);
+                    float r0, r1, r2, r3;
+                    ups_unpack2<T>(rr.x, r0, r1); ups_unpack2<T>(rr.y, r2, r3);
+                    if (p.res_act) {
+                        r0 = r0 > 0.f ? r0 : r0 * res_inv; r1 = r1 > 0.f ? r1 : r1 * res_inv;
+                        r2 = r2 > 0.f ? r2 : r2 * res_inv; r3 = r3 > 0.f ? r3 : r3 * res_inv;
+                    }
+                    v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+                }
+                if (p.out_act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ups_vmax(v[e], oact_ns * v[e]);
+                }
+                *(uint2*)(stage + p16 * 80 + (16 * j + 4 * q16) * 2) = make_uint2(Chunk<T>::pk(v[0], v[1]), Chunk<T>::pk(v[2], v[3]));
+            }
+            const uint4 o = *(const uint4*)(stage + (lane >> 2) * 80 + (lane & 3) * 16);
+            *(uint4*)(out_img + ((long long)y * W + 16 * ct + (lane >> 2)) * p.ldo * 2 + (cg * 32 + 8 * (lane & 3)) * 2) = o;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (outstanding row requests past the band target this block's LDS)
+}
+
+static int rows_on() {       // UPS_ROWS_KERNEL=0: these layers through the patch kernel (A/B runs); "force": also small batches (parity
+    const char* e = getenv("UPS_ROWS_KERNEL");      // tests); read per call
+    return (e && e[0] == '0') ? 0 : ((e && e[0] == 'f') ? 2 : 1);
+}
+
+template <typename T, int CI, int LW, int NR, bool FLIP, bool DG>
+int launch_rows(const RowsK& k, hipStream_t s) {
+    constexpr int W = 1 << LW, KC = CI / 32, NCT = W / 16, NCG = 8 / NCT;
+    constexpr size_t smem = (size_t)NR * KC * (W + 2) * 64 + (DG ? (size_t)(NR - 2) * NCG * W * 64 : 0) + 8 * 16 * 80 + 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_rows_kernel<T, CI, LW, NR, FLIP, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return UPS_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_rows_kernel<T, CI, LW, NR, FLIP, DG>), dim3(k.n * k.bands), dim3(512), smem, s, k);
+    return UPS_OK;
+}
+
+template <typename T>
+int launch_rows_t(const RowsK& k, int ci, int w, bool flip, bool dg, hipStream_t s) {
+    // ring depths: measured (tools/bench_conv.py ea_rb0 / ea_rb1): deeper rings at one block per CU lose to 8 rows at two blocks per CU
+    // (0.42 vs 0.35 ms forward at 32 channels); 64 channels keep 144 weight registers per lane and run one block per CU either way
+    if (ci == 32 && w == 128) {
+        if (dg) return flip ? launch_rows<T, 32, 7, 8, true, true>(k, s) : 1;
+        return flip ? launch_rows<T, 32, 7, 8, true, false>(k, s) : launch_rows<T, 32, 7, 8, false, false>(k, s);
+    }
+    if (ci == 64 && w == 64) {
+        if (dg) return flip ? launch_rows<T, 64, 6, 10, true, true>(k, s) : 1;
+        return flip ? launch_rows<T, 64, 6, 10, true, false>(k, s) : launch_rows<T, 64, 6, 10, false, false>(k, s);
+    }
+    return 1;
+}
+
+}  // namespace
+
+// Internal entry used by ups_conv_igemm's dispatcher (conv_igemm.hip).  Returns 1 if the problem is not eligible, 0 after a launch,
+// < 0 on a launch-setup failure.
+int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s) {
+    if (!rows_on()) return 1;
+    if (d->dtype != UPS_BF16 && d->dtype != UPS_F16) return 1;
+    if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox) return 1;
+    if (d->hi != d->ho || d->wi != d->wo || d->out_h != d->ho || d->out_w != d->wo) return 1;
+    if (!((d->ci == 32 && d->wi == 128) || (d->ci == 64 && d->wi == 64))) return 1;
+    const int co_need = d->wi == 128 ? 32 : 64;
+    if (d->co != co_need || d->co_fill != co_need || d->ldo < co_need || (d->ldo & 7) || (d->ldi & 7)) return 1;
+    if (d->hi % 32 || d->hi < 32) return 1;
+    if (rows_on() != 2 && (long long)d->n * (d->hi / 32) < 1024) return 1;      // small batches: the patch kernel's 16x16 tiles fill the chip better
+    if (d->act_in != UPS_ACT_NONE || d->coord_tab || d->mask_bits || d->mask_grad || d->d2s || d->f8_deq || d->in_f8 || d->out_f8 ||
+        d->out_f8_amax || d->out_f32)
+        return 1;
+    if (d->res && !(d->res == d->in && d->ldr == d->ldi && d->ci == d->co)) return 1;
+    bool fwd = true, flip = true;
+    for (int t = 0; t < 9; ++t) {
+        if (d->tap_w[t] != t) fwd = flip = false;
+        if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1) fwd = false;
+        if (d->tap_dy[t] != 1 - t / 3 || d->tap_dx[t] != 1 - t % 3) flip = false;
+    }
+    if (!fwd && !flip) return 1;
+    if (d->dact && (d->dtype != UPS_BF16 || !flip || (d->ldd & 7) || d->ldd < co_need)) return 1;
+    if ((long long)d->hi * d->wi * (d->ldi > d->ldo ? d->ldi : d->ldo) * 2 >= (1ll << 31) || (long long)d->wi * d->ldi * 2 > 65536) return 1;
+    RowsK k;
+    k.in = (const unsigned char*)d->in; k.w = (const unsigned char*)d->w; k.out = (unsigned char*)d->out;
+    k.bias = d->bias; k.dact = (const unsigned char*)d->dact;
+    k.n = d->n; k.h = d->hi; k.ldi = d->ldi; k.ldo = d->ldo; k.ldd = d->ldd; k.co_tot = d->co;
+    k.band_rows = 32; k.bands = d->hi / 32;
+    k.res_self = d->res != nullptr; k.res_act = d->res_act; k.out_act = d->out_act;
+    k.slope = d->act_slope; k.dact_ns = d->dact_kind == UPS_ACT_LRELU ? d->act_slope : 0.f;
+    const bool dg = d->dact != nullptr;
+    const int rc = d->dtype == UPS_F16 ? launch_rows_t<f16>(k, d->ci, d->wi, flip, dg, s) : launch_rows_t<bf16>(k, d->ci, d->wi, flip, dg, s);
+    return rc;
+}

@@ -468,6 +468,7 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
 int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_patch.hip
 int ups_conv3x3_first_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_first.hip
 int ups_conv3x3_s2_try(const ups_conv_desc* d, hipStream_t s);      // conv3x3_s2.hip
+int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s);    // conv3x3_rows.hip
 
 extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d != nullptr);
@@ -497,6 +498,12 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
             const int sr = ups_conv3x3_s2_try(d, (hipStream_t)stream);
             if (sr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
             if (sr < 0) { ups_set_error("ups_conv_igemm: stride-2 kernel launch setup failed"); return sr; }
+        }
+        // thin residual blocks on large batches of full-width rows: the row-streaming kernel
+        {
+            const int rr = ups_conv3x3_rows_try(d, (hipStream_t)stream);
+            if (rr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
+            if (rr < 0) { ups_set_error("ups_conv_igemm: row-streaming kernel launch setup failed"); return rr; }
         }
         const int pr = ups_conv3x3_patch_try(d, (hipStream_t)stream);
         if (pr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
