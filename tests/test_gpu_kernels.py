@@ -250,6 +250,45 @@ def test_conv_rows_kernel(case, dev, monkeypatch):
     assert_close(g1, g0, 1e-2, "rows vs patch kernel input gradient {}".format(case))
 
 
+ROWS_S2_CASES = [
+    # n, h = w, cin, cout, stored activation
+    (3, 128, 32, 64, False),     # encoder_1 / encoder_0 first downsample (N:816-817)
+    (3, 64, 64, 128, True),      # second downsample: two 32-channel planes, four output groups
+    (2, 128, 32, 64, True),
+]
+
+
+@pytest.mark.parametrize("case", ROWS_S2_CASES)
+def test_conv_rows_stride2_kernel(case, dev, monkeypatch):
+    """conv3x3_rows.hip, stride-2 form: the encoders' first two `downsample` forwards as row streams (even / odd pixel planes per
+    input row).  Against the fp64 oracle on the bf16-rounded operands and against the generic gather kernel on the same inputs."""
+    lib, ops, R = _mods()
+    n, h, cin, cout, out_act = case
+    g = torch.Generator().manual_seed(800 + ROWS_S2_CASES.index(case))
+    x = torch.randn(n, h, h, cin, generator=g).to(torch.bfloat16)
+    V = torch.randn(3, 3, cin, cout, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    yo = _oracle_conv(R, x.double(), V.to(torch.bfloat16).double(), b.double(), 2, False, None, False, None)
+    if out_act:
+        yo = torch.nn.functional.leaky_relu(yo, 0.2)
+    lay = _layer(ops, lib, V, b, 3, 2, False, None, dev)
+    if out_act:
+        lay.out_act = lib.ACT_LRELU
+    xd = x.to(dev)
+    monkeypatch.setenv("UPS_ROWS_KERNEL", "force")
+    y = ops.conv_forward(xd, lay)
+    y_again = ops.conv_forward(xd, lay)
+    monkeypatch.setenv("UPS_ROWS_KERNEL", "0")
+    monkeypatch.setenv("UPS_S2_KERNEL", "0")
+    y_gen = ops.conv_forward(xd, lay)
+    torch.cuda.synchronize()
+    assert y.shape == y_gen.shape == (n, h // 2, h // 2, cout)
+    assert torch.equal(y.view(torch.int16), y_again.view(torch.int16))
+    assert_close(y.float(), yo.float(), BF16_TOL, "row-streaming stride-2 kernel vs oracle {}".format(case))
+    assert_close(y_gen.float(), yo.float(), BF16_TOL, "generic kernel vs oracle {}".format(case))
+    assert_close(y.float(), y_gen.float(), 1e-2, "row-streaming stride-2 kernel vs generic kernel {}".format(case))
+
+
 F16_CASES = [c for c in CONV_CASES if c[6] == 1 and c[8] in (None, "leaky_relu")
              and c in ((2, 16, 16, 16, 16, 3, 1, True, "leaky_relu", True), (4, 1, 1, 16, 72, 1, 1, True, None, False),
                        (3, 32, 48, 64, 136, 3, 1, True, "leaky_relu", False), (2, 32, 32, 128, 128, 3, 1, True, "leaky_relu", True),

@@ -469,6 +469,7 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_p
 int ups_conv3x3_first_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_first.hip
 int ups_conv3x3_s2_try(const ups_conv_desc* d, hipStream_t s);      // conv3x3_s2.hip
 int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s);    // conv3x3_rows.hip
+int ups_conv3x3_rows_s2_try(const ups_conv_desc* d, hipStream_t s);
 
 extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d != nullptr);
@@ -494,6 +495,11 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
         // first layers (<= 8 input channels, 32 / 64 outputs): the im2col-in-the-fragment kernel, an output-write stream
         if (ups_conv3x3_first_try(d, (hipStream_t)stream) == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
         // the large 3x3 / stride-2 `downsample` forwards (32 / 64 input channels): taps straight from global memory, no gather
+        {
+            const int rr = ups_conv3x3_rows_s2_try(d, (hipStream_t)stream);      // (the two encoder shapes as row streams)
+            if (rr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
+            if (rr < 0) { ups_set_error("ups_conv_igemm: row-streaming stride-2 kernel launch setup failed"); return rr; }
+        }
         {
             const int sr = ups_conv3x3_s2_try(d, (hipStream_t)stream);
             if (sr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
