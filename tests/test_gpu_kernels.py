@@ -289,6 +289,59 @@ def test_conv_rows_stride2_kernel(case, dev, monkeypatch):
     assert_close(y.float(), y_gen.float(), 1e-2, "row-streaming stride-2 kernel vs generic kernel {}".format(case))
 
 
+THINOUT_CASES = [
+    # n, h, w, P, fmt, fp32 output, coords
+    (3, 128, 128, 10, "f16", True, True),       # decoder_visualize's logit convolution as the headline runs it (M:154)
+    (2, 64, 96, 16, "bf16", False, True),       # 16 outputs stored as bf16, non-square, three strips
+    (2, 32, 32, 3, "bf16", True, False),        # one strip, one band, three parts, no CoordConv
+    (1, 128, 256, 25, "f16", True, True),       # P = 25 does not fit 16 outputs: must fall through to the patch kernel
+]
+
+
+@pytest.mark.parametrize("case", THINOUT_CASES)
+def test_conv_thinout_kernel(case, dev, monkeypatch):
+    """conv3x3_rows.hip, K-deep thin-out form (256 -> P <= 16 channels, eight waves split K, partials summed through LDS): against
+    the fp64 oracle on the rounded operands and against the patch kernel (UPS_ROWS_KERNEL=0) on the same inputs."""
+    lib, ops, R = _mods()
+    n, h, w, P, fmt_name, out_f32, coords = case
+    g = torch.Generator().manual_seed(600 + THINOUT_CASES.index(case))
+    f16 = fmt_name == "f16"
+    TF = torch.float16 if f16 else torch.bfloat16
+    cin = 256
+    cin_v = cin + (2 if coords else 0)
+    x = torch.randn(n, h, w, cin, generator=g).to(TF)
+    V = torch.randn(3, 3, cin_v, P, generator=g) / math.sqrt(cin_v * 9)
+    b = torch.randn(P, generator=g) * 0.1
+    Vo = V.double().clone()
+    Vo[:, :, :cin] = V[:, :, :cin].to(TF).double()
+    yo = _oracle_conv(R, x.double(), Vo, b.double(), 1, coords, None, False, None)
+    lay = _layer(ops, lib, V, b, 3, 1, coords, None, dev)
+    lay.f16 = f16
+    fmt = lib.F16 if f16 else None
+    xd = x.to(dev).view(torch.bfloat16) if f16 else x.to(dev)
+
+    def run():
+        y = ops.conv_forward(xd, lay, out_f32=out_f32, fmt=fmt)
+        torch.cuda.synchronize()
+        if not out_f32:
+            y = (y.view(torch.float16) if f16 else y).float()
+        return y.cpu()
+    monkeypatch.setenv("UPS_ROWS_KERNEL", "force")
+    y1 = run()
+    y2 = run()
+    monkeypatch.setenv("UPS_ROWS_KERNEL", "0")
+    y0 = run()
+    assert torch.equal(y1, y2)
+    tol = (F16_TOL if f16 else BF16_TOL) / (1 if out_f32 else 1)
+    if not out_f32 and not f16:
+        tol = BF16_TOL
+    assert_close(y1[..., :P], yo.float(), tol, "thin-out kernel vs oracle {}".format(case))
+    assert_close(y0[..., :P], yo.float(), tol, "patch kernel vs oracle {}".format(case))
+    assert_close(y1[..., :P], y0[..., :P], 1e-2, "thin-out vs patch kernel {}".format(case))
+    if y1.shape[-1] > P:
+        assert float(y1[..., P:].abs().max()) == 0.0
+
+
 F16_CASES = [c for c in CONV_CASES if c[6] == 1 and c[8] in (None, "leaky_relu")
              and c in ((2, 16, 16, 16, 16, 3, 1, True, "leaky_relu", True), (4, 1, 1, 16, 72, 1, 1, True, None, False),
                        (3, 32, 48, 64, 136, 3, 1, True, "leaky_relu", False), (2, 32, 32, 128, 128, 3, 1, True, "leaky_relu", True),

@@ -40,8 +40,8 @@ struct RowsK {
 };
 
 // a row of zeros in global memory: input rows above / below the image are "fetched" from here, so that the loop has no row tests and
-// the number of DMAs per iteration is static (W * ldi * 2 <= 64 KiB is checked by the launcher)
-__device__ unsigned char ups_rows_zero[65536];
+// the number of DMAs per iteration is static (W * ldi * 2 <= 256 KiB is checked by the launchers)
+__device__ unsigned char ups_rows_zero[262144];
 
 __device__ __forceinline__ int r_swz(int P) { return ((P >> 2) & 1) << 1; }     // (g, g^2, g, g^2): conv3x3_patch.hip a_swz16
 
@@ -337,6 +337,163 @@ int launch_rows_s2(const RowsK& k, hipStream_t s) {
     return UPS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K-deep, thin-out form: the mask decoder's logit convolution 256 (+2 CoordConv) -> P <= 16 channels (cub/code/SB_model48i/model.py:154),
+// a 1.07 GB read for 84 MB of output.  The patch kernel ran it with one 32-channel patch chunk in flight per block -- 20 us of
+// dependent HBM round trips per tile (tools/probes/phase_timing.py), 2 TB/s.  Here a block owns a strip of 32 columns x 32 rows and
+// its eight waves split K: wave w streams the rows of ITS 32-channel plane (34 pixel slots with the halo) through a private ring --
+// its own DMA pieces, its own counted waits, no barrier for the input at all -- with the nine taps' weights of that plane in
+// registers (36 VGPRs), and computes a partial 32 pixels x 16 channels per output row (18 MFMAs for 18 fragment reads).  The eight
+// partials meet in LDS (double-buffered: one barrier per output row), thread (pixel, channel) adds them in a fixed order together with
+// bias and the CoordConv class-table term and stores fp32 or 16-bit.
+struct ThinK {
+    const unsigned char* in; const unsigned char* w; unsigned char* out;
+    const float* bias; const float* coord_tab;
+    int n, h, wd, ldi, ldo, co, co_fill, out_f32, strips, bands, band_rows;
+};
+
+template <typename T, int NR, int SW>        // SW: strip width (32: one block per CU; 16: two)
+__global__ __launch_bounds__(512, SW == 16 ? 4 : 2) void conv3x3_thinout_kernel(const ThinK p) {
+    constexpr int NSL = SW + 2, NC2 = SW / 16, NPC = (NSL + 15) / 16;        // pixel slots per plane row, column tiles, DMA pieces
+    constexpr int PLW = NSL * 64;               // bytes of one plane of a row
+    constexpr int RB = 8 * PLW;                 // eight planes = 256 channels
+    constexpr int L = NR - 3;                   // rows it .. it + 2 in use, L requested ahead
+    constexpr int RED = SW * 20;                // floats of one wave's partial row (pixel pitch 20 floats)
+    typedef typename RFrag<T>::type frag_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;
+    float* red = (float*)(smem + NR * RB);      // [2][8][RED]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, q16 = lane >> 4;
+    int t = blockIdx.x;
+    const int strip = t % p.strips; t /= p.strips;
+    const int band = t % p.bands; const int img = t / p.bands;
+    const int x0 = strip * SW, y0 = band * p.band_rows;
+    const int y1 = min(p.h, y0 + p.band_rows);
+
+    for (int i = tid * 16; i < NR * RB; i += 512 * 16) *(uint4*)(ring + i) = make_uint4(0u, 0u, 0u, 0u);
+    // the wave's weights: plane wid, co rows 0 .. 15 (rows past co repeat the last one; their outputs are never stored)
+    frag_t wb[9];
+    const int wrow = min(p16, p.co - 1);
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) wb[tp] = *(const frag_t*)(p.w + ((long long)(tp * 8 + wid) * p.co + wrow) * 64 + q16 * 16);
+    // the thread's output element in the reduction: (pixel px, channel co_t) of the current row; its bias and CoordConv terms for the
+    // three row classes (first row / interior / last row) of its column class
+    const int co_t = tid & 15, px_t = (tid >> 4) & (SW - 1);
+    const bool t_on = tid < SW * 16;            // threads that own an output element
+    const int xg = x0 + px_t;
+    const bool c_ok = co_t < p.co;
+    float bias_t = 0.f, ct0[3] = {0.f, 0.f, 0.f}, ct1[3] = {0.f, 0.f, 0.f}, ct2[3] = {0.f, 0.f, 0.f};
+    if (c_ok) {
+        if (p.bias) bias_t = p.bias[co_t];
+        if (p.coord_tab) {
+            const int xm = (xg > 0 ? 1 : 0) | 2 | (xg + 1 < p.wd ? 4 : 0);
+            const int yms[3] = {2 | 4, 7, 1 | 2};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* tb = p.coord_tab + (long long)(yms[c] * 8 + xm) * 3 * p.co + co_t;
+                ct0[c] = tb[0]; ct1[c] = tb[p.co]; ct2[c] = tb[2 * p.co];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- wave-private row DMA: three pieces of 16 pixel slots of plane wid
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned d_off[NPC];
+    unsigned long long d_mask[NPC];
+#pragma unroll
+    for (int q = 0; q < NPC; ++q) {
+        const int P = 16 * q + (lane >> 2), x = x0 - 1 + P;
+        const bool ok = P < NSL && (unsigned)x < (unsigned)p.wd;
+        d_off[q] = ok ? (unsigned)(x * p.ldi * 2 + wid * 64 + (((lane & 3) ^ r_swz(P)) << 4)) : 0u;
+        d_mask[q] = __ballot(ok);
+    }
+    const unsigned char* in_img = p.in + (long long)img * p.h * p.wd * p.ldi * 2;
+    const unsigned row_bytes = (unsigned)(p.wd * p.ldi * 2);
+    auto issue_row = [&](int k) __attribute__((always_inline)) {          // input row y0 - 1 + k
+        const int y = y0 - 1 + k;
+        const unsigned char* src = (unsigned)y < (unsigned)p.h ? in_img + (long long)y * row_bytes : ups_rows_zero;
+#pragma unroll
+        for (int q = 0; q < NPC; ++q) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((k % NR) * RB + wid * PLW + 16 * q * 64));
+            asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
+                         :: "s"(d_mask[q]), "s"(dst), "v"(d_off[q]), "s"(src) : "memory", "m0");
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < L + 2; ++k) issue_row(k);
+
+    const int iters = y1 - y0;
+    unsigned char* out_img = p.out + (long long)img * p.h * p.wd * p.ldo * (p.out_f32 ? 4 : 2);
+    auto finish_row = [&](int ir) __attribute__((always_inline)) {         // thread (px_t, co_t): the eight partials of output row y0 + ir
+        const float* all = red + (ir & 1) * 8 * RED + px_t * 20 + co_t;
+        float v = all[0];
+#pragma unroll
+        for (int w8 = 1; w8 < 8; ++w8) v += all[w8 * RED];
+        const int y = y0 + ir;
+        if (t_on && co_t < p.co_fill) {
+            v = c_ok ? v + bias_t : 0.f;          // (channels co .. co_fill - 1 of a 16-bit output are stored as zeros)
+            if (c_ok && p.coord_tab) {
+                const int c = y == 0 ? 0 : (y + 1 < p.h ? 1 : 2);
+                const float t0 = c == 0 ? ct0[0] : (c == 1 ? ct0[1] : ct0[2]);
+                const float t1 = c == 0 ? ct1[0] : (c == 1 ? ct1[1] : ct1[2]);
+                const float t2 = c == 0 ? ct2[0] : (c == 1 ? ct2[1] : ct2[2]);
+                v += t0 + (float)xg * t1 + (float)y * t2;
+            }
+            const long long o = ((long long)y * p.wd + xg) * p.ldo + co_t;
+            if (p.out_f32) ((float*)out_img)[o] = v;
+            else st_from_float<T>((T*)out_img + o, v);
+        }
+    };
+    for (int it = 0; it < iters; ++it) {
+        // rows it .. it + 2 of this wave's plane must have landed (row it + 2 was requested by iteration it - L); younger: the three
+        // requests of each of the L - 1 rows behind it and the stores issued since (every iteration ends with one: counted once)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * NPC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * NPC + 1) : "memory");
+        issue_row(it + L + 2);              // into the slot of row it - 1, whose last fragment reads fed the previous iteration's MFMAs
+        // four accumulator chains (two column tiles x two tap groups): nine dependent MFMAs per chain would leave the pipe idle
+        f32x4v acc[NC2][2];
+#pragma unroll
+        for (int c2 = 0; c2 < NC2; ++c2) { acc[c2][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[c2][1] = acc[c2][0]; }
+#pragma unroll
+        for (int dyi = 0; dyi < 3; ++dyi) {
+            const unsigned char* rowp = ring + ((it + dyi) % NR) * RB + wid * PLW;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int c2 = 0; c2 < NC2; ++c2) {
+                    const int P = 16 * c2 + p16 + dx;
+                    const frag_t a = *(const frag_t*)(rowp + P * 64 + ((q16 ^ r_swz(P)) << 4));
+                    const int gsel = (dyi * 3 + dx) & 1;
+                    if constexpr (__is_same(T, bf16)) acc[c2][gsel] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[dyi * 3 + dx], a, acc[c2][gsel], 0, 0, 0);
+                    else acc[c2][gsel] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[dyi * 3 + dx], a, acc[c2][gsel], 0, 0, 0);
+                }
+        }
+        float* mine = red + ((it & 1) * 8 + wid) * RED;
+#pragma unroll
+        for (int c2 = 0; c2 < NC2; ++c2) *(f32x4v*)(mine + (16 * c2 + p16) * 20 + 4 * q16) = acc[c2][0] + acc[c2][1];
+        __syncthreads();
+        finish_row(it);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename T, int SW>
+int launch_thinout(const ThinK& k, hipStream_t s) {
+    constexpr int NR = SW == 16 ? 6 : 7;
+    constexpr size_t smem = (size_t)NR * 8 * (SW + 2) * 64 + 2 * 8 * SW * 20 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_thinout_kernel<T, NR, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return UPS_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_thinout_kernel<T, NR, SW>), dim3(k.n * k.bands * k.strips), dim3(512), smem, s, k);
+    return UPS_OK;
+}
+
 static int rows_on() {       // UPS_ROWS_KERNEL=0: these layers through the patch kernel (A/B runs); "force": also small batches (parity
     const char* e = getenv("UPS_ROWS_KERNEL");      // tests); read per call
     return (e && e[0] == '0') ? 0 : ((e && e[0] == 'f') ? 2 : 1);
@@ -433,4 +590,36 @@ int ups_conv3x3_rows_s2_try(const ups_conv_desc* d, hipStream_t s) {
     k.res_self = 0; k.res_act = 0; k.out_act = d->out_act;
     k.slope = d->act_slope; k.dact_ns = 0.f;
     return d->ci == 32 ? launch_rows_s2<32, 7, 7>(k, s) : launch_rows_s2<64, 6, 9>(k, s);
+}
+
+// The logit convolution's forward: 256 input channels, <= 16 outputs, stride 1, no residual / activation; fp32 or 16-bit output.
+int ups_conv3x3_thinout_try(const ups_conv_desc* d, hipStream_t s) {
+    if (!rows_on()) return 1;
+    if (d->dtype != UPS_BF16 && d->dtype != UPS_F16) return 1;
+    if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox) return 1;
+    if (d->hi != d->ho || d->wi != d->wo || d->out_h != d->ho || d->out_w != d->wo) return 1;
+    if (d->ci != 256 || d->co > 16 || d->co_fill > d->ldo || d->co_fill < d->co || (d->ldi & 7) || d->ldi < 256) return 1;
+    if (d->out_f32 ? d->co_fill != d->co : ((d->ldo & 7) || d->co_fill > 16)) return 1;
+    if (d->hi % 32 || d->wi % 32) return 1;
+    if (d->act_in != UPS_ACT_NONE || d->res || d->dact || d->mask_bits || d->mask_grad || d->d2s || d->f8_deq || d->in_f8 || d->out_f8 ||
+        d->out_f8_amax || d->out_act || d->res_act)
+        return 1;
+    for (int t = 0; t < 9; ++t)
+        if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1 || d->tap_w[t] != t) return 1;
+    const long long blocks = (long long)d->n * (d->hi / 32) * (d->wi / 32);
+    if (rows_on() != 2 && blocks < 512) return 1;
+    if ((long long)d->wi * d->ldi * 2 + 1024 > 262144 || (long long)d->hi * d->wi * d->ldi * 2 >= (1ll << 31) || blocks >= (1ll << 31)) return 1;
+    ThinK k;
+    k.in = (const unsigned char*)d->in; k.w = (const unsigned char*)d->w; k.out = (unsigned char*)d->out;
+    k.bias = d->bias; k.coord_tab = d->coord_tab;
+    k.n = d->n; k.h = d->hi; k.wd = d->wi; k.ldi = d->ldi; k.ldo = d->ldo; k.co = d->co; k.co_fill = d->co_fill; k.out_f32 = d->out_f32;
+    k.strips = d->wi / 32; k.band_rows = 32; k.bands = d->hi / 32;
+    // UPS_THIN_SW=16: 16-column strips, two blocks per CU (measured equal to the 32-column form at one block per CU: 0.43 ms both;
+    // the 64-byte pieces at a 512-byte pixel pitch, not occupancy or prefetch depth, are what the launch is short of)
+    const char* e = getenv("UPS_THIN_SW");
+    if (e && e[0] == '1') {
+        k.strips = d->wi / 16;
+        return d->dtype == UPS_F16 ? launch_thinout<f16, 16>(k, s) : launch_thinout<bf16, 16>(k, s);
+    }
+    return d->dtype == UPS_F16 ? launch_thinout<f16, 32>(k, s) : launch_thinout<bf16, 32>(k, s);
 }
