@@ -188,11 +188,13 @@ def test_conv_stride2_forward_kernel(case, dev, monkeypatch):
 
 
 ROWS_CASES = [
-    # n, h (= w for 64, w = 128 for 32 channels), channels, fmt
+    # n, h (w = 128 for 32 channels, 64 for 64 channels), channels, fmt
     (3, 128, 32, "bf16"),       # encoder_1's first residual block on the part images (N:1042-1056 at 32 channels, 128x128)
     (3, 64, 64, "bf16"),        # its second (64 channels, 64x64: two 32-channel planes, two output groups)
     (2, 128, 32, "f16"),
     (2, 64, 64, "f16"),
+    (5, 32, 32, "bf16"),        # a single band per image (32 x 128): top and bottom zero rows in the same block
+    (1, 96, 64, "bf16"),        # three bands, non-square (96 x 64)
 ]
 
 

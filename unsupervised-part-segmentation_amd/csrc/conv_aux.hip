@@ -44,36 +44,65 @@ __host__ __device__ inline long long prep_elems(const ups_prep_item& it, int bk)
     return nf + nd + nc;
 }
 
-// one launch for all layers: block -> item by binary search in the block prefix
+// one launch for all layers: a 256-element chunk -> its item by binary search in the chunk prefix.  (Round 4: every block of the
+// first form searched the prefix in global memory -- eight dependent loads, ~4 us, before it converted its 256 elements: 243 447
+// blocks, 0.31 ms for 0.27 GB.  Now the prefix sits in LDS and a block converts CPB consecutive chunks.)
 template <typename T>
-__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const ups_prep_item* __restrict__ items,
-                                                                const long long* __restrict__ prefix, int n_items) {
+__device__ __forceinline__ void weight_prep_chunk(const ups_prep_item& it, long long blk0, float (*tile)[9]) {
     constexpr int BK = 64 / (int)sizeof(T);
-    int lo = 0, hi = n_items - 1;
-    const long long b = blockIdx.x;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (prefix[mid] <= b) lo = mid; else hi = mid - 1;
-    }
-    const ups_prep_item it = items[lo];
-    const long long idx = (b - prefix[lo]) * 256 + threadIdx.x;
+    const long long idx = blk0 + threadIdx.x;
     const int kcf = (it.ci_pad + BK - 1) / BK, kcd = (it.dgrad_k + BK - 1) / BK;
     const long long nf = it.w_fwd ? (long long)it.ntaps * kcf * it.co * BK : 0;
     const long long nd = it.w_dgrad ? (long long)it.ntaps * kcd * it.dgrad_rows * BK : 0;
     const long long nc = it.ctab ? (long long)64 * it.co : 0;
+    // forward layout [tap][k-chunk][co][BK]: the 256 outputs of a chunk are 8 output channels x 32 k of one (tap, k-chunk) -- a
+    // 32 x 8 patch of the [k][co] source: read along co, turned in LDS, written along k (16-bit layouts, co % 8 == 0)
+    if (sizeof(T) == 2 && (it.co & 7) == 0 && blk0 + 256 <= nf && nf < (1ll << 31)) {
+        unsigned t = (unsigned)(blk0 / BK);
+        const int c0 = (int)(t % (unsigned)it.co); t /= (unsigned)it.co;
+        const int kc = (int)(t % (unsigned)kcf), tap = (int)(t / (unsigned)kcf);
+        const int rk = threadIdx.x >> 3, rc = threadIdx.x & 7;
+        const int k = kc * BK + rk;
+        __syncthreads();                       // (the previous chunk's reads of the tile)
+        tile[rk][rc] = k < it.ci_log ? it.src[((long long)tap * it.cin_v + k) * it.co + c0 + rc] : 0.f;
+        __syncthreads();
+        st_from_float<T>((T*)it.w_fwd + idx, tile[threadIdx.x & 31][threadIdx.x >> 5]);
+        return;
+    }
+    // (32-bit index arithmetic where a layer's copies stay below 2^31 elements -- every layer of the shipped configs: 64-bit
+    // divisions by run-time values cost ~100 instructions each)
+    const bool small = nf + nd + nc < (1ll << 31);
     if (idx < nf) {
-        const int kk = (int)(idx % BK);
-        long long t = idx / BK;
-        const int c = (int)(t % it.co); t /= it.co;
-        const int kc = (int)(t % kcf), tap = (int)(t / kcf);
+        int kk, c, kc, tap;
+        if (small) {
+            const unsigned u = (unsigned)idx;
+            kk = (int)(u % BK);
+            unsigned t = u / BK;
+            c = (int)(t % (unsigned)it.co); t /= (unsigned)it.co;
+            kc = (int)(t % (unsigned)kcf); tap = (int)(t / (unsigned)kcf);
+        } else {
+            kk = (int)(idx % BK);
+            long long t = idx / BK;
+            c = (int)(t % it.co); t /= it.co;
+            kc = (int)(t % kcf); tap = (int)(t / kcf);
+        }
         const int k = kc * BK + kk;
         st_from_float<T>((T*)it.w_fwd + idx, k < it.ci_log ? it.src[((long long)tap * it.cin_v + k) * it.co + c] : 0.f);
     } else if (idx < nf + nd) {
         const long long j = idx - nf;
-        const int kk = (int)(j % BK);
-        long long t = j / BK;
-        const int r = (int)(t % it.dgrad_rows); t /= it.dgrad_rows;
-        const int kc = (int)(t % kcd), tap = (int)(t / kcd);
+        int kk, r, kc, tap;
+        if (small) {
+            const unsigned u = (unsigned)j;
+            kk = (int)(u % BK);
+            unsigned t = u / BK;
+            r = (int)(t % (unsigned)it.dgrad_rows); t /= (unsigned)it.dgrad_rows;
+            kc = (int)(t % (unsigned)kcd); tap = (int)(t / (unsigned)kcd);
+        } else {
+            kk = (int)(j % BK);
+            long long t = j / BK;
+            r = (int)(t % it.dgrad_rows); t /= it.dgrad_rows;
+            kc = (int)(t % kcd); tap = (int)(t / kcd);
+        }
         const int k = kc * BK + kk;
         st_from_float<T>((T*)it.w_dgrad + j, (k < it.co && r < it.ci_log) ? it.src[((long long)tap * it.cin_v + r) * it.co + k] : 0.f);
     } else if (idx < nf + nd + nc) {
@@ -97,6 +126,67 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const ups_prep_i
         it.ctab[((long long)cls * 3 + 0) * it.co + c] = k0;
         it.ctab[((long long)cls * 3 + 1) * it.co + c] = kj;
         it.ctab[((long long)cls * 3 + 2) * it.co + c] = ki;
+    }
+}
+
+constexpr int PREP_CPB = 16;        // chunks per block
+constexpr int PREP_LDS_ITEMS = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const ups_prep_item* __restrict__ items,
+                                                                const long long* __restrict__ prefix, int n_items, long long total_chunks) {
+    __shared__ long long spre[PREP_LDS_ITEMS];
+    __shared__ float tile[32][9];
+    __shared__ float tile4[32][33];
+    const bool in_lds = n_items <= PREP_LDS_ITEMS;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < n_items; i += 256) spre[i] = prefix[i];
+        __syncthreads();
+    }
+    const long long* pre = in_lds ? (const long long*)spre : prefix;
+    int lo = -1;
+    ups_prep_item it;
+    for (int j = 0; j < PREP_CPB; ++j) {
+        const long long b = (long long)blockIdx.x * PREP_CPB + j;
+        if (b >= total_chunks) break;
+        if (lo < 0 || (lo + 1 < n_items && pre[lo + 1] <= b)) {
+            int l = 0, h = n_items - 1;
+            while (l < h) {
+                const int mid = (l + h + 1) >> 1;
+                if (pre[mid] <= b) l = mid; else h = mid - 1;
+            }
+            lo = l;
+            it = items[lo];
+        }
+        // four aligned chunks of the forward layout = 32 output channels x 32 k of one (tap, k-chunk): read as 128-byte rows of the
+        // [k][co] source (the 8-channel form reads 32-byte pieces -- a quarter of a line each, of the 33152-wide head's rows above all)
+        constexpr int BK = 64 / (int)sizeof(T);
+        const long long c0i = b - pre[lo];
+        if (sizeof(T) == 2 && (it.co & 31) == 0 && (c0i & 3) == 0 && j + 4 <= PREP_CPB && b + 4 <= total_chunks && it.w_fwd &&
+            (((unsigned long long)it.src) & 15ull) == 0) {
+            const int kcf = (it.ci_pad + BK - 1) / BK;
+            const long long nf = (long long)it.ntaps * kcf * it.co * BK;
+            if ((c0i + 4) * 256 <= nf && nf < (1ll << 31)) {
+                unsigned t = (unsigned)(c0i * 256 / BK);
+                const int c0 = (int)(t % (unsigned)it.co); t /= (unsigned)it.co;
+                const int kc = (int)(t % (unsigned)kcf), tap = (int)(t / (unsigned)kcf);
+                const int rk = threadIdx.x >> 3, rc = (threadIdx.x & 7) * 4;
+                const int k = kc * BK + rk;
+                __syncthreads();
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < it.ci_log) v = *(const float4*)(it.src + ((long long)tap * it.cin_v + k) * it.co + c0 + rc);
+                tile4[rk][rc] = v.x; tile4[rk][rc + 1] = v.y; tile4[rk][rc + 2] = v.z; tile4[rk][rc + 3] = v.w;
+                __syncthreads();
+                T* dst = (T*)it.w_fwd + c0i * 256;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = q * 256 + threadIdx.x;         // element (c = e / 32, kk = e % 32) of the 32 x 32 unit
+                    st_from_float<T>(dst + e, tile4[e & 31][e >> 5]);
+                }
+                j += 3;
+                continue;
+            }
+        }
+        weight_prep_chunk<T>(it, c0i * 256, tile);
     }
 }
 
@@ -388,14 +478,14 @@ extern "C" int ups_weight_prep_batch(const ups_prep_item* items, const int64_t* 
                                      int64_t total_blocks, int32_t dtype, void* stream) {
     UPS_CHECK_ARG(items && block_prefix && n_items >= 1 && total_blocks >= 1 && total_blocks < 0x7fffffffLL);
     if (dtype == UPS_F32)
-        hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
-                           items, (const long long*)block_prefix, n_items);
+        hipLaunchKernelGGL(weight_prep_batch_kernel<float>, dim3((unsigned)ups_cdiv(total_blocks, PREP_CPB)), dim3(256), 0, (hipStream_t)stream,
+                           items, (const long long*)block_prefix, n_items, (long long)total_blocks);
     else if (dtype == UPS_F16)
-        hipLaunchKernelGGL(weight_prep_batch_kernel<f16>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
-                           items, (const long long*)block_prefix, n_items);
+        hipLaunchKernelGGL(weight_prep_batch_kernel<f16>, dim3((unsigned)ups_cdiv(total_blocks, PREP_CPB)), dim3(256), 0, (hipStream_t)stream,
+                           items, (const long long*)block_prefix, n_items, (long long)total_blocks);
     else
-        hipLaunchKernelGGL(weight_prep_batch_kernel<bf16>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
-                           items, (const long long*)block_prefix, n_items);
+        hipLaunchKernelGGL(weight_prep_batch_kernel<bf16>, dim3((unsigned)ups_cdiv(total_blocks, PREP_CPB)), dim3(256), 0, (hipStream_t)stream,
+                           items, (const long long*)block_prefix, n_items, (long long)total_blocks);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }
