@@ -1122,6 +1122,45 @@ def test_part_masked_convolution_matches_the_materialised_path(P, B, S, coords, 
     assert_close(res["fused"][0][..., :32].float(), yo.float(), BF16_TOL, "part-masked conv vs oracle")
 
 
+@pytest.mark.parametrize("P,B,H", [(10, 3, 128), (3, 4, 32), (25, 1, 64)])
+def test_part_mask_gradient_row_stream(P, B, H, dev, monkeypatch):
+    """conv3x3_rows.hip, mask-gradient form: d loss / d hard of encoder_1's part-masked first convolution (M:176-187) at 128 columns as a
+    row stream of the gradient tensor.  Against the patch kernel's epilogue (UPS_ROWS_KERNEL=0) on the same operands and against
+    the fp64 oracle's autograd through the materialised part images."""
+    lib, ops, R = _mods()
+    W = 128
+    g = torch.Generator().manual_seed(90 + P)
+    view = (torch.rand(B, H, W, 3, generator=g) * 2 - 1).to(dev)
+    mean = torch.randn(B, H, W, P, generator=g).to(dev)
+    _, m, hard, _, bits = ops.part_softmax(mean, None, want_bits=True)
+    V = torch.randn(3, 3, 3, 32, generator=g) / math.sqrt(27)
+    b = torch.randn(32, generator=g) * 0.1
+    T = torch.bfloat16
+    view_act = torch.zeros(B, H, W, 8, dtype=T, device=dev)
+    view_act[..., :3] = view.to(T)
+    gy = torch.randn(P * B, H, W, 32, generator=g).to(dev, T)
+    out = {}
+    for mode in ("force", "0"):
+        monkeypatch.setenv("UPS_ROWS_KERNEL", mode)
+        lay = _layer(ops, lib, V, b, 3, 1, False, None, dev)
+        h = hard.clone().requires_grad_(True)
+        y = ops.conv(view_act, lay, mask=(h, bits, view))
+        gh, = torch.autograd.grad([y], [h], grad_outputs=[gy])
+        torch.cuda.synchronize()
+        out[mode] = gh.cpu()
+    # (gx is rounded to bf16 before the dot product in both kernels; their fp32 tap sums differ in order, so a rounding flips now and then)
+    assert_close(out["force"], out["0"], 5e-3, "row-stream vs patch-kernel mask gradient")
+    # oracle: g_hard[b, y, x, p] = sum_c gx[p * B + b, y, x, c] * view[b, y, x, c], gx rounded to bf16 as the tensor it replaces was
+    vq = view.to(T).double().cpu()
+    parts = (vq.unsqueeze(3) * hard.double().cpu().unsqueeze(-1)).permute(3, 0, 1, 2, 4).reshape(P * B, H, W, 3).requires_grad_(True)
+    Vo = V.to(T).double()
+    yo = _oracle_conv(R, parts, Vo, b.double(), 1, False, None, False, None)
+    gx, = torch.autograd.grad([yo], [parts], grad_outputs=[gy.double().cpu()])
+    gx = gx.to(T).double().reshape(P, B, H, W, 3)
+    gho = (gx * view.double().cpu().unsqueeze(0)).sum(-1).permute(1, 2, 3, 0)
+    assert_close(out["force"], gho.float(), BF16_TOL, "row-stream mask gradient vs oracle")
+
+
 @pytest.mark.parametrize("case", [
     # n, h, cin, cout, coords, act, res_self
     (4, 32, 128, 128, False, "leaky_relu", True),

@@ -28,6 +28,7 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
+typedef __attribute__((ext_vector_type(3))) float f32x3v;
 template <typename T> struct RFrag;
 template <> struct RFrag<bf16> { typedef bf16x8 type; };
 template <> struct RFrag<f16> { typedef f16x8 type; };
@@ -215,6 +216,109 @@ __global__ __launch_bounds__(512, (CI == 32 && !DG && NR <= 8) ? 4 : 2) void con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Input gradient of the part-masked FIRST convolution of encoder_1 (cub/code/SB_model48i/model.py:176-187: the P x B part images
+// are view[b] * hard[b, :, :, p], never materialised), reduced to the hard mask on the way out:
+//     g_hard[b][y][x][p] = sum_c bf16(gx[p * B + b][y][x][c]) * view[b][y][x][c],   gx = conv^T(gy)  (3 view channels),
+// the contraction conv3x3_patch.hip's mask_grad epilogue does per 16x16 tile (0.39 ms for a 0.67 GB read).  Row stream of the
+// 32-channel gradient tensor, one 16-channel output block per wave (channels 0 .. 2 used), flipped taps; lanes q16 == 0 hold the
+// pixel's three channels and write one float each.
+struct MaskGK {
+    const unsigned char* in; const unsigned char* w; const float* view; float* g_hard;
+    int n, h, ldi, co, B, P, band_rows, bands;
+};
+
+template <int NR>
+__global__ __launch_bounds__(512, 4) void conv3x3_rows_maskgrad_kernel(const MaskGK p) {
+    constexpr int W = 128, PL = (W + 2) * 64, RB = PL;
+    constexpr int L = (NR - 4) / 2;
+    static_assert(L == 2, "the counted waits below are written for a lead of two iterations");
+    typedef bf16x8 frag_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);          // column tile = DMA segment
+    const int p16 = lane & 15, q16 = lane >> 4;
+    const int band = blockIdx.x % p.bands, img = blockIdx.x / p.bands;       // img = part * B + b (part-major)
+    const int part = img / p.B, b = img - part * p.B;
+    const int y0 = band * p.band_rows, y1 = min(p.h, y0 + p.band_rows);
+    for (int i = tid * 16; i < NR * RB; i += 512 * 16) *(uint4*)(ring + i) = make_uint4(0u, 0u, 0u, 0u);
+    frag_t wb[9];
+    const int wrow = min(p16, p.co - 1);         // rows past co repeat the last one; those outputs are not used
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wb[t] = *(const frag_t*)(p.w + ((long long)t * p.co + wrow) * 64 + q16 * 16);
+    __syncthreads();
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int Pd = 1 + 16 * ct + (lane >> 2);
+    const unsigned d_off = (unsigned)((16 * ct + (lane >> 2)) * p.ldi * 2 + (((lane & 3) ^ r_swz(Pd)) << 4));
+    const unsigned char* in_img = p.in + (long long)img * p.h * W * p.ldi * 2;
+    const unsigned row_bytes = (unsigned)(W * p.ldi * 2);
+    auto issue_row = [&](int k) __attribute__((always_inline)) {
+        const int y = y0 - 1 + k;
+        const unsigned char* src = (unsigned)y < (unsigned)p.h ? in_img + (long long)y * row_bytes : ups_rows_zero;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((k % NR) * RB + (1 + 16 * ct) * 64));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(d_off), "s"(src) : "memory", "m0");
+    };
+    issue_row(0); issue_row(1);
+#pragma unroll
+    for (int i = 0; i < L; ++i) { issue_row(2 * i + 2); issue_row(2 * i + 3); }
+    const float* view_img = p.view + (long long)b * p.h * W * p.co;
+    float* gh_img = p.g_hard + (long long)b * p.h * W * p.P + part;
+    const int iters = (y1 - y0 + 1) >> 1;
+    for (int it = 0; it < iters; ++it) {
+        // Per iteration a wave issues, in this order: two view loads (the three fp32 view channels of its pixel in the two output rows;
+        // inline asm like the DMAs -- a compiler-visible load would be waited for with vmcnt(0), i.e. together with every row request
+        // in flight), two row requests, two stores.  The requests of iteration it - L must have landed here: younger operations are
+        // the other prologue requests (it == 0) or at least the previous iteration's six (it >= 1).
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * 6) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const int x = 16 * ct + p16;
+        f32x3v vw[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = min(y0 + 2 * it + r, p.h - 1);
+            const float* vp = view_img + ((long long)y * W + x) * p.co;
+            asm volatile("global_load_dwordx3 %0, %1, off" : "=&v"(vw[r]) : "v"(vp) : "memory");
+        }
+        issue_row(2 * it + 2 * L + 2);
+        issue_row(2 * it + 2 * L + 3);
+        f32x4v acc[2];
+        acc[0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+        const unsigned char* rowp[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) rowp[r4] = ring + ((2 * it + r4) % NR) * RB;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int P = 16 * ct + p16 + dx;
+            const int aoff = P * 64 + ((q16 ^ r_swz(P)) << 4);
+            frag_t a[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) a[r4] = *(const frag_t*)(rowp[r4] + aoff);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int dyi = 0; dyi < 3; ++dyi)
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[(2 - dyi) * 3 + (2 - dx)], a[r + dyi], acc[r], 0, 0, 0);
+        }
+        // the view values: the two row requests issued behind them may stay in flight
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(vw[0]), "+v"(vw[1]) :: "memory");
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = y0 + 2 * it + r;
+            float s = (float)(bf16)acc[r][0] * vw[r][0];
+            if (p.co > 1) s += (float)(bf16)acc[r][1] * vw[r][1];
+            if (p.co > 2) s += (float)(bf16)acc[r][2] * vw[r][2];
+            // (every wave stores in every iteration -- a static count for the waits above; rows past the band and the lanes that
+            // hold other channels write nothing)
+            float* dst = gh_img + ((long long)min(y, p.h - 1) * W + x) * p.P;
+            const bool on = y < y1 && q16 == 0;
+            asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dword %1, %2, off\n\ts_mov_b64 exec, -1" :: "s"(__ballot(on)), "v"(dst), "v"(s) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // The same stream for the 3x3 / STRIDE-2 `downsample` forwards (cub/code/nn.py:816-817) of even-sized images ('SAME': taps at input
 // rows 2 y .. 2 y + 2, columns 2 x .. 2 x + 2, zero beyond the image).  A row buffer holds the even and the odd pixels of an input row
 // in separate planes [32-channel plane][parity][slot = x / 2][64 B] (+ one zero slot behind the even plane: pixel W of the last column
@@ -352,6 +456,28 @@ struct ThinK {
     int n, h, wd, ldi, ldo, co, co_fill, out_f32, strips, bands, band_rows;
 };
 
+// (no lambdas and no local arrays besides fragments in this kernel: with closures capturing by reference hipcc kept the argument struct
+// and the epilogue constants in scratch, and every scratch access is a vector-memory operation whose wait drains the row requests)
+#define UPS_THIN_DMA(SRC, DST, OFF, MLO, MHI)                                                                                      \
+    do {                                                                                                                         \
+        const unsigned long long msk_ = ((unsigned long long)(MHI) << 32) | (MLO);                                               \
+        asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"      \
+                     :: "s"(msk_), "s"(DST), "v"(OFF), "s"(SRC) : "memory", "m0");                                               \
+    } while (0)
+#define UPS_THIN_ISSUE_ROW(K)                                                                                                    \
+    do {                                                                                                                         \
+        const int yy_ = y0 - 1 + (K);                                                                                            \
+        const unsigned char* s0_ = (unsigned)yy_ < (unsigned)h_ ? in_img + (long long)yy_ * row_bytes : ups_rows_zero;           \
+        const unsigned long long sa_ = (unsigned long long)s0_;                                                                  \
+        const unsigned hi_ = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(sa_ >> 32));      /* (readfirstlane returns int) */   \
+        const unsigned lo_ = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)sa_);                                            \
+        const unsigned char* src_ = (const unsigned char*)(((unsigned long long)hi_ << 32) | (unsigned long long)lo_);          \
+        const unsigned base_ = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(((K) % NR) * RB + wid * PLW));                \
+        UPS_THIN_DMA(src_, base_, d_off0, m0lo, m0hi);                                                                           \
+        UPS_THIN_DMA(src_, base_ + 1024u, d_off1, m1lo, m1hi);                                                                   \
+        if constexpr (NPC > 2) UPS_THIN_DMA(src_, base_ + 2048u, d_off2, m2lo, m2hi);                                            \
+    } while (0)
+
 template <typename T, int NR, int SW>        // SW: strip width (32: one block per CU; 16: two)
 __global__ __launch_bounds__(512, SW == 16 ? 4 : 2) void conv3x3_thinout_kernel(const ThinK p) {
     constexpr int NSL = SW + 2, NC2 = SW / 16, NPC = (NSL + 15) / 16;        // pixel slots per plane row, column tiles, DMA pieces
@@ -366,119 +492,128 @@ __global__ __launch_bounds__(512, SW == 16 ? 4 : 2) void conv3x3_thinout_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p16 = lane & 15, q16 = lane >> 4;
+    // the argument struct's fields used inside the loop, as plain locals
+    const int h_ = p.h, wd_ = p.wd, ldo_ = p.ldo, co_ = p.co, cofill_ = p.co_fill, of32_ = p.out_f32;
+    const bool has_ct = p.coord_tab != nullptr;
     int t = blockIdx.x;
     const int strip = t % p.strips; t /= p.strips;
     const int band = t % p.bands; const int img = t / p.bands;
     const int x0 = strip * SW, y0 = band * p.band_rows;
-    const int y1 = min(p.h, y0 + p.band_rows);
+    const int y1 = min(h_, y0 + p.band_rows);
 
     for (int i = tid * 16; i < NR * RB; i += 512 * 16) *(uint4*)(ring + i) = make_uint4(0u, 0u, 0u, 0u);
     // the wave's weights: plane wid, co rows 0 .. 15 (rows past co repeat the last one; their outputs are never stored)
-    frag_t wb[9];
-    const int wrow = min(p16, p.co - 1);
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) wb[tp] = *(const frag_t*)(p.w + ((long long)(tp * 8 + wid) * p.co + wrow) * 64 + q16 * 16);
-    // the thread's output element in the reduction: (pixel px, channel co_t) of the current row; its bias and CoordConv terms for the
+    frag_t wb0, wb1, wb2, wb3, wb4, wb5, wb6, wb7, wb8;
+    {
+        const int wrow = min(p16, co_ - 1);
+        const unsigned char* wp = p.w + ((long long)wid * co_ + wrow) * 64 + q16 * 16;
+        const long long ts = (long long)8 * co_ * 64;
+        wb0 = *(const frag_t*)(wp); wb1 = *(const frag_t*)(wp + ts); wb2 = *(const frag_t*)(wp + 2 * ts);
+        wb3 = *(const frag_t*)(wp + 3 * ts); wb4 = *(const frag_t*)(wp + 4 * ts); wb5 = *(const frag_t*)(wp + 5 * ts);
+        wb6 = *(const frag_t*)(wp + 6 * ts); wb7 = *(const frag_t*)(wp + 7 * ts); wb8 = *(const frag_t*)(wp + 8 * ts);
+    }
+    // the thread's output element in the reduction: (pixel px_t, channel co_t) of the current row; its bias and CoordConv terms for the
     // three row classes (first row / interior / last row) of its column class
     const int co_t = tid & 15, px_t = (tid >> 4) & (SW - 1);
-    const bool t_on = tid < SW * 16;            // threads that own an output element
+    const bool t_on = tid < SW * 16;
     const int xg = x0 + px_t;
-    const bool c_ok = co_t < p.co;
-    float bias_t = 0.f, ct0[3] = {0.f, 0.f, 0.f}, ct1[3] = {0.f, 0.f, 0.f}, ct2[3] = {0.f, 0.f, 0.f};
+    const bool c_ok = co_t < co_;
+    float bias_l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
     if (c_ok) {
-        if (p.bias) bias_t = p.bias[co_t];
-        if (p.coord_tab) {
-            const int xm = (xg > 0 ? 1 : 0) | 2 | (xg + 1 < p.wd ? 4 : 0);
-            const int yms[3] = {2 | 4, 7, 1 | 2};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float* tb = p.coord_tab + (long long)(yms[c] * 8 + xm) * 3 * p.co + co_t;
-                ct0[c] = tb[0]; ct1[c] = tb[p.co]; ct2[c] = tb[2 * p.co];
-            }
+        if (p.bias) bias_l = p.bias[co_t];
+        if (has_ct) {
+            const int xm = (xg > 0 ? 1 : 0) | 2 | (xg + 1 < wd_ ? 4 : 0);
+            const float* ta = p.coord_tab + (long long)((2 | 4) * 8 + xm) * 3 * co_ + co_t;        // first row of the image
+            const float* tb = p.coord_tab + (long long)(7 * 8 + xm) * 3 * co_ + co_t;              // interior rows
+            const float* tc = p.coord_tab + (long long)((1 | 2) * 8 + xm) * 3 * co_ + co_t;        // last row
+            a0 = ta[0]; a1 = ta[co_]; a2 = ta[2 * co_];
+            b0 = tb[0]; b1 = tb[co_]; b2 = tb[2 * co_];
+            c0 = tc[0]; c1 = tc[co_]; c2 = tc[2 * co_];
         }
     }
+    // every set-up load is waited for HERE, before the first row request: left to the compiler the waits would sit at the first uses
+    // inside the loop (vmcnt(0) in every iteration)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias_l), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(c0), "+v"(c1), "+v"(c2)
+                 :: "memory");
+    const float bias_t = bias_l, ct0a = a0, ct1a = a1, ct2a = a2, ct0b = b0, ct1b = b1, ct2b = b2, ct0c = c0, ct1c = c1, ct2c = c2;
     __syncthreads();
 
-    // ---- wave-private row DMA: three pieces of 16 pixel slots of plane wid
+    // ---- wave-private row DMA: pieces of 16 pixel slots of plane wid
     const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
-    unsigned d_off[NPC];
-    unsigned long long d_mask[NPC];
+    unsigned d_off0 = 0u, d_off1 = 0u, d_off2 = 0u, m0lo = 0u, m0hi = 0u, m1lo = 0u, m1hi = 0u, m2lo = 0u, m2hi = 0u;
+#define UPS_THIN_PIECE(Q, OFF, MLO, MHI)                                                                                          \
+    do {                                                                                                                         \
+        const int P_ = 16 * (Q) + (lane >> 2), x_ = x0 - 1 + P_;                                                                 \
+        const bool ok_ = P_ < NSL && (unsigned)x_ < (unsigned)wd_;                                                               \
+        OFF = ok_ ? (unsigned)(x_ * p.ldi * 2 + wid * 64 + (((lane & 3) ^ r_swz(P_)) << 4)) : 0u;                                \
+        const unsigned long long m_ = __ballot(ok_);                                                                            \
+        MLO = __builtin_amdgcn_readfirstlane((unsigned)m_); MHI = __builtin_amdgcn_readfirstlane((unsigned)(m_ >> 32));          \
+    } while (0)
+    UPS_THIN_PIECE(0, d_off0, m0lo, m0hi);
+    UPS_THIN_PIECE(1, d_off1, m1lo, m1hi);
+    if constexpr (NPC > 2) UPS_THIN_PIECE(2, d_off2, m2lo, m2hi);
+#undef UPS_THIN_PIECE
+    const unsigned char* in_img = p.in + (long long)img * h_ * wd_ * p.ldi * 2;
+    const unsigned row_bytes = (unsigned)(wd_ * p.ldi * 2);
 #pragma unroll
-    for (int q = 0; q < NPC; ++q) {
-        const int P = 16 * q + (lane >> 2), x = x0 - 1 + P;
-        const bool ok = P < NSL && (unsigned)x < (unsigned)p.wd;
-        d_off[q] = ok ? (unsigned)(x * p.ldi * 2 + wid * 64 + (((lane & 3) ^ r_swz(P)) << 4)) : 0u;
-        d_mask[q] = __ballot(ok);
-    }
-    const unsigned char* in_img = p.in + (long long)img * p.h * p.wd * p.ldi * 2;
-    const unsigned row_bytes = (unsigned)(p.wd * p.ldi * 2);
-    auto issue_row = [&](int k) __attribute__((always_inline)) {          // input row y0 - 1 + k
-        const int y = y0 - 1 + k;
-        const unsigned char* src = (unsigned)y < (unsigned)p.h ? in_img + (long long)y * row_bytes : ups_rows_zero;
-#pragma unroll
-        for (int q = 0; q < NPC; ++q) {
-            const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((k % NR) * RB + wid * PLW + 16 * q * 64));
-            asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
-                         :: "s"(d_mask[q]), "s"(dst), "v"(d_off[q]), "s"(src) : "memory", "m0");
-        }
-    };
-#pragma unroll
-    for (int k = 0; k < L + 2; ++k) issue_row(k);
+    for (int k = 0; k < L + 2; ++k) UPS_THIN_ISSUE_ROW(k);
 
     const int iters = y1 - y0;
-    unsigned char* out_img = p.out + (long long)img * p.h * p.wd * p.ldo * (p.out_f32 ? 4 : 2);
-    auto finish_row = [&](int ir) __attribute__((always_inline)) {         // thread (px_t, co_t): the eight partials of output row y0 + ir
-        const float* all = red + (ir & 1) * 8 * RED + px_t * 20 + co_t;
-        float v = all[0];
-#pragma unroll
-        for (int w8 = 1; w8 < 8; ++w8) v += all[w8 * RED];
-        const int y = y0 + ir;
-        if (t_on && co_t < p.co_fill) {
-            v = c_ok ? v + bias_t : 0.f;          // (channels co .. co_fill - 1 of a 16-bit output are stored as zeros)
-            if (c_ok && p.coord_tab) {
-                const int c = y == 0 ? 0 : (y + 1 < p.h ? 1 : 2);
-                const float t0 = c == 0 ? ct0[0] : (c == 1 ? ct0[1] : ct0[2]);
-                const float t1 = c == 0 ? ct1[0] : (c == 1 ? ct1[1] : ct1[2]);
-                const float t2 = c == 0 ? ct2[0] : (c == 1 ? ct2[1] : ct2[2]);
-                v += t0 + (float)xg * t1 + (float)y * t2;
-            }
-            const long long o = ((long long)y * p.wd + xg) * p.ldo + co_t;
-            if (p.out_f32) ((float*)out_img)[o] = v;
-            else st_from_float<T>((T*)out_img + o, v);
-        }
-    };
+    unsigned char* out_img = p.out + (long long)img * h_ * wd_ * ldo_ * (of32_ ? 4 : 2);
     for (int it = 0; it < iters; ++it) {
-        // rows it .. it + 2 of this wave's plane must have landed (row it + 2 was requested by iteration it - L); younger: the three
+        // rows it .. it + 2 of this wave's plane must have landed (row it + 2 was requested by iteration it - L); younger: the NPC
         // requests of each of the L - 1 rows behind it and the stores issued since (every iteration ends with one: counted once)
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * NPC) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * NPC + 1) : "memory");
-        issue_row(it + L + 2);              // into the slot of row it - 1, whose last fragment reads fed the previous iteration's MFMAs
-        // four accumulator chains (two column tiles x two tap groups): nine dependent MFMAs per chain would leave the pipe idle
+        UPS_THIN_ISSUE_ROW(it + L + 2);      // into the slot of row it - 1, whose last fragment reads fed the previous iteration's MFMAs
+        // four accumulator chains (column tiles x two tap groups)
         f32x4v acc[NC2][2];
 #pragma unroll
-        for (int c2 = 0; c2 < NC2; ++c2) { acc[c2][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[c2][1] = acc[c2][0]; }
-#pragma unroll
-        for (int dyi = 0; dyi < 3; ++dyi) {
-            const unsigned char* rowp = ring + ((it + dyi) % NR) * RB + wid * PLW;
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                for (int c2 = 0; c2 < NC2; ++c2) {
-                    const int P = 16 * c2 + p16 + dx;
-                    const frag_t a = *(const frag_t*)(rowp + P * 64 + ((q16 ^ r_swz(P)) << 4));
-                    const int gsel = (dyi * 3 + dx) & 1;
-                    if constexpr (__is_same(T, bf16)) acc[c2][gsel] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[dyi * 3 + dx], a, acc[c2][gsel], 0, 0, 0);
-                    else acc[c2][gsel] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[dyi * 3 + dx], a, acc[c2][gsel], 0, 0, 0);
-                }
-        }
+        for (int c2i = 0; c2i < NC2; ++c2i) { acc[c2i][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[c2i][1] = acc[c2i][0]; }
+#define UPS_THIN_TAP(TP, WB)                                                                                                     \
+        do {                                                                                                                     \
+            constexpr int dyi_ = (TP) / 3, dx_ = (TP) % 3;                                                                       \
+            const unsigned char* rowp_ = ring + ((it + dyi_) % NR) * RB + wid * PLW;                                             \
+            _Pragma("unroll") for (int c2i = 0; c2i < NC2; ++c2i) {                                                              \
+                const int P_ = 16 * c2i + p16 + dx_;                                                                             \
+                const frag_t a_ = *(const frag_t*)(rowp_ + P_ * 64 + ((q16 ^ r_swz(P_)) << 4));                                  \
+                if constexpr (__is_same(T, bf16)) acc[c2i][(TP) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB, a_, acc[c2i][(TP) & 1], 0, 0, 0); \
+                else acc[c2i][(TP) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WB, a_, acc[c2i][(TP) & 1], 0, 0, 0);         \
+            }                                                                                                                    \
+        } while (0)
+        UPS_THIN_TAP(0, wb0); UPS_THIN_TAP(1, wb1); UPS_THIN_TAP(2, wb2); UPS_THIN_TAP(3, wb3); UPS_THIN_TAP(4, wb4);
+        UPS_THIN_TAP(5, wb5); UPS_THIN_TAP(6, wb6); UPS_THIN_TAP(7, wb7); UPS_THIN_TAP(8, wb8);
+#undef UPS_THIN_TAP
         float* mine = red + ((it & 1) * 8 + wid) * RED;
 #pragma unroll
-        for (int c2 = 0; c2 < NC2; ++c2) *(f32x4v*)(mine + (16 * c2 + p16) * 20 + 4 * q16) = acc[c2][0] + acc[c2][1];
-        __syncthreads();
-        finish_row(it);
+        for (int c2i = 0; c2i < NC2; ++c2i) *(f32x4v*)(mine + (16 * c2i + p16) * 20 + 4 * q16) = acc[c2i][0] + acc[c2i][1];
+        // (a raw barrier: __syncthreads() carries a fence that drains vmcnt -- every row request in flight -- each iteration)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // thread (px_t, co_t): the eight partials of this output row, in wave order
+        const float* all = red + (it & 1) * 8 * RED + px_t * 20 + co_t;
+        float v = all[0];
+#pragma unroll
+        for (int w8 = 1; w8 < 8; ++w8) v += all[w8 * RED];
+        const int y = y0 + it;
+        v = c_ok ? v + bias_t : 0.f;          // (channels co .. co_fill - 1 of a 16-bit output are stored as zeros)
+        if (has_ct && c_ok) {
+            const bool first = y == 0, last = y + 1 >= h_;
+            const float t0 = first ? ct0a : (last ? ct0c : ct0b);
+            const float t1 = first ? ct1a : (last ? ct1c : ct1b);
+            const float t2 = first ? ct2a : (last ? ct2c : ct2b);
+            v += t0 + (float)xg * t1 + (float)y * t2;
+        }
+        // (one store instruction per wave and iteration whatever the masks: the count of the wait above is static)
+        const long long o = ((long long)y * wd_ + xg) * ldo_ + co_t;
+        const bool on = t_on && co_t < cofill_;
+        if (of32_) { if (on) ((float*)out_img)[o] = v; }
+        else { if (on) st_from_float<T>((T*)out_img + o, v); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+#undef UPS_THIN_ISSUE_ROW
+#undef UPS_THIN_DMA
 
 template <typename T, int SW>
 int launch_thinout(const ThinK& k, hipStream_t s) {
@@ -622,4 +757,36 @@ int ups_conv3x3_thinout_try(const ups_conv_desc* d, hipStream_t s) {
         return d->dtype == UPS_F16 ? launch_thinout<f16, 16>(k, s) : launch_thinout<bf16, 16>(k, s);
     }
     return d->dtype == UPS_F16 ? launch_thinout<f16, 32>(k, s) : launch_thinout<bf16, 32>(k, s);
+}
+
+// The part-masked first convolution's input gradient reduced to the hard mask (ups_conv_desc.mask_grad): 32 gradient channels,
+// 128 columns, <= 4 view channels.
+int ups_conv3x3_rows_maskgrad_try(const ups_conv_desc* d, hipStream_t s) {
+    if (!rows_on()) return 1;
+    if (!d->mask_grad || !d->mask_view || d->mask_bits || d->dtype != UPS_BF16) return 1;
+    if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox) return 1;
+    if (d->hi != d->ho || d->wi != d->wo || d->wi != 128 || d->hi % 32) return 1;
+    if (d->ci != 32 || d->co != 3 || (d->ldi & 7) || d->ldi < 32) return 1;       // (three view channels: one dwordx3 load per pixel)
+    if (d->act_in != UPS_ACT_NONE || d->res || d->dact || d->coord_tab || d->d2s || d->f8_deq || d->in_f8 || d->out_f8 || d->out_f8_amax ||
+        d->out_act || d->res_act || d->bias)
+        return 1;
+    if (d->mask_batch <= 0 || d->n % d->mask_batch) return 1;
+    for (int t = 0; t < 9; ++t)
+        if (d->tap_dy[t] != 1 - t / 3 || d->tap_dx[t] != 1 - t % 3 || d->tap_w[t] != t) return 1;
+    if (rows_on() != 2 && (long long)d->n * (d->hi / 32) < 1024) return 1;
+    if ((long long)d->wi * d->ldi * 2 > 262144 || (long long)d->hi * d->wi * d->ldi * 2 >= (1ll << 31)) return 1;
+    MaskGK k;
+    k.in = (const unsigned char*)d->in; k.w = (const unsigned char*)d->w; k.view = d->mask_view; k.g_hard = d->mask_grad;
+    k.n = d->n; k.h = d->hi; k.ldi = d->ldi; k.co = d->co; k.B = d->mask_batch; k.P = d->n / d->mask_batch;
+    k.band_rows = 32; k.bands = d->hi / 32;
+    constexpr int NR = 8;
+    constexpr size_t smem = (size_t)NR * 130 * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_rows_maskgrad_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return UPS_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_rows_maskgrad_kernel<NR>), dim3(k.n * k.bands), dim3(512), smem, s, k);
+    return UPS_OK;
 }

@@ -471,6 +471,7 @@ int ups_conv3x3_s2_try(const ups_conv_desc* d, hipStream_t s);      // conv3x3_s
 int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s);    // conv3x3_rows.hip
 int ups_conv3x3_rows_s2_try(const ups_conv_desc* d, hipStream_t s);
 int ups_conv3x3_thinout_try(const ups_conv_desc* d, hipStream_t s);
+int ups_conv3x3_rows_maskgrad_try(const ups_conv_desc* d, hipStream_t s);
 
 extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d != nullptr);
@@ -511,6 +512,7 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
         {
             int rr = ups_conv3x3_thinout_try(d, (hipStream_t)stream);
             if (rr == 1) rr = ups_conv3x3_rows_try(d, (hipStream_t)stream);
+            if (rr == 1) rr = ups_conv3x3_rows_maskgrad_try(d, (hipStream_t)stream);
             if (rr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
             if (rr < 0) { ups_set_error("ups_conv_igemm: row-streaming kernel launch setup failed"); return rr; }
         }
