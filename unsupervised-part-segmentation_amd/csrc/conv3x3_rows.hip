@@ -688,7 +688,8 @@ int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s) {
         if (d->tap_dy[t] != 1 - t / 3 || d->tap_dx[t] != 1 - t % 3) flip = false;
     }
     if (!fwd && !flip) return 1;
-    if (d->dact && (d->dtype != UPS_BF16 || !flip || (d->ldd & 7) || d->ldd < co_need)) return 1;
+    if (d->dact && (d->dtype != UPS_BF16 || !flip || (d->ldd & 7) || d->ldd < co_need || ((uintptr_t)d->dact & 15))) return 1;
+    if (((uintptr_t)d->in & 15) || ((uintptr_t)d->out & 15) || ((uintptr_t)d->w & 15)) return 1;      // 16-byte DMA pieces / stores
     if ((long long)d->hi * d->wi * (d->ldi > d->ldo ? d->ldi : d->ldo) * 2 >= (1ll << 31) || (long long)d->wi * d->ldi * 2 > 65536) return 1;
     RowsK k;
     k.in = (const unsigned char*)d->in; k.w = (const unsigned char*)d->w; k.out = (unsigned char*)d->out;
@@ -716,6 +717,7 @@ int ups_conv3x3_rows_s2_try(const ups_conv_desc* d, hipStream_t s) {
     for (int t = 0; t < 9; ++t)
         if (d->tap_dy[t] != t / 3 || d->tap_dx[t] != t % 3 || d->tap_w[t] != t) return 1;
     if (rows_on() != 2 && (long long)d->n * (d->ho / 32) < 512) return 1;
+    if (((uintptr_t)d->in & 15) || ((uintptr_t)d->out & 15) || ((uintptr_t)d->w & 15)) return 1;
     if ((long long)d->wi * d->ldi * 2 > 65536 || (long long)d->hi * d->wi * d->ldi * 2 >= (1ll << 31)) return 1;
     RowsK k;
     k.in = (const unsigned char*)d->in; k.w = (const unsigned char*)d->w; k.out = (unsigned char*)d->out;
@@ -743,6 +745,7 @@ int ups_conv3x3_thinout_try(const ups_conv_desc* d, hipStream_t s) {
         if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1 || d->tap_w[t] != t) return 1;
     const long long blocks = (long long)d->n * (d->hi / 32) * (d->wi / 32);
     if (rows_on() != 2 && blocks < 512) return 1;
+    if (((uintptr_t)d->in & 15) || ((uintptr_t)d->w & 15) || ((uintptr_t)d->out & (d->out_f32 ? 3 : 1))) return 1;
     if ((long long)d->wi * d->ldi * 2 + 1024 > 262144 || (long long)d->hi * d->wi * d->ldi * 2 >= (1ll << 31) || blocks >= (1ll << 31)) return 1;
     ThinK k;
     k.in = (const unsigned char*)d->in; k.w = (const unsigned char*)d->w; k.out = (unsigned char*)d->out;
@@ -774,6 +777,7 @@ int ups_conv3x3_rows_maskgrad_try(const ups_conv_desc* d, hipStream_t s) {
     for (int t = 0; t < 9; ++t)
         if (d->tap_dy[t] != 1 - t / 3 || d->tap_dx[t] != 1 - t % 3 || d->tap_w[t] != t) return 1;
     if (rows_on() != 2 && (long long)d->n * (d->hi / 32) < 1024) return 1;
+    if (((uintptr_t)d->in & 15) || ((uintptr_t)d->w & 15) || ((uintptr_t)d->mask_view & 3) || ((uintptr_t)d->mask_grad & 3)) return 1;
     if ((long long)d->wi * d->ldi * 2 > 262144 || (long long)d->hi * d->wi * d->ldi * 2 >= (1ll << 31)) return 1;
     MaskGK k;
     k.in = (const unsigned char*)d->in; k.w = (const unsigned char*)d->w; k.view = d->mask_view; k.g_hard = d->mask_grad;
