@@ -195,6 +195,10 @@ ROWS_CASES = [
     (2, 64, 64, "f16"),
     (5, 32, 32, "bf16"),        # a single band per image (32 x 128): top and bottom zero rows in the same block
     (1, 96, 64, "bf16"),        # three bands, non-square (96 x 64)
+    # two column tiles per wave (conv3x3_rows2_kernel; the forward only -- the input gradient with act' stays on the patch kernel)
+    (2, 64, 64, "bf16", 128),   # 64 channels at 128 columns: VGG block 1 / the hourglass decoder
+    (2, 32, 32, "bf16", 256),   # 32 channels at 256 columns: encoder_1's first residual block of the 256 x 256 configs
+    (1, 64, 64, "f16", 128),
 ]
 
 
@@ -206,8 +210,8 @@ def test_conv_rows_kernel(case, dev, monkeypatch):
     gradient (flipped taps, act' from the stored forward input, residual gradient) against the fp64 oracle's autograd on the
     rounded operands, and against the patch kernel (UPS_ROWS_KERNEL=0) on the same inputs."""
     lib, ops, R = _mods()
-    n, h, c, fmt_name = case
-    w = 128 if c == 32 else 64
+    n, h, c, fmt_name = case[:4]
+    w = case[4] if len(case) > 4 else (128 if c == 32 else 64)
     g = torch.Generator().manual_seed(700 + ROWS_CASES.index(case))
     f16 = fmt_name == "f16"
     TF = torch.float16 if f16 else torch.bfloat16

@@ -216,6 +216,160 @@ __global__ __launch_bounds__(512, (CI == 32 && !DG && NR <= 8) ? 4 : 2) void con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The same stream with TWO column tiles per wave: 16 (column tile, channel group) jobs per row instead of 8 -- 64 channels at 128
+// columns (VGG block 1, the hourglass decoder, encoder_1's second residual block of the 256x256 configs) and 32 channels at 256 columns
+// (its first).  Two DMA pieces per wave and row, one block per CU (133 KB of row ring).  Forward-type epilogue (bias, residual from the
+// centre row, stored activation); FLIP for input gradients without an activation derivative.
+template <typename T, int CI, int LW, int NR, bool FLIP>
+__global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsK p) {
+    constexpr int W = 1 << LW, KC = CI / 32, NCT = W / 16, NCP = NCT / 2;       // column tiles, column-tile pairs
+    constexpr int PL = (W + 2) * 64, RB = KC * PL, ST = 16 * 80;
+    constexpr int L = (NR - 4) / 2;
+    constexpr int GS = 4;                       // DMA instructions (= stores) a wave issues per iteration
+    static_assert(KC * NCT == 16 && (8 / NCP) * NCP == 8, "two DMA pieces per wave and row");
+    typedef typename RFrag<T>::type frag_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* stage = smem + NR * RB + wid * ST;
+    float* biasL = (float*)(smem + NR * RB + 8 * ST);
+    const int p16 = lane & 15, q16 = lane >> 4;
+    const int ctp = wid % NCP, cg = wid / NCP;               // column-tile pair, output-channel group
+    const int band = blockIdx.x % p.bands, img = blockIdx.x / p.bands;
+    const int y0 = band * p.band_rows;
+    const int y1 = min(p.h, y0 + p.band_rows);
+    for (int i = tid * 16; i < NR * RB; i += 512 * 16) *(uint4*)(ring + i) = make_uint4(0u, 0u, 0u, 0u);
+    frag_t wb[9][KC][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                wb[t][kc][j] = *(const frag_t*)(p.w + ((long long)(t * KC + kc) * p.co_tot + cg * 32 + 16 * j + p16) * 64 + q16 * 16);
+    if (tid < 64) biasL[tid] = (p.bias && tid < p.co_tot) ? p.bias[tid] : 0.f;
+    __syncthreads();
+
+    // ---- row DMA: pieces 2 wid, 2 wid + 1 of the KC * NCT pieces of a row: plane = piece / NCT, 16-pixel segment = piece % NCT
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int pl0 = (2 * wid) / NCT, sg0 = (2 * wid) % NCT, pl1 = (2 * wid + 1) / NCT, sg1 = (2 * wid + 1) % NCT;
+    const int Pd0 = 1 + 16 * sg0 + (lane >> 2), Pd1 = 1 + 16 * sg1 + (lane >> 2);
+    const unsigned d_off0 = (unsigned)((16 * sg0 + (lane >> 2)) * p.ldi * 2 + pl0 * 64 + (((lane & 3) ^ r_swz(Pd0)) << 4));
+    const unsigned d_off1 = (unsigned)((16 * sg1 + (lane >> 2)) * p.ldi * 2 + pl1 * 64 + (((lane & 3) ^ r_swz(Pd1)) << 4));
+    const unsigned char* in_img = p.in + (long long)img * p.h * W * p.ldi * 2;
+    const unsigned row_bytes = (unsigned)(W * p.ldi * 2);
+    auto issue_row = [&](int k) __attribute__((always_inline)) {
+        const int y = y0 - 1 + k;
+        const unsigned char* src = (unsigned)y < (unsigned)p.h ? in_img + (long long)y * row_bytes : ups_rows_zero;
+        const unsigned dst0 = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((k % NR) * RB + pl0 * PL + (1 + 16 * sg0) * 64));
+        const unsigned dst1 = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((k % NR) * RB + pl1 * PL + (1 + 16 * sg1) * 64));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst0), "v"(d_off0), "s"(src) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst1), "v"(d_off1), "s"(src) : "memory", "m0");
+    };
+    issue_row(0); issue_row(1);
+#pragma unroll
+    for (int i = 0; i < L; ++i) { issue_row(2 * i + 2); issue_row(2 * i + 3); }
+
+    const float oact_ns = ups_slope_eff(p.out_act, p.slope);
+    const float res_inv = p.res_act ? 1.f / p.slope : 1.f;
+    const int iters = (y1 - y0 + 1) >> 1;
+    unsigned char* out_img = p.out + (long long)img * p.h * W * p.ldo * 2;
+    for (int it = 0; it < iters; ++it) {
+        // (as conv3x3_rows_kernel; four requests and four stores per wave and iteration)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS + 4) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_row(2 * it + 2 * L + 2);
+        issue_row(2 * it + 2 * L + 3);
+        const int yb = y0 + 2 * it;
+        const unsigned char* rowp[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) rowp[r4] = ring + ((2 * it + r4) % NR) * RB;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ct = 2 * ctp + c;
+            f32x4v acc[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4v b4 = *(const f32x4v*)(biasL + cg * 32 + 16 * j + 4 * q16);
+                acc[0][j] = b4; acc[1][j] = b4;
+            }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int P = 16 * ct + p16 + dx;
+                const int aoff = P * 64 + ((q16 ^ r_swz(P)) << 4);
+                frag_t a[4][KC];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                    for (int kc = 0; kc < KC; ++kc) a[r4][kc] = *(const frag_t*)(rowp[r4] + kc * PL + aoff);
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int dyi = 0; dyi < 3; ++dyi) {
+                        const int t = FLIP ? (2 - dyi) * 3 + (2 - dx) : dyi * 3 + dx;
+#pragma unroll
+                        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                if constexpr (__is_same(T, bf16))
+                                    acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[t][kc][j], a[r + dyi][kc], acc[r][j], 0, 0, 0);
+                                else
+                                    acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][kc][j], a[r + dyi][kc], acc[r][j], 0, 0, 0);
+                            }
+                    }
+            }
+            const int Pc = 16 * ct + p16 + 1;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int y = min(yb + r, p.h - 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[r][j][e];
+                    if (p.res_self) {
+                        const int c32 = 16 * j + 4 * q16;
+                        const uint2 rr = *(const uint2*)(rowp[1 + r] + cg * PL + Pc * 64 + (((c32 >> 3) ^ r_swz(Pc)) << 4) + (q16 & 1) * 8);
+                        float r0, r1, r2, r3;
+                        ups_unpack2<T>(rr.x, r0, r1); ups_unpack2<T>(rr.y, r2, r3);
+                        if (p.res_act) {
+                            r0 = r0 > 0.f ? r0 : r0 * res_inv; r1 = r1 > 0.f ? r1 : r1 * res_inv;
+                            r2 = r2 > 0.f ? r2 : r2 * res_inv; r3 = r3 > 0.f ? r3 : r3 * res_inv;
+                        }
+                        v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+                    }
+                    if (p.out_act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ups_vmax(v[e], oact_ns * v[e]);
+                    }
+                    *(uint2*)(stage + p16 * 80 + (16 * j + 4 * q16) * 2) = make_uint2(Chunk<T>::pk(v[0], v[1]), Chunk<T>::pk(v[2], v[3]));
+                }
+                // (band heights are even: every wave stores twice per column tile -- a static count for the waits above)
+                const uint4 o = *(const uint4*)(stage + (lane >> 2) * 80 + (lane & 3) * 16);
+                *(uint4*)(out_img + ((long long)y * W + 16 * ct + (lane >> 2)) * p.ldo * 2 + (cg * 32 + 8 * (lane & 3)) * 2) = o;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename T, int CI, int LW, int NR, bool FLIP>
+int launch_rows2(const RowsK& k, hipStream_t s) {
+    constexpr int W = 1 << LW, KC = CI / 32;
+    constexpr size_t smem = (size_t)NR * KC * (W + 2) * 64 + 8 * 16 * 80 + 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_rows2_kernel<T, CI, LW, NR, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return UPS_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_rows2_kernel<T, CI, LW, NR, FLIP>), dim3(k.n * k.bands), dim3(512), smem, s, k);
+    return UPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Input gradient of the part-masked FIRST convolution of encoder_1 (cub/code/SB_model48i/model.py:176-187: the P x B part images
 // are view[b] * hard[b, :, :, p], never materialised), reduced to the hard mask on the way out:
 //     g_hard[b][y][x][p] = sum_c bf16(gx[p * B + b][y][x][c]) * view[b][y][x][c],   gx = conv^T(gy)  (3 view channels),
@@ -672,11 +826,13 @@ int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s) {
     if (d->dtype != UPS_BF16 && d->dtype != UPS_F16) return 1;
     if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox) return 1;
     if (d->hi != d->ho || d->wi != d->wo || d->out_h != d->ho || d->out_w != d->wo) return 1;
-    if (!((d->ci == 32 && d->wi == 128) || (d->ci == 64 && d->wi == 64))) return 1;
-    const int co_need = d->wi == 128 ? 32 : 64;
+    const bool two = (d->ci == 64 && d->wi == 128) || (d->ci == 32 && d->wi == 256);      // two column tiles per wave (conv3x3_rows2_kernel)
+    if (!((d->ci == 32 && d->wi == 128) || (d->ci == 64 && d->wi == 64) || two)) return 1;
+    if (two && d->dact) return 1;                                                          // (no act' form there)
+    const int co_need = d->ci;
     if (d->co != co_need || d->co_fill != co_need || d->ldo < co_need || (d->ldo & 7) || (d->ldi & 7)) return 1;
     if (d->hi % 32 || d->hi < 32) return 1;
-    if (rows_on() != 2 && (long long)d->n * (d->hi / 32) < 1024) return 1;      // small batches: the patch kernel's 16x16 tiles fill the chip better
+    if (rows_on() != 2 && (long long)d->n * (d->hi / 32) < (two ? 256 : 1024)) return 1;      // small batches: the patch kernel's 16x16 tiles fill the chip better
     if (d->act_in != UPS_ACT_NONE || d->coord_tab || d->mask_bits || d->mask_grad || d->d2s || d->f8_deq || d->in_f8 || d->out_f8 ||
         d->out_f8_amax || d->out_f32)
         return 1;
@@ -699,6 +855,14 @@ int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s) {
     k.res_self = d->res != nullptr; k.res_act = d->res_act; k.out_act = d->out_act;
     k.slope = d->act_slope; k.dact_ns = d->dact_kind == UPS_ACT_LRELU ? d->act_slope : 0.f;
     const bool dg = d->dact != nullptr;
+    if (two) {
+        if (d->ci == 64) {
+            if (d->dtype == UPS_F16) return flip ? launch_rows2<f16, 64, 7, 8, true>(k, s) : launch_rows2<f16, 64, 7, 8, false>(k, s);
+            return flip ? launch_rows2<bf16, 64, 7, 8, true>(k, s) : launch_rows2<bf16, 64, 7, 8, false>(k, s);
+        }
+        if (d->dtype == UPS_F16) return flip ? launch_rows2<f16, 32, 8, 8, true>(k, s) : launch_rows2<f16, 32, 8, 8, false>(k, s);
+        return flip ? launch_rows2<bf16, 32, 8, 8, true>(k, s) : launch_rows2<bf16, 32, 8, 8, false>(k, s);
+    }
     const int rc = d->dtype == UPS_F16 ? launch_rows_t<f16>(k, d->ci, d->wi, flip, dg, s) : launch_rows_t<bf16>(k, d->ci, d->wi, flip, dg, s);
     return rc;
 }
