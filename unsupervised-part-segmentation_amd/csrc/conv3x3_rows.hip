@@ -220,13 +220,17 @@ __global__ __launch_bounds__(512, (CI == 32 && !DG && NR <= 8) ? 4 : 2) void con
 // columns (VGG block 1, the hourglass decoder, encoder_1's second residual block of the 256x256 configs) and 32 channels at 256 columns
 // (its first).  Two DMA pieces per wave and row, one block per CU (133 KB of row ring).  Forward-type epilogue (bias, residual from the
 // centre row, stored activation); FLIP for input gradients without an activation derivative.
-template <typename T, int CI, int LW, int NR, bool FLIP>
+// DG: input gradient with act'(x): the sign of the stored forward input, 8 bytes per lane, block and row in the accumulator layout,
+// by inline-asm loads issued ahead of the iteration's row requests and waited for with their own count (no second LDS ring).
+template <typename T, int CI, int LW, int NR, bool FLIP, bool DG>
 __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsK p) {
     constexpr int W = 1 << LW, KC = CI / 32, NCT = W / 16, NCP = NCT / 2;       // column tiles, column-tile pairs
     constexpr int PL = (W + 2) * 64, RB = KC * PL, ST = 16 * 80;
     constexpr int L = (NR - 4) / 2;
     constexpr int GS = 4;                       // DMA instructions (= stores) a wave issues per iteration
+    constexpr int NV = DG ? 8 : 0;              // act' loads per wave and iteration (2 rows x 2 column tiles x 2 channel blocks)
     static_assert(KC * NCT == 16 && (8 / NCP) * NCP == 8, "two DMA pieces per wave and row");
+    static_assert(!DG || L == 2, "the counted waits of the act' form are written for a lead of two iterations");
     typedef typename RFrag<T>::type frag_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
@@ -276,13 +280,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsK p) {
     const int iters = (y1 - y0 + 1) >> 1;
     unsigned char* out_img = p.out + (long long)img * p.h * W * p.ldo * 2;
     for (int it = 0; it < iters; ++it) {
-        // (as conv3x3_rows_kernel; four requests and four stores per wave and iteration)
+        // (as conv3x3_rows_kernel; per wave and iteration, in this order: NV act' loads, four row requests, four stores.  The requests
+        // of iteration it - L must have landed: younger are the other prologue requests (it == 0) or at least the whole previous
+        // iteration (it >= 1, L == 2 in the act' form))
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS + 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * (GS + NV) + 4) : "memory");
         __builtin_amdgcn_s_barrier();
+        const int yb = y0 + 2 * it;
+        uint2 dv[2][2][2];                      // [column tile][row][channel block]
+        if constexpr (DG) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const unsigned char* dp = p.dact + (((long long)img * p.h + min(yb + r, p.h - 1)) * W + 16 * (2 * ctp + c) + p16) * p.ldd * 2 +
+                                                  (cg * 32 + 16 * j + 4 * q16) * 2;
+                        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dv[c][r][j]) : "v"(dp) : "memory");
+                    }
+        }
         issue_row(2 * it + 2 * L + 2);
         issue_row(2 * it + 2 * L + 3);
-        const int yb = y0 + 2 * it;
         const unsigned char* rowp[4];
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) rowp[r4] = ring + ((2 * it + r4) % NR) * RB;
@@ -321,6 +340,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsK p) {
                     }
             }
             const int Pc = 16 * ct + p16 + 1;
+            if constexpr (DG) {
+                // the act' values of this column tile: behind them only the four row requests (and, for the second tile, the first
+                // tile's two stores) may still be in flight
+                if (c == 0) asm volatile("s_waitcnt vmcnt(4)" : "+v"(dv[0][0][0]), "+v"(dv[0][0][1]), "+v"(dv[0][1][0]), "+v"(dv[0][1][1]),
+                                         "+v"(dv[1][0][0]), "+v"(dv[1][0][1]), "+v"(dv[1][1][0]), "+v"(dv[1][1][1]) :: "memory");
+            }
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int y = min(yb + r, p.h - 1);
@@ -329,6 +354,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsK p) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[r][j][e];
+                    if constexpr (DG) {
+                        float d0, d1, d2, d3;
+                        ups_unpack2<T>(dv[c][r][j].x, d0, d1); ups_unpack2<T>(dv[c][r][j].y, d2, d3);
+                        v[0] *= d0 > 0.f ? 1.f : p.dact_ns; v[1] *= d1 > 0.f ? 1.f : p.dact_ns;
+                        v[2] *= d2 > 0.f ? 1.f : p.dact_ns; v[3] *= d3 > 0.f ? 1.f : p.dact_ns;
+                    }
                     if (p.res_self) {
                         const int c32 = 16 * j + 4 * q16;
                         const uint2 rr = *(const uint2*)(rowp[1 + r] + cg * PL + Pc * 64 + (((c32 >> 3) ^ r_swz(Pc)) << 4) + (q16 & 1) * 8);
@@ -355,17 +386,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsK p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename T, int CI, int LW, int NR, bool FLIP>
+template <typename T, int CI, int LW, int NR, bool FLIP, bool DG = false>
 int launch_rows2(const RowsK& k, hipStream_t s) {
     constexpr int W = 1 << LW, KC = CI / 32;
     constexpr size_t smem = (size_t)NR * KC * (W + 2) * 64 + 8 * 16 * 80 + 256;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_rows2_kernel<T, CI, LW, NR, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3x3_rows2_kernel<T, CI, LW, NR, FLIP, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_rows2_kernel<T, CI, LW, NR, FLIP>), dim3(k.n * k.bands), dim3(512), smem, s, k);
+    hipLaunchKernelGGL((conv3x3_rows2_kernel<T, CI, LW, NR, FLIP, DG>), dim3(k.n * k.bands), dim3(512), smem, s, k);
     return UPS_OK;
 }
 
@@ -828,7 +859,6 @@ int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s) {
     if (d->hi != d->ho || d->wi != d->wo || d->out_h != d->ho || d->out_w != d->wo) return 1;
     const bool two = (d->ci == 64 && d->wi == 128) || (d->ci == 32 && d->wi == 256);      // two column tiles per wave (conv3x3_rows2_kernel)
     if (!((d->ci == 32 && d->wi == 128) || (d->ci == 64 && d->wi == 64) || two)) return 1;
-    if (two && d->dact) return 1;                                                          // (no act' form there)
     const int co_need = d->ci;
     if (d->co != co_need || d->co_fill != co_need || d->ldo < co_need || (d->ldo & 7) || (d->ldi & 7)) return 1;
     if (d->hi % 32 || d->hi < 32) return 1;
@@ -855,6 +885,9 @@ int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s) {
     k.res_self = d->res != nullptr; k.res_act = d->res_act; k.out_act = d->out_act;
     k.slope = d->act_slope; k.dact_ns = d->dact_kind == UPS_ACT_LRELU ? d->act_slope : 0.f;
     const bool dg = d->dact != nullptr;
+    if (two && dg) {        // (bf16 and flipped taps: checked above)
+        return d->ci == 64 ? launch_rows2<bf16, 64, 7, 8, true, true>(k, s) : launch_rows2<bf16, 32, 8, 8, true, true>(k, s);
+    }
     if (two) {
         if (d->ci == 64) {
             if (d->dtype == UPS_F16) return flip ? launch_rows2<f16, 64, 7, 8, true>(k, s) : launch_rows2<f16, 64, 7, 8, false>(k, s);
