@@ -48,15 +48,19 @@ __device__ __forceinline__ int r_swz(int P) { return ((P >> 2) & 1) << 1; }     
 
 // CI input channels (32 / 64), image width 1 << LW (128 / 64): 8 waves = (W / 16 column tiles) x (8 / (W / 16) groups of 32 outputs),
 // i.e. 32 outputs at W = 128, 64 at W = 64.  NR ring rows.  FLIP: the input gradient's tap order (dy = 1 - t / 3, dx = 1 - t % 3).
-template <typename T, int CI, int LW, int NR, bool FLIP, bool DG>
-__global__ __launch_bounds__(512, (CI == 32 && !DG && NR <= 8) ? 4 : 2) void conv3x3_rows_kernel(const RowsK p) {
+// DG: 0 forward-type epilogue; 1 act' from a second DMA ring of the forward input's rows (one block per CU at 32 channels);
+// 2 act' by counted inline-asm loads in the accumulator layout (no ring: two blocks per CU at 32 channels)
+template <typename T, int CI, int LW, int NR, bool FLIP, int DG>
+__global__ __launch_bounds__(512, (CI == 32 && DG != 1 && NR <= 8) ? 4 : 2) void conv3x3_rows_kernel(const RowsK p) {
     constexpr int W = 1 << LW, KC = CI / 32, NCT = W / 16;
     constexpr int PL = (W + 2) * 64;            // bytes of one 32-channel plane of a row
     constexpr int RB = KC * PL;                 // bytes of a row buffer
     constexpr int ST = 16 * 80;                 // wave-private output stage: 16 pixels x (64 + 16) bytes
     constexpr int L = (NR - 4) / 2;             // iterations of lead of the row requests (NR = 2 L + 4)
-    constexpr int DR = DG ? 2 * L + 2 : 0;      // ring rows of the act' operand (W pixels x 64 B x output-channel planes; no halo)
-    constexpr int GS = DG ? 4 : 2;              // DMA instructions a wave issues per iteration
+    constexpr int DR = DG == 1 ? 2 * L + 2 : 0; // ring rows of the act' operand (W pixels x 64 B x output-channel planes; no halo)
+    constexpr int GS = DG == 1 ? 4 : 2;         // DMA instructions a wave issues per iteration
+    constexpr int NV = DG == 2 ? 4 : 0;         // act' loads per wave and iteration (DG == 2)
+    static_assert(DG != 2 || L == 2, "the counted waits of the asm-load form are written for a lead of two iterations");
     constexpr int NCG = 8 / NCT;                // output-channel groups of 32 = planes of the output / act' rows
     constexpr int DRB = NCG * W * 64;
     static_assert(KC * NCT == 8 && NCG * NCT == 8, "one DMA piece per wave and row");
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(512, (CI == 32 && !DG && NR <= 8) ? 4 : 2) void con
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(d_off), "s"(src) : "memory", "m0");
     };
     auto issue_drow = [&](int ko) __attribute__((always_inline)) {          // ko = output row index inside the band
-        if constexpr (DG) {
+        if constexpr (DG == 1) {
             const int y = min(y0 + ko, p.h - 1);
             const unsigned char* src = da_img + (long long)y * (unsigned)(W * p.ldd * 2);
             const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(NR * RB + (ko % DR) * DRB + cg * (W * 64) + 16 * ct * 64));
@@ -129,8 +133,18 @@ __global__ __launch_bounds__(512, (CI == 32 && !DG && NR <= 8) ? 4 : 2) void con
         // that may stay in flight: the requests of iterations it - L + 1 .. it - 1 (GS each) and, from the first real iteration on,
         // their two stores each (counted once: a lower bound that holds for every it >= 1)
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS + 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * (GS + NV) + 2) : "memory");
         __builtin_amdgcn_s_barrier();
+        uint2 dva[2][2];                        // DG == 2: act' operand [row][channel block], requested ahead of the row requests
+        if constexpr (DG == 2) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned char* dp = da_img + ((long long)min(y0 + 2 * it + r, p.h - 1) * W + 16 * ct + p16) * p.ldd * 2 + (cg * 32 + 16 * j + 4 * q16) * 2;
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dva[r][j]) : "v"(dp) : "memory");
+                }
+        }
         // the ring slots of input rows 2 it - 2, 2 it - 1 (and of the act' rows of iteration it - 1) are free now
         issue_row(2 * it + 2 * L + 2);
         issue_row(2 * it + 2 * L + 3);
@@ -173,6 +187,8 @@ __global__ __launch_bounds__(512, (CI == 32 && !DG && NR <= 8) ? 4 : 2) void con
         }
         // ---- epilogue: lane (p16, q16) holds channels cg * 32 + 16 j + 4 q16 + e of pixel (row, 16 ct + p16)
         const int Pc = 16 * ct + p16 + 1;
+        if constexpr (DG == 2)      // behind the act' loads only this iteration's two row requests may still be in flight
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(dva[0][0]), "+v"(dva[0][1]), "+v"(dva[1][0]), "+v"(dva[1][1]) :: "memory");
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int y = yb + r;
@@ -182,7 +198,13 @@ __global__ __launch_bounds__(512, (CI == 32 && !DG && NR <= 8) ? 4 : 2) void con
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[r][j][e];
-                if constexpr (DG) {
+                if constexpr (DG == 2) {
+                    float d0, d1, d2, d3;
+                    ups_unpack2<T>(dva[r][j].x, d0, d1); ups_unpack2<T>(dva[r][j].y, d2, d3);
+                    v[0] *= d0 > 0.f ? 1.f : p.dact_ns; v[1] *= d1 > 0.f ? 1.f : p.dact_ns;
+                    v[2] *= d2 > 0.f ? 1.f : p.dact_ns; v[3] *= d3 > 0.f ? 1.f : p.dact_ns;
+                }
+                if constexpr (DG == 1) {
                     if (p.dact) {
                         const uint2 dv = *(const uint2*)(dring + ((2 * it + r) % DR) * DRB + cg * (W * 64) + (16 * ct + p16) * 64 + (16 * j + 4 * q16) * 2);
                         float d0, d1, d2, d3;
@@ -819,10 +841,10 @@ static int rows_on() {       // UPS_ROWS_KERNEL=0: these layers through the patc
     return (e && e[0] == '0') ? 0 : ((e && e[0] == 'f') ? 2 : 1);
 }
 
-template <typename T, int CI, int LW, int NR, bool FLIP, bool DG>
+template <typename T, int CI, int LW, int NR, bool FLIP, int DG>
 int launch_rows(const RowsK& k, hipStream_t s) {
     constexpr int W = 1 << LW, KC = CI / 32, NCT = W / 16, NCG = 8 / NCT;
-    constexpr size_t smem = (size_t)NR * KC * (W + 2) * 64 + (DG ? (size_t)(NR - 2) * NCG * W * 64 : 0) + 8 * 16 * 80 + 256;
+    constexpr size_t smem = (size_t)NR * KC * (W + 2) * 64 + (DG == 1 ? (size_t)(NR - 2) * NCG * W * 64 : 0) + 8 * 16 * 80 + 256;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv3x3_rows_kernel<T, CI, LW, NR, FLIP, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -837,13 +859,24 @@ template <typename T>
 int launch_rows_t(const RowsK& k, int ci, int w, bool flip, bool dg, hipStream_t s) {
     // ring depths: measured (tools/bench_conv.py ea_rb0 / ea_rb1): deeper rings at one block per CU lose to 8 rows at two blocks per CU
     // (0.42 vs 0.35 ms forward at 32 channels); 64 channels keep 144 weight registers per lane and run one block per CU either way
+    // act' of the one-tile kernel: through the second DMA ring by default.  UPS_ROWS_DG=2: counted inline-asm loads -- no ring, so
+    // the 32-channel form would fit two blocks per CU, but at the 128 registers that allows it spills 14 (scratch accesses in the
+    // loop: see DESIGN section 3 on what those do to the row pipeline); kept for A/B runs
+    static int dgm = -1;
+    if (dgm < 0) { const char* e = getenv("UPS_ROWS_DG"); dgm = (e && e[0] == '2') ? 2 : 1; }
     if (ci == 32 && w == 128) {
-        if (dg) return flip ? launch_rows<T, 32, 7, 8, true, true>(k, s) : 1;
-        return flip ? launch_rows<T, 32, 7, 8, true, false>(k, s) : launch_rows<T, 32, 7, 8, false, false>(k, s);
+        if (dg) {
+            if (!flip) return 1;
+            return dgm == 1 ? launch_rows<T, 32, 7, 8, true, 1>(k, s) : launch_rows<T, 32, 7, 8, true, 2>(k, s);
+        }
+        return flip ? launch_rows<T, 32, 7, 8, true, 0>(k, s) : launch_rows<T, 32, 7, 8, false, 0>(k, s);
     }
     if (ci == 64 && w == 64) {
-        if (dg) return flip ? launch_rows<T, 64, 6, 10, true, true>(k, s) : 1;
-        return flip ? launch_rows<T, 64, 6, 10, true, false>(k, s) : launch_rows<T, 64, 6, 10, false, false>(k, s);
+        if (dg) {
+            if (!flip) return 1;
+            return dgm == 1 ? launch_rows<T, 64, 6, 10, true, 1>(k, s) : launch_rows<T, 64, 6, 8, true, 2>(k, s);
+        }
+        return flip ? launch_rows<T, 64, 6, 10, true, 0>(k, s) : launch_rows<T, 64, 6, 10, false, 0>(k, s);
     }
     return 1;
 }
