@@ -261,6 +261,8 @@ ROWS_S2_CASES = [
     (3, 128, 32, 64, False),     # encoder_1 / encoder_0 first downsample (N:816-817)
     (3, 64, 64, 128, True),      # second downsample: two 32-channel planes, four output groups
     (2, 128, 32, 64, True),
+    (2, 256, 32, 64, False),     # two column tiles per wave: the same layers of the 256 x 256 configs
+    (1, 128, 64, 128, True),
 ]
 
 

@@ -634,6 +634,127 @@ __global__ __launch_bounds__(512, CI == 32 ? 4 : 2) void conv3x3_rows_s2_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Two column tiles per wave (16 jobs per output row): 32 -> 64 channels at 256 input columns, 64 -> 128 at 128 -- the same two layers
+// of the 256 x 256 configs.  Two DMA pieces per wave and input row, one block per CU.
+template <int CI, int LWI, int NR>
+__global__ __launch_bounds__(512, 2) void conv3x3_rows_s2x2_kernel(const RowsK p) {
+    typedef bf16 T;
+    constexpr int WI = 1 << LWI, WO = WI / 2, KC = CI / 32, NCT = WO / 16, NCP = NCT / 2, SG = WI / 32;
+    constexpr int PLS = (WI / 2 + 1) * 64;
+    constexpr int RB = KC * 2 * PLS;
+    constexpr int ST = 16 * 80;
+    constexpr int L = (NR - 3) / 2;
+    static_assert(KC * 2 * SG == 16, "two DMA pieces per wave and input row");
+    typedef bf16x8 frag_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* stage = smem + NR * RB + wid * ST;
+    float* biasL = (float*)(smem + NR * RB + 8 * ST);         // 128 floats
+    const int p16 = lane & 15, q16 = lane >> 4;
+    const int ctp = wid % NCP, cg = wid / NCP;
+    const int band = blockIdx.x % p.bands, img = blockIdx.x / p.bands;
+    const int ho = p.h / 2;
+    const int y0 = band * p.band_rows;
+    const int y1 = min(ho, y0 + p.band_rows);
+    for (int i = tid * 16; i < NR * RB; i += 512 * 16) *(uint4*)(ring + i) = make_uint4(0u, 0u, 0u, 0u);
+    frag_t wb[9][KC][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                wb[t][kc][j] = *(const frag_t*)(p.w + ((long long)(t * KC + kc) * p.co_tot + cg * 32 + 16 * j + p16) * 64 + q16 * 16);
+    if (tid < 128) biasL[tid] = (p.bias && tid < p.co_tot) ? p.bias[tid] : 0.f;
+    __syncthreads();
+
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int pi0 = 2 * wid, pi1 = 2 * wid + 1;
+    const int sg0 = pi0 % SG, pr0 = (pi0 / SG) & 1, kp0 = pi0 / (2 * SG), sg1 = pi1 % SG, pr1 = (pi1 / SG) & 1, kp1 = pi1 / (2 * SG);
+    const int Pd0 = 16 * sg0 + (lane >> 2), Pd1 = 16 * sg1 + (lane >> 2);
+    const unsigned d_off0 = (unsigned)((2 * Pd0 + pr0) * p.ldi * 2 + kp0 * 64 + (((lane & 3) ^ r_swz(Pd0)) << 4));
+    const unsigned d_off1 = (unsigned)((2 * Pd1 + pr1) * p.ldi * 2 + kp1 * 64 + (((lane & 3) ^ r_swz(Pd1)) << 4));
+    const unsigned char* in_img = p.in + (long long)img * p.h * WI * p.ldi * 2;
+    const unsigned row_bytes = (unsigned)(WI * p.ldi * 2);
+    auto issue_row = [&](int k) __attribute__((always_inline)) {          // input row 2 y0 + k
+        const int y = 2 * y0 + k;
+        const unsigned char* src = y < p.h ? in_img + (long long)y * row_bytes : ups_rows_zero;
+        const unsigned dst0 = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((k % NR) * RB + (kp0 * 2 + pr0) * PLS + 16 * sg0 * 64));
+        const unsigned dst1 = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((k % NR) * RB + (kp1 * 2 + pr1) * PLS + 16 * sg1 * 64));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst0), "v"(d_off0), "s"(src) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst1), "v"(d_off1), "s"(src) : "memory", "m0");
+    };
+    issue_row(0);
+#pragma unroll
+    for (int i = 0; i < L; ++i) { issue_row(2 * i + 1); issue_row(2 * i + 2); }
+
+    const float oact_ns = ups_slope_eff(p.out_act, p.slope);
+    unsigned char* out_img = p.out + (long long)img * ho * WO * p.ldo * 2;
+    const int iters = y1 - y0;
+    for (int it = 0; it < iters; ++it) {
+        // (four requests and two stores per wave and iteration)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * 4 + 2) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_row(2 * (it + L) + 1);
+        issue_row(2 * (it + L) + 2);
+        const int y = y0 + it;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ct = 2 * ctp + c;
+            f32x4v acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = *(const f32x4v*)(biasL + cg * 32 + 16 * j + 4 * q16);
+#pragma unroll
+            for (int dyi = 0; dyi < 3; ++dyi) {
+                const unsigned char* rowp = ring + ((2 * it + dyi) % NR) * RB;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int P = 16 * ct + p16 + (dx == 2 ? 1 : 0);
+                    const int aoff = (dx & 1) * PLS + P * 64 + ((q16 ^ r_swz(P)) << 4);
+#pragma unroll
+                    for (int kc = 0; kc < KC; ++kc) {
+                        const frag_t a = *(const frag_t*)(rowp + kc * 2 * PLS + aoff);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[dyi * 3 + dx][kc][j], a, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][e];
+                if (p.out_act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ups_vmax(v[e], oact_ns * v[e]);
+                }
+                *(uint2*)(stage + p16 * 80 + (16 * j + 4 * q16) * 2) = make_uint2(Chunk<T>::pk(v[0], v[1]), Chunk<T>::pk(v[2], v[3]));
+            }
+            const uint4 o = *(const uint4*)(stage + (lane >> 2) * 80 + (lane & 3) * 16);
+            *(uint4*)(out_img + ((long long)y * WO + 16 * ct + (lane >> 2)) * p.ldo * 2 + (cg * 32 + 8 * (lane & 3)) * 2) = o;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int CI, int LWI, int NR>
+int launch_rows_s2x2(const RowsK& k, hipStream_t s) {
+    constexpr int WI = 1 << LWI, KC = CI / 32;
+    constexpr size_t smem = (size_t)NR * KC * 2 * (WI / 2 + 1) * 64 + 8 * 16 * 80 + 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_rows_s2x2_kernel<CI, LWI, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return UPS_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_rows_s2x2_kernel<CI, LWI, NR>), dim3(k.n * k.bands), dim3(512), smem, s, k);
+    return UPS_OK;
+}
+
 template <int CI, int LWI, int NR>
 int launch_rows_s2(const RowsK& k, hipStream_t s) {
     constexpr int WI = 1 << LWI, KC = CI / 32;
@@ -939,7 +1060,8 @@ int ups_conv3x3_rows_s2_try(const ups_conv_desc* d, hipStream_t s) {
     if (d->dtype != UPS_BF16 || d->ntaps != 9 || d->kh != 3 || d->kw != 3 || d->in_sy != 2 || d->in_sx != 2 || d->out_sy != 1 ||
         d->out_sx != 1 || d->out_oy || d->out_ox || d->out_h != d->ho || d->out_w != d->wo)
         return 1;
-    if (!((d->ci == 32 && d->wi == 128 && d->co == 64) || (d->ci == 64 && d->wi == 64 && d->co == 128))) return 1;
+    const bool two = (d->ci == 32 && d->wi == 256 && d->co == 64) || (d->ci == 64 && d->wi == 128 && d->co == 128);     // the 256 x 256 configs
+    if (!((d->ci == 32 && d->wi == 128 && d->co == 64) || (d->ci == 64 && d->wi == 64 && d->co == 128) || two)) return 1;
     if (d->hi != d->wi || d->ho * 2 != d->hi || d->wo * 2 != d->wi || d->co_fill != d->co || d->ldo < d->co || (d->ldo & 7) || (d->ldi & 7)) return 1;
     if (d->act_in != UPS_ACT_NONE || d->res || d->dact || d->coord_tab || d->d2s || d->out_f32 || d->mask_bits || d->mask_grad || d->f8_deq ||
         d->in_f8 || d->out_f8 || d->out_f8_amax || d->res_act)
@@ -956,6 +1078,7 @@ int ups_conv3x3_rows_s2_try(const ups_conv_desc* d, hipStream_t s) {
     k.band_rows = 32; k.bands = d->ho / 32;
     k.res_self = 0; k.res_act = 0; k.out_act = d->out_act;
     k.slope = d->act_slope; k.dact_ns = 0.f;
+    if (two) return d->ci == 32 ? launch_rows_s2x2<32, 8, 7>(k, s) : launch_rows_s2x2<64, 7, 7>(k, s);
     return d->ci == 32 ? launch_rows_s2<32, 7, 7>(k, s) : launch_rows_s2<64, 6, 9>(k, s);
 }
 
