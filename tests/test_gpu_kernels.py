@@ -1128,13 +1128,12 @@ def test_part_masked_convolution_matches_the_materialised_path(P, B, S, coords, 
     assert_close(res["fused"][0][..., :32].float(), yo.float(), BF16_TOL, "part-masked conv vs oracle")
 
 
-@pytest.mark.parametrize("P,B,H", [(10, 3, 128), (3, 4, 32), (25, 1, 64)])
-def test_part_mask_gradient_row_stream(P, B, H, dev, monkeypatch):
+@pytest.mark.parametrize("P,B,H,W", [(10, 3, 128, 128), (3, 4, 32, 128), (25, 1, 64, 128), (5, 2, 64, 256), (20, 1, 32, 256)])
+def test_part_mask_gradient_row_stream(P, B, H, W, dev, monkeypatch):
     """conv3x3_rows.hip, mask-gradient form: d loss / d hard of encoder_1's part-masked first convolution (M:176-187) at 128 columns as a
     row stream of the gradient tensor.  Against the patch kernel's epilogue (UPS_ROWS_KERNEL=0) on the same operands and against
     the fp64 oracle's autograd through the materialised part images."""
     lib, ops, R = _mods()
-    W = 128
     g = torch.Generator().manual_seed(90 + P)
     view = (torch.rand(B, H, W, 3, generator=g) * 2 - 1).to(dev)
     mean = torch.randn(B, H, W, P, generator=g).to(dev)

@@ -434,16 +434,18 @@ struct MaskGK {
     int n, h, ldi, co, B, P, band_rows, bands;
 };
 
-template <int NR>
-__global__ __launch_bounds__(512, 4) void conv3x3_rows_maskgrad_kernel(const MaskGK p) {
-    constexpr int W = 128, PL = (W + 2) * 64, RB = PL;
+// CTW column tiles per wave: 1 at 128 columns (two blocks per CU), 2 at 256 (one).
+template <int NR, int LW, int CTW>
+__global__ __launch_bounds__(512, CTW == 1 ? 4 : 2) void conv3x3_rows_maskgrad_kernel(const MaskGK p) {
+    constexpr int W = 1 << LW, PL = (W + 2) * 64, RB = PL;
     constexpr int L = (NR - 4) / 2;
-    static_assert(L == 2, "the counted waits below are written for a lead of two iterations");
+    static_assert(L == 2 && W == 128 * CTW, "the counted waits below are written for a lead of two iterations; 16 CTW columns per wave");
+    constexpr int NOP = 6 * CTW;               // vector-memory operations per wave and iteration: 2 CTW view loads, 2 CTW requests, 2 CTW stores
     typedef bf16x8 frag_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);          // column tile = DMA segment
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);         // column tile (pair) = DMA segment (pair)
     const int p16 = lane & 15, q16 = lane >> 4;
     const int band = blockIdx.x % p.bands, img = blockIdx.x / p.bands;       // img = part * B + b (part-major)
     const int part = img / p.B, b = img - part * p.B;
@@ -455,15 +457,23 @@ __global__ __launch_bounds__(512, 4) void conv3x3_rows_maskgrad_kernel(const Mas
     for (int t = 0; t < 9; ++t) wb[t] = *(const frag_t*)(p.w + ((long long)t * p.co + wrow) * 64 + q16 * 16);
     __syncthreads();
     const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int Pd = 1 + 16 * ct + (lane >> 2);
-    const unsigned d_off = (unsigned)((16 * ct + (lane >> 2)) * p.ldi * 2 + (((lane & 3) ^ r_swz(Pd)) << 4));
+    unsigned d_off[CTW];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+        const int ct = CTW * wid + c;
+        const int Pd = 1 + 16 * ct + (lane >> 2);
+        d_off[c] = (unsigned)((16 * ct + (lane >> 2)) * p.ldi * 2 + (((lane & 3) ^ r_swz(Pd)) << 4));
+    }
     const unsigned char* in_img = p.in + (long long)img * p.h * W * p.ldi * 2;
     const unsigned row_bytes = (unsigned)(W * p.ldi * 2);
     auto issue_row = [&](int k) __attribute__((always_inline)) {
         const int y = y0 - 1 + k;
         const unsigned char* src = (unsigned)y < (unsigned)p.h ? in_img + (long long)y * row_bytes : ups_rows_zero;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((k % NR) * RB + (1 + 16 * ct) * 64));
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(d_off), "s"(src) : "memory", "m0");
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((k % NR) * RB + (1 + 16 * (CTW * wid + c)) * 64));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(d_off[c]), "s"(src) : "memory", "m0");
+        }
     };
     issue_row(0); issue_row(1);
 #pragma unroll
@@ -472,54 +482,63 @@ __global__ __launch_bounds__(512, 4) void conv3x3_rows_maskgrad_kernel(const Mas
     float* gh_img = p.g_hard + (long long)b * p.h * W * p.P + part;
     const int iters = (y1 - y0 + 1) >> 1;
     for (int it = 0; it < iters; ++it) {
-        // Per iteration a wave issues, in this order: two view loads (the three fp32 view channels of its pixel in the two output rows;
-        // inline asm like the DMAs -- a compiler-visible load would be waited for with vmcnt(0), i.e. together with every row request
-        // in flight), two row requests, two stores.  The requests of iteration it - L must have landed here: younger operations are
-        // the other prologue requests (it == 0) or at least the previous iteration's six (it >= 1).
-        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * 2) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * 6) : "memory");
+        // Per iteration a wave issues, in this order: 2 CTW view loads (the three fp32 view channels of its pixels in the two output
+        // rows; inline asm like the DMAs -- a compiler-visible load would be waited for with vmcnt(0), i.e. together with every row
+        // request in flight), 2 CTW row requests, 2 CTW stores.  The requests of iteration it - L must have landed here: younger
+        // operations are the other prologue requests (it == 0) or at least the previous iteration's NOP (it >= 1).
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * 2 * CTW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * NOP) : "memory");
         __builtin_amdgcn_s_barrier();
-        const int x = 16 * ct + p16;
-        f32x3v vw[2];
+        f32x3v vw[CTW][2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int y = min(y0 + 2 * it + r, p.h - 1);
-            const float* vp = view_img + ((long long)y * W + x) * p.co;
-            asm volatile("global_load_dwordx3 %0, %1, off" : "=&v"(vw[r]) : "v"(vp) : "memory");
-        }
+        for (int c = 0; c < CTW; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int y = min(y0 + 2 * it + r, p.h - 1);
+                const float* vp = view_img + ((long long)y * W + 16 * (CTW * wid + c) + p16) * p.co;
+                asm volatile("global_load_dwordx3 %0, %1, off" : "=&v"(vw[c][r]) : "v"(vp) : "memory");
+            }
         issue_row(2 * it + 2 * L + 2);
         issue_row(2 * it + 2 * L + 3);
-        f32x4v acc[2];
-        acc[0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
         const unsigned char* rowp[4];
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) rowp[r4] = ring + ((2 * it + r4) % NR) * RB;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int P = 16 * ct + p16 + dx;
-            const int aoff = P * 64 + ((q16 ^ r_swz(P)) << 4);
-            frag_t a[4];
+        for (int c = 0; c < CTW; ++c) {
+            const int ct = CTW * wid + c;
+            f32x4v acc[2];
+            acc[0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) a[r4] = *(const frag_t*)(rowp[r4] + aoff);
+            for (int dx = 0; dx < 3; ++dx) {
+                const int P = 16 * ct + p16 + dx;
+                const int aoff = P * 64 + ((q16 ^ r_swz(P)) << 4);
+                frag_t a[4];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+                for (int r4 = 0; r4 < 4; ++r4) a[r4] = *(const frag_t*)(rowp[r4] + aoff);
 #pragma unroll
-                for (int dyi = 0; dyi < 3; ++dyi)
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[(2 - dyi) * 3 + (2 - dx)], a[r + dyi], acc[r], 0, 0, 0);
-        }
-        // the view values: the two row requests issued behind them may stay in flight
-        asm volatile("s_waitcnt vmcnt(2)" : "+v"(vw[0]), "+v"(vw[1]) :: "memory");
+                for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int y = y0 + 2 * it + r;
-            float s = (float)(bf16)acc[r][0] * vw[r][0];
-            if (p.co > 1) s += (float)(bf16)acc[r][1] * vw[r][1];
-            if (p.co > 2) s += (float)(bf16)acc[r][2] * vw[r][2];
-            // (every wave stores in every iteration -- a static count for the waits above; rows past the band and the lanes that
-            // hold other channels write nothing)
-            float* dst = gh_img + ((long long)min(y, p.h - 1) * W + x) * p.P;
-            const bool on = y < y1 && q16 == 0;
-            asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dword %1, %2, off\n\ts_mov_b64 exec, -1" :: "s"(__ballot(on)), "v"(dst), "v"(s) : "memory");
+                    for (int dyi = 0; dyi < 3; ++dyi)
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[(2 - dyi) * 3 + (2 - dx)], a[r + dyi], acc[r], 0, 0, 0);
+            }
+            // the view values: behind them the 2 CTW row requests (and the first tile's two stores) may stay in flight
+            if (c == 0) {
+                if constexpr (CTW == 1) asm volatile("s_waitcnt vmcnt(2)" : "+v"(vw[0][0]), "+v"(vw[0][1]) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" : "+v"(vw[0][0]), "+v"(vw[0][1]), "+v"(vw[CTW - 1][0]), "+v"(vw[CTW - 1][1]) :: "memory");
+            }
+            const int x = 16 * ct + p16;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int y = y0 + 2 * it + r;
+                float s = (float)(bf16)acc[r][0] * vw[c][r][0];
+                s += (float)(bf16)acc[r][1] * vw[c][r][1];
+                s += (float)(bf16)acc[r][2] * vw[c][r][2];
+                // (every wave stores in every iteration -- a static count for the waits above; rows past the band and the lanes that
+                // hold other channels write nothing)
+                float* dst = gh_img + ((long long)min(y, p.h - 1) * W + x) * p.P;
+                const bool on = y < y1 && q16 == 0;
+                asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dword %1, %2, off\n\ts_mov_b64 exec, -1" :: "s"(__ballot(on)), "v"(dst), "v"(s) : "memory");
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1121,7 +1140,7 @@ int ups_conv3x3_rows_maskgrad_try(const ups_conv_desc* d, hipStream_t s) {
     if (!rows_on()) return 1;
     if (!d->mask_grad || !d->mask_view || d->mask_bits || d->dtype != UPS_BF16) return 1;
     if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox) return 1;
-    if (d->hi != d->ho || d->wi != d->wo || d->wi != 128 || d->hi % 32) return 1;
+    if (d->hi != d->ho || d->wi != d->wo || (d->wi != 128 && d->wi != 256) || d->hi % 32) return 1;
     if (d->ci != 32 || d->co != 3 || (d->ldi & 7) || d->ldi < 32) return 1;       // (three view channels: one dwordx3 load per pixel)
     if (d->act_in != UPS_ACT_NONE || d->res || d->dact || d->coord_tab || d->d2s || d->f8_deq || d->in_f8 || d->out_f8 || d->out_f8_amax ||
         d->out_act || d->res_act || d->bias)
@@ -1137,13 +1156,24 @@ int ups_conv3x3_rows_maskgrad_try(const ups_conv_desc* d, hipStream_t s) {
     k.n = d->n; k.h = d->hi; k.ldi = d->ldi; k.co = d->co; k.B = d->mask_batch; k.P = d->n / d->mask_batch;
     k.band_rows = 32; k.bands = d->hi / 32;
     constexpr int NR = 8;
-    constexpr size_t smem = (size_t)NR * 130 * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_rows_maskgrad_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return UPS_E_LAUNCH;
-        attr_set = true;
+    if (d->wi == 128) {
+        constexpr size_t smem = (size_t)NR * 130 * 64;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)conv3x3_rows_maskgrad_kernel<NR, 7, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+                return UPS_E_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv3x3_rows_maskgrad_kernel<NR, 7, 1>), dim3(k.n * k.bands), dim3(512), smem, s, k);
+    } else {
+        constexpr size_t smem = (size_t)NR * 258 * 64;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)conv3x3_rows_maskgrad_kernel<NR, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+                return UPS_E_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv3x3_rows_maskgrad_kernel<NR, 8, 2>), dim3(k.n * k.bands), dim3(512), smem, s, k);
     }
-    hipLaunchKernelGGL((conv3x3_rows_maskgrad_kernel<NR>), dim3(k.n * k.bands), dim3(512), smem, s, k);
     return UPS_OK;
 }
