@@ -577,7 +577,12 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         constexpr int BST = 3 * BN * 64;                 // bytes per weight stage
         constexpr int NJ = 3 * BN * 4 / 64;              // DMA wave-instructions per stage: 24 / 12 / 6
         constexpr int NW = (NJ + 7) / 8;                 // per wave: 3 / 2 / 1
-        constexpr int NST = (OCC == 2) ? 2 : 3;          // ring stages
+        // CHUNKST (multi-image tiles, N-tiles up to 64 wide): the 4x4 / 8x8 maps run as grids of 64-160 blocks whose 24 tap-rows of
+        // 4-8 MFMAs per wave sit behind a weight stream two tap-rows deep -- one L2 round trip per two tap-rows and nothing else
+        // (25-48 us per launch for 2-10 us of MFMA work).  There a stage is a whole 32-channel chunk (all nine taps: 3 x BST), two
+        // of them: the next chunk's 18 / 37 KB are requested at once, one barrier and one exposed round trip per CHUNK
+        constexpr bool CHUNKST = SUB < TS && BN <= 64 && F8 == 0 && OCC == 1;
+        constexpr int NST = (OCC == 2) ? 2 : (CHUNKST ? 6 : 3);          // ring stages (tap-rows)
 #if defined(UPS_OCC2_FRAG2)
         constexpr int FRAG_BUFS = 2;
 #else
@@ -749,7 +754,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         // up front, ONE wait + barrier, then the three tap-rows run back to back (the thin 128x128 layers of encoder_1 on the
         // part images and the heads' input gradients are chains of load -> barrier round trips otherwise)
         const bool one_shot = OCC != 2 && kchunks == 1;
-        if (one_shot) dma_w(2);
+        if (one_shot || CHUNKST) dma_w(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         UPS_PHASE(2);
@@ -815,6 +820,29 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #endif
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        } else if constexpr (CHUNKST) {
+        for (int cc = 0; cc < kchunks; ++cc) {
+            if (cc + 1 < kchunks) {
+                load_patch(cc + 1);
+                dma_w(3 * cc + 3); dma_w(3 * cc + 4); dma_w(3 * cc + 5);
+            }
+            const unsigned char* A = Abuf + (cc & 1) * ABY;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const unsigned char* B = Bst + ((3 * cc + g) % NST) * BST + (wn * TN * 32) * 64 + boff16;
+                const int dx0 = p_dx(p.tap_off, 3 * g) + 1, dx1 = p_dx(p.tap_off, 3 * g + 1) + 1, dx2 = p_dx(p.tap_off, 3 * g + 2) + 1;
+                const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
+                const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
+                const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
+                bf16_taps16<T, TM16, TN16, 0, F8, A2FR>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
+                                        a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
+                                        a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
+            }
+            if (cc + 1 < kchunks) store_patch(Abuf + ((cc + 1) & 1) * ABY);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1239,8 +1267,9 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     kk.m_tx = div_magic(nblocks, tiles_x); kk.m_ty = div_magic(nblocks, tiles_y);
     constexpr size_t BST = 3 * (size_t)BN * 64;
     const int nabuf = (sizeof(T) == 2 && SUB == TS && (kchunks == 1 || OCC == 2)) ? 1 : 2;
-    size_t shmem = sizeof(T) == 2 ? nabuf * ABY + (OCC == 2 ? 2 : 3) * BST : 2 * ABY + 2 * 3 * BN * RS;
-    size_t shmem_max = sizeof(T) == 2 ? (OCC == 2 ? 1 : 2) * ABY + (OCC == 2 ? 2 : 3) * BST : shmem;
+    constexpr int nst = OCC == 2 ? 2 : ((SUB < TS && BN <= 64 && F8 == 0 && OCC == 1) ? 6 : 3);      // (NST / CHUNKST of the kernel)
+    size_t shmem = sizeof(T) == 2 ? nabuf * ABY + nst * BST : 2 * ABY + 2 * 3 * BN * RS;
+    size_t shmem_max = sizeof(T) == 2 ? (OCC == 2 ? 1 : 2) * ABY + nst * BST : shmem;
     if (F8 >= 3) shmem = shmem_max = 2 * ABY + 2 * (2 * (size_t)BN * 64);      // block-scaled fp8: two patch images, two per-tap stages
     const size_t epi = sizeof(T) == 2 ? 256 * (size_t)(BN * 2 + 16) + 256 * (size_t)(BN / 8) : 0;   // staged bf16 epilogue
     if (epi > shmem) shmem = epi;
