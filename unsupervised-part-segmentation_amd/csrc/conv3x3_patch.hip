@@ -259,7 +259,10 @@ template <> struct PMma<float> {
 // halo patch then arrives by LDS-DMA like the weights -- 23 wave-instructions of 1 KiB per chunk, the swizzle applied on the
 // source side, patch pixels outside the image masked off in EXEC (their slots were zeroed once and are never written) -- with
 // no staging registers, no VALU and no ds_write.  Every input-gradient launch qualifies (its input is the gradient tensor).
-template <typename T, int BN, int OCC, int SUB, int F8 = 0, bool PRE = false, int TAPS = 0, bool DMAP = false>
+// CSTD: chunk-granular weight stages (CHUNKST below) for a one-tile-per-image instance with the DMA patch -- chosen by the launcher
+// for grids of at most one 128-wide block per CU (16x16 / 32x32 maps at small batches), as 64-wide tiles: twice the blocks, one
+// barrier and one exposed L2 round trip per 32-channel chunk instead of three
+template <typename T, int BN, int OCC, int SUB, int F8 = 0, bool PRE = false, int TAPS = 0, bool DMAP = false, bool CSTD = false>
 __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const PatchK p, const int tiles_x, const int tiles_y,
                                                                  const int ntn, const int kchunks, const int nblocks) {
     constexpr int EPC = Chunk<T>::N;
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         // 4-8 MFMAs per wave sit behind a weight stream two tap-rows deep -- one L2 round trip per two tap-rows and nothing else
         // (25-48 us per launch for 2-10 us of MFMA work).  There a stage is a whole 32-channel chunk (all nine taps: 3 x BST), two
         // of them: the next chunk's 18 / 37 KB are requested at once, one barrier and one exposed round trip per CHUNK
-        constexpr bool CHUNKST = SUB < TS && BN <= 64 && F8 == 0 && OCC == 1;
+        constexpr bool CHUNKST = (SUB < TS || (CSTD && DMAP && SUB == TS)) && BN <= 64 && F8 == 0 && OCC == 1;
         constexpr int NST = (OCC == 2) ? 2 : (CHUNKST ? 6 : 3);          // ring stages (tap-rows)
 #if defined(UPS_OCC2_FRAG2)
         constexpr int FRAG_BUFS = 2;
@@ -827,22 +830,31 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         } else if constexpr (CHUNKST) {
         for (int cc = 0; cc < kchunks; ++cc) {
             if (cc + 1 < kchunks) {
-                load_patch(cc + 1);
+                if constexpr (DMAP) dma_patch(cc + 1, ((cc + 1) & 1) * ABY);
+                else load_patch(cc + 1);
                 dma_w(3 * cc + 3); dma_w(3 * cc + 4); dma_w(3 * cc + 5);
             }
             const unsigned char* A = Abuf + (cc & 1) * ABY;
+            add_res_patch(A, cc);
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const unsigned char* B = Bst + ((3 * cc + g) % NST) * BST + (wn * TN * 32) * 64 + boff16;
-                const int dx0 = p_dx(p.tap_off, 3 * g) + 1, dx1 = p_dx(p.tap_off, 3 * g + 1) + 1, dx2 = p_dx(p.tap_off, 3 * g + 2) + 1;
-                const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
-                const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
-                const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
-                bf16_taps16<T, TM16, TN16, 0, F8, A2FR>(A, B, arow16, po0, po1, po2, a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4),
-                                        a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
-                                        a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
+                if constexpr (TAPS != 0) {
+                    const int po0 = ((TAPS == 1 ? g : 2 - g) * PWPS + (TAPS == 1 ? 0 : 2)) * APX;
+                    bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8, A2FR>(A, B, arow16, po0, po0 + (TAPS == 1 ? APX : -APX),
+                                            po0 + (TAPS == 1 ? 2 * APX : -2 * APX), TAPS == 1 ? swx0 : swx2, swx1, TAPS == 1 ? swx2 : swx0,
+                                            BN * 64, acc16);
+                } else {
+                    const int dx0 = p_dx(p.tap_off, 3 * g) + 1, dx1 = p_dx(p.tap_off, 3 * g + 1) + 1, dx2 = p_dx(p.tap_off, 3 * g + 2) + 1;
+                    const int po0 = ((p_dy(p.tap_off, 3 * g) + 1) * PWPS + dx0) * APX;
+                    const int po1 = ((p_dy(p.tap_off, 3 * g + 1) + 1) * PWPS + dx1) * APX;
+                    const int po2 = ((p_dy(p.tap_off, 3 * g + 2) + 1) * PWPS + dx2) * APX;
+                    bf16_taps16<T, TM16, TN16, (SUB == TS ? PWPS * APX : 0), F8, A2FR>(A, B, arow16, po0, po1, po2,
+                                            a_lane16 + ((q16 ^ a_swz16(px_l16 + dx0)) << 4), a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
+                                            a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
+                }
             }
-            if (cc + 1 < kchunks) store_patch(Abuf + ((cc + 1) & 1) * ABY);
+            if constexpr (!DMAP) { if (cc + 1 < kchunks) store_patch(Abuf + ((cc + 1) & 1) * ABY); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1249,7 +1261,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     }
 }
 
-template <typename T, int BN, int OCC, int SUB, int F8 = 0, bool PRE = false, int TAPS = 0, bool DMAP = false>
+template <typename T, int BN, int OCC, int SUB, int F8 = 0, bool PRE = false, int TAPS = 0, bool DMAP = false, bool CSTD = false>
 int launch_bn(const PatchK& k, hipStream_t s) {
     constexpr int EPC = Chunk<T>::N;
     constexpr int G = TS / SUB, PR = G * (SUB + 2), PWPS = (PR + 3) / 4 * 4;
@@ -1267,7 +1279,7 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     kk.m_tx = div_magic(nblocks, tiles_x); kk.m_ty = div_magic(nblocks, tiles_y);
     constexpr size_t BST = 3 * (size_t)BN * 64;
     const int nabuf = (sizeof(T) == 2 && SUB == TS && (kchunks == 1 || OCC == 2)) ? 1 : 2;
-    constexpr int nst = OCC == 2 ? 2 : ((SUB < TS && BN <= 64 && F8 == 0 && OCC == 1) ? 6 : 3);      // (NST / CHUNKST of the kernel)
+    constexpr int nst = OCC == 2 ? 2 : (((SUB < TS || (CSTD && DMAP && SUB == TS)) && BN <= 64 && F8 == 0 && OCC == 1) ? 6 : 3);      // (NST / CHUNKST of the kernel)
     size_t shmem = sizeof(T) == 2 ? nabuf * ABY + nst * BST : 2 * ABY + 2 * 3 * BN * RS;
     size_t shmem_max = sizeof(T) == 2 ? (OCC == 2 ? 1 : 2) * ABY + nst * BST : shmem;
     if (F8 >= 3) shmem = shmem_max = 2 * ABY + 2 * (2 * (size_t)BN * 64);      // block-scaled fp8: two patch images, two per-tap stages
@@ -1275,12 +1287,12 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     if (epi > shmem) shmem = epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE, TAPS, DMAP>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE, TAPS, DMAP, CSTD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(epi > shmem_max ? epi : shmem_max));
         if (e != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE, TAPS, DMAP>), dim3(nblocks), dim3(512), shmem, s, kk, tiles_x, tiles_y, ntn,
+    hipLaunchKernelGGL((conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE, TAPS, DMAP, CSTD>), dim3(nblocks), dim3(512), shmem, s, kk, tiles_x, tiles_y, ntn,
                        kchunks, nblocks);
     return UPS_OK;
 }
@@ -1370,6 +1382,15 @@ int launch_t(const PatchK& k, hipStream_t s) {
             static int mid = -1;
             if (mid < 0) { const char* e = getenv("UPS_PATCH_MID"); mid = (e && e[0] == '0') ? 0 : 1; }
             if (mid && patch_occ() == 2 && tiles * ups_cdiv(k.co_fill, 64) >= 512) return launch_v<T, 64, 2>(k, s);
+            {   // at most one 128-wide block per CU, many channel chunks: 64-wide tiles with chunk-granular weight stages (CSTD)
+                static int cst = -1;
+                if (cst < 0) { const char* e = getenv("UPS_PATCH_CST"); cst = (e && e[0] == '0') ? 0 : 1; }
+                const bool dmap = dma_patch_on() && k.act_in == UPS_ACT_NONE && !k.mask && !k.mask_grad && k.ci % 32 == 0;
+                if (cst && static_taps_on() && dmap && !k.out_f8_amax && k.ci >= 128 && tiles * ups_cdiv(k.co_fill, 128) <= 256) {
+                    if (k.taps_static == 1) return launch_bn<T, 64, 1, TS, 0, false, 1, true, true>(k, s);
+                    if (k.taps_static == 2) return launch_bn<T, 64, 1, TS, 0, false, 2, true, true>(k, s);
+                }
+            }
             return launch_v<T, 128, 1>(k, s);
         }
         if (k.co_fill > 32) {
