@@ -20,6 +20,7 @@ struct WgK {
     float act_slope;
     unsigned long long tap_off, tap_wi;
     const void* in; const void* dout; float* ws;
+    float* bias_direct;      // one split: ws is the gradient itself (same offsets as a slab's weight part), the bias goes here
 };
 
 __device__ inline int wtap_dy(unsigned long long off, int t) { return (int)((off >> (4 * t + 2)) & 3) - 1; }
@@ -233,7 +234,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p, const int 
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < BPARTS; ++k) s += red[k * BNW + tid];
-            slab[(long long)p.ntaps * p.cin_v * p.co + co0 + tid] = s;
+            if (p.bias_direct) p.bias_direct[co0 + tid] = s;
+            else slab[(long long)p.ntaps * p.cin_v * p.co + co0 + tid] = s;
         }
     }
 }
@@ -365,7 +367,7 @@ extern "C" int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream) {
     k.ntaps = d->ntaps; k.act_in = d->act_in; k.act_slope = d->act_slope; k.want_bias = d->grad_bias != nullptr;
     k.in_f16 = d->in_f16;
     UPS_CHECK_ARG(!d->in_f16 || (d->dtype == UPS_BF16 && !d->mask_bits));
-    k.in = d->in; k.dout = d->dout; k.ws = d->workspace;
+    k.in = d->in; k.dout = d->dout; k.ws = d->workspace; k.bias_direct = nullptr;
     k.tap_off = 0; k.tap_wi = 0;
     int max_tw = 0;
     for (int t = 0; t < d->ntaps; ++t) {
@@ -390,8 +392,18 @@ extern "C" int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream) {
         UPS_CHECK_ARG(d->splitk == sk3);
         if (ups_wgrad3x3_run(d, s) != UPS_OK) { ups_set_error("ups_conv_wgrad: patch kernel launch setup failed"); return UPS_E_LAUNCH; }
         nslabs = slabs3;
-    } else if (d->dtype == UPS_F32) launch_m<float>(k, (int)M, d->splitk, s);
-    else launch_m<bf16>(k, (int)M, d->splitk, s);
+    } else {
+        // a single split writes exactly the elements the reduction would (rows < ci_log of every tap, the bias): straight into the
+        // gradient, no slab and no second launch (the critics' 30 dense layers; UPS_WGRAD_DIRECT=0: off)
+        static int direct = -1;
+        if (direct < 0) { const char* e = getenv("UPS_WGRAD_DIRECT"); direct = (e && e[0] == '0') ? 0 : 1; }
+        const bool one = direct && d->splitk == 1;
+        if (one) { k.ws = d->grad; k.bias_direct = d->grad_bias; }
+        if (d->dtype == UPS_F32) launch_m<float>(k, (int)M, d->splitk, s);
+        else launch_m<bf16>(k, (int)M, d->splitk, s);
+        UPS_LAUNCH_CHECK();
+        if (one) return UPS_OK;
+    }
     UPS_LAUNCH_CHECK();
     const long long slab = (long long)d->ntaps * d->cin_v * d->co + d->co;
     const long long total = (long long)d->ntaps * d->ci_log * d->co + d->co;

@@ -33,6 +33,9 @@ from .schedules import make_var, make_linear_var
 
 PERCEPTUAL_INPUTS = ("native", "resize256", "resize256_crop224")
 LATE_JOIN = os.environ.get("UPS_LATE_JOIN", "1") != "0"      # A/B switch: single rank joins the weight-gradient stream only before Adam
+CRITIC_STREAMS = os.environ.get("UPS_CRITIC_STREAMS", "1") != "0"      # A/B switch: the three critics on three side streams
+EARLY_ALPHA = os.environ.get("UPS_EARLY_ALPHA", "1") != "0"      # A/B switch: appearance code on "aux" beside the pose encoder
+JOIN_TIMING = os.environ.get("UPS_JOIN_TIMING", "0") == "1"
 EARLY_ADAM = os.environ.get("UPS_EARLY_ADAM", "1") != "0"    # A/B switch: ... and queues each key's Adam behind its weight gradients
 
 
@@ -561,7 +564,7 @@ class Trainer(object):
             try:
                 with torch.cuda.stream(cap["stream"]):
                     if cap["cur"] is not None:
-                        ops.Streams.join(dev, names=("wgrad", "aux", "pre"))
+                        ops.Streams.join(dev, names=("wgrad", "aux1", "aux2", "aux", "pre"))
                         cap["cur"].capture_end()
             except Exception:
                 pass
@@ -697,6 +700,8 @@ class Trainer(object):
         c.img01 = torch.empty((2 * B, S, S, 8), dtype=c.T, device=self.device)     # both views, each converted into its half
         model.to_act(c.v0, out=c.img01[:B])
         model.to_act(c.v1, out=c.img01[B:])
+        if EARLY_ALPHA:
+            self._alpha(c)
         c.pe = nets.e_pi(Act(c.img01, 2 * B, S, S, 3)).t                  # fp32 [2B,1,1,NP], taped
         c.pe2 = c.pe.detach().view(2 * B, -1)
         c.pe_v0, c.pe_v1 = c.pe2[:B].contiguous(), c.pe2[B:].contiguous()
@@ -707,6 +712,24 @@ class Trainer(object):
         c.samples0, c.kl_rows = ops.latent_fwd(c.pe_v0, c.noise["eps_pi0"], c.levels0, True)
         c.samples1, _ = ops.latent_fwd(c.pe_v1, c.noise["eps_pi1"][None], [1.0], False)
 
+    def _alpha(self, c):
+        """Appearance code of the whole views: it feeds the critics only -> forward only (model.py:394-397).  It depends on the
+        images alone, so it is enqueued on the "aux" stream BEFORE the pose encoder goes to the launching stream: the two encoders
+        run side by side, and the critics can start the moment the latent samples exist."""
+        nets, B, S = self.model.nets, c.B, c.S
+
+        def run():
+            with torch.no_grad():
+                c.alpha = nets.e_alpha(Act(c.img01, 2 * B, S, S, 3)).t            # [2B,1,1,A]
+                c.alpha_in = torch.cat([c.alpha[B:], torch.flip(c.alpha[:B], dims=[0])], 0).contiguous()
+        if ops.Streams.enabled:
+            aux = ops.Streams.get("aux", self.device)
+            aux.wait_stream(c.main_stream)
+            with torch.cuda.stream(aux):
+                run()
+        else:
+            run()
+
     def _critics(self, c):
         """D: the three critics (model.py:502-521, 800-866), their own gradients, the adversarial gradient d adv / d z_joint0 for
         encoder_0 (model.py:886-909) and, for SB_model48c, the three single-sample decoders.  They depend on the latent samples
@@ -714,36 +737,56 @@ class Trainer(object):
         whole block (72 tiny GEMMs that cannot fill the chip) runs on the "aux" stream beside segments B and C."""
         cfg, model, nets, bank = self.config, self.model, self.model.nets, self.model.bank
         B, S, Z, A, keys, st, mi = c.B, c.S, c.Z, c.A, c.keys, c.st, c.mi
-        # appearance of the whole views feeds the critics only -> forward only (model.py:394-397)
-        with torch.no_grad():
-            alpha = nets.e_alpha(Act(c.img01, 2 * B, S, S, 3)).t            # [2B,1,1,A]
-            alpha_in = torch.cat([alpha[B:], torch.flip(alpha[:B], dims=[0])], 0).contiguous()
+        if not EARLY_ALPHA:
+            with torch.no_grad():
+                c.alpha = nets.e_alpha(Act(c.img01, 2 * B, S, S, 3)).t            # [2B,1,1,A]
+                c.alpha_in = torch.cat([c.alpha[B:], torch.flip(c.alpha[:B], dims=[0])], 0).contiguous()
+        alpha, alpha_in = c.alpha, c.alpha_in
         crit = {}
-        for ci, name in enumerate(("mi0_discriminator", "mi1_discriminator", "mi_estimator")):
+        c.adv, c.g_adv = None, None
+        names = ("mi0_discriminator", "mi1_discriminator", "mi_estimator")
+
+        def one(ci, name):
             pi_in = model.to_act(torch.cat([c.samples0[1 + 2 * ci], c.samples0[2 + 2 * ci]], 0).view(2 * B, 1, 1, Z))
             pi_in.requires_grad_(name == "mi0_discriminator")
             h_pi, h_al = nets.critic(name, (Act(pi_in, 2 * B, 1, 1, Z), Act(alpha_in, 2 * B, 1, 1, A)))
             # dot product of the two embeddings, logistic losses, accuracy and the mean joint logit: one launch (+ one backward)
             loss, acc, mean_joint = ops.CriticHeadFn.apply(h_pi.t, h_al.t, B, N.DSIZE)
             crit[name] = (loss, mean_joint, acc, pi_in)
-        _, c.mim, _, pi_leaf0 = crit["mi0_discriminator"]                    # logit_constraint(real=False), model.py:855
-        _, c.ind_mim, _, _ = crit["mi1_discriminator"]
-        c.adv, c.g_adv = None, None
-        if cfg.get("adversarial_regularization", True):                   # model.py:886-909
-            loa, loa_lr = st["loa"], mi.get("loa_lr", 4.0)
-            loa_gain = c.mim - (1.0 - c.MI_SLACK) * c.MI_TARGET
-            if mi.get("loa_adaptive", True):
-                active = (loa_lr * loa_gain.detach() >= -loa).float()
-                c.adv = active * (loa * loa_gain + loa_lr / 2.0 * loa_gain ** 2)
-            else:
-                c.adv = loa * loa_gain
-            if "encoder_0" in keys:
-                with ops.skip_wgrad():
-                    c.g_adv = torch.autograd.grad([c.adv], [pi_leaf0], retain_graph=True)[0].float().view(2 * B, Z)[:B]
-        for name in ("mi0_discriminator", "mi1_discriminator", "mi_estimator"):
+            if ci == 0:
+                c.mim = mean_joint                                            # logit_constraint(real=False), model.py:855
+                if cfg.get("adversarial_regularization", True):               # model.py:886-909
+                    loa, loa_lr = st["loa"], mi.get("loa_lr", 4.0)
+                    loa_gain = c.mim - (1.0 - c.MI_SLACK) * c.MI_TARGET
+                    if mi.get("loa_adaptive", True):
+                        active = (loa_lr * loa_gain.detach() >= -loa).float()
+                        c.adv = active * (loa * loa_gain + loa_lr / 2.0 * loa_gain ** 2)
+                    else:
+                        c.adv = loa * loa_gain
+                    if "encoder_0" in keys:
+                        with ops.skip_wgrad():
+                            c.g_adv = torch.autograd.grad([c.adv], [pi_in], retain_graph=True)[0].float().view(2 * B, Z)[:B]
+            elif ci == 1:
+                c.ind_mim = mean_joint
             if name in keys:
-                ps = [bank.params[n] for n in bank.groups[name]["names"]]
-                torch.autograd.grad([crit[name][0]], ps)
+                torch.autograd.grad([loss], [bank.params[n] for n in bank.groups[name]["names"]])
+
+        # the three critics are independent chains of ~80 launches of a few blocks each; behind a main stream whose kernels fill
+        # every CU each of those launches waits for a slot, so the chains run side by side on three streams (all joined into "aux")
+        cur = torch.cuda.current_stream(self.device)
+        # (not while a HIP graph is being captured: ending a capture with streams forked from a forked stream crashes inside the runtime)
+        if ops.Streams.enabled and ops.Streams.on_aux(self.device) and CRITIC_STREAMS and self._step_graph_lr is None:
+            sides = [cur] + [ops.Streams.get("aux{}".format(i), self.device) for i in (1, 2)]
+            for sd in sides[1:]:
+                sd.wait_stream(cur)
+            for ci, name in enumerate(names):
+                with torch.cuda.stream(sides[ci]):
+                    one(ci, name)
+            for sd in sides[1:]:
+                cur.wait_stream(sd)
+        else:
+            for ci, name in enumerate(names):
+                one(ci, name)
         if c.df:
             # SB_model48c:491-505, 672-684, 812-814: three single-sample decoders on batch item 0 (inputs under
             # stop_gradient), each with its own perceptual loss and optimizer key
@@ -1021,7 +1064,14 @@ class Trainer(object):
         self._priors(c)
         pending += self._bwd_mask_decoder(c)
         # the critics' block (aux stream) must be complete from here on: g_adv, the critic losses and their gradients
-        ops.Streams.join(dev, names=("aux",))
+        if JOIN_TIMING and graph_lr is None:       # debug: how long the launching stream sits at this join (tools/probes/join_wait.py)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            ops.Streams.join(dev, names=("aux",))
+            ev[1].record()
+            self._join_events = getattr(self, "_join_events", []) + [ev]
+        else:
+            ops.Streams.join(dev, names=("aux",))
         pending += self._launch_reduce([k for k in ("mi0_discriminator", "mi1_discriminator", "mi_estimator") + N.EXTRA_48C
                                         if k in c.keys])
         self._bwd_pose(c)

@@ -76,8 +76,8 @@ class Streams(object):
 
     @classmethod
     def on_aux(cls, device):
-        st = cls._pool.get(("aux", torch.device(device).index))
-        return st is not None and torch.cuda.current_stream(device) == st
+        cur, idx = torch.cuda.current_stream(device), torch.device(device).index
+        return any(cls._pool.get((n, idx)) == cur for n in ("aux", "aux1", "aux2"))      # (aux1 / aux2: critics two and three)
 
     @classmethod
     def join(cls, device, names=("wgrad", "aux")):
