@@ -775,31 +775,33 @@ class Trainer(object):
         # every CU each of those launches waits for a slot, so the chains run side by side on three streams (all joined into "aux")
         cur = torch.cuda.current_stream(self.device)
         # (not while a HIP graph is being captured: ending a capture with streams forked from a forked stream crashes inside the runtime)
-        if ops.Streams.enabled and ops.Streams.on_aux(self.device) and CRITIC_STREAMS and self._step_graph_lr is None:
-            sides = [cur] + [ops.Streams.get("aux{}".format(i), self.device) for i in (1, 2)]
-            for sd in sides[1:]:
+        multi = ops.Streams.enabled and ops.Streams.on_aux(self.device) and CRITIC_STREAMS and self._step_graph_lr is None
+        sides = [cur] + ([ops.Streams.get("aux{}".format(i), self.device) for i in (1, 2)] if multi else [cur, cur])
+        for sd in sides[1:]:
+            if sd is not cur:
                 sd.wait_stream(cur)
-            for ci, name in enumerate(names):
-                with torch.cuda.stream(sides[ci]):
-                    one(ci, name)
-            for sd in sides[1:]:
-                cur.wait_stream(sd)
-        else:
-            for ci, name in enumerate(names):
+        for ci, name in enumerate(names):
+            with torch.cuda.stream(sides[ci]):
                 one(ci, name)
         if c.df:
             # SB_model48c:491-505, 672-684, 812-814: three single-sample decoders on batch item 0 (inputs under
-            # stop_gradient), each with its own perceptual loss and optimizer key
+            # stop_gradient), each with its own perceptual loss and optimizer key; one per side stream, behind that stream's critic
             scale = 1e-3 * 0.5 * (S * S * 3)
-            a1 = alpha[B:B + 1, ..., :A].float().reshape(1, A)
-            ins = {"d_single": (torch.cat([c.samples0[7][:1], a1], 1), c.v0[:1], Z + A),
-                   "d_alpha": (a1, c.v1[:1], A), "d_pi": (c.samples0[8][:1], c.v0[:1], Z)}
-            for name, (zin, tgt, cz) in ins.items():
-                g_img = nets.dsingle(name, Act(model.to_act(zin.view(1, 1, 1, cz)), 1, 1, 1, cz)).t
-                lss = scale * self.vgg.loss(tgt.contiguous(), g_img, c.T)
-                crit[name] = (lss, g_img)
-                if name in keys:
-                    torch.autograd.grad([lss], [bank.params[n] for n in bank.groups[name]["names"]])
+
+            def a1():
+                return alpha[B:B + 1, ..., :A].float().reshape(1, A)
+            ins = {"d_single": (lambda: torch.cat([c.samples0[7][:1], a1()], 1), c.v0[:1], Z + A),
+                   "d_alpha": (a1, c.v1[:1], A), "d_pi": (lambda: c.samples0[8][:1], c.v0[:1], Z)}
+            for i, (name, (zin, tgt, cz)) in enumerate(ins.items()):
+                with torch.cuda.stream(sides[i]):
+                    g_img = nets.dsingle(name, Act(model.to_act(zin().view(1, 1, 1, cz)), 1, 1, 1, cz)).t
+                    lss = scale * self.vgg.loss(tgt.contiguous(), g_img, c.T)
+                    crit[name] = (lss, g_img)
+                    if name in keys:
+                        torch.autograd.grad([lss], [bank.params[n] for n in bank.groups[name]["names"]])
+        for sd in sides[1:]:
+            if sd is not cur:
+                cur.wait_stream(sd)
         c.crit = crit
         c.loss_dis0, _, c.acc0, _ = crit["mi0_discriminator"]
         c.loss_dis1, _, c.acc1, _ = crit["mi1_discriminator"]
