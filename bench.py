@@ -276,6 +276,8 @@ def run_rank(args):
                                                 "bf16 out)" if args.precision == "fp8" else "2.15e9") if traffic else
                                             "no PMC pass committed for this launch shape",
                             "flop_per_launch": ops.KernelTimer.flops}}
+        if not ops.KernelTimer.events:
+            out["roofline"]["note"] = "no launch timed: under HIP-graph replay (hip_graph / UPS_GRAPH=1) the roofline launches are graph nodes"
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, CPU_THREAD_CAP)
             if args.config == "cub128p10":      # the CPU leg is BASELINE config #1 (the CUB yaml at batch 8)

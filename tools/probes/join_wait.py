@@ -13,7 +13,7 @@ from upsparts_amd.model import TrainModel, Trainer  # noqa: E402
 
 dev = torch.device("cuda:0")
 cfg = configs.cub_config(n_parts=10, batch_size=64)
-cfg["precision"] = "bf16"
+cfg["precision"] = os.environ.get("PRECISION", "bf16")
 model = TrainModel(cfg, device=dev, seed=0)
 tr = Trainer(cfg, None, model)
 g = torch.Generator().manual_seed(1234)
@@ -22,11 +22,14 @@ for _ in range(8):
     tr.train_step(batch)
 torch.cuda.synchronize()
 tr._join_events = []
+tr._tail_events = []
 t0 = time.perf_counter()
 for _ in range(20):
     tr.train_step(batch)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 20
 w = [a.elapsed_time(b) for a, b in tr._join_events]
-print("streams={} step {:.2f} ms; wait at the critics' join: mean {:.3f} ms, max {:.3f} ms".format(
-    os.environ.get("UPS_CRITIC_STREAMS", "1"), dt * 1e3, sum(w) / len(w), max(w)))
+t = [a.elapsed_time(b) for a, b in tr._tail_events]
+print("{} streams={} step {:.2f} ms; wait at the critics' join: mean {:.3f} ms, max {:.3f} ms; wait for the weight-gradient streams at the end of "
+      "the backward pass: mean {:.3f} ms, max {:.3f} ms".format(cfg["precision"], os.environ.get("UPS_CRITIC_STREAMS", "1"), dt * 1e3, sum(w) / len(w), max(w),
+                                                                sum(t) / len(t), max(t)))

@@ -1184,7 +1184,14 @@ class Trainer(object):
     def _finish_step(self, keys, handles, graph_lr=None):
         """Wait for the buckets, then one fused Adam launch per key (tf.train.AdamOptimizer semantics, Appendix A.12).
         graph_lr: device scalar holding lr_t (HIP-graph mode; the python step counters then advance outside)."""
-        ops.Streams.join(self.device)
+        if JOIN_TIMING and graph_lr is None:       # debug: the tail of the weight-gradient stream that nothing hides (join_wait.py)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            ops.Streams.join(self.device)
+            ev[1].record()
+            self._tail_events = getattr(self, "_tail_events", []) + [ev]
+        else:
+            ops.Streams.join(self.device)
         D.wait_all(handles)
         self._adam([k for k in keys if k not in self._adam_done], graph_lr)
         self._adam_done = set()

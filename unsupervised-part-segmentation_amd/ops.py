@@ -103,6 +103,11 @@ class KernelTimer(object):
     kinds = []        # "fwd" / "dgrad" per timed launch
 
     @classmethod
+    def active(cls):
+        # (events recorded while a HIP graph is being captured become graph nodes and cannot be read back: replayed steps are not timed)
+        return cls.enabled and not torch.cuda.is_current_stream_capturing()
+
+    @classmethod
     def mean_ms(cls, kind=None):
         ev = [e for e, k in zip(cls.events, cls.kinds) if kind is None or k == kind]
         return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
@@ -578,7 +583,7 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
     Fp8.last_out = f8_out
     _attach_ws(d, x.device)
     assert round8(layer.ci_log) <= ldi, (layer.name, layer.ci_log, ldi)
-    if KernelTimer.layer == layer.name and KernelTimer.enabled:
+    if KernelTimer.layer == layer.name and KernelTimer.active():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.call("ups_conv_igemm", C.byref(d), L.stream())
@@ -709,7 +714,7 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
                         Fp8.stats["dgrad_copy_out"] += 1
         _attach_ws(d, x.device)
         assert round8(layer.co) <= g.shape[-1]
-        if KernelTimer.layer == layer.name and KernelTimer.enabled and st == 1:
+        if KernelTimer.layer == layer.name and KernelTimer.active() and st == 1:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             L.call("ups_conv_igemm", C.byref(d), L.stream())
