@@ -95,7 +95,9 @@ CONV_CASES = [
     (4, 64, 64, 32, 64, 3, 2, False, None, False),             # encoder first downsample: 4 x 32 = 128 GEMM channels, one N-tile
     (2, 128, 128, 32, 64, 3, 2, False, "leaky_relu", False),   # with act' on the 2x lattice
     (3, 32, 32, 128, 256, 3, 2, True, None, False),            # CoordConv layer, 512 GEMM channels (4 N-tiles), kchunks 8
-    (2, 64, 32, 64, 128, 3, 2, False, "relu", False),          # non-square, two N-tiles
+    (2, 64, 32, 64, 128, 3, 2, False, "relu", False),          # non-square, two N-tiles    # the critics' dense layers (128 rows): split-K forward / input gradient, single-split weight gradient written in place
+    (128, 1, 1, 512, 512, 1, 1, False, "leaky_relu", True),
+    (128, 1, 1, 64, 512, 1, 1, False, None, False),
 ]
 
 
