@@ -372,6 +372,42 @@ def test_hip_graph_replay_matches_eager(dev):
     assert runs["eager"][2] == runs["graph"][2]
 
 
+@pytest.mark.parametrize("variant", ["cub", "deepfashion"])
+def test_side_stream_schedules_are_bit_identical(variant, dev, monkeypatch):
+    """The critics on three side streams (with SB_model48c's single-sample decoders behind them), the appearance encoder enqueued
+    beside the pose encoder and the in-place single-split weight gradient change WHERE and WHEN launches run, not what they
+    compute: four steps with every switch on must equal four steps on the one-stream schedule bit for bit (losses, every
+    parameter, the state scalars)."""
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import model as M, ops
+    from oracle import ref_model as R, configs
+    cfg = copy.deepcopy(configs.tiny_config(variant=variant))
+    cfg.update(precision="bf16", vgg_widths=VGG_W)
+    runs = {}
+    for mode in ("one_stream", "side_streams"):
+        on = mode == "side_streams"
+        monkeypatch.setattr(M, "CRITIC_STREAMS", on)
+        monkeypatch.setattr(M, "EARLY_ALPHA", on)
+        monkeypatch.setattr(ops.Streams, "enabled", on)
+        c = copy.deepcopy(cfg)
+        model = M.TrainModel(c, device=dev, seed=0)
+        tr = M.Trainer(c, None, model)
+        hist = []
+        for step in range(4):
+            views = R.synthetic_views(c, seed=100 + step)
+            noise = R.synthetic_noise(c, seed=200 + step)
+            losses = tr.train_step(views, noise)
+            hist.append({k: float(v) for k, v in losses.items()})
+        torch.cuda.synchronize()
+        runs[mode] = (hist, {k: g["flat"]["p"].detach().cpu().clone() for k, g in model.bank.groups.items()},
+                      {k: float(v) for k, v in tr.state.items()})
+    for a, b in zip(runs["one_stream"][0], runs["side_streams"][0]):
+        assert a == b, (a, b)
+    for k in runs["one_stream"][1]:
+        assert torch.equal(runs["one_stream"][1][k], runs["side_streams"][1][k]), k
+    assert runs["one_stream"][2] == runs["side_streams"][2]
+
+
 def test_forty_steps_bf16_and_fp8_track_fp32(dev):
     """A short training run on a fixed synthetic batch (mid-size config with 64-wide decoders, 32x32): 40 optimizer steps in
     fp32, bf16 and fp8-forward mode from the same initial weights.  Every loss stays finite, the reconstruction loss falls by
