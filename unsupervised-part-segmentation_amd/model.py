@@ -774,12 +774,14 @@ class Trainer(object):
         # the three critics are independent chains of ~80 launches of a few blocks each; behind a main stream whose kernels fill
         # every CU each of those launches waits for a slot, so the chains run side by side on three streams (all joined into "aux")
         cur = torch.cuda.current_stream(self.device)
-        # (not while a HIP graph is being captured: ending a capture with streams forked from a forked stream crashes inside the runtime)
+        # (not in a captured step: replayed from a HIP graph the three branches cost more than they save -- 1 887 against 1 919 img/s
+        # with one critic stream, eager 1 979 -- so a capture keeps the one-stream form)
         multi = ops.Streams.enabled and ops.Streams.on_aux(self.device) and CRITIC_STREAMS and self._step_graph_lr is None
         sides = [cur] + ([ops.Streams.get("aux{}".format(i), self.device) for i in (1, 2)] if multi else [cur, cur])
         for sd in sides[1:]:
             if sd is not cur:
-                sd.wait_stream(cur)
+                sd.wait_stream(c.main_stream)      # forked from the launching stream (a HIP-graph capture wants first-level forks) ...
+                sd.wait_stream(cur)                # ... and behind the appearance code
         for ci, name in enumerate(names):
             with torch.cuda.stream(sides[ci]):
                 one(ci, name)
@@ -799,9 +801,7 @@ class Trainer(object):
                     crit[name] = (lss, g_img)
                     if name in keys:
                         torch.autograd.grad([lss], [bank.params[n] for n in bank.groups[name]["names"]])
-        for sd in sides[1:]:
-            if sd is not cur:
-                cur.wait_stream(sd)
+        # ("aux1" / "aux2" are joined wherever "aux" is: ops.Streams.join)
         c.crit = crit
         c.loss_dis0, _, c.acc0, _ = crit["mi0_discriminator"]
         c.loss_dis1, _, c.acc1, _ = crit["mi1_discriminator"]

@@ -87,6 +87,8 @@ class Streams(object):
         cur = torch.cuda.current_stream(device)
         if "wgrad" in names:
             names = tuple(names) + ("wgrad2",)          # the CoordConv rows of the weight gradients (conv_wgrad) belong to it
+        if "aux" in names:
+            names = tuple(names) + ("aux1", "aux2")         # critics two and three (Trainer._critics)
         for n in names:
             st = cls._pool.get((n, torch.device(device).index))
             if st is not None and st != cur:
