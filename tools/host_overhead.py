@@ -18,3 +18,14 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("host enqueue ms/step", (t1 - t0) / 4 * 1e3, "total ms/step", (t2 - t0) / 4 * 1e3)
+if len(sys.argv) > 1 and sys.argv[1] == "profile":      # where the host time goes: cProfile over 6 steps, top functions by own time
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    with torch.autograd.set_multithreading_enabled(False):      # backward on this thread, so that the profile sees it
+        tr.train_step(batch)
+        pr.enable()
+        for _ in range(6): tr.train_step(batch)
+        pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(45)

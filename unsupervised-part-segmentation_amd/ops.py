@@ -37,7 +37,7 @@ class _Workspace(object):
         self.bufs = {}
 
     def get(self, nbytes, device):
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, L.raw_stream(device))
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -56,6 +56,7 @@ class Streams(object):
     again at the encoder_0 backward.  UPS_NO_OVERLAP=1 keeps everything on one stream (A/B runs, debugging)."""
     enabled = os.environ.get("UPS_NO_OVERLAP", "0") != "1"
     _pool = {}
+    _raw = {}       # (name, device index) -> raw hipStream_t
     _alive = {}     # device index -> tensors the "wgrad" stream still reads.  Holding references until the next join keeps
                     # their memory out of the allocator without record_stream (whose deferred frees made the caching
                     # allocator reserve ~9x the live set: 84 GB at B = 64); once the launching stream has waited for the
@@ -72,12 +73,13 @@ class Streams(object):
         if st is None:
             st = torch.cuda.Stream(device=device)
             cls._pool[key] = st
+            cls._raw[key] = st.cuda_stream
         return st
 
     @classmethod
     def on_aux(cls, device):
-        cur, idx = torch.cuda.current_stream(device), torch.device(device).index
-        return any(cls._pool.get((n, idx)) == cur for n in ("aux", "aux1", "aux2"))      # (aux1 / aux2: critics two and three)
+        cur, idx = L.raw_stream(device), torch.device(device).index
+        return any(cls._raw.get((n, idx)) == cur for n in ("aux", "aux1", "aux2"))      # (aux1 / aux2: critics two and three)
 
     @classmethod
     def join(cls, device, names=("wgrad", "aux")):
