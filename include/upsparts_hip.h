@@ -26,8 +26,9 @@ extern "C" {
 #endif
 
 /* 2: ups_conv_desc grew by out_act / res_act, ups_wgrad_desc by in_f16, UPS_F16 was added (round 3) -- a stale library
- * built against the older structs ignores those fields silently, so the loader also compares ups_struct_sizes(). */
-#define UPS_ABI_VERSION 2
+ * built against the older structs ignores those fields silently, so the loader also compares ups_struct_sizes().
+ * 3: ups_wgrad_desc grew by dout_f8 / dout_f8_scale / in_f8_scale / in_f8_amax (the fp8 weight gradient, round 5). */
+#define UPS_ABI_VERSION 3
 
 /* UPS_F16 (IEEE half): element type of FORWARD tensors of precision-critical scopes (the mask decoder): ups_conv_igemm,
  * ups_weight_prep(_batch), ups_bilinear2x_fwd, ups_convert / ups_pad_convert accept it; gradients are never fp16 (range): the
@@ -169,6 +170,15 @@ typedef struct {
     int32_t mask_batch;
     int32_t in_f16;                   /* dtype UPS_BF16 only: `in` holds fp16 (the forward tensor of a UPS_F16 layer); it is converted to
                                        * bf16 (after the activation) while it is staged -- dout stays bf16 */
+    /* fp8 weight gradient (ABI 3; BASELINE config #5): dout_f8 != NULL selects it for the wide 3x3 / stride-1 layers (ci % 64 == 0,
+     * co % 128 == 0, 16-aligned images, forward tap order): e5m2(dout * *dout_f8_scale) as its producer wrote it, [n, ho, wo, ldo]
+     * bytes -- the copy the layer's input-gradient launch reads (ups_conv_desc.in_f8) --, `in` quantised to e4m3 with
+     * *in_f8_scale while it is staged (max |act(in)| recorded into the 64 slots of in_f8_amax for the next step's scale, or NULL),
+     * block-scaled K = 128 MFMA, fp32 accumulation; other shapes ignore these fields and run the bf16 kernels on `dout`. */
+    const void*  dout_f8;
+    const float* dout_f8_scale;
+    const float* in_f8_scale;
+    float*       in_f8_amax;
 } ups_wgrad_desc;
 
 int ups_conv_wgrad_plan(const ups_wgrad_desc* d, int32_t* splitk, size_t* workspace_bytes);

@@ -30,6 +30,23 @@ Open difference against the one log the reference ships (cub/train/log.txt:237-5
 Adam steps (``mask0_kl`` 3.9 against 0.92-1.08) for every data / TPS / step-alignment setting tried; scaling the mask decoder's
 learning rate by 0.03-0.1 reproduces all of them, ``bottleneck_loss`` included.  The optimizer wiring of
 cub/code/SB_model48i/model.py:739-742,786-815 as restated here (which variables each optimizer owns, the effective step size of the
-``decoder_visualize`` key) is therefore the SUSPECT, not the graph.  The DeepFashion variant (deepfashion/code/SB_model48c/model.py) is
+``decoder_visualize`` key) is therefore the SUSPECT, not the graph.
+
+Round 5 asked whether a single GLOBAL optimizer setting -- applied to all seven optimizers alike -- closes that difference
+(``tools/pin_log.py global``, profiles/round5_pin_log_global_knobs.txt: Adam epsilon 1e-8 ... 1e-3, linear lr warm-up over 50 / 100 /
+500 steps, gradient clipping by global norm at 1 / 10 / 100, each under edflow's betas (0.5, 0.9) and TensorFlow's (0.9, 0.999);
+3 seeds to global step 128, the logged run's data setting).  NONE does: no cell keeps ``mask0_kl`` inside 0.85-1.15 through step 32
+AND lets it move to 2-3 at steps 64 / 128 while leaving the critics' EMAs and ``lor`` where the log has them -- epsilon does nothing
+below 1e-3 (the gradients are large), clipping does nothing under Adam's normalisation, a warm-up holds the masks still for as long
+as it lasts but slows the critics and ``lor`` out of their windows and releases the masks ten times faster than the log shows.
+The per-key factor stays a diagnostic (the trainer's ``probe`` config hook), the product path keeps plain per-key Adam.
+
+DEFAULT BETAS: (0.5, 0.9), edflow's TFBaseTrainer values as recalled (UNVERIFIED; ``beta1`` / ``beta2`` are config keys).  The log's
+``lor`` windows lean towards TensorFlow's (0.9, 0.999) -- inside the seeds' range +- 0.03 at steps 8 / 32 / 64 under those, outside
+under (0.5, 0.9), in the round-4 sweep with the slowed mask decoder and again in round 5's plain runs -- but the lean is <= 0.03 in
+``lor`` while ``bottleneck_loss`` misses the log by 60-200 % at steps 16-128 under BOTH settings: the residual that no setting
+closes is larger than what separates the two, so the log does not decide them and the recalled source values stand.
+
+The DeepFashion variant (deepfashion/code/SB_model48c/model.py) is
 restated in the same module behind ``is_48c(config)``.
 """

@@ -178,6 +178,49 @@ def test_full_width_step_bf16_mask_iou(dev, mode, precision):
             precision, key, ratio, cos, nbar, cbar)
 
 
+@pytest.mark.parametrize("mode", ["native", "cub256p20"])
+def test_fp8_steady_state_step_matches_oracle_fixture(dev, mode):
+    """The fp8 mode IN THE STATE THE BENCHMARK RUNS IT IN (round-4 verdict, weak 2): default `fp8_copy_only` -- a layer takes the
+    fp8 kernels only when its operand arrives as a copy written by its producer --, delayed scales, copies flowing.  The one-step
+    tests above force in-kernel conversion because at step 0 no producer has a scale yet; round 3's poisoned-copy bug lived in
+    exactly the gap between the two.  Here the optimizer is frozen (lr = 0: Adam moves nothing) and the Lagrangian / EMA state is
+    put back before every step, so the step is a pure function of the fixture's views and noise: after four warm-up steps the
+    delayed scales have settled on the tensors' own maxima and every hand-off is live, and the FIFTH step -- copy-fed forwards,
+    block-scaled input gradients, fp8 weight gradients, whatever the mode runs -- is held to the full-width fp64 fixture:
+    part-mask IoU >= 0.99, losses within 10 %, per optimizer key the gradient norm within 10 % and the cosine >= 0.99."""
+    z = np.load(os.path.join(GOLD, FIXTURES[mode]))
+    cfg, model, trainer, views, noise = _trainer(dev, "fp8", mode, lr=0.0)
+    assert model.fp8.copy_only(), "the default fp8 policy is copy-only"
+    state0 = {k: v.clone() for k, v in trainer.state.items()}
+    before = {n: p.detach().clone() for n, p in model.variables.items()}
+    stats = None
+    for step in range(5):
+        trainer.state = {k: v.clone() for k, v in state0.items()}
+        for k in model.fp8.stats:
+            model.fp8.stats[k] = 0
+        losses = trainer.train_step(views, noise)
+        stats = dict(model.fp8.stats)
+    for n, p in model.variables.items():
+        assert torch.equal(p.detach(), before[n]), "lr = 0 moved {}".format(n)
+    print("{} fp8 steady state: launches on fp8 operands / copies {}".format(mode, stats))
+    assert stats["fwd_copy_in"] > 0 and stats["dgrad_copy_in"] > 0 and stats["dgrad_copy_out"] > 0, stats
+    assert stats["fwd_f8"] == stats["fwd_copy_in"] and stats["dgrad_f8"] == stats["dgrad_copy_in"], \
+        "copy-only policy: every fp8 launch is fed by a producer's copy: {}".format(stats)
+    B, P = cfg["batch_size"], cfg["n_parts"]
+    hard = trainer._debug["hard"]
+    iou0, iou1 = _iou(hard[:B], z["hard0_argmax"], P), _iou(hard[B:], z["hard1_argmax"], P)
+    print("{} fp8 steady state: part-mask IoU vs oracle {:.4f} / {:.4f}".format(mode, iou0, iou1))
+    assert min(iou0, iou1) >= 0.99, (iou0, iou1)
+    for k in losses:
+        lo, lh = float(z["loss_" + k]), float(losses[k])
+        assert abs(lo - lh) <= 0.10 * max(1.0, abs(lo)), "loss {}: oracle {} hip(fp8, steady state) {}".format(k, lo, lh)
+    rep = _gradient_report(model, z)
+    for key, (ratio, rel, cos, _w) in rep.items():
+        print("  {} fp8 steady-state gradient of {}: norm ratio {:.4f}, projected rel. error {:.4f}, cosine {:.5f}".format(mode, key, ratio, rel, cos))
+    for key, (ratio, rel, cos, _w) in rep.items():
+        assert abs(ratio - 1.0) <= 0.10 and cos >= 0.99, "fp8 steady-state gradient of key {}: norm ratio {:.4f}, cosine {:.5f}".format(key, ratio, cos)
+
+
 @pytest.mark.parametrize("precision", ["bf16", "bf16-pure", "fp32", "fp8"])
 def test_full_width_confident_masks_iou(dev, precision):
     """Part-mask IoU vs the fp64 oracle on CONFIDENT masks.  At random init the mask decoder's output is nearly flat (noise-free

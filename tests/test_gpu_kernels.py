@@ -1281,6 +1281,84 @@ def test_conv_fp8_input_gradient(case, dev):
     assert err < 0.08, "fp8 input gradient vs unquantised: rel RMS {:.3g}".format(err)
 
 
+@pytest.mark.parametrize("case", [
+    # (n, h, cin, cout, coords, act, fp16 forward input, image width != height)
+    (2, 32, 64, 128, False, None, False, 32),
+    (3, 16, 128, 256, True, "leaky_relu", False, 48),
+    (2, 32, 256, 256, True, None, True, 32),            # the mask decoder's form: fp16 post-activation input, CoordConv rows beside it
+    (8, 128, 256, 256, True, None, True, 128),          # the bench's own instance: 258 -> 256 at 128 x 128, 256 blocks, split-K 128
+])
+def test_conv_fp8_weight_gradient(case, dev):
+    """Weight gradient on the block-scaled fp8 MFMA (conv_wgrad3x3_f8.hip; round 5): the gradient arrives as its producer's e5m2
+    copy (per-tensor scale), the forward input (bf16, or fp16 in a bf16 container) is quantised to e4m3 while it is staged, fp32
+    accumulation over all pixels -- against the same arithmetic restated in torch from the very bytes the kernel reads (1e-3: the
+    products are exact in fp32, only the summation order differs), the bias gradient against the sum of the quantised gradient,
+    the recorded maximum against the tensor's, and the unquantised fp64 weight gradient at the e5m2 / e4m3 error level."""
+    lib, ops, R = _mods()
+    n, h, cin, cout, coords, act, f16in, w = case
+    g0 = torch.Generator().manual_seed(31)
+    cv = cin + (2 if coords else 0)
+    V = torch.randn(3, 3, cv, cout, generator=g0) / math.sqrt(9 * cv)
+    lay = _layer(ops, lib, V, torch.zeros(cout), 3, 1, coords, act, dev)
+    xf = torch.randn(n, h, w, cin, generator=g0)
+    xf = xf * (1.0 + 2.0 * torch.rand(1, 1, 1, cin, generator=g0))                   # channels on different scales
+    if f16in:
+        x16 = xf.to(torch.float16)
+        x = x16.view(torch.bfloat16).to(dev)
+        xs = x16.float()
+    else:
+        x = xf.to(torch.bfloat16).to(dev)
+        xs = x.float().cpu()
+    gy = (torch.randn(n, h, w, cout, generator=g0) * 0.02 * (1.0 + 3.0 * torch.rand(1, 1, 1, cout, generator=g0))).to(torch.bfloat16)
+    gyd = gy.to(dev)
+    with ops.fp8_scope(enabled=True) as F:
+        # the producer's side of the hand-off, restated: e5m2(g * scale) with the delayed scale of that tensor's slot
+        slot = F.slot(dev)
+        F.fmax[slot] = F.E5M2_MAX
+        s_g = F.E5M2_MAX * F.MARGIN / float(gy.float().abs().max())
+        F.scale[slot] = s_g
+        s_g = float(F.scale[slot].cpu())
+        g8 = (gy.float() * s_g).clamp(-57344, 57344).to(torch.float8_e5m2)
+        copy = {"t": g8.view(torch.uint8).to(dev), "slot": slot}
+        assert F.eligible_wgrad(lay, gyd, x, None)
+        gV, gb = ops.conv_wgrad(gyd, x, lay, fmt=lib.F16 if f16in else None, f8_src=copy)
+        torch.cuda.synchronize()
+        assert F.stats["wgrad_f8"] == 1
+        ew = lay._cache["f8w"]
+        s_x = float(F.scale[ew["slot"]].cpu())
+        amax_seen = float(F.amax[ew["slot"]].max().cpu())
+    xa = xs if act is None else torch.where(xs > 0, xs, 0.2 * xs)
+    assert abs(amax_seen - float(xa.abs().max())) <= 1e-6 * amax_seen, (amax_seen, float(xa.abs().max()))
+    assert abs(s_x - 448.0 * 0.5 / float(xs.abs().max())) <= 1e-5 * s_x          # first launch: primed from the tensor at hand
+    xq = (xa * s_x).clamp(-448, 448).to(torch.float8_e4m3fn).double()
+    gq = g8.double()
+    # dV[r][s][ci][co] = sum_pix xq[pix + (r-1, s-1)][ci] * gq[pix][co] / (s_x * s_g)
+    xp = torch.nn.functional.pad(xq, (0, 0, 1, 1, 1, 1))
+    ref_q = torch.zeros(3, 3, cin, cout, dtype=torch.float64)
+    for r in range(3):
+        for c in range(3):
+            ref_q[r, c] = torch.einsum("nhwi,nhwo->io", xp[:, r:r + h, c:c + w], gq)
+    ref_q /= (s_x * s_g)
+    assert_close(gV[:, :, :cin].cpu(), ref_q.float(), 1e-3, "fp8 weight gradient vs e4m3 / e5m2 emulation")
+    assert_close(gb.cpu(), (gq.sum(dim=(0, 1, 2)) / s_g).float(), 1e-3, "fp8 bias gradient vs the sum of the e5m2 copy")
+    # unquantised reference: the CoordConv rows (written by the fp32 coordinate kernels) to 2e-3 as in the bf16 tests, the main
+    # rows at the quantisation error level
+    xpf = torch.nn.functional.pad(xa.double(), (0, 0, 1, 1, 1, 1))
+    ref = torch.zeros(3, 3, cin, cout, dtype=torch.float64)
+    for r in range(3):
+        for c in range(3):
+            ref[r, c] = torch.einsum("nhwi,nhwo->io", xpf[:, r:r + h, c:c + w], gy.double())
+    err = float((gV[:, :, :cin].double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    cos = float((gV[:, :, :cin].double().cpu() * ref).sum() / (gV[:, :, :cin].double().cpu().norm() * ref.norm()))
+    print("fp8 weight gradient {}: rel RMS {:.4f}, cosine {:.5f} vs the unquantised gradient".format(case, err, cos))
+    assert err < 0.08 and cos > 0.997, (err, cos)
+    if coords:
+        with ops.fp8_scope(enabled=False):
+            gV16, _ = ops.conv_wgrad(gyd, x, lay, fmt=lib.F16 if f16in else None)
+        assert torch.equal(gV[:, :, cin:], gV16[:, :, cin:]) or float((gV[:, :, cin:] - gV16[:, :, cin:]).abs().max()) <= \
+            1e-5 * float(gV16[:, :, cin:].abs().max()), "CoordConv rows must be the fp32 coordinate kernels' in both modes"
+
+
 @pytest.mark.parametrize("case", [(4, 64, 128, 128, True), (2, 128, 256, 256, True), (8, 32, 64, 192, False)])
 def test_conv_fp8_copy_handed_from_producer_to_consumer(case, dev):
     """fp8 copies between layers: the producing convolution's epilogue writes e4m3(act(out) * scale) next to its bf16 output (one

@@ -531,32 +531,24 @@ def test_reference_log_mask_statistics_conditional_pin(dev):
                "variance_loss": (16.3, 17.0), "prior_gmrf": (100.0, 360.0)}
     for k, (lo, hi) in windows.items():          # the windows contain the reference's own values at these steps
         assert all(lo <= pin.REF[k][idx[s]] <= hi for s in steps), k
-    orig_adam = ops.adam_step
     bott = {}
-    try:
-        for seed in range(3):
-            cfg = copy.deepcopy(configs.cub_config(n_parts=25, batch_size=8, use_tps=True))
-            cfg.update({"precision": "bf16", "noise_seed": 4321 + seed})
-            model = TrainModel(cfg, device=dev, seed=seed)
-            tr = Trainer(cfg, None, model)
-            dv_p = model.bank.groups["decoder_visualize"]["flat"]["p"]
-
-            def adam(p, g, m, v, lr_t, *a, _dv=dv_p, **kw):
-                return orig_adam(p, g, m, v, lr_t * 0.03 if p.data_ptr() == _dv.data_ptr() else lr_t, *a, **kw)
-            ops.adam_step = adam
-            for s in range(32):
-                batch = {k: v.to(dev) for k, v in pin.make_views("same", "pink", 8, 128, 1000 * seed + s).items()}
-                tr.train_step(batch)
-                g_step = s + 1                       # the logged state at global step g carries g - 1 updates
-                if g_step in steps:
-                    lg = tr.fetch_logs()
-                    for k, (lo, hi) in windows.items():
-                        assert lo <= lg[k] <= hi, "seed {} global step {}: {} = {} outside [{}, {}] (logged {})".format(
-                            seed, g_step, k, lg[k], lo, hi, pin.REF[k][idx[g_step]])
-                    if g_step <= 16:
-                        bott.setdefault(g_step, []).append(lg["bottleneck_loss"])
-    finally:
-        ops.adam_step = orig_adam
+    for seed in range(3):
+        cfg = copy.deepcopy(configs.cub_config(n_parts=25, batch_size=8, use_tps=True))
+        # the trainer's diagnostic hook (Trainer.probe): decoder_visualize alone steps with 0.03 * lr
+        cfg.update({"precision": "bf16", "noise_seed": 4321 + seed, "probe": {"lr_scale": {"decoder_visualize": 0.03}}})
+        model = TrainModel(cfg, device=dev, seed=seed)
+        tr = Trainer(cfg, None, model)
+        for s in range(32):
+            batch = {k: v.to(dev) for k, v in pin.make_views("same", "pink", 8, 128, 1000 * seed + s).items()}
+            tr.train_step(batch)
+            g_step = s + 1                       # the logged state at global step g carries g - 1 updates
+            if g_step in steps:
+                lg = tr.fetch_logs()
+                for k, (lo, hi) in windows.items():
+                    assert lo <= lg[k] <= hi, "seed {} global step {}: {} = {} outside [{}, {}] (logged {})".format(
+                        seed, g_step, k, lg[k], lo, hi, pin.REF[k][idx[g_step]])
+                if g_step <= 16:
+                    bott.setdefault(g_step, []).append(lg["bottleneck_loss"])
     for g_step, vals in bott.items():            # encoder_0's KL: the seeds' mean within 20 % of the log, every seed within 45 %
         want = pin.REF["bottleneck_loss"][idx[g_step]]
         mean = sum(vals) / len(vals)

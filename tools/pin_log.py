@@ -20,6 +20,8 @@ version sweeps the factors that were confounded there, all combinations, over se
     python tools/pin_log.py [seeds] [steps] [out.json]        (GPU box; stand-in VGG; ~25 ms per step)
     python tools/pin_log.py probe [seeds] [steps] [betas]     optimizer-wiring probes on the logged run's data setting
                                                               (same / pink / tps1): see probes()
+    python tools/pin_log.py global [seeds] [steps]            GLOBAL optimizer hypotheses (Adam epsilon, betas, lr warm-up,
+                                                              gradient clipping; all seven optimizers alike): see global_knobs()
 """
 import copy
 import itertools
@@ -104,6 +106,92 @@ def run(views, texture, tps, seed, steps, betas=(0.5, 0.9), precision="bf16"):
     return logs
 
 
+def _trajectory(cfg_updates, seed, steps, want):
+    """One run on the logged run's data setting (same / pink / tps1); logs fetched only at the step indices in `want`."""
+    cfg = copy.deepcopy(configs.cub_config(n_parts=25, batch_size=8, use_tps=True))
+    cfg.update({"precision": "bf16", "noise_seed": 4321 + seed})
+    cfg.update(cfg_updates)
+    dev = torch.device("cuda:0")
+    model = TrainModel(cfg, device=dev, seed=seed)
+    tr = Trainer(cfg, None, model)
+    logs = {}
+    for s in range(steps + 1):
+        batch = {k: v.to(dev) for k, v in make_views("same", "pink", 8, 128, 1000 * seed + s).items()}
+        tr.train_step(batch)
+        if s in want:
+            lg = tr.fetch_logs()
+            logs[s] = {k: lg[k] for k in REF}
+    return logs
+
+
+def _dump_case(path, tag, runs):
+    """Append one finished case to a JSON-lines file (a run that is cut short keeps what it has measured)."""
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"case": tag, "runs": [{str(k): v for k, v in r.items()} for r in runs]}) + "\n")
+
+
+def _load_cases(path):
+    res = {}
+    with open(path) as f:
+        for line in f:
+            if line.strip():
+                d = json.loads(line)
+                res[d["case"]] = [{int(k): v for k, v in r.items()} for r in d["runs"]]
+    return res
+
+
+def _table(res, steps, keys):
+    for k in keys:
+        print("== " + k)
+        for tag, runs in res.items():
+            row = "  {:22s}".format(tag)
+            for i, s in enumerate(STEPS):
+                if s > steps:
+                    continue
+                v = torch.tensor([r[max(0, s - 1)][k] for r in runs], dtype=torch.float64)     # g - 1 alignment
+                row += "  {:>4d}: {:10.4f} [{:10.4f},{:10.4f}] ref {:10.4f}".format(s, float(v.mean()), float(v.min()), float(v.max()), REF[k][i])
+            print(row)
+
+
+# windows around the logged values (the conditional-pin test's, tests/test_gpu_model.py): the mask statistics stay at their
+# random-init values through global step 32; bottleneck_loss within 45 % per seed at steps 2-16; lor / avg_loss_dis inside the
+# seeds' range widened by a pad
+FIT_WINDOWS = {"mask0_kl": (0.85, 1.15), "weakly_superv_loss_p": (2.60, 2.80), "patch_loss": (15050.0, 15350.0),
+               "variance_loss": (16.3, 17.0), "prior_gmrf": (100.0, 360.0)}
+
+
+def _verdict(res, steps):
+    """Per case: which logged quantities the seeds reproduce.  Mask statistics: EVERY seed inside FIT_WINDOWS at global steps
+    2..32; bottleneck_loss: every seed within 45 % of the log at steps 2..16; lor at 8 / 32 / 64 and avg_loss_dis0/1 at 8 / 16 / 32:
+    the logged value inside the seeds' [min, max] widened by 0.03 (lor) / 0.006 (EMAs); late mask trajectory: mask0_kl at 64 / 128
+    within a factor 1.5 of the log."""
+    print("== verdict: per case, the logged quantities reproduced (g - 1 alignment)")
+    for tag, runs in res.items():
+        ok = {}
+        ms = [s for s in (2, 4, 8, 16, 32) if s <= steps]
+        for k, (lo, hi) in FIT_WINDOWS.items():
+            ok[k] = all(lo <= r[s - 1][k] <= hi for r in runs for s in ms)
+        bs = [s for s in (2, 4, 8, 16) if s <= steps]
+        ok["bottleneck_loss"] = all(abs(r[s - 1]["bottleneck_loss"] / REF["bottleneck_loss"][STEPS.index(s)] - 1.0) <= 0.45 for r in runs for s in bs)
+
+        def inside(k, ss, pad):
+            good = True
+            for s in ss:
+                if s > steps:
+                    continue
+                vals = [r[s - 1][k] for r in runs]
+                good = good and (min(vals) - pad <= REF[k][STEPS.index(s)] <= max(vals) + pad)
+            return good
+        ok["lor"] = inside("lor", (8, 32, 64), 0.03)
+        ok["avg_loss_dis0"] = inside("avg_loss_dis0", (8, 16, 32), 0.006)
+        ok["avg_loss_dis1"] = inside("avg_loss_dis1", (8, 16, 32), 0.006)
+        late = [s for s in (64, 128) if s <= steps]
+        ok["mask0_kl@64/128"] = all(1 / 1.5 <= (sum(r[s - 1]["mask0_kl"] for r in runs) / len(runs)) / REF["mask0_kl"][STEPS.index(s)] <= 1.5 for s in late)
+        n_ok = sum(ok.values())
+        print("  {:22s} {:2d}/{:2d}  ".format(tag, n_ok, len(ok)) + "  ".join("{}:{}".format(k, "ok" if v else "NO") for k, v in ok.items()))
+
+
 def probes():
     """No data / TPS / alignment setting closes the gap (main()): in the restated trainer the reconstruction gradient reaches
     decoder_visualize through the straight-through masks 20-40x stronger than all priors together (fp64 CPU restatement, P = 25, random
@@ -113,11 +201,9 @@ def probes():
     the log cannot show -- how strongly decoder_visualize's update follows the reconstruction term (M:739-742, 786-797):
         rec x s : decoder_visualize sees priors + s * (reconstruction gradient through the masks), s = 1, 0.1, 0.01, 0
         lr x f  : decoder_visualize alone steps with f * lr
-    (monkey-patched here, not options of the product path)."""
+    (the trainer's diagnostic `probe` config hooks: Trainer.probe; not options a shipped config sets)."""
     seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 128
-    from upsparts_amd import ops as OPS
-    orig_prior, orig_adam = Trainer._prior, OPS.adam_step
     res = {}
     cases = (("rec x1", 1.0, 1.0, (0.5, 0.9)), ("rec x0.1", 0.1, 1.0, (0.5, 0.9)), ("rec x0.01", 0.01, 1.0, (0.5, 0.9)),
              ("rec x0", 0.0, 1.0, (0.5, 0.9)), ("lr_dv x0.1", 1.0, 0.1, (0.5, 0.9)), ("lr_dv x0.01", 1.0, 0.01, (0.5, 0.9)))
@@ -126,49 +212,58 @@ def probes():
         # the OTHER sub-networks' trajectories -- bottleneck_loss = encoder_0's KL -- can tell edflow's Adam betas from TensorFlow's
         cases = (("lr_dv x0.03", 1.0, 0.03, (0.5, 0.9)), ("lr_dv x0.1", 1.0, 0.1, (0.5, 0.9)),
                  ("lr_dv x0.03 tf", 1.0, 0.03, (0.9, 0.999)), ("lr_dv x0.1 tf", 1.0, 0.1, (0.9, 0.999)))
+    want = set(max(0, s - 1) for s in STEPS)
     for tag, rec_s, lr_f, betas in cases:
-        def patched(self, view, n, S, P, l, lm, m, hard, px, per_np, sums, w, g_hard=None, dl=None, bwd=False, dl_rec=None, _s=rec_s):
-            orig_prior(self, view, n, S, P, l, lm, m, hard, px, per_np, sums, w, g_hard, dl, bwd, dl_rec)
-            if bwd and _s != 1.0:
-                dl.copy_((dl - dl_rec) + _s * dl_rec)
-        Trainer._prior = patched
-        runs = []
-        for sd in range(seeds):
-            cfg = copy.deepcopy(configs.cub_config(n_parts=25, batch_size=8, use_tps=True))
-            cfg.update({"precision": "bf16", "noise_seed": 4321 + sd, "beta1": betas[0], "beta2": betas[1]})
-            dev = torch.device("cuda:0")
-            model = TrainModel(cfg, device=dev, seed=sd)
-            tr = Trainer(cfg, None, model)
-            dv_p = model.bank.groups["decoder_visualize"]["flat"]["p"]
-
-            def adam(p, g, m, v, lr_t, *a, _f=lr_f, _dv=dv_p, **kw):
-                return orig_adam(p, g, m, v, lr_t * _f if p.data_ptr() == _dv.data_ptr() else lr_t, *a, **kw)
-            OPS.adam_step = adam
-            logs = []
-            for s in range(steps + 1):
-                batch = {k: v.to(dev) for k, v in make_views("same", "pink", 8, 128, 1000 * sd + s).items()}
-                tr.train_step(batch)
-                lg = tr.fetch_logs()
-                logs.append({k: lg[k] for k in REF})
-            runs.append(logs)
-        res[tag] = runs
+        upd = {"beta1": betas[0], "beta2": betas[1], "probe": {"rec_scale": rec_s, "lr_scale": {"decoder_visualize": lr_f}}}
+        res[tag] = [_trajectory(upd, sd, steps, want) for sd in range(seeds)]
         sys.stderr.write("done {}\n".format(tag))
-    Trainer._prior, OPS.adam_step = orig_prior, orig_adam
-    for k in MASK_KEYS + ("loss_decoder_delta", "bottleneck_loss", "lor", "avg_loss_dis0", "avg_loss_dis1"):
-        print("== " + k)
-        for tag, runs in res.items():
-            row = "  {:12s}".format(tag)
-            for i, s in enumerate(STEPS):
-                if s > steps:
-                    continue
-                v = torch.tensor([r[max(0, s - 1)][k] for r in runs], dtype=torch.float64)     # g - 1 alignment
-                row += "  {:>4d}: {:10.4f} [{:10.4f},{:10.4f}] ref {:10.4f}".format(s, float(v.mean()), float(v.min()), float(v.max()), REF[k][i])
-            print(row)
+    _table(res, steps, MASK_KEYS + ("loss_decoder_delta", "bottleneck_loss", "lor", "avg_loss_dis0", "avg_loss_dis1"))
+    _verdict(res, steps)
+
+
+def global_knobs():
+    """Round-4 verdict, item 2: the per-key learning-rate factor above is a fitted fudge, not a mechanism.  Is there a single GLOBAL
+    optimizer setting -- applied to all seven optimizers alike -- under which the restated trainer reproduces the logged windows
+    (mask statistics flat through step 32, moving at 64 / 128; bottleneck_loss; lor; the critics' EMAs)?  Swept, each with edflow's
+    betas (0.5, 0.9) and with TensorFlow's defaults (0.9, 0.999):
+        Adam epsilon      1e-8 (TF default) / 1e-6 / 1e-5 / 1e-4 / 1e-3      (config `adam_eps`)
+        linear lr warm-up over 50 / 100 / 500 steps                           (config `lr_warmup_steps`)
+        gradient clipping by global norm per key at 1 / 10 / 100              (config `grad_clip_norm`)
+    on the logged run's data setting (one image for all three views, 1/f texture, TPS on), `seeds` seeds to global step `steps`.
+        python tools/pin_log.py global [seeds] [steps] [dump.jsonl]      (finished cases are appended to / resumed from the dump)
+        python tools/pin_log.py table dump.jsonl [steps]                 (tables + verdict from a dump, no GPU)"""
+    seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+    dump = sys.argv[4] if len(sys.argv) > 4 else None          # JSON-lines file: finished cases are appended / resumed from
+    want = set(max(0, s - 1) for s in STEPS)
+    res = _load_cases(dump) if dump and os.path.exists(dump) else {}
+    for bname, betas in (("edflow", (0.5, 0.9)), ("tf", (0.9, 0.999))):
+        cases = [("eps 1e-8 (plain)", {})]
+        cases += [("eps {:g}".format(e), {"adam_eps": e}) for e in (1e-6, 1e-5, 1e-4, 1e-3)]
+        cases += [("warmup {}".format(w), {"lr_warmup_steps": w}) for w in (50, 100, 500)]
+        cases += [("clip {}".format(c), {"grad_clip_norm": float(c)}) for c in (1, 10, 100)]
+        for tag, upd in cases:
+            upd = dict(upd, beta1=betas[0], beta2=betas[1])
+            name = "{} {}".format(bname, tag)
+            if name in res:
+                continue                     # (resumed from the dump of an earlier, interrupted run)
+            res[name] = [_trajectory(upd, sd, steps, want) for sd in range(seeds)]
+            _dump_case(dump, name, res[name])
+            sys.stderr.write("done {}\n".format(name))
+    _table(res, steps, MASK_KEYS + ("bottleneck_loss", "lor", "avg_loss_dis0", "avg_loss_dis1"))
+    _verdict(res, steps)
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "probe":
         return probes()
+    if len(sys.argv) > 1 and sys.argv[1] == "global":
+        return global_knobs()
+    if len(sys.argv) > 1 and sys.argv[1] == "table":
+        res = _load_cases(sys.argv[2])
+        steps = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+        _table(res, steps, MASK_KEYS + ("bottleneck_loss", "lor", "avg_loss_dis0", "avg_loss_dis1"))
+        return _verdict(res, steps)
     seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     out = sys.argv[3] if len(sys.argv) > 3 else None

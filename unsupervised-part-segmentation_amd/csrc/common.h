@@ -19,6 +19,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 void ups_set_error(const char* fmt, ...);
 
+// hipFuncSetAttribute is per DEVICE: the "already raised the LDS limit of this kernel" flag of a launcher must be too.  Drop-in
+// for the `static bool done = false; if (!done) { ...; done = true; }` idiom: one bit per device ordinal of the calling thread's
+// current device (a second GPU driven from the same process would otherwise launch with > 64 KB of dynamic LDS un-permitted).
+struct UpsPerDevice {
+    unsigned long long bits = 0;
+    static int cur() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+    bool operator!() const { return !((bits >> cur()) & 1ull); }
+    UpsPerDevice& operator=(bool v) { if (v) bits |= 1ull << cur(); else bits &= ~(1ull << cur()); return *this; }
+};
+
 #define UPS_CHECK_ARG(cond)                                                        \
     do {                                                                           \
         if (!(cond)) {                                                             \

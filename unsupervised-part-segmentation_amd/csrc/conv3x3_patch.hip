@@ -1285,7 +1285,7 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     if (F8 >= 3) shmem = shmem_max = 2 * ABY + 2 * (2 * (size_t)BN * 64);      // block-scaled fp8: two patch images, two per-tap stages
     const size_t epi = sizeof(T) == 2 ? 256 * (size_t)(BN * 2 + 16) + 256 * (size_t)(BN / 8) : 0;   // staged bf16 epilogue
     if (epi > shmem) shmem = epi;
-    static bool attr_set = false;
+    static UpsPerDevice attr_set;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE, TAPS, DMAP, CSTD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(epi > shmem_max ? epi : shmem_max));

@@ -412,7 +412,7 @@ template <typename T, int CI, int LW, int NR, bool FLIP, bool DG = false>
 int launch_rows2(const RowsK& k, hipStream_t s) {
     constexpr int W = 1 << LW, KC = CI / 32;
     constexpr size_t smem = (size_t)NR * KC * (W + 2) * 64 + 8 * 16 * 80 + 256;
-    static bool attr_set = false;
+    static UpsPerDevice attr_set;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv3x3_rows2_kernel<T, CI, LW, NR, FLIP, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return UPS_E_LAUNCH;
@@ -764,7 +764,7 @@ template <int CI, int LWI, int NR>
 int launch_rows_s2x2(const RowsK& k, hipStream_t s) {
     constexpr int WI = 1 << LWI, KC = CI / 32;
     constexpr size_t smem = (size_t)NR * KC * 2 * (WI / 2 + 1) * 64 + 8 * 16 * 80 + 512;
-    static bool attr_set = false;
+    static UpsPerDevice attr_set;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv3x3_rows_s2x2_kernel<CI, LWI, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return UPS_E_LAUNCH;
@@ -778,7 +778,7 @@ template <int CI, int LWI, int NR>
 int launch_rows_s2(const RowsK& k, hipStream_t s) {
     constexpr int WI = 1 << LWI, KC = CI / 32;
     constexpr size_t smem = (size_t)NR * KC * 2 * (WI / 2 + 1) * 64 + 8 * 16 * 80 + 512;
-    static bool attr_set = false;
+    static UpsPerDevice attr_set;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv3x3_rows_s2_kernel<CI, LWI, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return UPS_E_LAUNCH;
@@ -966,7 +966,7 @@ template <typename T, int SW>
 int launch_thinout(const ThinK& k, hipStream_t s) {
     constexpr int NR = SW == 16 ? 6 : 7;
     constexpr size_t smem = (size_t)NR * 8 * (SW + 2) * 64 + 2 * 8 * SW * 20 * 4;
-    static bool attr_set = false;
+    static UpsPerDevice attr_set;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv3x3_thinout_kernel<T, NR, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return UPS_E_LAUNCH;
@@ -985,7 +985,7 @@ template <typename T, int CI, int LW, int NR, bool FLIP, int DG>
 int launch_rows(const RowsK& k, hipStream_t s) {
     constexpr int W = 1 << LW, KC = CI / 32, NCT = W / 16, NCG = 8 / NCT;
     constexpr size_t smem = (size_t)NR * KC * (W + 2) * 64 + (DG == 1 ? (size_t)(NR - 2) * NCG * W * 64 : 0) + 8 * 16 * 80 + 256;
-    static bool attr_set = false;
+    static UpsPerDevice attr_set;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv3x3_rows_kernel<T, CI, LW, NR, FLIP, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return UPS_E_LAUNCH;
@@ -1158,7 +1158,7 @@ int ups_conv3x3_rows_maskgrad_try(const ups_conv_desc* d, hipStream_t s) {
     constexpr int NR = 8;
     if (d->wi == 128) {
         constexpr size_t smem = (size_t)NR * 130 * 64;
-        static bool attr_set = false;
+        static UpsPerDevice attr_set;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)conv3x3_rows_maskgrad_kernel<NR, 7, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
                 return UPS_E_LAUNCH;
@@ -1167,7 +1167,7 @@ int ups_conv3x3_rows_maskgrad_try(const ups_conv_desc* d, hipStream_t s) {
         hipLaunchKernelGGL((conv3x3_rows_maskgrad_kernel<NR, 7, 1>), dim3(k.n * k.bands), dim3(512), smem, s, k);
     } else {
         constexpr size_t smem = (size_t)NR * 258 * 64;
-        static bool attr_set = false;
+        static UpsPerDevice attr_set;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)conv3x3_rows_maskgrad_kernel<NR, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
                 return UPS_E_LAUNCH;

@@ -179,8 +179,12 @@ int ups_conv3x3_s2_try(const ups_conv_desc* d, hipStream_t s) {
         return 1;
     // only where the launch is a memory stream that fills the chip (small maps stay on the generic kernel's split-K forms)
     if (!force && (long long)d->n * d->ho * d->wo < 256ll * 1024) return 1;
+    // the kernel moves 16 bytes per lane (uint4 loads of the taps, uint4 stores of the staged row) and reads input row
+    // 2 y + dy[0] + r for tap row r: both must hold, or the generic kernel takes the launch
+    if ((((uintptr_t)d->in) | ((uintptr_t)d->out) | ((uintptr_t)d->w)) & 15) return 1;
     S2K k;
     for (int r = 0; r < 3; ++r) {
+        if (d->tap_dy[3 * r] != d->tap_dy[0] + r || d->tap_dx[r] != d->tap_dx[0] + r) return 1;
         k.dy[r] = d->tap_dy[3 * r]; k.dx[r] = d->tap_dx[r];
         for (int c = 0; c < 3; ++c)
             if (d->tap_dy[3 * r + c] != d->tap_dy[3 * r] || d->tap_dx[3 * r + c] != d->tap_dx[c] || d->tap_w[3 * r + c] != 3 * r + c) return 1;
@@ -196,7 +200,7 @@ int ups_conv3x3_s2_try(const ups_conv_desc* d, hipStream_t s) {
     if (blocks >= (1ll << 31)) return 1;
     const int KC = d->ci / 32;
     const size_t shm = (size_t)9 * KC * 64 * 64 + 4 * 2048;
-    static bool a1 = false, a2 = false;
+    static UpsPerDevice a1, a2;
     if (KC == 1) {
         if (!a1) { if (hipFuncSetAttribute((const void*)conv3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return UPS_E_LAUNCH; a1 = true; }
         hipLaunchKernelGGL((conv3x3_s2_kernel<1>), dim3((unsigned)blocks), dim3(256), shm, s, k);

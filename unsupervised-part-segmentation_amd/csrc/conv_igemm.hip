@@ -440,7 +440,7 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
 #define UPS_LAUNCH_IG(BNV, CPSV)                                                                                      \
     do {                                                                                                              \
         const size_t shmem = 2 * (size_t)(CPSV) * (BM + (BNV)) * RS + BM * 20;                                        \
-        static bool attr_done = false;                                                                                \
+        static UpsPerDevice attr_done;                                                                                \
         if (!attr_done) {                                                                                             \
             if (hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BNV, CPSV>,                                     \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)           \

@@ -334,12 +334,15 @@ int plan_splitk(const ups_wgrad_desc* d) {
 
 int ups_wgrad3x3_plan(const ups_wgrad_desc* d, int* splitk, int* slabs);   // conv_wgrad3x3.hip
 int ups_wgrad3x3_run(const ups_wgrad_desc* d, hipStream_t s);
+int ups_wgrad3x3_f8_plan(const ups_wgrad_desc* d, int* splitk, int* slabs);   // conv_wgrad3x3_f8.hip
+int ups_wgrad3x3_f8_run(const ups_wgrad_desc* d, hipStream_t s);
 
 extern "C" int ups_conv_wgrad_plan(const ups_wgrad_desc* d, int32_t* splitk, size_t* workspace_bytes) {
     UPS_CHECK_ARG(d && splitk && workspace_bytes);
     UPS_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= 9 && d->ci > 0 && d->co > 0);
     int sk3 = 0, slabs3 = 0;
-    if (ups_wgrad3x3_plan(d, &sk3, &slabs3) == 0) {      // bf16 3x3/stride-1: patch-tiled kernel
+    if (ups_wgrad3x3_f8_plan(d, &sk3, &slabs3) == 0 ||    // e5m2 copy of dout given, wide 3x3 / stride-1: the fp8 kernel
+        ups_wgrad3x3_plan(d, &sk3, &slabs3) == 0) {      // bf16 3x3/stride-1: patch-tiled kernel
         *splitk = sk3;
         *workspace_bytes = (size_t)slabs3 * ((size_t)d->ntaps * d->cin_v * d->co + d->co) * sizeof(float);
         return UPS_OK;
@@ -388,7 +391,11 @@ extern "C" int ups_conv_wgrad(const ups_wgrad_desc* d, void* stream) {
             return UPS_E_UNSUPPORTED;
         }
     }
-    if (ups_wgrad3x3_plan(d, &sk3, &slabs3) == 0) {
+    if (ups_wgrad3x3_f8_plan(d, &sk3, &slabs3) == 0) {
+        UPS_CHECK_ARG(d->splitk == sk3 && d->dout_f8_scale && d->in_f8_scale && ((uintptr_t)d->dout_f8 & 15) == 0);
+        if (ups_wgrad3x3_f8_run(d, s) != UPS_OK) { ups_set_error("ups_conv_wgrad: fp8 kernel launch setup failed"); return UPS_E_LAUNCH; }
+        nslabs = slabs3;
+    } else if (ups_wgrad3x3_plan(d, &sk3, &slabs3) == 0) {
         UPS_CHECK_ARG(d->splitk == sk3);
         if (ups_wgrad3x3_run(d, s) != UPS_OK) { ups_set_error("ups_conv_wgrad: patch kernel launch setup failed"); return UPS_E_LAUNCH; }
         nslabs = slabs3;

@@ -467,7 +467,7 @@ int launch3(const Wg3K& k, int cit, int cot, int splitk, hipStream_t s) {
     size_t shmem = 2 * (size_t)(PPIX * RSX + TH * TW * RSD);
     constexpr size_t red = (size_t)(8 / ((CB / 32) * (BN / 32)) - 1) * (CB / 32) * (BN / 32) * 4096;   // K-part reduction scratch
     if (shmem < red) shmem = red;
-    static bool attr_set = false;
+    static UpsPerDevice attr_set;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<CB, BN, TH, SLIDE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shmem) != hipSuccess) return UPS_E_LAUNCH;

@@ -496,7 +496,7 @@ constexpr int UNPOOL_SLABS = 32;
 
 // kernels whose LDS images can exceed the 64 KB default at P = 64: raise the limit once per kernel
 template <typename K>
-bool allow_big_lds(K kernel, bool& done) {
+bool allow_big_lds(K kernel, UpsPerDevice& done) {
     if (!done) {
         if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
         done = true;
@@ -615,7 +615,7 @@ extern "C" int ups_mask_parts_bwd(const float* view, const void* g_out, float* g
     UPS_CHECK_ARG(P >= 1 && P <= 64);
     const int grid = ups_cdiv((long long)B * hw, 256);
     const size_t shm = (size_t)256 * (P | 1) * sizeof(float);
-    static bool a0 = false, a1 = false;
+    static UpsPerDevice a0, a1;
     if (!allow_big_lds(mask_parts_bwd_kernel<float>, a0) || !allow_big_lds(mask_parts_bwd_kernel<bf16>, a1)) return UPS_E_LAUNCH;
     if (dtype == UPS_F32) hipLaunchKernelGGL(mask_parts_bwd_kernel<float>, dim3(grid), dim3(256), shm, (hipStream_t)stream, view, (const float*)g_out, g_hard, B, (long long)hw, P);
     else hipLaunchKernelGGL(mask_parts_bwd_kernel<bf16>, dim3(grid), dim3(256), shm, (hipStream_t)stream, view, (const bf16*)g_out, g_hard, B, (long long)hw, P);
@@ -628,7 +628,7 @@ extern "C" int ups_unpool_fwd(const float* hard, const float* feat, void* out, i
     UPS_CHECK_ARG(hard && feat && out && F % 8 == 0 && ldo % 8 == 0 && ldo >= F + P && P >= 1 && P <= 64);
     const dim3 grid(ups_cdiv(hw, 256), B);
     const size_t shm = ((size_t)256 * (P | 1) + (size_t)P * F + 256) * sizeof(float);
-    static bool a0 = false, a1 = false;
+    static UpsPerDevice a0, a1;
     if (!allow_big_lds(unpool_fwd_kernel<float>, a0) || !allow_big_lds(unpool_fwd_kernel<bf16>, a1)) return UPS_E_LAUNCH;
     if (dtype == UPS_F32) hipLaunchKernelGGL(unpool_fwd_kernel<float>, grid, dim3(256), shm, (hipStream_t)stream, hard, feat, (float*)out, (long long)hw, P, F, ldo);
     else hipLaunchKernelGGL(unpool_fwd_kernel<bf16>, grid, dim3(256), shm, (hipStream_t)stream, hard, feat, (bf16*)out, (long long)hw, P, F, ldo);
@@ -654,7 +654,7 @@ extern "C" int ups_unpool_bwd(const float* hard, const float* feat, const void* 
     const size_t shmem = lds_bytes(tpx);
     UPS_CHECK_ARG(shmem <= 160 * 1024);
     const dim3 grid(B, UNPOOL_SLABS);
-    static bool ah0 = false, ah1 = false;
+    static UpsPerDevice ah0, ah1;
     if (!allow_big_lds(unpool_bwd_kernel<float>, ah0) || !allow_big_lds(unpool_bwd_kernel<bf16>, ah1)) return UPS_E_LAUNCH;
     if (dtype == UPS_F32)
         hipLaunchKernelGGL(unpool_bwd_kernel<float>, grid, dim3(256), shmem, s, hard, feat, (const float*)g, g_hard, partial, (long long)hw,

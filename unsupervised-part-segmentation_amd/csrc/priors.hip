@@ -503,7 +503,7 @@ PriorK to_k(const ups_prior_desc* d, float* ws) {
 // Launch KERNEL<PC, LW> for the descriptor's (P, w): specialised instances for the part counts of the shipped / benchmark configs and
 // 128- / 256-wide images, the generic <0, -1> instance otherwise.  (Every instance may need more than the 64 KB default of LDS.)
 template <typename K, typename... A>
-static int prior_launch_one(K kernel, bool& attr, dim3 grid, size_t shm, hipStream_t s, A... args) {
+static int prior_launch_one(K kernel, UpsPerDevice& attr, dim3 grid, size_t shm, hipStream_t s, A... args) {
     if (!attr) {
         if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return UPS_E_LAUNCH;
         attr = true;
@@ -512,7 +512,7 @@ static int prior_launch_one(K kernel, bool& attr, dim3 grid, size_t shm, hipStre
     return UPS_OK;
 }
 #define UPS_PRIOR_CASE(KERNEL, PCV, LWV, ...)                                                            \
-    do { static bool at_ = false; const int rc_ = prior_launch_one(KERNEL<PCV, LWV>, at_, __VA_ARGS__); if (rc_ != UPS_OK) return rc_; } while (0)
+    do { static UpsPerDevice at_; const int rc_ = prior_launch_one(KERNEL<PCV, LWV>, at_, __VA_ARGS__); if (rc_ != UPS_OK) return rc_; } while (0)
 #define UPS_PRIOR_DISPATCH(KERNEL, grid, shm, ...)                                                       \
     do {                                                                                                 \
         const int lw_ = d->w == 128 ? 7 : (d->w == 256 ? 8 : -1);                                        \

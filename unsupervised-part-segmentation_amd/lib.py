@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UPS_LIB", os.path.join(_HERE, "csrc", "libupsparts_hip.so"))   # UPS_LIB: A/B builds
 
-ABI_VERSION = 2               # include/upsparts_hip.h UPS_ABI_VERSION
+ABI_VERSION = 3               # include/upsparts_hip.h UPS_ABI_VERSION
 F32, BF16, F16 = 0, 1, 2      # F16: forward tensors of precision-critical scopes (held in torch.bfloat16 containers, see ops.py)
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 ACT = {None: ACT_NONE, "leaky_relu": ACT_LRELU, "relu": ACT_RELU}
@@ -48,7 +48,8 @@ class WgradDesc(C.Structure):
                 ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9), ("tap_w", C.c_int32 * 9),
                 ("act_in", C.c_int32), ("act_slope", C.c_float), ("splitk", C.c_int32),
                 ("in_", C.c_void_p), ("dout", C.c_void_p), ("grad", C.c_void_p), ("grad_bias", C.c_void_p),
-                ("workspace", C.c_void_p), ("mask_bits", C.c_void_p), ("mask_batch", C.c_int32), ("in_f16", C.c_int32)]
+                ("workspace", C.c_void_p), ("mask_bits", C.c_void_p), ("mask_batch", C.c_int32), ("in_f16", C.c_int32),
+                ("dout_f8", C.c_void_p), ("dout_f8_scale", C.c_void_p), ("in_f8_scale", C.c_void_p), ("in_f8_amax", C.c_void_p)]
 
 
 class PriorDesc(C.Structure):

@@ -15,6 +15,7 @@ The part path between B and C (soft-max, hard max, moments, rectangles, priors) 
 its forward and its fused backward are single HIP kernels.
 """
 import ctypes as C
+import contextlib
 import math
 import os
 from collections import OrderedDict
@@ -36,6 +37,9 @@ LATE_JOIN = os.environ.get("UPS_LATE_JOIN", "1") != "0"      # A/B switch: singl
 CRITIC_STREAMS = os.environ.get("UPS_CRITIC_STREAMS", "1") != "0"      # A/B switch: the three critics on three side streams
 EARLY_ALPHA = os.environ.get("UPS_EARLY_ALPHA", "1") != "0"      # A/B switch: appearance code on "aux" beside the pose encoder
 JOIN_TIMING = os.environ.get("UPS_JOIN_TIMING", "0") == "1"
+# data parallel: bucket all-reduces are enqueued from the weight-gradient stream's position instead of after a join of the launching
+# stream with it (UPS_DP_SIDE_LAUNCH=0: the round-4 form, A/B runs)
+DP_SIDE_LAUNCH = os.environ.get("UPS_DP_SIDE_LAUNCH", "1") != "0"
 EARLY_ADAM = os.environ.get("UPS_EARLY_ADAM", "1") != "0"    # A/B switch: ... and queues each key's Adam behind its weight gradients
 
 
@@ -216,7 +220,19 @@ class Trainer(object):
         self.process_group = kwargs.get("process_group")
         self.beta1 = config.get("beta1", 0.5)        # edflow TFBaseTrainer defaults (UNVERIFIED)
         self.beta2 = config.get("beta2", 0.9)
-        self.adam_eps = 1e-8
+        # Global optimizer knobs beyond the yaml (all optimizers alike; defaults = tf.train.AdamOptimizer's epsilon, no warm-up, no
+        # clipping).  They exist so that hypotheses about edflow's TFBaseTrainer (source absent) are config keys, not patches:
+        # tools/pin_log.py sweeps them against the reference's training log.
+        self.adam_eps = float(config.get("adam_eps", 1e-8))
+        self.lr_warmup_steps = int(config.get("lr_warmup_steps", 0))       # linear ramp of lr over the first N global steps
+        self.grad_clip_norm = float(config.get("grad_clip_norm", 0.0))     # per optimizer key, global L2 norm (0 = off)
+        # `probe`: DIAGNOSTIC hooks (tools/pin_log.py, the conditional-pin test) -- never set by a shipped config:
+        #   lr_scale: {optimizer key: factor}  that key alone steps with factor * lr
+        #   rec_scale: s                        decoder_visualize's gradient sees priors + s * (reconstruction term), M:786-797
+        self.probe = dict(config.get("probe") or {})
+        unknown = set(self.probe) - {"lr_scale", "rec_scale"}
+        if unknown:
+            raise ValueError("probe: unknown hook(s) {}".format(sorted(unknown)))
         self.perceptual_input = config.get("perceptual_input", "native")
         if float(config.get("gram_weight", 0.0)) != 0.0:        # model.py:608: default 0.0 in every shipped yaml
             raise NotImplementedError("gram_weight != 0 (Gram-matrix terms of edflow's VGG19Features) is not on the shipped path")
@@ -253,6 +269,8 @@ class Trainer(object):
         self._noise = ops.NoiseStream(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))  # the sampling noise
         self._lazy_logs, self._done_thunk = None, None
         self._adam_done, self._step_graph_lr = set(), None
+        self._reduce_marks = []         # (key, bytes) of the bucket all-reduces of the running step, in launch order
+        self._poisoned = None           # set when a step failed half-way through its optimizer updates (_after_failed_step)
         self._losses = OrderedDict((k, None) for k in self.loss_keys())
         self._early, self._early_hooked = {}, False
         self._graph_enabled = bool(config.get("hip_graph", os.environ.get("UPS_GRAPH", "0") == "1"))
@@ -325,6 +343,13 @@ class Trainer(object):
         for k, v in ck.get("state", {}).items():
             if k in self.state:
                 self.state[k].fill_(float(v))
+        if "noise_offset" in ck:
+            self._noise.offset = int(ck["noise_offset"])
+        if "gen_state" in ck:
+            try:
+                self._gen.set_state(ck["gen_state"])
+            except Exception:           # a state written on another device type / torch build: fall back to a step-derived seed
+                self._gen.manual_seed(D.shard_seed(self.config.get("noise_seed", 4321), self.rank) + int(ck.get("global_step", 0)))
         base = os.path.basename(checkpoint_path)
         digits = "".join(ch for ch in base.split("-")[-1] if ch.isdigit())
         # the stored step is authoritative (it agrees with the restored Adam t); the file name is the fallback (model.py:597-601)
@@ -426,11 +451,15 @@ class Trainer(object):
         tfckpt.write_bundle(prefix, tensors)
 
     def save_checkpoint(self, path):
+        if self._poisoned:
+            raise RuntimeError("refusing to write a checkpoint: " + self._poisoned)
         bank = self.model.bank
         torch.save({"params": bank.state(), "global_step": self.global_step,
                     "adam": {k: {"m": g["flat"]["m"].cpu(), "v": g["flat"]["v"].cpu(), "t": g["t"]}
                              for k, g in bank.groups.items()},
-                    "state": {k: float(v) for k, v in self.state.items()}}, path)
+                    "state": {k: float(v) for k, v in self.state.items()},
+                    # a resumed run continues the sampling-noise stream instead of replaying steps 0..N's draws
+                    "noise_offset": self._noise.offset, "gen_state": self._gen.get_state().cpu()}, path)
 
     # ------------------------------------------------------------------ helpers
     def draw_noise(self, B):
@@ -447,8 +476,11 @@ class Trainer(object):
     def learning_rate(self):
         cfg = self.config
         lr = cfg.get("lr", 1e-4)
-        return make_linear_var(self.global_step, cfg.get("lr_decay_begin", 1000), cfg.get("lr_decay_end", 1001), lr, 0.0,
-                               0.0, lr)
+        lr = make_linear_var(self.global_step, cfg.get("lr_decay_begin", 1000), cfg.get("lr_decay_end", 1001), lr, 0.0,
+                             0.0, lr)
+        if self.lr_warmup_steps > 0:
+            lr = lr * min(1.0, (self.global_step + 1.0) / self.lr_warmup_steps)
+        return lr
 
     def _prior(self, view, n, S, P, l, lm, m, hard, px, per_np, sums, w, g_hard=None, dl=None, bwd=False, dl_rec=None):
         d = L.PriorDesc()
@@ -481,6 +513,36 @@ class Trainer(object):
         captured once into HIP graphs and replayed (one graph on a single GPU; under data parallelism a sequence of graphs cut
         at the collectives); see ``_graph_step`` / ``_capture_step``."""
         ops.Fp8.activate(self.model.fp8)
+        if self._poisoned:
+            raise RuntimeError("this trainer's state is inconsistent: " + self._poisoned + " -- restore a checkpoint (Trainer.initialize)")
+        try:
+            return self._train_step(batch, noise)
+        except BaseException as e:
+            self._after_failed_step(e)
+            raise
+
+    def _after_failed_step(self, exc):
+        """A step that raises after some optimizer keys have already taken their Adam step on the weight-gradient stream
+        (EARLY_ADAM) leaves those keys at step t + 1 and the others at t, with the converted weight copies stale.  Make the
+        device state coherent (side streams joined, copies re-converted from whatever the masters now hold) and refuse further
+        steps / checkpoints: the run has to restart from its last checkpoint."""
+        done = sorted(self._adam_done)
+        self._adam_done = set()
+        ops.Streams.master_busy.clear()
+        if not done:
+            return
+        try:
+            ops.Streams.join(self.device, names=("wgrad", "aux", "pre"))
+            ops.WeightVersion.value += 1
+            self.model.nets.prep.refresh()
+            if ops.Fp8.enabled:
+                ops.Fp8.after_step()
+        except Exception:
+            pass
+        self._poisoned = ("a training step failed ({}: {}) after the optimizer keys {} had been updated while the others had not"
+                          .format(type(exc).__name__, exc, done))
+
+    def _train_step(self, batch, noise=None):
         if self._graph_enabled and not self.model.use_tps:
             # one device scalar carries Adam's bias-corrected step size: usable only while every trained key is at the same
             # Adam step (not after restoring a checkpoint whose keys were trained for different numbers of steps)
@@ -522,6 +584,8 @@ class Trainer(object):
             elif k == "eps_l" and "eps_l" not in noise:          # explicit noise in the fixtures' two-tensor form
                 buf[:B].copy_(noise["eps_l0"], non_blocking=True)
                 buf[B:].copy_(noise["eps_l1"], non_blocking=True)
+            elif k == "crop_yx" and "crop_yx" not in noise:      # explicit noise without a window corner: draw it as usual
+                buf.random_(0, 33, generator=self._gen)
             else:
                 buf.copy_(noise[k], non_blocking=True)
         t = self.model.bank.groups[self.loss_keys()[0]]["t"] + 1
@@ -659,6 +723,8 @@ class Trainer(object):
         if c.pmode == "resize256_crop224":
             if df:
                 raise NotImplementedError("perceptual_input: resize256_crop224 is restated for the SB_model48i variants only")
+            if "crop_yx" not in noise:          # explicit (fixture-style) noise without a window corner: draw it as usual
+                noise = dict(noise, crop_yx=torch.randint(0, 33, (2,), generator=self._gen, device=dev, dtype=torch.int32))
             c.crop_yx = noise["crop_yx"].to(dev, torch.int32).contiguous()
         c.ft_pre, c.ft_ready = None, None
         if ops.Streams.enabled:
@@ -892,6 +958,9 @@ class Trainer(object):
         self._prior(0, B, S, P, l0, c.lm[:B], m0, c.hard[:B], px0, per_np0, c.sums0, wp, c.g_hard0, c.dl_tot[:B], bwd=True,
                     dl_rec=c.dl_rec[:B])
         self._prior(1, B, S, P, l1, None, m1, None, px1, c.stats_v, c.sums1, wp, c.g_hard1, c.dl_tot[B:], bwd=True, dl_rec=c.dl_rec[B:])
+        rs = self.probe.get("rec_scale")
+        if rs is not None and float(rs) != 1.0:     # diagnostic hook: how strongly the mask decoder's update follows the reconstruction term
+            c.dl_tot.copy_((c.dl_tot - c.dl_rec) + float(rs) * c.dl_rec)
 
     def _bwd_mask_decoder(self, c):
         """B backward: the weights see rec + priors, the latent sees rec only (one extra input-gradient pass)."""
@@ -1071,7 +1140,7 @@ class Trainer(object):
             ev[0].record()
             ops.Streams.join(dev, names=("aux",))
             ev[1].record()
-            self._join_events = getattr(self, "_join_events", []) + [ev]
+            self._join_events = (getattr(self, "_join_events", []) + [ev])[-256:]       # (bounded: a debug aid for short runs)
         else:
             ops.Streams.join(dev, names=("aux",))
         pending += self._launch_reduce([k for k in ("mi0_discriminator", "mi1_discriminator", "mi_estimator") + N.EXTRA_48C
@@ -1121,8 +1190,16 @@ class Trainer(object):
         def launch():
             if "encoder_0" in trainer._early or getattr(trainer, "_cap", None) is not None:
                 return                      # (graph capture: the whole bucket is reduced at the segment boundary)
-            ops.Streams.join(trainer.device, names=("wgrad",))
-            h = D.allreduce_bucket(grp["flat"]["g"][off:], trainer.world_size, trainer.process_group)
+            if ops.Streams.enabled and DP_SIDE_LAUNCH:       # behind the head's weight gradient on ITS stream (see _launch_reduce)
+                side = ops.Streams.get("wgrad", trainer.device)
+                w2 = ops.Streams._pool.get(("wgrad2", torch.device(trainer.device).index))
+                if w2 is not None:
+                    side.wait_stream(w2)
+                with torch.cuda.stream(side):
+                    h = D.allreduce_bucket(grp["flat"]["g"][off:], trainer.world_size, trainer.process_group)
+            else:
+                ops.Streams.join(trainer.device, names=("wgrad",))
+                h = D.allreduce_bucket(grp["flat"]["g"][off:], trainer.world_size, trainer.process_group)
             trainer._early["encoder_0"] = (off, h)
 
         for key, lay in self.model.nets.layers.items():
@@ -1152,24 +1229,48 @@ class Trainer(object):
                 side.wait_stream(ops.Streams.get("wgrad2", self.device))     # (the CoordConv rows of these keys' weight gradients)
                 with torch.cuda.stream(side):
                     self._adam(key_list, None)
+                    ev = side.record_event()
+                # a converted-weight cache entry created later in this step (a new (dtype, size) instance, the depth-to-space or
+                # fp8 copies) reads the fp32 master: it must see the finished update, not race with it (ops.ConvLayer._wait_master)
+                for k in key_list:
+                    ops.Streams.master_busy[k] = ev
                 self._adam_done.update(key_list)
             return []
-        ops.Streams.join(self.device, names=("wgrad",))
         bank = self.model.bank
         handles = []
-        for k in key_list:
-            g = bank.groups[k]["flat"]["g"]
-            early = self._early.pop(k, None)
-            if early is not None:            # the tail slice is already in flight (see _hook_early_reduce)
-                handles.append(early[1])
-                g = g[:early[0]]
-            handles.append(D.allreduce_bucket(g, self.world_size, self.process_group))
+        # The all-reduce of a bucket has to wait for the segment's weight gradients -- they run on the "wgrad" side stream -- but
+        # the LAUNCHING stream does not: the collective is enqueued from the side stream's position (torch's process group orders
+        # its own stream behind the stream that is current at the call), so the backward pass goes on while the bucket is reduced.
+        # (Until round 5 the launching stream joined the side stream here: under data parallelism it idled at every segment
+        # boundary for as long as the weight-gradient queue lagged -- the 2 % a single rank gains from LATE_JOIN.)
+        if ops.Streams.enabled and DP_SIDE_LAUNCH:
+            side = ops.Streams.get("wgrad", self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))      # (critics: their gradients were taken on "aux", joined by now)
+            w2 = ops.Streams._pool.get(("wgrad2", torch.device(self.device).index))
+            if w2 is not None:
+                side.wait_stream(w2)                                       # the CoordConv rows of these keys' weight gradients
+            ctx = torch.cuda.stream(side)
+        else:
+            ops.Streams.join(self.device, names=("wgrad",))
+            ctx = contextlib.nullcontext()
+        with ctx:
+            for k in key_list:
+                g = bank.groups[k]["flat"]["g"]
+                early = self._early.pop(k, None)
+                if early is not None:            # the tail slice is already in flight (see _hook_early_reduce)
+                    handles.append(early[1])
+                    g = g[:early[0]]
+                handles.append(D.allreduce_bucket(g, self.world_size, self.process_group))
+                self._reduce_marks.append((k, g.numel() * 4))
         return handles
 
     def _adam(self, keys, graph_lr):
         """One fused TF-Adam launch per key on the current stream (Appendix A.12); advances the keys' step counters (eager mode)."""
         bank = self.model.bank
         lr = self.learning_rate()
+        lr_scale = self.probe.get("lr_scale") or {}
+        if graph_lr is not None and (lr_scale or self.grad_clip_norm > 0):
+            raise NotImplementedError("probe.lr_scale / grad_clip_norm are eager-mode options (hip_graph: False)")
         for k in keys:
             grp = bank.groups[k]
             f = grp["flat"]
@@ -1178,7 +1279,10 @@ class Trainer(object):
             else:
                 grp["t"] += 1
                 t = grp["t"]
-                lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+                lr_t = lr * lr_scale.get(k, 1.0) * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+                if self.grad_clip_norm > 0:         # tf.clip_by_global_norm over the key's variables (device side, no sync)
+                    gn = torch.linalg.vector_norm(f["g"]) / self.world_size
+                    f["g"].mul_(torch.clamp(self.grad_clip_norm / gn.clamp_min(1e-30), max=1.0))
             ops.adam_step(f["p"], f["g"], f["m"], f["v"], lr_t, self.beta1, self.beta2, self.adam_eps, 1.0 / self.world_size)
 
     def _finish_step(self, keys, handles, graph_lr=None):
@@ -1189,17 +1293,49 @@ class Trainer(object):
             ev[0].record()
             ops.Streams.join(self.device)
             ev[1].record()
-            self._tail_events = getattr(self, "_tail_events", []) + [ev]
+            self._tail_events = (getattr(self, "_tail_events", []) + [ev])[-256:]
         else:
+            timed = bool(handles) and graph_lr is None and any(h is not None for h in handles) and not torch.cuda.is_current_stream_capturing()
+            if timed:       # data parallel: what the launching stream WAITS at the end of the backward pass, split into its parts
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(handles) + 2)]
+                evs[0].record()
             ops.Streams.join(self.device)
+            if timed:
+                evs[1].record()
+                for i, h in enumerate(handles):
+                    if h is not None:
+                        h.wait()
+                    evs[2 + i].record()
+                self._dp_wait_events = (getattr(self, "_dp_wait_events", []) + [(evs, list(self._reduce_marks))])[-64:]
+                handles = []
+        self._reduce_marks = []
         D.wait_all(handles)
         self._adam([k for k in keys if k not in self._adam_done], graph_lr)
         self._adam_done = set()
+        ops.Streams.master_busy.clear()         # (the join above ordered this stream behind every early Adam)
+        ops.Streams.epoch += 1                  # lazy weight conversions of this step are ordered before everything that follows
         if graph_lr is None:
             ops.WeightVersion.value += 1
         self.model.nets.prep.refresh()          # one launch: every layer's converted weights + CoordConv tables
         if ops.Fp8.enabled:
             ops.Fp8.after_step()
+
+    def dp_wait_ms(self):
+        """Data parallel: mean time per step the launching stream waited at the end of the backward pass -- for the weight-gradient
+        streams to drain (`side_streams`), then, bucket by bucket in launch order, for each gradient all-reduce that had not
+        finished by then (`<key>` with its bytes; 0 when the collective was fully hidden behind the backward pass).  Synchronises."""
+        rec = getattr(self, "_dp_wait_events", [])
+        if not rec:
+            return None
+        torch.cuda.synchronize(self.device)
+        out, n = OrderedDict(), 0
+        for evs, marks in rec:
+            n += 1
+            out["side_streams"] = out.get("side_streams", 0.0) + evs[0].elapsed_time(evs[1])
+            for i in range(len(evs) - 2):
+                key = "{}:{}B".format(*marks[i]) if i < len(marks) else "bucket{}".format(i)
+                out[key] = out.get(key, 0.0) + evs[1 + i].elapsed_time(evs[2 + i])
+        return OrderedDict((k, round(v / n, 4)) for k, v in out.items())
 
     # ------------------------------------------------------------------ edflow iterate(): log cadence of LoggingHook
     def fetch_logs(self):

@@ -57,6 +57,8 @@ class Streams(object):
     enabled = os.environ.get("UPS_NO_OVERLAP", "0") != "1"
     _pool = {}
     _raw = {}       # (name, device index) -> raw hipStream_t
+    epoch = 0          # bumped by the trainer at the end of every step (all side streams joined): scopes ConvLayer._mark_ready
+    master_busy = {}   # optimizer key -> event on the "wgrad" stream behind that key's early Adam launch (model.Trainer._launch_reduce)
     _alive = {}     # device index -> tensors the "wgrad" stream still reads.  Holding references until the next join keeps
                     # their memory out of the allocator without record_stream (whose deferred frees made the caching
                     # allocator reserve ~9x the live set: 84 GB at B = 64); once the launching stream has waited for the
@@ -175,6 +177,7 @@ class PrepRegistry(object):
             L.call("ups_weight_prep_batch", L.ptr(items_dev), L.ptr(prefix_dev), n, total, dcode, L.stream())
         for (_lay, ent, _d, _h, _w) in self.entries:
             ent["version"] = WeightVersion.value
+            ent["ready"] = None
         for fn in self.extra:
             fn()
 
@@ -206,6 +209,9 @@ class Fp8State(object):
         self.count = 0
         self.layers = []            # trainable layers with e4m3 weights (re-converted by after_step)
         self.GRAD = True            # input gradients of the fp8 layers on e5m2 operands (False: bf16 kernels)
+        # weight gradients of the wide 3x3 layers on e4m3 x e5m2 operands (conv_wgrad3x3_f8.hip) wherever the gradient arrives with
+        # its producer's e5m2 copy; UPS_F8_WGRAD=0: bf16 weight gradients (A/B runs)
+        self.WGRAD = os.environ.get("UPS_F8_WGRAD", "1") != "0"
         # COPY_ONLY: a layer takes the fp8 kernels only when its operand arrives quantised (a copy written by the producing
         # bilinear / convolution kernel); layers whose operand would have to be converted inside the kernel (24 staging
         # registers, one block per CU: slower than bf16) stay on the bf16 kernels.  None: follows PRODUCER.
@@ -310,6 +316,12 @@ class Fp8State(object):
                 and x.shape[1] % 16 == 0 and x.shape[2] % 16 == 0 and round8(layer.co) % 64 == 0 and layer.ci_log >= 64
                 and g.shape[-1] >= round8(layer.co))
 
+    def eligible_wgrad(self, layer, g, x, mask):
+        """Weight gradient on the block-scaled fp8 MFMA (mirrors eligible8 of conv_wgrad3x3_f8.hip): K = pixels."""
+        return (self.enabled and self.WGRAD and mask is None and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+                and layer.k == 3 and layer.stride == 1 and x.shape[1] % 16 == 0 and x.shape[2] % 16 == 0
+                and round8(layer.ci_log) % 64 == 0 and layer.co % 128 == 0 and g.shape[-1] % 16 == 0)
+
     def eligible(self, layer, x):
         return (self.enabled and x.dtype == torch.bfloat16 and layer.k == 3 and layer.stride == 1
                 and x.shape[1] % 16 == 0 and x.shape[2] % 16 == 0 and round8(layer.ci_log) % 64 == 0 and layer.co >= 64)
@@ -378,6 +390,38 @@ class ConvLayer(object):
         self.out_act = L.ACT_NONE
         self._cache = {}
 
+    def _mark_ready(self, ent):
+        """A lazy conversion was just enqueued on the current stream: remember where, so that a consumer on ANOTHER stream of the same
+        step (the appearance encoder first runs on "aux", the frozen trunk on "pre", both again on the launching stream) waits for
+        it instead of racing with it.  The batched refresh at the end of a step runs on the launching stream, from which every
+        side stream forks afterwards: it clears the mark."""
+        dev = self.V.device
+        if torch.cuda.is_current_stream_capturing():       # (captures start after eager steps: nothing converts lazily in them)
+            ent["ready"] = None
+            return
+        ent["ready"] = (L.raw_stream(dev), torch.cuda.current_stream(dev).record_event(), set(), Streams.epoch)
+
+    def _wait_ready(self, ent):
+        rd = ent.get("ready")
+        if rd is not None:
+            if rd[3] != Streams.epoch:          # an earlier step's conversion: every stream has been joined and re-forked since
+                ent["ready"] = None
+                return
+            cur = L.raw_stream(self.V.device)
+            if cur != rd[0] and cur not in rd[2] and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(self.V.device).wait_event(rd[1])
+                rd[2].add(cur)
+
+    def _wait_master(self):
+        """Before reading the fp32 master weights on this stream: wait for an Adam launch of this layer's optimizer key that is
+        still in flight on the weight-gradient stream (the trainer's early per-key Adam; keys match by substring, as edflow's
+        variable lists do)."""
+        if Streams.master_busy:
+            cur = torch.cuda.current_stream(self.V.device)
+            for key, ev in Streams.master_busy.items():
+                if key in self.name:
+                    cur.wait_event(ev)
+
     # ---- converted weights (refreshed when the optimizer has stepped)
     def prepared(self, dtype_code, hi, wi, need_dgrad):
         key = (dtype_code, hi, wi)
@@ -399,6 +443,7 @@ class ConvLayer(object):
             if self.registry is not None and not self.frozen:
                 self.registry.register(self, ent, dtype_code, hi, wi)
         if ent["version"] != WeightVersion.value and not (self.frozen and ent["version"] >= 0):
+            self._wait_master()
             L.call("ups_weight_prep", L.ptr(self.V), ntaps, self.cin_v, self.ci_log, self.co, dtype_code,
                    L.ptr(ent["w_fwd"]), ci_pad, L.ptr(ent["w_dgrad"]), self.ci_log, round8(self.co), L.stream())
             if ent["ctab"] is not None:
@@ -408,6 +453,9 @@ class ConvLayer(object):
                        (C.c_int32 * 9)(*dy), (C.c_int32 * 9)(*dx), self.stride, self.stride, ax, ay,
                        L.ptr(ent["ctab"]), L.stream())
             ent["version"] = WeightVersion.value
+            self._mark_ready(ent)
+        else:
+            self._wait_ready(ent)
         return ent
 
     def d2s_channels(self, x):
@@ -427,6 +475,7 @@ class ConvLayer(object):
             _, pbx = same_geometry(wi, 3, 2)
 
             def prep():
+                self._wait_master()
                 L.call("ups_weight_prep_d2s", L.ptr(self.V), self.cin_v, self.ci_log, self.co, pby, pbx, self.ci_log,
                        L.ptr(ent["w"]), L.stream())
                 ent["version"] = WeightVersion.value
@@ -436,6 +485,9 @@ class ConvLayer(object):
                 self.registry.extra.append(prep)
         if ent["version"] != WeightVersion.value and not (self.frozen and ent["version"] >= 0):
             ent["prep"]()
+            self._mark_ready(ent)
+        else:
+            self._wait_ready(ent)
         return ent
 
     def prepared_f8_grad(self, g):
@@ -452,12 +504,26 @@ class ConvLayer(object):
             if not self.frozen and self not in Fp8.layers:
                 Fp8.layers.append(self)
         if ent["version"] != WeightVersion.value and not (self.frozen and ent["version"] >= 0):
+            self._wait_master()
             L.call("ups_weight_prep_f8", L.ptr(self.V), self.k * self.k, self.cin_v, self.ci_log, self.co, 1,
                    L.ptr(ent["w"]), L.ptr(ent["deq"]), L.stream())
             ent["version"] = WeightVersion.value
         if not ent["primed"] and g is not None:
             m = g[..., :self.co].abs().amax().float()
             Fp8.scale[ent["slot"]] = torch.where(m > 0, (Fp8.E5M2_MAX * Fp8.MARGIN) / m.clamp_min(1e-30), torch.ones_like(m))
+            ent["primed"] = True
+        return ent
+
+    def prepared_f8_wgrad(self, x, fmt):
+        """Scale slot of the forward input as the fp8 weight gradient quantises it (delayed scaling: the kernel records
+        max |act(x)|, ops.Fp8.update turns it into the next step's scale; the first launch scales from the tensor at hand)."""
+        ent = Fp8.layer_entry(self, "f8w")
+        if ent is None:
+            ent = self._cache["f8w"] = {"slot": Fp8.slot(self.V.device), "primed": False, "gen": Fp8.generation}
+        if not ent["primed"]:
+            xv = x.view(torch.float16) if fmt == L.F16 else x       # (fp16 forward tensors live in bf16 containers)
+            m = xv[..., :round8(self.ci_log)].abs().amax().float()
+            Fp8.scale[ent["slot"]] = torch.where(m > 0, (448.0 * Fp8.MARGIN) / m.clamp_min(1e-30), torch.ones_like(m))
             ent["primed"] = True
         return ent
 
@@ -474,6 +540,7 @@ class ConvLayer(object):
             if not self.frozen and self not in Fp8.layers:
                 Fp8.layers.append(self)
         if ent["version"] != WeightVersion.value and not (self.frozen and ent["version"] >= 0):
+            self._wait_master()
             L.call("ups_weight_prep_f8", L.ptr(self.V), self.k * self.k, self.cin_v, self.ci_log, self.co, 0,
                    L.ptr(ent["w"]), L.ptr(ent["deq"]), L.stream())
             ent["version"] = WeightVersion.value
@@ -600,10 +667,11 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
     return out
 
 
-def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
+def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0, f8_src="pop"):
     """gx = act'(x) * conv^T(g) (+ res);  g [n,ho,wo,ldg] in the activation dtype, x the forward input.
     mask_view (fp32 [B,hi,wi,3], with n_parts): the forward was the part-masked convolution; returns d loss / d hard
-    [B,hi,wi,P] = sum_c gx[p*B+b,...,c] * view[b,...,c] straight from the kernel's epilogue (gx is never written)."""
+    [B,hi,wi,P] = sum_c gx[p*B+b,...,c] * view[b,...,c] straight from the kernel's epilogue (gx is never written).
+    f8_src: the e5m2 copy of g its producer registered (ops.Fp8.grad_copy), None, or "pop" = look it up here."""
     n, hi, wi, ldi = x.shape
     dcode = L.dt(x)
     ho, wo = layer.out_hw(hi, wi)
@@ -680,7 +748,7 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
         if mask_view is not None:
             d.mask_grad, d.mask_view, d.mask_batch = g_hard.data_ptr(), mask_view.data_ptr(), n
         elif st == 1 and Fp8.enabled and Fp8.GRAD and g.dtype == torch.bfloat16:
-            src = Fp8.grad_copy(g)
+            src = Fp8.grad_copy(g) if isinstance(f8_src, str) else f8_src
             use_f8 = Fp8.eligible_grad(layer, g, x)
             src_ok = use_f8 and src is not None and layer.ci_log > 32 and g.shape[-1] % 16 == 0
             emit = False
@@ -733,13 +801,15 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0):
 COORD_STREAM = os.environ.get("UPS_COORD_STREAM", "1") != "0"     # A/B switch: CoordConv rows of the weight gradients on their own stream
 
 
-def conv_wgrad(g, x, layer, mask=None, fmt=None, launch_stream=None):
+def conv_wgrad(g, x, layer, mask=None, fmt=None, launch_stream=None, f8_src=None):
     """(dV [kh,kw,cin_v,co] fp32, db [co] fp32).  mask = (hard_bits, P): x is the unmasked view of a part-masked convolution.
     fmt = L.F16: x holds fp16 (converted to bf16, the gradient's type, while it is staged).
     launch_stream: the stream whose position marks "g and x are ready" when the call itself runs on the weight-gradient side stream:
     the CoordConv rows (batch sum of g + two small kernels: they write rows of dV the main kernel does not touch) then go to a
     second side stream, beside the layer's main weight-gradient kernel instead of behind it -- the weight-gradient stream is a
-    serial chain that ends the step (tools/timeline.py), and these ~40 small launches were 1 ms of it."""
+    serial chain that ends the step (tools/timeline.py), and these ~40 small launches were 1 ms of it.
+    f8_src: the e5m2 copy of g (the handle ops.Fp8.grad_copy returns): the wide 3x3 / stride-1 layers then run on the fp8 kernel
+    (ups_wgrad_desc.dout_f8; x is quantised while it is staged, with this layer's delayed scale)."""
     n, hi, wi, ldi = x.shape
     if mask is not None:
         n = n * mask[1]
@@ -762,6 +832,15 @@ def conv_wgrad(g, x, layer, mask=None, fmt=None, launch_stream=None):
     if mask is not None:
         d.mask_bits, d.mask_batch = mask[0].data_ptr(), x.shape[0]
     d.in_f16 = int(fmt == L.F16)
+    if f8_src is not None and f8_src.get("t") is not None and Fp8.eligible_wgrad(layer, g, x, mask) \
+            and tuple(f8_src["t"].shape) == tuple(g.shape):
+        ew = layer.prepared_f8_wgrad(x, fmt)
+        d.dout_f8 = f8_src["t"].data_ptr()
+        d.dout_f8_scale = Fp8.scale[f8_src["slot"]:].data_ptr()
+        d.in_f8_scale = Fp8.scale[ew["slot"]:].data_ptr()
+        d.in_f8_amax = Fp8.amax[ew["slot"]].data_ptr()
+        Fp8.stats["wgrad_f8"] += 1
+        Fp8.mark_used(f8_src)
     L.call("ups_conv_wgrad_plan", C.byref(d), C.byref(sk), C.byref(wsb))
     ws = WORKSPACE.get(wsb.value, dev)
     d.splitk, d.workspace = sk.value, ws.data_ptr()
@@ -836,6 +915,9 @@ class ConvFn(torch.autograd.Function):
         g = to_act_dtype(g, x.dtype, layer.co)
         gx = gV = gb = gres = g_hard = None
         offloaded = False
+        # the e5m2 copy of g its producer wrote (fp8 mode): looked up ONCE, read by the weight gradient and by the input gradient
+        f8_src = Fp8.grad_copy(g) if (Fp8.enabled and Fp8.GRAD and ctx.mask is None and layer.stride == 1
+                                      and g.dtype == torch.bfloat16) else None
         if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not GradMode.skip_wgrad:
             if Streams.enabled and layer.grad_V is not None and not Streams.on_aux(x.device):
                 offloaded = True
@@ -845,17 +927,19 @@ class ConvFn(torch.autograd.Function):
                 side = Streams.get("wgrad", x.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask, fmt=ctx.fmt, launch_stream=cur)
+                    gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask, fmt=ctx.fmt, launch_stream=cur, f8_src=f8_src)
                 Streams.keep(x.device, g, x)      # alive until the launching stream has joined the side stream(s)
+                if f8_src is not None:
+                    Streams.keep(x.device, f8_src["t"])
             else:
-                gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask, fmt=ctx.fmt)
+                gV, gb = conv_wgrad(g, x, layer, mask=ctx.mask, fmt=ctx.fmt, f8_src=f8_src)
             if layer.after_wgrad is not None:
                 layer.after_wgrad()
         if ctx.mask is not None:
             if ctx.needs_input_grad[8]:
                 g_hard = conv_dgrad(g, x, layer, mask_view=view_f32, n_parts=ctx.mask[1])
         elif ctx.needs_input_grad[0]:
-            gx = conv_dgrad(g, x, layer, res=g if ctx.res_mode == 2 else None)
+            gx = conv_dgrad(g, x, layer, res=g if ctx.res_mode == 2 else None, f8_src=f8_src if layer.stride == 1 else "pop")
         if ctx.res_mode == 1 and ctx.needs_input_grad[3]:
             # the autograd engine may accumulate other branches into the returned tensor IN PLACE; the side stream
             # is still reading g, so hand out a copy in that case
