@@ -73,6 +73,10 @@ def launch_ranks(args):
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ)
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC; with the legacy mode RCCL's
+        # intra-node set-up (and any sharing of device tensors between the rank processes) fails with
+        # `hipIpcGetMemHandle: invalid argument`.  The image exports it already; it is repeated here so that the ranks get it
+        # whatever environment the launcher itself was started from (tests/test_host.py checks the launcher's environment).
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         out = subprocess.PIPE if r == 0 else sys.stderr     # rank 0 prints the JSON line; whatever else the ranks print goes to stderr
@@ -223,14 +227,17 @@ def run_rank(args):
         dname = {"bf16": "bf16", "fp8": "fp8"}.get(args.precision, "f32")
         traffic = None
         pmc_used = None
+        pmc_tree = None
         # HBM bytes per launch of the roofline kernel from the PMC passes committed for this tree (profiles/), not live; they were
         # taken on the headline shape (2 x 64 images of 128x128, 256 channels, bf16): reported for exactly that launch only
         if args.config == "cub128p10" and args.precision in ("bf16", "fp8") and args.batch == 64:
             for pf in (PMC_FILES_FP8 if args.precision == "fp8" else PMC_FILES):
                 try:
                     with open(pf) as f:
-                        traffic = json.load(f)["traffic_bytes_per_launch"]
+                        pj = json.load(f)
+                    traffic = pj["traffic_bytes_per_launch"]
                     pmc_used = os.path.relpath(pf, ROOT)
+                    pmc_tree = pj.get("tree", "unrecorded (taken before round 5: the 823-launch tree of round 4)")
                     break
                 except Exception:
                     traffic = None
@@ -259,10 +266,12 @@ def run_rank(args):
                                           if args.precision == "fp8" else ""),
                           "name": args.config, "perceptual_input": args.perceptual_input,
                           "global_batch": args.batch * world, "parallelism": "dp{}".format(world),
-                          "rccl_world_size": rccl_world},
+                          "rccl_world_size": rccl_world, "stream_plan": trainer.stream_plan},
                "model_tflops_per_gpu": round(value * gflop_img / 1e3 / world, 2), "train_gflop_per_image": gflop_img,
-               "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel<{},128,2,16> @ {} ({})".format(
-                                "bf16 tensors, block-scaled fp8 MFMA" if args.precision == "fp8" else dname, ops.KernelTimer.layer,
+               "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel<{}> @ {} ({})".format(
+                                "bf16 tensors, block-scaled fp8 MFMA,128,2,16" if args.precision == "fp8" else
+                                ("float,128,1,16: v_mfma_f32_32x32x2_f32, exact f32, one block per CU" if dname == "f32" else
+                                 "f16 forward / bf16 input gradients,128,2,16"), ops.KernelTimer.layer,
                                 "the 2 input-gradient launches per step, e5m2 x e4m3 operands; the layer's forward launch stays fp16 and is "
                                 "listed under kernel_ms_forward" if args.precision == "fp8" else
                                 "1 forward + 2 input-gradient launches per step, all timed"),
@@ -276,6 +285,11 @@ def run_rank(args):
                                                 "bf16 out)" if args.precision == "fp8" else "2.15e9") if traffic else
                                             "no PMC pass committed for this launch shape",
                             "flop_per_launch": ops.KernelTimer.flops}}
+        if traffic:      # the PMC passes are not live: say which tree they were taken on, so a traffic regression is not hidden by a stale file
+            out["roofline"]["traffic_tree"] = pmc_tree
+        dpw = trainer.dp_wait_ms()
+        if dpw is not None:      # data parallel: what rank 0's launching stream waited at the end of the backward pass, per step
+            out["dp_wait_ms"] = dpw
         if not ops.KernelTimer.events:
             out["roofline"]["note"] = "no launch timed: under HIP-graph replay (hip_graph / UPS_GRAPH=1) the roofline launches are graph nodes"
         if world == 1 and not args.no_cpu_baseline:

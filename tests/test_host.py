@@ -305,6 +305,7 @@ import torch
 import torch.distributed as dist
 world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
 assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0", "ranks must run with dmabuf IPC (RCCL on this pool's host driver)"
 if os.environ.get("UPS_TEST_DIE_EARLY") == "1" and rank == 1:
     sys.exit(9)           # dies before the rendezvous: rank 0 would sit in init_process_group until its timeout
 dist.init_process_group("gloo", init_method="env://", world_size=world, rank=rank)
@@ -328,7 +329,8 @@ def test_bench_launcher_spawns_n_ranks(tmp_path):
     import sys
     entry = tmp_path / "rank.py"
     entry.write_text(_RANK_STANDIN)
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    # (HSA_ENABLE_IPC_MODE_LEGACY is dropped from the launcher's own environment: it must reach the ranks regardless)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--rank-entry", str(entry)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode()

@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="forward / input gradient of the eligible layers on the fp8 path (ops.Fp8)")
     ap.add_argument("--fp8-copy", action="store_true", help="with --fp8: the forward input arrives as the fp8 copy a producing layer "
                     "would have written (no conversion in the kernel, two blocks per CU)")
+    ap.add_argument("--fp8-wgrad", action="store_true", help="with --fp8: the weight gradient of the eligible layers on the fp8 kernel "
+                    "(the gradient arrives as its producer's e5m2 copy)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ops.Fp8.enabled = args.fp8
@@ -110,7 +112,12 @@ def main():
         if fmt == lib.F16:
             gy = torch.randn(y.shape, device=dev).to(T)
         td = timeit(lambda: ops.conv_dgrad(gy, x, lay, res=gy if res_self else None), args.iters)
-        tw = timeit(lambda: ops.conv_wgrad(gy, x, lay, fmt=fmt), args.iters)
+        wsrc = None
+        if args.fp8 and args.fp8_wgrad and ops.Fp8.eligible_wgrad(lay, gy, x, None):
+            gslot = ops.Fp8.slot(dev)
+            ops.Fp8.scale[gslot] = 57344.0 * 0.5 / gy.float().abs().max()
+            wsrc = {"t": (gy.float() * ops.Fp8.scale[gslot]).clamp(-57344, 57344).to(torch.float8_e5m2).view(torch.uint8), "slot": gslot}
+        tw = timeit(lambda: ops.conv_wgrad(gy, x, lay, fmt=fmt, f8_src=wsrc), args.iters)
         tot[0] += tf; tot[1] += td; tot[2] += tw
         print("{:10s} {:9.3f} {:8.1f} {:9.3f} {:8.1f} {:9.3f} {:8.1f}".format(
             name, tf, flops / tf / 1e9, td, flops / td / 1e9, tw, flops / tw / 1e9))

@@ -2,7 +2,8 @@
 Usage: python tools/one_conv.py [fwd|dgrad|wgrad] [case of tools/bench_conv.py, default dv_rb128] [plain]
 The launch is issued the way the model issues it: residual block (res = in), for a 3x3 layer with an activation the input in
 post-activation storage and -- the mask decoder's layers (dv_*) -- fp16 forward tensors; `plain`: bf16, activation-on-load;
-`f8`: the fp8 mode's launch -- the operand arrives as a producer's e4m3 (forward) / e5m2 (input gradient) copy."""
+`f8`: the fp8 mode's launch -- the operand arrives as a producer's e4m3 (forward) / e5m2 (input gradient) copy; `wgrad ... f8`: the
+fp8 weight gradient (conv_wgrad3x3_f8.hip): the gradient's e5m2 copy + the forward tensor quantised while it is staged."""
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +23,8 @@ from upsparts_amd import lib
 lay = ops.ConvLayer("x/conv2d_0", V, b, k, stride, coords, act)
 plain = len(sys.argv) > 3 and sys.argv[3] == "plain"
 f8 = len(sys.argv) > 3 and sys.argv[3] == "f8"
-fmt = lib.F16 if (not plain and not f8 and case.startswith("dv_") and k == 3) else None
+# (the fp8 WEIGHT gradient of a mask-decoder layer reads the fp16 forward tensor as the model hands it over)
+fmt = lib.F16 if (not plain and (not f8 or mode == "wgrad") and case.startswith("dv_") and k == 3) else None
 lay.f16 = fmt == lib.F16
 if not plain and act == "leaky_relu":
     lay.in_post, lay.out_act = True, lib.ACT_LRELU
@@ -35,8 +37,10 @@ if f8:
     F = ops.Fp8.activate(ops.Fp8State(True))
     sx, sg = F.slot(dev), F.slot(dev)
     F.scale[sx] = 448.0 * F.MARGIN / float(x.float().abs().max()); F.scale[sg] = 57344.0 * F.MARGIN / 6.0
-    x8 = (x.float() * F.scale[sx]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
-    F.next_in = {"t": x8, "slot": sx, "act": lay.act_in, "site": None}
+    xf = x.view(torch.float16).float() if fmt == lib.F16 else x.float()
+    x8 = (xf * F.scale[sx]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    if fmt != lib.F16:
+        F.next_in = {"t": x8, "slot": sx, "act": lay.act_in, "site": None}
 y = ops.conv_forward(x, lay, res=res, fmt=fmt, res_post=lay.in_post)
 gy = torch.randn(y.shape, device=dev).to(torch.bfloat16)
 if f8:
@@ -51,7 +55,7 @@ for _ in range(3):
             F.register_grad_copy(gy, {"t": g8, "slot": sg, "site": None})
         ops.conv_dgrad(gy, x, lay, res=gy if res is not None else None)
     elif mode == "wgrad":
-        ops.conv_wgrad(gy, x, lay, fmt=fmt)
+        ops.conv_wgrad(gy, x, lay, fmt=fmt, f8_src={"t": g8, "slot": sg, "site": None} if f8 else None)
 torch.cuda.synchronize()
 if f8:
     print(F.stats)

@@ -1,5 +1,7 @@
 """Per-kernel VGPRs / spills / scratch / LDS / occupancy from a `hipcc -Rpass-analysis=kernel-resource-usage` log.
-Usage: python tools/res_usage.py <log> [name-filter]   (lines: vgprs spill scratch lds occupancy name)"""
+Usage: python tools/res_usage.py <log> [name-filter]   (lines: vgprs agprs spill scratch lds occupancy name)
+       python tools/res_usage.py <log> --patch [f8]    conv3x3_patch_kernel instances with their template arguments decoded
+                                                       (T BN OCC SUB F8 PRE TAPS DMAP; `f8`: the fp8 instances only)"""
 import re
 import subprocess
 import sys
@@ -32,8 +34,21 @@ def demangle(names):
         return names
 
 
+def patch_table(rows, only_f8):
+    """The conv3x3_patch_kernel instances, template arguments read off the mangled name (what tools/resusage.py printed)."""
+    for r in rows:
+        m = re.search(r"conv3x3_patch_kernelI(\w+?)Li(\d+)ELi(\d)ELi(\d+)ELi(\d)ELb(\d)ELi(\d)ELb(\d)", r["name"])
+        if not m or (only_f8 and m.group(5) == "0"):
+            continue
+        print("T=%s BN=%s OCC=%s SUB=%s F8=%s PRE=%s TAPS=%s DMAP=%s" % m.groups(), "vgpr", r.get("vgpr", -1), "agpr", r.get("agpr", 0),
+              "spill", r.get("spill", 0), "scratch", r.get("scratch", 0), "lds", r.get("lds", 0))
+
+
 if __name__ == "__main__":
     rows = parse(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[2] == "--patch":
+        patch_table(rows, len(sys.argv) > 3)
+        sys.exit(0)
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
     names = demangle([r["name"] for r in rows])
     for r, n in zip(rows, names):

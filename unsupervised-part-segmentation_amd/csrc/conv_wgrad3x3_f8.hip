@@ -140,8 +140,11 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_f8_kernel(const Wg8K p, con
         y0 = ty * 16 + half * TH; x0 = tx * TW;
     };
     uint4 rx[NX][2];
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    auto load_unit = [&](int u, int buf) __attribute__((always_inline)) {
+    bool rxok[NX];
+    // X loads of unit u into registers, UNCONDITIONALLY (lanes whose item lies outside the image read the tensor's first bytes and
+    // drop them) and as inline asm: the number of vector-memory operations per wave is then static and invisible to hipcc's own
+    // wait-count pass, so counted s_waitcnt's can leave exactly these loads in flight across the barrier (as conv_wgrad3x3.hip)
+    auto load_x = [&](int u) __attribute__((always_inline)) {
         int img, y0, x0;
         unit_origin(u, img, y0, x0);
         const unsigned edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.h ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == p.w ? 8u : 0u) | 16u;
@@ -151,13 +154,18 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_f8_kernel(const Wg8K p, con
         for (int k = 0; k < NX; ++k) {
             unsigned r = xr[k], f = xs[k];
             asm volatile("" : "+v"(r), "+v"(f));
-            uint4 v0 = zero4, v1 = zero4;
-            if (((f >> 16) & edge) == 0u) {
-                const unsigned char* src = xb + (__umul24(r, x_rowb) + x_chb);
-                v0 = *(const uint4*)src; v1 = *(const uint4*)(src + 16);
-            }
+            const bool ok = ((f >> 16) & edge) == 0u;
+            const unsigned char* src = ok ? xb + (__umul24(r, x_rowb) + x_chb) : (const unsigned char*)p.in;
+            uint4 v0, v1;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v0) : "v"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(v1) : "v"(src) : "memory");
             rx[k][0] = v0; rx[k][1] = v1;
+            rxok[k] = ok;
         }
+    };
+    auto dma_d = [&](int u, int buf) __attribute__((always_inline)) {
+        int img, y0, x0;
+        unit_origin(u, img, y0, x0);
         const unsigned char* db = p.dout8 + (((long long)img * p.h + y0) * p.w + x0) * p.ldo8;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -167,17 +175,19 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_f8_kernel(const Wg8K p, con
         }
     };
     float amax = 0.f;
-    auto store_unit = [&](int buf) __attribute__((always_inline)) {
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    auto store_x = [&](int buf, int k) __attribute__((always_inline)) {
         unsigned char* X = Xbuf + buf * XB;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            unsigned f = xs[k];
-            asm volatile("" : "+v"(f));
-            const uint4 v = quant16(rx[k][0], rx[k][1], sx, act_ns, act, f16in, amax);
-            if (k + 1 < NX || tid + 512 * k < NITEMS) *(uint4*)(X + (f & 0xffffu)) = v;
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        unsigned f = xs[k];
+        asm volatile("" : "+v"(f));
+        const uint4 v = quant16(rxok[k] ? rx[k][0] : zero4, rxok[k] ? rx[k][1] : zero4, sx, act_ns, act, f16in, amax);
+        if (k + 1 < NX || tid + 512 * k < NITEMS) *(uint4*)(X + (f & 0xffffu)) = v;
     };
+    // every staging register is an operand of the wait, so that no use of them is scheduled above it
+#define UPS_WAIT_X8(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(rx[0][0].x), "+v"(rx[0][0].y), "+v"(rx[0][0].z), "+v"(rx[0][0].w), \
+                                    "+v"(rx[0][1].x), "+v"(rx[0][1].y), "+v"(rx[0][1].z), "+v"(rx[0][1].w), "+v"(rx[1][0].x), "+v"(rx[1][0].y), \
+                                    "+v"(rx[1][0].z), "+v"(rx[1][0].w), "+v"(rx[1][1].x), "+v"(rx[1][1].y), "+v"(rx[1][1].z), "+v"(rx[1][1].w) :: "memory")
+    static_assert(NX == 2, "pipelined staging: two items (four loads) per thread and unit");
 
     f32x4v acc[9][2][2];
 #pragma unroll
@@ -197,12 +207,22 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_f8_kernel(const Wg8K p, con
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) da[jb] = ((2 * q) * TW + pp) * DPP + (((w_co * 2 + jb) ^ gd) << 4) + piece * 8;
 
-    if (u_begin < u_end) { load_unit(u_begin, 0); store_unit(0); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // Software-pipelined staging (one block per CU runs its eight waves in lock-step between barriers: a load -> wait -> convert ->
+    // ds_write phase at the end of every unit would idle the matrix pipe for its whole length -- and on the block-scaled MFMA a
+    // unit's 36 MFMAs are only ~1.1 k cycles).  Order of the vector-memory operations of a wave: [unit u-1, middle] 4 X loads of unit
+    // u+1, [unit u, start] 2 dout DMA pieces of unit u+1, [unit u, middle] X of u+1 converted and written (counted wait: all but the
+    // 2 DMA pieces), then the 4 X loads of unit u+2; [unit u, end] the DMA pieces must have landed, the 4 loads stay in flight.
+    if (u_begin < u_end) {
+        load_x(u_begin); dma_d(u_begin, 0);
+        UPS_WAIT_X8(0);
+        store_x(0, 0); store_x(0, 1);
+        if (u_begin + 1 < u_end) load_x(u_begin + 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     for (int u = u_begin; u < u_end; ++u) {
         const int buf = (u - u_begin) & 1;
-        if (u + 1 < u_end) load_unit(u + 1, buf ^ 1);
+        if (u + 1 < u_end) dma_d(u + 1, buf ^ 1);
         const unsigned char* X = Xbuf + buf * XB + xa;
         const unsigned char* D = Dbuf + buf * DB;
         i32x8v fb[2];
@@ -229,15 +249,28 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_f8_kernel(const Wg8K p, con
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb) asm volatile("" : "+v"(acc[t][ib][jb]));
             __builtin_amdgcn_sched_barrier(0);
+            if (t == 3 && u + 1 < u_end) {
+                UPS_WAIT_X8(2);                     // the X loads of unit u+1 (older than this unit's two DMA pieces) have landed
+                store_x(buf ^ 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t == 5 && u + 1 < u_end) {
+                store_x(buf ^ 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 2 < u_end) load_x(u + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (do_bias) {
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
                 accb[jb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, fb[jb], accb[jb], 0, 1, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
-        if (u + 1 < u_end) store_unit(buf ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA of the next dout tile has landed
-        __syncthreads();
+        // the dout DMA of unit u+1 (older than the four X loads of unit u+2) must have landed; those loads stay in flight
+        if (u + 2 < u_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
     // ---- next step's activation scale

@@ -15,6 +15,36 @@ import torch.distributed as dist
 # UPS_FORCE_COLLECTIVES=1: issue the gradient all-reduces even at world size 1 (identity) -- exercises the RCCL call pattern
 # (asynchronous bucket all-reduces launched from inside the backward pass beside the side streams) on a single-GPU box
 FORCE_COLLECTIVES = __import__("os").environ.get("UPS_FORCE_COLLECTIVES", "0") == "1"
+# UPS_DP_STANDIN=1 (single-GPU measurement of the data-parallel stream budget, tools/probes/stream_dp.py): every bucket "all-reduce"
+# is an out-of-place device copy of the bucket on a stream of its own, started where the real collective would start and waited
+# for where the real one is -- the load an RCCL kernel puts on HBM and on a hardware queue, without a second GPU.  The values are
+# untouched (world size 1: the sum over ranks is the bucket itself).
+STANDIN = __import__("os").environ.get("UPS_DP_STANDIN", "0") == "1"
+FORCE_COLLECTIVES = FORCE_COLLECTIVES or STANDIN
+_standin = {}
+
+
+class _StandinWork(object):
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+def _standin_copy(flat_grad):
+    dev = flat_grad.device
+    st = _standin.get(("stream", dev))
+    if st is None:
+        st = _standin[("stream", dev)] = torch.cuda.Stream(device=dev)
+    buf = _standin.get(("buf", dev))
+    if buf is None or buf.numel() < flat_grad.numel():
+        buf = _standin[("buf", dev)] = torch.empty(max(flat_grad.numel(), 16 << 20), dtype=flat_grad.dtype, device=dev)
+    st.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(st):
+        buf[:flat_grad.numel()].copy_(flat_grad)
+        ev = st.record_event()
+    return _StandinWork(ev)
 
 
 def init_from_env(backend="nccl"):
@@ -33,6 +63,8 @@ def allreduce_bucket(flat_grad, world_size, group=None, async_op=True):
     """Sum-all-reduce one optimizer key's flat gradient; returns the work handle (or None)."""
     if world_size <= 1 and not FORCE_COLLECTIVES:
         return None
+    if STANDIN and world_size <= 1 and flat_grad.is_cuda:
+        return _standin_copy(flat_grad)
     return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 

@@ -269,6 +269,14 @@ class Trainer(object):
         self._noise = ops.NoiseStream(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))  # the sampling noise
         self._lazy_logs, self._done_thunk = None, None
         self._adam_done, self._step_graph_lr = set(), None
+        # `stream_plan` (full | compact | auto): how the step's logical streams map onto HIP streams (ops.Streams.set_plan).  auto =
+        # full on one rank, compact under data parallelism, where the collectives' stream needs a hardware queue of its own
+        # (measured with a stand-in for the collectives on one GPU: tools/probes/stream_dp.py, profiles/round5_stream_dp.txt)
+        plan = str(config.get("stream_plan", os.environ.get("UPS_STREAM_PLAN", "auto"))).lower()
+        if plan == "auto":
+            plan = "compact" if (self.world_size > 1 or D.FORCE_COLLECTIVES) else "full"
+        self.stream_plan = plan
+        ops.Streams.set_plan(plan)
         self._reduce_marks = []         # (key, bytes) of the bucket all-reduces of the running step, in launch order
         self._poisoned = None           # set when a step failed half-way through its optimizer updates (_after_failed_step)
         self._losses = OrderedDict((k, None) for k in self.loss_keys())

@@ -68,8 +68,23 @@ class Streams(object):
     def keep(cls, device, *tensors):
         cls._alive.setdefault(torch.device(device).index, []).extend(tensors)
 
+    # Stream plan.  "full": every logical stream is a HIP stream of its own (seven with the launching stream) -- the fastest form on
+    # ONE rank.  "compact": the logical streams fold onto three -- launching stream, "wgrad" (weight gradients
+    # and their CoordConv rows), "aux" (target features, appearance code, the three critics) -- which leaves the fourth of the
+    # four hardware queues (GPU_MAX_HW_QUEUES) to the collectives' stream under data parallelism: more than four ACTIVE queues are
+    # time-sliced by the hardware scheduler (+30 % on the step).  The trainer picks the plan (`stream_plan`, model.Trainer).
+    COMPACT_ALIAS = {"pre": "aux", "aux1": "aux", "aux2": "aux", "wgrad2": "wgrad"}
+    alias = {}
+
+    @classmethod
+    def set_plan(cls, plan):
+        if plan not in ("full", "compact"):
+            raise ValueError("stream plan '{}' (full | compact)".format(plan))
+        cls.alias = dict(cls.COMPACT_ALIAS) if plan == "compact" else {}
+
     @classmethod
     def get(cls, name, device):
+        name = cls.alias.get(name, name)
         key = (name, torch.device(device).index)
         st = cls._pool.get(key)
         if st is None:
@@ -93,7 +108,12 @@ class Streams(object):
             names = tuple(names) + ("wgrad2",)          # the CoordConv rows of the weight gradients (conv_wgrad) belong to it
         if "aux" in names:
             names = tuple(names) + ("aux1", "aux2")         # critics two and three (Trainer._critics)
+        seen = set()
         for n in names:
+            n = cls.alias.get(n, n)
+            if n in seen:
+                continue
+            seen.add(n)
             st = cls._pool.get((n, torch.device(device).index))
             if st is not None and st != cur:
                 cur.wait_stream(st)
