@@ -262,6 +262,10 @@ int ups_act_mean_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h
 int ups_act_mean_bwd(const void* x, const void* gy, void* gx, int32_t dtype, int32_t n, int32_t hw, int32_t c, int32_t act, float slope, void* stream);
 /* 2x2/2 max pool on pre-activations (Keras VGG19 block*_pool); bwd routes to the first maximal element */
 int ups_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+/* bf16 form that also hands the pooled tensor to an fp8 convolution (Keras VGG19 pools in front of block{2..5}_conv1; edflow
+ * VGG19Features, external): max |act(y)| into amax[64]; with y_f8 != NULL the e4m3 bytes of act(y) * *scale next to y. */
+int ups_maxpool2_fwd_f8(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void* y_f8, const float* scale,
+                        float* amax, int32_t act, float slope, void* stream);
 int ups_maxpool2_bwd(const void* x, const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
 /* copy `c` channels between tensors with different physical widths / offsets (concat for N:1049-1051) */
 int ups_copy_channels(const void* src, int32_t lds, void* dst, int32_t ldd, int32_t dtype, int64_t rows, int32_t c, void* stream);

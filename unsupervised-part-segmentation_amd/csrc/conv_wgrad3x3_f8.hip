@@ -10,8 +10,8 @@
 // layout probed on the hardware, tools/probes/tr8_probe.hip).  The order of k is free as long as both operands agree, and they
 // do: the same (q, read, pixel) walk on both images, the X window shifted by the tap.
 //
-// Block = 512 threads = 8 waves = 2 (32 input channels) x 4 (32 output channels); it owns a 64 x 128 slice of dV for ALL nine
-// taps (9 x 2 x 2 accumulator tiles of 16 x 16 = 144 registers per lane, as the bf16 kernel) and walks its share of the units:
+// Block = 512 threads = 8 waves = 4 (16 input channels) x 2 (64 output channels); it owns a 64 x 128 slice of dV for ALL nine
+// taps (9 x 1 x 4 accumulator tiles of 16 x 16 = 144 registers per lane, as the bf16 kernel) and walks its share of the units:
 //   dout   the e5m2 copy its producer wrote (ups_wgrad_desc.dout_f8: the input-gradient epilogue of the layer above / the
 //          bilinear backward kernel; the same copy the layer's input-gradient launch reads) arrives by LDS-DMA into an unpadded
 //          [8 rows][16 px][128 B] tile whose 16-byte slots are XOR-swizzled on the source side (slot ^= ((x >> 1) & 3) | ((r >> 1) & 1) << 2:
@@ -21,7 +21,7 @@
 //          5 bank quads, row pitch 100 quads -- 8 consecutive pixels hit 8 different quads (5 x mod 16) and the row pair two
 //          rows down hits the other 8 (2 x 100 = 8 mod 16) for EVERY tap shift, so the nine windows are immediate offsets from
 //          one lane address and there is no swizzle to undo.
-// Both images are double-buffered; one barrier per unit (36 MFMAs of 32 cycles per wave).  The bias gradient is one more MFMA per
+// Two X images, three dout images (staging pipelined two units ahead); one barrier per unit (36 MFMAs of 32 cycles per wave).  The bias gradient is one more MFMA per
 // output block against an all-ones e4m3 operand (waves of input-channel half 0 of the first input-channel tile).
 // Slabs, split-K and the deterministic reduce are the bf16 kernel's (conv_wgrad3x3.hip / conv_wgrad.hip).
 #include <stdlib.h>
@@ -64,15 +64,16 @@ __device__ __forceinline__ i32x8v frag8(const unsigned char* a) {
 }
 
 // 16 bf16 / fp16 values (two 16-byte words) -> act -> running max -> * scale -> 16 e4m3 bytes
-__device__ __forceinline__ uint4 quant16(uint4 u0, uint4 u1, float sc, float ns, bool act, bool f16in, float& amax) {
+template <bool F16IN, bool ACT>
+__device__ __forceinline__ uint4 quant16(uint4 u0, uint4 u1, float sc, float ns, float& amax) {
     const unsigned w[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
     int d[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         float lo, hi;
-        if (f16in) ups_unpack2<f16>(w[k], lo, hi);
+        if constexpr (F16IN) ups_unpack2<f16>(w[k], lo, hi);
         else { lo = __uint_as_float(w[k] << 16); hi = __uint_as_float(w[k] & 0xffff0000u); }
-        if (act) { lo = ups_vmax(lo, ns * lo); hi = ups_vmax(hi, ns * hi); }
+        if constexpr (ACT) { lo = ups_vmax(lo, ns * lo); hi = ups_vmax(hi, ns * hi); }
         amax = fmaxf(fmaxf(amax, fabsf(lo)), fabsf(hi));
         lo = __builtin_amdgcn_fmed3f(lo * sc, -448.f, 448.f);
         hi = __builtin_amdgcn_fmed3f(hi * sc, -448.f, 448.f);
@@ -82,15 +83,16 @@ __device__ __forceinline__ uint4 quant16(uint4 u0, uint4 u1, float sc, float ns,
     return make_uint4((unsigned)d[0], (unsigned)d[1], (unsigned)d[2], (unsigned)d[3]);
 }
 
+// F16IN: `in` holds fp16 (the mask decoder's forward tensors); ACT: activation-on-load (instances: straight-line quantisation code)
+template <bool F16IN, bool ACT>
 __global__ __launch_bounds__(512) void conv_wgrad3x3_f8_kernel(const Wg8K p, const int cit, const int cot, const int nsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Xbuf = smem;                 // 2 x XB
-    unsigned char* Dbuf = smem + 2 * XB;        // 2 x DB
+    unsigned char* Dbuf = smem + 2 * XB;        // 3 x DB
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float act_ns = ups_slope_eff(p.act_in, p.act_slope);
-    const bool act = p.act_in != UPS_ACT_NONE, f16in = p.in_f16 != 0;
     const float sx = *p.sx, sg = *p.sg;
     // XCD-aware order (as the bf16 kernel): the cit * cot blocks of one K split share an XCD's L2
     const int pairs = cit * cot;
@@ -101,9 +103,11 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_f8_kernel(const Wg8K p, con
         split = (j / pairs) * 8 + (blockIdx.x & 7);
     }
     const int cot_i = pair % cot, cit_i = pair / cot;
-    const int w_ci = wid & 1, w_co = wid >> 1;
+    const int w_ci = wid & 3, w_co = wid >> 2;              // wave tile: 16 input channels x 64 output channels
     const int ci0 = cit_i * CB, co0 = cot_i * BN;
-    const bool do_bias = p.want_bias && cit_i == 0 && w_ci == 0;
+    // bias gradient: the waves of input-channel quarters 0 / 1 of the first input-channel tile take output blocks 0, 1 / 2, 3 of
+    // their 64 channels (two accumulator tiles per wave instead of four: registers)
+    const bool do_bias = p.want_bias && cit_i == 0 && w_ci < 2;
     const int u_begin = split * p.units_per;
     const int u_end = min(p.units_total, u_begin + p.units_per);
 
@@ -139,11 +143,27 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_f8_kernel(const Wg8K p, con
         img = t / p.tiles_y;
         y0 = ty * 16 + half * TH; x0 = tx * TW;
     };
+    // X loads of unit u into registers (plain loads: hipcc keeps their waits and register hazards right).  The dout DMA of the SAME
+    // unit is inline asm (the builtin would put an lgkmcnt(0) in front of every later LDS access) and therefore invisible to
+    // hipcc's wait-count pass -- it is always issued right BEFORE these loads, so the vmcnt wait the compiler places in front of
+    // their first use covers it too (vector-memory operations complete in issue order).
     uint4 rx[NX][2];
-    bool rxok[NX];
-    // X loads of unit u into registers, UNCONDITIONALLY (lanes whose item lies outside the image read the tensor's first bytes and
-    // drop them) and as inline asm: the number of vector-memory operations per wave is then static and invisible to hipcc's own
-    // wait-count pass, so counted s_waitcnt's can leave exactly these loads in flight across the barrier (as conv_wgrad3x3.hip)
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    auto dma_d = [&](int u, int dbuf) __attribute__((always_inline)) {
+        int img, y0, x0;
+        unit_origin(u, img, y0, x0);
+        const unsigned char* db = p.dout8 + (((long long)img * p.h + y0) * p.w + x0) * p.ldo8;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned lds_dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(2 * XB + dbuf * DB + (wid + 8 * k) * 1024));
+#if !defined(UPS_W8_NO_DMA)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(lds_dst), "v"(dd[k]), "s"(db) : "memory", "m0");
+#else
+            asm volatile("" :: "s"(lds_dst), "v"(dd[k]), "s"(db));                                  // (ablation: no dout traffic)
+#endif
+        }
+    };
     auto load_x = [&](int u) __attribute__((always_inline)) {
         int img, y0, x0;
         unit_origin(u, img, y0, x0);
@@ -154,121 +174,113 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_f8_kernel(const Wg8K p, con
         for (int k = 0; k < NX; ++k) {
             unsigned r = xr[k], f = xs[k];
             asm volatile("" : "+v"(r), "+v"(f));
-            const bool ok = ((f >> 16) & edge) == 0u;
-            const unsigned char* src = ok ? xb + (__umul24(r, x_rowb) + x_chb) : (const unsigned char*)p.in;
-            uint4 v0, v1;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v0) : "v"(src) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(v1) : "v"(src) : "memory");
+            uint4 v0 = zero4, v1 = zero4;
+#if !defined(UPS_W8_NO_XLOAD)
+            if (((f >> 16) & edge) == 0u) {
+                const unsigned char* src = xb + (__umul24(r, x_rowb) + x_chb);
+                v0 = *(const uint4*)src; v1 = *(const uint4*)(src + 16);
+            }
+#else
+            v0 = v1 = make_uint4(r, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);                          // (ablation: no X traffic)
+#endif
             rx[k][0] = v0; rx[k][1] = v1;
-            rxok[k] = ok;
-        }
-    };
-    auto dma_d = [&](int u, int buf) __attribute__((always_inline)) {
-        int img, y0, x0;
-        unit_origin(u, img, y0, x0);
-        const unsigned char* db = p.dout8 + (((long long)img * p.h + y0) * p.w + x0) * p.ldo8;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const unsigned lds_dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(2 * XB + buf * DB + (wid + 8 * k) * 1024));
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         :: "s"(lds_dst), "v"(dd[k]), "s"(db) : "memory", "m0");
         }
     };
     float amax = 0.f;
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     auto store_x = [&](int buf, int k) __attribute__((always_inline)) {
         unsigned char* X = Xbuf + buf * XB;
         unsigned f = xs[k];
         asm volatile("" : "+v"(f));
-        const uint4 v = quant16(rxok[k] ? rx[k][0] : zero4, rxok[k] ? rx[k][1] : zero4, sx, act_ns, act, f16in, amax);
+#if defined(UPS_W8_NO_QUANT)
+        const uint4 v = rx[k][0];                                                                     // (ablation: no conversion arithmetic)
+#else
+        const uint4 v = quant16<F16IN, ACT>(rx[k][0], rx[k][1], sx, act_ns, amax);
+#endif
         if (k + 1 < NX || tid + 512 * k < NITEMS) *(uint4*)(X + (f & 0xffffu)) = v;
     };
-    // every staging register is an operand of the wait, so that no use of them is scheduled above it
-#define UPS_WAIT_X8(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(rx[0][0].x), "+v"(rx[0][0].y), "+v"(rx[0][0].z), "+v"(rx[0][0].w), \
-                                    "+v"(rx[0][1].x), "+v"(rx[0][1].y), "+v"(rx[0][1].z), "+v"(rx[0][1].w), "+v"(rx[1][0].x), "+v"(rx[1][0].y), \
-                                    "+v"(rx[1][0].z), "+v"(rx[1][0].w), "+v"(rx[1][1].x), "+v"(rx[1][1].y), "+v"(rx[1][1].z), "+v"(rx[1][1].w) :: "memory")
-    static_assert(NX == 2, "pipelined staging: two items (four loads) per thread and unit");
+    static_assert(NX == 2, "pipelined staging: two items per thread and unit");
 
-    f32x4v acc[9][2][2];
+    f32x4v acc[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[t][a][b] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 4; ++b) acc[t][b] = (f32x4v){0.f, 0.f, 0.f, 0.f};
     f32x4v accb[2] = {(f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}};
     const i32x8v ones = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};   // e4m3 1.0
 
     // ---- fragment lane addresses
     const int q = lane >> 4, pp = (lane & 15) >> 1, piece = lane & 1;
-    const int xa = (2 * q) * XRP + pp * XPP + piece * 8 + w_ci * 32;                 // + tap window + 16 * input block
+    const int xa = (2 * q) * XRP + pp * XPP + piece * 8 + w_ci * 16;                 // + tap window
     const int gd = ((pp >> 1) & 3) | ((q & 1) << 2);
-    int da[2];
+    int da[4];
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) da[jb] = ((2 * q) * TW + pp) * DPP + (((w_co * 2 + jb) ^ gd) << 4) + piece * 8;
+    for (int jb = 0; jb < 4; ++jb) da[jb] = ((2 * q) * TW + pp) * DPP + (((w_co * 4 + jb) ^ gd) << 4) + piece * 8;
 
     // Software-pipelined staging (one block per CU runs its eight waves in lock-step between barriers: a load -> wait -> convert ->
     // ds_write phase at the end of every unit would idle the matrix pipe for its whole length -- and on the block-scaled MFMA a
-    // unit's 36 MFMAs are only ~1.1 k cycles).  Order of the vector-memory operations of a wave: [unit u-1, middle] 4 X loads of unit
-    // u+1, [unit u, start] 2 dout DMA pieces of unit u+1, [unit u, middle] X of u+1 converted and written (counted wait: all but the
-    // 2 DMA pieces), then the 4 X loads of unit u+2; [unit u, end] the DMA pieces must have landed, the 4 loads stay in flight.
+    // unit's 36 MFMAs are only ~1.1 k cycles).  While unit u is multiplied: [taps 3, 5] the X items of unit u+1 (requested during
+    // unit u-1) are converted and written to the other X image, then the dout DMA and the X loads of unit u+2 are issued -- a
+    // whole unit of latency cover for both.  dout images: THREE (the DMA of unit u+2 lands while unit u+1's image is waiting and
+    // unit u's is being read); X images: two.
     if (u_begin < u_end) {
-        load_x(u_begin); dma_d(u_begin, 0);
-        UPS_WAIT_X8(0);
+        dma_d(u_begin, 0); load_x(u_begin);
         store_x(0, 0); store_x(0, 1);
-        if (u_begin + 1 < u_end) load_x(u_begin + 1);
+        if (u_begin + 1 < u_end) { dma_d(u_begin + 1, 1); load_x(u_begin + 1); }
     }
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    int dcur = 0;                           // dout image of the running unit (u - u_begin) % 3
     for (int u = u_begin; u < u_end; ++u) {
         const int buf = (u - u_begin) & 1;
-        if (u + 1 < u_end) dma_d(u + 1, buf ^ 1);
+        const int dnext2 = dcur == 0 ? 2 : dcur - 1;      // (dcur + 2) % 3
         const unsigned char* X = Xbuf + buf * XB + xa;
-        const unsigned char* D = Dbuf + buf * DB;
-        i32x8v fb[2];
+        const unsigned char* D = Dbuf + dcur * DB;
+        // a wave's tile is 16 x 64 (one X fragment per tap against four dout fragments that stay resident for the unit): 36 + 16
+        // transposing reads per 36 MFMAs (the 32 x 32 form read 72 + 8: with the matrix work halved by the fp8 MFMA the LDS reads
+        // and their issue slots were what the loop was short of -- the same launch without MFMAs took 1.0 of its 1.4 ms)
+        i32x8v fb[4];
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) fb[jb] = frag8<TW * DPP, 8 * DPP>(D + da[jb]);
-        i32x8v fa[2][2];
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) fa[0][ib] = frag8<XRP, 8 * XPP>(X + ib * 16);            // tap 0: window (0, 0)
+        for (int jb = 0; jb < 4; ++jb) fb[jb] = frag8<TW * DPP, 8 * DPP>(D + da[jb]);
+        i32x8v fa[2];
+        fa[0] = frag8<XRP, 8 * XPP>(X);                                                          // tap 0: window (0, 0)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (t + 1 < 9) {
                 const int off = ((t + 1) / 3) * XRP + ((t + 1) % 3) * XPP;                        // taps r-major: dy = t / 3 - 1, dx = t % 3 - 1
-#pragma unroll
-                for (int ib = 0; ib < 2; ++ib) fa[(t + 1) & 1][ib] = frag8<XRP, 8 * XPP>(X + off + ib * 16);
+                fa[(t + 1) & 1] = frag8<XRP, 8 * XPP>(X + off);
             }
 #pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
+            for (int jb = 0; jb < 4; ++jb)
+#if defined(UPS_W8_NO_MFMA)
+                acc[t][jb][0] += __int_as_float(fa[t & 1][jb] ^ fb[jb][t & 7]);                           // (ablation: no matrix work)
+#else
+                acc[t][jb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[t & 1], fb[jb], acc[t][jb], 0, 1, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#endif
 #pragma unroll
-                for (int jb = 0; jb < 2; ++jb)
-                    acc[t][ib][jb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[t & 1][ib], fb[jb], acc[t][ib][jb], 0, 1, 0, 0x7f7f7f7f, 0,
-                                                                                  0x7f7f7f7f);
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb) asm volatile("" : "+v"(acc[t][ib][jb]));
+            for (int jb = 0; jb < 4; ++jb) asm volatile("" : "+v"(acc[t][jb]));
             __builtin_amdgcn_sched_barrier(0);
             if (t == 3 && u + 1 < u_end) {
-                UPS_WAIT_X8(2);                     // the X loads of unit u+1 (older than this unit's two DMA pieces) have landed
-                store_x(buf ^ 1, 0);
+                store_x(buf ^ 1, 0);                // (the compiler's vmcnt wait in front of this also covers the DMA of unit u+1)
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (t == 5 && u + 1 < u_end) {
                 store_x(buf ^ 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (u + 2 < u_end) load_x(u + 2);
+                if (u + 2 < u_end) { dma_d(u + 2, dnext2); load_x(u + 2); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (do_bias) {
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
-                accb[jb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, fb[jb], accb[jb], 0, 1, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            if (w_ci == 0) {
+                accb[0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, fb[0], accb[0], 0, 1, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                accb[1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, fb[1], accb[1], 0, 1, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            } else {
+                accb[0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, fb[2], accb[0], 0, 1, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                accb[1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, fb[3], accb[1], 0, 1, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
         }
-        // the dout DMA of unit u+1 (older than the four X loads of unit u+2) must have landed; those loads stay in flight
-        if (u + 2 < u_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dcur = dcur == 2 ? 0 : dcur + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -286,21 +298,19 @@ __global__ __launch_bounds__(512) void conv_wgrad3x3_f8_kernel(const Wg8K p, con
     for (int t = 0; t < 9; ++t) {
         const int tw = g_w8(p.tap_wi, t);
 #pragma unroll
-        for (int ib = 0; ib < 2; ++ib)
+        for (int jb = 0; jb < 4; ++jb) {
+            const int col = co0 + w_co * 64 + jb * 16 + (lane & 15);
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb) {
-                const int col = co0 + w_co * 32 + jb * 16 + (lane & 15);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = ci0 + w_ci * 32 + ib * 16 + 4 * (lane >> 4) + e;
-                    if (row < p.ci_log && col < p.co) slab[((long long)tw * p.cin_v + row) * p.co + col] = acc[t][ib][jb][e] * inv;
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int row = ci0 + w_ci * 16 + 4 * (lane >> 4) + e;
+                if (row < p.ci_log && col < p.co) slab[((long long)tw * p.cin_v + row) * p.co + col] = acc[t][jb][e] * inv;
             }
+        }
     }
     if (do_bias && (lane >> 4) == 0) {
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
-            const int col = co0 + w_co * 32 + jb * 16 + lane;
+            const int col = co0 + w_co * 64 + (2 * w_ci + jb) * 16 + lane;
             if (col < p.co) slab[(long long)9 * p.cin_v * p.co + col] = accb[jb][0] * (1.f / sg);
         }
     }
@@ -324,7 +334,7 @@ int ups_wgrad3x3_f8_plan(const ups_wgrad_desc* d, int* splitk, int* slabs) {
     if (!eligible8(d)) return 1;
     const int pairs = (d->ci / CB) * (d->co / BN);
     const int units = d->n * (d->hi / 16) * (d->wi / 16) * 2;
-    int sk = ups_cdiv(256, pairs);                  // one block per CU (67 KB of LDS, 2 waves per SIMD on 144 accumulator registers)
+    int sk = ups_cdiv(256, pairs);                  // one block per CU (81 KB of LDS, 2 waves per SIMD on 144 accumulator registers)
     if (sk > units / 4) sk = units / 4 > 0 ? units / 4 : 1;
     if (sk > 256) sk = 256;
     if (sk >= 8) sk &= ~7;
@@ -347,13 +357,20 @@ int ups_wgrad3x3_f8_run(const ups_wgrad_desc* d, hipStream_t s) {
     k.tap_wi = 0;
     for (int t = 0; t < 9; ++t) k.tap_wi |= (unsigned long long)d->tap_w[t] << (4 * t);
     const int cit = d->ci / CB, cot = d->co / BN;
-    constexpr size_t shmem = 2 * (size_t)(XB + DB);
-    static UpsPerDevice attr_set;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_wgrad3x3_f8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
-            return UPS_E_LAUNCH;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(conv_wgrad3x3_f8_kernel, dim3(cit * cot * d->splitk), dim3(512), shmem, s, k, cit, cot, d->splitk);
+    constexpr size_t shmem = 2 * (size_t)XB + 3 * (size_t)DB;
+#define UPS_W8_LAUNCH(F16V, ACTV)                                                                                                   \
+    do {                                                                                                                              \
+        static UpsPerDevice attr_set;                                                                                                 \
+        if (!attr_set) {                                                                                                              \
+            if (hipFuncSetAttribute((const void*)conv_wgrad3x3_f8_kernel<F16V, ACTV>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                    (int)shmem) != hipSuccess) return UPS_E_LAUNCH;                                                   \
+            attr_set = true;                                                                                                          \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((conv_wgrad3x3_f8_kernel<F16V, ACTV>), dim3(cit * cot * d->splitk), dim3(512), shmem, s, k, cit, cot, d->splitk); \
+    } while (0)
+    const bool act = d->act_in != UPS_ACT_NONE;
+    if (d->in_f16) { if (act) UPS_W8_LAUNCH(true, true); else UPS_W8_LAUNCH(true, false); }
+    else { if (act) UPS_W8_LAUNCH(false, true); else UPS_W8_LAUNCH(false, false); }
+#undef UPS_W8_LAUNCH
     return UPS_OK;
 }

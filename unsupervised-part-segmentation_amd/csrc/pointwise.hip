@@ -184,9 +184,13 @@ __global__ void act_mean_bwd_kernel(const T* __restrict__ x, const T* __restrict
 }
 
 // ------------------------------------------------------------------ 2x2 max pool
-template <typename T>
-__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c) {
+// EMIT (bf16): the pooled tensor also leaves as the e4m3 copy its consuming convolution stages (ups_conv_desc.in_f8; round 5: the
+// first convolution of every block of the perceptual trunk reads a pooled map, and the chain of copies through a block starts here)
+template <typename T, bool EMIT = false>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, F8Emit q8 = F8Emit()) {
     constexpr int E = V16<T>::N;
+    float amax = 0.f;
+    const float sc = (EMIT && q8.out) ? *q8.scale : 1.f, ns = EMIT ? ups_slope_eff(q8.act, q8.slope) : 0.f;
     const int cc = c / E, ho = h / 2, wo = w / 2;
     const long long total = (long long)n * ho * wo * cc;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -208,8 +212,9 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
         V16<T>::ld(base + (long long)w * c + c, q);
 #pragma unroll
         for (int e = 0; e < E; ++e) a[e] = fmaxf(a[e], q[e]);
-        V16<T>::st(y + idx * E, a);
+        st_emit<T, EMIT>(y + idx * E, a, q8, sc, ns, idx * E, amax);
     }
+    if constexpr (EMIT) f8_emit_finish(q8, amax);
 }
 template <typename T>
 __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx, int n, int h,
@@ -597,6 +602,18 @@ extern "C" int ups_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t n
     hipStream_t s = (hipStream_t)stream;
     if (dtype == UPS_F32) hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)x, (float*)y, n, h, w, c);
     else hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w, c);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+// bf16 2x2 max pool that also hands its output to an fp8 convolution: max |act(y)| into amax[64]; with y_f8 != NULL the e4m3 bytes
+// of act(y) * *scale next to y (as ups_bilinear2x_fwd_f8)
+extern "C" int ups_maxpool2_fwd_f8(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void* y_f8, const float* scale,
+                                   float* amax, int32_t act, float slope, void* stream) {
+    UPS_CHECK_ARG(x && y && amax && c % 8 == 0 && h % 2 == 0 && w % 2 == 0 && (!y_f8 || scale) && slope >= 0.f && slope <= 1.f);
+    const long long work = (long long)n * (h / 2) * (w / 2) * (c / 8);
+    F8Emit q; q.out = (unsigned char*)y_f8; q.scale = scale; q.amax = amax; q.act = act; q.e5m2 = 0; q.slope = slope;
+    hipLaunchKernelGGL((maxpool2_fwd_kernel<bf16, true>), dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y,
+                       n, h, w, c, q);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

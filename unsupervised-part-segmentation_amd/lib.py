@@ -101,6 +101,7 @@ _SIGS = {
     "ups_act_mean_fwd": ([_P, _P, _I, _I, _I, _I, _I, _F, _P], C.c_int),
     "ups_act_mean_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _F, _P], C.c_int),
     "ups_maxpool2_fwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
+    "ups_maxpool2_fwd_f8": ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P], C.c_int),
     "ups_maxpool2_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "ups_copy_channels": ([_P, _I, _P, _I, _I, _L, _I, _P], C.c_int),
     "ups_add_channels": ([_P, _I, _P, _I, _I, _L, _I, _P], C.c_int),

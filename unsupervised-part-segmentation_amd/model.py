@@ -240,7 +240,11 @@ class Trainer(object):
             raise NotImplementedError("the 'pretty' image discriminator (model.py:190-212) is not used by the shipped configs")
         vw = config.get("vgg_widths", N.VGG_WIDTHS)
         self.vgg = N.VggTrunk(self.device, seed=config.get("vgg_seed", 7), widths=tuple(vw),
-                              post_storage=model.nets.post_storage)
+                              post_storage=model.nets.post_storage,
+                              # (measured, round 5: the trunk on fp8 copies -- 20 more launches per step on e4m3 operands -- runs the
+                              # step 1.4 % SLOWER: the pools' and the convolutions' copy emission costs more than blocks 2-4 gain at
+                              # 64 images; off by default, `vgg_fp8: True` / UPS_VGG_FP8=1 for measurements)
+                              fp8=bool(config.get("vgg_fp8", os.environ.get("UPS_VGG_FP8", "0") == "1")))
         # `vgg_weights`: npz / torch file with the Keras VGG19 ImageNet kernels in HWIO (edflow downloads them at run time;
         # they are not obtainable offline).  Without it the perceptual loss runs on seeded He-normal stand-ins: fine for
         # timing and parity, NOT for training a model that should match the reference's part quality -- say so loudly.

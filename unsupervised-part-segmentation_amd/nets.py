@@ -392,9 +392,11 @@ class VggTrunk(object):
     the ImageNet weights are not obtainable offline, so He-normal stand-ins are generated per name --
     ``load`` accepts real Keras kernels in HWIO)."""
 
-    def __init__(self, device, seed=7, widths=VGG_WIDTHS, depths=VGG_DEPTHS, post_storage=True):
+    def __init__(self, device, seed=7, widths=VGG_WIDTHS, depths=VGG_DEPTHS, post_storage=True, fp8=True):
         self.depths = depths
         self.layers = []
+        self.fp8 = bool(fp8)            # precision fp8: blocks 2-4 on e4m3 operands handed from producer to consumer
+        self.f8_sites = {}              # (block, input shape) -> scale slot state of that block's max-pool copy
         cin = 3
         for bi, (wd, dp) in enumerate(zip(widths, depths)):
             blk = []
@@ -431,11 +433,26 @@ class VggTrunk(object):
         x = ops.VggPreFn.apply(x_img, act_dtype)
         feats = [(x, 3, L.ACT_NONE)]
         h = x
+        # fp8 mode (round 5): the 2x2 max-pool in front of a block writes the e4m3 copy of its output, every convolution of the block
+        # that feeds another convolution writes one of its own, so blocks 2-4 run on fp8 operands (block 1 is thin, block 5's 8x8
+        # maps are packed four to a tile: both stay bf16).  VGG_FP8 = False: the trunk stays bf16 (A/B runs; `vgg_fp8` config key)
+        f8 = ops.Fp8.enabled and ops.Fp8.PRODUCER and self.fp8
+        h8 = None
         for bi, blk in enumerate(self.layers):
             if bi > 0:
-                h = ops.MaxPoolFn.apply(h)     # max-pool commutes with ReLU: pool the pre-activations
+                if f8:
+                    site = self.f8_sites.setdefault((bi, tuple(h.shape)), {})
+                    ops.Fp8.last_out = None
+                    h = ops.MaxPoolFn.apply(h, site, L.ACT_RELU)     # max-pool commutes with ReLU: pool the pre-activations
+                    h8, ops.Fp8.last_out = ops.Fp8.last_out, None
+                else:
+                    h = ops.MaxPoolFn.apply(h)     # max-pool commutes with ReLU: pool the pre-activations
             for ci, lay in enumerate(blk):
+                if f8:
+                    ops.Fp8.next_in, ops.Fp8.next_out_act, ops.Fp8.last_out = h8, (L.ACT_RELU if ci + 1 < len(blk) else None), None
                 h = ops.ConvFn.apply(h, lay.V, lay.b, None, lay, 0, False, None, None, None, None, None)
+                if f8:
+                    h8, ops.Fp8.last_out = ops.Fp8.last_out, None
                 if ci == 1:
                     feats.append((h, lay.co, L.ACT_RELU))
         return feats

@@ -1132,12 +1132,30 @@ class ActMeanFn(torch.autograd.Function):
 
 
 class MaxPoolFn(torch.autograd.Function):
+    """site (fp8 mode): per-call-site state when the pooled tensor feeds an fp8 convolution -- the forward then also writes the
+    e4m3 copy of act(y) (ops.Fp8 hand-off, as BilinearFn); `act` = the activation-on-load of that consumer."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, site=None, act=0):
         x = x.contiguous()
         n, h, w, c = x.shape
         y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
-        L.call("ups_maxpool2_fwd", L.ptr(x), L.ptr(y), L.dt(x), n, h, w, c, L.stream())
+        f8 = (site is not None and Fp8.enabled and Fp8.PRODUCER and x.dtype == torch.bfloat16 and c % 64 == 0
+              and (h // 2) % 16 == 0 and (w // 2) % 16 == 0)
+        if f8:
+            so = site.get("fwd")
+            if so is None:
+                so = site["fwd"] = {"slot": Fp8.slot(x.device), "born": Fp8.steps}
+            f8 = Fp8.wanted(so)
+        if f8:
+            t8 = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if Fp8.steps > so["born"] else None
+            if t8 is not None:
+                so["emitted"] = so.get("emitted", 0) + 1
+            L.call("ups_maxpool2_fwd_f8", L.ptr(x), L.ptr(y), n, h, w, c, L.ptr(t8) if t8 is not None else None,
+                   L.ptr(Fp8.scale[so["slot"]:]), L.ptr(Fp8.amax[so["slot"]]), act, 0.2, L.stream())
+            Fp8.last_out = {"t": t8, "act": act, "slot": so["slot"], "site": so} if t8 is not None else None
+        else:
+            L.call("ups_maxpool2_fwd", L.ptr(x), L.ptr(y), L.dt(x), n, h, w, c, L.stream())
         ctx.save_for_backward(x)
         return y
 
@@ -1148,7 +1166,7 @@ class MaxPoolFn(torch.autograd.Function):
         g = g.contiguous()
         gx = torch.empty_like(x)
         L.call("ups_maxpool2_bwd", L.ptr(x), L.ptr(g), L.ptr(gx), L.dt(x), n, h, w, c, L.stream())
-        return gx
+        return gx, None, None
 
 
 class VggPreFn(torch.autograd.Function):
