@@ -35,7 +35,9 @@ extern "C" {
  * input-gradient call of such a layer is a plain UPS_BF16 call (`dact` only has its sign read, which is the same bit in both
  * 16-bit formats), its weight-gradient call sets ups_wgrad_desc.in_f16. */
 enum { UPS_F32 = 0, UPS_BF16 = 1, UPS_F16 = 2 };
-enum { UPS_ACT_NONE = 0, UPS_ACT_LRELU = 1, UPS_ACT_RELU = 2 };
+/* UPS_ACT_ELU (tf.nn.elu, N:757-758; no shipped yaml uses it): accepted by the pointwise entry points only (ups_elu_fwd / _bwd,
+ * ups_act_mean_*); the convolution descriptors take NONE / LRELU / RELU -- a scope with `activation: elu` materialises act(x). */
+enum { UPS_ACT_NONE = 0, UPS_ACT_LRELU = 1, UPS_ACT_RELU = 2, UPS_ACT_ELU = 3 };
 enum { UPS_OK = 0, UPS_E_ARG = -1, UPS_E_UNSUPPORTED = -2, UPS_E_LAUNCH = -3 };
 
 int ups_abi_version(void);
@@ -258,6 +260,10 @@ int ups_bilinear2x_fwd_f8(const void* x, void* y, int32_t n, int32_t h, int32_t 
 int ups_bilinear2x_bwd_f8(const void* gy, void* gx, int32_t n, int32_t h, int32_t w, int32_t c, void* gx_f8, const float* scale,
                           float* amax, int32_t e5m2, void* stream);
 /* activate + global spatial mean (M:50-51): y[n][c] = mean_hw act(x) */
+/* y = elu(x) = x > 0 ? x : exp(x) - 1 (nn.py:747-758 `activate(x, "elu")`), gx = gy * (x > 0 ? 1 : exp(x)); n elements of dtype
+ * UPS_F32 / UPS_BF16 / UPS_F16 (n a multiple of 8). */
+int ups_elu_fwd(const void* x, void* y, int32_t dtype, int64_t n, void* stream);
+int ups_elu_bwd(const void* x, const void* gy, void* gx, int32_t dtype, int64_t n, void* stream);
 int ups_act_mean_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t hw, int32_t c, int32_t act, float slope, void* stream);
 int ups_act_mean_bwd(const void* x, const void* gy, void* gx, int32_t dtype, int32_t n, int32_t hw, int32_t c, int32_t act, float slope, void* stream);
 /* 2x2/2 max pool on pre-activations (Keras VGG19 block*_pool); bwd routes to the first maximal element */

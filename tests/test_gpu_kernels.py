@@ -98,6 +98,14 @@ CONV_CASES = [
     (2, 64, 32, 64, 128, 3, 2, False, "relu", False),          # non-square, two N-tiles    # the critics' dense layers (128 rows): split-K forward / input gradient, single-split weight gradient written in place
     (128, 1, 1, 512, 512, 1, 1, False, "leaky_relu", True),
     (128, 1, 1, 64, 512, 1, 1, False, None, False),
+    # ragged patch tiles (round 5): maps that are not a multiple of the 16-pixel tile -- the 56 / 28 / 14-pixel levels of the
+    # perceptual trunk behind the 224 x 224 crop (`perceptual_input: resize256_crop224`) -- on the patch kernel with the pixels of
+    # the overhanging tiles skipped in the epilogue (forward, input gradient with act'; (1, 40, 40, ...) above adds CoordConv + residual)
+    (16, 28, 28, 256, 256, 3, 1, False, "relu", False),        # VGG block 4 at 28 x 28: 2 x 2 tiles, 12 of 16 pixels valid in the last
+    (16, 14, 14, 512, 512, 3, 1, False, "relu", False),        # VGG block 5 at 14 x 14: one tile per image, kchunks 16
+    (8, 56, 56, 128, 256, 3, 1, False, "relu", False),         # VGG block 3 at 56 x 56: 4 x 4 tiles, two N-tiles
+    (3, 24, 40, 64, 136, 3, 1, True, "leaky_relu", False),     # non-square, both edges ragged, CoordConv, ragged second N-tile
+    (40, 56, 56, 64, 64, 3, 1, False, "leaky_relu", True),     # >= 512 blocks: the two-blocks-per-CU instance, residual from the patch
 ]
 
 

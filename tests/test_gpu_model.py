@@ -32,6 +32,10 @@ def _setup(precision, dev, variant="cub", size="tiny"):
         cfg = configs.tiny_config(variant=variant)
         cfg["dv"]["upsample_config"] = ["nearest_neighbor", "linear"]
         cfg["final_hour"]["upsample_method"] = "nearest_neighbor"
+    elif size == "tiny_elu":        # `activation: elu` (nn.py:747-758) in every sub-network: materialised activation (nets.Scope.conv2d)
+        cfg = configs.tiny_config(variant=variant)
+        for key in ("encoder0", "encoder1", "dv", "final_hour", "discriminator"):
+            cfg[key] = dict(cfg[key], activation="elu")
     elif size == "tiny25":        # 25 parts (the shipped yamls' part count), odd batch: ragged lane groups / fallback conv paths
         cfg = configs.tiny_config(n_parts=25, batch_size=3, variant=variant)
     else:
@@ -56,7 +60,7 @@ def _setup(precision, dev, variant="cub", size="tiny"):
 
 CASES = [("cub", "tiny"), ("pennaction", "tiny"), ("deepfashion", "tiny"), ("cub", "small"), ("deepfashion", "small"),
          ("cub", "tiny25"), ("deepfashion", "tiny25"), ("cub", "tiny_tps"), ("cub", "tiny_det"), ("cub", "tiny_subpixel"),
-         ("cub", "tiny_nearest")]
+         ("cub", "tiny_nearest"), ("cub", "tiny_elu")]
 
 
 @pytest.mark.parametrize("variant,size", CASES)

@@ -109,6 +109,7 @@ template <> __device__ __forceinline__ void ups_unpack2<f16>(unsigned w, float& 
 __device__ inline float ups_act(float x, int act, float slope) {
     if (act == UPS_ACT_LRELU) return x > 0.f ? x : slope * x;
     if (act == UPS_ACT_RELU) return x > 0.f ? x : 0.f;
+    if (act == UPS_ACT_ELU) return x > 0.f ? x : expm1f(x);
     return x;
 }
 // branch-free activation for the staging paths: leaky-relu(slope) and relu (slope_eff = 0) share one formula,
@@ -179,6 +180,7 @@ __device__ __forceinline__ uint4 ups_act_chunk(uint4 u, float s, float*) {
 __device__ inline float ups_dact(float x, int act, float slope) {
     if (act == UPS_ACT_LRELU) return x > 0.f ? 1.f : slope;
     if (act == UPS_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    if (act == UPS_ACT_ELU) return x > 0.f ? 1.f : expf(x);
     return 1.f;
 }
 

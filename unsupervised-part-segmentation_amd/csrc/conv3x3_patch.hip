@@ -1008,6 +1008,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         }
         return gpix(q) * (unsigned)ld + (unsigned)chn;
     };
+    // ragged images (round 5: height / width not a multiple of the 16-pixel tile -- the 56 / 28 / 14-pixel maps of the perceptual
+    // trunk behind a 224 x 224 crop): the tiles of the last tile row / column hang over the image.  The staging side needs nothing
+    // (patch pixels outside the image are zero, as the halo of every border tile is); the epilogue skips their pixels.
+    const bool ragged = SUB == TS && ((p.h & (TS - 1)) | (p.w & (TS - 1))) != 0;
+    auto pix_ok = [&](int q) __attribute__((always_inline)) -> bool {
+        return !ragged || (ty0 + (q >> 4) < p.h && tx0 + (q & 15) < p.w);
+    };
     auto ycoord = [&](int ty) -> int { return SUB == TS ? ty0 + ty : ty % SUB; };
     auto xcoord = [&](int tx) -> int { return SUB == TS ? tx0 + tx : tx % SUB; };
 
@@ -1025,7 +1032,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #pragma unroll
                 for (int i = 0; i < NIT; ++i) {
                     const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
-                    if (ch * 8 < c_lim) {
+                    if (ch * 8 < c_lim && pix_ok(px)) {
                         if (res) *(uint4*)(R0 + px * ERS + ch * 16) = *(const uint4*)(res + gaddr(px, nt * BN + ch * 8, p.ldr));
                         if (dact) {
                             const uint4 dv = *(const uint4*)(dact + gaddr(px, nt * BN + ch * 8, p.ldd));
@@ -1146,7 +1153,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             if (p.mask_grad) {
                 // input gradient of the part-masked convolution, reduced to the hard mask: g_hard[b][y][x][part] =
                 // sum_c gx[c] * view[b][y][x][c] with gx rounded to the activation dtype first (as the tensor it replaces was)
-                if (SUB == TS && tid < 256 && __is_same(T, bf16)) {
+                if (SUB == TS && tid < 256 && __is_same(T, bf16) && pix_ok(tid)) {
                     const long long pixb = (long long)img * p.h * p.w + (long long)(ty0 + (tid >> 4)) * p.w + tx0 + (tid & 15);
                     const bf16* gv = (const bf16*)(R0 + tid * ERS);
                     const float* vv = p.mask_view + pixb * p.co;
@@ -1159,7 +1166,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
-                if (ch * 8 < c_lim) {
+                if (ch * 8 < c_lim && pix_ok(px)) {
                     const uint4 u = *(const uint4*)(R0 + px * ERS + ch * 16);
                     const unsigned ga = gaddr(px, nt * BN + ch * 8, p.ldo);
                     *(uint4*)(outT + ga) = u;
@@ -1210,6 +1217,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
     auto emit = [&](float a, int tyq, int txq, int col, float bias) __attribute__((always_inline)) {
         const bool cvalid = col < p.co;
         const int y = ycoord(tyq), x = xcoord(txq);
+        if (!pix_ok(tyq * 16 + txq)) return;
         const unsigned pix = gpix(tyq * 16 + txq);
         float v = 0.f;
         if (cvalid) {
@@ -1270,7 +1278,7 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     // a launch that asks for one must never land on another instance and leave the copy unwritten
     constexpr bool emits = __is_same(T, bf16) && (F8 != 0 || !(OCC == 2 && BN == 128) || (TAPS == 0 && !DMAP));
     if ((k.out_f8 || k.out_f8_amax) && !emits) return UPS_E_UNSUPPORTED;
-    const int tiles_x = SUB == TS ? k.w / TS : 1, tiles_y = SUB == TS ? k.h / TS : 1;
+    const int tiles_x = SUB == TS ? (k.w + TS - 1) / TS : 1, tiles_y = SUB == TS ? (k.h + TS - 1) / TS : 1;
     const int ntn = ups_cdiv(k.co_fill, BN);
     const int kchunks = ups_cdiv(k.ci, F8 ? 64 : 4 * EPC);
     const int nblocks = (k.n / (G * G)) * tiles_x * tiles_y * ntn;
@@ -1345,7 +1353,7 @@ int launch_t(const PatchK& k, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
       if constexpr (__is_same(T, bf16)) {
         if (k.f8_deq && k.in_f8) {      // pre-quantised input: bf16-sized staging, two blocks per CU on large grids
-            const int tiles8 = k.n * (k.w / TS) * (k.h / TS);
+            const int tiles8 = k.n * ((k.w + TS - 1) / TS) * ((k.h + TS - 1) / TS);
             const bool big128 = patch_occ() == 2 && tiles8 * ups_cdiv(k.co_fill, 128) >= 512;
             const bool big64 = patch_occ() == 2 && tiles8 * ups_cdiv(k.co_fill, 64) >= 512;
             // whole 128-channel double chunks on a grid of two blocks per CU: the block-scaled K = 128 MFMA (UPS_F8_SCALED=0: off)
@@ -1375,7 +1383,7 @@ int launch_t(const PatchK& k, hipStream_t s) {
       }
         // two blocks per CU once the grid has at least two blocks for every CU (smaller grids spread over the chip instead);
         // single-chunk layers (ci <= 32, e.g. the dgrad of the P-channel logit conv) use 64-wide tiles and one patch buffer
-        const int tiles = k.n * (k.w / TS) * (k.h / TS);
+        const int tiles = k.n * ((k.w + TS - 1) / TS) * ((k.h + TS - 1) / TS);
         if (k.co_fill > 64 && k.ci > 32) {
             if (patch_occ() == 2 && !k.out_f8_amax && tiles * ups_cdiv(k.co_fill, 128) >= 512) return launch_v<T, 128, 2>(k, s);
             // a grid of one 128-wide block per CU: 64-wide tiles put two blocks on every CU instead (4 waves per SIMD)
@@ -1443,7 +1451,14 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     {
         static int small_on = -1;
         if (small_on < 0) { const char* e = getenv("UPS_NO_SMALL_PATCH"); small_on = (e && e[0] == '1') ? 0 : 1; }
-        if ((d->hi % TS || d->wi % TS) && !(small && small_on)) return 1;
+        // ragged tiles (UPS_PATCH_RAGGED=0: off): plain forward / input-gradient launches only -- no depth-to-space output, part
+        // masks, fp8 operands or copies (their store loops and scale maxima assume whole tiles), at least one whole tile row's worth
+        // of pixels so that the launch is not mostly padding
+        static int ragged_on = -1;
+        if (ragged_on < 0) { const char* e = getenv("UPS_PATCH_RAGGED"); ragged_on = (e && e[0] == '0') ? 0 : 1; }
+        const bool ragged_ok = ragged_on && d->hi >= 12 && d->wi >= 12 && !d->d2s && !d->mask_bits && !d->mask_grad && !d->f8_deq &&
+                               !d->in_f8 && !d->out_f8 && !d->out_f8_amax;
+        if ((d->hi % TS || d->wi % TS) && !(small && small_on) && !ragged_ok) return 1;
     }
     bool seen[9] = {false, false, false, false, false, false, false, false, false};
     for (int t = 0; t < 9; ++t) {

@@ -183,6 +183,25 @@ __global__ void act_mean_bwd_kernel(const T* __restrict__ x, const T* __restrict
     st_from_float<T>(gx + idx, g * ups_dact(ld_as_float<T>(x + idx), act, slope));
 }
 
+// ------------------------------------------------------------------ elu (nn.py:747-758): the one activation that is materialised
+template <typename T>
+__global__ void elu_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ out, long long chunks) {
+    constexpr int E = V16<T>::N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
+        float a[E], g[E];
+        V16<T>::ld(x + i * E, a);
+        if (gy) {
+            V16<T>::ld(gy + i * E, g);
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] = g[e] * ups_dact(a[e], UPS_ACT_ELU, 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] = ups_act(a[e], UPS_ACT_ELU, 0.f);
+        }
+        V16<T>::st(out + i * E, a);
+    }
+}
+
 // ------------------------------------------------------------------ 2x2 max pool
 // EMIT (bf16): the pooled tensor also leaves as the e4m3 copy its consuming convolution stages (ups_conv_desc.in_f8; round 5: the
 // first convolution of every block of the perceptual trunk reads a pooled map, and the chain of copies through a block starts here)
@@ -595,6 +614,21 @@ extern "C" int ups_act_mean_bwd(const void* x, const void* gy, void* gx, int32_t
     else hipLaunchKernelGGL(act_mean_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, (const bf16*)gy, (bf16*)gx, n, hw, c, act, slope);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
+}
+static int elu_launch(const void* x, const void* gy, void* out, int32_t dtype, int64_t n, void* stream) {
+    UPS_CHECK_ARG(x && out && n > 0 && n % 8 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(elu_kernel<float>, dim3(grid_for(n / 4)), dim3(256), 0, s, (const float*)x, (const float*)gy, (float*)out, (long long)(n / 4));
+    else if (dtype == UPS_F16) hipLaunchKernelGGL(elu_kernel<f16>, dim3(grid_for(n / 8)), dim3(256), 0, s, (const f16*)x, (const f16*)gy, (f16*)out, (long long)(n / 8));
+    else if (dtype == UPS_BF16) hipLaunchKernelGGL(elu_kernel<bf16>, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16*)x, (const bf16*)gy, (bf16*)out, (long long)(n / 8));
+    else { ups_set_error("bad dtype %d", (int)dtype); return UPS_E_ARG; }
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_elu_fwd(const void* x, void* y, int32_t dtype, int64_t n, void* stream) { return elu_launch(x, nullptr, y, dtype, n, stream); }
+extern "C" int ups_elu_bwd(const void* x, const void* gy, void* gx, int32_t dtype, int64_t n, void* stream) {
+    UPS_CHECK_ARG(gy != nullptr);
+    return elu_launch(x, gy, gx, dtype, n, stream);
 }
 extern "C" int ups_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
     UPS_CHECK_ARG(x && y && c % 8 == 0 && h % 2 == 0 && w % 2 == 0);

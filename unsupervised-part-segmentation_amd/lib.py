@@ -14,8 +14,8 @@ LIB_PATH = os.environ.get("UPS_LIB", os.path.join(_HERE, "csrc", "libupsparts_hi
 
 ABI_VERSION = 3               # include/upsparts_hip.h UPS_ABI_VERSION
 F32, BF16, F16 = 0, 1, 2      # F16: forward tensors of precision-critical scopes (held in torch.bfloat16 containers, see ops.py)
-ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
-ACT = {None: ACT_NONE, "leaky_relu": ACT_LRELU, "relu": ACT_RELU}
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_ELU = 0, 1, 2, 3
+ACT = {None: ACT_NONE, "leaky_relu": ACT_LRELU, "relu": ACT_RELU, "elu": ACT_ELU}
 
 
 class UpsError(RuntimeError):
@@ -100,6 +100,8 @@ _SIGS = {
     "ups_bilinear2x_bwd_f8": ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "ups_act_mean_fwd": ([_P, _P, _I, _I, _I, _I, _I, _F, _P], C.c_int),
     "ups_act_mean_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _F, _P], C.c_int),
+    "ups_elu_fwd": ([_P, _P, _I, C.c_int64, _P], C.c_int),
+    "ups_elu_bwd": ([_P, _P, _P, _I, C.c_int64, _P], C.c_int),
     "ups_maxpool2_fwd": ([_P, _P, _I, _I, _I, _I, _I, _P], C.c_int),
     "ups_maxpool2_fwd_f8": ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P], C.c_int),
     "ups_maxpool2_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], C.c_int),

@@ -147,6 +147,12 @@ class Scope(object):
         scope (the builders below say so); the consumer then runs with the activation already applied."""
         post = bool(post) and self.post_ok() and not out_f32
         in_post = bool(x.post)
+        if act_in == L.ACT_ELU:         # materialised: elu is not of the max(x, slope * x) family the kernels fuse into their loads
+            if res_self:                # x + conv(elu(x)): the residual is the UN-activated input
+                res, res_self = x, False
+            if x.t is not None:
+                x = Act(ops.EluFn.apply(x.t, self.fmt), x.n, x.h, x.w, x.c, mask=None, fmt=x.fmt)
+            act_in = L.ACT_NONE
         if in_post and act_in != self.act:
             raise L.UpsError("{}: a post-activation tensor feeds a convolution that wants {}".format(self.prefix, act_in))
         lay = self._layer(x.c, cout, k, stride, act_in, in_post, self.act if post else L.ACT_NONE)
@@ -154,7 +160,7 @@ class Scope(object):
         if lay is None:
             return Act(None, x.n, ho, wo, cout, fmt=None if out_f32 else self.fmt, post=post)
         if ops.Fp8.enabled:     # hand the input's fp8 copy in, ask for one of the output (consumed with this scope's activation)
-            ops.Fp8.next_in, ops.Fp8.next_out_act, ops.Fp8.last_out = x.f8, self.act, None
+            ops.Fp8.next_in, ops.Fp8.next_out_act, ops.Fp8.last_out = x.f8, (self.act if self.act != L.ACT_ELU else None), None
         assert x.fmt == self.fmt and (res is None or res.fmt == self.fmt), "tensor format does not match the scope's"
         t = ops.conv(x.t, lay, res=None if res is None else res.t, res_self=res_self, out_f32=out_f32, mask=x.mask, fmt=self.fmt,
                      res_post=bool(res is not None and res.post))
@@ -186,7 +192,7 @@ class Scope(object):
             raise L.UpsError("{}: bilinear up-sampling of a post-activation tensor".format(self.prefix))
         if x.t is None:
             return Act(None, x.n, 2 * x.h, 2 * x.w, x.c, fmt=self.fmt, post=post)
-        if not ops.Fp8.enabled:
+        if not ops.Fp8.enabled or self.act == L.ACT_ELU:
             return Act(ops.BilinearFn.apply(x.t, None, 0, 0.2, self.fmt, self.act if post else 0), x.n, 2 * x.h, 2 * x.w, x.c,
                        fmt=self.fmt, post=post)
         # fp8: the up-sampled tensor feeds this scope's next convolution -- hand it an e4m3 copy of act(y) (and, backwards, the

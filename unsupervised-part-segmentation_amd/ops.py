@@ -1131,6 +1131,34 @@ class ActMeanFn(torch.autograd.Function):
         return gx, None, None, None
 
 
+class EluFn(torch.autograd.Function):
+    """activate(x, "elu") (nn.py:747-758): the one activation that is materialised -- the convolution kernels fuse only the
+    max(x, slope * x) family into their loads; a scope with `activation: elu` (no shipped yaml) runs its convolutions on the
+    activated tensor.  fmt = L.F16: fp16 bits in a bf16 container."""
+
+    @staticmethod
+    def forward(ctx, x, fmt=None):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ctx.dcode = L.dt(x) if fmt is None else fmt
+        L.call("ups_elu_fwd", L.ptr(x), L.ptr(y), ctx.dcode, x.numel(), L.stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        # (gradients of fp16 forward tensors are bf16: the derivative is taken in the gradient's type from the fp16 input)
+        if ctx.dcode == L.F16:
+            xb = x.view(torch.float16).to(torch.bfloat16)
+            L.call("ups_elu_bwd", L.ptr(xb), L.ptr(g), L.ptr(gx), L.BF16, x.numel(), L.stream())
+        else:
+            L.call("ups_elu_bwd", L.ptr(x), L.ptr(g), L.ptr(gx), ctx.dcode, x.numel(), L.stream())
+        return gx, None
+
+
 class MaxPoolFn(torch.autograd.Function):
     """site (fp8 mode): per-call-site state when the pooled tensor feeds an fp8 convolution -- the forward then also writes the
     e4m3 copy of act(y) (ops.Fp8 hand-off, as BilinearFn); `act` = the activation-on-load of that consumer."""
