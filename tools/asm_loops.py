@@ -67,6 +67,9 @@ def main():
             continue
         n = cnt["mfma"]
         print("loop {} (lines {}..{}): {}".format(m.group(1), lo, i, dict(cnt)))
+        if n == 0:          # a loop without matrix instructions (the part-path kernels): totals only
+            print("   most frequent VALU / SALU: " + ", ".join("{} x{}".format(k, v) for k, v in valu.most_common(14)))
+            continue
         print("   per MFMA: other VALU {:.2f}  SALU {:.2f}  ds_read {:.2f}  ds_write {:.2f}  vmem {:.2f}  waitcnt {:.2f}  barrier {:.3f}".format(
             cnt["valu"] / n, cnt["salu"] / n, cnt["ds_read"] / n, cnt["ds_write"] / n, cnt["vmem"] / n, cnt["waitcnt"] / n, cnt["barrier"] / n))
         print("   per 48 MFMAs: " + "  ".join("{} {:.1f}".format(k, cnt[k] * 48.0 / n) for k in ("valu", "salu", "ds_read", "ds_write", "vmem", "waitcnt", "barrier")))
