@@ -115,6 +115,16 @@ for pi in resize256 resize256_crop224; do python3 bench.py --no-cpu-baseline --p
 python3 bench.py --no-cpu-baseline --precision fp8 2>/dev/null | grep '"metric"' > $O/${TAG}_final_bench_b64_fp8.json
 for cf in deepfashion256p16 pennaction128 cub256p20; do python3 bench.py --no-cpu-baseline --config $cf 2>/dev/null | grep '"metric"' > $O/${TAG}_bench_$cf.json; done
 python3 bench.py --no-cpu-baseline --config cub256p20 --precision bf16 2>/dev/null | grep '"metric"' > $O/${TAG}_bench_cub256p20_bf16.json
+# round 5: the un-profiled headline line (with the CPU baseline leg), the fp32 line, and the fp8 weight gradient of the roofline layer
+# (SQ counters, HBM traffic, isolated timings against the bf16 kernel)
+python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '"metric"' > $O/${TAG}_final_bench_b64.json
+python3 bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '"metric"' > $O/${TAG}_bench_b64_fp32.json
+bash tools/pmc_conv.sh ${TAG}_sq8_wgrad wgrad dv_rb128 f8 > /dev/null 2>&1
+(echo "== wgrad, fp8 kernel (conv_wgrad3x3_f8.hip): e5m2 copy of the gradient in, fp16 forward tensor quantised while staged"; cat $R/gpurun_out/pmc_${TAG}_sq8_wgrad.txt) > $O/${TAG}_sq_wgrad_dv_rb128_fp8.txt 2>/dev/null
+rm -rf $R/gpurun_out/pmc_${TAG}_sq8_wgrad $R/gpurun_out/pmc_${TAG}_sq8_wgrad.txt
+# tensor-once bytes of that launch: fp16 forward tensor 1 073 741 824 + e5m2 copy 536 870 912 + 128 fp32 slabs of (9 x 258 x 256 + 256) floats 304 218 112
+bash tools/pmc_traffic.sh $O/${TAG}_pmc_wgrad_dv_rb128_fp8.json conv_wgrad3x3_f8 1914830848 -- wgrad dv_rb128 f8 > /dev/null 2>&1
+(echo "== bf16 weight gradient (conv_wgrad3x3<64,128,8,SLIDE>), the mask decoder's residual blocks as the model issues them"; python3 tools/bench_conv.py --f16 --post --only dv_rb128,dv_rb64,dv_rb32,dv_rb16 --iters 10; echo "== fp8 weight gradient (wgrad column; the other columns are bench_conv's in-kernel-conversion forms)"; python3 tools/bench_conv.py --f16 --post --fp8 --fp8-wgrad --only dv_rb128,dv_rb64,dv_rb32,dv_rb16 --iters 10) > $O/${TAG}_bench_conv_wgrad_fp8.txt 2>&1
 cat $O/${TAG}_bench_b64.json | cut -c1-300; cat $O/${TAG}_bench_b64_nooverlap.json | cut -c1-200
 head -14 $O/${TAG}_bench_b64_kernel_stats.csv | cut -c1-160
 cat $O/${TAG}_patch_kernel_by_grid.txt | head -8; cat $O/${TAG}_bilinear_by_grid.txt | head -8; cat $O/${TAG}_bilinear_by_grid_nooverlap.txt | head -8
