@@ -29,8 +29,8 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (guide)
 PEAK_F32_TFLOPS = 157.3
 PEAK_FP8_TFLOPS = 5000.0           # dense fp8 on the block-scaled K = 128 MFMA (guide); the K = 32 fp8 forms run at the bf16 rate
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("round4_pmc_dv_rb128.json", "round3_pmc_dv_rb128.json")]   # tools/profile_round.sh
-PMC_FILES_FP8 = [os.path.join(ROOT, "profiles", "round4_pmc_dv_rb128_fp8.json")]       # the fp8 mode's input-gradient launch
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("round5_pmc_dv_rb128.json", "round4_pmc_dv_rb128.json")]   # tools/profile_round.sh
+PMC_FILES_FP8 = [os.path.join(ROOT, "profiles", f) for f in ("round5_pmc_dv_rb128_fp8.json", "round4_pmc_dv_rb128_fp8.json")]       # the fp8 mode's input-gradient launch
 CPU_THREAD_CAP = 32                # torch-CPU stops scaling on this graph well before the GPU box's core count (see cpu_baseline)
 
 
