@@ -428,3 +428,44 @@ def test_tf_checkpoint_bundle_reader_and_writer(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "stub.index").write_bytes(b"version https://git-lfs.github.com/spec/v1\n" * 3)
         tfckpt.read_index(str(tmp_path / "stub.index"))
+
+
+def test_stream_plan_aliases_and_tools_offline(tmp_path):
+    """Host logic of round 5 that needs no GPU: the compact stream plan folds the logical streams onto three (ops.Streams.alias);
+    `tools/pin_log.py table` renders a dump without a device; `tools/asm_loops.py` splits a listing into loops."""
+    import json
+    import subprocess
+    import sys
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import ops
+    try:
+        ops.Streams.set_plan("compact")
+        assert {ops.Streams.alias.get(n, n) for n in ("pre", "aux", "aux1", "aux2", "wgrad", "wgrad2")} == {"aux", "wgrad"}
+        ops.Streams.set_plan("full")
+        assert not ops.Streams.alias
+        with pytest.raises(ValueError):
+            ops.Streams.set_plan("seven")
+    finally:
+        ops.Streams.set_plan("full")
+    # a two-case dump in the format tools/pin_log.py global appends to
+    steps = (0, 1, 3, 7, 15, 31, 63, 127)
+    keys = ("lor", "loa", "avg_loss_dis0", "avg_loss_dis1", "bottleneck_loss", "mask0_kl", "prior_gmrf", "variance_loss", "patch_loss",
+            "weakly_superv_loss_p", "loss_mi0_discriminator", "loss_decoder_delta")
+    dump = tmp_path / "dump.jsonl"
+    with open(dump, "w") as f:
+        for case in ("edflow plain", "tf plain"):
+            runs = [{str(s): {k: 1.0 + 0.01 * i for i, k in enumerate(keys)} for s in steps} for _ in range(2)]
+            f.write(json.dumps({"case": case, "runs": runs}) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pin_log.py"), "table", str(dump)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    assert "== mask0_kl" in out and "== verdict" in out and "edflow plain" in out and "tf plain" in out
+    listing = tmp_path / "k.s"
+    listing.write_text("_ZN4testEv: ; @test\n\ts_mov_b32 s0, 0\n.LBB0_1:\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]\n"
+                       "\tds_read_b128 v[4:7], v12\n\tv_add_u32_e32 v12, 64, v12\n\ts_add_i32 s0, s0, 1\n\ts_cmp_lt_i32 s0, 8\n"
+                       "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_loops.py"), str(listing), "test", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=60)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "loop .LBB0_1" in out and "'mfma': 1" in out and "'ds_read': 1" in out, out + r.stderr.decode()
