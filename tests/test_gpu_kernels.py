@@ -743,7 +743,9 @@ def _prior_oracle(R, variant, lm0, eps0, lm1, eps1, px_order, gamma, patch, w, g
 
 
 @pytest.mark.parametrize("variant,P,S,entropy_func", [(0, 10, 32, "entropy"), (0, 25, 32, "cross_entropy"), (0, 10, 20, "entropy"),
-                                                      (1, 10, 32, "cross_entropy"), (1, 25, 32, "cross_entropy"), (0, 3, 48, "entropy")])
+                                                      (1, 10, 32, "cross_entropy"), (1, 25, 32, "cross_entropy"), (0, 3, 48, "entropy"),
+                                                      # the pixel-per-lane forward of round 5 (P = 10 at 128- / 256-wide images)
+                                                      (0, 10, 128, "entropy"), (1, 10, 128, "cross_entropy"), (0, 10, 256, "cross_entropy")])
 def test_mask_priors_forward_and_backward(variant, P, S, entropy_func, dev):
     """ups_prior_fwd / ups_prior_bwd ALONE (8a-12; until round 4 only covered through the whole-step tests): every logged prior
     and the fused analytic d/d logits -- total (`dl`, the decoder_visualize key) and reconstruction-only (`dl_rec`, what
@@ -1534,3 +1536,29 @@ def test_bilinear_fp8_copies(dev):
         F.PRODUCER = producer_was
         F.last_out = None
         F.grad_side.clear()
+
+
+@pytest.mark.parametrize("k,stride,ci,co,hw", [(3, 1, 16, 16, 16), (3, 2, 8, 16, 32), (3, 1, 256, 10, 128), (1, 1, 32, 64, 8)])
+def test_weight_copies_per_layer_and_batched_are_bit_identical(k, stride, ci, co, hw, dev):
+    """A layer's converted weights and CoordConv table come from ups_weight_prep + ups_coord_table the first time (and after a
+    restore), from ups_weight_prep_batch after every optimizer step: both must give the SAME bits, or a run restored from a
+    checkpoint drifts an ulp from the run that wrote it (round 5: the table's arithmetic was left to per-call-site contraction)."""
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(k * 100 + ci + co)
+    V = (torch.randn(k, k, ci + 2, co, generator=g) / math.sqrt(k * k * (ci + 2))).to(dev)
+    b = torch.randn(co, generator=g).to(dev)
+    lay = ops.ConvLayer("t/conv2d_0", V, b, k, stride, True, "leaky_relu")
+    reg = ops.PrepRegistry()
+    lay.registry = reg
+    ops.WeightVersion.value += 1
+    ent = lay.prepared(lib.BF16, hw, hw, True)              # per-layer launches (registers the entry)
+    first = {n: ent[n].clone() for n in ("w_fwd", "w_dgrad", "ctab") if ent[n] is not None}
+    assert "ctab" in first and float(first["ctab"].abs().max()) > 0
+    for t in (ent["w_fwd"], ent["w_dgrad"], ent["ctab"]):
+        if t is not None:
+            t.view(torch.uint8).fill_(0x55)
+    ops.WeightVersion.value += 1
+    reg.refresh()                                           # the batched launch
+    torch.cuda.synchronize()
+    for n, t in first.items():
+        assert torch.equal(t.view(torch.uint8), ent[n].view(torch.uint8)), n

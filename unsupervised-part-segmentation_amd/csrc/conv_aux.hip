@@ -44,6 +44,31 @@ __host__ __device__ inline long long prep_elems(const ups_prep_item& it, int bk)
     return nf + nd + nc;
 }
 
+// One CoordConv table entry (class = which taps are inside the image, channel c): the affine form k0 + kj * j + ki * i of the two
+// coordinate channels' contribution.  ONE definition with explicit fused operations for the per-layer launch and the batched one:
+// left to the compiler's contraction the two call sites rounded differently, and a model restored from a checkpoint (tables from
+// the per-layer launch) was an ulp away from the run that wrote it (tables from the batched launch after its last step).
+__device__ __forceinline__ void coord_table_entry(const float* __restrict__ V, int kh, int kw, int cin_v, int ci_log, int co, int c,
+                                                  int ym, int xm, const int* dy, const int* dx, int in_sy, int in_sx, float ax, float ay,
+                                                  float& k0, float& kj, float& ki) {
+    k0 = 0.f; kj = 0.f; ki = 0.f;
+    const float sxj = __fmul_rn(ax, (float)in_sx), syi = __fmul_rn(ay, (float)in_sy);
+    for (int r = 0; r < kh; ++r) {
+        if (!((ym >> r) & 1)) continue;
+        for (int s = 0; s < kw; ++s) {
+            if (!((xm >> s) & 1)) continue;
+            const float vx = V[((long long)(r * kw + s) * cin_v + ci_log) * co + c];
+            const float vy = V[((long long)(r * kw + s) * cin_v + ci_log + 1) * co + c];
+            const int dys = r == 0 ? dy[0] : (r == 1 ? dy[1] : dy[2]);
+            const int dxs = s == 0 ? dx[0] : (s == 1 ? dx[1] : dx[2]);
+            k0 = __fmaf_rn(__fmaf_rn(ax, (float)dxs, -1.f), vx, k0);
+            k0 = __fmaf_rn(__fmaf_rn(ay, (float)dys, -1.f), vy, k0);
+            kj = __fmaf_rn(sxj, vx, kj);
+            ki = __fmaf_rn(syi, vy, ki);
+        }
+    }
+}
+
 // one launch for all layers: a 256-element chunk -> its item by binary search in the chunk prefix.  (Round 4: every block of the
 // first form searched the prefix in global memory -- eight dependent loads, ~4 us, before it converted its 256 elements: 243 447
 // blocks, 0.31 ms for 0.27 GB.  Now the prefix sits in LDS and a block converts CPB consecutive chunks.)
@@ -109,20 +134,9 @@ __device__ __forceinline__ void weight_prep_chunk(const ups_prep_item& it, long 
         const long long j = idx - nf - nd;
         const int c = (int)(j % it.co), cls = (int)(j / it.co);
         const int ym = cls >> 3, xm = cls & 7;
-        float k0 = 0.f, kj = 0.f, ki = 0.f;
-        for (int r = 0; r < it.kh; ++r) {
-            if (!((ym >> r) & 1)) continue;
-            for (int s = 0; s < it.kw; ++s) {
-                if (!((xm >> s) & 1)) continue;
-                const float vx = it.src[((long long)(r * it.kw + s) * it.cin_v + it.ci_log) * it.co + c];
-                const float vy = it.src[((long long)(r * it.kw + s) * it.cin_v + it.ci_log + 1) * it.co + c];
-                const int dys = r == 0 ? it.dy[0] : (r == 1 ? it.dy[1] : it.dy[2]);
-                const int dxs = s == 0 ? it.dx[0] : (s == 1 ? it.dx[1] : it.dx[2]);
-                k0 += (it.ax * (float)dxs - 1.f) * vx + (it.ay * (float)dys - 1.f) * vy;
-                kj += it.ax * (float)it.in_sx * vx;
-                ki += it.ay * (float)it.in_sy * vy;
-            }
-        }
+        float k0, kj, ki;
+        coord_table_entry(it.src, it.kh, it.kw, it.cin_v, it.ci_log, it.co, c, ym, xm, it.dy, it.dx, it.in_sy, it.in_sx, it.ax, it.ay,
+                          k0, kj, ki);
         it.ctab[((long long)cls * 3 + 0) * it.co + c] = k0;
         it.ctab[((long long)cls * 3 + 1) * it.co + c] = kj;
         it.ctab[((long long)cls * 3 + 2) * it.co + c] = ki;
@@ -198,21 +212,8 @@ __global__ void coord_table_kernel(const float* __restrict__ V, int kh, int kw, 
     const int ym = cls >> 3, xm = cls & 7;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= co) return;
-    float k0 = 0.f, kj = 0.f, ki = 0.f;
-    const int cin_v = ci_log + 2;
-    for (int r = 0; r < kh; ++r) {
-        if (!((ym >> r) & 1)) continue;
-        for (int s = 0; s < kw; ++s) {
-            if (!((xm >> s) & 1)) continue;
-            const float vx = V[((long long)(r * kw + s) * cin_v + ci_log) * co + c];
-            const float vy = V[((long long)(r * kw + s) * cin_v + ci_log + 1) * co + c];
-            const int dys = r == 0 ? tp.dy[0] : (r == 1 ? tp.dy[1] : tp.dy[2]);
-            const int dxs = s == 0 ? tp.dx[0] : (s == 1 ? tp.dx[1] : tp.dx[2]);
-            k0 += (ax * (float)dxs - 1.f) * vx + (ay * (float)dys - 1.f) * vy;
-            kj += ax * (float)in_sx * vx;
-            ki += ay * (float)in_sy * vy;
-        }
-    }
+    float k0, kj, ki;
+    coord_table_entry(V, kh, kw, ci_log + 2, ci_log, co, c, ym, xm, tp.dy, tp.dx, in_sy, in_sx, ax, ay, k0, kj, ki);
     tab[((long long)cls * 3 + 0) * co + c] = k0;
     tab[((long long)cls * 3 + 1) * co + c] = kj;
     tab[((long long)cls * 3 + 2) * co + c] = ki;

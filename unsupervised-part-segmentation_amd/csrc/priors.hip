@@ -17,6 +17,8 @@
 //   4 sum_np R^2   5 sum_np S^2   6 sum_np Rsmooth^2   7 sum_np Rcontour^2
 // per_np (view 0) [n][P][8]: 0 S = sum m, 1 R = sum r, 2 Rsmooth, 3 Rcontour
 // per_np (view 1) = stats of ups_spatial_moments: 0 max, 1 Z, 2 S0, 3 Sy, 4 Sx, 5 Q
+#include <stdlib.h>
+
 #include "common.h"
 #include "tile.h"
 
@@ -206,6 +208,168 @@ __global__ __launch_bounds__(256, 3) void prior_fwd_kernel(const PriorK p, int r
     v = block_sum_256(gmrf, red4); if (threadIdx.x == 0) gp[3] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the view-0 forward sums for the headline shape class as a PIXEL-PER-LANE kernel (north_star's ">= 50 % of the HBM roof" on
+// this row, asked four times).  What held prior_fwd_kernel at a quarter of the roof was instruction count, not bytes: ~500 VALU per
+// thread and tile to convert the [pixel][P] rows into an odd-pitch LDS image (a division by P per 16-byte piece, four ds_write per
+// piece) and ~175 instructions per (pixel, part) item where the arithmetic needs ~35 (tools/asm_loops.py).  Here
+//   * a tile is 256 consecutive pixels (whole rows: W | 256) and EVERY map of it is copied LINEARLY into LDS by LDS-DMA (1 KiB per
+//     wave instruction, no registers, no VALU): a P-float pixel pitch with P even is conflict-free for ds_read_b64 at one pixel per
+//     lane (P/2 * px mod 32 hits every bank pair once for P/2 odd; P = 10: 5 px mod 32);
+//   * one thread owns one pixel with its P parts unrolled in registers; the right neighbour is pixel + 1 of the same image, the lower
+//     neighbour pixel + W: in the same tile or in the first rows of the NEXT tile, which the ring already holds (no halo copies);
+//   * per-part sums (S, R, Rsmooth, Rcontour) and the four pixel sums are carried in registers over the block's tiles and reduced
+//     once per block (shuffles + one LDS exchange), written into the first slab record of the block's slab group (the others zero),
+//     so the finalize kernels and the workspace layout are unchanged;
+//   * rings: (m, l_mean) four slots -- tiles i, i+1 are read while i+2, i+3 are in flight -- and (l, hard) three slots; the pieces of
+//     tile i+2's (l, hard) and tile i+3's (m, l_mean) are issued in iteration i, so every byte has one to two tile times of cover.
+// Instances: P = 10, W = 128 / 256 (the CUB / PennAction benchmark shapes); everything else keeps prior_fwd_kernel.
+template <int P, int LW, int VAR>
+__global__ __launch_bounds__(256) void prior_fwd_px_kernel(const PriorK p, const int tiles_per_block, const int slabs_per_block) {
+    static_assert(P % 2 == 0 && ((P / 2) & 1) == 1, "conflict-free ds_read_b64 needs P / 2 odd");
+    constexpr int W = 1 << LW;
+    static_assert(W <= 256 && 256 % W == 0, "a tile is a whole number of rows");
+    constexpr int TB = 256 * P * 4;                 // bytes of one map of one tile
+    constexpr int PCS = TB / 1024;                  // 1 KiB DMA pieces per map and tile (= P)
+    static_assert(TB % 1024 == 0 && (2 * PCS) % 4 == 0, "piece counts");
+    constexpr int PW = 2 * PCS / 4;                 // pieces per wave and map pair
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ML = smem;                       // 4 slots x (m, l_mean)
+    unsigned char* LH = smem + 4 * 2 * TB;          // 3 slots x (l, hard)
+    float* red = (float*)(smem + 7 * 2 * TB);       // [4 waves][4 + 4 P]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = p.h * W, tiles_img = hw >> 8;
+    const int bpi = tiles_img / tiles_per_block;
+    const int n = blockIdx.x / bpi, bi = blockIdx.x - n * bpi;
+    const int t_begin = bi * tiles_per_block, t_end = t_begin + tiles_per_block;       // tiles of this image
+    const long long img = (long long)n * hw;
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned char* gm = (const unsigned char*)(p.m + img * P);
+    const unsigned char* glm = (const unsigned char*)(p.l_mean + img * P);
+    const unsigned char* gl = (const unsigned char*)(p.l + img * P);
+    const unsigned char* gh = (const unsigned char*)(p.hard + img * P);
+    const unsigned voff = (unsigned)lane * 16u;
+
+    // pieces of a map pair: piece q = wid + 4 k of 2 * PCS (first map then second), into ring slot `slot`
+    auto issue_pair = [&](const unsigned char* a, const unsigned char* b, int tile, unsigned lds_base) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            const int q = wid + 4 * k;
+            const unsigned char* src = (q < PCS ? a : b) + (long long)tile * TB + (q < PCS ? q : q - PCS) * 1024;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)q * 1024u);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
+        }
+    };
+    auto issue_ml = [&](int t) __attribute__((always_inline)) { issue_pair(gm, glm, t, smem_lds + (unsigned)(((t - t_begin) & 3) * 2 * TB)); };
+    auto issue_lh = [&](int t) __attribute__((always_inline)) { issue_pair(gl, gh, t, smem_lds + (unsigned)(4 * 2 * TB + ((t - t_begin) % 3) * 2 * TB)); };
+    // tiles whose (m, l_mean) are needed: t_begin .. min(t_end, tiles_img - 1) (the tile below the block's last one, if the image has one)
+    const int ml_last = min(t_end, tiles_img - 1);
+
+    // rectangle centres of this image (uniform: scalar loads)
+    int cy[P], cx[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        cy[c] = (VAR == 0 && p.px) ? p.px[((long long)n * P + c) * 2] : 0;
+        cx[c] = (VAR == 0 && p.px) ? p.px[((long long)n * P + c) * 2 + 1] : 0;
+    }
+    float kl = 0.f, ent = 0.f, patch = 0.f, gmrf = 0.f;
+    float S[P], R[P], Rs[P], Rc[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) S[c] = R[c] = Rs[c] = Rc[c] = 0.f;
+
+    // prologue: (m, l_mean) of tiles t_begin, +1, +2 and (l, hard) of t_begin, +1 -- in the order the loop issues them
+    issue_ml(t_begin); issue_lh(t_begin);
+    if (t_begin + 1 <= ml_last) issue_ml(t_begin + 1);
+    if (t_begin + 1 < t_end) issue_lh(t_begin + 1);
+    if (t_begin + 2 <= ml_last) issue_ml(t_begin + 2);
+
+    for (int t = t_begin; t < t_end; ++t) {
+        // landed from here on: (m, l_mean) of t and t + 1, (l, hard) of t.  Younger, allowed in flight: (l, hard) of t + 1 and
+        // (m, l_mean) of t + 2 -- PW pieces per wave each, where they exist
+        const int young = (t + 1 < t_end ? PW : 0) + (t + 2 <= ml_last ? PW : 0);
+        if (young == 2 * PW) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW) : "memory");
+        else if (young == PW) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // every wave's pieces are in; every wave is done with tile t - 1's slots
+        if (t + 2 < t_end) issue_lh(t + 2);           // slot (t + 2) % 3 = (t - 1) % 3: free
+        if (t + 3 <= ml_last) issue_ml(t + 3);        // slot (t + 3) & 3 = (t - 1) & 3: free
+
+        const int s4 = (t - t_begin) & 3, s3 = (t - t_begin) % 3;
+        const float* tm = (const float*)(ML + s4 * 2 * TB);
+        const float* tlm = tm + 256 * P;
+        const float* tmn = (const float*)(ML + ((s4 + 1) & 3) * 2 * TB);       // the tile below
+        const float* tlmn = tmn + 256 * P;
+        const float* tl = (const float*)(LH + s3 * 2 * TB);
+        const float* th = tl + 256 * P;
+        const int q = (t << 8) + tid;                  // pixel of the image
+        const int yy = q >> LW, xx = q & (W - 1);
+        const bool vr = xx + 1 < W, vd = yy + 1 < p.h;
+        const int qd = tid + W;                        // lower neighbour: this tile or the next one
+        const float* md_p = qd < 256 ? tm + qd * P : tmn + (qd - 256) * P;
+        const float* lmd_p = qd < 256 ? tlm + qd * P : tlmn + (qd - 256) * P;
+        float m[P], mr[P], md[P], lm[P], lr[P], ld[P], l[P], hv[P];
+        auto ld_row = [&](const float* src, float (&dst)[P]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < P; c += 2) { const float2 v = *(const float2*)(src + c); dst[c] = v.x; dst[c + 1] = v.y; }
+        };
+        ld_row(tm + tid * P, m); ld_row(tlm + tid * P, lm); ld_row(tl + tid * P, l); ld_row(th + tid * P, hv);
+        ld_row(tm + (tid + 1) * P, mr); ld_row(tlm + (tid + 1) * P, lr);      // (tid = 255: x = W - 1, the values are dropped)
+        ld_row(md_p, md); ld_row(lmd_p, ld);
+        float mx = l[0];
+#pragma unroll
+        for (int c = 1; c < P; ++c) mx = fmaxf(mx, l[c]);
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) se += __expf(l[c] - mx);
+        const float lse = mx + __logf(se);
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            const float mc = m[c];
+            kl += mc * __logf((float)P * mc + 1e-20f);
+            ent += -(p.entropy_ce ? hv[c] : mc) * (l[c] - lse);
+            const float lmc = lm[c];
+            const float lrc = vr ? lr[c] : 0.f, ldc = vd ? ld[c] : 0.f;
+            if (VAR == 0) {
+                const bool in_rect = abs(yy - cy[c]) <= p.half_h && abs(xx - cx[c]) <= p.half_w;
+                patch += in_rect ? 0.f : hv[c];
+            } else {
+                const float gw = 0.25f * (lmc - lrc), gh = 0.25f * (lmc - ldc);
+                patch += fminf(p.ms_alpha * (gw * gw + gh * gh), p.ms_lambda);
+            }
+            if (vd) { const float d = ldc - lmc; gmrf += 0.5f * d * d; }
+            if (vr) { const float d = lrc - lmc; gmrf += 0.5f * d * d; }
+            const float mrc = vr ? mr[c] : 0.f, mdc = vd ? md[c] : 0.f;
+            const float gw = 0.25f * (mc - mrc), gh = 0.25f * (mc - mdc);
+            const float g = p.ms_alpha * (gw * gw + gh * gh);
+            const float r = fminf(g, p.ms_lambda);
+            S[c] += mc; R[c] += r;
+            if (g < p.ms_lambda) Rs[c] += r; else Rc[c] += r;
+        }
+    }
+    // ---- block reduction: wave sums by shuffles, the four waves through LDS, one record per block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    kl = wave_sum(kl); ent = wave_sum(ent); patch = wave_sum(patch); gmrf = wave_sum(gmrf);
+#pragma unroll
+    for (int c = 0; c < P; ++c) { S[c] = wave_sum(S[c]); R[c] = wave_sum(R[c]); Rs[c] = wave_sum(Rs[c]); Rc[c] = wave_sum(Rc[c]); }
+    if (lane == 0) {
+        float* d = red + wid * (4 + 4 * P);
+        d[0] = kl; d[1] = ent; d[2] = patch; d[3] = gmrf;
+#pragma unroll
+        for (int c = 0; c < P; ++c) { d[4 + 4 * c] = S[c]; d[5 + 4 * c] = R[c]; d[6 + 4 * c] = Rs[c]; d[7 + 4 * c] = Rc[c]; }
+    }
+    __syncthreads();
+    // workspace: glob_partial[n][NSLAB][4], np_partial[n][NSLAB][P][4]; this block owns slabs [bi * slabs_per_block, + slabs_per_block)
+    float* gpart = p.ws + ((long long)n * NSLAB + (long long)bi * slabs_per_block) * 4;
+    float* npart = p.ws + (long long)p.n * NSLAB * 4 + ((long long)n * NSLAB + (long long)bi * slabs_per_block) * P * 4;
+    for (int i = tid; i < slabs_per_block * 4; i += 256)
+        gpart[i] = i < 4 ? red[i] + red[(4 + 4 * P) + i] + red[2 * (4 + 4 * P) + i] + red[3 * (4 + 4 * P) + i] : 0.f;
+    for (int i = tid; i < slabs_per_block * P * 4; i += 256)
+        npart[i] = i < 4 * P ? red[4 + i] + red[(4 + 4 * P) + 4 + i] + red[2 * (4 + 4 * P) + 4 + i] + red[3 * (4 + 4 * P) + 4 + i] : 0.f;
+}
+
 // Two short stages instead of one single-block pass (which walked n * NSLAB * (1 + P) partial records serially per thread: 16 us
 // behind a 120 us forward pass).  Stage 1, one block per image: the image's slab partials -> per_np[n][P][8] and the image's eight
 // sums (4 pixel sums, 4 sums of squares over its parts), every reduction in a fixed order.  Stage 2, one block: the images.
@@ -242,6 +406,38 @@ __global__ __launch_bounds__(256) void prior_finalize_img_kernel(const PriorK p)
         const float v = block_sum_256(sq[k], red4);
         if (threadIdx.x == 0) img_part[4 + k] = v;
     }
+}
+
+// Finalize of the pixel-per-lane forward: a block of prior_fwd_px_kernel leaves ONE record per slab group, so an image has only
+// `bpi` non-zero records and the whole reduction -- per_np[n][P][8], the four pixel sums and the four sums of squares over (n, part) --
+// is a few thousand floats: one block, one launch (the two-stage pair of the slab kernel costs 10 us behind a 38 us forward).
+__global__ __launch_bounds__(256) void prior_finalize_px_kernel(const PriorK p, const int bpi, const int spb) {
+    __shared__ float red4[4];
+    const float* gpart = p.ws;
+    const float* npart = p.ws + (long long)p.n * NSLAB * 4;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int n = threadIdx.x; n < p.n; n += 256)
+        for (int b = 0; b < bpi; ++b) {
+            const float* g = gpart + ((long long)n * NSLAB + (long long)b * spb) * 4;
+            for (int k = 0; k < 4; ++k) a[k] += g[k];
+        }
+    const int items = p.n * p.P;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int n = it / p.P, c = it - n * p.P;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < bpi; ++b) {
+            const float* q = npart + (((long long)n * NSLAB + (long long)b * spb) * p.P + c) * 4;
+            for (int k = 0; k < 4; ++k) o[k] += q[k];
+        }
+        float* d = p.per_np + (long long)it * 8;
+        d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3]; d[4] = d[5] = d[6] = d[7] = 0.f;
+        a[4] += o[1] * o[1]; a[5] += o[0] * o[0]; a[6] += o[2] * o[2]; a[7] += o[3] * o[3];
+    }
+    for (int k = 0; k < 8; ++k) {
+        const float v = block_sum_256(a[k], red4);
+        if (threadIdx.x == 0) p.sums[k] = v;
+    }
+    if (threadIdx.x == 0) for (int k = 8; k < 16; ++k) p.sums[k] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void prior_finalize_kernel(const PriorK p) {
@@ -485,6 +681,135 @@ __global__ __launch_bounds__(256) void prior_bwd_kernel(const PriorK p, int tpx)
     if (p.dl_rec) tile_store_f32(p.dl_rec + (img + t0) * P, cnt, P, PP, tg);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the VIEW-1 backward (KL + variance terms through the soft-max Jacobian; inputs m and g_hard, outputs dl and dl_rec) in the
+// pixel-per-lane form of prior_fwd_px_kernel: linear LDS-DMA tiles of 256 pixels (two slots), one thread = one pixel with its P
+// parts and the image's per-part constants in registers, the two result rows written back into a linear LDS tile (ds_write_b64 at
+// a 40-byte pitch is conflict-free like the reads) and stored with 16-byte accesses.  Two blocks per CU cover each other's waits.
+template <int P, int LW, int VAR>
+__global__ __launch_bounds__(256, 2) void prior_bwd1_px_kernel(const PriorK p, const int tiles_per_block) {
+    static_assert(P % 2 == 0 && ((P / 2) & 1) == 1, "conflict-free 8-byte LDS accesses need P / 2 odd");
+    constexpr int W = 1 << LW;
+    constexpr int TB = 256 * P * 4, PCS = TB / 1024, PW = 2 * PCS / 4;
+    static_assert(TB % 1024 == 0 && (2 * PCS) % 4 == 0 && (2 * TB / 16) % 256 == 0, "piece counts");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* IN = smem;                        // 2 slots x (m, g_hard)
+    unsigned char* OUT = smem + 2 * 2 * TB;          // (dl, dl_rec)
+    float* cst = (float*)(smem + 3 * 2 * TB);        // [P][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = p.h * W, tiles_img = hw >> 8;
+    const int bpi = tiles_img / tiles_per_block;
+    const int n = blockIdx.x / bpi, bi = blockIdx.x - n * bpi;
+    const int t_begin = bi * tiles_per_block, t_end = t_begin + tiles_per_block;
+    const long long img = (long long)n * hw;
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned char* gm_ = (const unsigned char*)(p.m + img * P);
+    const unsigned char* gg_ = (const unsigned char*)(p.g_hard + img * P);
+    const unsigned voff = (unsigned)lane * 16u;
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        const unsigned base = smem_lds + (unsigned)(((t - t_begin) & 1) * 2 * TB);
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            const int q = wid + 4 * k;
+            const unsigned char* src = (q < PCS ? gm_ : gg_) + (long long)t * TB + (q < PCS ? q : q - PCS) * 1024;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)q * 1024u);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
+        }
+    };
+    issue(t_begin);
+    // the image's per-part constants (as prior_bwd_kernel): rectangle centre, max / Z / means / second moments of the spatial soft-max
+    for (int c = tid; c < P; c += 256) {
+        float* k = cst + c * 8;
+        const float* np = p.per_np + ((long long)n * P + c) * 8;
+        const float Z = np[1];
+        k[0] = p.px ? (float)p.px[((long long)n * P + c) * 2] : 0.f;
+        k[1] = p.px ? (float)p.px[((long long)n * P + c) * 2 + 1] : 0.f;
+        k[2] = np[0]; k[3] = Z; k[4] = np[3] / Z; k[5] = np[4] / Z; k[6] = np[5] / Z; k[7] = np[6] / Z;
+    }
+    __syncthreads();
+    const float inv_pix = 1.f / (float)((long long)p.n * hw), inv_n = 1.f / (float)p.n;
+    const float sy = p.h > 1 ? 2.f / (float)(p.h - 1) : 0.f, sx = W > 1 ? 2.f / (float)(W - 1) : 0.f;
+    const float wkl = p.w_kl * inv_pix;
+    int rcy[P], rcx[P];
+    float kmax[P], wv[P], muy2[P], mux2[P], ca[P], cb[P], cc[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        const float* k = cst + c * 8;
+        rcy[c] = (int)k[0]; rcx[c] = (int)k[1];
+        kmax[c] = k[2];
+        const float rZ = __fdividef(1.f, k[3]), muy = k[4], mux = k[5], k6 = k[6], k7 = k[7];
+        wv[c] = p.w_var * inv_n * p.gamma * rZ;
+        muy2[c] = 2.f * muy; mux2[c] = 2.f * mux;
+        if (VAR == 1) {     // SB_model48c: v = S00^2 + S11^2 of the renormalised spatial soft-max (DF:750-776)
+            const float Qyn = k7, Qxn = k6 - k7;
+            ca[c] = Qyn - 2.f * muy * muy; cb[c] = Qxn - 2.f * mux * mux;          // subtracted from ay / ax
+            cc[c] = Qyn - muy * muy;                                                // S00; S11 is recomputed from cb below
+            wv[c] *= 2.f;
+        } else {            // SB_model48i: v = Q / Z - muy^2 - mux^2 over softmax_hw(gamma m) * (1 - rect)
+            ca[c] = k6 - 2.f * muy * muy - 2.f * mux * mux;                         // T
+            cb[c] = 0.f; cc[c] = 0.f;
+        }
+    }
+    float s11[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) s11[c] = VAR == 1 ? (cst[c * 8 + 6] - cst[c * 8 + 7]) - 0.25f * mux2[c] * mux2[c] : 0.f;
+
+    for (int t = t_begin; t < t_end; ++t) {
+        if (t + 1 < t_end) { issue(t + 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const float* tm = (const float*)(IN + ((t - t_begin) & 1) * 2 * TB);
+        const float* tg = tm + 256 * P;
+        const int q = (t << 8) + tid;
+        const int yy = q >> LW, xx = q & (W - 1);
+        const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
+        const float gq = gy * gy + gx * gx;
+        float m[P], gh[P], gmv[P];
+#pragma unroll
+        for (int c = 0; c < P; c += 2) {
+            const float2 a = *(const float2*)(tm + tid * P + c), b = *(const float2*)(tg + tid * P + c);
+            m[c] = a.x; m[c + 1] = a.y; gh[c] = b.x; gh[c + 1] = b.y;
+        }
+        float dot = 0.f, dot_r = 0.f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            const float mc = m[c];
+            const float pm = (float)P * mc;
+            float g = wkl * (__logf(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[c];
+            const float sq = __expf(p.gamma * mc - kmax[c]);
+            if (VAR == 1) {
+                const float ay = gy * gy - muy2[c] * gy - ca[c];
+                const float ax = gx * gx - mux2[c] * gx - cb[c];
+                g += wv[c] * sq * (cc[c] * ay + s11[c] * ax);
+            } else {
+                const float kk = (abs(yy - rcy[c]) <= p.half_h && abs(xx - rcx[c]) <= p.half_w) ? 0.f : 1.f;
+                const float a = gq - muy2[c] * gy - mux2[c] * gx;
+                g += wv[c] * sq * (a * kk - ca[c]);
+            }
+            gmv[c] = g;
+            dot += mc * g; dot_r += mc * gh[c];
+        }
+        float* to = (float*)OUT;
+#pragma unroll
+        for (int c = 0; c < P; c += 2) {
+            *(float2*)(to + tid * P + c) = make_float2(m[c] * (gmv[c] - dot), m[c + 1] * (gmv[c + 1] - dot));
+            *(float2*)(to + 256 * P + tid * P + c) = make_float2(m[c] * (gh[c] - dot_r), m[c + 1] * (gh[c + 1] - dot_r));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float4* d0 = (float4*)(p.dl + (img + ((long long)t << 8)) * P);
+        float4* d1 = (float4*)(p.dl_rec + (img + ((long long)t << 8)) * P);
+        const float4* o4 = (const float4*)OUT;
+#pragma unroll
+        for (int k = 0; k < 2 * TB / 16 / 256; ++k) {      // 2 * 640 16-byte pieces over 256 threads
+            const int j = tid + 256 * k;
+            if (j < TB / 16) d0[j] = o4[j]; else d1[j - TB / 16] = o4[j];
+        }
+    }
+}
+
 int gp_of(int P) { int g = 2; while (g < P) g *= 2; return g; }
 
 PriorK to_k(const ups_prior_desc* d, float* ws) {
@@ -539,6 +864,40 @@ extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
     UPS_CHECK_ARG(d->view == 1 || (d->l && d->l_mean && d->hard && (d->px || d->variant == 1) && d->per_np));
     hipStream_t s = (hipStream_t)stream;
     PriorK k = to_k(d, d->sums + 16);
+    {   // pixel-per-lane form (round 5): view 0, P = 10, 128- / 256-wide images whose tiles deal evenly onto the slab records
+        static int px_on = -1;
+        if (px_on < 0) { const char* e = getenv("UPS_PRIOR_PX"); px_on = (e && e[0] == '0') ? 0 : 1; }
+        const long long hw = (long long)d->h * d->w;
+        const bool aligned = ((((uintptr_t)d->m) | ((uintptr_t)d->l_mean) | ((uintptr_t)d->l) | ((uintptr_t)d->hard)) & 15) == 0;
+        if (px_on && d->view == 0 && d->P == 10 && (d->w == 128 || d->w == 256) && hw % 256 == 0 && aligned) {
+            const int tiles_img = (int)(hw / 256);
+            // blocks per image: enough blocks for one per CU, a power of two that divides both the tiles and the NSLAB slab records
+            int bpi = 1;
+            while (bpi < NSLAB && bpi < tiles_img && (long long)d->n * bpi < 256 && tiles_img % (2 * bpi) == 0) bpi *= 2;
+            if (tiles_img % bpi == 0 && NSLAB % bpi == 0) {
+                constexpr size_t shm_px = 7 * 2 * (size_t)(256 * 10 * 4) + 4 * (4 + 4 * 10) * sizeof(float);
+                const dim3 grid(d->n * bpi);
+                const int tpb = tiles_img / bpi, spb = NSLAB / bpi;
+#define UPS_PRIOR_PX(LWV, VARV)                                                                                                          \
+                do {                                                                                                                      \
+                    static UpsPerDevice at_;                                                                                              \
+                    if (!at_) {                                                                                                           \
+                        if (hipFuncSetAttribute((const void*)prior_fwd_px_kernel<10, LWV, VARV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                (int)shm_px) != hipSuccess) return UPS_E_LAUNCH;                                           \
+                        at_ = true;                                                                                                       \
+                    }                                                                                                                     \
+                    hipLaunchKernelGGL((prior_fwd_px_kernel<10, LWV, VARV>), grid, dim3(256), shm_px, s, k, tpb, spb);                     \
+                } while (0)
+                if (d->w == 128) { if (d->variant == 0) UPS_PRIOR_PX(7, 0); else UPS_PRIOR_PX(7, 1); }
+                else { if (d->variant == 0) UPS_PRIOR_PX(8, 0); else UPS_PRIOR_PX(8, 1); }
+#undef UPS_PRIOR_PX
+                UPS_LAUNCH_CHECK();
+                hipLaunchKernelGGL(prior_finalize_px_kernel, dim3(1), dim3(256), 0, s, k, bpi, spb);
+                UPS_LAUNCH_CHECK();
+                return UPS_OK;
+            }
+        }
+    }
     const int rows = ups_cdiv(d->h, NSLAB);
     const int PP = d->P | 1, NS = 256 / d->P;
     auto lds_fl = [&](int t) {
@@ -562,6 +921,36 @@ extern "C" int ups_prior_bwd(const ups_prior_desc* d, void* stream) {
     UPS_CHECK_ARG(d->view == 1 || (d->l && d->l_mean && d->hard));
     hipStream_t s = (hipStream_t)stream;
     PriorK k = to_k(d, nullptr);
+    {   // pixel-per-lane form of the view-1 backward (round 5): P = 10, 128- / 256-wide images, both result maps asked for
+        static int px_on = -1;
+        if (px_on < 0) { const char* e = getenv("UPS_PRIOR_PX"); px_on = (e && e[0] == '0') ? 0 : 1; }
+        const long long hw = (long long)d->h * d->w;
+        const bool aligned = d->g_hard && d->dl_rec &&
+                             ((((uintptr_t)d->m) | ((uintptr_t)d->g_hard) | ((uintptr_t)d->dl) | ((uintptr_t)d->dl_rec)) & 15) == 0;
+        if (px_on && d->view == 1 && d->P == 10 && (d->w == 128 || d->w == 256) && hw % 256 == 0 && aligned) {
+            const int tiles_img = (int)(hw / 256);
+            int bpi = 1;          // ~two blocks per CU
+            while (bpi < tiles_img && (long long)d->n * bpi < 512 && tiles_img % (2 * bpi) == 0) bpi *= 2;
+            constexpr size_t shm_px = 3 * 2 * (size_t)(256 * 10 * 4) + 10 * 8 * sizeof(float);
+            const dim3 grid(d->n * bpi);
+            const int tpb = tiles_img / bpi;
+#define UPS_PRIOR_B1(LWV, VARV)                                                                                                          \
+            do {                                                                                                                          \
+                static UpsPerDevice at_;                                                                                                  \
+                if (!at_) {                                                                                                               \
+                    if (hipFuncSetAttribute((const void*)prior_bwd1_px_kernel<10, LWV, VARV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                            (int)shm_px) != hipSuccess) return UPS_E_LAUNCH;                                               \
+                    at_ = true;                                                                                                           \
+                }                                                                                                                         \
+                hipLaunchKernelGGL((prior_bwd1_px_kernel<10, LWV, VARV>), grid, dim3(256), shm_px, s, k, tpb);                              \
+            } while (0)
+            if (d->w == 128) { if (d->variant == 0) UPS_PRIOR_B1(7, 0); else UPS_PRIOR_B1(7, 1); }
+            else { if (d->variant == 0) UPS_PRIOR_B1(8, 0); else UPS_PRIOR_B1(8, 1); }
+#undef UPS_PRIOR_B1
+            UPS_LAUNCH_CHECK();
+            return UPS_OK;
+        }
+    }
     const int PP = d->P | 1;
     auto lds_fl = [&](int t) { return ((d->view == 0 ? (size_t)(5 * t + 4 * d->w) : (size_t)(4 * t)) * PP + (size_t)d->P * 8 + (size_t)t * 4); };
     int tpx = 256;
