@@ -746,7 +746,8 @@ def _prior_oracle(R, variant, lm0, eps0, lm1, eps1, px_order, gamma, patch, w, g
                                                       (1, 10, 32, "cross_entropy"), (1, 25, 32, "cross_entropy"), (0, 3, 48, "entropy"),
                                                       # the pixel-per-lane forward of round 5 (P = 10 at 128- / 256-wide images)
                                                       (0, 10, 128, "entropy"), (1, 10, 128, "cross_entropy"), (0, 10, 256, "cross_entropy")])
-def test_mask_priors_forward_and_backward(variant, P, S, entropy_func, dev):
+@pytest.mark.parametrize("px_bpi", [0, 4, 1])
+def test_mask_priors_forward_and_backward(variant, P, S, entropy_func, px_bpi, dev, monkeypatch):
     """ups_prior_fwd / ups_prior_bwd ALONE (8a-12; until round 4 only covered through the whole-step tests): every logged prior
     and the fused analytic d/d logits -- total (`dl`, the decoder_visualize key) and reconstruction-only (`dl_rec`, what
     encoder_0 sees) -- for both views and both model variants against torch-fp64 autograd over the oracle's restatement, with
@@ -756,6 +757,12 @@ def test_mask_priors_forward_and_backward(variant, P, S, entropy_func, dev):
     lib, ops, R = _mods()
     from oracle import np_ops
     from upsparts_amd.model import Trainer
+    # px_bpi (UPS_PRIOR_PX_BPI): blocks per image of the pixel-per-lane kernels -- 0: the launcher's choice (one tile per block for
+    # three images), 4 / 1: 16 / 64 tiles per block at 128 x 128, the multi-tile loops of the 64-image benchmark shape
+    if px_bpi:
+        if not (P == 10 and S in (128, 256)):
+            pytest.skip("the pixel-per-lane kernels take P = 10 at 128- / 256-wide images")
+        monkeypatch.setenv("UPS_PRIOR_PX_BPI", str(px_bpi))
     g = torch.Generator().manual_seed(100 * variant + P + S)
     B, gamma, patch = 3, 10.0, 8
     # logits with spatial structure (so that rectangles, Mumford-Shah contours and moments are non-degenerate) + unit noise

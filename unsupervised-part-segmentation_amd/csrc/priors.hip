@@ -412,32 +412,41 @@ __global__ __launch_bounds__(256) void prior_finalize_img_kernel(const PriorK p)
 // `bpi` non-zero records and the whole reduction -- per_np[n][P][8], the four pixel sums and the four sums of squares over (n, part) --
 // is a few thousand floats: one block, one launch (the two-stage pair of the slab kernel costs 10 us behind a 38 us forward).
 __global__ __launch_bounds__(256) void prior_finalize_px_kernel(const PriorK p, const int bpi, const int spb) {
-    __shared__ float red4[4];
-    const float* gpart = p.ws;
-    const float* npart = p.ws + (long long)p.n * NSLAB * 4;
+    // (one block, latency-bound: 16-byte loads that do not depend on each other, ONE exchange through LDS for the eight sums)
+    __shared__ float red[4][8];
+    const float4* gpart = (const float4*)p.ws;
+    const float4* npart = (const float4*)(p.ws + (long long)p.n * NSLAB * 4);
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int n = threadIdx.x; n < p.n; n += 256)
         for (int b = 0; b < bpi; ++b) {
-            const float* g = gpart + ((long long)n * NSLAB + (long long)b * spb) * 4;
-            for (int k = 0; k < 4; ++k) a[k] += g[k];
+            const float4 g = gpart[(long long)n * NSLAB + (long long)b * spb];
+            a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
         }
     const int items = p.n * p.P;
     for (int it = threadIdx.x; it < items; it += 256) {
         const int n = it / p.P, c = it - n * p.P;
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
         for (int b = 0; b < bpi; ++b) {
-            const float* q = npart + (((long long)n * NSLAB + (long long)b * spb) * p.P + c) * 4;
-            for (int k = 0; k < 4; ++k) o[k] += q[k];
+            const float4 q = npart[((long long)n * NSLAB + (long long)b * spb) * p.P + c];
+            o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
         }
-        float* d = p.per_np + (long long)it * 8;
-        d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3]; d[4] = d[5] = d[6] = d[7] = 0.f;
-        a[4] += o[1] * o[1]; a[5] += o[0] * o[0]; a[6] += o[2] * o[2]; a[7] += o[3] * o[3];
+        float4* d = (float4*)(p.per_np + (long long)it * 8);
+        d[0] = o; d[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a[4] += o.y * o.y; a[5] += o.x * o.x; a[6] += o.z * o.z; a[7] += o.w * o.w;
     }
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const float v = block_sum_256(a[k], red4);
-        if (threadIdx.x == 0) p.sums[k] = v;
+        float v = a[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        a[k] = v;
     }
-    if (threadIdx.x == 0) for (int k = 8; k < 16; ++k) p.sums[k] = 0.f;
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 8; ++k) red[threadIdx.x >> 6][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x < 16)
+        p.sums[threadIdx.x] = threadIdx.x < 8 ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.f;
 }
 
 __global__ __launch_bounds__(256) void prior_finalize_kernel(const PriorK p) {
@@ -810,6 +819,235 @@ __global__ __launch_bounds__(256, 2) void prior_bwd1_px_kernel(const PriorK p, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the VIEW-0 backward (KL, entropy, patch / Mumford-Shah on the logits, area, Mumford-Shah, GMRF through the soft-max
+// Jacobian; seven maps of traffic: m, l_mean, l, hard, g_hard in, dl, dl_rec out) pixel-per-lane.  The stencils reach one row up and
+// one row down, so the (m, l_mean) ring holds the tiles t - 1, t, t + 1 with t + 2 in flight (four slots); (l, hard, g_hard) of a
+// tile arrive one tile ahead (two slots) and the tile's results overwrite its own l / g_hard rows (thread-private) before they
+// leave LINEARLY with 16-byte stores.  140 KB of LDS: one block per CU, so nothing may idle: the wait at the top of a tile is
+// COUNTED -- vmcnt(STORES) lets the previous tile's stores stay in flight (gfx9 retires vector memory operations of one wave in
+// issue order, loads and stores alike; the compiler's own waits rely on the same) -- and a slot is re-filled as soon as the stores'
+// LDS reads are over (the barrier), not when the stores are acknowledged.
+template <int P, int LW, int VAR>
+__global__ __launch_bounds__(256, 1) void prior_bwd0_px_kernel(const PriorK p, const int tiles_per_block) {
+    static_assert(P % 2 == 0 && ((P / 2) & 1) == 1, "conflict-free 8-byte LDS accesses need P / 2 odd");
+    constexpr int W = 1 << LW;
+    static_assert(W <= 256 && 256 % W == 0, "a tile is a whole number of rows");
+    constexpr int TB = 256 * P * 4, PCS = TB / 1024;
+    constexpr int STORES = 2 * TB / 16 / 256;          // 16-byte stores per thread and tile (dl + dl_rec)
+    static_assert(TB % 1024 == 0 && (2 * TB / 16) % 256 == 0 && (TB / 16) % 64 == 0, "piece counts");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ML = smem;                          // 4 slots x (m, l_mean)
+    unsigned char* LHG = smem + 4 * 2 * TB;            // 2 slots x (l, hard, g_hard)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = p.h * W, tiles_img = hw >> 8;
+    const int bpi = tiles_img / tiles_per_block;
+    const int n = blockIdx.x / bpi, bi = blockIdx.x - n * bpi;
+    const int t_begin = bi * tiles_per_block, t_end = t_begin + tiles_per_block;
+    const int ml_first = max(t_begin - 1, 0), ml_last = min(t_end, tiles_img - 1);
+    const long long img = (long long)n * hw;
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned char* g_m = (const unsigned char*)(p.m + img * P);
+    const unsigned char* g_lm = (const unsigned char*)(p.l_mean + img * P);
+    const unsigned char* g_l = (const unsigned char*)(p.l + img * P);
+    const unsigned char* g_h = (const unsigned char*)(p.hard + img * P);
+    const unsigned char* g_g = (const unsigned char*)(p.g_hard + img * P);
+    const unsigned voff = (unsigned)lane * 16u;
+    // (m, l_mean) of tile t: slot (t - t_begin + 1) & 3, 2 * PCS pieces over the four waves
+    auto issue_ml = [&](int t) __attribute__((always_inline)) {
+        const unsigned base = smem_lds + (unsigned)(((t - t_begin + 1) & 3) * 2 * TB);
+#pragma unroll
+        for (int k = 0; k < 2 * PCS / 4; ++k) {
+            const int q = wid + 4 * k;
+            const unsigned char* src = (q < PCS ? g_m : g_lm) + (long long)t * TB + (q < PCS ? q : q - PCS) * 1024;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)q * 1024u);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
+        }
+    };
+    // (l, hard, g_hard) of tile t: slot (t - t_begin) & 1, 3 * PCS pieces: wave w takes pieces w, w + 4, ...
+    auto issue_lhg = [&](int t) __attribute__((always_inline)) {
+        const unsigned base = smem_lds + (unsigned)(4 * 2 * TB + ((t - t_begin) & 1) * 3 * TB);
+#pragma unroll
+        for (int k = 0; k < (3 * PCS + 3) / 4; ++k) {
+            const int q = wid + 4 * k;
+            if (q < 3 * PCS) {
+                const int mp = q < PCS ? 0 : (q < 2 * PCS ? 1 : 2);
+                const unsigned char* src = (mp == 0 ? g_l : (mp == 1 ? g_h : g_g)) + (long long)t * TB + (q - mp * PCS) * 1024;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)q * 1024u);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
+            }
+        }
+    };
+    if (ml_first < t_begin) issue_ml(ml_first);
+    issue_ml(t_begin); issue_lhg(t_begin);
+    if (t_begin + 1 <= ml_last) issue_ml(t_begin + 1);
+
+    // the image's per-part constants (uniform): rectangle centre, S and R of the forward pass
+    int rcy[P], rcx[P];
+    float kS[P], kR[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        rcy[c] = (VAR == 0 && p.px) ? p.px[((long long)n * P + c) * 2] : 0;
+        rcx[c] = (VAR == 0 && p.px) ? p.px[((long long)n * P + c) * 2 + 1] : 0;
+        kS[c] = p.per_np[((long long)n * P + c) * 8];
+        kR[c] = p.per_np[((long long)n * P + c) * 8 + 1];
+    }
+    const float inv_pix = 1.f / (float)((long long)p.n * hw), inv_n = 1.f / (float)p.n;
+    const float a8 = p.ms_alpha * 0.125f, a16 = p.ms_alpha * 0.0625f;
+    const float wkl = p.w_kl * inv_pix, went = p.w_entropy * inv_pix;
+    const float wpatch = p.w_patch * inv_n, warea2 = p.w_area * inv_n * 2.f, wms2 = p.w_ms * inv_n * 2.f;
+    const float wmsl = p.w_msl * inv_n, wgmrf = p.w_gmrf * inv_n;
+
+    for (int t = t_begin; t < t_end; ++t) {
+        // landed from here on: (m, l_mean) of t - 1, t, t + 1 and (l, hard, g_hard) of t -- all issued before the previous tile's stores
+        if (t == t_begin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(STORES) : "memory");
+        __builtin_amdgcn_s_barrier();                 // every wave's pieces are in; every wave has read tile t - 1's results out of LDS
+        if (t + 2 <= ml_last) issue_ml(t + 2);        // slot of tile t - 2: free
+        if (t + 1 < t_end) issue_lhg(t + 1);          // slot of tile t - 1: free
+
+        const int s4 = (t - t_begin + 1) & 3;
+        const float* tm = (const float*)(ML + s4 * 2 * TB);
+        const float* tmu = (const float*)(ML + ((s4 + 3) & 3) * 2 * TB);       // the tile above
+        const float* tmd = (const float*)(ML + ((s4 + 1) & 3) * 2 * TB);       // the tile below
+        float* tl = (float*)(LHG + ((t - t_begin) & 1) * 3 * TB);
+        const float* th = tl + 256 * P;
+        float* tg = tl + 2 * 256 * P;
+        const int q = (t << 8) + tid;
+        const int yy = q >> LW, xx = q & (W - 1);
+        const bool vr = xx + 1 < W, vd = yy + 1 < p.h, vl = xx > 0, vu = yy > 0;
+        // neighbour rows: pixel index within the tile, or in the tile above / below (m at +0, l_mean at +256 * P floats)
+        const int iu = tid - W, id = tid + W;
+        const float* pu = iu >= 0 ? tm + iu * P : tmu + (iu + 256) * P;          // up
+        const float* pur = iu + 1 >= 0 ? tm + (iu + 1) * P : tmu + (iu + 257) * P;   // up-right
+        const float* pd = id < 256 ? tm + id * P : tmd + (id - 256) * P;         // down
+        const float* pld = id - 1 < 256 ? tm + (id - 1) * P : tmd + (id - 257) * P;  // left-down
+        const float* po = tm + tid * P;
+        auto ld_row = [&](const float* src, float (&dst)[P]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < P; c += 2) { const float2 v = *(const float2*)(src + c); dst[c] = v.x; dst[c + 1] = v.y; }
+        };
+        float m[P], l[P], hv[P], gh[P];
+        ld_row(po, m); ld_row(tl + tid * P, l); ld_row(th + tid * P, hv); ld_row(tg + tid * P, gh);
+        float mx = l[0];
+#pragma unroll
+        for (int c = 1; c < P; ++c) mx = fmaxf(mx, l[c]);
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) se += __expf(l[c] - mx);
+        const float lse = mx + __logf(se);
+        float qs = 0.f, labsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) { qs += m[c] * (l[c] - lse); labsum += hv[c]; }
+        float gm[P], direct[P];
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            const float mc = m[c];
+            const float pm = (float)P * mc;
+            float g = wkl * (__logf(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[c];
+            float dr = went * (-mc * ((l[c] - lse) - qs));
+            if (p.entropy_ce) dr += went * (-(hv[c] - mc * labsum));
+            if (VAR == 0) {
+                const bool in_rect = abs(yy - rcy[c]) <= p.half_h && abs(xx - rcx[c]) <= p.half_w;
+                g += in_rect ? 0.f : wpatch;
+            }
+            g += warea2 * kS[c];
+            gm[c] = g; direct[c] = dr;
+        }
+        {   // Mumford-Shah on the soft masks: own cell, the left neighbour's cell (its right value is me), the upper neighbour's
+            float mr[P], md[P], ml[P], mld[P], mu[P], mur[P];
+            ld_row(po + P, mr); ld_row(pd, md); ld_row(po - P, ml); ld_row(pld, mld); ld_row(pu, mu); ld_row(pur, mur);
+#pragma unroll
+            for (int c = 0; c < P; ++c) {
+                const float mc = m[c];
+                const float m_r = vr ? mr[c] : 0.f, m_d = vd ? md[c] : 0.f;
+                float dR = 0.f;
+                {
+                    const float g = a16 * ((mc - m_r) * (mc - m_r) + (mc - m_d) * (mc - m_d));
+                    if (g <= p.ms_lambda) dR += a8 * ((mc - m_r) + (mc - m_d));
+                }
+                if (vl) {
+                    const float m_l = ml[c], m_ld = vd ? mld[c] : 0.f;
+                    const float g = a16 * ((m_l - mc) * (m_l - mc) + (m_l - m_ld) * (m_l - m_ld));
+                    if (g <= p.ms_lambda) dR -= a8 * (m_l - mc);
+                }
+                if (vu) {
+                    const float m_u = mu[c], m_ur = vr ? mur[c] : 0.f;
+                    const float g = a16 * ((m_u - m_ur) * (m_u - m_ur) + (m_u - mc) * (m_u - mc));
+                    if (g <= p.ms_lambda) dR -= a8 * (m_u - mc);
+                }
+                gm[c] += wms2 * kR[c] * dR;
+            }
+        }
+        {   // the noise-free logits: GMRF, and (SB_model48c) the Mumford-Shah stencil on them
+            constexpr int LMO = 256 * P;
+            float lm[P], lr[P], ld[P], ll[P], lu[P];
+            ld_row(po + LMO, lm); ld_row(po + LMO + P, lr); ld_row(pd + LMO, ld); ld_row(po + LMO - P, ll); ld_row(pu + LMO, lu);
+            if (VAR == 1) {
+                float lld[P], lur[P];
+                ld_row(pld + LMO, lld); ld_row(pur + LMO, lur);
+#pragma unroll
+                for (int c = 0; c < P; ++c) {
+                    const float lmc = lm[c];
+                    const float l_r = vr ? lr[c] : 0.f, l_d = vd ? ld[c] : 0.f;
+                    float dL = 0.f;
+                    {
+                        const float g = a16 * ((lmc - l_r) * (lmc - l_r) + (lmc - l_d) * (lmc - l_d));
+                        if (g <= p.ms_lambda) dL += a8 * ((lmc - l_r) + (lmc - l_d));
+                    }
+                    if (vl) {
+                        const float l_l = ll[c], l_ld = vd ? lld[c] : 0.f;
+                        const float g = a16 * ((l_l - lmc) * (l_l - lmc) + (l_l - l_ld) * (l_l - l_ld));
+                        if (g <= p.ms_lambda) dL -= a8 * (l_l - lmc);
+                    }
+                    if (vu) {
+                        const float l_u = lu[c], l_ur = vr ? lur[c] : 0.f;
+                        const float g = a16 * ((l_u - l_ur) * (l_u - l_ur) + (l_u - lmc) * (l_u - lmc));
+                        if (g <= p.ms_lambda) dL -= a8 * (l_u - lmc);
+                    }
+                    direct[c] += wmsl * dL;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < P; ++c) {
+                const float lmc = lm[c];
+                float gg = 0.f;
+                if (vu) gg += lmc - lu[c];
+                if (vd) gg -= ld[c] - lmc;
+                if (vl) gg += lmc - ll[c];
+                if (vr) gg -= lr[c] - lmc;
+                direct[c] += wgmrf * gg;
+            }
+        }
+        float dot = 0.f, dot_r = 0.f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) { dot += m[c] * gm[c]; dot_r += m[c] * gh[c]; }
+#pragma unroll
+        for (int c = 0; c < P; c += 2) {
+            *(float2*)(tl + tid * P + c) = make_float2(m[c] * (gm[c] - dot) + direct[c], m[c + 1] * (gm[c + 1] - dot) + direct[c + 1]);
+            *(float2*)(tg + tid * P + c) = make_float2(m[c] * (gh[c] - dot_r), m[c + 1] * (gh[c + 1] - dot_r));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float4* d0 = (float4*)(p.dl + (img + ((long long)t << 8)) * P);
+        float4* d1 = (float4*)(p.dl_rec + (img + ((long long)t << 8)) * P);
+        const float4* o0 = (const float4*)tl;
+        const float4* o1 = (const float4*)tg;
+#pragma unroll
+        for (int k = 0; k < STORES; ++k) {          // exactly STORES store instructions per wave (the counted wait above)
+            const int j = tid + 256 * k;
+            const bool first = j < TB / 16;          // (wave-uniform: TB / 16 is a multiple of 64)
+            const float4 v = first ? o0[j] : o1[j - TB / 16];
+            float4* dst = first ? d0 + j : d1 + (j - TB / 16);
+            *dst = v;
+        }
+    }
+}
+
+// Test hook: UPS_PRIOR_PX_BPI caps the blocks per image of the pixel-per-lane kernels, so that a three-image test walks the multi-tile
+// loops (ring slots, counted waits) the 64-image benchmark shape walks.  Read at every call (a getenv, microseconds).
+int px_bpi_cap() { const char* e = getenv("UPS_PRIOR_PX_BPI"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 30); }
 int gp_of(int P) { int g = 2; while (g < P) g *= 2; return g; }
 
 PriorK to_k(const ups_prior_desc* d, float* ws) {
@@ -873,7 +1111,8 @@ extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
             const int tiles_img = (int)(hw / 256);
             // blocks per image: enough blocks for one per CU, a power of two that divides both the tiles and the NSLAB slab records
             int bpi = 1;
-            while (bpi < NSLAB && bpi < tiles_img && (long long)d->n * bpi < 256 && tiles_img % (2 * bpi) == 0) bpi *= 2;
+            const int cap = px_bpi_cap();
+            while (2 * bpi <= cap && bpi < NSLAB && bpi < tiles_img && (long long)d->n * bpi < 256 && tiles_img % (2 * bpi) == 0) bpi *= 2;
             if (tiles_img % bpi == 0 && NSLAB % bpi == 0) {
                 constexpr size_t shm_px = 7 * 2 * (size_t)(256 * 10 * 4) + 4 * (4 + 4 * 10) * sizeof(float);
                 const dim3 grid(d->n * bpi);
@@ -930,7 +1169,8 @@ extern "C" int ups_prior_bwd(const ups_prior_desc* d, void* stream) {
         if (px_on && d->view == 1 && d->P == 10 && (d->w == 128 || d->w == 256) && hw % 256 == 0 && aligned) {
             const int tiles_img = (int)(hw / 256);
             int bpi = 1;          // ~two blocks per CU
-            while (bpi < tiles_img && (long long)d->n * bpi < 512 && tiles_img % (2 * bpi) == 0) bpi *= 2;
+            const int cap = px_bpi_cap();
+            while (2 * bpi <= cap && bpi < tiles_img && (long long)d->n * bpi < 512 && tiles_img % (2 * bpi) == 0) bpi *= 2;
             constexpr size_t shm_px = 3 * 2 * (size_t)(256 * 10 * 4) + 10 * 8 * sizeof(float);
             const dim3 grid(d->n * bpi);
             const int tpb = tiles_img / bpi;
@@ -947,6 +1187,31 @@ extern "C" int ups_prior_bwd(const ups_prior_desc* d, void* stream) {
             if (d->w == 128) { if (d->variant == 0) UPS_PRIOR_B1(7, 0); else UPS_PRIOR_B1(7, 1); }
             else { if (d->variant == 0) UPS_PRIOR_B1(8, 0); else UPS_PRIOR_B1(8, 1); }
 #undef UPS_PRIOR_B1
+            UPS_LAUNCH_CHECK();
+            return UPS_OK;
+        }
+        if (px_on && d->view == 0 && d->P == 10 && (d->w == 128 || d->w == 256) && hw % 256 == 0 && aligned && d->l && d->l_mean &&
+            d->hard && ((((uintptr_t)d->l) | ((uintptr_t)d->l_mean) | ((uintptr_t)d->hard)) & 15) == 0) {
+            const int tiles_img = (int)(hw / 256);
+            int bpi = 1;          // one block per CU
+            const int cap = px_bpi_cap();
+            while (2 * bpi <= cap && bpi < tiles_img && (long long)d->n * bpi < 256 && tiles_img % (2 * bpi) == 0) bpi *= 2;
+            constexpr size_t shm_px = (4 * 2 + 2 * 3) * (size_t)(256 * 10 * 4);
+            const dim3 grid(d->n * bpi);
+            const int tpb = tiles_img / bpi;
+#define UPS_PRIOR_B0(LWV, VARV)                                                                                                          \
+            do {                                                                                                                          \
+                static UpsPerDevice at_;                                                                                                  \
+                if (!at_) {                                                                                                               \
+                    if (hipFuncSetAttribute((const void*)prior_bwd0_px_kernel<10, LWV, VARV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                            (int)shm_px) != hipSuccess) return UPS_E_LAUNCH;                                               \
+                    at_ = true;                                                                                                           \
+                }                                                                                                                         \
+                hipLaunchKernelGGL((prior_bwd0_px_kernel<10, LWV, VARV>), grid, dim3(256), shm_px, s, k, tpb);                              \
+            } while (0)
+            if (d->w == 128) { if (d->variant == 0) UPS_PRIOR_B0(7, 0); else UPS_PRIOR_B0(7, 1); }
+            else { if (d->variant == 0) UPS_PRIOR_B0(8, 0); else UPS_PRIOR_B0(8, 1); }
+#undef UPS_PRIOR_B0
             UPS_LAUNCH_CHECK();
             return UPS_OK;
         }
