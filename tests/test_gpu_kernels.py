@@ -1569,3 +1569,37 @@ def test_weight_copies_per_layer_and_batched_are_bit_identical(k, stride, ci, co
     torch.cuda.synchronize()
     for n, t in first.items():
         assert torch.equal(t.view(torch.uint8), ent[n].view(torch.uint8)), n
+
+
+@pytest.mark.parametrize("B,S", [(3, 128), (1, 32), (2, 64)])
+def test_unpool_backward_on_the_matrix_cores(B, S, dev, monkeypatch):
+    """ups_unpool_bwd at the benchmark shape class (bf16 gradient, 64 features + 10 parts in 80-channel rows): the MFMA form of
+    round 5 against torch-fp64 and against the VALU form it replaces (UPS_UNPOOL_MFMA=0).  hard: one-hot rows (what the model
+    passes), a tie, and a block of arbitrary fp32 values (the hi + lo bf16 pair of the mask operand must keep them to ~1e-5)."""
+    lib, ops, R = _mods()
+    L = lib
+    P, F, ld = 10, 64, 80
+    g = torch.Generator().manual_seed(5 + B + S)
+    hard = torch.nn.functional.one_hot(torch.randint(0, P, (B, S, S), generator=g), P).float()
+    hard[0, 0, 0] = torch.tensor([1.0, 1.0] + [0.0] * (P - 2))
+    hard[0, 1, :8] = torch.randn(8, P, generator=g)
+    feat = torch.randn(B, P, F, generator=g).bfloat16().float()          # bf16 mode: the float view of a bf16 tensor
+    gi = torch.zeros(B, S, S, ld)
+    gi[..., :F + P] = torch.randn(B, S, S, F + P, generator=g)
+    gi = gi.bfloat16()
+    gd = gi.double()
+    want_h = torch.einsum("bhwf,bpf->bhwp", gd[..., :F], feat.double()) + gd[..., F:F + P]
+    want_f = torch.einsum("bhwp,bhwf->bpf", hard.double(), gd[..., :F])
+    hd, fd, gdv = hard.to(dev), feat.to(dev), gi.to(dev)
+    nfl = L.load().ups_unpool_bwd_floats(B, P, F)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("UPS_UNPOOL_MFMA", mode)
+        gh = torch.full((B, S, S, P), float("nan"), device=dev)
+        gf = torch.full((nfl,), float("nan"), dtype=torch.float32, device=dev)
+        L.call("ups_unpool_bwd", L.ptr(hd), L.ptr(fd), L.ptr(gdv), L.ptr(gh), L.ptr(gf), L.dt(gdv), B, S * S, P, F, ld, L.stream())
+        torch.cuda.synchronize()
+        res[mode] = (gh.cpu(), gf[:B * P * F].view(B, P, F).cpu())
+        assert_close(res[mode][0], want_h.float(), 1e-5, "unpool d hard (UPS_UNPOOL_MFMA={})".format(mode))
+        assert_close(res[mode][1], want_f.float(), 2e-5, "unpool d feat (UPS_UNPOOL_MFMA={})".format(mode), elementwise=False)
+    assert_close(res["1"][0], res["0"][0], 1e-5, "MFMA vs VALU form, d hard")

@@ -98,10 +98,11 @@ def main():
         "[P*B,S,S,8] bf16 gradient + view read, g_hard written")
     ginj = torch.randn(B, S, S, 80, device=dev, generator=g).to(T)
     gfe = torch.empty(L.load().ups_unpool_bwd_floats(B, P, A), dtype=torch.float32, device=dev)
-    add("unpool_bwd (g_hard + g_feat)", 2 * ginj.numel() * 2 + 2 * half_b,
+    add("unpool_bwd (g_hard + g_feat)", ginj.numel() * 2 + 2 * half_b,
         lambda: L.call("ups_unpool_bwd", L.ptr(h0), L.ptr(feat), L.ptr(ginj), L.ptr(ghp), L.ptr(gfe), L.dt(ginj), B, S * S, P, A, 80,
                        L.stream()),
-        "two kernels: [B,S,S,80] bf16 gradient read twice, hard read, g_hard written")
+        "one pass since round 4: [B,S,S,80] bf16 gradient read ONCE, hard read, g_hard written (until round 5 this row still counted "
+        "the gradient twice, the two-kernel form of round 3: its fractions were overstated by 1.67x)")
     m1 = m[B:].contiguous()
     px1 = px[B:].contiguous()
     sums1 = torch.empty(nfl, dtype=torch.float32, device=dev)

@@ -3,6 +3,7 @@
 // appearance images, part-feature un-pooling.  All HBM-bound.  Data moves between HBM and LDS in whole pixel tiles with
 // 16-byte accesses (tile.h: enough bytes in flight to cover the HBM latency); compute runs out of LDS with lanes along the
 // part / feature axis so the part reductions are wavefront shuffles.
+#include <stdlib.h>
 #include "common.h"
 #include "tile.h"
 
@@ -483,6 +484,167 @@ __global__ __launch_bounds__(256) void unpool_bwd_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same backward on the matrix cores for the benchmark shape (bf16 gradient, F = 64 features, P = 10 parts, 80-channel
+// rows).  unpool_bwd_kernel issued 60 M wave instructions per launch -- a pixel's feature row added into its part's accumulator row
+// by one wave at a time (27 instructions per pixel), 32 dot2 per (pixel, part) -- and the SIMDs' issue slots, not HBM, set its
+// 137 us (SQ counters, profiles/round5_pmc_part.txt).  Both products are small GEMMs:
+//   g_hard[px][p] = sum_f G[px][f] feat[p][f] (+ G[px][64 + p])   : A = G rows as they lie in LDS, B = feat, K = 64 features
+//   g_feat[p][f]  = sum_px hard[px][p] G[px][f]                   : A = hard^T (hi + lo bf16 pair: exact to 2^-17 for any
+//                                                                   fp32 mask, exact for the 0 / 1 masks the model passes),
+//                                                                   B = G read column-wise with ds_read_b64_tr_b16, K = 32 pixels
+// ~100 wave instructions per 128-pixel tile instead of ~460.  Tiles (gradient rows + hard rows) arrive LINEARLY by LDS-DMA, three
+// slots (two tiles in flight), g_hard leaves through an LDS tile with 16-byte stores; waits are counted (loads, stores and LDS-DMA
+// retire in issue order).  80 KB of LDS: two blocks per CU.
+constexpr int UB_TP = 128, UB_P = 10, UB_F = 64, UB_LD = 80;
+constexpr int UB_GT = UB_TP * UB_LD * 2;            // 20480 B gradient tile
+constexpr int UB_HT = UB_TP * UB_P * 4;             // 5120 B hard tile (and g_hard tile)
+constexpr int UB_SLOT = UB_GT + UB_HT;
+constexpr int UB_PIECES = UB_SLOT / 1024;           // 25 LDS-DMA pieces per tile: wave 0 takes 7, the others 6
+constexpr size_t UB_SHMEM = 3 * (size_t)UB_SLOT + UB_HT;
+
+__device__ __forceinline__ void ub_wait_vm(int young) {
+    switch (young) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void unpool_bwd_mfma_kernel(const float* __restrict__ hard, const float* __restrict__ feat,
+                                                                  const bf16* __restrict__ g, float* __restrict__ gh,
+                                                                  float* __restrict__ gfeat_partial, const long long hw,
+                                                                  const int tiles_per_block, const int slabs_per_block, const int nslab) {
+    typedef __attribute__((ext_vector_type(4))) short v4s;
+    typedef __attribute__((address_space(3))) v4s lds_v4s;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* OS = smem + 3 * UB_SLOT;          // g_hard tile [128][10] fp32, linear
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.x, sb = blockIdx.y;       // image, block of the image
+    const long long px0 = (long long)sb * tiles_per_block * UB_TP;       // first pixel of this block
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned char* gsrc = (const unsigned char*)(g + ((long long)b * hw + px0) * UB_LD);
+    const unsigned char* hsrc = (const unsigned char*)(hard + ((long long)b * hw + px0) * UB_P);
+    const unsigned voff = (unsigned)lane * 16u;
+    const int L = wid == 0 ? 7 : 6, S = wid == 0 ? 2 : 1;                 // LDS-DMA pieces / stores per wave and tile
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        const unsigned base = smem_lds + (unsigned)((t % 3) * UB_SLOT);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int q = wid + 4 * k;
+            if (q < UB_PIECES) {
+                const unsigned char* src = q < UB_GT / 1024 ? gsrc + (long long)t * UB_GT + q * 1024
+                                                            : hsrc + (long long)t * UB_HT + (q - UB_GT / 1024) * 1024;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)q * 1024u);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
+            }
+        }
+    };
+    issue(0);
+    if (1 < tiles_per_block) issue(1);
+    // B operand of the first product: feat[b][part li][features 8 lg .. + 7] and [32 + 8 lg .. + 7] as bf16 (exact: in bf16 mode feat is
+    // the float view of a bf16 tensor)
+    bf16x8 fb[2];
+    {
+        const float* fr = feat + ((long long)b * UB_P + min(li, UB_P - 1)) * UB_F;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fb[h][e] = (__bf16)(li < UB_P ? fr[32 * h + 8 * lg + e] : 0.f);
+    }
+    f32x4 acc[4];                                     // g_feat: parts 4 lg + i x features 16 nb + li, this wave's pixels
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < tiles_per_block; ++t) {
+        // younger than tile t's pieces: the stores of up to two tiles and tile t + 1's pieces
+        ub_wait_vm(min(t, 2) * S + (t + 1 < tiles_per_block ? L : 0));
+        __builtin_amdgcn_s_barrier();                 // tile t is in; everyone is done with tile t - 1 (its slot, the g_hard tile)
+        if (t + 2 < tiles_per_block) issue(t + 2);
+        const unsigned char* G = smem + (t % 3) * UB_SLOT;
+        const unsigned char* H = G + UB_GT;
+        const int R0 = wid * 32;                      // this wave's 32 pixels of the tile
+        // ---- g_hard: two 16-pixel blocks, K = 64 features in two steps
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int row = R0 + 16 * mb + li;
+            const bf16x8 a0 = *(const bf16x8*)(G + row * (UB_LD * 2) + 16 * lg);
+            const bf16x8 a1 = *(const bf16x8*)(G + row * (UB_LD * 2) + 64 + 16 * lg);
+            f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, fb[0], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, fb[1], d, 0, 0, 0);
+            // lane: pixels R0 + 16 mb + 4 lg + i, part li; + the gradient's own part channel
+            if (li < UB_P) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = R0 + 16 * mb + 4 * lg + i;
+                    const unsigned short u = *(const unsigned short*)(G + r * (UB_LD * 2) + 2 * (UB_F + li));
+                    *(float*)(OS + r * (UB_P * 4) + 4 * li) = d[i] + __uint_as_float((unsigned)u << 16);
+                }
+            }
+        }
+        // ---- g_feat: K = this wave's 32 pixels; k-index j of lane group lg <-> rows R0 + 4 lg + j (j < 4), R0 + 16 + 4 lg + j - 4
+        // (two 4-row blocks per 16-lane group that a 32-lane half reads from eight DIFFERENT rows: conflict-free at 160-byte rows)
+        bf16x8 ah, al;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = R0 + (j < 4 ? 4 * lg + j : 16 + 4 * lg + j - 4);
+            const float v = *(const float*)(H + r * (UB_P * 4) + 4 * li);          // (li >= P: the next pixel's values, dropped)
+            const float hv = li < UB_P ? v : 0.f;
+            const __bf16 hi = (__bf16)hv;
+            ah[j] = hi;
+            al[j] = (__bf16)(hv - (float)hi);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            // lane 4 q + p of a group supplies row q, columns 4 p .. 4 p + 3 of the 4 x 16 block (guide T10); EXEC is all ones here
+            const int q = li >> 2, pp = li & 3;
+            const v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(G + (R0 + 4 * lg + q) * (UB_LD * 2) + 2 * (16 * nb + 4 * pp)));
+            const v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(G + (R0 + 16 + 4 * lg + q) * (UB_LD * 2) + 2 * (16 * nb + 4 * pp)));
+            bf16x8 bb;
+            __builtin_memcpy(&bb, &b0, 8);
+            __builtin_memcpy((char*)&bb + 8, &b1, 8);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bb, acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bb, acc[nb], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // the g_hard tile is complete
+        {
+            float4* dst = (float4*)(gh + ((long long)b * hw + px0 + (long long)t * UB_TP) * UB_P);
+            const float4* o4 = (const float4*)OS;
+            dst[tid] = o4[tid];                                        // 320 16-byte pieces: one per thread + one more for wave 0
+            if (wid == 0) dst[256 + tid] = o4[256 + tid];
+        }
+    }
+    // ---- the four waves' g_feat blocks -> one record of the block's slab group (the other records of the group: zero)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* red = (float*)smem;                        // [4 waves][16 parts][64 features]
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(wid * 16 + 4 * lg + i) * 64 + 16 * nb + li] = acc[nb][i];
+    __syncthreads();
+    float* out = gfeat_partial + (((long long)b * nslab + (long long)sb * slabs_per_block) * UB_P) * UB_F;
+    for (int i = tid; i < slabs_per_block * UB_P * UB_F; i += 256) {
+        float v = 0.f;
+        if (i < UB_P * UB_F) {
+            const int pp = i >> 6, ff = i & 63;
+            v = (red[pp * 64 + ff] + red[(16 + pp) * 64 + ff]) + (red[(32 + pp) * 64 + ff] + red[(48 + pp) * 64 + ff]);
+        }
+        out[i] = v;
+    }
+}
+
 __global__ void unpool_feat_reduce_kernel(const float* __restrict__ partial, int B, int nslab, int PF, float* __restrict__ gfeat) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * PF) return;
@@ -643,6 +805,30 @@ extern "C" int ups_unpool_bwd(const float* hard, const float* feat, const void* 
     hipStream_t s = (hipStream_t)stream;
     float* partial = g_feat + (long long)B * P * F;
     const size_t esz = dtype == UPS_F32 ? 4 : 2;
+    {   // matrix-core form (round 5): bf16 gradient, 64 features + 10 parts in 80-channel rows, whole 128-pixel tiles
+        const char* e = getenv("UPS_UNPOOL_MFMA");          // (read at every call: the unit test compares both forms)
+        const bool mf_on = !(e && e[0] == '0');
+        const bool al16 = ((((uintptr_t)hard) | ((uintptr_t)g) | ((uintptr_t)g_hard)) & 15) == 0;
+        if (mf_on && dtype == UPS_BF16 && P == UB_P && F == UB_F && ldo == UB_LD && hw % UB_TP == 0 && al16) {
+            const int tiles_img = (int)(hw / UB_TP);
+            // blocks per image: two per CU over the batch, a power of two dividing the tiles and the slab records
+            int bpi = 1;
+            while (2 * bpi <= UNPOOL_SLABS && (long long)B * bpi < 512 && tiles_img % (2 * bpi) == 0) bpi *= 2;
+            static UpsPerDevice am;
+            if (!am) {
+                if (hipFuncSetAttribute((const void*)unpool_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)UB_SHMEM) != hipSuccess)
+                    return UPS_E_LAUNCH;
+                am = true;
+            }
+            hipLaunchKernelGGL(unpool_bwd_mfma_kernel, dim3(B, bpi), dim3(256), UB_SHMEM, s, hard, feat, (const bf16*)g, g_hard, partial,
+                               (long long)hw, tiles_img / bpi, UNPOOL_SLABS / bpi, UNPOOL_SLABS);
+            UPS_LAUNCH_CHECK();
+            const int total = B * P * F;
+            hipLaunchKernelGGL(unpool_feat_reduce_kernel, dim3(ups_cdiv(total, 256)), dim3(256), 0, s, partial, B, UNPOOL_SLABS, P * F, g_feat);
+            UPS_LAUNCH_CHECK();
+            return UPS_OK;
+        }
+    }
     int tpx = 128;
     auto lds_bytes = [&](int t) {
         return ((size_t)4 * P * 64 + 2 * (((size_t)t * (P | 1) + 3) & ~(size_t)3) + (((size_t)P * (F + 1) + 3) & ~(size_t)3)) * sizeof(float)
