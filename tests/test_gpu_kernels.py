@@ -1603,3 +1603,48 @@ def test_unpool_backward_on_the_matrix_cores(B, S, dev, monkeypatch):
         assert_close(res[mode][0], want_h.float(), 1e-5, "unpool d hard (UPS_UNPOOL_MFMA={})".format(mode))
         assert_close(res[mode][1], want_f.float(), 2e-5, "unpool d feat (UPS_UNPOOL_MFMA={})".format(mode), elementwise=False)
     assert_close(res["1"][0], res["0"][0], 1e-5, "MFMA vs VALU form, d hard")
+
+
+@pytest.mark.parametrize("N,H,W,rect", [(3, 128, 128, True), (2, 64, 256, True), (5, 128, 128, False), (64, 32, 128, True)])
+def test_spatial_moments_pixel_per_lane_matches_the_slab_form(N, H, W, rect, dev, monkeypatch):
+    """ups_spatial_moments(_kl) at P = 10 / 128- and 256-wide maps runs pixel-per-lane since round 5 (moments_px_kernel): the same
+    statistics {max, Z, S0, Sy, Sx, Q, Qy} and the same categorical-KL sum as the (part, sub-lane) form it replaces
+    (UPS_MOMENTS_PX=0) and as a torch-fp64 evaluation, one to many 512-pixel tiles per block."""
+    lib, ops, R = _mods()
+    L = lib
+    P, gamma = 10, 10.0
+    g = torch.Generator().manual_seed(N + H + W)
+    x = torch.softmax(2.0 * torch.randn(N, H, W, P, generator=g), -1)
+    px = torch.stack([torch.randint(0, H, (N, P), generator=g), torch.randint(0, W, (N, P), generator=g)], -1).int() if rect else None
+    hh, hw_ = 9, 5
+    xd = x.to(dev)
+    pxd = px.to(dev).contiguous() if rect else None
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("UPS_MOMENTS_PX", mode)
+        nfl = L.load().ups_spatial_moments_floats(N, P)
+        st = torch.full((nfl,), float("nan"), dtype=torch.float32, device=dev)
+        kl = torch.full((16,), float("nan"), dtype=torch.float32, device=dev)
+        L.call("ups_spatial_moments_kl", L.ptr(xd), N, H, W, P, gamma, L.ptr(pxd) if rect else None, hh, hw_, L.ptr(st), L.ptr(kl), L.stream())
+        torch.cuda.synchronize()
+        out[mode] = (st[:N * P * 8].view(N, P, 8).cpu().double(), float(kl[0]), kl[1:].cpu())
+    xv = x.double()
+    e = torch.exp(gamma * xv - (gamma * xv).amax(dim=(1, 2), keepdim=True))
+    gy = torch.linspace(-1, 1, H, dtype=torch.float64).view(1, H, 1, 1)
+    gx = torch.linspace(-1, 1, W, dtype=torch.float64).view(1, 1, W, 1)
+    k = torch.ones_like(xv)
+    if rect:
+        yy = torch.arange(H).view(1, H, 1, 1); xx = torch.arange(W).view(1, 1, W, 1)
+        inside = ((yy - px[:, :, 0].view(N, 1, 1, P)).abs() <= hh) & ((xx - px[:, :, 1].view(N, 1, 1, P)).abs() <= hw_)
+        k = (~inside).double()
+    ek = e * k
+    want = torch.stack([(gamma * xv).amax(dim=(1, 2)), e.sum((1, 2)), ek.sum((1, 2)), (ek * gy).sum((1, 2)), (ek * gx).sum((1, 2)),
+                        (ek * (gy * gy + gx * gx)).sum((1, 2)), (ek * gy * gy).sum((1, 2))], -1)
+    want_kl = float((xv * torch.log(P * xv + 1e-20)).sum())
+    for mode, (st, klv, rest) in out.items():
+        assert float(rest.abs().max()) == 0.0
+        assert abs(klv - want_kl) <= 2e-5 * abs(want_kl), (mode, klv, want_kl)
+        scale = want[..., 1:2].abs()           # sums relative to Z (Sy / Sx cross zero)
+        err = ((st[..., :7] - want).abs() / torch.cat([torch.ones_like(scale), scale.expand(-1, -1, 6)], -1)).max()
+        assert float(err) <= 2e-5, (mode, float(err))
+    assert torch.equal(out["1"][0][..., 0], out["0"][0][..., 0])

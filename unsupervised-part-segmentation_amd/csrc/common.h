@@ -193,6 +193,39 @@ template <> __device__ inline void st_from_float<f16>(f16* p, float v) { *p = (f
 template <> __device__ inline void st_from_float<float>(float* p, float v) { *p = v; }
 template <> __device__ inline void st_from_float<bf16>(bf16* p, float v) { *p = (bf16)v; }
 
+// ln(x) for x well above the denormal range (> 1e-37): the bare v_log_f32 (1 ulp on log2) times ln 2, two instructions.  hipcc expands
+// __logf into the denormal-safe, extended-precision sequence (15 instructions) -- in the pixel-per-lane kernels, whose arguments are
+// P * m + 1e-20 or a sum of exponentials >= 1, that was a third of the instruction stream.
+__device__ __forceinline__ float ups_log_fast(float x) { return __builtin_amdgcn_logf(x) * 0.69314718056f; }
+
+// Wave-wide reductions on the DPP data path: four row-local steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: every lane of
+// a 16-lane row then holds the row's result) and four v_readlane for the rows -- 12 VALU / SALU instructions, no LDS, result
+// uniform.  (Until round 5 these were six __shfl_xor steps, which hipcc lowers to ds_bpermute_b32 + s_waitcnt each: the 70
+// reductions at the end of a pixel-per-lane block -- 420 LDS round trips in a dependent chain -- cost more than the block's tiles.)
+__device__ __forceinline__ float ups_dpp(float v, const int ctrl_sel) {
+    const int i = __builtin_bit_cast(int, v);
+    int r;
+    switch (ctrl_sel) {
+        case 0: r = __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xf, 0xf, false); break;      // quad_perm [1,0,3,2]
+        case 1: r = __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xf, 0xf, false); break;      // quad_perm [2,3,0,1]
+        case 2: r = __builtin_amdgcn_update_dpp(i, i, 0x141, 0xf, 0xf, false); break;     // row_half_mirror
+        default: r = __builtin_amdgcn_update_dpp(i, i, 0x140, 0xf, 0xf, false); break;    // row_mirror
+    }
+    return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float ups_row(float v, const int row) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * row));
+}
+// (`_full`: EVERY lane of the wave must be active -- a DPP read of an inactive lane returns the reader's own value and v_readlane
+// whatever the register holds; the shuffle forms below tolerate partial waves: ds_bpermute returns 0 for inactive lanes.)
+__device__ inline float wave_sum_full(float v) {
+    v += ups_dpp(v, 0); v += ups_dpp(v, 1); v += ups_dpp(v, 2); v += ups_dpp(v, 3);
+    return (ups_row(v, 0) + ups_row(v, 1)) + (ups_row(v, 2) + ups_row(v, 3));
+}
+__device__ inline float wave_max_full(float v) {
+    v = fmaxf(v, ups_dpp(v, 0)); v = fmaxf(v, ups_dpp(v, 1)); v = fmaxf(v, ups_dpp(v, 2)); v = fmaxf(v, ups_dpp(v, 3));
+    return fmaxf(fmaxf(ups_row(v, 0), ups_row(v, 1)), fmaxf(ups_row(v, 2), ups_row(v, 3)));
+}
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

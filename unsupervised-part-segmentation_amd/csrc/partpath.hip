@@ -154,6 +154,131 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
     }
 }
 
+// Round 5: the same partial sums pixel-per-lane for P = 10 at 128- / 256-wide maps (the soft map of view 1: 42 MB read once, the
+// launch was VALU-bound at 1.3 TB/s -- 85 instructions per (pixel, part) element in the (part, sub-lane) form above).  Tiles of 512
+// pixels arrive linearly by LDS-DMA (three slots, two tiles in flight); a thread owns two pixels of a tile with its ten parts'
+// running (max, Z, S0, Sy, Sx, Q, Qy) in registers -- one branch-free rescale per part and tile -- and the block leaves ONE record
+// per part (shuffle trees, then the four waves through LDS): the launcher hands moments_combine_kernel `blocks per image` as its
+// slab count.
+template <int P, int LW>
+__global__ __launch_bounds__(256) void moments_px_kernel(const float* __restrict__ x, const int h, const float gamma,
+                                                            const int* __restrict__ rc, const int hh, const int hw_half,
+                                                            const int tiles_per_block, float* __restrict__ partial,
+                                                            float* __restrict__ kl_partial) {
+    static_assert(P % 2 == 0 && ((P / 2) & 1) == 1, "conflict-free 8-byte LDS reads need P / 2 odd");
+    constexpr int W = 1 << LW;
+    constexpr int TPX = 512, TB = TPX * P * 4, PW = TB / 1024 / 4;          // 20 pieces per tile: five per wave
+    static_assert(TB % 4096 == 0, "piece counts");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];    // 3 tiles (2 when the block has only 2), then [4 waves][P][7] + 4 floats
+    float* red = (float*)(smem + min(3, tiles_per_block) * TB);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hwp = h * W, tiles_img = hwp / TPX;
+    const int bpi = tiles_img / tiles_per_block;
+    const int n = blockIdx.x / bpi, bi = blockIdx.x - n * bpi;
+    const int t_begin = bi * tiles_per_block, t_end = t_begin + tiles_per_block;
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned char* src0 = (const unsigned char*)(x + (long long)n * hwp * P);
+    const unsigned voff = (unsigned)lane * 16u;
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        const unsigned base = smem_lds + (unsigned)(((t - t_begin) % 3) * TB);
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            const int q = wid + 4 * k;
+            const unsigned char* src = src0 + (long long)t * TB + q * 1024;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)q * 1024u);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
+        }
+    };
+    issue(t_begin);
+    if (t_begin + 1 < t_end) issue(t_begin + 1);
+    int cy[P], cx[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        cy[c] = rc ? rc[((long long)n * P + c) * 2] : 0;
+        cx[c] = rc ? rc[((long long)n * P + c) * 2 + 1] : 0;
+    }
+    const float sy = h > 1 ? 2.f / (float)(h - 1) : 0.f, sx = W > 1 ? 2.f / (float)(W - 1) : 0.f;
+    float mx[P], Z[P], S0[P], Sy[P], Sx[P], Q[P], Qy[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) { mx[c] = -INFINITY; Z[c] = S0[c] = Sy[c] = Sx[c] = Q[c] = Qy[c] = 0.f; }
+    float kl = 0.f;
+    for (int t = t_begin; t < t_end; ++t) {
+        if (t + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < t_end) issue(t + 2);
+        const float* tile = (const float*)(smem + ((t - t_begin) % 3) * TB);
+        float v0[P], v1[P];
+#pragma unroll
+        for (int c = 0; c < P; c += 2) {
+            const float2 a = *(const float2*)(tile + tid * P + c), b = *(const float2*)(tile + (256 + tid) * P + c);
+            v0[c] = a.x; v0[c + 1] = a.y; v1[c] = b.x; v1[c + 1] = b.y;
+        }
+        // a wave's 64 pixels lie in one row (W >= 64): the row index is wave-uniform (scalar rectangle tests, scalar gy); the thread's
+        // second pixel sits 256 / W rows below the first, in the SAME column
+        const int q0 = t * TPX + tid;
+        const int y0 = __builtin_amdgcn_readfirstlane(q0 >> LW), x0 = q0 & (W - 1), y1 = y0 + 256 / W, x1 = x0;
+        const float gy0 = -1.f + sy * (float)y0, gx0 = -1.f + sx * (float)x0;
+        const float gy1 = -1.f + sy * (float)y1, gx1 = -1.f + sx * (float)x1;
+        const float r0 = gy0 * gy0 + gx0 * gx0, r1 = gy1 * gy1 + gx1 * gx1;
+        const float yy0 = gy0 * gy0, yy1 = gy1 * gy1;
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            const float a = v0[c], b = v1[c];
+            if (kl_partial) kl += a * ups_log_fast((float)P * a + 1e-20f) + b * ups_log_fast((float)P * b + 1e-20f);
+            const float ga = gamma * a, gb = gamma * b;
+            const float nm = fmaxf(mx[c], fmaxf(ga, gb));
+            const float sc = __expf(mx[c] - nm);          // exp(-inf) = 0 on the first tile
+            const float ea = __expf(ga - nm), eb = __expf(gb - nm);
+            float ka = ea, kb = eb;
+            if (rc) {
+                if (abs(y0 - cy[c]) <= hh && abs(x0 - cx[c]) <= hw_half) ka = 0.f;
+                if (abs(y1 - cy[c]) <= hh && abs(x1 - cx[c]) <= hw_half) kb = 0.f;
+            }
+            mx[c] = nm;
+            Z[c] = Z[c] * sc + (ea + eb);
+            S0[c] = S0[c] * sc + (ka + kb);
+            Sy[c] = Sy[c] * sc + (ka * gy0 + kb * gy1);
+            Sx[c] = Sx[c] * sc + (ka * gx0 + kb * gx1);
+            Q[c] = Q[c] * sc + (ka * r0 + kb * r1);
+            Qy[c] = Qy[c] * sc + (ka * yy0 + kb * yy1);
+        }
+    }
+    // ---- one record per part: wave trees (max, then the rescaled sums), the four waves through LDS
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        const float M = wave_max_full(mx[c]);
+        const float sc = __expf(mx[c] - M);
+        const float z = wave_sum_full(Z[c] * sc), s0 = wave_sum_full(S0[c] * sc), s1 = wave_sum_full(Sy[c] * sc), s2 = wave_sum_full(Sx[c] * sc);
+        const float s3 = wave_sum_full(Q[c] * sc), s4 = wave_sum_full(Qy[c] * sc);
+        if (lane == 0) {
+            float* d = red + (wid * P + c) * 7;
+            d[0] = M; d[1] = z; d[2] = s0; d[3] = s1; d[4] = s2; d[5] = s3; d[6] = s4;
+        }
+    }
+    kl = wave_sum_full(kl);
+    if (lane == 0) red[4 * P * 7 + wid] = kl;
+    __syncthreads();
+    if (tid < P) {
+        const int c = tid;
+        float M = red[c * 7];
+        for (int w = 1; w < 4; ++w) M = fmaxf(M, red[(w * P + c) * 7]);
+        float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < 4; ++w) {
+            const float* r = red + (w * P + c) * 7;
+            const float sc = __expf(r[0] - M);
+            for (int k = 0; k < 6; ++k) o[k] += sc * r[1 + k];
+        }
+        float* dst = partial + (((long long)n * bpi + bi) * P + c) * 8;
+        dst[0] = M;
+        for (int k = 0; k < 6; ++k) dst[1 + k] = o[k];
+        dst[7] = 0.f;
+    }
+    if (kl_partial && tid == 0)
+        kl_partial[(long long)n * bpi + bi] = (red[4 * P * 7] + red[4 * P * 7 + 1]) + (red[4 * P * 7 + 2] + red[4 * P * 7 + 3]);
+}
+
 // stats[n][p] = {max, Z, S0, Sy, Sx, Q, Qy, 0} of spatial_softmax(gamma * hard) (no rectangle) from the integer sums of the
 // hard pixels: e = 1 on them, exp(-gamma) elsewhere (all e = 1 when the part owns no pixel); grid sums of the linspace(-1, 1)
 // coordinates in closed form (sum g = 0, sum g^2 = n (n + 1) / (3 (n - 1)))
@@ -650,7 +775,8 @@ __global__ void unpool_feat_reduce_kernel(const float* __restrict__ partial, int
     if (idx >= B * PF) return;
     const int b = idx / PF, r = idx - b * PF;
     float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += partial[((long long)b * nslab + k) * PF + r];
+#pragma unroll 8
+    for (int k = 0; k < nslab; ++k) s += partial[((long long)b * nslab + k) * PF + r];      // (independent loads, one chain of adds)
     gfeat[idx] = s;
 }
 
@@ -715,6 +841,38 @@ static int spatial_moments_launch(const float* x, int32_t n, int32_t h, int32_t 
     hipStream_t s = (hipStream_t)stream;
     // the stats buffer doubles as the workspace: n*P*8 floats of result, then n*MOMENT_SLABS*P*8 floats of per-slab partials and
     // n*MOMENT_SLABS floats of KL partials (ups_spatial_moments_floats)
+    {   // pixel-per-lane form (round 5): P = 10, 128- / 256-wide maps in whole 512-pixel tiles
+        const char* e = getenv("UPS_MOMENTS_PX");
+        const long long hwp = (long long)h * w;
+        if (!(e && e[0] == '0') && P == 10 && (w == 128 || w == 256) && hwp % 512 == 0 && (((uintptr_t)x) & 15) == 0) {
+            const int tiles_img = (int)(hwp / 512);
+            int bpi = 1;          // two blocks per CU over the batch; at most MOMENT_SLABS records per image
+            const char* eb = getenv("UPS_MOMENTS_PX_BLOCKS");
+            const long long want_blocks = eb ? atoll(eb) : 512;
+            while (2 * bpi <= MOMENT_SLABS && (long long)n * bpi < want_blocks && tiles_img % (2 * bpi) == 0) bpi *= 2;
+            float* partial_px = stats + (long long)n * P * 8;
+            float* klp_px = kl_sum ? partial_px + (long long)n * MOMENT_SLABS * P * 8 : nullptr;
+            constexpr size_t shm_max = 3 * (size_t)(512 * 10 * 4) + (4 * 10 * 7 + 4) * sizeof(float);
+            const size_t shm_px = (size_t)(tiles_img / bpi < 3 ? tiles_img / bpi : 3) * (512 * 10 * 4) + (4 * 10 * 7 + 4) * sizeof(float);
+            static UpsPerDevice a7;
+            if (!a7) {
+                if (hipFuncSetAttribute((const void*)moments_px_kernel<10, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_max) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)moments_px_kernel<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_max) != hipSuccess)
+                    return UPS_E_LAUNCH;
+                a7 = true;
+            }
+            if (w == 128)
+                hipLaunchKernelGGL((moments_px_kernel<10, 7>), dim3(n * bpi), dim3(256), shm_px, s, x, h, gamma, rect_c, half_h, half_w,
+                                   tiles_img / bpi, partial_px, klp_px);
+            else
+                hipLaunchKernelGGL((moments_px_kernel<10, 8>), dim3(n * bpi), dim3(256), shm_px, s, x, h, gamma, rect_c, half_h, half_w,
+                                   tiles_img / bpi, partial_px, klp_px);
+            UPS_LAUNCH_CHECK();
+            hipLaunchKernelGGL(moments_combine_kernel, dim3(ups_cdiv(n * P, 4) + 1), dim3(256), 0, s, partial_px, n, bpi, P, stats, klp_px, kl_sum);
+            UPS_LAUNCH_CHECK();
+            return UPS_OK;
+        }
+    }
     const int nslab = MOMENT_SLABS;
     float* partial = stats + (long long)n * P * 8;
     float* klp = kl_sum ? partial + (long long)n * nslab * P * 8 : nullptr;
@@ -820,11 +978,12 @@ extern "C" int ups_unpool_bwd(const float* hard, const float* feat, const void* 
                     return UPS_E_LAUNCH;
                 am = true;
             }
+            // (one record per block, `bpi` records per image: the reduction walks 8 records instead of UNPOOL_SLABS = 32)
             hipLaunchKernelGGL(unpool_bwd_mfma_kernel, dim3(B, bpi), dim3(256), UB_SHMEM, s, hard, feat, (const bf16*)g, g_hard, partial,
-                               (long long)hw, tiles_img / bpi, UNPOOL_SLABS / bpi, UNPOOL_SLABS);
+                               (long long)hw, tiles_img / bpi, 1, bpi);
             UPS_LAUNCH_CHECK();
             const int total = B * P * F;
-            hipLaunchKernelGGL(unpool_feat_reduce_kernel, dim3(ups_cdiv(total, 256)), dim3(256), 0, s, partial, B, UNPOOL_SLABS, P * F, g_feat);
+            hipLaunchKernelGGL(unpool_feat_reduce_kernel, dim3(ups_cdiv(total, 256)), dim3(256), 0, s, partial, B, bpi, P * F, g_feat);
             UPS_LAUNCH_CHECK();
             return UPS_OK;
         }

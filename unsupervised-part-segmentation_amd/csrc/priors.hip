@@ -323,11 +323,11 @@ __global__ __launch_bounds__(256) void prior_fwd_px_kernel(const PriorK p, const
         float se = 0.f;
 #pragma unroll
         for (int c = 0; c < P; ++c) se += __expf(l[c] - mx);
-        const float lse = mx + __logf(se);
+        const float lse = mx + ups_log_fast(se);
 #pragma unroll
         for (int c = 0; c < P; ++c) {
             const float mc = m[c];
-            kl += mc * __logf((float)P * mc + 1e-20f);
+            kl += mc * ups_log_fast((float)P * mc + 1e-20f);
             ent += -(p.entropy_ce ? hv[c] : mc) * (l[c] - lse);
             const float lmc = lm[c];
             const float lrc = vr ? lr[c] : 0.f, ldc = vd ? ld[c] : 0.f;
@@ -351,9 +351,9 @@ __global__ __launch_bounds__(256) void prior_fwd_px_kernel(const PriorK p, const
     // ---- block reduction: wave sums by shuffles, the four waves through LDS, one record per block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    kl = wave_sum(kl); ent = wave_sum(ent); patch = wave_sum(patch); gmrf = wave_sum(gmrf);
+    kl = wave_sum_full(kl); ent = wave_sum_full(ent); patch = wave_sum_full(patch); gmrf = wave_sum_full(gmrf);
 #pragma unroll
-    for (int c = 0; c < P; ++c) { S[c] = wave_sum(S[c]); R[c] = wave_sum(R[c]); Rs[c] = wave_sum(Rs[c]); Rc[c] = wave_sum(Rc[c]); }
+    for (int c = 0; c < P; ++c) { S[c] = wave_sum_full(S[c]); R[c] = wave_sum_full(R[c]); Rs[c] = wave_sum_full(Rs[c]); Rc[c] = wave_sum_full(Rc[c]); }
     if (lane == 0) {
         float* d = red + wid * (4 + 4 * P);
         d[0] = kl; d[1] = ent; d[2] = patch; d[3] = gmrf;
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void prior_bwd1_px_kernel(const PriorK p, c
         for (int c = 0; c < P; ++c) {
             const float mc = m[c];
             const float pm = (float)P * mc;
-            float g = wkl * (__logf(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[c];
+            float g = wkl * (ups_log_fast(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[c];
             const float sq = __expf(p.gamma * mc - kmax[c]);
             if (VAR == 1) {
                 const float ay = gy * gy - muy2[c] * gy - ca[c];
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(256, 1) void prior_bwd0_px_kernel(const PriorK p, c
         float se = 0.f;
 #pragma unroll
         for (int c = 0; c < P; ++c) se += __expf(l[c] - mx);
-        const float lse = mx + __logf(se);
+        const float lse = mx + ups_log_fast(se);
         float qs = 0.f, labsum = 0.f;
 #pragma unroll
         for (int c = 0; c < P; ++c) { qs += m[c] * (l[c] - lse); labsum += hv[c]; }
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256, 1) void prior_bwd0_px_kernel(const PriorK p, c
         for (int c = 0; c < P; ++c) {
             const float mc = m[c];
             const float pm = (float)P * mc;
-            float g = wkl * (__logf(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[c];
+            float g = wkl * (ups_log_fast(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[c];
             float dr = went * (-mc * ((l[c] - lse) - qs));
             if (p.entropy_ce) dr += went * (-(hv[c] - mc * labsum));
             if (VAR == 0) {
