@@ -1648,3 +1648,37 @@ def test_spatial_moments_pixel_per_lane_matches_the_slab_form(N, H, W, rect, dev
         err = ((st[..., :7] - want).abs() / torch.cat([torch.ones_like(scale), scale.expand(-1, -1, 6)], -1)).max()
         assert float(err) <= 2e-5, (mode, float(err))
     assert torch.equal(out["1"][0][..., 0], out["0"][0][..., 0])
+
+
+@pytest.mark.parametrize("N,H,W,eps_on", [(4, 128, 128, True), (2, 64, 256, True), (3, 128, 128, False), (130, 16, 128, True)])
+def test_part_softmax_pixel_per_lane_matches_the_lds_walking_form(N, H, W, eps_on, dev, monkeypatch):
+    """ups_part_softmax(_moments)_fwd at P = 10 runs pixel-per-lane since round 5 (part_softmax_px_kernel): l bit-identical, m to
+    ~1 ulp (exp / rcp + Newton instead of expf and a division), hard mask / bit set / arg-max and the hard-mask moments identical to
+    the form it replaces (UPS_SOFTMAX_PX=0), m against torch-fp64; one to sixteen tiles per block, a tie included."""
+    lib, ops, R = _mods()
+    P, gamma = 10, 10.0
+    g = torch.Generator().manual_seed(N + H + W)
+    mean = torch.randn(N, H, W, P, generator=g) * 2.0
+    eps = torch.randn(N, H, W, P, generator=g) if eps_on else None
+    mean[0, 0, 0, :] = 0.0
+    if eps_on:
+        eps[0, 0, 0, :] = 0.0                      # a ten-way tie: every part is a maximum
+    md, ed = mean.to(dev), (eps.to(dev) if eps_on else None)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("UPS_SOFTMAX_PX", mode)
+        l, m, hard, am, bits, stats = ops.part_softmax(md, ed, want_argmax=True, want_bits=True, moments_gamma=gamma)
+        l2, m2, hard2, _ = ops.part_softmax(md, ed)                     # the launch without moments
+        torch.cuda.synchronize()
+        assert torch.equal(m2, m) and torch.equal(hard2, hard) and torch.equal(l2, l)
+        out[mode] = (l.cpu(), m.cpu(), hard.cpu(), am.cpu(), bits.cpu(), stats.cpu())
+    a, b = out["1"], out["0"]
+    lo = (mean + eps).double() if eps_on else mean.double()
+    mo = torch.softmax(lo, -1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[0], lo.float())
+    assert_close(a[1], mo.float(), 2e-6, "softmax (pixel-per-lane)")
+    assert float((a[1] - b[1]).abs().max()) <= 3e-7
+    assert torch.equal(a[2].argmax(-1), mo.argmax(-1)) or float((a[2].argmax(-1) != mo.argmax(-1)).float().mean()) < 1e-5
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert float(a[2][0, 0, 0].sum()) == float(P) and int(a[4][0, 0, 0]) == (1 << P) - 1 and int(a[3][0, 0, 0]) == 0
+    assert torch.equal(a[5], b[5])

@@ -226,6 +226,13 @@ __device__ inline float wave_max_full(float v) {
     v = fmaxf(v, ups_dpp(v, 0)); v = fmaxf(v, ups_dpp(v, 1)); v = fmaxf(v, ups_dpp(v, 2)); v = fmaxf(v, ups_dpp(v, 3));
     return fmaxf(fmaxf(ups_row(v, 0), ups_row(v, 1)), fmaxf(ups_row(v, 2), ups_row(v, 3)));
 }
+__device__ inline int wave_sum_full_i(int v) {          // (all 64 lanes active, as wave_sum_full)
+    v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

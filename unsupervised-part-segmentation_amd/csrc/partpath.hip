@@ -70,6 +70,165 @@ __global__ __launch_bounds__(256) void part_softmax_kernel(const float* __restri
     if (hard) tile_store_f32(hard + pix0 * P, cnt, P, PP, ts, TileSign());
 }
 
+// Round 5: the same pass pixel-per-lane for P = 10 at 128- / 256-wide maps (the benchmark's [2B, H, W, 10] logits: 419 MB of traffic,
+// 0.51 of the HBM roof in the LDS-walking form above).  mean and eps tiles arrive linearly by LDS-DMA (two slots), a thread owns one
+// pixel with its ten parts in registers (exp / rcp instead of expf and ten divisions), l / m / hard leave through a linear LDS tile
+// with 16-byte stores, arg-max and bit set straight from registers.  Hard-mask moments: a wave's 64 pixels lie in one image row, so
+// per part present in the wave the pixel count is a popcount, the iy sums are scalar products and only ix, ix^2 take a DPP sum;
+// lane 0 adds the five integers into the block's LDS record (exact, order-independent), one record per block.
+template <int P>
+__global__ __launch_bounds__(256, 2) void part_softmax_px_kernel(const float* __restrict__ mean, const float* __restrict__ eps,
+                                                                  float* __restrict__ l, float* __restrict__ m, float* __restrict__ hard,
+                                                                  long long* __restrict__ amax, unsigned* __restrict__ bits,
+                                                                  const int tiles_img, const int tiles_per_block, int* __restrict__ mom,
+                                                                  const int img_w) {
+    static_assert(P % 2 == 0 && ((P / 2) & 1) == 1, "conflict-free 8-byte LDS accesses need P / 2 odd");
+    constexpr int TB = 256 * P * 4, PCS = TB / 1024, PW = 2 * PCS / 4;
+    static_assert(TB % 1024 == 0 && (2 * PCS) % 4 == 0, "piece counts");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* OUT = smem + 2 * 2 * TB;          // (l, m, hard) of the tile
+    int* red = (int*)(smem + 2 * 2 * TB + 3 * TB);   // [P][5]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bpi = tiles_img / tiles_per_block;
+    const int n = blockIdx.x / bpi, bi = blockIdx.x - n * bpi;
+    const int t_begin = bi * tiles_per_block, t_end = t_begin + tiles_per_block;
+    const long long img = (long long)n * tiles_img * 256;                 // first pixel of the image
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned char* g0 = (const unsigned char*)(mean + img * P);
+    const unsigned char* g1 = (const unsigned char*)((eps ? eps : mean) + img * P);
+    const unsigned voff = (unsigned)lane * 16u;
+    const bool has_eps = eps != nullptr;
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        const unsigned base = smem_lds + (unsigned)(((t - t_begin) & 1) * 2 * TB);
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            const int q = wid + 4 * k;
+            const unsigned char* src = (q < PCS ? g0 : g1) + (long long)t * TB + (q < PCS ? q : q - PCS) * 1024;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)q * 1024u);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
+        }
+    };
+    issue(t_begin);
+    if (mom) { for (int i = tid; i < P * 5; i += 256) red[i] = 0; }
+    const bool col_fixed = mom && (256 % img_w) == 0;
+    unsigned mcnt[P], msy[P], msyy[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) mcnt[c] = msy[c] = msyy[c] = 0u;
+    for (int t = t_begin; t < t_end; ++t) {
+        if (t + 1 < t_end) { issue(t + 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const float* tm = (const float*)(smem + ((t - t_begin) & 1) * 2 * TB);
+        const float* te = tm + 256 * P;
+        float v[P];
+#pragma unroll
+        for (int c = 0; c < P; c += 2) {
+            const float2 a = *(const float2*)(tm + tid * P + c);
+            v[c] = a.x; v[c + 1] = a.y;
+        }
+        if (has_eps) {
+#pragma unroll
+            for (int c = 0; c < P; c += 2) {
+                const float2 b = *(const float2*)(te + tid * P + c);
+                v[c] += b.x; v[c + 1] += b.y;
+            }
+        }
+        float* to = (float*)OUT;
+        if (l) {
+#pragma unroll
+            for (int c = 0; c < P; c += 2) *(float2*)(to + tid * P + c) = make_float2(v[c], v[c + 1]);
+        }
+        float mx = v[0];
+#pragma unroll
+        for (int c = 1; c < P; ++c) mx = fmaxf(mx, v[c]);
+        float sm = 0.f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) { v[c] = __expf(v[c] - mx); sm += v[c]; }
+        float r = __builtin_amdgcn_rcpf(sm);
+        r = r * (2.f - sm * r);                       // one Newton step: the quotient to ~1 ulp
+        float mm = 0.f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) { v[c] *= r; mm = fmaxf(mm, v[c]); }
+        unsigned bm = 0u;
+#pragma unroll
+        for (int c = 0; c < P; ++c) bm |= (v[c] == mm) ? (1u << c) : 0u;
+#pragma unroll
+        for (int c = 0; c < P; c += 2) {
+            *(float2*)(to + 256 * P + tid * P + c) = make_float2(v[c], v[c + 1]);
+            if (hard) *(float2*)(to + 2 * 256 * P + tid * P + c) = make_float2((bm >> c) & 1u ? 1.f : 0.f, (bm >> (c + 1)) & 1u ? 1.f : 0.f);
+        }
+        const long long px = img + ((long long)t << 8) + tid;
+        if (amax) amax[px] = (long long)(__ffs(bm) - 1);
+        if (bits) bits[px] = bm;
+        if (mom) {
+            const int q = (t << 8) + tid;
+            const int iy = q / img_w, ix = q - iy * img_w;
+            if (col_fixed) {
+                // the thread's column is the same in every tile of the block (img_w | 256): per part only the pixel count and the
+                // row sums are carried per thread (4 instructions per part and pixel, whatever the masks look like); the column sums
+                // follow as ix * count at the end of the block
+                const unsigned iy2 = (unsigned)(iy * iy);
+#pragma unroll
+                for (int c = 0; c < P; ++c) {
+                    const unsigned bit = (bm >> c) & 1u;
+                    mcnt[c] += bit; msy[c] += bit * (unsigned)iy; msyy[c] += bit * iy2;
+                }
+            } else {
+                const bool one_row = (img_w & 63) == 0;                    // a wave's 64 pixels lie in one image row: scalar iy sums
+                const int iy_u = __builtin_amdgcn_readfirstlane(iy);
+#pragma unroll
+                for (int c = 0; c < P; ++c) {
+                    const bool sel = (bm >> c) & 1u;
+                    const unsigned long long mask = __ballot(sel);
+                    if (mask) {                                                         // (uniform)
+                        const int cnt = __popcll(mask);
+                        const int sx = wave_sum_full_i(sel ? ix : 0), sxx = wave_sum_full_i(sel ? ix * ix : 0);
+                        int sy, syy;
+                        if (one_row) { sy = iy_u * cnt; syy = iy_u * iy_u * cnt; }
+                        else { sy = wave_sum_full_i(sel ? iy : 0); syy = wave_sum_full_i(sel ? iy * iy : 0); }
+                        if (lane == 0) {
+                            int* rr = red + 5 * c;
+                            atomicAdd(rr, cnt); atomicAdd(rr + 1, sy); atomicAdd(rr + 2, sx); atomicAdd(rr + 3, syy); atomicAdd(rr + 4, sxx);
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const float4* o4 = (const float4*)OUT;
+        const long long o16 = (img + ((long long)t << 8)) * P / 4;                     // first 16-byte piece of the tile in a map
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                // l, m, hard: 640 pieces each
+            float* dstp = k == 0 ? l : (k == 1 ? m : hard);
+            if (!dstp) continue;                     // (uniform)
+            float4* dst = (float4*)dstp + o16;
+#pragma unroll
+            for (int j = tid; j < TB / 16; j += 256) dst[j] = o4[k * (TB / 16) + j];
+        }
+    }
+    if (mom) {
+        if (col_fixed) {
+            const int ix = tid % img_w;
+#pragma unroll
+            for (int c = 0; c < P; ++c) {
+                const int cnt = wave_sum_full_i((int)mcnt[c]);
+                if (cnt) {                                                              // (uniform)
+                    const int sy = wave_sum_full_i((int)msy[c]), syy = wave_sum_full_i((int)msyy[c]);
+                    const int sx = wave_sum_full_i(ix * (int)mcnt[c]), sxx = wave_sum_full_i(ix * ix * (int)mcnt[c]);
+                    if (lane == 0) {
+                        int* rr = red + 5 * c;
+                        atomicAdd(rr, cnt); atomicAdd(rr + 1, sy); atomicAdd(rr + 2, sx); atomicAdd(rr + 3, syy); atomicAdd(rr + 4, sxx);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < P * 5; i += 256) mom[((long long)n * bpi + bi) * P * 5 + i] = red[i];
+    }
+}
+
 // ------------------------------------------------------------------ spatial soft-max moments (nn.py:65-71, 1541-1587)
 // partial[n][slab][p][8] = {max, Z, S0, Sy, Sx, Q, Qy, -} relative to the slab max (Q = sum e*k*(gy^2+gx^2), Qy = sum e*k*gy^2)
 // threads = (part c, sub-lane s) with NS = 256 / P sub-lanes per part (250 of 256 lanes busy at P = 10, against 160 with a
@@ -794,11 +953,44 @@ bool allow_big_lds(K kernel, UpsPerDevice& done) {
 
 }  // namespace
 
+// Launch of part_softmax_px_kernel when the shape allows it (P = 10, whole 256-pixel tiles, 16-byte aligned maps); images of
+// img_hw pixels in rows of img_w (no moments: no image structure needed, the pixels are cut into pseudo-images).
+// Returns blocks per image (> 0) when launched, 0 when the caller has to take the generic kernel.
+static int part_softmax_px_launch(const float* mean, const float* eps, float* l, float* m, float* hard, int64_t* argmax,
+                                  uint32_t* hard_bits, long long pixels, int P, int img_w, long long img_hw, int* mom, hipStream_t s) {
+    const char* e = getenv("UPS_SOFTMAX_PX");
+    if ((e && e[0] == '0') || P != 10 || pixels % 256 != 0) return 0;
+    if (((((uintptr_t)mean) | ((uintptr_t)eps) | ((uintptr_t)l) | ((uintptr_t)m) | ((uintptr_t)hard)) & 15) != 0) return 0;
+    if (eps && !l) return 0;
+    if (!mom) { img_w = 128; img_hw = pixels % 16384 == 0 ? 16384 : 256; }
+    if (img_hw % 256 != 0 || pixels % img_hw != 0 || img_w < 1) return 0;
+    const int tiles_img = (int)(img_hw / 256);
+    const long long n = pixels / img_hw;
+    // blocks per image: two blocks per CU over the batch; at most 32 tiles per block (int32 sums of iy^2 over <= 8192 pixels of rows
+    // < 2^11); the block records must fit the caller's scratch (one record per 512 pixels: ups_part_softmax_moments_ints)
+    int bpi = 1;
+    while ((n * bpi < 512 || tiles_img / bpi > 32) && tiles_img % (2 * bpi) == 0 && 2 * bpi * 512 <= img_hw) bpi *= 2;
+    if (tiles_img / bpi > 32 || (mom && img_hw / img_w > 256)) return 0;      // (int32 sums of iy^2: rows < 256, <= 8192 pixels per block)
+    constexpr size_t shm = (2 * 2 + 3) * (size_t)(256 * 10 * 4) + 10 * 5 * sizeof(int);
+    static UpsPerDevice at;
+    if (!at) {
+        if (hipFuncSetAttribute((const void*)part_softmax_px_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return 0;
+        at = true;
+    }
+    hipLaunchKernelGGL((part_softmax_px_kernel<10>), dim3((unsigned)(n * bpi)), dim3(256), shm, s, mean, eps, l, m, hard,
+                       (long long*)argmax, (unsigned*)hard_bits, tiles_img, tiles_img / bpi, mom, img_w);
+    return bpi;
+}
+
 extern "C" int ups_part_softmax_fwd(const float* mean, const float* eps, float* l, float* m, float* hard, int64_t* argmax,
                                     uint32_t* hard_bits, int64_t pixels, int32_t P, void* stream) {
     UPS_CHECK_ARG(mean && m && pixels > 0 && P >= 1 && P <= 64);
     UPS_CHECK_ARG(!hard_bits || P <= 32);
     hipStream_t s = (hipStream_t)stream;
+    if (part_softmax_px_launch(mean, eps, l, m, hard, argmax, hard_bits, pixels, P, 0, 0, nullptr, s) > 0) {
+        UPS_LAUNCH_CHECK();
+        return UPS_OK;
+    }
     const int tpx = tile_pixels(P, 1, 24 * 1024);
     const int grid = ups_cdiv(pixels, tpx);
     const size_t shm = (size_t)tpx * (P | 1) * sizeof(float);
@@ -822,6 +1014,16 @@ extern "C" int ups_part_softmax_moments_fwd(const float* mean, const float* eps,
     const long long pixels = (long long)n * h * w;
     const int tpx = tile_pixels(P, 1, 24 * 1024);
     UPS_CHECK_ARG((h * w) % tpx == 0);           // a tile never straddles two images
+    {
+        const int bpi = part_softmax_px_launch(mean, eps, l, m, hard, argmax, hard_bits, pixels, P, w, (long long)h * w, (int*)scratch, s);
+        if (bpi > 0) {
+            UPS_LAUNCH_CHECK();
+            hipLaunchKernelGGL(hard_moments_finalize_kernel, dim3(ups_cdiv((long long)n * P, 4)), dim3(256), 0, s, (const int*)scratch, n,
+                               bpi, P, h, w, gamma, stats);
+            UPS_LAUNCH_CHECK();
+            return UPS_OK;
+        }
+    }
     const int grid = ups_cdiv(pixels, tpx);
     const size_t shm = (size_t)tpx * (P | 1) * sizeof(float) + (size_t)P * 5 * sizeof(int);
     hipLaunchKernelGGL(part_softmax_kernel, dim3(grid), dim3(256), shm, s, mean, eps, l, m, hard, (long long*)argmax,
