@@ -28,7 +28,7 @@ extern "C" {
 /* 2: ups_conv_desc grew by out_act / res_act, ups_wgrad_desc by in_f16, UPS_F16 was added (round 3) -- a stale library
  * built against the older structs ignores those fields silently, so the loader also compares ups_struct_sizes().
  * 3: ups_wgrad_desc grew by dout_f8 / dout_f8_scale / in_f8_scale / in_f8_amax (the fp8 weight gradient, round 5). */
-#define UPS_ABI_VERSION 3
+#define UPS_ABI_VERSION 4
 
 /* UPS_F16 (IEEE half): element type of FORWARD tensors of precision-critical scopes (the mask decoder): ups_conv_igemm,
  * ups_weight_prep(_batch), ups_bilinear2x_fwd, ups_convert / ups_pad_convert accept it; gradients are never fp16 (range): the
@@ -131,9 +131,22 @@ typedef struct {
      *            the residual stream x + conv(act(x)) of N:1042-1056 with x stored as act(x).  UPS_ACT_LRELU or UPS_ACT_NONE.
      * Gradients are always with respect to the pre-activation values: nothing changes in the backward calls. */
     int32_t      out_act, res_act;
+    /* Bit-packed activation signs (ABI 4).  An input-gradient launch needs ONE bit of every element of the layer's forward input --
+     * the sign, for act' -- and used to re-read the whole 16-bit tensor for it (`dact`).
+     *   sign_out   forward call, 16-bit `out` [n, out_h, out_w, ldo] with ldo % 8 == 0, plain (unstrided, no d2s) output: also
+     *              write bits[n][out_h][out_w][ldo / 8] bytes, bit e of byte j = (out[..., 8 j + e] > 0) of the STORED value
+     *              (with out_act: of act(value), which has the value's sign).  BEST EFFORT: written by the kernels that have the
+     *              output tile in hand (the 16-bit patch kernel); a launch that went to another kernel leaves the buffer untouched
+     *              (a pass over `out` would cost the read the bits save) -- ups_conv_sign_out_written() tells, ups_sign_pack packs.
+     *   dact_bits  backward call with `dact`: the same bytes for the tensor `dact` points to ([n, out_h, out_w, ldd / 8]); kernels
+     *              that can (the 16-bit patch kernel) read them INSTEAD of `dact`, the others ignore them.  `dact` stays mandatory. */
+    void*        sign_out;
+    const void*  dact_bits;
 } ups_conv_desc;
 
 int ups_conv_igemm(const ups_conv_desc* d, void* stream);
+/* 1 when the calling thread's last ups_conv_igemm call wrote its ups_conv_desc.sign_out buffer, else 0 */
+int ups_conv_sign_out_written(void);
 
 /* Weights of the depth-to-space input gradient of a 3x3 / stride-2 'SAME' convolution with forward variable V [3][3][cin_v][co]:
  * w[t9][k][(py*2+px)*C + c][32] (blocked-K over the co gradient channels, bf16), t9 = (dy+1)*3 + (dx+1) the 3x3 neighbourhood of
@@ -253,6 +266,12 @@ int ups_crop_bwd(const void* gy, void* gx, int32_t dtype, int32_t n, int32_t h, 
 /* y = act(bilinear x2 of x): the up-sampled tensor in post-activation storage (ups_conv_desc.out_act) for a consuming residual block */
 int ups_bilinear2x_fwd_act(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t act, float slope,
                            void* stream);
+/* ... the same, also writing the sign bits of the stored values (ups_conv_desc.sign_out layout: [n][2h][2w][c / 8] bytes);
+ * 16-bit dtypes. */
+int ups_bilinear2x_fwd_bits(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t act, float slope,
+                            void* sign_bits, void* stream);
+/* bits[i] = sign byte of the 8 elements x[8 i .. 8 i + 7] (16-bit dtype), chunks = elements / 8 */
+int ups_sign_pack(const void* x, int32_t dtype, int64_t chunks, void* sign_bits, void* stream);
 /* The same (bf16) with an fp8 copy of the result for a consuming fp8 convolution (ups_conv_desc.in_f8): max |act(y)| goes to
  * amax[64]; with y_f8 != NULL also e4m3 (e5m2 != 0: e5m2) of act(y) * *scale, one byte per element, laid out like y. */
 int ups_bilinear2x_fwd_f8(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void* y_f8, const float* scale,

@@ -1682,3 +1682,67 @@ def test_part_softmax_pixel_per_lane_matches_the_lds_walking_form(N, H, W, eps_o
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
     assert float(a[2][0, 0, 0].sum()) == float(P) and int(a[4][0, 0, 0]) == (1 << P) - 1 and int(a[3][0, 0, 0]) == 0
     assert torch.equal(a[5], b[5])
+
+
+def _pack_signs(t16):
+    """[.., c] 16-bit tensor (bf16, or fp16 in a bf16 container) -> [.., c / 8] uint8, bit e of byte j = element 8 j + e > 0."""
+    pos = (t16.view(torch.int16) > 0).view(*t16.shape[:-1], -1, 8).to(torch.uint8)
+    return (pos * (2 ** torch.arange(8, device=t16.device, dtype=torch.uint8))).sum(-1).to(torch.uint8).contiguous()
+
+
+@pytest.mark.parametrize("n,h,cin,cout,k,stride,f16", [(4, 32, 64, 64, 3, 1, False), (2, 64, 256, 256, 3, 1, True), (3, 28, 64, 64, 3, 1, False),
+                                                       (8, 8, 128, 128, 3, 1, False), (4, 32, 64, 128, 1, 1, False), (4, 32, 64, 64, 3, 2, False),
+                                                       (2, 32, 16, 24, 3, 1, False)])
+def test_sign_bits_written_by_the_producer_and_read_by_the_input_gradient(n, h, cin, cout, k, stride, f16, dev):
+    """ups_conv_desc.sign_out / dact_bits (ABI 4): a forward launch also writes one bit per stored element (> 0), whatever kernel
+    runs it (the patch kernel's epilogue, or the pass over the output behind the other kernels); an input-gradient launch that is
+    handed the bits of its forward input returns exactly what it returns from the input itself."""
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(n + h + cin + cout)
+    V = (torch.randn(k, k, cin, cout, generator=g) / math.sqrt(k * k * cin)).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    lay = ops.ConvLayer("t/conv2d_0", V, b, k, stride, False, "leaky_relu")
+    lay.f16 = f16
+    lay.in_post, lay.out_act = True, lib.ACT_LRELU
+    fmt = lib.F16 if f16 else None
+    x = torch.randn(n, h, h, ops.round8(cin), device=dev)
+    x = torch.where(x > 0, x, 0.2 * x)                      # a post-activation tensor
+    x[0, 0, 0, :8] = 0.0                                    # zeros are not positive
+    xs = x.to(torch.float16).view(torch.bfloat16) if f16 else x.to(torch.bfloat16)
+    res = xs if (cin == cout and stride == 1 and k == 3) else None
+    ops.SignBits.want, ops.SignBits.last = True, None
+    y = ops.conv_forward(xs, lay, res=res, fmt=fmt, res_post=res is not None)
+    bits = ops.SignBits.take()
+    on_patch = k == 3 and stride == 1             # (best effort: only the patch kernel's epilogue writes them)
+    assert (bits is not None) == on_patch
+    if bits is None:                              # ... and ups_sign_pack packs what another kernel stored
+        bits = torch.empty(tuple(y.shape[:-1]) + (y.shape[-1] // 8,), dtype=torch.uint8, device=dev)
+        lib.call("ups_sign_pack", lib.ptr(y), lib.F16 if f16 else lib.BF16, y.numel() // 8, lib.ptr(bits), lib.stream())
+    assert tuple(bits.shape) == tuple(y.shape[:-1]) + (y.shape[-1] // 8,)
+    assert torch.equal(bits, _pack_signs(y))
+    assert float((y.view(torch.float16).float() if f16 else y.float())[..., :cout].abs().max()) > 0
+    # the input gradient: bits of x instead of x
+    gy = torch.randn(y.shape, device=dev).to(torch.bfloat16)
+    xb = _pack_signs(xs)
+    ref = ops.conv_dgrad(gy, xs, lay, res=gy if res is not None else None)
+    got = ops.conv_dgrad(gy, xs, lay, res=gy if res is not None else None, x_bits=xb)
+    assert torch.equal(ref, got)
+    if k == 3 and stride == 1 and cin % 16 == 0 and cin >= 64:          # on the patch kernel the bits are what is read: flip them all
+        flipped = ops.conv_dgrad(gy, xs, lay, res=gy if res is not None else None, x_bits=~xb)
+        assert not torch.equal(ref, flipped)
+
+
+def test_bilinear_sign_bits(dev):
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(3)
+    for f16 in (False, True):
+        x = torch.randn(2, 16, 16, 64, generator=g).to(dev)
+        xs = x.to(torch.float16).view(torch.bfloat16) if f16 else x.to(torch.bfloat16)
+        fmt = lib.F16 if f16 else None
+        ops.SignBits.want, ops.SignBits.last = False, None
+        y0 = ops.BilinearFn.apply(xs, None, 0, 0.2, fmt, lib.ACT_LRELU)
+        assert ops.SignBits.take() is None
+        ops.SignBits.want = True
+        y1 = ops.BilinearFn.apply(xs, None, 0, 0.2, fmt, lib.ACT_LRELU)
+        bits = ops.SignBits.take()
+        assert torch.equal(y0, y1) and bits is not None and torch.equal(bits, _pack_signs(y1))

@@ -54,6 +54,8 @@ struct PatchK {
     unsigned long long tap_off, tap_wi;   // 4 bits per tap: (dy+1)<<2|(dx+1) ; weight slice
     const void* in; const void* wgt; void* out;
     const float* bias; const float* coord_tab; const void* res; const void* dact;
+    // bit-packed activation signs (ups_conv_desc.sign_out / dact_bits, ABI 4): [n][h][w][ld / 8] bytes
+    unsigned char* sign_out; const unsigned char* dact_bits;
     // part-masked input / mask gradient (ups_conv_desc.mask_*): mask_B > 0 switches the block order to (image b, tile, part)
     // with the part fastest, so that the P blocks that read one view patch / write one g_hard line run back to back on one XCD
     const unsigned* mask; float* mask_grad; const float* mask_view;
@@ -1034,7 +1036,12 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                     const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
                     if (ch * 8 < c_lim && pix_ok(px)) {
                         if (res) *(uint4*)(R0 + px * ERS + ch * 16) = *(const uint4*)(res + gaddr(px, nt * BN + ch * 8, p.ldr));
-                        if (dact) {
+                        if (dact && p.dact_bits) {
+                            // round 5: the byte the loop below would derive from 16 bytes of the forward input arrives packed (one bit per
+                            // element, written by the tensor's producer): 1.07 GB less per launch of the roofline layer, no compares
+                            R1[px * CPR + ch] = p.dact_bits[((unsigned long long)img_pix + gpix(px)) * (unsigned)(p.ldd >> 3) +
+                                                            (unsigned)((nt * BN + ch * 8) >> 3)];
+                        } else if (dact) {
                             const uint4 dv = *(const uint4*)(dact + gaddr(px, nt * BN + ch * 8, p.ldd));
                             const unsigned wv[4] = {dv.x, dv.y, dv.z, dv.w};
                             unsigned sb = 0;
@@ -1170,6 +1177,17 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                     const uint4 u = *(const uint4*)(R0 + px * ERS + ch * 16);
                     const unsigned ga = gaddr(px, nt * BN + ch * 8, p.ldo);
                     *(uint4*)(outT + ga) = u;
+                    if (p.sign_out) {          // (uniform) bit e = stored element e > 0: positive and non-zero as a 16-bit integer
+                        const unsigned wv[4] = {u.x, u.y, u.z, u.w};
+                        unsigned sb = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            sb |= ((short)(wv[k] & 0xffffu) > 0 ? 1u : 0u) << (2 * k);
+                            sb |= (((int)wv[k] >> 16) > 0 ? 1u : 0u) << (2 * k + 1);
+                        }
+                        p.sign_out[((unsigned long long)img_pix + gpix(px)) * (unsigned)(p.ldo >> 3) + (unsigned)((nt * BN + ch * 8) >> 3)] =
+                            (unsigned char)sb;
+                    }
                     // fp8 copy for the consumer (uniform branch; not compiled into the 128-wide bf16 kernel at two blocks per CU, which
                     // has no register to spare -- the launcher keeps producers off it): act(out) -> max -> * scale -> 8 bytes
                     if (EMITS && p.out_f8_amax) {
@@ -1433,6 +1451,12 @@ int launch_t(const PatchK& k, hipStream_t s) {
 
 }  // namespace
 
+// Does a launch of this kernel take the staged 16-bit epilogue on a plain lattice -- the one that writes ups_conv_desc.sign_out and
+// reads ups_conv_desc.dact_bits?  (conv_igemm.hip packs the signs in a separate pass when the launch that ran did not.)
+bool ups_conv3x3_patch_signs(const ups_conv_desc* d) {
+    return d->dtype != UPS_F32 && !d->out_f32 && (d->ldo & 7) == 0 && (d->co_fill & 7) == 0 && !d->d2s && !d->mask_grad && !d->mask_bits;
+}
+
 // Internal entry used by ups_conv_igemm's dispatcher (conv_igemm.hip). Returns 1 if the problem is not eligible.
 int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox)
@@ -1507,6 +1531,9 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
     k.ldo = d->ldo; k.ldr = d->ldr; k.ldd = d->ldd; k.act_in = d->act_in; k.out_f32 = d->out_f32;
     k.dact_kind = d->dact_kind; k.has_ctab = d->coord_tab != nullptr; k.act_slope = d->act_slope;
     k.in = d->in; k.wgt = d->w; k.out = d->out; k.bias = d->bias; k.coord_tab = d->coord_tab; k.res = d->res; k.dact = d->dact;
+    // sign bits: only the staged 16-bit epilogue writes / reads them (ups_conv3x3_patch_signs says when that one runs)
+    k.sign_out = ups_conv3x3_patch_signs(d) ? (unsigned char*)d->sign_out : nullptr;
+    k.dact_bits = (d->dact && ups_conv3x3_patch_signs(d) && (d->ldd & 7) == 0) ? (const unsigned char*)d->dact_bits : nullptr;
     bool fwd = true, flip = true;
     {
         for (int t = 0; t < 9; ++t) {

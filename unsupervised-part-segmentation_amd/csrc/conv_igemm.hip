@@ -466,6 +466,15 @@ int launch(const ups_conv_desc& dd, hipStream_t s) {
 }  // namespace
 
 int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_patch.hip
+bool ups_conv3x3_patch_signs(const ups_conv_desc* d);               // conv3x3_patch.hip
+extern "C" int ups_sign_pack(const void* x, int32_t dtype, int64_t chunks, void* sign_bits, void* stream);   // pointwise.hip
+
+// ups_conv_desc.sign_out is written by the kernels that have the output tile in hand (the 16-bit patch kernel); a launch that went to
+// another kernel leaves it untouched -- a pass over the finished output would cost the read the bits are there to save -- and says
+// so: ups_conv_sign_out_written() reports on the calling thread's last ups_conv_igemm call.
+static thread_local int g_sign_written = 0;
+extern "C" int ups_conv_sign_out_written(void) { return g_sign_written; }
+static int sign_out_pass(const ups_conv_desc* d, void* stream) { (void)d; (void)stream; g_sign_written = 0; return UPS_OK; }
 int ups_conv3x3_first_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_first.hip
 int ups_conv3x3_s2_try(const ups_conv_desc* d, hipStream_t s);      // conv3x3_s2.hip
 int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s);    // conv3x3_rows.hip
@@ -491,20 +500,24 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(!d->coord_tab || (d->kh * d->kw == d->ntaps && d->kh <= 3 && d->kw <= 3));
     UPS_CHECK_ARG(((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->w & 15) == 0);
     UPS_CHECK_ARG((d->out_sy * (d->ho - 1) + d->out_oy) < d->out_h && (d->out_sx * (d->wo - 1) + d->out_ox) < d->out_w);
+    if (d->sign_out) {      // sign bits of a plain 16-bit output tensor
+        UPS_CHECK_ARG(d->dtype != UPS_F32 && !d->out_f32 && (d->ldo & 7) == 0 && d->out && !d->d2s && !d->mask_grad);
+        UPS_CHECK_ARG(d->out_sy == 1 && d->out_sx == 1 && !d->out_oy && !d->out_ox && d->out_h == d->ho && d->out_w == d->wo);
+    }
     // 3x3 / stride-1 problems on 16-aligned images go to the patch-tiled kernel (halo reuse across the 9 taps)
     const char* force = getenv("UPS_FORCE_GENERIC_CONV");
     if (!(force && force[0] == '1')) {
         // first layers (<= 8 input channels, 32 / 64 outputs): the im2col-in-the-fragment kernel, an output-write stream
-        if (ups_conv3x3_first_try(d, (hipStream_t)stream) == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
+        if (ups_conv3x3_first_try(d, (hipStream_t)stream) == 0) { UPS_LAUNCH_CHECK(); return sign_out_pass(d, stream); }
         // the large 3x3 / stride-2 `downsample` forwards (32 / 64 input channels): taps straight from global memory, no gather
         {
             const int rr = ups_conv3x3_rows_s2_try(d, (hipStream_t)stream);      // (the two encoder shapes as row streams)
-            if (rr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
+            if (rr == 0) { UPS_LAUNCH_CHECK(); return sign_out_pass(d, stream); }
             if (rr < 0) { ups_set_error("ups_conv_igemm: row-streaming stride-2 kernel launch setup failed"); return rr; }
         }
         {
             const int sr = ups_conv3x3_s2_try(d, (hipStream_t)stream);
-            if (sr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
+            if (sr == 0) { UPS_LAUNCH_CHECK(); return sign_out_pass(d, stream); }
             if (sr < 0) { ups_set_error("ups_conv_igemm: stride-2 kernel launch setup failed"); return sr; }
         }
         // thin residual blocks on large batches of full-width rows: the row-streaming kernel; the K-deep logit convolution: its
@@ -513,11 +526,11 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
             int rr = ups_conv3x3_thinout_try(d, (hipStream_t)stream);
             if (rr == 1) rr = ups_conv3x3_rows_try(d, (hipStream_t)stream);
             if (rr == 1) rr = ups_conv3x3_rows_maskgrad_try(d, (hipStream_t)stream);
-            if (rr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
+            if (rr == 0) { UPS_LAUNCH_CHECK(); return sign_out_pass(d, stream); }
             if (rr < 0) { ups_set_error("ups_conv_igemm: row-streaming kernel launch setup failed"); return rr; }
         }
         const int pr = ups_conv3x3_patch_try(d, (hipStream_t)stream);
-        if (pr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
+        if (pr == 0) { UPS_LAUNCH_CHECK(); g_sign_written = (d->sign_out && ups_conv3x3_patch_signs(d)) ? 1 : 0; return UPS_OK; }
         if (pr < 0) { ups_set_error("ups_conv_igemm: patch kernel launch setup failed"); return pr; }
     }
     if (d->d2s) {
@@ -540,5 +553,5 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
              : (d->dtype == UPS_F16 ? launch<f16>(*d, (hipStream_t)stream) : launch<bf16>(*d, (hipStream_t)stream));
     if (rc != UPS_OK) { ups_set_error("ups_conv_igemm: bad problem size"); return rc; }
     UPS_LAUNCH_CHECK();
-    return UPS_OK;
+    return sign_out_pass(d, stream);
 }

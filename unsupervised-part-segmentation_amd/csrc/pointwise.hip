@@ -116,15 +116,29 @@ template <typename T, bool EMIT = false>
 // ons >= 0: the stored value is max(v, ons * v) (post-activation storage of the up-sampled tensor, ups_bilinear2x_fwd_act); the
 // interpolation itself always runs on the un-activated values
 __global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, F8Emit q = F8Emit(),
-                                      float ons = -1.f) {
+                                      float ons = -1.f, unsigned char* __restrict__ sbits = nullptr) {
+    // sbits (16-bit T): the sign byte of every stored 8-element chunk (ups_conv_desc.sign_out layout), for the input gradient of the
+    // convolution that consumes the up-sampled tensor
     auto stv = [&](T* ptr, const float* v) __attribute__((always_inline)) {
-        if (ons >= 0.f) {
-            float t[V16<T>::N];
+        float t[V16<T>::N];
 #pragma unroll
-            for (int e = 0; e < V16<T>::N; ++e) t[e] = ups_vmax(v[e], ons * v[e]);
-            V16<T>::st(ptr, t);
+        for (int e = 0; e < V16<T>::N; ++e) t[e] = ons >= 0.f ? ups_vmax(v[e], ons * v[e]) : v[e];
+        if constexpr (sizeof(T) == 2) {
+            const uint4 u = Chunk<T>::pack(t);
+            *(uint4*)ptr = u;
+            if (sbits) {
+                // (the sign of the STORED 16-bit value: a tiny positive fp32 that rounds to zero must not count as positive)
+                const unsigned wv[4] = {u.x, u.y, u.z, u.w};
+                unsigned sb = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    sb |= ((short)(wv[k] & 0xffffu) > 0 ? 1u : 0u) << (2 * k);
+                    sb |= (((int)wv[k] >> 16) > 0 ? 1u : 0u) << (2 * k + 1);
+                }
+                sbits[(ptr - y) >> 3] = (unsigned char)sb;
+            }
         } else {
-            V16<T>::st(ptr, v);
+            V16<T>::st(ptr, t);
         }
     };
     constexpr int E = V16<T>::N;
@@ -217,6 +231,21 @@ __global__ void act_mean_bwd_kernel(const T* __restrict__ x, const T* __restrict
     const int b = (int)(idx / ((long long)hw * c));
     const float g = ld_as_float<T>(gy + (long long)b * c + ch) / (float)hw;
     st_from_float<T>(gx + idx, g * ups_dact(ld_as_float<T>(x + idx), act, slope));
+}
+
+// ------------------------------------------------------------------ sign bytes of a stored 16-bit tensor (ups_conv_desc.sign_out)
+__global__ void sign_pack_kernel(const uint4* __restrict__ x, unsigned char* __restrict__ bits, long long chunks) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 u = x[i];
+        const unsigned wv[4] = {u.x, u.y, u.z, u.w};
+        unsigned sb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sb |= ((short)(wv[k] & 0xffffu) > 0 ? 1u : 0u) << (2 * k);
+            sb |= (((int)wv[k] >> 16) > 0 ? 1u : 0u) << (2 * k + 1);
+        }
+        bits[i] = (unsigned char)sb;
+    }
 }
 
 // ------------------------------------------------------------------ elu (nn.py:747-758): the one activation that is materialised
@@ -565,6 +594,25 @@ extern "C" int ups_bilinear2x_bwd(const void* gy, void* gx, int32_t dtype, int32
     hipStream_t s = (hipStream_t)stream;
     if (dtype == UPS_F32) hipLaunchKernelGGL(bilinear2x_bwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, s, (const float*)gy, (float*)gx, n, h, w, c);
     else hipLaunchKernelGGL(bilinear2x_bwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)gy, (bf16*)gx, n, h, w, c);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_bilinear2x_fwd_bits(const void* x, void* y, int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, int32_t act,
+                                       float slope, void* sign_bits, void* stream) {
+    UPS_CHECK_ARG(x && y && sign_bits && c % 8 == 0 && slope >= 0.f && slope <= 1.f && act >= UPS_ACT_NONE && act <= UPS_ACT_RELU);
+    UPS_CHECK_ARG(dtype == UPS_BF16 || dtype == UPS_F16);
+    const long long work = (long long)n * h * w * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    const float ons = act == UPS_ACT_NONE ? -1.f : (act == UPS_ACT_LRELU ? slope : 0.f);
+    if (dtype == UPS_F16) hipLaunchKernelGGL(bilinear2x_fwd_kernel<f16>, dim3(grid_for(work)), dim3(256), 0, s, (const f16*)x, (f16*)y, n, h, w, c, F8Emit(), ons, (unsigned char*)sign_bits);
+    else hipLaunchKernelGGL(bilinear2x_fwd_kernel<bf16>, dim3(grid_for(work)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n, h, w, c, F8Emit(), ons, (unsigned char*)sign_bits);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+extern "C" int ups_sign_pack(const void* x, int32_t dtype, int64_t chunks, void* sign_bits, void* stream) {
+    UPS_CHECK_ARG(x && sign_bits && chunks > 0 && (dtype == UPS_BF16 || dtype == UPS_F16) && ((uintptr_t)x & 15) == 0);
+    hipLaunchKernelGGL(sign_pack_kernel, dim3(grid_for(chunks)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (unsigned char*)sign_bits,
+                       (long long)chunks);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UPS_LIB", os.path.join(_HERE, "csrc", "libupsparts_hip.so"))   # UPS_LIB: A/B builds
 
-ABI_VERSION = 3               # include/upsparts_hip.h UPS_ABI_VERSION
+ABI_VERSION = 4               # include/upsparts_hip.h UPS_ABI_VERSION
 F32, BF16, F16 = 0, 1, 2      # F16: forward tensors of precision-critical scopes (held in torch.bfloat16 containers, see ops.py)
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_ELU = 0, 1, 2, 3
 ACT = {None: ACT_NONE, "leaky_relu": ACT_LRELU, "relu": ACT_RELU, "elu": ACT_ELU}
@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
                 ("f8_deq", C.c_void_p), ("f8_scale", C.c_void_p), ("f8_amax", C.c_void_p), ("f8_e5m2", C.c_int32),
                 ("in_f8", C.c_void_p), ("out_f8", C.c_void_p), ("out_f8_scale", C.c_void_p), ("out_f8_amax", C.c_void_p),
                 ("out_f8_act", C.c_int32), ("out_f8_e5m2", C.c_int32), ("d2s", C.c_int32),
-                ("out_act", C.c_int32), ("res_act", C.c_int32)]
+                ("out_act", C.c_int32), ("res_act", C.c_int32), ("sign_out", C.c_void_p), ("dact_bits", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -96,6 +96,9 @@ _SIGS = {
     "ups_crop_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "ups_crop_bwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "ups_bilinear2x_fwd_act": ([_P, _P, _I, _I, _I, _I, _I, _I, _F, _P], C.c_int),
+    "ups_bilinear2x_fwd_bits": ([_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P], C.c_int),
+    "ups_sign_pack": ([_P, _I, C.c_int64, _P, _P], C.c_int),
+    "ups_conv_sign_out_written": ([], C.c_int),
     "ups_bilinear2x_fwd_f8": ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _I, _P], C.c_int),
     "ups_bilinear2x_bwd_f8": ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P], C.c_int),
     "ups_act_mean_fwd": ([_P, _P, _I, _I, _I, _I, _I, _F, _P], C.c_int),

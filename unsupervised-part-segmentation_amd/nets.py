@@ -94,9 +94,11 @@ class ParamBank(object):
 
 class Act(object):
     """Activation handle: tensor (None in the shape-only dry run) + logical channel count."""
-    __slots__ = ("t", "n", "h", "w", "c", "mask", "f8", "fmt", "post")
+    __slots__ = ("t", "n", "h", "w", "c", "mask", "f8", "fmt", "post", "bits")
 
-    def __init__(self, t, n, h, w, c, mask=None, f8=None, fmt=None, post=False):
+    def __init__(self, t, n, h, w, c, mask=None, f8=None, fmt=None, post=False, bits=None):
+        # bits: the sign bytes of `t` its producer wrote (ops.SignBits; [n,h,w,ld/8] uint8 or None)
+        self.bits = bits
         # fmt = L.F16: `t` holds fp16 in a bf16 container (ops.py module docstring); None: what t.dtype says
         # post: `t` holds act(x) of its scope's activation instead of x (post-activation storage, ops.ConvLayer.in_post)
         self.fmt, self.post = fmt, post
@@ -162,11 +164,14 @@ class Scope(object):
         if ops.Fp8.enabled:     # hand the input's fp8 copy in, ask for one of the output (consumed with this scope's activation)
             ops.Fp8.next_in, ops.Fp8.next_out_act, ops.Fp8.last_out = x.f8, (self.act if self.act != L.ACT_ELU else None), None
         assert x.fmt == self.fmt and (res is None or res.fmt == self.fmt), "tensor format does not match the scope's"
+        # a post-activation output feeds an activated convolution of this scope: its producer writes the sign bytes that
+        # convolution's input gradient needs (ops.SignBits), and this convolution hands its own input's on
+        ops.SignBits.want, ops.SignBits.last = bool(post), None
         t = ops.conv(x.t, lay, res=None if res is None else res.t, res_self=res_self, out_f32=out_f32, mask=x.mask, fmt=self.fmt,
-                     res_post=bool(res is not None and res.post))
+                     res_post=bool(res is not None and res.post), x_bits=x.bits if (act_in != L.ACT_NONE and x.mask is None) else None)
         f8 = ops.Fp8.last_out if ops.Fp8.enabled else None
         ops.Fp8.last_out = None
-        return Act(t, x.n, ho, wo, cout, f8=f8, fmt=None if out_f32 else self.fmt, post=post)
+        return Act(t, x.n, ho, wo, cout, f8=f8, fmt=None if out_f32 else self.fmt, post=post, bits=ops.SignBits.take())
 
     def nin(self, x, cout, **kw):
         return self.conv2d(x, cout, k=1, **kw)
@@ -193,8 +198,9 @@ class Scope(object):
         if x.t is None:
             return Act(None, x.n, 2 * x.h, 2 * x.w, x.c, fmt=self.fmt, post=post)
         if not ops.Fp8.enabled or self.act == L.ACT_ELU:
-            return Act(ops.BilinearFn.apply(x.t, None, 0, 0.2, self.fmt, self.act if post else 0), x.n, 2 * x.h, 2 * x.w, x.c,
-                       fmt=self.fmt, post=post)
+            ops.SignBits.want, ops.SignBits.last = bool(post), None
+            t = ops.BilinearFn.apply(x.t, None, 0, 0.2, self.fmt, self.act if post else 0)
+            return Act(t, x.n, 2 * x.h, 2 * x.w, x.c, fmt=self.fmt, post=post, bits=ops.SignBits.take())
         # fp8: the up-sampled tensor feeds this scope's next convolution -- hand it an e4m3 copy of act(y) (and, backwards, the
         # convolution below an e5m2 copy of the gradient); per-call-site scale slots live with the model.  A scope whose FORWARD
         # stays fp16 (the mask decoder: its logits decide the masks, fp8 operands cost IoU) keeps the fp16 / post-activation
@@ -202,8 +208,9 @@ class Scope(object):
         sites = self.owner.__dict__.setdefault("f8_sites", {})
         site = sites.setdefault("{}/upsample@{}".format(self.prefix, self.counter), {})
         if self.fmt == L.F16:
-            return Act(ops.BilinearFn.apply(x.t, site, 0, 0.2, self.fmt, self.act if post else 0), x.n, 2 * x.h, 2 * x.w, x.c,
-                       fmt=self.fmt, post=post)
+            ops.SignBits.want, ops.SignBits.last = bool(post), None
+            t = ops.BilinearFn.apply(x.t, site, 0, 0.2, self.fmt, self.act if post else 0)
+            return Act(t, x.n, 2 * x.h, 2 * x.w, x.c, fmt=self.fmt, post=post, bits=ops.SignBits.take())
         ops.Fp8.last_out = None
         t = ops.BilinearFn.apply(x.t, site, self.act, 0.2)
         f8, ops.Fp8.last_out = ops.Fp8.last_out, None

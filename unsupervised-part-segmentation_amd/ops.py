@@ -144,6 +144,22 @@ class WeightVersion(object):
     value = 0
 
 
+class SignBits(object):
+    """Bit-packed activation signs (ups_conv_desc.sign_out / dact_bits, round 5).  The input gradient of a convolution needs one
+    bit of every element of the layer's forward input -- the sign, for act' -- and re-read the whole 16-bit tensor for it.  The
+    PRODUCER of such a tensor (a convolution's epilogue, the x2 bilinear kernel) now also writes [n,h,w,c/8] sign bytes, the handle
+    carries them (nets.Act.bits) and the consuming convolution's backward passes them to ups_conv_igemm next to `dact`.
+    Hand-off like Fp8.last_out: `want` is set by the caller that will keep the bits, `last` by the producer."""
+    ENABLED = os.environ.get("UPS_SIGN_BITS", "1") != "0"
+    want = False
+    last = None
+
+    @classmethod
+    def take(cls):
+        b, cls.last, cls.want = cls.last, None, False
+        return b
+
+
 class PrepRegistry(object):
     """Converted-weight buffers of the layers of a model, refreshed by ONE launch after the optimizer step
     (ups_weight_prep_batch) instead of two small launches per layer and step."""
@@ -672,6 +688,11 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
                     Fp8.stats["fwd_copy_out"] += 1
     Fp8.next_in = Fp8.next_out_act = None
     Fp8.last_out = f8_out
+    SignBits.last = None
+    if SignBits.want and SignBits.ENABLED and not out_f32 and mask is None and out.dtype == torch.bfloat16 and ldo % 8 == 0:
+        SignBits.last = torch.empty((n, ho, wo, ldo // 8), dtype=torch.uint8, device=x.device)
+        d.sign_out = SignBits.last.data_ptr()
+    SignBits.want = False
     _attach_ws(d, x.device)
     assert round8(layer.ci_log) <= ldi, (layer.name, layer.ci_log, ldi)
     if KernelTimer.layer == layer.name and KernelTimer.active():
@@ -684,15 +705,20 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
         KernelTimer.flops = 2.0 * n * ho * wo * layer.k * layer.k * layer.cin_v * layer.co
     else:
         L.call("ups_conv_igemm", C.byref(d), L.stream())
+    if SignBits.last is not None and not L.load().ups_conv_sign_out_written():
+        SignBits.last = None            # the launch went to a kernel that does not write them (best effort: upsparts_hip.h)
     return out
 
 
-def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0, f8_src="pop"):
+def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0, f8_src="pop", x_bits=None):
     """gx = act'(x) * conv^T(g) (+ res);  g [n,ho,wo,ldg] in the activation dtype, x the forward input.
     mask_view (fp32 [B,hi,wi,3], with n_parts): the forward was the part-masked convolution; returns d loss / d hard
     [B,hi,wi,P] = sum_c gx[p*B+b,...,c] * view[b,...,c] straight from the kernel's epilogue (gx is never written).
-    f8_src: the e5m2 copy of g its producer registered (ops.Fp8.grad_copy), None, or "pop" = look it up here."""
+    f8_src: the e5m2 copy of g its producer registered (ops.Fp8.grad_copy), None, or "pop" = look it up here.
+    x_bits: the sign bytes of x its producer wrote ([n,hi,wi,ldi/8] uint8, ops.SignBits): read instead of x for act'."""
     n, hi, wi, ldi = x.shape
+    if x_bits is not None and (tuple(x_bits.shape) != (n, hi, wi, ldi // 8) or layer.act_in == L.ACT_NONE):
+        x_bits = None
     dcode = L.dt(x)
     ho, wo = layer.out_hw(hi, wi)
     ent = layer.prepared(dcode, hi, wi, need_dgrad=True)
@@ -728,6 +754,7 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0, f8_src="pop"):
         d.bias, d.coord_tab = None, None
         d.res = res.data_ptr() if res is not None else None
         d.dact = x.data_ptr() if layer.act_in != L.ACT_NONE else None
+        d.dact_bits = x_bits.data_ptr() if (x_bits is not None and d.dact) else None
         d.d2s = cd2s
         _attach_ws(d, x.device)
         L.call("ups_conv_igemm", C.byref(d), L.stream())
@@ -765,6 +792,7 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0, f8_src="pop"):
         d.bias, d.coord_tab = None, None
         d.res = res.data_ptr() if res is not None else None
         d.dact = x.data_ptr() if layer.act_in != L.ACT_NONE else None
+        d.dact_bits = x_bits.data_ptr() if (x_bits is not None and d.dact) else None
         if mask_view is not None:
             d.mask_grad, d.mask_view, d.mask_batch = g_hard.data_ptr(), mask_view.data_ptr(), n
         elif st == 1 and Fp8.enabled and Fp8.GRAD and g.dtype == torch.bfloat16:
@@ -915,7 +943,8 @@ class ConvFn(torch.autograd.Function):
     """res_mode 0: plain; 1: out = res + conv(x); 2: out = x + conv(act(x)) (residual_block, nn.py:1042-1056)."""
 
     @staticmethod
-    def forward(ctx, x, V, b, res, layer, res_mode, out_f32, ldo, hard=None, hard_bits=None, view_f32=None, fmt=None, res_post=False):
+    def forward(ctx, x, V, b, res, layer, res_mode, out_f32, ldo, hard=None, hard_bits=None, view_f32=None, fmt=None, res_post=False,
+                x_bits=None):
         """hard / hard_bits / view_f32 given: the part-masked convolution (x = the unmasked view in the activation dtype,
         the P*B part images are formed in the kernel's load); the gradient w.r.t. `hard` comes out of the dgrad epilogue."""
         x = x.contiguous()
@@ -926,6 +955,7 @@ class ConvFn(torch.autograd.Function):
                            res_post=layer.in_post if res_mode == 2 else bool(res_post))
         ctx.save_for_backward(x, view_f32)
         ctx.layer, ctx.res_mode, ctx.fmt = layer, res_mode, fmt
+        ctx.x_bits = x_bits             # sign bytes of x from its producer (SignBits): the input gradient reads them instead of x
         return out
 
     @staticmethod
@@ -959,20 +989,21 @@ class ConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[8]:
                 g_hard = conv_dgrad(g, x, layer, mask_view=view_f32, n_parts=ctx.mask[1])
         elif ctx.needs_input_grad[0]:
-            gx = conv_dgrad(g, x, layer, res=g if ctx.res_mode == 2 else None, f8_src=f8_src if layer.stride == 1 else "pop")
+            gx = conv_dgrad(g, x, layer, res=g if ctx.res_mode == 2 else None, f8_src=f8_src if layer.stride == 1 else "pop",
+                            x_bits=ctx.x_bits)
         if ctx.res_mode == 1 and ctx.needs_input_grad[3]:
             # the autograd engine may accumulate other branches into the returned tensor IN PLACE; the side stream
             # is still reading g, so hand out a copy in that case
             gres = g.clone() if offloaded else g
-        return gx, gV, gb, gres, None, None, None, None, g_hard, None, None, None, None
+        return gx, gV, gb, gres, None, None, None, None, g_hard, None, None, None, None, None
 
 
-def conv(x, layer, res=None, res_self=False, out_f32=False, ldo=None, mask=None, fmt=None, res_post=False):
+def conv(x, layer, res=None, res_self=False, out_f32=False, ldo=None, mask=None, fmt=None, res_post=False, x_bits=None):
     """mask = (hard [B,H,W,P] fp32 autograd leaf, hard_bits [B,H,W] int32, view_f32 [B,H,W,3]): part-masked convolution.
-    res_post: `res` is stored post-activation (ups_conv_desc.res_act)."""
+    res_post: `res` is stored post-activation (ups_conv_desc.res_act).  x_bits: the sign bytes of x (SignBits)."""
     mode = 2 if res_self else (1 if res is not None else 0)
     if mask is None:
-        return ConvFn.apply(x, layer.V, layer.b, res, layer, mode, out_f32, ldo, None, None, None, fmt, res_post)
+        return ConvFn.apply(x, layer.V, layer.b, res, layer, mode, out_f32, ldo, None, None, None, fmt, res_post, x_bits)
     assert mode == 0
     return ConvFn.apply(x, layer.V, layer.b, None, layer, 0, out_f32, ldo, mask[0], mask[1], mask[2].contiguous(), None, False)
 
@@ -997,7 +1028,14 @@ class BilinearFn(torch.autograd.Function):
         f8_site = site is not None and Fp8.enabled and Fp8.PRODUCER and x.dtype == torch.bfloat16 and c % 64 == 0 and (2 * h) % 16 == 0
         ctx.site, ctx.shape = (site if f8_site else None), (n, h, w, c)
         if out_act:
-            L.call("ups_bilinear2x_fwd_act", L.ptr(x), L.ptr(y), L.dt(x) if fmt is None else fmt, n, h, w, c, out_act, slope, L.stream())
+            SignBits.last = None
+            if SignBits.want and SignBits.ENABLED and x.dtype == torch.bfloat16 and c % 8 == 0:
+                SignBits.last = torch.empty((n, 2 * h, 2 * w, c // 8), dtype=torch.uint8, device=x.device)
+                L.call("ups_bilinear2x_fwd_bits", L.ptr(x), L.ptr(y), L.dt(x) if fmt is None else fmt, n, h, w, c, out_act, slope,
+                       L.ptr(SignBits.last), L.stream())
+            else:
+                L.call("ups_bilinear2x_fwd_act", L.ptr(x), L.ptr(y), L.dt(x) if fmt is None else fmt, n, h, w, c, out_act, slope, L.stream())
+            SignBits.want = False
             return y
         f8 = f8_site and fmt != L.F16
         if f8 and "fwd" not in site:
