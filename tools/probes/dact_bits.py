@@ -1,8 +1,8 @@
-"""EXPERIMENT (round 5): what would bit-packed activation signs buy the patch kernel's input gradient?  An A/B library
-(conv3x3_patch.hip with a debug hook, not in the tree: docs/design/negative_results.md has the patch) takes the sign bytes of act'
-from a pre-packed [n,h,w,c/8] byte tensor instead of re-reading the forward input (2 B per element for one bit).
-Usage: UPS_LIB=<that library> python tools/probes/dact_bits.py [case]"""
-import ctypes as C, math, os, sys
+"""What bit-packed activation signs buy the patch kernel's input gradient (round 5, ups_conv_desc.dact_bits): the sign bytes of act'
+from a pre-packed [n,h,w,c/8] byte tensor instead of re-reading the forward input (2 B per element for one bit).  The first
+version of this probe, against a debug hook, is what motivated the feature (2.23 -> 2.04 ms on dv_rb128, 0.68 -> 0.56 on dv_rb64).
+Usage: python tools/probes/dact_bits.py [case of tools/bench_conv.py]"""
+import math, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -26,10 +26,6 @@ gy = torch.randn(y.shape, device=dev).to(torch.bfloat16)
 # bit e of byte c / 8 = (x[8 (c / 8) + e] > 0)
 pos = (x > 0).view(n, h, h, -1, 8).to(torch.uint8)
 bits = (pos * (2 ** torch.arange(8, device=dev, dtype=torch.uint8))).sum(-1).to(torch.uint8).contiguous()
-L = lib.load()
-setter = getattr(L, "ups_debug_set_dact_bits", None)
-
-
 def timeit(fn, it=10):
     for _ in range(3):
         fn()
@@ -43,15 +39,7 @@ def timeit(fn, it=10):
 
 
 fn = lambda: ops.conv_dgrad(gy, xb, lay, res=gy)
-ref = fn().clone()
-t0 = timeit(fn)
-print("{} input gradient, act' from the forward input: {:.3f} ms".format(case, t0))
-if setter is not None:
-    setter.argtypes = [C.c_void_p]; setter.restype = None
-    setter(bits.data_ptr())
-    out = fn().clone()
-    t1 = timeit(fn)
-    setter(None)
-    print("{} input gradient, act' from packed sign bits:  {:.3f} ms   identical: {}".format(case, t1, torch.equal(out, ref)))
-else:
-    print("(library without the debug hook)")
+fb = lambda: ops.conv_dgrad(gy, xb, lay, res=gy, x_bits=bits)
+ref, out = fn().clone(), fb().clone()
+print("{} input gradient, act' from the forward input: {:.3f} ms".format(case, timeit(fn)))
+print("{} input gradient, act' from packed sign bits:  {:.3f} ms   identical: {}".format(case, timeit(fb), torch.equal(out, ref)))
