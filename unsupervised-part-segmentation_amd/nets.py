@@ -451,6 +451,7 @@ class VggTrunk(object):
         # maps are packed four to a tile: both stay bf16).  VGG_FP8 = False: the trunk stays bf16 (A/B runs; `vgg_fp8` config key)
         f8 = ops.Fp8.enabled and ops.Fp8.PRODUCER and self.fp8
         h8 = None
+        hb = None       # sign bytes of h from the convolution that produced it (ops.SignBits): the next one's input gradient reads them
         for bi, blk in enumerate(self.layers):
             if bi > 0:
                 if f8:
@@ -460,10 +461,15 @@ class VggTrunk(object):
                     h8, ops.Fp8.last_out = ops.Fp8.last_out, None
                 else:
                     h = ops.MaxPoolFn.apply(h)     # max-pool commutes with ReLU: pool the pre-activations
+                hb = None
             for ci, lay in enumerate(blk):
                 if f8:
                     ops.Fp8.next_in, ops.Fp8.next_out_act, ops.Fp8.last_out = h8, (L.ACT_RELU if ci + 1 < len(blk) else None), None
-                h = ops.ConvFn.apply(h, lay.V, lay.b, None, lay, 0, False, None, None, None, None, None)
+                ops.SignBits.want = bool(torch.is_grad_enabled() and lay.out_act and ci + 1 < len(blk))
+                ops.SignBits.last = None
+                h = ops.ConvFn.apply(h, lay.V, lay.b, None, lay, 0, False, None, None, None, None, None, False,
+                                     hb if lay.in_post else None)
+                hb = ops.SignBits.take()
                 if f8:
                     h8, ops.Fp8.last_out = ops.Fp8.last_out, None
                 if ci == 1:
