@@ -153,6 +153,7 @@ class SignBits(object):
     ENABLED = os.environ.get("UPS_SIGN_BITS", "1") != "0"
     want = False
     last = None
+    stats = None        # a dict when a probe wants to know which input gradients ran without bits (tools/probes/sign_bits_coverage.py)
 
     @classmethod
     def take(cls):
@@ -719,6 +720,9 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0, f8_src="pop", x
     n, hi, wi, ldi = x.shape
     if x_bits is not None and (tuple(x_bits.shape) != (n, hi, wi, ldi // 8) or layer.act_in == L.ACT_NONE):
         x_bits = None
+    if SignBits.stats is not None and layer.act_in != L.ACT_NONE and mask_view is None:
+        key = (layer.name, n, hi, wi, ldi, layer.k, layer.stride, x_bits is not None)
+        SignBits.stats[key] = SignBits.stats.get(key, 0) + 1
     dcode = L.dt(x)
     ho, wo = layer.out_hw(hi, wi)
     ent = layer.prepared(dcode, hi, wi, need_dgrad=True)
