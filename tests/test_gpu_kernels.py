@@ -1692,18 +1692,23 @@ def _pack_signs(t16):
 
 @pytest.mark.parametrize("n,h,cin,cout,k,stride,f16", [(4, 32, 64, 64, 3, 1, False), (2, 64, 256, 256, 3, 1, True), (3, 28, 64, 64, 3, 1, False),
                                                        (8, 8, 128, 128, 3, 1, False), (4, 32, 64, 128, 1, 1, False), (4, 32, 64, 64, 3, 2, False),
-                                                       (2, 32, 16, 24, 3, 1, False)])
-def test_sign_bits_written_by_the_producer_and_read_by_the_input_gradient(n, h, cin, cout, k, stride, f16, dev):
+                                                       (2, 32, 16, 24, 3, 1, False),
+                                                       # shapes the row-stream kernels take when forced: no bits from them, bits ignored
+                                                       (4, 128, 32, 32, 3, 1, False), (2, 128, 64, 64, 3, 1, False), (4, 128, 32, 64, 3, 2, False)])
+def test_sign_bits_written_by_the_producer_and_read_by_the_input_gradient(n, h, cin, cout, k, stride, f16, dev, monkeypatch):
     """ups_conv_desc.sign_out / dact_bits (ABI 4): a forward launch also writes one bit per stored element (> 0), whatever kernel
     runs it (the patch kernel's epilogue, or the pass over the output behind the other kernels); an input-gradient launch that is
     handed the bits of its forward input returns exactly what it returns from the input itself."""
     lib, ops, R = _mods()
+    rows = cin in (32, 64) and h in (64, 128) and k == 3
+    if rows:
+        monkeypatch.setenv("UPS_ROWS_KERNEL", "force")
     g = torch.Generator().manual_seed(n + h + cin + cout)
     V = (torch.randn(k, k, cin, cout, generator=g) / math.sqrt(k * k * cin)).to(dev)
     b = torch.randn(cout, generator=g).to(dev)
-    lay = ops.ConvLayer("t/conv2d_0", V, b, k, stride, False, "leaky_relu")
+    lay = ops.ConvLayer("t/conv2d_0", V, b, k, stride, False, "leaky_relu" if stride == 1 else None)
     lay.f16 = f16
-    lay.in_post, lay.out_act = True, lib.ACT_LRELU
+    lay.in_post, lay.out_act = stride == 1, lib.ACT_LRELU          # (a `downsample` takes its input as it is and stores act(out))
     fmt = lib.F16 if f16 else None
     x = torch.randn(n, h, h, ops.round8(cin), device=dev)
     x = torch.where(x > 0, x, 0.2 * x)                      # a post-activation tensor
@@ -1713,21 +1718,23 @@ def test_sign_bits_written_by_the_producer_and_read_by_the_input_gradient(n, h, 
     ops.SignBits.want, ops.SignBits.last = True, None
     y = ops.conv_forward(xs, lay, res=res, fmt=fmt, res_post=res is not None)
     bits = ops.SignBits.take()
-    on_patch = k == 3 and stride == 1             # (best effort: only the patch kernel's epilogue writes them)
-    assert (bits is not None) == on_patch
+    native = k == 3 and stride == 1 and not rows  # (best effort: only the patch kernel's epilogue writes them)
+    assert (bits is not None) == native
     if bits is None:                              # ... and ups_sign_pack packs what another kernel stored
         bits = torch.empty(tuple(y.shape[:-1]) + (y.shape[-1] // 8,), dtype=torch.uint8, device=dev)
         lib.call("ups_sign_pack", lib.ptr(y), lib.F16 if f16 else lib.BF16, y.numel() // 8, lib.ptr(bits), lib.stream())
     assert tuple(bits.shape) == tuple(y.shape[:-1]) + (y.shape[-1] // 8,)
     assert torch.equal(bits, _pack_signs(y))
     assert float((y.view(torch.float16).float() if f16 else y.float())[..., :cout].abs().max()) > 0
+    if stride != 1:
+        return                                    # (no activation on a downsample's input: its input gradient needs no signs)
     # the input gradient: bits of x instead of x
     gy = torch.randn(y.shape, device=dev).to(torch.bfloat16)
     xb = _pack_signs(xs)
     ref = ops.conv_dgrad(gy, xs, lay, res=gy if res is not None else None)
     got = ops.conv_dgrad(gy, xs, lay, res=gy if res is not None else None, x_bits=xb)
     assert torch.equal(ref, got)
-    if k == 3 and stride == 1 and cin % 16 == 0 and cin >= 64:          # on the patch kernel the bits are what is read: flip them all
+    if k == 3 and stride == 1 and cin % 16 == 0 and cin >= 64 and not rows:   # on the patch kernel the bits are what is read: flip them all
         flipped = ops.conv_dgrad(gy, xs, lay, res=gy if res is not None else None, x_bits=~xb)
         assert not torch.equal(ref, flipped)
 

@@ -22,6 +22,9 @@ void ups_set_error(const char* fmt, ...);
 // hipFuncSetAttribute is per DEVICE: the "already raised the LDS limit of this kernel" flag of a launcher must be too.  Drop-in
 // for the `static bool done = false; if (!done) { ...; done = true; }` idiom: one bit per device ordinal of the calling thread's
 // current device (a second GPU driven from the same process would otherwise launch with > 64 KB of dynamic LDS un-permitted).
+// set by the kernel launchers of ups_conv_igemm that wrote ups_conv_desc.sign_out (conv_igemm.hip; ups_conv_sign_out_written())
+extern thread_local int g_ups_sign_written;
+
 struct UpsPerDevice {
     unsigned long long bits = 0;
     static int cur() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
@@ -197,6 +200,19 @@ template <> __device__ inline void st_from_float<bf16>(bf16* p, float v) { *p = 
 // __logf into the denormal-safe, extended-precision sequence (15 instructions) -- in the pixel-per-lane kernels, whose arguments are
 // P * m + 1e-20 or a sum of exponentials >= 1, that was a third of the instruction stream.
 __device__ __forceinline__ float ups_log_fast(float x) { return __builtin_amdgcn_logf(x) * 0.69314718056f; }
+
+// Sign byte of eight stored 16-bit values (ups_conv_desc.sign_out): bit e = element e > 0, i.e. positive and non-zero as a 16-bit
+// integer (bf16 and fp16 alike).
+__device__ __forceinline__ unsigned ups_sign_byte(const uint4& u) {
+    const unsigned wv[4] = {u.x, u.y, u.z, u.w};
+    unsigned sb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sb |= ((short)(wv[k] & 0xffffu) > 0 ? 1u : 0u) << (2 * k);
+        sb |= (((int)wv[k] >> 16) > 0 ? 1u : 0u) << (2 * k + 1);
+    }
+    return sb;
+}
 
 // Wave-wide reductions on the DPP data path: four row-local steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: every lane of
 // a 16-lane row then holds the row's result) and four v_readlane for the rows -- 12 VALU / SALU instructions, no LDS, result

@@ -1059,6 +1059,17 @@ int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s) {
     k.slope = d->act_slope; k.dact_ns = d->dact_kind == UPS_ACT_LRELU ? d->act_slope : 0.f;
     const bool dg = d->dact != nullptr;
     if (two && dg) {        // (bf16 and flipped taps: checked above)
+        // Round 5: OFF by default (UPS_ROWS2_DG=1 turns it back on for A/B runs).  The act' operand of this form arrives by inline-asm
+        // register loads with a hand-counted wait; hipcc is free to MOVE those registers before the wait statement, and does
+        // (tools/check_asm_loads.py: `v_mov_b64 v[236:237], v[186:187]` 114 instructions after the load, seven more just ahead of
+        // the wait) -- the kernel then multiplies by whatever the register held when it was copied.  It has always passed its parity
+        // tests because the loads land within those ~114 instructions in practice, but nothing guarantees that, and one more
+        // conditional store in the kernel moved a copy forward far enough to corrupt 0.1 % of the elements.  These launches (VGG
+        // block 1, the hourglass decoder's 128-wide levels, the 256 x 256 configs' first residual block) take the patch kernel, whose
+        // input gradient reads the producer's sign bytes since this round.
+        static int on = -1;
+        if (on < 0) { const char* e = getenv("UPS_ROWS2_DG"); on = (e && e[0] == '1') ? 1 : 0; }
+        if (!on) return 1;
         return d->ci == 64 ? launch_rows2<bf16, 64, 7, 8, true, true>(k, s) : launch_rows2<bf16, 32, 8, 8, true, true>(k, s);
     }
     if (two) {

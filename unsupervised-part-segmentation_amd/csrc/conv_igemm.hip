@@ -472,9 +472,9 @@ extern "C" int ups_sign_pack(const void* x, int32_t dtype, int64_t chunks, void*
 // ups_conv_desc.sign_out is written by the kernels that have the output tile in hand (the 16-bit patch kernel); a launch that went to
 // another kernel leaves it untouched -- a pass over the finished output would cost the read the bits are there to save -- and says
 // so: ups_conv_sign_out_written() reports on the calling thread's last ups_conv_igemm call.
-static thread_local int g_sign_written = 0;
-extern "C" int ups_conv_sign_out_written(void) { return g_sign_written; }
-static int sign_out_pass(const ups_conv_desc* d, void* stream) { (void)d; (void)stream; g_sign_written = 0; return UPS_OK; }
+thread_local int g_ups_sign_written = 0;        // (set to 1 by the launcher of a kernel that writes the bits)
+extern "C" int ups_conv_sign_out_written(void) { return g_ups_sign_written; }
+static int sign_out_pass(const ups_conv_desc* d, void* stream) { (void)d; (void)stream; return UPS_OK; }
 int ups_conv3x3_first_try(const ups_conv_desc* d, hipStream_t s);   // conv3x3_first.hip
 int ups_conv3x3_s2_try(const ups_conv_desc* d, hipStream_t s);      // conv3x3_s2.hip
 int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s);    // conv3x3_rows.hip
@@ -484,6 +484,7 @@ int ups_conv3x3_rows_maskgrad_try(const ups_conv_desc* d, hipStream_t s);
 
 extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     UPS_CHECK_ARG(d != nullptr);
+    g_ups_sign_written = 0;
     UPS_CHECK_ARG(d->dtype == UPS_F32 || d->dtype == UPS_BF16 || d->dtype == UPS_F16);
     UPS_CHECK_ARG(d->in && d->w && (d->out || d->mask_grad));
     if (d->dtype == UPS_F16 && (d->d2s || d->f8_deq || d->mask_bits || d->mask_grad || d->in_f8 || d->out_f8 || d->out_f8_amax)) {
@@ -508,11 +509,11 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
     const char* force = getenv("UPS_FORCE_GENERIC_CONV");
     if (!(force && force[0] == '1')) {
         // first layers (<= 8 input channels, 32 / 64 outputs): the im2col-in-the-fragment kernel, an output-write stream
-        if (ups_conv3x3_first_try(d, (hipStream_t)stream) == 0) { UPS_LAUNCH_CHECK(); return sign_out_pass(d, stream); }
+        if (ups_conv3x3_first_try(d, (hipStream_t)stream) == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
         // the large 3x3 / stride-2 `downsample` forwards (32 / 64 input channels): taps straight from global memory, no gather
         {
             const int rr = ups_conv3x3_rows_s2_try(d, (hipStream_t)stream);      // (the two encoder shapes as row streams)
-            if (rr == 0) { UPS_LAUNCH_CHECK(); return sign_out_pass(d, stream); }
+            if (rr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
             if (rr < 0) { ups_set_error("ups_conv_igemm: row-streaming stride-2 kernel launch setup failed"); return rr; }
         }
         {
@@ -526,11 +527,11 @@ extern "C" int ups_conv_igemm(const ups_conv_desc* d, void* stream) {
             int rr = ups_conv3x3_thinout_try(d, (hipStream_t)stream);
             if (rr == 1) rr = ups_conv3x3_rows_try(d, (hipStream_t)stream);
             if (rr == 1) rr = ups_conv3x3_rows_maskgrad_try(d, (hipStream_t)stream);
-            if (rr == 0) { UPS_LAUNCH_CHECK(); return sign_out_pass(d, stream); }
+            if (rr == 0) { UPS_LAUNCH_CHECK(); return UPS_OK; }
             if (rr < 0) { ups_set_error("ups_conv_igemm: row-streaming kernel launch setup failed"); return rr; }
         }
         const int pr = ups_conv3x3_patch_try(d, (hipStream_t)stream);
-        if (pr == 0) { UPS_LAUNCH_CHECK(); g_sign_written = (d->sign_out && ups_conv3x3_patch_signs(d)) ? 1 : 0; return UPS_OK; }
+        if (pr == 0) { UPS_LAUNCH_CHECK(); if (d->sign_out && ups_conv3x3_patch_signs(d)) g_ups_sign_written = 1; return UPS_OK; }
         if (pr < 0) { ups_set_error("ups_conv_igemm: patch kernel launch setup failed"); return pr; }
     }
     if (d->d2s) {
