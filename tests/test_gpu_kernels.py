@@ -1693,8 +1693,10 @@ def _pack_signs(t16):
 @pytest.mark.parametrize("n,h,cin,cout,k,stride,f16", [(4, 32, 64, 64, 3, 1, False), (2, 64, 256, 256, 3, 1, True), (3, 28, 64, 64, 3, 1, False),
                                                        (8, 8, 128, 128, 3, 1, False), (4, 32, 64, 128, 1, 1, False), (4, 32, 64, 64, 3, 2, False),
                                                        (2, 32, 16, 24, 3, 1, False),
-                                                       # shapes the row-stream kernels take when forced: no bits from them, bits ignored
-                                                       (4, 128, 32, 32, 3, 1, False), (2, 128, 64, 64, 3, 1, False), (4, 128, 32, 64, 3, 2, False)])
+                                                       # the row-stream kernels (UPS_ROWS_KERNEL=force takes them at small batches): the one-tile
+                                                       # forms write / read the bytes (LDS-DMA ring), the two-tile form does neither
+                                                       (4, 128, 32, 32, 3, 1, False), (4, 64, 64, 64, 3, 1, False), (2, 128, 64, 64, 3, 1, False),
+                                                       (4, 128, 32, 64, 3, 2, False), (4, 64, 64, 128, 3, 2, False), (3, 96, 64, 64, 3, 1, False)])
 def test_sign_bits_written_by_the_producer_and_read_by_the_input_gradient(n, h, cin, cout, k, stride, f16, dev, monkeypatch):
     """ups_conv_desc.sign_out / dact_bits (ABI 4): a forward launch also writes one bit per stored element (> 0), whatever kernel
     runs it (the patch kernel's epilogue, or the pass over the output behind the other kernels); an input-gradient launch that is
@@ -1718,7 +1720,8 @@ def test_sign_bits_written_by_the_producer_and_read_by_the_input_gradient(n, h, 
     ops.SignBits.want, ops.SignBits.last = True, None
     y = ops.conv_forward(xs, lay, res=res, fmt=fmt, res_post=res is not None)
     bits = ops.SignBits.take()
-    native = k == 3 and stride == 1 and not rows  # (best effort: only the patch kernel's epilogue writes them)
+    two_tile = rows and cin == 64 and h == 128    # (64 channels at 128 columns: conv3x3_rows2_kernel, no sign bytes)
+    native = (k == 3 and stride == 1 and not rows) or (rows and stride == 2)     # best effort: patch epilogue, stride-2 row kernel
     assert (bits is not None) == native
     if bits is None:                              # ... and ups_sign_pack packs what another kernel stored
         bits = torch.empty(tuple(y.shape[:-1]) + (y.shape[-1] // 8,), dtype=torch.uint8, device=dev)
@@ -1734,7 +1737,7 @@ def test_sign_bits_written_by_the_producer_and_read_by_the_input_gradient(n, h, 
     ref = ops.conv_dgrad(gy, xs, lay, res=gy if res is not None else None)
     got = ops.conv_dgrad(gy, xs, lay, res=gy if res is not None else None, x_bits=xb)
     assert torch.equal(ref, got)
-    if k == 3 and stride == 1 and cin % 16 == 0 and cin >= 64 and not rows:   # on the patch kernel the bits are what is read: flip them all
+    if k == 3 and stride == 1 and cin % 16 == 0 and cin >= 32 and not two_tile and (rows or cin >= 64):   # where the bits are what is read: flip them all
         flipped = ops.conv_dgrad(gy, xs, lay, res=gy if res is not None else None, x_bits=~xb)
         assert not torch.equal(ref, flipped)
 

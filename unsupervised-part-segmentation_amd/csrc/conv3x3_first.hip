@@ -25,6 +25,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
 struct FirstK {
     const unsigned char* in; const unsigned char* w; unsigned char* out;
+    unsigned char* sign_out;            // ups_conv_desc.sign_out: one sign byte beside every stored 16-byte chunk (or NULL)
     const float* bias; const float* coord_tab; const unsigned* mask;
     int B, P, h, wd, ldi, co, co_fill, ldo, out_act, tiles_x, tiles_y;
     float slope;
@@ -151,7 +152,12 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const FirstK p) {
             for (int k = 0; k < NC / 2; ++k) {
                 const int idx = lane + 64 * k;                 // 16-byte piece of the staged row
                 const int px = idx / (NC * 2), ch = idx - px * (NC * 2);
-                if (ch * 8 < p.co_fill) *(uint4*)(orow + (long long)px * p.ldo * 2 + ch * 16) = *(const uint4*)(st + idx * 16);
+                if (ch * 8 < p.co_fill) {
+                    const uint4 o = *(const uint4*)(st + idx * 16);
+                    *(uint4*)(orow + (long long)px * p.ldo * 2 + ch * 16) = o;
+                    if (p.sign_out)
+                        p.sign_out[((((long long)(part * p.B + b) * p.h + y) * p.wd + tx0) + px) * (p.ldo >> 3) + ch] = (unsigned char)ups_sign_byte(o);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the staging row is rewritten by the next part)
         }
@@ -175,6 +181,7 @@ int ups_conv3x3_first_try(const ups_conv_desc* d, hipStream_t s) {
     FirstK k;
     k.in = (const unsigned char*)d->in; k.w = (const unsigned char*)d->w; k.out = (unsigned char*)d->out;
     k.bias = d->bias; k.coord_tab = d->coord_tab; k.mask = d->mask_bits;
+    k.sign_out = (unsigned char*)d->sign_out;
     k.B = d->n; k.P = 1;
     if (d->mask_bits) {
         if (d->mask_batch <= 0 || d->n % d->mask_batch) return 1;
@@ -188,6 +195,7 @@ int ups_conv3x3_first_try(const ups_conv_desc* d, hipStream_t s) {
     if (blocks >= (1ll << 31)) return 1;
     if (d->co_fill == 32) hipLaunchKernelGGL((conv3x3_first_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((conv3x3_first_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, k);
+    if (k.sign_out) g_ups_sign_written = 1;
     return 0;
 }
 

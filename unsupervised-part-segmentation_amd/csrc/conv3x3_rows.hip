@@ -36,6 +36,8 @@ template <> struct RFrag<f16> { typedef f16x8 type; };
 struct RowsK {
     const unsigned char* in; const unsigned char* w; unsigned char* out;
     const float* bias; const unsigned char* dact;
+    const unsigned char* dact_bits;     // ups_conv_desc.dact_bits: the sign bytes of the tensor `dact` points to (DG == 3) or NULL
+    unsigned char* sign_out;            // ups_conv_desc.sign_out: one sign byte beside every stored 16-byte chunk, or NULL
     int n, h, ldi, ldo, ldd, co_tot, band_rows, bands, res_self, res_act, out_act;
     float slope, dact_ns;
 };
@@ -49,20 +51,22 @@ __device__ __forceinline__ int r_swz(int P) { return ((P >> 2) & 1) << 1; }     
 // CI input channels (32 / 64), image width 1 << LW (128 / 64): 8 waves = (W / 16 column tiles) x (8 / (W / 16) groups of 32 outputs),
 // i.e. 32 outputs at W = 128, 64 at W = 64.  NR ring rows.  FLIP: the input gradient's tap order (dy = 1 - t / 3, dx = 1 - t % 3).
 // DG: 0 forward-type epilogue; 1 act' from a second DMA ring of the forward input's rows (one block per CU at 32 channels);
+// 3 (round 5): act' from the producer's SIGN BYTES (RowsK.dact_bits), the same second ring with 4 bytes per pixel and plane instead
+// of 64 -- by LDS-DMA like everything else these kernels fetch inside their loop (no register results for hipcc to move);
 // 2 act' by counted inline-asm loads in the accumulator layout (no ring: two blocks per CU at 32 channels)
 template <typename T, int CI, int LW, int NR, bool FLIP, int DG>
-__global__ __launch_bounds__(512, (CI == 32 && DG != 1 && NR <= 8) ? 4 : 2) void conv3x3_rows_kernel(const RowsK p) {
+__global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) ? 4 : 2) void conv3x3_rows_kernel(const RowsK p) {
     constexpr int W = 1 << LW, KC = CI / 32, NCT = W / 16;
     constexpr int PL = (W + 2) * 64;            // bytes of one 32-channel plane of a row
     constexpr int RB = KC * PL;                 // bytes of a row buffer
     constexpr int ST = 16 * 80;                 // wave-private output stage: 16 pixels x (64 + 16) bytes
     constexpr int L = (NR - 4) / 2;             // iterations of lead of the row requests (NR = 2 L + 4)
-    constexpr int DR = DG == 1 ? 2 * L + 2 : 0; // ring rows of the act' operand (W pixels x 64 B x output-channel planes; no halo)
-    constexpr int GS = DG == 1 ? 4 : 2;         // DMA instructions a wave issues per iteration
+    constexpr int DR = (DG == 1 || DG == 3) ? 2 * L + 2 : 0;   // ring rows of the act' operand (W pixels x 64 B x output-channel planes; no halo)
+    constexpr int GS = (DG == 1 || DG == 3) ? 4 : 2;            // DMA instructions a wave issues per iteration
     constexpr int NV = DG == 2 ? 4 : 0;         // act' loads per wave and iteration (DG == 2)
     static_assert(DG != 2 || L == 2, "the counted waits of the asm-load form are written for a lead of two iterations");
     constexpr int NCG = 8 / NCT;                // output-channel groups of 32 = planes of the output / act' rows
-    constexpr int DRB = NCG * W * 64;
+    constexpr int DRB = DG == 3 ? 8 * 256 : NCG * W * 64;       // (DG == 3: one dword per lane and wave: the pixel's four sign bytes of the wave's plane)
     static_assert(KC * NCT == 8 && NCG * NCT == 8, "one DMA piece per wave and row");
     typedef typename RFrag<T>::type frag_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -102,14 +106,24 @@ __global__ __launch_bounds__(512, (CI == 32 && DG != 1 && NR <= 8) ? 4 : 2) void
     // act' operand (DG): wave (segment ct, plane cg) moves 16 pixels x 64 B of row y of the forward input (no halo, no swizzle
     // needed: the epilogue reads 8 bytes per lane at a 64-byte pixel pitch -- 2-way conflicts on a 4-instruction read)
     const unsigned dd_off = (unsigned)((16 * ct + (lane >> 2)) * p.ldd * 2 + cg * 64 + ((lane & 3) << 4));
-    const unsigned char* da_img = DG ? p.dact + (long long)img * p.h * W * p.ldd * 2 : nullptr;
+    const unsigned char* da_img = (DG == 1 || DG == 2) ? p.dact + (long long)img * p.h * W * p.ldd * 2 : nullptr;
     auto issue_row = [&](int k) __attribute__((always_inline)) {
         const int y = y0 - 1 + k;
         const unsigned char* src = (unsigned)y < (unsigned)p.h ? in_img + (long long)y * row_bytes : ups_rows_zero;
         const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((k % NR) * RB + cg * PL + (1 + 16 * ct) * 64));
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(d_off), "s"(src) : "memory", "m0");
     };
+    const unsigned db_off = DG == 3 ? (unsigned)((16 * ct + (lane & 15)) * (p.ldd >> 3) + cg * 4) : 0u;
+    const unsigned char* db_img = DG == 3 ? p.dact_bits + (long long)img * p.h * W * (p.ldd >> 3) : nullptr;
     auto issue_drow = [&](int ko) __attribute__((always_inline)) {          // ko = output row index inside the band
+        if constexpr (DG == 3) {
+            // lane l fetches the dword of pixel 16 ct + (l & 15) (lanes 16 .. 63 repeat the first sixteen: no exec games) into the
+            // wave's 256-byte slot of act' ring row ko
+            const int y = min(y0 + ko, p.h - 1);
+            const unsigned char* src = db_img + (long long)y * (unsigned)(W * (p.ldd >> 3));
+            const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(NR * RB + (ko % DR) * DRB + wid * 256));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" :: "s"(dst), "v"(db_off), "s"(src) : "memory", "m0");
+        }
         if constexpr (DG == 1) {
             const int y = min(y0 + ko, p.h - 1);
             const unsigned char* src = da_img + (long long)y * (unsigned)(W * p.ldd * 2);
@@ -204,6 +218,12 @@ __global__ __launch_bounds__(512, (CI == 32 && DG != 1 && NR <= 8) ? 4 : 2) void
                     v[0] *= d0 > 0.f ? 1.f : p.dact_ns; v[1] *= d1 > 0.f ? 1.f : p.dact_ns;
                     v[2] *= d2 > 0.f ? 1.f : p.dact_ns; v[3] *= d3 > 0.f ? 1.f : p.dact_ns;
                 }
+                if constexpr (DG == 3) {
+                    const unsigned w4 = *(const unsigned*)(dring + ((2 * it + r) % DR) * DRB + wid * 256 + p16 * 4);
+                    const unsigned nib = w4 >> (8 * (2 * j + (q16 >> 1)) + 4 * (q16 & 1));      // the lane's four channels
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= (nib >> e) & 1u ? 1.f : p.dact_ns;
+                }
                 if constexpr (DG == 1) {
                     if (p.dact) {
                         const uint2 dv = *(const uint2*)(dring + ((2 * it + r) % DR) * DRB + cg * (W * 64) + (16 * ct + p16) * 64 + (16 * j + 4 * q16) * 2);
@@ -232,6 +252,8 @@ __global__ __launch_bounds__(512, (CI == 32 && DG != 1 && NR <= 8) ? 4 : 2) void
             }
             const uint4 o = *(const uint4*)(stage + (lane >> 2) * 80 + (lane & 3) * 16);
             *(uint4*)(out_img + ((long long)y * W + 16 * ct + (lane >> 2)) * p.ldo * 2 + (cg * 32 + 8 * (lane & 3)) * 2) = o;
+            // (no sign bytes from this kernel: its outputs feed `downsample` convolutions, which apply no activation to their input --
+            // and one more conditional store here made the 64-channel instance irreproducible, docs/design/negative_results.md)
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (outstanding row requests past the band target this block's LDS)
@@ -649,6 +671,8 @@ __global__ __launch_bounds__(512, CI == 32 ? 4 : 2) void conv3x3_rows_s2_kernel(
         }
         const uint4 o = *(const uint4*)(stage + (lane >> 2) * 80 + (lane & 3) * 16);
         *(uint4*)(out_img + ((long long)y * WO + 16 * ct + (lane >> 2)) * p.ldo * 2 + (cg * 32 + 8 * (lane & 3)) * 2) = o;
+        if (p.sign_out)
+            p.sign_out[(((long long)img * ho + y) * WO + 16 * ct + (lane >> 2)) * (p.ldo >> 3) + cg * 4 + (lane & 3)] = (unsigned char)ups_sign_byte(o);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -984,7 +1008,8 @@ static int rows_on() {       // UPS_ROWS_KERNEL=0: these layers through the patc
 template <typename T, int CI, int LW, int NR, bool FLIP, int DG>
 int launch_rows(const RowsK& k, hipStream_t s) {
     constexpr int W = 1 << LW, KC = CI / 32, NCT = W / 16, NCG = 8 / NCT;
-    constexpr size_t smem = (size_t)NR * KC * (W + 2) * 64 + (DG == 1 ? (size_t)(NR - 2) * NCG * W * 64 : 0) + 8 * 16 * 80 + 256;
+    constexpr size_t smem = (size_t)NR * KC * (W + 2) * 64 + (DG == 1 ? (size_t)(NR - 2) * NCG * W * 64 : (DG == 3 ? (size_t)(NR - 2) * 8 * 256 : 0)) +
+                            8 * 16 * 80 + 256;
     static UpsPerDevice attr_set;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv3x3_rows_kernel<T, CI, LW, NR, FLIP, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -1007,6 +1032,7 @@ int launch_rows_t(const RowsK& k, int ci, int w, bool flip, bool dg, hipStream_t
     if (ci == 32 && w == 128) {
         if (dg) {
             if (!flip) return 1;
+            if (k.dact_bits) return launch_rows<T, 32, 7, 8, true, 3>(k, s);
             return dgm == 1 ? launch_rows<T, 32, 7, 8, true, 1>(k, s) : launch_rows<T, 32, 7, 8, true, 2>(k, s);
         }
         return flip ? launch_rows<T, 32, 7, 8, true, 0>(k, s) : launch_rows<T, 32, 7, 8, false, 0>(k, s);
@@ -1014,6 +1040,7 @@ int launch_rows_t(const RowsK& k, int ci, int w, bool flip, bool dg, hipStream_t
     if (ci == 64 && w == 64) {
         if (dg) {
             if (!flip) return 1;
+            if (k.dact_bits) return launch_rows<T, 64, 6, 10, true, 3>(k, s);
             return dgm == 1 ? launch_rows<T, 64, 6, 10, true, 1>(k, s) : launch_rows<T, 64, 6, 8, true, 2>(k, s);
         }
         return flip ? launch_rows<T, 64, 6, 10, true, 0>(k, s) : launch_rows<T, 64, 6, 10, false, 0>(k, s);
@@ -1053,6 +1080,9 @@ int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s) {
     RowsK k;
     k.in = (const unsigned char*)d->in; k.w = (const unsigned char*)d->w; k.out = (unsigned char*)d->out;
     k.bias = d->bias; k.dact = (const unsigned char*)d->dact;
+    // sign bytes: read by the one-tile input gradient (DG == 3: 4-byte DMA pieces, so ldd % 32 == 0), written by the one-tile forward
+    k.dact_bits = (d->dact && !two && (d->ldd & 31) == 0 && ((uintptr_t)d->dact_bits & 3) == 0) ? (const unsigned char*)d->dact_bits : nullptr;
+    k.sign_out = nullptr;                // (only the stride-2 row kernel writes sign bytes: ups_conv3x3_rows_s2_try)
     k.n = d->n; k.h = d->hi; k.ldi = d->ldi; k.ldo = d->ldo; k.ldd = d->ldd; k.co_tot = d->co;
     k.band_rows = 32; k.bands = d->hi / 32;
     k.res_self = d->res != nullptr; k.res_act = d->res_act; k.out_act = d->out_act;
@@ -1081,6 +1111,7 @@ int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s) {
         return flip ? launch_rows2<bf16, 32, 8, 8, true>(k, s) : launch_rows2<bf16, 32, 8, 8, false>(k, s);
     }
     const int rc = d->dtype == UPS_F16 ? launch_rows_t<f16>(k, d->ci, d->wi, flip, dg, s) : launch_rows_t<bf16>(k, d->ci, d->wi, flip, dg, s);
+    if (rc == 0 && k.sign_out) g_ups_sign_written = 1;
     return rc;
 }
 
@@ -1103,13 +1134,15 @@ int ups_conv3x3_rows_s2_try(const ups_conv_desc* d, hipStream_t s) {
     if ((long long)d->wi * d->ldi * 2 > 65536 || (long long)d->hi * d->wi * d->ldi * 2 >= (1ll << 31)) return 1;
     RowsK k;
     k.in = (const unsigned char*)d->in; k.w = (const unsigned char*)d->w; k.out = (unsigned char*)d->out;
-    k.bias = d->bias; k.dact = nullptr;
+    k.bias = d->bias; k.dact = nullptr; k.dact_bits = nullptr; k.sign_out = two ? nullptr : (unsigned char*)d->sign_out;
     k.n = d->n; k.h = d->hi; k.ldi = d->ldi; k.ldo = d->ldo; k.ldd = 0; k.co_tot = d->co;
     k.band_rows = 32; k.bands = d->ho / 32;
     k.res_self = 0; k.res_act = 0; k.out_act = d->out_act;
     k.slope = d->act_slope; k.dact_ns = 0.f;
     if (two) return d->ci == 32 ? launch_rows_s2x2<32, 8, 7>(k, s) : launch_rows_s2x2<64, 7, 7>(k, s);
-    return d->ci == 32 ? launch_rows_s2<32, 7, 7>(k, s) : launch_rows_s2<64, 6, 9>(k, s);
+    const int rc = d->ci == 32 ? launch_rows_s2<32, 7, 7>(k, s) : launch_rows_s2<64, 6, 9>(k, s);
+    if (rc == 0 && k.sign_out) g_ups_sign_written = 1;
+    return rc;
 }
 
 // The logit convolution's forward: 256 input channels, <= 16 outputs, stride 1, no residual / activation; fp32 or 16-bit output.

@@ -690,7 +690,7 @@ def conv_forward(x, layer, res=None, out_f32=False, ldo=None, co_fill=None, mask
     Fp8.next_in = Fp8.next_out_act = None
     Fp8.last_out = f8_out
     SignBits.last = None
-    if SignBits.want and SignBits.ENABLED and not out_f32 and mask is None and out.dtype == torch.bfloat16 and ldo % 8 == 0:
+    if SignBits.want and SignBits.ENABLED and not out_f32 and out.dtype == torch.bfloat16 and ldo % 8 == 0:
         SignBits.last = torch.empty((n, ho, wo, ldo // 8), dtype=torch.uint8, device=x.device)
         d.sign_out = SignBits.last.data_ptr()
     SignBits.want = False
