@@ -243,10 +243,11 @@ def test_conv_rows_kernel(case, dev, monkeypatch):
         return (y.view(torch.float16) if f16 else y).float().cpu(), gx.float().cpu()
     monkeypatch.setenv("UPS_ROWS_KERNEL", "force")
     y1, g1 = run()
-    y2, g2 = run()
+    for _ in range(4):      # (round 5: an edit that left the wait counts alone made the 64-channel instance differ from run to run)
+        y2, g2 = run()
+        assert torch.equal(y1, y2) and torch.equal(g1, g2), "not reproducible {}".format(case)
     monkeypatch.setenv("UPS_ROWS_KERNEL", "0")
     y0, g0 = run()
-    assert torch.equal(y1, y2) and torch.equal(g1, g2), "not reproducible {}".format(case)
     # oracle: out = act(conv(act(x)) + b + x) with x = act^-1(stored); gx = d<out_pre, gy>/dx
     xo = xs.double()
     xpre = torch.where(xo > 0, xo, xo / 0.2).requires_grad_(True)
