@@ -2,6 +2,7 @@
 Usage: python tools/one_conv.py [fwd|dgrad|wgrad] [case of tools/bench_conv.py, default dv_rb128] [plain]
 The launch is issued the way the model issues it: residual block (res = in), for a 3x3 layer with an activation the input in
 post-activation storage and -- the mask decoder's layers (dv_*) -- fp16 forward tensors; `plain`: bf16, activation-on-load;
+`bits` (dgrad): act' from the producer's sign bytes (ups_conv_desc.dact_bits) instead of the forward input;
 `f8`: the fp8 mode's launch -- the operand arrives as a producer's e4m3 (forward) / e5m2 (input gradient) copy; `wgrad ... f8`: the
 fp8 weight gradient (conv_wgrad3x3_f8.hip): the gradient's e5m2 copy + the forward tensor quantised while it is staged."""
 import math, os, sys
@@ -22,6 +23,7 @@ b = torch.randn(cout, generator=g).to(dev)
 from upsparts_amd import lib
 lay = ops.ConvLayer("x/conv2d_0", V, b, k, stride, coords, act)
 plain = len(sys.argv) > 3 and sys.argv[3] == "plain"
+bits = len(sys.argv) > 3 and sys.argv[3] == "bits"
 f8 = len(sys.argv) > 3 and sys.argv[3] == "f8"
 # (the fp8 WEIGHT gradient of a mask-decoder layer reads the fp16 forward tensor as the model hands it over)
 fmt = lib.F16 if (not plain and (not f8 or mode == "wgrad") and case.startswith("dv_") and k == 3) else None
@@ -45,6 +47,10 @@ y = ops.conv_forward(x, lay, res=res, fmt=fmt, res_post=lay.in_post)
 gy = torch.randn(y.shape, device=dev).to(torch.bfloat16)
 if f8:
     g8 = (gy.float() * F.scale[sg]).clamp(-57344, 57344).to(torch.float8_e5m2).view(torch.uint8)
+xbits = None
+if bits:
+    pos = (x.view(torch.int16) > 0).view(n, h, h, -1, 8).to(torch.uint8)
+    xbits = (pos * (2 ** torch.arange(8, device=dev, dtype=torch.uint8))).sum(-1).to(torch.uint8).contiguous()
 for _ in range(3):
     if mode == "fwd":
         if f8:
@@ -53,7 +59,7 @@ for _ in range(3):
     elif mode == "dgrad":
         if f8:
             F.register_grad_copy(gy, {"t": g8, "slot": sg, "site": None})
-        ops.conv_dgrad(gy, x, lay, res=gy if res is not None else None)
+        ops.conv_dgrad(gy, x, lay, res=gy if res is not None else None, x_bits=xbits)
     elif mode == "wgrad":
         ops.conv_wgrad(gy, x, lay, fmt=fmt, f8_src={"t": g8, "slot": sg, "site": None} if f8 else None)
 torch.cuda.synchronize()
