@@ -406,6 +406,34 @@ int ups_critic_head_fwd(const void* h_pi, const void* h_al, int32_t dtype, int32
 int ups_critic_head_bwd(const void* h_pi, const void* h_al, const float* logits, const float* g_loss, const float* g_mim,
                         int32_t dtype, int32_t B, int32_t K, int32_t ld, void* g_h_pi, void* g_h_al, void* stream);
 
+/* ---------------------------------------------------------------- the critics' towers as grouped launches (M:159-173, round 5)
+ * discriminator_model is two towers of nin -> (L - 2) x residual_block(k = 1) -> nin on [M = 2B, 512] rows; the three critics of a
+ * step are six such towers.  ups_towers_fwd runs layer l of EVERY tower in one launch (L launches), ups_towers_bwd the input
+ * gradients likewise (L - 1 launches, + 1 where a tower's first input wants its gradient) and EVERY weight / bias gradient of every
+ * tower and layer in one more -- instead of T * L generic convolution calls (each a split-K GEMM + epilogue launch) per direction.
+ * UPS_BF16 only, leaky-ReLU, post-activation storage as ups_conv_desc.out_act / res_act describe it: acts[t * L + l] holds
+ * lrelu(x) for l < L - 1 (the next layer activates its input) and the plain value for the last layer; a residual layer adds the x it
+ * recovers from its stored input.  Requirements (else UPS_E_ARG): k % 32 == 0, n % 128 == 0, square residual layers, T <= 8, L <= 6.
+ *   layers  [T * L], tower-major.  w_fwd / w_dgrad: ups_weight_prep's blocked-K copies of the 1x1 kernel; bias [n] or NULL;
+ *           grad_w [k][n] (HWIO of a 1x1 kernel) / grad_b [n]: OVERWRITTEN by ups_towers_bwd(want_wgrad = 1); grad_w NULL skips the layer
+ *   x0, ld0 [T]: the towers' inputs [M][ld0] (plain values);  acts [T * L]: outputs [M][n] of every layer (caller-owned)
+ *   g_out   [T]: gradients w.r.t. the towers' outputs [M][n_last]; a NULL entry leaves that tower out of the call
+ *   g_ws    [T * L]: scratch [M][n] per layer (entry l receives the gradient w.r.t. layer l's output; the last entry is unused)
+ *   g_x0, ldg0 [T] or NULL: where a tower's input gradient [M][ldg0] is wanted (k of its first layer % 128 == 0) */
+typedef struct ups_tower_layer {
+    const void*  w_fwd;
+    const void*  w_dgrad;
+    const float* bias;
+    float*       grad_w;
+    float*       grad_b;
+    int32_t      k, n;
+} ups_tower_layer;
+int ups_towers_fwd(const ups_tower_layer* layers, int32_t T, int32_t L, const void* const* x0, const int32_t* ld0,
+                   void* const* acts, int32_t M, float slope, void* stream);
+int ups_towers_bwd(const ups_tower_layer* layers, int32_t T, int32_t L, const void* const* x0, const int32_t* ld0,
+                   const void* const* acts, const void* const* g_out, void* const* g_ws, void* const* g_x0,
+                   const int32_t* ldg0, int32_t want_wgrad, int32_t M, float slope, void* stream);
+
 /* ---------------------------------------------------------------- full-covariance latent (N:1134-1208, util.py:878-995)
  * params [B][dim + dim(dim+1)/2] fp32.  samples[s][b][i] = mean + L (level[s]*eps[s][b]) ; kl_rows[b][i]. */
 /* `level` is a HOST array of S noise levels (S <= 12).  kl_rows may be NULL. */

@@ -919,6 +919,99 @@ def test_critic_head(dtype, B, dev):
         assert_close(gh[1].float(), go[1].float(), gtol, "d / d h_alpha ({}, {})".format(wl, wm))
 
 
+@pytest.mark.parametrize("M", [128, 6, 40])
+def test_critic_towers_grouped(M, dev):
+    """ops.TowersFn (ups_towers_fwd / _bwd: the same layer of every tower in one launch, every weight / bias gradient in one) against
+    discriminator_model's tower (M:159-173: nin, 4 x residual_block(k = 1) = x + nin(lrelu(x)), nin(lrelu(x))) in fp64, and against
+    the generic convolution path on the SAME layer objects (the storage form is the same, so the two differ by summation order
+    only): outputs, the gradients of every kernel and bias, the input gradient of the 256-wide towers; a backward call that is given
+    one tower's output gradient only (the adversarial term's) must leave the other towers out; ragged row counts."""
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(5 + M)
+    widths, D, Ln = (256, 64, 256), 512, 6
+    towers, ref = [], []
+    for t, c in enumerate(widths):
+        tw, rw = [], []
+        for l in range(Ln):
+            k = c if l == 0 else D
+            bound = math.sqrt(1.0 / k)
+            V = (torch.rand(1, 1, k, D, generator=g) * 2 - 1) * bound * (1.0 if l in (0, Ln - 1) else 0.5)
+            b = (torch.rand(D, generator=g) * 2 - 1) * bound
+            lay = ops.ConvLayer("t{}/conv2d_{}".format(t, l), V.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True), 1, 1, False,
+                                None if l == 0 else "leaky_relu")
+            lay.in_post = l > 0
+            lay.out_act = lib.ACT_LRELU if l < Ln - 1 else lib.ACT_NONE
+            lay.grad_V, lay.grad_b = torch.zeros_like(lay.V), torch.zeros_like(lay.b)
+            tw.append(lay)
+            rw.append((V.double().requires_grad_(True), b.double().requires_grad_(True)))
+        towers.append(tw); ref.append(rw)
+    xs = [(torch.randn(M, 1, 1, c, generator=g)).to(torch.bfloat16) for c in widths]
+    gos = [(torch.randn(M, 1, 1, D, generator=g) * 0.1).to(torch.bfloat16) for _ in widths]
+    lrelu = lambda v: torch.nn.functional.leaky_relu(v, 0.2)
+
+    # fp64 reference on the kernels' operands: bf16 kernels, and every stored tensor (lrelu(x), from which the residual x is
+    # recovered) rounded to bf16 with a straight-through gradient
+    xo = [x.double().requires_grad_(True) for x in xs]
+    outs_o = []
+    stored = lambda v: v + (v.detach().to(torch.bfloat16).double() - v.detach())
+    wq = lambda v: v + (v.detach().to(torch.bfloat16).double() - v.detach())
+    for t, rw in enumerate(ref):
+        hs_ = stored(lrelu(xo[t].view(M, -1) @ wq(rw[0][0][0, 0]) + rw[0][1]))
+        for l in range(1, Ln - 1):
+            x_rec = torch.where(hs_ > 0, hs_, hs_ / 0.2)
+            hs_ = stored(lrelu(x_rec + hs_ @ wq(rw[l][0][0, 0]) + rw[l][1]))
+        outs_o.append(hs_ @ wq(rw[Ln - 1][0][0, 0]) + rw[Ln - 1][1])
+    loss_o = sum((o * go.double().view(M, -1)).sum() for o, go in zip(outs_o, gos))
+    par_o = [t_ for rw in ref for vb in rw for t_ in vb]
+    gr_o = torch.autograd.grad(loss_o, par_o + [xo[0], xo[2]])
+
+    # grouped launches
+    assert ops.towers_eligible(towers, [x.to(dev) for x in xs])
+    xd = [x.to(dev).requires_grad_(c == 256) for x, c in zip(xs, widths)]
+    params = [t_ for tw in towers for lay in tw for t_ in (lay.V, lay.b)]
+    hs = ops.TowersFn.apply(towers, *(xd + params))
+    for t in range(3):
+        assert_close(hs[t].float().view(M, -1), outs_o[t].float(), BF16_TOL, "tower {} output".format(t))
+    loss = sum((h.float() * go.to(dev).float()).sum() for h, go in zip(hs, gos))
+    gr = torch.autograd.grad(loss, params + [xd[0], xd[2]], retain_graph=True)
+    gr = [t_.clone() for t_ in gr]
+    for i, (a, b_) in enumerate(zip(gr, gr_o)):
+        what = "d x" if i >= len(params) else "tower {} layer {} {}".format(i // (2 * Ln), (i // 2) % Ln, "b" if i % 2 else "V")
+        # (the gradient is stored in bf16 after every layer, up to five roundings deep at the first one: 3e-2 here, and with
+        # few rows (M = 6, 40), where nothing averages them, the max-norm and RMS bars only -- the element-wise check of that case is the
+        # one against the generic path below, which rounds alike)
+        assert_close(a.float().reshape(b_.shape), b_.float(), 1.5 * BF16_TOL, what, elementwise=M >= 128)
+    # one tower's output gradient only, input gradients only (the adversarial term): the others' buffers stay untouched
+    for tw in towers:
+        for lay in tw:
+            lay.grad_V.fill_(7.0); lay.grad_b.fill_(7.0)
+    with ops.skip_wgrad():
+        gx0, = torch.autograd.grad((hs[0].float() * gos[0].to(dev).float()).sum(), [xd[0]], retain_graph=True)
+    assert_close(gx0.float().reshape(gr_o[-2].shape), gr_o[-2].float(), 1.5 * BF16_TOL, "d x of tower 0 alone", elementwise=M >= 128)
+    assert all(bool((lay.grad_V == 7.0).all()) and bool((lay.grad_b == 7.0).all()) for tw in towers for lay in tw)
+    # the critic whose key trains: towers 1 and 2 only
+    par12 = [t_ for tw in towers[1:] for lay in tw for t_ in (lay.V, lay.b)]
+    torch.autograd.grad(sum((h.float() * go.to(dev).float()).sum() for h, go in zip(hs[1:], gos[1:])), par12)
+    assert all(bool((lay.grad_V == 7.0).all()) for lay in towers[0])
+    for i, lay in enumerate(lay for tw in towers[1:] for lay in tw):
+        assert_close(lay.grad_V.float(), gr[2 * Ln + 2 * i].float(), 1e-6, "repeat of layer {}".format(i))
+
+    # the generic path on the same layers
+    outs_g = []
+    xg = [x.to(dev).requires_grad_(c == 256) for x, c in zip(xs, widths)]
+    for t, tw in enumerate(towers):
+        h = ops.conv(xg[t], tw[0])
+        for l in range(1, Ln - 1):
+            h = ops.conv(h, tw[l], res_self=True)
+        outs_g.append(ops.conv(h, tw[Ln - 1]))
+    for t in range(3):
+        assert_close(hs[t].float(), outs_g[t].float(), BF16_TOL, "tower {} output vs the generic path".format(t))
+    loss_g = sum((h.float() * go.to(dev).float()).sum() for h, go in zip(outs_g, gos))
+    gg = torch.autograd.grad(loss_g, params + [xg[0], xg[2]])
+    for i, (a, b_) in enumerate(zip(gr, gg)):
+        assert_close(a.float(), b_.float().reshape(a.shape), BF16_TOL, "gradient {} vs the generic path".format(i))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_mask_parts_unpool(dtype, dev):
     lib, ops, R = _mods()

@@ -66,6 +66,176 @@ __global__ __launch_bounds__(256) void critic_head_bwd_kernel(const T* __restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The critics' towers as grouped launches (round 5).  discriminator_model (cub/code/SB_model48i/model.py:159-173) is two towers of
+// nin -> 4 x residual_block(k = 1) -> nin on [2B, 512] rows; the three critics make six towers of six 1x1 layers that the generic
+// convolution path ran as 72 GEMMs of 32 blocks + 65 split-K epilogues + 36 weight gradients + 36 bias sums per step, every one of
+// them launch latency.  Here ONE launch runs the same layer of every tower (blockIdx.z = tower), and ONE launch takes every weight
+// and bias gradient of every tower and layer.  Storage is the generic path's post-activation form: a layer's output is stored as
+// lrelu(x) when an activated layer consumes it, the residual x is recovered from it (x = h > 0 ? h : h / slope), act' is read off
+// the sign of the stored tensor.
+//
+// GEMM: out[m][n] = sum_k A[m][k] * W[k / 32][n][k % 32] (ups_weight_prep's blocked-K layout), fp32 accumulate.  No LDS: the
+// operands are a few hundred KB that live in L2 and every lane's 16-byte pieces are the MFMA fragments as they lie in memory
+// (weights = first operand: a lane's four accumulators are four consecutive channels of one row).  One wave = 16 rows x 32 channels.
+struct TowerGemmArgs {
+    const bf16* A[8]; const bf16* W[8]; const float* bias[8]; const bf16* sgn[8]; const bf16* res[8]; bf16* out[8];
+    int lda[8], lds[8], ldr[8], ldo[8], K[8];
+    int M, N;
+    int res_self, out_act;          // forward: + the residual recovered from A (K == N); store lrelu(v)
+    float slope;
+};
+
+__global__ __launch_bounds__(256) void tower_gemm_kernel(const TowerGemmArgs a) {
+    const int tw = blockIdx.z;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int p16 = lane & 15, q16 = lane >> 4;
+    const int m = blockIdx.y * 16 + p16;
+    const int n0 = blockIdx.x * 128 + wid * 32;
+    const int mc = min(m, a.M - 1);
+    const int N = a.N, nkc = a.K[tw] >> 5;
+    const bf16* arow = a.A[tw] + (long long)mc * a.lda[tw] + q16 * 8;
+    const bf16* wrow = a.W[tw] + (long long)(n0 + p16) * 32 + q16 * 8;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int kc = 0;
+    for (; kc + 8 <= nkc; kc += 8) {            // 24 independent 16-byte loads in flight, then their 16 MFMAs
+        bf16x8 af[8], w0[8], w1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            af[u] = *(const bf16x8*)(arow + (kc + u) * 32);
+            w0[u] = *(const bf16x8*)(wrow + (long long)(kc + u) * N * 32);
+            w1[u] = *(const bf16x8*)(wrow + (long long)(kc + u) * N * 32 + 16 * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[u], af[u], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[u], af[u], acc[1], 0, 0, 0);
+        }
+    }
+    for (; kc + 2 <= nkc; kc += 2) {
+        bf16x8 af[2], w0[2], w1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            af[u] = *(const bf16x8*)(arow + (kc + u) * 32);
+            w0[u] = *(const bf16x8*)(wrow + (long long)(kc + u) * N * 32);
+            w1[u] = *(const bf16x8*)(wrow + (long long)(kc + u) * N * 32 + 16 * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[u], af[u], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[u], af[u], acc[1], 0, 0, 0);
+        }
+    }
+    for (; kc < nkc; ++kc) {
+        const bf16x8 af = *(const bf16x8*)(arow + kc * 32);
+        const bf16x8 w0 = *(const bf16x8*)(wrow + (long long)kc * N * 32);
+        const bf16x8 w1 = *(const bf16x8*)(wrow + (long long)kc * N * 32 + 16 * 32);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af, acc[1], 0, 0, 0);
+    }
+    if (m >= a.M) return;
+    const float inv = 1.f / a.slope;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + 16 * j + 4 * q16;
+        float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+        if (a.bias[tw]) {
+            const float4 b4 = *(const float4*)(a.bias[tw] + n);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+        if (a.sgn[tw]) {                // input gradient: act' off the sign of the stored forward input
+            const uint2 sw = *(const uint2*)(a.sgn[tw] + (long long)m * a.lds[tw] + n);
+            float s0, s1, s2, s3;
+            ups_unpack2<bf16>(sw.x, s0, s1); ups_unpack2<bf16>(sw.y, s2, s3);
+            v[0] *= s0 > 0.f ? 1.f : a.slope; v[1] *= s1 > 0.f ? 1.f : a.slope;
+            v[2] *= s2 > 0.f ? 1.f : a.slope; v[3] *= s3 > 0.f ? 1.f : a.slope;
+        }
+        if (a.res[tw]) {                // input gradient of x + conv(act(x)): + g
+            const uint2 rw = *(const uint2*)(a.res[tw] + (long long)m * a.ldr[tw] + n);
+            float r0, r1, r2, r3;
+            ups_unpack2<bf16>(rw.x, r0, r1); ups_unpack2<bf16>(rw.y, r2, r3);
+            v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+        }
+        if (a.res_self) {               // forward x + conv(act(x)) with x stored as act(x)
+            const uint2 rw = *(const uint2*)(a.A[tw] + (long long)m * a.lda[tw] + n);
+            float r0, r1, r2, r3;
+            ups_unpack2<bf16>(rw.x, r0, r1); ups_unpack2<bf16>(rw.y, r2, r3);
+            v[0] += r0 > 0.f ? r0 : r0 * inv; v[1] += r1 > 0.f ? r1 : r1 * inv;
+            v[2] += r2 > 0.f ? r2 : r2 * inv; v[3] += r3 > 0.f ? r3 : r3 * inv;
+        }
+        if (a.out_act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ups_vmax(v[e], a.slope * v[e]);
+        }
+        *(uint2*)(a.out[tw] + (long long)m * a.ldo[tw] + n) = make_uint2(Chunk<bf16>::pk(v[0], v[1]), Chunk<bf16>::pk(v[2], v[3]));
+    }
+}
+
+// Every weight and bias gradient of every tower and layer in one launch: item = (tower, layer), dW[k][n] = sum_m X[m][k] G[m][n]
+// (HWIO of a 1x1 kernel), db[n] = sum_m G[m][n].  Block = 64 k x 64 n of one item, rows in chunks of 32 staged row-major in LDS;
+// both MFMA operands are columns of those tiles: ds_read_b64_tr_b16 (guide T10; the same row assignment on both sides, so the
+// permuted order of the reduction index does not matter).  No atomics: fixed summation order.
+struct TowerWgItem { const bf16* X; const bf16* G; float* dW; float* db; int ldx, ldg, K, N; };
+struct TowerWgArgs { TowerWgItem it[48]; int M; };
+constexpr int TW_PITCH = 64 * 2 + 16;        // bytes per staged row (64 bf16 + 16: the four rows of a transposing read hit distinct banks)
+
+__global__ __launch_bounds__(256) void tower_wgrad_kernel(const TowerWgArgs a) {
+    typedef __attribute__((ext_vector_type(4))) short v4s;
+    typedef __attribute__((address_space(3))) v4s lds_v4s;
+    __shared__ __attribute__((aligned(16))) unsigned char XS[32 * TW_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char GS[32 * TW_PITCH];
+    const TowerWgItem& it = a.it[blockIdx.z];
+    const int k0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    if (k0 >= it.K || n0 >= it.N) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lg = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int srow = tid >> 3, spc = tid & 7;          // staging: thread -> (row of the chunk, 16-byte piece of the 64 columns)
+    const bool kfull = k0 + 64 <= it.K;                 // (K = 64 * i always here; the check keeps a ragged K out of bounds)
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float bsum = 0.f;
+    for (int mb = 0; mb < a.M; mb += 32) {
+        const int m = mb + srow;
+        uint4 xv = make_uint4(0u, 0u, 0u, 0u), gv = make_uint4(0u, 0u, 0u, 0u);
+        if (m < a.M) {
+            if (kfull || k0 + spc * 8 + 8 <= it.K) xv = *(const uint4*)(it.X + (long long)m * it.ldx + k0 + spc * 8);
+            gv = *(const uint4*)(it.G + (long long)m * it.ldg + n0 + spc * 8);
+        }
+        __syncthreads();                                 // the previous chunk's reads are done
+        *(uint4*)(XS + srow * TW_PITCH + spc * 16) = xv;
+        *(uint4*)(GS + srow * TW_PITCH + spc * 16) = gv;
+        __syncthreads();
+        // rows (4 lg + q) and (16 + 4 lg + q) of the chunk: lane group lg holds reduction indices {4 lg .. 4 lg + 3, 16 + 4 lg .. }
+        const v4s x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(XS + (4 * lg + q) * TW_PITCH + 2 * (16 * wid + 4 * pp)));
+        const v4s x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(XS + (16 + 4 * lg + q) * TW_PITCH + 2 * (16 * wid + 4 * pp)));
+        bf16x8 xf;
+        __builtin_memcpy(&xf, &x0, 8);
+        __builtin_memcpy((char*)&xf + 8, &x1, 8);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const v4s g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(GS + (4 * lg + q) * TW_PITCH + 2 * (16 * nb + 4 * pp)));
+            const v4s g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(GS + (16 + 4 * lg + q) * TW_PITCH + 2 * (16 * nb + 4 * pp)));
+            bf16x8 gf;
+            __builtin_memcpy(&gf, &g0, 8);
+            __builtin_memcpy((char*)&gf + 8, &g1, 8);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf, acc[nb], 0, 0, 0);
+        }
+        if (blockIdx.y == 0 && tid < 64) {
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) bsum += (float)*(const bf16*)(GS + r * TW_PITCH + tid * 2);
+        }
+    }
+    // lane (li, lg) holds dW rows k0 + 16 wid + 4 lg + e, column n0 + 16 nb + li
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + 16 * wid + 4 * lg + e;
+            if (k < it.K) it.dW[(long long)k * it.N + n0 + 16 * nb + li] = acc[nb][e];
+        }
+    if (blockIdx.y == 0 && tid < 64 && it.db) it.db[n0 + tid] = bsum;
+}
+
 }  // namespace
 
 extern "C" int ups_critic_head_fwd(const void* h_pi, const void* h_al, int32_t dtype, int32_t B, int32_t K, int32_t ld, float* logits,
@@ -87,6 +257,101 @@ extern "C" int ups_critic_head_bwd(const void* h_pi, const void* h_al, const flo
     if (dtype == UPS_F32) hipLaunchKernelGGL(critic_head_bwd_kernel<float>, dim3(2 * B), dim3(256), 0, s, (const float*)h_pi, (const float*)h_al, logits, g_loss, g_mim, B, K, ld, (float*)g_h_pi, (float*)g_h_al);
     else if (dtype == UPS_BF16) hipLaunchKernelGGL(critic_head_bwd_kernel<bf16>, dim3(2 * B), dim3(256), 0, s, (const bf16*)h_pi, (const bf16*)h_al, logits, g_loss, g_mim, B, K, ld, (bf16*)g_h_pi, (bf16*)g_h_al);
     else { ups_set_error("bad dtype %d", (int)dtype); return UPS_E_ARG; }
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+bool tower_layers_ok(const ups_tower_layer* ly, int T, int L) {
+    for (int i = 0; i < T * L; ++i) {
+        const ups_tower_layer& l = ly[i];
+        if (!l.w_fwd || !l.w_dgrad || l.k <= 0 || l.n <= 0 || l.k % 32 || l.n % 128) return false;
+        const int li = i % L;
+        if (li > 0 && l.k != ly[i - 1].n) return false;             // the chain's widths
+        if (li > 0 && li < L - 1 && l.k != l.n) return false;       // residual layers are square
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int ups_towers_fwd(const ups_tower_layer* layers, int32_t T, int32_t L, const void* const* x0, const int32_t* ld0,
+                              void* const* acts, int32_t M, float slope, void* stream) {
+    UPS_CHECK_ARG(layers && x0 && ld0 && acts && T > 0 && T <= 8 && L >= 2 && L <= 6 && M > 0 && slope > 0.f && slope < 1.f);
+    UPS_CHECK_ARG(tower_layers_ok(layers, T, L));
+    hipStream_t s = (hipStream_t)stream;
+    for (int l = 0; l < L; ++l) {
+        TowerGemmArgs a = {};
+        a.M = M; a.N = layers[l].n; a.slope = slope;
+        a.res_self = (l > 0 && l < L - 1) ? 1 : 0;
+        a.out_act = l < L - 1 ? 1 : 0;
+        for (int t = 0; t < T; ++t) {
+            const ups_tower_layer& ly = layers[t * L + l];
+            UPS_CHECK_ARG(ly.n == a.N && acts[t * L + l] && (l > 0 || (x0[t] && ld0[t] >= ly.k)));
+            a.A[t] = (const bf16*)(l == 0 ? x0[t] : acts[t * L + l - 1]);
+            a.lda[t] = l == 0 ? ld0[t] : ly.k;
+            a.W[t] = (const bf16*)ly.w_fwd; a.bias[t] = ly.bias; a.K[t] = ly.k;
+            a.out[t] = (bf16*)acts[t * L + l]; a.ldo[t] = ly.n;
+        }
+        hipLaunchKernelGGL(tower_gemm_kernel, dim3(a.N / 128, (M + 15) / 16, T), dim3(256), 0, s, a);
+    }
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
+extern "C" int ups_towers_bwd(const ups_tower_layer* layers, int32_t T, int32_t L, const void* const* x0, const int32_t* ld0,
+                              const void* const* acts, const void* const* g_out, void* const* g_ws, void* const* g_x0,
+                              const int32_t* ldg0, int32_t want_wgrad, int32_t M, float slope, void* stream) {
+    UPS_CHECK_ARG(layers && x0 && ld0 && acts && g_out && g_ws && T > 0 && T <= 8 && L >= 2 && L <= 6 && M > 0 && slope > 0.f && slope < 1.f);
+    UPS_CHECK_ARG(tower_layers_ok(layers, T, L));
+    hipStream_t s = (hipStream_t)stream;
+    int act_t[8], na = 0;
+    for (int t = 0; t < T; ++t) if (g_out[t]) act_t[na++] = t;
+    if (!na) return UPS_OK;
+    // gin[l] = the gradient w.r.t. layer l's (pre-storage-activation) output: g_out for l = L - 1, else g_ws[t * L + l]
+    for (int l = L - 1; l >= 0; --l) {
+        TowerGemmArgs a = {};
+        a.M = M; a.slope = slope;
+        int nt = 0;
+        for (int i = 0; i < na; ++i) {
+            const int t = act_t[i];
+            const ups_tower_layer& ly = layers[t * L + l];
+            const bf16* gin = (const bf16*)(l == L - 1 ? g_out[t] : g_ws[t * L + l]);
+            if (l == 0) {
+                if (!g_x0 || !g_x0[t]) continue;
+                UPS_CHECK_ARG(ldg0 && ldg0[t] >= ly.k && ly.k % 128 == 0);
+                a.out[nt] = (bf16*)g_x0[t]; a.ldo[nt] = ldg0[t];
+            } else {
+                UPS_CHECK_ARG(g_ws[t * L + l - 1]);
+                a.out[nt] = (bf16*)g_ws[t * L + l - 1]; a.ldo[nt] = ly.k;
+                a.sgn[nt] = (const bf16*)acts[t * L + l - 1]; a.lds[nt] = ly.k;        // act' of the layer's stored input
+                if (l < L - 1) { a.res[nt] = gin; a.ldr[nt] = ly.n; }                   // the residual stream's gradient
+            }
+            if (nt && a.N != ly.k) { ups_set_error("ups_towers_bwd: towers of different widths at layer %d", l); return UPS_E_ARG; }
+            a.N = ly.k;                                   // the input gradient's "output channels" are the layer's inputs
+            a.A[nt] = gin; a.lda[nt] = ly.n; a.K[nt] = ly.n;
+            a.W[nt] = (const bf16*)ly.w_dgrad;
+            ++nt;
+        }
+        if (nt) hipLaunchKernelGGL(tower_gemm_kernel, dim3(a.N / 128, (M + 15) / 16, nt), dim3(256), 0, s, a);
+    }
+    if (want_wgrad) {
+        TowerWgArgs w = {};
+        w.M = M;
+        int ni = 0, kmax = 0, nmax = 0;
+        for (int i = 0; i < na; ++i)
+            for (int l = 0; l < L; ++l) {
+                const int t = act_t[i];
+                const ups_tower_layer& ly = layers[t * L + l];
+                if (!ly.grad_w) continue;
+                TowerWgItem& it = w.it[ni++];
+                it.X = (const bf16*)(l == 0 ? x0[t] : acts[t * L + l - 1]); it.ldx = l == 0 ? ld0[t] : ly.k;
+                it.G = (const bf16*)(l == L - 1 ? g_out[t] : g_ws[t * L + l]); it.ldg = ly.n;
+                it.dW = ly.grad_w; it.db = ly.grad_b; it.K = ly.k; it.N = ly.n;
+                kmax = ly.k > kmax ? ly.k : kmax; nmax = ly.n > nmax ? ly.n : nmax;
+            }
+        if (ni) hipLaunchKernelGGL(tower_wgrad_kernel, dim3(nmax / 64, (kmax + 63) / 64, ni), dim3(256), 0, s, w);
+    }
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }

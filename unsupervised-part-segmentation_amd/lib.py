@@ -71,6 +71,12 @@ class PrepItem(C.Structure):
                 ("dy", C.c_int32 * 3), ("dx", C.c_int32 * 3), ("ax", C.c_float), ("ay", C.c_float)]
 
 
+class TowerLayer(C.Structure):
+    """ups_tower_layer: one 1x1 layer of one critic tower (ups_towers_fwd / ups_towers_bwd)."""
+    _fields_ = [("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p), ("bias", C.c_void_p), ("grad_w", C.c_void_p), ("grad_b", C.c_void_p),
+                ("k", C.c_int32), ("n", C.c_int32)]
+
+
 _lib = None
 
 _I, _L, _F, _P, _Z = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -135,6 +141,9 @@ _SIGS = {
     "ups_randn": ([_P, _L, C.c_uint64, C.c_uint64, _P], C.c_int),
     "ups_critic_head_fwd": ([_P, _P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "ups_critic_head_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "ups_towers_fwd": ([C.POINTER(TowerLayer), _I, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_P), _I, _F, _P], C.c_int),
+    "ups_towers_bwd": ([C.POINTER(TowerLayer), _I, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                        C.POINTER(_P), C.POINTER(_I), _I, _I, _F, _P], C.c_int),
     "ups_latent_fwd": ([_P, _P, C.POINTER(_F), _I, _I, _I, _P, _P, _P], C.c_int),
     "ups_latent_bwd": ([_P, _P, C.POINTER(_F), _P, _P, _F, _I, _I, _I, _P, _P], C.c_int),
     "ups_adam": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P], C.c_int),

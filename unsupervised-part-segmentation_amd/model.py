@@ -860,9 +860,10 @@ class Trainer(object):
             if sd is not cur:
                 sd.wait_stream(c.main_stream)      # forked from the launching stream (a HIP-graph capture wants first-level forks) ...
                 sd.wait_stream(cur)                # ... and behind the appearance code
-        for ci, name in enumerate(names):
-            with torch.cuda.stream(sides[ci]):
-                one(ci, name)
+        if not self._critics_grouped(c, names, crit, alpha_in):
+            for ci, name in enumerate(names):
+                with torch.cuda.stream(sides[ci]):
+                    one(ci, name)
         if c.df:
             # SB_model48c:491-505, 672-684, 812-814: three single-sample decoders on batch item 0 (inputs under
             # stop_gradient), each with its own perceptual loss and optimizer key; one per side stream, behind that stream's critic
@@ -884,6 +885,55 @@ class Trainer(object):
         c.loss_dis0, _, c.acc0, _ = crit["mi0_discriminator"]
         c.loss_dis1, _, c.acc1, _ = crit["mi1_discriminator"]
         c.loss_est, _, c.acc_est, _ = crit["mi_estimator"]
+
+    def _critics_grouped(self, c, names, crit, alpha_in):
+        """The three critics through ops.TowersFn (round 5): six towers of six 1x1 layers as 6 forward launches, 5 + 1 input-gradient
+        launches per backward call and ONE launch for all 72 weight / bias gradients, on the current ("aux") stream -- against ~210
+        launches of a few blocks each on three streams.  The same graph as `one` above: the adversarial term differentiates critic
+        0's pi tower alone (skip_wgrad, retain_graph), the critics' own losses are differentiated together (their variables are
+        disjoint, so the sum's gradient is each loss's).  Returns False when the towers do not have the form the grouped launches
+        take (fp32 / non-leaky / materialised storage): the caller then runs the generic path."""
+        cfg, model, nets, bank = self.config, self.model, self.model.nets, self.model.bank
+        B, Z, A, keys, st, mi = c.B, c.Z, c.A, c.keys, c.st, c.mi
+        if not ops.TOWERS:
+            return False
+        towers = []
+        for name in names:
+            tw = nets.critic_layers(name, (Z, A))
+            if tw is None:
+                return False
+            towers += tw
+        pi_ins = [model.to_act(torch.cat([c.samples0[1 + 2 * ci], c.samples0[2 + 2 * ci]], 0).view(2 * B, 1, 1, Z)) for ci in range(3)]
+        xs = [x for ci in range(3) for x in (pi_ins[ci], alpha_in)]
+        if not ops.towers_eligible(towers, xs):
+            return False
+        pi_ins[0].requires_grad_(True)
+        params = [t for tw in towers for lay in tw for t in (lay.V, lay.b)]
+        hs = ops.TowersFn.apply(towers, *(xs + params))
+        losses = []
+        for ci, name in enumerate(names):
+            loss, acc, mean_joint = ops.CriticHeadFn.apply(hs[2 * ci], hs[2 * ci + 1], B, N.DSIZE)
+            crit[name] = (loss, mean_joint, acc, pi_ins[ci])
+            if ci == 0:
+                c.mim = mean_joint                                            # logit_constraint(real=False), model.py:855
+                if cfg.get("adversarial_regularization", True):               # model.py:886-909
+                    loa, loa_lr = st["loa"], mi.get("loa_lr", 4.0)
+                    loa_gain = c.mim - (1.0 - c.MI_SLACK) * c.MI_TARGET
+                    if mi.get("loa_adaptive", True):
+                        active = (loa_lr * loa_gain.detach() >= -loa).float()
+                        c.adv = active * (loa * loa_gain + loa_lr / 2.0 * loa_gain ** 2)
+                    else:
+                        c.adv = loa * loa_gain
+                    if "encoder_0" in keys:
+                        with ops.skip_wgrad():
+                            c.g_adv = torch.autograd.grad([c.adv], [pi_ins[0]], retain_graph=True)[0].float().view(2 * B, Z)[:B]
+            elif ci == 1:
+                c.ind_mim = mean_joint
+            if name in keys:
+                losses.append((name, loss))
+        if losses:
+            torch.autograd.grad([l for _, l in losses], [bank.params[n] for name, _ in losses for n in bank.groups[name]["names"]])
+        return True
 
     def _fwd_masks(self, c):
         """B forward: mask decoder z -> logits (model.py:411-412), then the un-taped part path (model.py:414-473): l = mean + eps,

@@ -373,6 +373,22 @@ class Nets(object):
     def critic(self, name, pair):
         return discriminator_towers(self._scope(name, self.config["discriminator"]), pair)
 
+    def critic_layers(self, name, widths):
+        """The ConvLayer objects discriminator_towers would run for inputs of `widths` channels, [[6 layers] per tower] -- the same
+        objects (variables, converted copies, gradient views) under the same keys, for the grouped launches of ops.TowersFn.  None
+        when the scope does not use the post-activation storage form those launches are written for."""
+        sc = self._scope(name, self.config["discriminator"])
+        if not sc.post_ok() or sc.coords:
+            return None
+        towers = []
+        for c in widths:
+            tw = [sc._layer(c, DSIZE, 1, 1, L.ACT_NONE, False, sc.act)]
+            for _ in range(4):
+                tw.append(sc._layer(DSIZE, DSIZE, 1, 1, sc.act, True, sc.act))
+            tw.append(sc._layer(DSIZE, DSIZE, 1, 1, sc.act, True, L.ACT_NONE))
+            towers.append(tw)
+        return towers
+
     def dsingle(self, name, z):
         """d_single / d_alpha / d_pi (SB_model48c:320-323): single_decoder_model with n_out = 3; the image stays in the
         activation dtype because it feeds the perceptual trunk."""

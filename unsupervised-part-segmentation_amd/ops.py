@@ -1324,6 +1324,96 @@ class CriticHeadFn(torch.autograd.Function):
         return gp, ga, None, None
 
 
+TOWERS = os.environ.get("UPS_TOWERS", "1") != "0"      # A/B switch: the critics' towers as grouped launches (ups_towers_*)
+
+
+def towers_eligible(towers, xs):
+    """towers: [[ConvLayer] * L] * T (nets.Nets.critic_layers), xs: their inputs [M, 1, 1, ld].  The grouped launches take bf16 rows,
+    the leaky-ReLU post-activation storage form and widths of 32 k / 128 n; anything else keeps the generic convolution path."""
+    if not TOWERS or not towers or len(towers) > 8 or not (2 <= len(towers[0]) <= 6):
+        return False
+    Ln = len(towers[0])
+    for tw, x in zip(towers, xs):
+        if len(tw) != Ln or x.dtype != torch.bfloat16 or x.shape[1:3] != (1, 1):
+            return False
+        for l, lay in enumerate(tw):
+            if lay.k != 1 or lay.stride != 1 or lay.coords or lay.f16 or lay.ci_log % 32 or lay.co % 128:
+                return False
+            want_in = (L.ACT_NONE, False) if l == 0 else (L.ACT_LRELU, True)
+            if (lay.act_in, lay.in_post) != want_in or lay.out_act != (L.ACT_LRELU if l < Ln - 1 else L.ACT_NONE):
+                return False
+            if l > 0 and (lay.ci_log != tw[l - 1].co or (l < Ln - 1 and lay.ci_log != lay.co)):
+                return False
+        if x.shape[-1] < tw[0].ci_log:
+            return False
+    return True
+
+
+class TowersFn(torch.autograd.Function):
+    """T towers of nin -> residual_block(k = 1) x (L - 2) -> nin (discriminator_model, model.py:159-173) as grouped launches: the same
+    layer of every tower in one launch, every weight / bias gradient in one (ups_towers_fwd / _bwd).  apply(towers, x_0 .. x_{T-1},
+    V, b of every layer tower-major) -> the T embeddings [M, 1, 1, n].  A backward call takes the towers whose output gradient it is
+    given (the adversarial term differentiates critic 0's pi tower alone, under skip_wgrad)."""
+
+    @staticmethod
+    def forward(ctx, towers, *tensors):
+        T, Ln = len(towers), len(towers[0])
+        xs = [t.contiguous() for t in tensors[:T]]
+        M, dev = xs[0].shape[0], xs[0].device
+        lay_arr = (L.TowerLayer * (T * Ln))()
+        for t, tw in enumerate(towers):
+            for l, lay in enumerate(tw):
+                ent = lay.prepared(L.BF16, 1, 1, need_dgrad=True)
+                e = lay_arr[t * Ln + l]
+                e.w_fwd, e.w_dgrad, e.bias = ent["w_fwd"].data_ptr(), ent["w_dgrad"].data_ptr(), lay.b.data_ptr()
+                e.grad_w = lay.grad_V.data_ptr() if lay.grad_V is not None else None
+                e.grad_b = lay.grad_b.data_ptr() if lay.grad_b is not None else None
+                e.k, e.n = lay.ci_log, lay.co
+        acts = [[torch.empty((M, 1, 1, lay.co), dtype=torch.bfloat16, device=dev) for lay in tw] for tw in towers]
+        x0 = (C.c_void_p * T)(*[x.data_ptr() for x in xs])
+        ld0 = (C.c_int32 * T)(*[x.shape[-1] for x in xs])
+        ap = (C.c_void_p * (T * Ln))(*[a.data_ptr() for tw in acts for a in tw])
+        slope = towers[0][0].slope
+        L.call("ups_towers_fwd", lay_arr, T, Ln, x0, ld0, ap, M, slope, L.stream())
+        outs = tuple(tw[-1] for tw in acts)
+        ctx.save_for_backward(*(xs + list(outs)))            # (the pointer arrays below stay valid while these are alive)
+        ctx.inner = [tw[:-1] for tw in acts]
+        ctx.towers, ctx.arrays, ctx.M, ctx.slope = towers, (lay_arr, x0, ld0, ap), M, slope
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gs):
+        towers, M = ctx.towers, ctx.M
+        T, Ln = len(towers), len(towers[0])
+        xs = list(ctx.saved_tensors[:T])
+        lay_arr, x0, ld0, ap = ctx.arrays
+        dev = xs[0].device
+        gout = [None if g is None else to_act_dtype(g, torch.bfloat16, towers[t][-1].co) for t, g in enumerate(gs)]
+        want_w = not GradMode.skip_wgrad
+        gx = [torch.empty_like(xs[t]) if (gout[t] is not None and ctx.needs_input_grad[1 + t] and towers[t][0].ci_log % 128 == 0
+                                          and xs[t].shape[-1] == towers[t][0].ci_log) else None for t in range(T)]
+        if any(gout[t] is not None and ctx.needs_input_grad[1 + t] and gx[t] is None for t in range(T)):
+            raise L.UpsError("TowersFn: the input gradient of a tower whose first layer is not 128 k wide")
+        ws = [[torch.empty((M, lay.co), dtype=torch.bfloat16, device=dev) if (gout[t] is not None and l < Ln - 1) else None
+               for l, lay in enumerate(tw)] for t, tw in enumerate(towers)]
+        gp = (C.c_void_p * T)(*[None if g is None else g.data_ptr() for g in gout])
+        wp = (C.c_void_p * (T * Ln))(*[None if w is None else w.data_ptr() for tw in ws for w in tw])
+        gxp = (C.c_void_p * T)(*[None if g is None else g.data_ptr() for g in gx])
+        ldg = (C.c_int32 * T)(*[x.shape[-1] for x in xs])
+        L.call("ups_towers_bwd", lay_arr, T, Ln, x0, ld0, ap, gp, wp, gxp, ldg, int(want_w), M, ctx.slope, L.stream())
+        grads = [None] + gx
+        for t, tw in enumerate(towers):
+            for lay in tw:
+                if want_w and gout[t] is not None and lay.grad_V is not None:
+                    grads += [lay.grad_V, lay.grad_b]
+                    if lay.after_wgrad is not None:
+                        lay.after_wgrad()
+                else:
+                    grads += [None, None]
+        return tuple(grads)
+
+
 class MaskPartsFn(torch.autograd.Function):
     """mask_parts + part-major transpose (model.py:176-187, nn.py:97-103): -> [P*B,H,W,8]."""
 
