@@ -406,6 +406,16 @@ int ups_critic_head_fwd(const void* h_pi, const void* h_al, int32_t dtype, int32
 int ups_critic_head_bwd(const void* h_pi, const void* h_al, const float* logits, const float* g_loss, const float* g_mim,
                         int32_t dtype, int32_t B, int32_t K, int32_t ld, void* g_h_pi, void* g_h_al, void* stream);
 
+/* ---------------------------------------------------------------- state update (M:28-35, 829-834, 861-866, 890-909, 921-930)
+ * stats[6] = {mean joint logit of critic 0 (mim), of critic 1 (independent mim), accuracy 0, accuracy 1, loss_dis0, loss_dis1}
+ * (batch means, already averaged over the ranks); old_state / new_state [9] = {avg_acc0, avg_acc1, avg_acc_error, avg_loss_dis0,
+ * avg_loss_dis1, avg_mim, avg_independent_mim, loa, lor}.  EMAs: new = decay * old + gain * value (value of avg_acc_error =
+ * acc1 - acc0); loa' = max(loa + loa_lr (mim - loa_target), 0) when update_loa, lor' = clip(lor + lor_lr (ind - lor_target),
+ * lor_min, lor_max) when update_lor, else copied.  One launch, every product and sum rounded on its own. */
+int ups_state_update(const float* stats, const float* old_state, float* new_state, float decay, float gain,
+                     int32_t update_loa, float loa_lr, float loa_target, int32_t update_lor, float lor_lr,
+                     float lor_target, float lor_min, float lor_max, void* stream);
+
 /* ---------------------------------------------------------------- the critics' towers as grouped launches (M:159-173, round 5)
  * discriminator_model is two towers of nin -> (L - 2) x residual_block(k = 1) -> nin on [M = 2B, 512] rows; the three critics of a
  * step are six such towers.  ups_towers_fwd runs layer l of EVERY tower in one launch (L launches), ups_towers_bwd the input

@@ -919,6 +919,27 @@ def test_critic_head(dtype, B, dev):
         assert_close(gh[1].float(), go[1].float(), gtol, "d / d h_alpha ({}, {})".format(wl, wm))
 
 
+def test_state_update_kernel(dev):
+    """ups_state_update against the scalar expressions it replaces (M:28-35 EMA, M:890-909 loa, M:921-930 lor): bit-identical to
+    the fp32 torch ops, with either multiplier frozen, and clipped where the reference clips."""
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(3)
+    for trial in range(6):
+        stats = (torch.randn(6, generator=g) * (3.0 if trial % 2 else 0.3)).to(dev)
+        old = (torch.randn(9, generator=g).abs() * (5.0 if trial >= 3 else 1.0)).to(dev)
+        up_loa, up_lor = trial % 3 != 1, trial % 3 != 2
+        loa_lr, loa_t, lor_lr, lor_t, lo, hi = 4.0, (1.0 - 0.05) * 0.125, 0.05, 0.125, 1.0, 7.5
+        out = torch.empty(9, device=dev)
+        lib.call("ups_state_update", lib.ptr(stats), lib.ptr(old), lib.ptr(out), 0.99, 1.0 - 0.99, int(up_loa), loa_lr, loa_t,
+                 int(up_lor), lor_lr, lor_t, lo, hi, lib.stream())
+        mim, ind, a0, a1, l0, l1 = stats.unbind(0)
+        ema = lambda o, v: 0.99 * o + (1.0 - 0.99) * v
+        want = [ema(old[0], a0), ema(old[1], a1), ema(old[2], a1 - a0), ema(old[3], l0), ema(old[4], l1), ema(old[5], mim), ema(old[6], ind),
+                torch.clamp(old[7] + loa_lr * (mim - loa_t), min=0.0) if up_loa else old[7],
+                torch.clamp(old[8] + lor_lr * (ind - lor_t), lo, hi) if up_lor else old[8]]
+        assert torch.equal(out, torch.stack(want)), (trial, out, torch.stack(want))
+
+
 @pytest.mark.parametrize("M", [128, 6, 40])
 def test_critic_towers_grouped(M, dev):
     """ops.TowersFn (ups_towers_fwd / _bwd: the same layer of every tower in one launch, every weight / bias gradient in one) against

@@ -242,6 +242,40 @@ extern "C" int ups_adam_dev(float* p, const float* g, float* m, float* v, int64_
     return UPS_OK;
 }
 
+// The step's state update (cub/code/SB_model48i/model.py:28-35, 829-834, 861-866, 890-909, 921-930) in ONE launch: seven EMAs and the
+// two multipliers.  As ~30 scalar torch launches this was the last thing a step enqueued, with the GPU long drained behind it.  The
+// products and sums are rounded one by one (no contraction), as the scalar torch expressions they replace were.
+namespace {
+__global__ void state_update_kernel(const float* __restrict__ stats, const float* __restrict__ old, float* __restrict__ out,
+                                    float decay, float gain, int up_loa, float loa_lr, float loa_target, int up_lor, float lor_lr,
+                                    float lor_target, float lor_min, float lor_max) {
+    const int i = threadIdx.x;
+    if (i >= 9) return;
+    const float mim = stats[0], ind = stats[1], acc0 = stats[2], acc1 = stats[3], l0 = stats[4], l1 = stats[5];
+    const float o = old[i];
+    float v;
+    if (i < 7) {
+        const float val = i == 0 ? acc0 : i == 1 ? acc1 : i == 2 ? __fsub_rn(acc1, acc0) : i == 3 ? l0 : i == 4 ? l1 : i == 5 ? mim : ind;
+        v = __fadd_rn(__fmul_rn(decay, o), __fmul_rn(gain, val));
+    } else if (i == 7) {
+        v = up_loa ? fmaxf(__fadd_rn(o, __fmul_rn(loa_lr, __fsub_rn(mim, loa_target))), 0.f) : o;
+    } else {
+        v = up_lor ? fminf(fmaxf(__fadd_rn(o, __fmul_rn(lor_lr, __fsub_rn(ind, lor_target))), lor_min), lor_max) : o;
+    }
+    out[i] = v;
+}
+}  // namespace
+
+extern "C" int ups_state_update(const float* stats, const float* old_state, float* new_state, float decay, float gain,
+                                int32_t update_loa, float loa_lr, float loa_target, int32_t update_lor, float lor_lr,
+                                float lor_target, float lor_min, float lor_max, void* stream) {
+    UPS_CHECK_ARG(stats && old_state && new_state && lor_min <= lor_max);
+    hipLaunchKernelGGL(state_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, old_state, new_state, decay, gain,
+                       update_loa, loa_lr, loa_target, update_lor, lor_lr, lor_target, lor_min, lor_max);
+    UPS_LAUNCH_CHECK();
+    return UPS_OK;
+}
+
 extern "C" int ups_gauss_hm(const float* pts, const float* stddev, float* out, int32_t B, int32_t h, int32_t w, int32_t K,
                             void* stream) {
     UPS_CHECK_ARG(pts && stddev && out);

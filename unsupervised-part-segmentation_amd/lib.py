@@ -141,6 +141,7 @@ _SIGS = {
     "ups_randn": ([_P, _L, C.c_uint64, C.c_uint64, _P], C.c_int),
     "ups_critic_head_fwd": ([_P, _P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
     "ups_critic_head_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "ups_state_update": ([_P, _P, _P, _F, _F, _I, _F, _F, _I, _F, _F, _F, _F, _P], C.c_int),
     "ups_towers_fwd": ([C.POINTER(TowerLayer), _I, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_P), _I, _F, _P], C.c_int),
     "ups_towers_bwd": ([C.POINTER(TowerLayer), _I, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                         C.POINTER(_P), C.POINTER(_I), _I, _I, _F, _P], C.c_int),

@@ -34,6 +34,10 @@ from .schedules import make_var, make_linear_var
 
 PERCEPTUAL_INPUTS = ("native", "resize256", "resize256_crop224")
 LATE_JOIN = os.environ.get("UPS_LATE_JOIN", "1") != "0"      # A/B switch: single rank joins the weight-gradient stream only before Adam
+# A/B switch (off: measured neutral, 2 032 / 2 034 against 2 017 / 2 057 img/s): enqueue the mask decoder's forward before the critics
+CRITICS_LATE = os.environ.get("UPS_CRITICS_LATE", "0") != "0"
+STATE_KERNEL = os.environ.get("UPS_STATE_KERNEL", "1") != "0"          # A/B switch: the state update as one launch (ups_state_update)
+STATE_KEYS = ("avg_acc0", "avg_acc1", "avg_acc_error", "avg_loss_dis0", "avg_loss_dis1", "avg_mim", "avg_independent_mim", "loa", "lor")
 CRITIC_STREAMS = os.environ.get("UPS_CRITIC_STREAMS", "1") != "0"      # A/B switch: the three critics on three side streams
 EARLY_ALPHA = os.environ.get("UPS_EARLY_ALPHA", "1") != "0"      # A/B switch: appearance code on "aux" beside the pose encoder
 JOIN_TIMING = os.environ.get("UPS_JOIN_TIMING", "0") == "1"
@@ -808,7 +812,7 @@ class Trainer(object):
         else:
             run()
 
-    def _critics(self, c):
+    def _critics(self, c, forked_at=None):
         """D: the three critics (model.py:502-521, 800-866), their own gradients, the adversarial gradient d adv / d z_joint0 for
         encoder_0 (model.py:886-909) and, for SB_model48c, the three single-sample decoders.  They depend on the latent samples
         and on the appearance code of the whole views only, and the main path needs them again at the encoder_0 backward: the
@@ -858,7 +862,10 @@ class Trainer(object):
         sides = [cur] + ([ops.Streams.get("aux{}".format(i), self.device) for i in (1, 2)] if multi else [cur, cur])
         for sd in sides[1:]:
             if sd is not cur:
-                sd.wait_stream(c.main_stream)      # forked from the launching stream (a HIP-graph capture wants first-level forks) ...
+                if forked_at is not None:          # (the launching stream has moved on to the mask decoder: fork where the samples exist)
+                    sd.wait_event(forked_at)
+                else:
+                    sd.wait_stream(c.main_stream)  # forked from the launching stream (a HIP-graph capture wants first-level forks) ...
                 sd.wait_stream(cur)                # ... and behind the appearance code
         if not self._critics_grouped(c, names, crit, alpha_in):
             for ci, name in enumerate(names):
@@ -1069,9 +1076,22 @@ class Trainer(object):
             self._boundary("scalars", stats)             # (the tensor lives in the graphs' pool: same address at every replay)
         else:
             D.average_scalars(stats, self.world_size, self.process_group)
+        new = dict(st)
+        up_loa = bool(cfg.get("adversarial_regularization", True) and mi.get("loa_adaptive", True))
+        up_lor = bool(c.var_reg and mi.get("lor_adaptive", True))
+        if STATE_KERNEL and stats.is_cuda and all(st[k].dtype == torch.float32 and st[k].device == stats.device for k in STATE_KEYS):
+            # one launch instead of ~30 scalar ones (they were the last thing a step enqueued, behind a drained GPU)
+            old = torch.stack([st[k].reshape(()) for k in STATE_KEYS])
+            vec = torch.empty_like(old)
+            L.call("ups_state_update", L.ptr(stats), L.ptr(old), L.ptr(vec), 0.99, 1.0 - 0.99, int(up_loa), mi.get("loa_lr", 4.0),
+                   (1.0 - c.MI_SLACK) * c.MI_TARGET, int(up_lor), mi.get("lor_lr", 0.05), c.MI_TARGET, mi.get("lor_min", 1.0),
+                   mi.get("lor_max", 7.5), L.stream())
+            for i, k in enumerate(STATE_KEYS):
+                if k not in ("loa", "lor") or (k == "loa" and up_loa) or (k == "lor" and up_lor):
+                    new[k] = vec[i]
+            return new
         g_mim, g_ind, g_acc0, g_acc1, g_l0, g_l1 = stats.unbind(0)
         ema = lambda old, val: 0.99 * old + (1.0 - 0.99) * val            # model.py:28-35
-        new = dict(st)
         new["avg_acc0"] = ema(st["avg_acc0"], g_acc0); new["avg_acc1"] = ema(st["avg_acc1"], g_acc1)
         new["avg_acc_error"] = ema(st["avg_acc_error"], g_acc1 - g_acc0)
         new["avg_loss_dis0"] = ema(st["avg_loss_dis0"], g_l0); new["avg_loss_dis1"] = ema(st["avg_loss_dis1"], g_l1)
@@ -1184,14 +1204,26 @@ class Trainer(object):
         self._step_graph_lr, self._adam_done = graph_lr, set()
         c = self._step_begin(batch, noise)
         self._fwd_pose(c)
-        if ops.Streams.enabled:
+        if ops.Streams.enabled and CRITICS_LATE and graph_lr is None:
+            # The critics need the latent samples only, but their block is ~50 launches of a few blocks each: enqueued FIRST, the
+            # launching stream sat idle behind the pose encoder until the host was through them (tools/probes/step_sequence.py).
+            # So the mask decoder's forward pass goes to the launching stream first and the critics to "aux" behind the point where
+            # the samples exist -- the host builds its lead on kernels that fill the chip.
+            ready = c.main_stream.record_event()
+            self._fwd_masks(c)
             aux = ops.Streams.get("aux", dev)
-            aux.wait_stream(c.main_stream)
+            aux.wait_event(ready)
             with torch.cuda.stream(aux):
-                self._critics(c)
+                self._critics(c, forked_at=ready)
         else:
-            self._critics(c)
-        self._fwd_masks(c)
+            if ops.Streams.enabled:
+                aux = ops.Streams.get("aux", dev)
+                aux.wait_stream(c.main_stream)
+                with torch.cuda.stream(aux):
+                    self._critics(c)
+            else:
+                self._critics(c)
+            self._fwd_masks(c)
         self._fwd_reconstruction(c)
         pending = self._bwd_reconstruction(c)
         self._priors(c)
