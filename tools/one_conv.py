@@ -22,9 +22,9 @@ V = (torch.randn(k, k, cin_v, cout, generator=g) / math.sqrt(k * k * cin_v)).to(
 b = torch.randn(cout, generator=g).to(dev)
 from upsparts_amd import lib
 lay = ops.ConvLayer("x/conv2d_0", V, b, k, stride, coords, act)
-plain = len(sys.argv) > 3 and sys.argv[3] == "plain"
-bits = len(sys.argv) > 3 and sys.argv[3] == "bits"
-f8 = len(sys.argv) > 3 and sys.argv[3] == "f8"
+plain = "plain" in sys.argv[3:]
+bits = "bits" in sys.argv[3:]         # forward: the launch also writes the sign bytes; input gradient: it reads them instead of x
+f8 = "f8" in sys.argv[3:]
 # (the fp8 WEIGHT gradient of a mask-decoder layer reads the fp16 forward tensor as the model hands it over)
 fmt = lib.F16 if (not plain and (not f8 or mode == "wgrad") and case.startswith("dv_") and k == 3) else None
 lay.f16 = fmt == lib.F16
@@ -55,7 +55,10 @@ for _ in range(3):
     if mode == "fwd":
         if f8:
             F.next_in = {"t": x8, "slot": sx, "act": lay.act_in, "site": None}
+        ops.SignBits.want, ops.SignBits.last = bool(bits), None
         ops.conv_forward(x, lay, res=res, fmt=fmt, res_post=lay.in_post)
+        if bits:
+            assert ops.SignBits.take() is not None, "the launch did not write the sign bytes"
     elif mode == "dgrad":
         if f8:
             F.register_grad_copy(gy, {"t": g8, "slot": sg, "site": None})

@@ -26,6 +26,7 @@ rd = 2 * 1024 * sum(vals["FETCH_SIZE"]) / max(1, len(vals["FETCH_SIZE"]))
 wr = 1024 * sum(vals["WRITE_SIZE"]) / max(1, len(vals["WRITE_SIZE"]))
 json.dump({"kernel": key, "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 tools/one_conv.py " + args,
            "launches_seen": [len(vals["FETCH_SIZE"]), len(vals["WRITE_SIZE"])],
+           "tree": __import__("os").environ.get("UPS_TREE", "unrecorded"),
            "correction": "gfx950: FETCH_SIZE x2 (it reports half the bytes of wide coalesced reads), WRITE_SIZE exact",
            "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr,
            "algorithmic_bytes_per_launch_tensor_once": alg, "traffic_over_algorithmic": (rd + wr) / alg if alg else None},
