@@ -29,8 +29,8 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (guide)
 PEAK_F32_TFLOPS = 157.3
 PEAK_FP8_TFLOPS = 5000.0           # dense fp8 on the block-scaled K = 128 MFMA (guide); the K = 32 fp8 forms run at the bf16 rate
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("round5_pmc_dv_rb128.json", "round4_pmc_dv_rb128.json")]   # tools/profile_round.sh
-PMC_FILES_FP8 = [os.path.join(ROOT, "profiles", f) for f in ("round5_pmc_dv_rb128_fp8.json", "round4_pmc_dv_rb128_fp8.json")]       # the fp8 mode's input-gradient launch
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("round5b_pmc_dv_rb128.json", "round5_pmc_dv_rb128.json", "round4_pmc_dv_rb128.json")]   # tools/profile_round.sh
+PMC_FILES_FP8 = [os.path.join(ROOT, "profiles", f) for f in ("round5b_pmc_dv_rb128_fp8.json", "round5_pmc_dv_rb128_fp8.json", "round4_pmc_dv_rb128_fp8.json")]       # the fp8 mode's input-gradient launch
 CPU_THREAD_CAP = 32                # torch-CPU stops scaling on this graph well before the GPU box's core count (see cpu_baseline)
 
 
@@ -228,6 +228,7 @@ def run_rank(args):
         traffic = None
         pmc_used = None
         pmc_tree = None
+        pmc_alg = None
         # HBM bytes per launch of the roofline kernel from the PMC passes committed for this tree (profiles/), not live; they were
         # taken on the headline shape (2 x 64 images of 128x128, 256 channels, bf16): reported for exactly that launch only
         if args.config == "cub128p10" and args.precision in ("bf16", "fp8") and args.batch == 64:
@@ -238,6 +239,8 @@ def run_rank(args):
                     traffic = pj["traffic_bytes_per_launch"]
                     pmc_used = os.path.relpath(pf, ROOT)
                     pmc_tree = pj.get("tree", "unrecorded (taken before round 5: the 823-launch tree of round 4)")
+                    pmc_alg = pj.get("algorithmic_bytes_per_launch_tensor_once")
+                    pmc_alg = pmc_alg if isinstance(pmc_alg, (int, float)) else pj.get("algorithmic_total")
                     break
                 except Exception:
                     traffic = None
@@ -281,8 +284,9 @@ def run_rank(args):
                             "launches_timed": len(ops.KernelTimer.events), "traffic": traffic,
                             "traffic_note": "HBM bytes of the forward launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes "
                                             "({}); tensor-once algorithmic bytes {}".format(
-                                                pmc_used, "3.76e9 of the input-gradient launch (e5m2 copy of the gradient in, the bf16 gradient as residual, the forward input for act', "
-                                                "bf16 out)" if args.precision == "fp8" else "2.15e9") if traffic else
+                                                pmc_used, "{:.3g} of the input-gradient launch (e5m2 copy of the gradient in, the bf16 gradient as residual, the "
+                                                "producer's sign bytes for act', bf16 out)".format(pmc_alg or 0.0) if args.precision == "fp8" else
+                                                "{:.3g} (input, output, sign bytes, weights)".format(pmc_alg or 0.0)) if traffic else
                                             "no PMC pass committed for this launch shape",
                             "flop_per_launch": ops.KernelTimer.flops}}
         if traffic:      # the PMC passes are not live: say which tree they were taken on, so a traffic regression is not hidden by a stale file
