@@ -119,9 +119,13 @@ __device__ inline float ups_act(float x, int act, float slope) {
 // max(x, slope * x) for 0 <= slope <= 1 (the launchers check the range): the same product and hence the same bits as
 // x > 0 ? x : slope * x.  v_max_f32 is written out so that no canonicalising max(x, x) is put in front of it.
 __device__ __forceinline__ float ups_vmax(float a, float b) {
+#ifdef UPS_VMAX_BUILTIN         // (hazard hunt, tools/probes/rows_hazard.sh: the compiler-visible form)
+    return __builtin_fmaxf(a, b);
+#else
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#endif
 }
 __device__ inline float ups_act_ns(float x, float slope_eff) { return ups_vmax(x, slope_eff * x); }
 __device__ inline float ups_slope_eff(int act, float slope) { return act == UPS_ACT_LRELU ? slope : 0.f; }

@@ -146,8 +146,15 @@ __global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) 
         // The requests of iteration it - L (input rows up to 2 it + 3, act' rows 2 it, 2 it + 1) must have landed.  Younger operations
         // that may stay in flight: the requests of iterations it - L + 1 .. it - 1 (GS each) and, from the first real iteration on,
         // their two stores each (counted once: a lower bound that holds for every it >= 1)
+#ifdef UPS_ROWS_WAIT0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * (GS + NV) + 2) : "memory");
+#endif
+#ifdef UPS_ROWS_LGKM0
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_s_barrier();
         uint2 dva[2][2];                        // DG == 2: act' operand [row][channel block], requested ahead of the row requests
         if constexpr (DG == 2) {
@@ -192,13 +199,36 @@ __global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) 
                     for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
+#ifdef UPS_ROWS_TIED
+                            // (hazard hunt: accumulators tied to their registers; hipcc does not see an MFMA here, so the waits it
+                            // would add around one are written out: UPS_ROWS_NOP is defined with this switch)
+                            if constexpr (__is_same(T, bf16))
+                                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[r][j]) : "v"(wb[t][kc][j]), "v"(a[r + dyi][kc]));
+                            else
+                                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[r][j]) : "v"(wb[t][kc][j]), "v"(a[r + dyi][kc]));
+#else
                             if constexpr (__is_same(T, bf16))
                                 acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[t][kc][j], a[r + dyi][kc], acc[r][j], 0, 0, 0);
                             else
                                 acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][kc][j], a[r + dyi][kc], acc[r][j], 0, 0, 0);
+#endif
                         }
                 }
+#ifdef UPS_ROWS_SCHEDB
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+#ifdef UPS_ROWS_NOP
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef UPS_ROWS_SB_END
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef UPS_ROWS_NOP_ONLY
+        asm volatile("s_nop 15\n\ts_nop 15");
+#endif
         // ---- epilogue: lane (p16, q16) holds channels cg * 32 + 16 j + 4 q16 + e of pixel (row, 16 ct + p16)
         const int Pc = 16 * ct + p16 + 1;
         if constexpr (DG == 2)      // behind the act' loads only this iteration's two row requests may still be in flight
@@ -253,7 +283,12 @@ __global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) 
             const uint4 o = *(const uint4*)(stage + (lane >> 2) * 80 + (lane & 3) * 16);
             *(uint4*)(out_img + ((long long)y * W + 16 * ct + (lane >> 2)) * p.ldo * 2 + (cg * 32 + 8 * (lane & 3)) * 2) = o;
             // (no sign bytes from this kernel: its outputs feed `downsample` convolutions, which apply no activation to their input --
-            // and one more conditional store here made the 64-channel instance irreproducible, docs/design/negative_results.md)
+            // and one more conditional store here made the 64-channel instance irreproducible, docs/design/negative_results.md;
+            // -DUPS_ROWS_FWD_SIGN rebuilds that form for tools/probes/rows_hazard.sh)
+#ifdef UPS_ROWS_FWD_SIGN
+            if (p.sign_out)
+                p.sign_out[(((long long)img * p.h + y) * W + 16 * ct + (lane >> 2)) * (p.ldo >> 3) + cg * 4 + (lane & 3)] = (unsigned char)ups_sign_byte(o);
+#endif
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (outstanding row requests past the band target this block's LDS)
