@@ -140,9 +140,9 @@ __global__ __launch_bounds__(256) void tower_gemm_kernel(const TowerGemmArgs a) 
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + 16 * j + 4 * q16;
         float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
-        if (a.bias[tw]) {
-            const float4 b4 = *(const float4*)(a.bias[tw] + n);
-            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        if (a.bias[tw]) {               // (scalar loads: a bias is a 4-byte aligned slice of its key's flat parameter buffer)
+            const float* bp = a.bias[tw] + n;
+            v[0] += bp[0]; v[1] += bp[1]; v[2] += bp[2]; v[3] += bp[3];
         }
         if (a.sgn[tw]) {                // input gradient: act' off the sign of the stored forward input
             const uint2 sw = *(const uint2*)(a.sgn[tw] + (long long)m * a.lds[tw] + n);
@@ -267,6 +267,7 @@ bool tower_layers_ok(const ups_tower_layer* ly, int T, int L) {
     for (int i = 0; i < T * L; ++i) {
         const ups_tower_layer& l = ly[i];
         if (!l.w_fwd || !l.w_dgrad || l.k <= 0 || l.n <= 0 || l.k % 32 || l.n % 128) return false;
+        if (((uintptr_t)l.w_fwd & 15) || ((uintptr_t)l.w_dgrad & 15) || ((uintptr_t)l.bias & 3) || ((uintptr_t)l.grad_w & 3) || ((uintptr_t)l.grad_b & 3)) return false;
         const int li = i % L;
         if (li > 0 && l.k != ly[i - 1].n) return false;             // the chain's widths
         if (li > 0 && li < L - 1 && l.k != l.n) return false;       // residual layers are square
@@ -287,7 +288,8 @@ extern "C" int ups_towers_fwd(const ups_tower_layer* layers, int32_t T, int32_t 
         a.out_act = l < L - 1 ? 1 : 0;
         for (int t = 0; t < T; ++t) {
             const ups_tower_layer& ly = layers[t * L + l];
-            UPS_CHECK_ARG(ly.n == a.N && acts[t * L + l] && (l > 0 || (x0[t] && ld0[t] >= ly.k)));
+            UPS_CHECK_ARG(ly.n == a.N && acts[t * L + l] && (l > 0 || (x0[t] && ld0[t] >= ly.k && ld0[t] % 8 == 0)));
+            UPS_CHECK_ARG(((uintptr_t)acts[t * L + l] & 15) == 0 && (l > 0 || ((uintptr_t)x0[t] & 15) == 0));      // 16-byte fragments
             a.A[t] = (const bf16*)(l == 0 ? x0[t] : acts[t * L + l - 1]);
             a.lda[t] = l == 0 ? ld0[t] : ly.k;
             a.W[t] = (const bf16*)ly.w_fwd; a.bias[t] = ly.bias; a.K[t] = ly.k;
@@ -317,6 +319,7 @@ extern "C" int ups_towers_bwd(const ups_tower_layer* layers, int32_t T, int32_t 
             const int t = act_t[i];
             const ups_tower_layer& ly = layers[t * L + l];
             const bf16* gin = (const bf16*)(l == L - 1 ? g_out[t] : g_ws[t * L + l]);
+            UPS_CHECK_ARG(gin && ((uintptr_t)gin & 15) == 0);
             if (l == 0) {
                 if (!g_x0 || !g_x0[t]) continue;
                 UPS_CHECK_ARG(ldg0 && ldg0[t] >= ly.k && ly.k % 128 == 0);

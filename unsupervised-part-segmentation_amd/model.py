@@ -912,8 +912,8 @@ class Trainer(object):
             towers += tw
         pi_ins = [model.to_act(torch.cat([c.samples0[1 + 2 * ci], c.samples0[2 + 2 * ci]], 0).view(2 * B, 1, 1, Z)) for ci in range(3)]
         xs = [x for ci in range(3) for x in (pi_ins[ci], alpha_in)]
-        if not ops.towers_eligible(towers, xs):
-            return False
+        if not ops.towers_eligible(towers, xs) or Z % 128 or pi_ins[0].shape[-1] != Z:      # (the adversarial term's input gradient is
+            return False                                                                    # written 128 channels per block)
         pi_ins[0].requires_grad_(True)
         params = [t for tw in towers for lay in tw for t in (lay.V, lay.b)]
         hs = ops.TowersFn.apply(towers, *(xs + params))
