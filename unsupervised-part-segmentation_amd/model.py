@@ -36,6 +36,7 @@ PERCEPTUAL_INPUTS = ("native", "resize256", "resize256_crop224")
 LATE_JOIN = os.environ.get("UPS_LATE_JOIN", "1") != "0"      # A/B switch: single rank joins the weight-gradient stream only before Adam
 # A/B switch (off: measured neutral, 2 032 / 2 034 against 2 017 / 2 057 img/s): enqueue the mask decoder's forward before the critics
 CRITICS_LATE = os.environ.get("UPS_CRITICS_LATE", "0") != "0"
+PRE_FREE = os.environ.get("UPS_PRE_FREE", "0") != "0"                  # A/B switch: the target's perceptual features do not wait for the previous step
 STATE_KERNEL = os.environ.get("UPS_STATE_KERNEL", "1") != "0"          # A/B switch: the state update as one launch (ups_state_update)
 STATE_KEYS = ("avg_acc0", "avg_acc1", "avg_acc_error", "avg_loss_dis0", "avg_loss_dis1", "avg_mim", "avg_independent_mim", "loa", "lor")
 CRITIC_STREAMS = os.environ.get("UPS_CRITIC_STREAMS", "1") != "0"      # A/B switch: the three critics on three side streams
@@ -745,7 +746,19 @@ class Trainer(object):
         c.ft_pre, c.ft_ready = None, None
         if ops.Streams.enabled:
             pre = ops.Streams.get("pre", dev)
-            pre.wait_stream(c.main_stream)
+            # The target's features depend on the batch alone.  When the batch arrives ready (resident, fp32, no in-graph TPS) nothing
+            # the launching stream has queued is an input of this block, so it need not wait for the previous step's tail (Adam,
+            # weight conversion, the thin last layers of the backward pass): it only must not overwrite the previous step's features
+            # before that step's perceptual backward has read them (the event recorded there) -- a host that runs a step ahead
+            # then fills the previous step's bubbles with this block instead of sharing the chip with the pose encoder.
+            src = batch["view0"] if df else batch["view0_target"]
+            free = (PRE_FREE and getattr(self, "_cap", None) is None and self._step_graph_lr is None and torch.is_tensor(src)
+                    and vt.data_ptr() == src.data_ptr() and not model.use_tps and c.crop_yx is None)
+            consumed = getattr(self, "_ft_consumed", None)
+            if free and consumed is not None:
+                pre.wait_event(consumed)
+            else:
+                pre.wait_stream(c.main_stream)
             with torch.cuda.stream(pre), torch.no_grad():
                 tgt_pre = vt if c.pmode == "native" else self._perceptual_view(c, model.to_act(vt))
                 c.ft_pre = self.vgg.features(tgt_pre, c.T)
@@ -996,6 +1009,8 @@ class Trainer(object):
         rec_keys = [k for k in ("encoder_1", "decoder_delta") if k in c.keys]
         rec_params = [bank.params[n] for k in rec_keys for n in bank.groups[k]["names"]]
         gr = torch.autograd.grad([c.auto_rec], [c.hard0, c.hard1] + rec_params)
+        if c.ft_pre is not None and getattr(self, "_cap", None) is None:
+            self._ft_consumed = c.main_stream.record_event()        # (the target's features have been read: _step_begin, PRE_FREE)
         c.g_hard0, c.g_hard1 = gr[0].contiguous(), gr[1].contiguous()
         return self._launch_reduce(rec_keys)
 
