@@ -282,8 +282,9 @@ def run_rank(args):
                             "kernel_ms": round(kms, 4), "kernel_ms_forward": round(ops.KernelTimer.mean_ms("fwd"), 4),
                             "kernel_ms_dgrad": round(ops.KernelTimer.mean_ms("dgrad"), 4),
                             "launches_timed": len(ops.KernelTimer.events), "traffic": traffic,
-                            "traffic_note": "HBM bytes of the forward launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes "
+                            "traffic_note": "HBM bytes of the {} launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes "
                                             "({}); tensor-once algorithmic bytes {}".format(
+                                                "input-gradient" if args.precision == "fp8" else "forward",
                                                 pmc_used, "{:.3g} of the input-gradient launch (e5m2 copy of the gradient in, the bf16 gradient as residual, the "
                                                 "producer's sign bytes for act', bf16 out)".format(pmc_alg or 0.0) if args.precision == "fp8" else
                                                 "{:.3g} (input, output, sign bytes, weights)".format(pmc_alg or 0.0)) if traffic else
