@@ -3,7 +3,7 @@ all-reduce (identity) exactly where the multi-GPU run issues it -- asynchronousl
 side streams, with the early encoder_0 head slice -- and the result must equal the run without collectives bit for bit.  A third
 run adds `hip_graph: True`: the step captured as a sequence of HIP graphs cut at the collectives, RCCL all-reduces issued eagerly
 between the replayed segments (model.Trainer._capture_step).
-Usage: UPS_FORCE_COLLECTIVES=1 python tools/nccl_trainer_check.py"""
+Usage: UPS_FORCE_COLLECTIVES=1 python tools/nccl_trainer_check.py [towers]"""
 import copy, os, sys
 import torch
 import torch.distributed as dist
@@ -17,6 +17,8 @@ assert D.FORCE_COLLECTIVES
 dev = torch.device("cuda:0")
 cfg = copy.deepcopy(configs.cub_config(n_parts=4, batch_size=2, spatial_size=32))      # the CUB yaml at reduced widths
 cfg.update(precision="bf16", vgg_widths=(8, 8, 16, 16, 16), patch_size=8, z0_size=16, local_app_size=16)
+if len(sys.argv) > 1 and sys.argv[1] == "towers":      # the yaml's latent widths (256 / 64): the critics run as grouped launches (ops.TowersFn)
+    cfg.update(z0_size=256, local_app_size=64)
 cfg["encoder0"].update(config=[16, 32, 32, 64], extra_resnets=1)
 cfg["encoder1"].update(config=[16, 32, 32, 64], extra_resnets=1)
 cfg["dv"].update(config=[8, 16, 32, 40], upsample_config=["linear"] * 3)
