@@ -412,6 +412,67 @@ def test_side_stream_schedules_are_bit_identical(variant, dev, monkeypatch):
     assert runs["one_stream"][2] == runs["side_streams"][2]
 
 
+def test_grouped_critics_match_the_generic_path(dev, monkeypatch):
+    """The critics' towers as grouped launches (ops.TowersFn, the default where the latent widths allow it) against the generic
+    convolution path (UPS_TOWERS=0) inside the whole step: the yaml's latent widths (256 / 64) at tiny spatial sizes, one step from
+    the same weights, views and noise.  The storage points are the same, so the two differ by fp32 summation order only: critic
+    losses, the adversarial term's effect (encoder_0's gradient) and every critic gradient agree (cosine >= 0.9999, norms within
+    1 %), the state update agrees; and the host-order variants of the step (UPS_CRITICS_LATE, UPS_PRE_FREE) and the one-launch state
+    update leave a grouped run BIT-identical."""
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import model as M, ops
+    from oracle import ref_model as R, configs
+    cfg = copy.deepcopy(configs.tiny_config(variant="cub"))
+    cfg.update(precision="bf16", vgg_widths=VGG_W, z0_size=256, local_app_size=64)
+
+    def run(steps=2):
+        c = copy.deepcopy(cfg)
+        model = M.TrainModel(c, device=dev, seed=0)
+        tr = M.Trainer(c, None, model)
+        out = []
+        for step in range(steps):
+            losses = tr.train_step(R.synthetic_views(c, seed=100 + step), R.synthetic_noise(c, seed=200 + step))
+            torch.cuda.synchronize()
+            out.append(({k: float(v) for k, v in losses.items()},
+                        {k: g["flat"]["g"].detach().cpu().clone() for k, g in model.bank.groups.items()},
+                        {k: g["flat"]["p"].detach().cpu().clone() for k, g in model.bank.groups.items()},
+                        {k: float(v) for k, v in tr.state.items()}))
+        return out
+
+    calls = {"n": 0}
+    orig = ops.TowersFn.forward
+
+    def counted(ctx, towers, *tensors):
+        calls["n"] += 1
+        return orig(ctx, towers, *tensors)
+    monkeypatch.setattr(ops.TowersFn, "forward", staticmethod(counted))
+    grouped = run()
+    assert calls["n"] == 2, "the grouped path did not run"
+    monkeypatch.setattr(ops, "TOWERS", False)
+    generic = run()
+    assert calls["n"] == 2, "UPS_TOWERS=0 still took the grouped path"
+    (la, ga, _, sa), (lb, gb, _, sb) = grouped[0], generic[0]
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    for k in ga:
+        a, b = ga[k].double(), gb[k].double()
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        bar = 0.9999 if "discriminator" in k or "estimator" in k or k == "encoder_0" else 0.999
+        assert cos >= bar and abs(float(a.norm() / (b.norm() + 1e-30)) - 1.0) <= 1e-2, (k, cos, float(a.norm()), float(b.norm()))
+    for k in sa:
+        assert abs(sa[k] - sb[k]) <= 1e-4 * max(1.0, abs(sb[k])), (k, sa[k], sb[k])
+    # host-order / stream-order variants and the torch form of the state update: the same launches, so the same bits
+    monkeypatch.setattr(ops, "TOWERS", True)
+    for name, val in (("CRITICS_LATE", True), ("PRE_FREE", True), ("STATE_KERNEL", False)):
+        monkeypatch.setattr(M, name, val)
+        other = run()
+        monkeypatch.setattr(M, name, not val)
+        for (l0, g0, p0, s0), (l1, g1, p1, s1) in zip(grouped, other):
+            assert l0 == l1 and s0 == s1, name
+            for k in p0:
+                assert torch.equal(p0[k], p1[k]), (name, k)
+
+
 def test_forty_steps_bf16_and_fp8_track_fp32(dev):
     """A short training run on a fixed synthetic batch (mid-size config with 64-wide decoders, 32x32): 40 optimizer steps in
     fp32, bf16 and fp8-forward mode from the same initial weights.  Every loss stays finite, the reconstruction loss falls by
