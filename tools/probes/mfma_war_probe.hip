@@ -34,6 +34,13 @@
 #define MFMA_CN "v_mfma_f32_16x16x32_bf16 v[104:107], v[112:115], v[116:119], v[100:103]\n\t"      /* consumer of v[100:103], D != C, A = 0 */
 #define MFMA_CT "v_mfma_f32_16x16x32_bf16 v[104:107], v[112:115], v[116:119], v[104:107]\n\t"      /* consumer of v[104:107], tied, A = 0 */
 #define FINISH "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\tv_mov_b32 %0, v104\n\tv_mov_b32 %1, v105\n\tv_mov_b32 %2, v106\n\tv_mov_b32 %3, v107"
+/* does the VALU's OWN write survive?  read back C's last / first register after the overwrite */
+#define FINISH_C "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\tv_mov_b32 %0, v103\n\tv_mov_b32 %1, v100\n\tv_mov_b32 %2, v104\n\tv_mov_b32 %3, v107"
+#define WRITE03 "v_mov_b32 v103, 0x7fc00000\n\tv_mov_b32 v100, 0x7fc00000\n\t"
+/* the epilogue's first arithmetic: VALU writes into C's registers (the residual halves), then a packed add with swapped halves */
+#define PKADD "v_mov_b32 v103, %4\n\tv_mov_b32 v102, %5\n\tv_mov_b32 v122, %4\n\tv_mov_b32 v123, %4\n\t" \
+              "v_pk_add_f32 v[120:121], v[122:123], v[102:103] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+#define FINISH_PK "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\tv_mov_b32 %0, v120\n\tv_mov_b32 %1, v121\n\tv_mov_b32 %2, v104\n\tv_mov_b32 %3, v107"
 #define CLOB "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123"
 
 #define NOPS0 ""
@@ -59,6 +66,9 @@ __device__ __forceinline__ void one(float cval, unsigned bval, float& o0, float&
     if constexpr (VAR == 7) asm volatile(SETUP MFMA_T N WRITE3 FINISH : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(cval), "v"(bval) : CLOB);          \
     if constexpr (VAR == 8) asm volatile(SETUP MFMA_T MFMA_I N WRITE3 FINISH : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(cval), "v"(bval) : CLOB);   \
     if constexpr (VAR == 9) asm volatile(SETUP MFMA_P MFMA_I MFMA_T N WRITEB FINISH : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(cval), "v"(bval) : CLOB); \
+    if constexpr (VAR == 12) asm volatile(SETUP MFMA_P MFMA_I MFMA_T MFMA_I N PKADD FINISH_PK : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(cval), "v"(bval) : CLOB); \
+    if constexpr (VAR == 10) asm volatile(SETUP MFMA_T N WRITE03 FINISH_C : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(cval), "v"(bval) : CLOB);         \
+    if constexpr (VAR == 11) asm volatile(SETUP MFMA_P MFMA_I MFMA_T MFMA_I N WRITE03 FINISH_C : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(cval), "v"(bval) : CLOB); \
     if constexpr (VAR == 3) asm volatile(SETUP MFMA_P1T N MFMA_CN FINISH : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(cval), "v"(bval) : CLOB);                  \
     if constexpr (VAR == 4) asm volatile(SETUP MFMA_P1T MFMA_I N MFMA_CN FINISH : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(cval), "v"(bval) : CLOB);           \
     if constexpr (VAR == 5) asm volatile(SETUP MFMA_P1N N MFMA_CT FINISH : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(cval), "v"(bval) : CLOB);                  \
@@ -88,8 +98,16 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* bad, int iters)
         one<VAR, K>(cval, 0x3f803f80u, o0, o1, o2, o3);
         const float want = (VAR >= 3 && VAR <= 6) ? cval + 32.0f : cval;     // (A = 0: D must equal C; VAR >= 3: C plus the producer's 32)
         if (it == 0 && blockIdx.x == 0 && threadIdx.x == 5) { ((float*)bad)[6] = o0; ((float*)bad)[7] = want; }
-        w0 |= o0 != want;
-        wx |= o1 != want || o2 != want || o3 != want;          // the registers that are not overwritten
+        if constexpr (VAR == 12) {      // o0 = v122 + v103 = 2 cval, o1 = v123 + v102 = cval + float(bval bits); o2 / o3 = D = C as it was
+            w0 |= o0 != cval + cval || o1 != cval + __uint_as_float(0x3f803f80u);
+            wx |= o2 != cval || o3 != cval;
+        } else if constexpr (VAR >= 10) {      // o0 / o1 = C's last / first register after the VALU wrote the marker, o2 / o3 = D
+            w0 |= __float_as_uint(o0) != 0x7fc00000u || __float_as_uint(o1) != 0x7fc00000u;
+            wx |= o2 != cval || o3 != cval;
+        } else {
+            w0 |= o0 != want;
+            wx |= o1 != want || o2 != want || o3 != want;          // the registers that are not overwritten
+        }
     }
     const unsigned long long b0 = __ballot(w0), bx = __ballot(wx);
     if (lane == 0 && (b0 | bx)) { atomicOr(&bad[0], b0); atomicAdd(&bad[1], 1ull); atomicOr(&bad[2], bx); }
@@ -120,6 +138,9 @@ int main() {
     sweep<7>(d, "MFMA (D != C) alone, LAST register of C overwritten");
     sweep<8>(d, "MFMA (D != C) + indep. MFMA, LAST register of C");
     sweep<9>(d, "chain of 3 MFMAs, then SrcB overwritten (A = 0)");
+    sweep<12>(d, "chain + MFMAs in flight, VALU writes into C, v_pk_add_f32 op_sel");
+    sweep<10>(d, "MFMA (D != C), then VALU writes C: does the WRITE survive");
+    sweep<11>(d, "chain + MFMA (D != C) + indep., VALU writes C: survives?");
     sweep<3>(d, "RAW: tied producer -> consumer with D != C");
     sweep<4>(d, "RAW: tied producer, indep. MFMA -> consumer D != C");
     sweep<5>(d, "RAW: producer with D != C -> tied consumer");
