@@ -36,6 +36,7 @@ PERCEPTUAL_INPUTS = ("native", "resize256", "resize256_crop224")
 LATE_JOIN = os.environ.get("UPS_LATE_JOIN", "1") != "0"      # A/B switch: single rank joins the weight-gradient stream only before Adam
 # A/B switch (off: measured neutral, 2 032 / 2 034 against 2 017 / 2 057 img/s): enqueue the mask decoder's forward before the critics
 CRITICS_LATE = os.environ.get("UPS_CRITICS_LATE", "0") != "0"
+LAZY_SIDES = os.environ.get("UPS_LAZY_SIDES", "0") != "0"             # A/B switch: no extra critic streams when the critics run grouped
 PRE_FREE = os.environ.get("UPS_PRE_FREE", "0") != "0"                  # A/B switch: the target's perceptual features do not wait for the previous step
 STATE_KERNEL = os.environ.get("UPS_STATE_KERNEL", "1") != "0"          # A/B switch: the state update as one launch (ups_state_update)
 STATE_KEYS = ("avg_acc0", "avg_acc1", "avg_acc_error", "avg_loss_dis0", "avg_loss_dis1", "avg_mim", "avg_independent_mim", "loa", "lor")
@@ -273,6 +274,8 @@ class Trainer(object):
                       "avg_acc0": _scalar(0.5, d), "avg_acc1": _scalar(0.5, d), "avg_acc_error": _scalar(0.0, d),
                       "avg_loss_dis0": _scalar(1.0, d), "avg_loss_dis1": _scalar(1.0, d),
                       "avg_mim": _scalar(0.0, d), "avg_independent_mim": _scalar(0.0, d)}
+        if os.environ.get("UPS_STREAM_ORDER") and ops.Streams.enabled and torch.device(d).type == "cuda":
+            ops.Streams.precreate(d, os.environ["UPS_STREAM_ORDER"].split(","))
         self._gen = torch.Generator(device=d)
         self._gen.manual_seed(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))      # TPS uniforms, crop window
         self._noise = ops.NoiseStream(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))  # the sampling noise
@@ -872,6 +875,11 @@ class Trainer(object):
         # (not in a captured step: replayed from a HIP graph the three branches cost more than they save -- 1 887 against 1 919 img/s
         # with one critic stream, eager 1 979 -- so a capture keeps the one-stream form)
         multi = ops.Streams.enabled and ops.Streams.on_aux(self.device) and CRITIC_STREAMS and self._step_graph_lr is None
+        # (LAZY_SIDES: with the critics on grouped launches the two extra critic streams are only needed by SB_model48c's single-sample
+        # decoders -- not creating them changes which of the remaining streams share a hardware queue)
+        grouped = LAZY_SIDES and self._critics_grouped(c, names, crit, alpha_in)
+        if LAZY_SIDES and grouped and not c.df:
+            multi = False
         sides = [cur] + ([ops.Streams.get("aux{}".format(i), self.device) for i in (1, 2)] if multi else [cur, cur])
         for sd in sides[1:]:
             if sd is not cur:
@@ -880,7 +888,7 @@ class Trainer(object):
                 else:
                     sd.wait_stream(c.main_stream)  # forked from the launching stream (a HIP-graph capture wants first-level forks) ...
                 sd.wait_stream(cur)                # ... and behind the appearance code
-        if not self._critics_grouped(c, names, crit, alpha_in):
+        if not (grouped if LAZY_SIDES else self._critics_grouped(c, names, crit, alpha_in)):
             for ci, name in enumerate(names):
                 with torch.cuda.stream(sides[ci]):
                     one(ci, name)

@@ -93,6 +93,18 @@ class Streams(object):
             cls._raw[key] = st.cuda_stream
         return st
 
+    _pads = []
+
+    @classmethod
+    def precreate(cls, device, order):
+        """Create the side streams in a given order before their first use ("pad" = a stream nobody uses): the HIP runtime deals
+        streams onto its hardware queues in creation order, and streams that share a queue serialize (UPS_STREAM_ORDER, A/B runs)."""
+        for name in order:
+            if name == "pad":
+                cls._pads.append(torch.cuda.Stream(device=device))
+            elif name:
+                cls.get(name, device)
+
     @classmethod
     def on_aux(cls, device):
         cur, idx = L.raw_stream(device), torch.device(device).index
