@@ -9,8 +9,8 @@ exactly that; 0.1 % of the elements wrong, not reproducible).
 
 This script compiles the file to assembly and checks, for every kernel: between an asm-block `global_load_{ubyte,dword,dwordx2,...}`
 and the next asm-block `s_waitcnt vmcnt`, no instruction reads or writes the load's destination registers.
-A DIAGNOSTIC, not a gate: the two-tile input-gradient form (conv3x3_rows2_kernel<.., DG>) has such moves in every build so far and is
-switched off by default for that reason (UPS_ROWS2_DG); the one-tile forms (DG = 2, A/B only) are clean in this build.
+Round 6: a BUILD GATE (csrc/build.sh -> tools/check_listing.py, rule `asm-loads`).  The forms that violated it (the two-tile input
+gradient, the DG == 2 one-tile form) are deleted; what is left to check is conv3x3_rows_maskgrad_kernel's view loads.
 Usage: python tools/check_asm_loads.py [file.hip ...]      (exit code 1 on a violation)"""
 import os
 import re
@@ -46,6 +46,12 @@ def check(path):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-inline-asm", "-S",
                                "--cuda-device-only", os.path.abspath(path), "-o", out], cwd=os.path.dirname(os.path.abspath(path)), stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
+    return check_listing(lines)
+
+
+def check_listing(lines):
+    """The check itself, on the lines of a device listing (the build gate tools/check_listing.py runs it on the listing of the very
+    flags the object was built with)."""
     bad, kernel, in_asm, pending, n_loads = [], None, False, {}, 0
     for i, raw in enumerate(lines):
         ln = raw.strip()

@@ -24,6 +24,10 @@ for r in range(reps):
     torch.cuda.synchronize()
     d = (y - y0).abs()
     bad = d > 0.05 * (y0.abs() + 0.1)
+    if os.environ.get("UPS_REPRO_CH"):      # observation builds overwrite a neighbouring channel on purpose: look at this one only
+        keep = torch.zeros_like(bad)
+        keep[..., int(os.environ["UPS_REPRO_CH"])] = True
+        bad &= keep
     nb = int(bad.sum())
     if nb:
         bad_runs += 1
@@ -34,4 +38,14 @@ for r in range(reps):
         # what do the wrong values look like: equal to a neighbouring row's / an earlier image's result?
         i0 = idx[0].tolist()
         print("        first: (img %d, y %d, x %d, c %d) got %.4f want %.4f" % (*i0, float(y[tuple(i0)]), float(y0[tuple(i0)])))
+        # accumulator view (round 6): undo the stored activation and take the residual off -- what the MFMA chain held
+        inv = lambda t: torch.where(t > 0, t, t / 0.2)
+        res = inv(xd.float())
+        for j in range(min(3, idx.shape[0])):
+            k = tuple(idx[j].tolist())
+            print("        acc view %s: got %.4f want %.4f (residual %.4f, bias %.4f)" % (
+                k, float(inv(y)[k] - res[k]), float(inv(y0)[k] - res[k]), float(res[k]), float(b[k[3]])))
+            k1 = k[:3] + (k[3] + 1,)        # the neighbouring channel: where the observation builds (ab/d_*) put a copy of a register
+            print("          channel +1: pre-activation got %.4f want %.4f (its residual %.4f; want - residual = %.4f)" % (
+                float(inv(y)[k1]), float(inv(y0)[k1]), float(res[k1]), float(inv(y0)[k1] - res[k1])))
 print("%d of %d runs differ from the patch kernel" % (bad_runs, reps))

@@ -1,18 +1,29 @@
 #!/bin/bash
 # Build libupsparts_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [outdir]
+# Files with listing gates (flags.sh: ups_file_gates) are also compiled to a device listing, which tools/check_listing.py must pass
+# before the library is linked: a rebuild with another hipcc cannot silently bring back a form this tree has measured wrong.
 set -e
 cd "$(dirname "$0")"
 OUT=${1:-.}
-HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-inline-asm"
+. ./flags.sh
 mkdir -p build
 pids=()
-for f in conv_igemm conv3x3_patch conv3x3_first conv3x3_s2 conv3x3_rows conv_wgrad conv_wgrad3x3 conv_wgrad3x3_f8 conv_aux pointwise partpath priors latent_adam critic; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ tile.h -nt build/$f.o ] || [ build.sh -nt build/$f.o ] || [ ../../include/upsparts_hip.h -nt build/$f.o ]; then
-    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+gated=()
+for f in $UPS_SOURCES; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ tile.h -nt build/$f.o ] || [ build.sh -nt build/$f.o ] || [ flags.sh -nt build/$f.o ] || [ ../../include/upsparts_hip.h -nt build/$f.o ]; then
+    ups_quiet $HIPCC $UPS_FLAGS $(ups_file_flags $f) -c $f.hip -o build/$f.o &
     pids+=($!)
+    if [ -n "$(ups_file_gates $f)" ]; then
+      ups_quiet $HIPCC $UPS_FLAGS $(ups_file_flags $f) -S --cuda-device-only $f.hip -o build/$f.s &
+      pids+=($!)
+      gated+=($f)
+    fi
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
+for f in "${gated[@]}"; do
+  python3 ../../tools/check_listing.py --rules "$(ups_file_gates $f)" build/$f.s || { rm -f build/$f.o; echo "listing gate failed for $f.hip: not linking"; exit 1; }
+done
 $HIPCC --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT/libupsparts_hip.so
+$HIPCC --version | head -1 > $OUT/libupsparts_hip.hipcc_version
 echo "built $OUT/libupsparts_hip.so"

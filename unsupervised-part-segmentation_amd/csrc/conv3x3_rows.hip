@@ -48,14 +48,40 @@ __device__ unsigned char ups_rows_zero[262144];
 
 __device__ __forceinline__ int r_swz(int P) { return ((P >> 2) & 1) << 1; }     // (g, g^2, g, g^2): conv3x3_patch.hip a_swz16
 
+// ---- Correctness rules of this file (round 6; the hunt and its evidence: docs/design/rows_hazard.md) ------------------------------
+// Round 5 left conv3x3_rows_kernel<bf16,64,6,10,false,0> "correct by timing": one more never-taken conditional store in its epilogue
+// (-DUPS_ROWS_FWD_SIGN, kept below as the reproducer) made output channel 12 of the even rows wrong in 99 launches of 100.  Round 6
+// traced the wrong element, with listing-level patches that change ONE thing at a time (tools/asm_patch_build.sh), to the epilogue's
+// first PACKED fp32 instruction, `v_pk_add_f32 acc, acc, residual op_sel:[0,1] op_sel_hi:[1,0]`: in lanes 48..63 its low half came back
+// as `acc + 0` although both operands were read intact by the instructions right before and right after it -- only in the four waves
+// that reach their epilogue while their SIMD sibling is still inside its MFMA section, only within ~16 cycles of a fixed point of the
+// epilogue.  It is NOT an MFMA operand hazard (renaming every register involved off the MFMA operands changes nothing), not the row
+// DMA, not an early LDS return.  Two independent cures, both measured at 0 wrong launches of 500 on the reproducer build and at no
+// cost on the step (profiles/round6_rows_hazard_*.txt):
+//   1. no packed fp32 VALU instructions in this translation unit: it is compiled with `-target-feature -packed-fp32-ops`
+//      (csrc/flags.sh), and tools/check_listing.py fails the build if a v_pk_*_f32 appears in its listing;
+//   2. ups_rows_fence(): 32 idle issue slots between the MFMA section and the epilogue of every iteration, pinned by scheduling
+//      barriers, in every kernel of this file that runs its epilogue beside a sibling's MFMA section.
+// The forms whose operands arrived by inline-asm REGISTER loads with hand-counted waits (hipcc is free to move such registers before
+// the wait: the two-tile input gradient and the DG == 2 one-tile form) are deleted; the one kernel that still loads registers that way
+// (conv3x3_rows_maskgrad_kernel) is checked by tools/check_asm_loads.py at build time.
+__device__ __forceinline__ void ups_rows_fence() {
+#ifndef UPS_ROWS_NO_FENCE
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // CI input channels (32 / 64), image width 1 << LW (128 / 64): 8 waves = (W / 16 column tiles) x (8 / (W / 16) groups of 32 outputs),
 // i.e. 32 outputs at W = 128, 64 at W = 64.  NR ring rows.  FLIP: the input gradient's tap order (dy = 1 - t / 3, dx = 1 - t % 3).
 // DG: 0 forward-type epilogue; 1 act' from a second DMA ring of the forward input's rows (one block per CU at 32 channels);
 // 3 (round 5): act' from the producer's SIGN BYTES (RowsK.dact_bits), the same second ring with 4 bytes per pixel and plane instead
-// of 64 -- by LDS-DMA like everything else these kernels fetch inside their loop (no register results for hipcc to move);
-// 2 act' by counted inline-asm loads in the accumulator layout (no ring: two blocks per CU at 32 channels)
+// of 64 -- by LDS-DMA like everything else these kernels fetch inside their loop (no register results for hipcc to move).
+// (DG == 2, act' by counted inline-asm register loads, was deleted in round 6: see the rules above.)
 template <typename T, int CI, int LW, int NR, bool FLIP, int DG>
-__global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) ? 4 : 2) void conv3x3_rows_kernel(const RowsK p) {
+__global__ __launch_bounds__(512, (CI == 32 && DG == 0 && NR <= 8) ? 4 : 2) void conv3x3_rows_kernel(const RowsK p) {
+    static_assert(DG == 0 || DG == 1 || DG == 3, "act' operand: none, the forward input's rows, or its sign bytes");
     constexpr int W = 1 << LW, KC = CI / 32, NCT = W / 16;
     constexpr int PL = (W + 2) * 64;            // bytes of one 32-channel plane of a row
     constexpr int RB = KC * PL;                 // bytes of a row buffer
@@ -63,8 +89,6 @@ __global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) 
     constexpr int L = (NR - 4) / 2;             // iterations of lead of the row requests (NR = 2 L + 4)
     constexpr int DR = (DG == 1 || DG == 3) ? 2 * L + 2 : 0;   // ring rows of the act' operand (W pixels x 64 B x output-channel planes; no halo)
     constexpr int GS = (DG == 1 || DG == 3) ? 4 : 2;            // DMA instructions a wave issues per iteration
-    constexpr int NV = DG == 2 ? 4 : 0;         // act' loads per wave and iteration (DG == 2)
-    static_assert(DG != 2 || L == 2, "the counted waits of the asm-load form are written for a lead of two iterations");
     constexpr int NCG = 8 / NCT;                // output-channel groups of 32 = planes of the output / act' rows
     constexpr int DRB = DG == 3 ? 8 * 256 : NCG * W * 64;       // (DG == 3: one dword per lane and wave: the pixel's four sign bytes of the wave's plane)
     static_assert(KC * NCT == 8 && NCG * NCT == 8, "one DMA piece per wave and row");
@@ -106,7 +130,7 @@ __global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) 
     // act' operand (DG): wave (segment ct, plane cg) moves 16 pixels x 64 B of row y of the forward input (no halo, no swizzle
     // needed: the epilogue reads 8 bytes per lane at a 64-byte pixel pitch -- 2-way conflicts on a 4-instruction read)
     const unsigned dd_off = (unsigned)((16 * ct + (lane >> 2)) * p.ldd * 2 + cg * 64 + ((lane & 3) << 4));
-    const unsigned char* da_img = (DG == 1 || DG == 2) ? p.dact + (long long)img * p.h * W * p.ldd * 2 : nullptr;
+    const unsigned char* da_img = DG == 1 ? p.dact + (long long)img * p.h * W * p.ldd * 2 : nullptr;
     auto issue_row = [&](int k) __attribute__((always_inline)) {
         const int y = y0 - 1 + k;
         const unsigned char* src = (unsigned)y < (unsigned)p.h ? in_img + (long long)y * row_bytes : ups_rows_zero;
@@ -146,26 +170,9 @@ __global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) 
         // The requests of iteration it - L (input rows up to 2 it + 3, act' rows 2 it, 2 it + 1) must have landed.  Younger operations
         // that may stay in flight: the requests of iterations it - L + 1 .. it - 1 (GS each) and, from the first real iteration on,
         // their two stores each (counted once: a lower bound that holds for every it >= 1)
-#ifdef UPS_ROWS_WAIT0
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * (GS + NV) + 2) : "memory");
-#endif
-#ifdef UPS_ROWS_LGKM0
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS + 2) : "memory");
         __builtin_amdgcn_s_barrier();
-        uint2 dva[2][2];                        // DG == 2: act' operand [row][channel block], requested ahead of the row requests
-        if constexpr (DG == 2) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const unsigned char* dp = da_img + ((long long)min(y0 + 2 * it + r, p.h - 1) * W + 16 * ct + p16) * p.ldd * 2 + (cg * 32 + 16 * j + 4 * q16) * 2;
-                    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dva[r][j]) : "v"(dp) : "memory");
-                }
-        }
         // the ring slots of input rows 2 it - 2, 2 it - 1 (and of the act' rows of iteration it - 1) are free now
         issue_row(2 * it + 2 * L + 2);
         issue_row(2 * it + 2 * L + 3);
@@ -199,40 +206,16 @@ __global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) 
                     for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-#ifdef UPS_ROWS_TIED
-                            // (hazard hunt: accumulators tied to their registers; hipcc does not see an MFMA here, so the waits it
-                            // would add around one are written out: UPS_ROWS_NOP is defined with this switch)
-                            if constexpr (__is_same(T, bf16))
-                                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[r][j]) : "v"(wb[t][kc][j]), "v"(a[r + dyi][kc]));
-                            else
-                                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[r][j]) : "v"(wb[t][kc][j]), "v"(a[r + dyi][kc]));
-#else
                             if constexpr (__is_same(T, bf16))
                                 acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[t][kc][j], a[r + dyi][kc], acc[r][j], 0, 0, 0);
                             else
                                 acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[t][kc][j], a[r + dyi][kc], acc[r][j], 0, 0, 0);
-#endif
                         }
                 }
-#ifdef UPS_ROWS_SCHEDB
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
-#ifdef UPS_ROWS_NOP
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef UPS_ROWS_SB_END
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef UPS_ROWS_NOP_ONLY
-        asm volatile("s_nop 15\n\ts_nop 15");
-#endif
+        ups_rows_fence();
         // ---- epilogue: lane (p16, q16) holds channels cg * 32 + 16 j + 4 q16 + e of pixel (row, 16 ct + p16)
         const int Pc = 16 * ct + p16 + 1;
-        if constexpr (DG == 2)      // behind the act' loads only this iteration's two row requests may still be in flight
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(dva[0][0]), "+v"(dva[0][1]), "+v"(dva[1][0]), "+v"(dva[1][1]) :: "memory");
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int y = yb + r;
@@ -242,12 +225,6 @@ __global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) 
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[r][j][e];
-                if constexpr (DG == 2) {
-                    float d0, d1, d2, d3;
-                    ups_unpack2<T>(dva[r][j].x, d0, d1); ups_unpack2<T>(dva[r][j].y, d2, d3);
-                    v[0] *= d0 > 0.f ? 1.f : p.dact_ns; v[1] *= d1 > 0.f ? 1.f : p.dact_ns;
-                    v[2] *= d2 > 0.f ? 1.f : p.dact_ns; v[3] *= d3 > 0.f ? 1.f : p.dact_ns;
-                }
                 if constexpr (DG == 3) {
                     const unsigned w4 = *(const unsigned*)(dring + ((2 * it + r) % DR) * DRB + wid * 256 + p16 * 4);
                     const unsigned nib = w4 >> (8 * (2 * j + (q16 >> 1)) + 4 * (q16 & 1));      // the lane's four channels
@@ -282,9 +259,10 @@ __global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) 
             }
             const uint4 o = *(const uint4*)(stage + (lane >> 2) * 80 + (lane & 3) * 16);
             *(uint4*)(out_img + ((long long)y * W + 16 * ct + (lane >> 2)) * p.ldo * 2 + (cg * 32 + 8 * (lane & 3)) * 2) = o;
-            // (no sign bytes from this kernel: its outputs feed `downsample` convolutions, which apply no activation to their input --
-            // and one more conditional store here made the 64-channel instance irreproducible, docs/design/negative_results.md;
-            // -DUPS_ROWS_FWD_SIGN rebuilds that form for tools/probes/rows_hazard.sh)
+            // (no sign bytes from this kernel: its outputs feed `downsample` convolutions, which apply no activation to their input.
+            // -DUPS_ROWS_FWD_SIGN adds the conditional store that made the 64-channel instance irreproducible in round 5; together with
+            // -DUPS_ROWS_NO_FENCE and packed fp32 instructions allowed it is the REPRODUCER of docs/design/rows_hazard.md, and with this
+            // file's two rules in force it is the regression build of tools/probes/rows_hunt.sh: 0 wrong launches)
 #ifdef UPS_ROWS_FWD_SIGN
             if (p.sign_out)
                 p.sign_out[(((long long)img * p.h + y) * W + 16 * ct + (lane >> 2)) * (p.ldo >> 3) + cg * 4 + (lane & 3)] = (unsigned char)ups_sign_byte(o);
@@ -298,18 +276,16 @@ __global__ __launch_bounds__(512, (CI == 32 && (DG == 0 || DG == 2) && NR <= 8) 
 // The same stream with TWO column tiles per wave: 16 (column tile, channel group) jobs per row instead of 8 -- 64 channels at 128
 // columns (VGG block 1, the hourglass decoder, encoder_1's second residual block of the 256x256 configs) and 32 channels at 256 columns
 // (its first).  Two DMA pieces per wave and row, one block per CU (133 KB of row ring).  Forward-type epilogue (bias, residual from the
-// centre row, stored activation); FLIP for input gradients without an activation derivative.
-// DG: input gradient with act'(x): the sign of the stored forward input, 8 bytes per lane, block and row in the accumulator layout,
-// by inline-asm loads issued ahead of the iteration's row requests and waited for with their own count (no second LDS ring).
-template <typename T, int CI, int LW, int NR, bool FLIP, bool DG>
+// centre row, stored activation); FLIP for input gradients without an activation derivative.  (The input gradient WITH act' of these
+// shapes takes the patch kernel, which reads the producer's sign bytes: the act' form of this kernel brought its operand in by
+// inline-asm register loads that hipcc moved ahead of their counted wait -- off since round 5, deleted in round 6.)
+template <typename T, int CI, int LW, int NR, bool FLIP>
 __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsK p) {
     constexpr int W = 1 << LW, KC = CI / 32, NCT = W / 16, NCP = NCT / 2;       // column tiles, column-tile pairs
     constexpr int PL = (W + 2) * 64, RB = KC * PL, ST = 16 * 80;
     constexpr int L = (NR - 4) / 2;
     constexpr int GS = 4;                       // DMA instructions (= stores) a wave issues per iteration
-    constexpr int NV = DG ? 8 : 0;              // act' loads per wave and iteration (2 rows x 2 column tiles x 2 channel blocks)
     static_assert(KC * NCT == 16 && (8 / NCP) * NCP == 8, "two DMA pieces per wave and row");
-    static_assert(!DG || L == 2, "the counted waits of the act' form are written for a lead of two iterations");
     typedef typename RFrag<T>::type frag_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
@@ -359,26 +335,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsK p) {
     const int iters = (y1 - y0 + 1) >> 1;
     unsigned char* out_img = p.out + (long long)img * p.h * W * p.ldo * 2;
     for (int it = 0; it < iters; ++it) {
-        // (as conv3x3_rows_kernel; per wave and iteration, in this order: NV act' loads, four row requests, four stores.  The requests
-        // of iteration it - L must have landed: younger are the other prologue requests (it == 0) or at least the whole previous
-        // iteration (it >= 1, L == 2 in the act' form))
+        // (as conv3x3_rows_kernel; per wave and iteration four row requests and four stores.  The requests of iteration it - L must
+        // have landed: younger are the other prologue requests (it == 0) or the later iterations' requests and this count of stores)
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * (GS + NV) + 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * GS + 4) : "memory");
         __builtin_amdgcn_s_barrier();
         const int yb = y0 + 2 * it;
-        uint2 dv[2][2][2];                      // [column tile][row][channel block]
-        if constexpr (DG) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const unsigned char* dp = p.dact + (((long long)img * p.h + min(yb + r, p.h - 1)) * W + 16 * (2 * ctp + c) + p16) * p.ldd * 2 +
-                                                  (cg * 32 + 16 * j + 4 * q16) * 2;
-                        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dv[c][r][j]) : "v"(dp) : "memory");
-                    }
-        }
         issue_row(2 * it + 2 * L + 2);
         issue_row(2 * it + 2 * L + 3);
         const unsigned char* rowp[4];
@@ -418,13 +380,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsK p) {
                             }
                     }
             }
+            ups_rows_fence();
             const int Pc = 16 * ct + p16 + 1;
-            if constexpr (DG) {
-                // the act' values of this column tile: behind them only the four row requests (and, for the second tile, the first
-                // tile's two stores) may still be in flight
-                if (c == 0) asm volatile("s_waitcnt vmcnt(4)" : "+v"(dv[0][0][0]), "+v"(dv[0][0][1]), "+v"(dv[0][1][0]), "+v"(dv[0][1][1]),
-                                         "+v"(dv[1][0][0]), "+v"(dv[1][0][1]), "+v"(dv[1][1][0]), "+v"(dv[1][1][1]) :: "memory");
-            }
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int y = min(yb + r, p.h - 1);
@@ -433,12 +390,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsK p) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[r][j][e];
-                    if constexpr (DG) {
-                        float d0, d1, d2, d3;
-                        ups_unpack2<T>(dv[c][r][j].x, d0, d1); ups_unpack2<T>(dv[c][r][j].y, d2, d3);
-                        v[0] *= d0 > 0.f ? 1.f : p.dact_ns; v[1] *= d1 > 0.f ? 1.f : p.dact_ns;
-                        v[2] *= d2 > 0.f ? 1.f : p.dact_ns; v[3] *= d3 > 0.f ? 1.f : p.dact_ns;
-                    }
                     if (p.res_self) {
                         const int c32 = 16 * j + 4 * q16;
                         const uint2 rr = *(const uint2*)(rowp[1 + r] + cg * PL + Pc * 64 + (((c32 >> 3) ^ r_swz(Pc)) << 4) + (q16 & 1) * 8);
@@ -465,17 +416,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsK p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename T, int CI, int LW, int NR, bool FLIP, bool DG = false>
+template <typename T, int CI, int LW, int NR, bool FLIP>
 int launch_rows2(const RowsK& k, hipStream_t s) {
     constexpr int W = 1 << LW, KC = CI / 32;
     constexpr size_t smem = (size_t)NR * KC * (W + 2) * 64 + 8 * 16 * 80 + 256;
     static UpsPerDevice attr_set;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_rows2_kernel<T, CI, LW, NR, FLIP, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3x3_rows2_kernel<T, CI, LW, NR, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return UPS_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_rows2_kernel<T, CI, LW, NR, FLIP, DG>), dim3(k.n * k.bands), dim3(512), smem, s, k);
+    hipLaunchKernelGGL((conv3x3_rows2_kernel<T, CI, LW, NR, FLIP>), dim3(k.n * k.bands), dim3(512), smem, s, k);
     return UPS_OK;
 }
 
@@ -578,6 +529,7 @@ __global__ __launch_bounds__(512, CTW == 1 ? 4 : 2) void conv3x3_rows_maskgrad_k
                     for (int dyi = 0; dyi < 3; ++dyi)
                         acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[(2 - dyi) * 3 + (2 - dx)], a[r + dyi], acc[r], 0, 0, 0);
             }
+            ups_rows_fence();
             // the view values: behind them the 2 CTW row requests (and the first tile's two stores) may stay in flight
             if (c == 0) {
                 if constexpr (CTW == 1) asm volatile("s_waitcnt vmcnt(2)" : "+v"(vw[0][0]), "+v"(vw[0][1]) :: "memory");
@@ -692,6 +644,7 @@ __global__ __launch_bounds__(512, CI == 32 ? 4 : 2) void conv3x3_rows_s2_kernel(
                 }
             }
         }
+        ups_rows_fence();
         const int y = y0 + it;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -801,6 +754,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_s2x2_kernel(const RowsK p
                     }
                 }
             }
+            ups_rows_fence();
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float v[4];
@@ -1059,16 +1013,13 @@ template <typename T>
 int launch_rows_t(const RowsK& k, int ci, int w, bool flip, bool dg, hipStream_t s) {
     // ring depths: measured (tools/bench_conv.py ea_rb0 / ea_rb1): deeper rings at one block per CU lose to 8 rows at two blocks per CU
     // (0.42 vs 0.35 ms forward at 32 channels); 64 channels keep 144 weight registers per lane and run one block per CU either way
-    // act' of the one-tile kernel: through the second DMA ring by default.  UPS_ROWS_DG=2: counted inline-asm loads -- no ring, so
-    // the 32-channel form would fit two blocks per CU, but at the 128 registers that allows it spills 14 (scratch accesses in the
-    // loop: see DESIGN section 3 on what those do to the row pipeline); kept for A/B runs
-    static int dgm = -1;
-    if (dgm < 0) { const char* e = getenv("UPS_ROWS_DG"); dgm = (e && e[0] == '2') ? 2 : 1; }
+    // act' of the one-tile kernel: the producer's sign bytes (DG == 3) or the forward input's rows (DG == 1), both through the second
+    // DMA ring
     if (ci == 32 && w == 128) {
         if (dg) {
             if (!flip) return 1;
             if (k.dact_bits) return launch_rows<T, 32, 7, 8, true, 3>(k, s);
-            return dgm == 1 ? launch_rows<T, 32, 7, 8, true, 1>(k, s) : launch_rows<T, 32, 7, 8, true, 2>(k, s);
+            return launch_rows<T, 32, 7, 8, true, 1>(k, s);
         }
         return flip ? launch_rows<T, 32, 7, 8, true, 0>(k, s) : launch_rows<T, 32, 7, 8, false, 0>(k, s);
     }
@@ -1076,7 +1027,7 @@ int launch_rows_t(const RowsK& k, int ci, int w, bool flip, bool dg, hipStream_t
         if (dg) {
             if (!flip) return 1;
             if (k.dact_bits) return launch_rows<T, 64, 6, 10, true, 3>(k, s);
-            return dgm == 1 ? launch_rows<T, 64, 6, 10, true, 1>(k, s) : launch_rows<T, 64, 6, 8, true, 2>(k, s);
+            return launch_rows<T, 64, 6, 10, true, 1>(k, s);
         }
         return flip ? launch_rows<T, 64, 6, 10, true, 0>(k, s) : launch_rows<T, 64, 6, 10, false, 0>(k, s);
     }
@@ -1123,20 +1074,7 @@ int ups_conv3x3_rows_try(const ups_conv_desc* d, hipStream_t s) {
     k.res_self = d->res != nullptr; k.res_act = d->res_act; k.out_act = d->out_act;
     k.slope = d->act_slope; k.dact_ns = d->dact_kind == UPS_ACT_LRELU ? d->act_slope : 0.f;
     const bool dg = d->dact != nullptr;
-    if (two && dg) {        // (bf16 and flipped taps: checked above)
-        // Round 5: OFF by default (UPS_ROWS2_DG=1 turns it back on for A/B runs).  The act' operand of this form arrives by inline-asm
-        // register loads with a hand-counted wait; hipcc is free to MOVE those registers before the wait statement, and does
-        // (tools/check_asm_loads.py: `v_mov_b64 v[236:237], v[186:187]` 114 instructions after the load, seven more just ahead of
-        // the wait) -- the kernel then multiplies by whatever the register held when it was copied.  It has always passed its parity
-        // tests because the loads land within those ~114 instructions in practice, but nothing guarantees that, and one more
-        // conditional store in the kernel moved a copy forward far enough to corrupt 0.1 % of the elements.  These launches (VGG
-        // block 1, the hourglass decoder's 128-wide levels, the 256 x 256 configs' first residual block) take the patch kernel, whose
-        // input gradient reads the producer's sign bytes since this round.
-        static int on = -1;
-        if (on < 0) { const char* e = getenv("UPS_ROWS2_DG"); on = (e && e[0] == '1') ? 1 : 0; }
-        if (!on) return 1;
-        return d->ci == 64 ? launch_rows2<bf16, 64, 7, 8, true, true>(k, s) : launch_rows2<bf16, 32, 8, 8, true, true>(k, s);
-    }
+    if (two && dg) return 1;        // the input gradient WITH act' of the two-tile shapes: the patch kernel (it reads the sign bytes)
     if (two) {
         if (d->ci == 64) {
             if (d->dtype == UPS_F16) return flip ? launch_rows2<f16, 64, 7, 8, true>(k, s) : launch_rows2<f16, 64, 7, 8, false>(k, s);

@@ -1,0 +1,19 @@
+# Compiler flags of libupsparts_hip.so, sourced by build.sh and by the A/B builders (tools/ab_build.sh, tools/asm_patch_build.sh) so that
+# an A/B library differs from the shipped one by exactly what its command line says.
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+UPS_FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-inline-asm"
+UPS_SOURCES="conv_igemm conv3x3_patch conv3x3_first conv3x3_s2 conv3x3_rows conv_wgrad conv_wgrad3x3 conv_wgrad3x3_f8 conv_aux pointwise partpath priors latent_adam critic"
+# per-file flags.  conv3x3_rows: no packed fp32 VALU instructions (rule 1 of that file's header; docs/design/rows_hazard.md).  The
+# feature switch is a cc1 option, so the HOST pass of the same command line sees it too and says "not a recognized feature": filtered.
+ups_file_flags() {
+  case "$1" in
+    conv3x3_rows) [ -n "$UPS_ROWS_ALLOW_PK" ] || echo "-Xclang -target-feature -Xclang -packed-fp32-ops" ;;
+  esac
+}
+ups_quiet() { "$@" 2> >(grep -v "is not a recognized feature for this target" >&2); }
+# listing gates (tools/check_listing.py <rules> <listing>): which rules a file's device listing must pass before the library is linked
+ups_file_gates() {
+  case "$1" in
+    conv3x3_rows) echo "no-packed-fp32 asm-loads" ;;
+  esac
+}

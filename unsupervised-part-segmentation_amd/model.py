@@ -281,6 +281,7 @@ class Trainer(object):
         self._noise = ops.NoiseStream(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))  # the sampling noise
         self._lazy_logs, self._done_thunk = None, None
         self._adam_done, self._step_graph_lr = set(), None
+        self._adam_stepped = set()      # keys whose Adam step of the RUNNING training step has been enqueued (cleared when the step ends)
         # `stream_plan` (full | compact | auto): how the step's logical streams map onto HIP streams (ops.Streams.set_plan).  auto =
         # full on one rank, compact under data parallelism, where the collectives' stream needs a hardware queue of its own
         # (measured with a stand-in for the collectives on one GPU: tools/probes/stream_dp.py, profiles/round5_stream_dp.txt)
@@ -366,10 +367,20 @@ class Trainer(object):
         if "noise_offset" in ck:
             self._noise.offset = int(ck["noise_offset"])
         if "gen_state" in ck:
-            try:
-                self._gen.set_state(ck["gen_state"])
-            except Exception:           # a state written on another device type / torch build: fall back to a step-derived seed
-                self._gen.manual_seed(D.shard_seed(self.config.get("noise_seed", 4321), self.rank) + int(ck.get("global_step", 0)))
+            # The generator is seeded PER RANK (shard_seed) and only rank 0 writes checkpoints: its state is restored on the rank and
+            # world size that wrote it only.  Every other rank (and any restore under a different world size) re-seeds with its own
+            # shard seed advanced by the restored step, so that the ranks keep drawing DIFFERENT TPS uniforms / crop windows
+            # (round-5 advisor: all ranks used to resume with rank 0's stream).
+            same = int(ck.get("rank", 0)) == self.rank and int(ck.get("world_size", 1)) == self.world_size
+            restored = False
+            if same:
+                try:
+                    self._gen.set_state(ck["gen_state"])
+                    restored = True
+                except Exception:       # a state written on another device type / torch build
+                    pass
+            if not restored:
+                self._gen.manual_seed(D.shard_seed(self.config.get("noise_seed", 4321), self.rank) + 1000003 * (1 + int(ck.get("global_step", 0))))
         base = os.path.basename(checkpoint_path)
         digits = "".join(ch for ch in base.split("-")[-1] if ch.isdigit())
         # the stored step is authoritative (it agrees with the restored Adam t); the file name is the fallback (model.py:597-601)
@@ -479,7 +490,8 @@ class Trainer(object):
                              for k, g in bank.groups.items()},
                     "state": {k: float(v) for k, v in self.state.items()},
                     # a resumed run continues the sampling-noise stream instead of replaying steps 0..N's draws
-                    "noise_offset": self._noise.offset, "gen_state": self._gen.get_state().cpu()}, path)
+                    "noise_offset": self._noise.offset, "gen_state": self._gen.get_state().cpu(),
+                    "rank": self.rank, "world_size": self.world_size}, path)
 
     # ------------------------------------------------------------------ helpers
     def draw_noise(self, B):
@@ -546,8 +558,8 @@ class Trainer(object):
         (EARLY_ADAM) leaves those keys at step t + 1 and the others at t, with the converted weight copies stale.  Make the
         device state coherent (side streams joined, copies re-converted from whatever the masters now hold) and refuse further
         steps / checkpoints: the run has to restart from its last checkpoint."""
-        done = sorted(self._adam_done)
-        self._adam_done = set()
+        done = sorted(self._adam_done | self._adam_stepped)     # early (side-stream) steps AND a partly run final Adam loop
+        self._adam_done, self._adam_stepped = set(), set()
         ops.Streams.master_busy.clear()
         if not done:
             return
@@ -1224,7 +1236,7 @@ class Trainer(object):
         """One training step on the launching stream (+ the "pre", "aux" and "wgrad" side streams): forward A -> D (aux) -> B ->
         C, backward C -> priors -> B -> A, each optimizer key's bucket reduced as soon as its segment is complete, Adam, state."""
         dev = self.device
-        self._step_graph_lr, self._adam_done = graph_lr, set()
+        self._step_graph_lr, self._adam_done, self._adam_stepped = graph_lr, set(), set()
         c = self._step_begin(batch, noise)
         self._fwd_pose(c)
         if ops.Streams.enabled and CRITICS_LATE and graph_lr is None:
@@ -1376,6 +1388,7 @@ class Trainer(object):
                 early = self._early.pop(k, None)
                 if early is not None:            # the tail slice is already in flight (see _hook_early_reduce)
                     handles.append(early[1])
+                    self._reduce_marks.append((k + "[head]", (g.numel() - early[0]) * 4))      # one mark per handle (dp_wait_ms)
                     g = g[:early[0]]
                 handles.append(D.allreduce_bucket(g, self.world_size, self.process_group))
                 self._reduce_marks.append((k, g.numel() * 4))
@@ -1395,6 +1408,7 @@ class Trainer(object):
                 lr_t = graph_lr
             else:
                 grp["t"] += 1
+                self._adam_stepped.add(k)         # (for _after_failed_step: this key's counter and weights have moved)
                 t = grp["t"]
                 lr_t = lr * lr_scale.get(k, 1.0) * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
                 if self.grad_clip_norm > 0:         # tf.clip_by_global_norm over the key's variables (device side, no sync)
@@ -1428,7 +1442,7 @@ class Trainer(object):
         self._reduce_marks = []
         D.wait_all(handles)
         self._adam([k for k in keys if k not in self._adam_done], graph_lr)
-        self._adam_done = set()
+        self._adam_done, self._adam_stepped = set(), set()
         ops.Streams.master_busy.clear()         # (the join above ordered this stream behind every early Adam)
         ops.Streams.epoch += 1                  # lazy weight conversions of this step are ordered before everything that follows
         if graph_lr is None:

@@ -1356,7 +1356,12 @@ def towers_eligible(towers, xs):
                 return False
             if l > 0 and (lay.ci_log != tw[l - 1].co or (l < Ln - 1 and lay.ci_log != lay.co)):
                 return False
-        if x.shape[-1] < tw[0].ci_log:
+        # the checks ups_towers_fwd / _bwd make on the first layer's input (csrc/critic.hip: ld0 >= k, ld0 % 8 == 0, 16-byte aligned
+        # rows): a view that fails them keeps the generic path instead of raising UpsError in the middle of a step
+        if x.shape[-1] < tw[0].ci_log or x.shape[-1] % 8 or (x.is_contiguous() and x.data_ptr() % 16):
+            return False
+    for l in range(Ln):                     # one launch per layer index: every tower must have the same width there
+        if len(set(tw[l].co for tw in towers)) != 1:
             return False
     return True
 
