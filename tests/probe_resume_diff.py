@@ -3,7 +3,7 @@ test_resumed_run_continues_the_noise_stream): per optimizer key the largest diff
 the restore and after one more step."""
 import copy, os, sys, tempfile
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import upsparts_amd  # noqa
 from upsparts_amd.model import TrainModel, Trainer
 from oracle import ref_model as R, configs

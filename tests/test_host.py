@@ -58,11 +58,15 @@ def test_product_does_not_import_the_oracle():
 
 
 def test_tools_do_not_import_the_oracle():
-    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
-    tdir = os.path.join(ROOT, "tools")
-    for fn in os.listdir(tdir):
-        if fn.endswith(".py"):
-            assert "oracle" not in open(os.path.join(tdir, fn)).read(), "tools/" + fn + " must not use oracle/"
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/ (tools/probes/ included since round 6:
+    the one probe that used it lives under tests/ now)."""
+    for tdir in (os.path.join(ROOT, "tools"), os.path.join(ROOT, "tools", "probes")):
+        for fn in os.listdir(tdir):
+            if fn.endswith(".py"):
+                src = open(os.path.join(tdir, fn)).read()
+                assert "from oracle" not in src and "import oracle" not in src, os.path.relpath(os.path.join(tdir, fn), ROOT) + " must not use oracle/"
+                if tdir.endswith("tools"):
+                    assert "oracle" not in src, "tools/" + fn + " must not use oracle/"
     src = open(os.path.join(ROOT, "bench.py")).read()
     head, _, tail = src.partition("def cpu_baseline")
     body, _, rest = tail.partition("\ndef run_rank")
@@ -469,3 +473,65 @@ def test_stream_plan_aliases_and_tools_offline(tmp_path):
                        stderr=subprocess.PIPE, timeout=60)
     out = r.stdout.decode()
     assert r.returncode == 0 and "loop .LBB0_1" in out and "'mfma': 1" in out and "'ds_read': 1" in out, out + r.stderr.decode()
+
+
+REF = "/root/reference"
+REF_YAMLS = [
+    # yaml, configs function, trainable parameters (M) of nets.Nets at the yaml's own settings
+    ("cub/code/SB_model48i/train_cub_subset_tps.yaml", "cub_config", 33.13),
+    ("pennaction/code/SB_model48i/train_pennaction.yaml", "pennaction_config", 33.18),
+    ("deepfashion/code/SB_model48c/train_deepfashion.yaml", "deepfashion_config", 50.08),
+]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not on this machine (the GPU box gets /root/repo only)")
+@pytest.mark.parametrize("rel,fn,mparams", REF_YAMLS, ids=[r[1] for r in REF_YAMLS])
+def test_reference_yaml_files_drop_in_unchanged(rel, fn, mparams):
+    """north_star: "keeping the edflow Iterator/Trainer and config.yaml surface so cub/deepfashion/pennaction configs drop in
+    unchanged" (round-5 verdict, missing 5).  The three yaml files the reference ships are loaded through runner.load_config as
+    they lie: `model:` / `iterator:` resolve to this package's classes, `dataset:` to a class of data.py, every model / trainer key
+    equals what configs.<fn>() builds for the same (n_parts, batch_size, spatial_size) -- the configs the tests and the bench run on --
+    and nets.Nets builds the parameter count of the reference's graph."""
+    from upsparts_amd import configs, nets, runner
+    from upsparts_amd.model import TrainModel, Trainer
+    cfg = runner.load_config([os.path.join(REF, rel)])
+    assert runner.get_obj_from_str(cfg["model"]) is TrainModel and runner.get_obj_from_str(cfg["iterator"]) is Trainer
+    assert cfg["dataset"] in runner.DATA_ALIASES, cfg["dataset"]
+    kw = dict(n_parts=cfg["n_parts"], batch_size=cfg["batch_size"], spatial_size=cfg["spatial_size"])
+    if fn == "cub_config":
+        kw["use_tps"] = bool(cfg.get("use_tps", False))
+    ours = getattr(configs, fn)(**kw)
+    data_keys = lambda k: k == "dataset" or k.startswith("data_")
+    for k in sorted(set(cfg) | set(ours)):
+        if data_keys(k):
+            continue            # (where the images are: the yaml's business; data.py reads exactly these keys, test_data_* below)
+        if k == "d_single" and fn != "deepfashion_config":
+            assert k in cfg and k not in ours      # the 48i yamls carry the key, the 48i model never reads it (M:313-521)
+            continue
+        assert k in cfg and k in ours, "key {} is in {} only".format(k, "the yaml" if k in cfg else "configs." + fn)
+        assert cfg[k] == ours[k], "key {}: yaml {!r}, configs.{} {!r}".format(k, cfg[k], fn, ours[k])
+    n = nets.Nets(cfg, torch.device("cpu"), seed=0)
+    total = sum(int(p.numel()) for p in n.bank.params.values())
+    assert abs(total / 1e6 - mparams) < 0.01, "{}: {:.3f} M parameters, expected {:.2f} M".format(rel, total / 1e6, mparams)
+
+
+def test_runner_does_not_train_on_noise_silently(tmp_path, monkeypatch, caplog):
+    """runner.py used to swallow EVERY exception of the dataset constructor and train on U(-1, 1) noise without a word (round-5
+    verdict, weak 10).  Now: only a missing file / missing package falls back, the fallback says SYNTHETIC DATA at WARNING level when
+    it happens and with every logged step, anything else (a wrong key, a bug in data.py) propagates."""
+    from upsparts_amd import runner
+    cfg = {"dataset": "src.data.data.AugmentedPair2", "data_root": str(tmp_path / "nowhere"), "data_csv": str(tmp_path / "nowhere" / "x.csv"),
+           "batch_size": 2, "spatial_size": 16}
+    import logging
+    with caplog.at_level(logging.WARNING, logger="upsparts"):
+        ds, why = runner.make_dataset(cfg, rank=0, strict=False)
+    assert isinstance(ds, runner.SyntheticPairs) and why and "SYNTHETIC DATA" in caplog.text
+    with pytest.raises((FileNotFoundError, OSError)):
+        runner.make_dataset(cfg, rank=0, strict=True)
+
+    class Boom(object):
+        def __init__(self, config):
+            raise KeyError("a bug, not a missing file")
+    monkeypatch.setitem(runner.DATA_ALIASES, "src.data.data.AugmentedPair2", Boom)
+    with pytest.raises(KeyError):
+        runner.make_dataset(cfg, rank=0, strict=False)
