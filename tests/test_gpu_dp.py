@@ -203,3 +203,48 @@ def test_runner_wires_data_parallelism(dev, tmp_path):
     log = open(os.path.join(root, "train", "log.txt")).read()
     assert log.count("global_step: 0\n") == 1                      # one writer
     assert sorted(os.listdir(os.path.join(root, "train", "checkpoints"))) == ["model.ckpt-2", "model.ckpt-3"]
+
+
+def _resume_worker(rank, world, port, out, ckpt):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import upsparts_amd  # noqa: F401
+    from upsparts_amd import dist as D
+    from upsparts_amd.model import TrainModel, Trainer
+    D.init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    cfg = _cfg()
+    model = TrainModel(cfg, device=dev, seed=0)
+    tr = Trainer(cfg, None, model, world_size=world, rank=rank)
+    views, noise = _shard(rank)
+    tr.train_step(views, noise)
+    before = tr._gen.get_state().cpu()
+    if rank == 0:                       # only rank 0 writes checkpoints (Trainer._checkpoint)
+        tr.save_checkpoint(ckpt)
+    torch.distributed.barrier()
+    tr.initialize(ckpt)
+    after = tr._gen.get_state().cpu()
+    draw = torch.randint(0, 1 << 30, (4,), generator=tr._gen, device=dev).cpu()
+    out[rank] = {"before": before, "after": after, "draw": draw, "noise_seed": tr._noise.seed if hasattr(tr._noise, "seed") else None}
+    torch.distributed.destroy_process_group()
+
+
+def test_resume_keeps_the_ranks_generators_apart(dev, tmp_path):
+    """Round-5 advisor: only rank 0 writes the checkpoint, and every rank used to restore ITS generator state from it -- after a
+    resume all ranks drew the same TPS uniforms and crop windows.  Now the state is restored on the rank / world size that wrote it
+    only; the others re-seed from their own shard seed and the restored step."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    ckpt = str(tmp_path / "model.ckpt-1")
+    mp.spawn(_resume_worker, args=(2, _free_port(), out, ckpt), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert torch.equal(r0["after"], r0["before"]), "rank 0 must continue its own stream"
+    assert not torch.equal(r1["after"], r0["after"]), "rank 1 resumed with rank 0's generator state"
+    assert not torch.equal(r0["draw"], r1["draw"])
+    # a single-rank restore of the same file (another world size) does not take rank 0's state of the two-rank run either
+    from upsparts_amd.model import TrainModel, Trainer
+    cfg = _cfg()
+    tr = Trainer(cfg, None, TrainModel(cfg, device=dev, seed=0))
+    tr.initialize(ckpt)
+    assert not torch.equal(tr._gen.get_state().cpu(), r0["after"])

@@ -746,7 +746,10 @@ def _prior_oracle(R, variant, lm0, eps0, lm1, eps1, px_order, gamma, patch, w, g
 @pytest.mark.parametrize("variant,P,S,entropy_func", [(0, 10, 32, "entropy"), (0, 25, 32, "cross_entropy"), (0, 10, 20, "entropy"),
                                                       (1, 10, 32, "cross_entropy"), (1, 25, 32, "cross_entropy"), (0, 3, 48, "entropy"),
                                                       # the pixel-per-lane forward of round 5 (P = 10 at 128- / 256-wide images)
-                                                      (0, 10, 128, "entropy"), (1, 10, 128, "cross_entropy"), (0, 10, 256, "cross_entropy")])
+                                                      (0, 10, 128, "entropy"), (1, 10, 128, "cross_entropy"), (0, 10, 256, "cross_entropy"),
+                                                      # the direct-from-global forms of round 6 (P = 16 / 20 / 25 at 128- / 256-wide images)
+                                                      (0, 16, 128, "entropy"), (1, 20, 128, "cross_entropy"), (0, 25, 128, "cross_entropy"),
+                                                      (0, 20, 256, "entropy"), (1, 16, 256, "cross_entropy")])
 @pytest.mark.parametrize("px_bpi", [0, 4, 1])
 def test_mask_priors_forward_and_backward(variant, P, S, entropy_func, px_bpi, dev, monkeypatch):
     """ups_prior_fwd / ups_prior_bwd ALONE (8a-12; until round 4 only covered through the whole-step tests): every logged prior

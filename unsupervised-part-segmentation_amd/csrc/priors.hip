@@ -1045,6 +1045,281 @@ __global__ __launch_bounds__(256, 1) void prior_bwd0_px_kernel(const PriorK p, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 6: the view-0 passes for the part counts the pixel-per-lane RINGS cannot hold (P = 16 / 20 / 25: BASELINE configs #3 / #5 and
+// every shipped yaml).  A tile-row of the four maps is 16-25 KB per map at 256 columns; seven slot pairs of them do not fit 160 KB of
+// LDS, and the staged kernels above pay for that with a two-row halo around a one-row tile (3x the reads of m and l_mean, one HBM
+// round trip per block: prior_bwd at 256x256, P = 20 ran at 0.06 of the HBM roof, 1.27 ms of config #5's step --
+// profiles/round6_hbm_kernels.txt).  These forms keep NOTHING in LDS: one thread owns one pixel and takes every row it needs straight
+// from global memory with the widest aligned loads P allows (the neighbours' rows are the neighbouring lanes' / the next tile's own
+// rows: served by L1 / the XCD's L2, blocks of one image run on one XCD in row order), the stencil terms are evaluated in chunks of
+// four (five) parts so that the six neighbour rows never sit in registers at once.  Every wait is the compiler's own: no inline-asm
+// loads, no counted waits -- correct by construction; what it gives up against the DMA rings is the last third of the bandwidth.
+template <int P> struct PChunk { static constexpr int N = (P % 4 == 0) ? 4 : ((P % 5 == 0) ? 5 : (P % 2 == 0 ? 2 : 1)); };
+template <int N>
+__device__ __forceinline__ void ldg_chunk(const float* __restrict__ src, float (&dst)[N]) {
+    if constexpr (N == 4) { const float4 v = *(const float4*)src; dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+    else if constexpr (N == 2) { const float2 v = *(const float2*)src; dst[0] = v.x; dst[1] = v.y; }
+    else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) dst[e] = src[e];
+    }
+}
+template <int N>
+__device__ __forceinline__ void stg_chunk(float* __restrict__ dst, const float (&v)[N]) {
+    if constexpr (N == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+    else if constexpr (N == 2) *(float2*)dst = make_float2(v[0], v[1]);
+    else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) dst[e] = v[e];
+    }
+}
+template <int P>
+__device__ __forceinline__ void ldg_row(const float* __restrict__ src, float (&dst)[P]) {
+    constexpr int CH = PChunk<P>::N;
+#pragma unroll
+    for (int c = 0; c < P; c += CH) {
+        float t[CH];
+        ldg_chunk<CH>(src + c, t);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) dst[c + e] = t[e];
+    }
+}
+
+// The view-0 forward sums in the same form: a block walks `tiles_per_block` consecutive tiles of 256 pixels of one image, carries the
+// four pixel sums and the per-part sums (S, R, Rsmooth, Rcontour) in registers and writes ONE slab record (the workspace layout and the
+// finalize kernel of the pixel-per-lane form: blocks per image = NSLAB records, one each).
+template <int P, int LW, int VAR>
+__global__ __launch_bounds__(256) void prior_fwd_direct_kernel(const PriorK p, const int tiles_per_block, const int bpi, const int spb) {
+    constexpr int W = 1 << LW, CH = PChunk<P>::N;
+    __shared__ float cst[P][2];
+    __shared__ float red[4][4 + 4 * P];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int hw = p.h * W;
+    const int lb = xcd_logical_block();
+    const int n = lb / bpi, bi = lb - n * bpi;
+    if (tid < P) {
+        cst[tid][0] = (VAR == 0 && p.px) ? (float)p.px[((long long)n * P + tid) * 2] : 0.f;
+        cst[tid][1] = (VAR == 0 && p.px) ? (float)p.px[((long long)n * P + tid) * 2 + 1] : 0.f;
+    }
+    __syncthreads();
+    const long long img = (long long)n * hw;
+    float kl = 0.f, ent = 0.f, patch = 0.f, gmrf = 0.f;
+    float S[P], R[P], Rs[P], Rc[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) S[c] = R[c] = Rs[c] = Rc[c] = 0.f;
+    for (int t = bi * tiles_per_block; t < (bi + 1) * tiles_per_block; ++t) {
+        const int q = (t << 8) + tid;
+        const int yy = q >> LW, xx = q & (W - 1);
+        const bool vr = xx + 1 < W, vd = yy + 1 < p.h;
+        const long long o0 = (img + q) * P, oR = (img + (vr ? q + 1 : q)) * P, oD = (img + (vd ? q + W : q)) * P;
+        float l[P];
+        ldg_row<P>(p.l + o0, l);
+        float mx = l[0];
+#pragma unroll
+        for (int c = 1; c < P; ++c) mx = fmaxf(mx, l[c]);
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) se += __expf(l[c] - mx);
+        const float lse = mx + ups_log_fast(se);
+#pragma unroll
+        for (int c0 = 0; c0 < P; c0 += CH) {
+            float m[CH], lm[CH], hv[CH], mr[CH], lr[CH], md[CH], ld[CH];
+            ldg_chunk<CH>(p.m + o0 + c0, m); ldg_chunk<CH>(p.l_mean + o0 + c0, lm); ldg_chunk<CH>(p.hard + o0 + c0, hv);
+            ldg_chunk<CH>(p.m + oR + c0, mr); ldg_chunk<CH>(p.l_mean + oR + c0, lr);
+            ldg_chunk<CH>(p.m + oD + c0, md); ldg_chunk<CH>(p.l_mean + oD + c0, ld);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int c = c0 + e;
+                const float mc = m[e];
+                kl += mc * ups_log_fast((float)P * mc + 1e-20f);
+                ent += -(p.entropy_ce ? hv[e] : mc) * (l[c] - lse);
+                const float lmc = lm[e];
+                const float lrc = vr ? lr[e] : 0.f, ldc = vd ? ld[e] : 0.f;
+                if (VAR == 0) {
+                    const bool in_rect = abs(yy - (int)cst[c][0]) <= p.half_h && abs(xx - (int)cst[c][1]) <= p.half_w;
+                    patch += in_rect ? 0.f : hv[e];
+                } else {
+                    const float gw = 0.25f * (lmc - lrc), gh = 0.25f * (lmc - ldc);
+                    patch += fminf(p.ms_alpha * (gw * gw + gh * gh), p.ms_lambda);
+                }
+                if (vd) { const float d = ldc - lmc; gmrf += 0.5f * d * d; }
+                if (vr) { const float d = lrc - lmc; gmrf += 0.5f * d * d; }
+                const float mrc = vr ? mr[e] : 0.f, mdc = vd ? md[e] : 0.f;
+                const float gw = 0.25f * (mc - mrc), gh = 0.25f * (mc - mdc);
+                const float g = p.ms_alpha * (gw * gw + gh * gh);
+                const float r = fminf(g, p.ms_lambda);
+                S[c] += mc; R[c] += r;
+                if (g < p.ms_lambda) Rs[c] += r; else Rc[c] += r;
+            }
+        }
+    }
+    kl = wave_sum_full(kl); ent = wave_sum_full(ent); patch = wave_sum_full(patch); gmrf = wave_sum_full(gmrf);
+#pragma unroll
+    for (int c = 0; c < P; ++c) { S[c] = wave_sum_full(S[c]); R[c] = wave_sum_full(R[c]); Rs[c] = wave_sum_full(Rs[c]); Rc[c] = wave_sum_full(Rc[c]); }
+    if (lane == 0) {
+        float* d = red[wid];
+        d[0] = kl; d[1] = ent; d[2] = patch; d[3] = gmrf;
+#pragma unroll
+        for (int c = 0; c < P; ++c) { d[4 + 4 * c] = S[c]; d[5 + 4 * c] = R[c]; d[6 + 4 * c] = Rs[c]; d[7 + 4 * c] = Rc[c]; }
+    }
+    __syncthreads();
+    // workspace: glob_partial[n][NSLAB][4], np_partial[n][NSLAB][P][4]; this block owns record bi * spb of image n (the finalize
+    // kernel reads the records b * spb, b < bpi, only)
+    float* gpart = p.ws + ((long long)n * NSLAB + (long long)bi * spb) * 4;
+    float* npart = p.ws + (long long)p.n * NSLAB * 4 + ((long long)n * NSLAB + (long long)bi * spb) * P * 4;
+    if (tid < 4) gpart[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    for (int i = tid; i < 4 * P; i += 256) npart[i] = (red[0][4 + i] + red[1][4 + i]) + (red[2][4 + i] + red[3][4 + i]);
+}
+
+template <int P, int LW, int VAR>
+__global__ __launch_bounds__(256) void prior_bwd0_direct_kernel(const PriorK p) {
+    constexpr int W = 1 << LW, CH = PChunk<P>::N;
+    __shared__ float cst[P][4];                      // rectangle centre (y, x), S, R of the image's parts
+    const int tid = threadIdx.x;
+    const int hw = p.h * W, tiles_img = hw >> 8;
+    const int lb = xcd_logical_block();
+    const int n = lb / tiles_img, t = lb - n * tiles_img;
+    if (tid < P) {
+        cst[tid][0] = (VAR == 0 && p.px) ? (float)p.px[((long long)n * P + tid) * 2] : 0.f;
+        cst[tid][1] = (VAR == 0 && p.px) ? (float)p.px[((long long)n * P + tid) * 2 + 1] : 0.f;
+        cst[tid][2] = p.per_np[((long long)n * P + tid) * 8];
+        cst[tid][3] = p.per_np[((long long)n * P + tid) * 8 + 1];
+    }
+    __syncthreads();
+    const long long img = (long long)n * hw;
+    const int q = (t << 8) + tid;
+    const int yy = q >> LW, xx = q & (W - 1);
+    const bool vr = xx + 1 < W, vd = yy + 1 < p.h, vl = xx > 0, vu = yy > 0;
+    // neighbour pixels, clamped into the image (a clamped row is loaded and its values dropped by the validity flags)
+    const long long o0 = (img + q) * P;
+    const long long oR = (img + (vr ? q + 1 : q)) * P, oL = (img + (vl ? q - 1 : q)) * P;
+    const long long oD = (img + (vd ? q + W : q)) * P, oU = (img + (vu ? q - W : q)) * P;
+    const long long oLD = (img + ((vl && vd) ? q + W - 1 : q)) * P, oUR = (img + ((vu && vr) ? q - W + 1 : q)) * P;
+    const float inv_pix = 1.f / (float)((long long)p.n * hw), inv_n = 1.f / (float)p.n;
+    const float a8 = p.ms_alpha * 0.125f, a16 = p.ms_alpha * 0.0625f;
+    const float wkl = p.w_kl * inv_pix, went = p.w_entropy * inv_pix;
+    const float wpatch = p.w_patch * inv_n, warea2 = p.w_area * inv_n * 2.f, wms2 = p.w_ms * inv_n * 2.f;
+    const float wmsl = p.w_msl * inv_n, wgmrf = p.w_gmrf * inv_n;
+
+    float m[P], gh[P], gm[P], direct[P];
+    {
+        float l[P], hv[P];
+        ldg_row<P>(p.m + o0, m); ldg_row<P>(p.l + o0, l); ldg_row<P>(p.hard + o0, hv); ldg_row<P>(p.g_hard + o0, gh);
+        float mx = l[0];
+#pragma unroll
+        for (int c = 1; c < P; ++c) mx = fmaxf(mx, l[c]);
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) se += __expf(l[c] - mx);
+        const float lse = mx + ups_log_fast(se);
+        float qs = 0.f, labsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) { qs += m[c] * (l[c] - lse); labsum += hv[c]; }
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            const float mc = m[c];
+            const float pm = (float)P * mc;
+            float g = wkl * (ups_log_fast(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[c];
+            float dr = went * (-mc * ((l[c] - lse) - qs));
+            if (p.entropy_ce) dr += went * (-(hv[c] - mc * labsum));
+            if (VAR == 0) {
+                const bool in_rect = abs(yy - (int)cst[c][0]) <= p.half_h && abs(xx - (int)cst[c][1]) <= p.half_w;
+                g += in_rect ? 0.f : wpatch;
+            }
+            g += warea2 * cst[c][2];
+            gm[c] = g; direct[c] = dr;
+        }
+    }
+    // Mumford-Shah on the soft masks (own cell, the left neighbour's cell, the upper neighbour's) and, on the noise-free logits, the
+    // GMRF term and (SB_model48c) the same stencil: chunks of CH parts
+#pragma unroll
+    for (int c0 = 0; c0 < P; c0 += CH) {
+        {
+            float mr[CH], md[CH], ml[CH], mld[CH], mu[CH], mur[CH];
+            ldg_chunk<CH>(p.m + oR + c0, mr); ldg_chunk<CH>(p.m + oD + c0, md); ldg_chunk<CH>(p.m + oL + c0, ml);
+            ldg_chunk<CH>(p.m + oLD + c0, mld); ldg_chunk<CH>(p.m + oU + c0, mu); ldg_chunk<CH>(p.m + oUR + c0, mur);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int c = c0 + e;
+                const float mc = m[c];
+                const float m_r = vr ? mr[e] : 0.f, m_d = vd ? md[e] : 0.f;
+                float dR = 0.f;
+                {
+                    const float g = a16 * ((mc - m_r) * (mc - m_r) + (mc - m_d) * (mc - m_d));
+                    if (g <= p.ms_lambda) dR += a8 * ((mc - m_r) + (mc - m_d));
+                }
+                if (vl) {
+                    const float m_l = ml[e], m_ld = vd ? mld[e] : 0.f;
+                    const float g = a16 * ((m_l - mc) * (m_l - mc) + (m_l - m_ld) * (m_l - m_ld));
+                    if (g <= p.ms_lambda) dR -= a8 * (m_l - mc);
+                }
+                if (vu) {
+                    const float m_u = mu[e], m_ur = vr ? mur[e] : 0.f;
+                    const float g = a16 * ((m_u - m_ur) * (m_u - m_ur) + (m_u - mc) * (m_u - mc));
+                    if (g <= p.ms_lambda) dR -= a8 * (m_u - mc);
+                }
+                gm[c] += wms2 * cst[c][3] * dR;
+            }
+        }
+        {
+            float lm[CH], lr[CH], ld[CH], ll[CH], lu[CH];
+            ldg_chunk<CH>(p.l_mean + o0 + c0, lm); ldg_chunk<CH>(p.l_mean + oR + c0, lr); ldg_chunk<CH>(p.l_mean + oD + c0, ld);
+            ldg_chunk<CH>(p.l_mean + oL + c0, ll); ldg_chunk<CH>(p.l_mean + oU + c0, lu);
+            if (VAR == 1) {
+                float lld[CH], lur[CH];
+                ldg_chunk<CH>(p.l_mean + oLD + c0, lld); ldg_chunk<CH>(p.l_mean + oUR + c0, lur);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const float lmc = lm[e];
+                    const float l_r = vr ? lr[e] : 0.f, l_d = vd ? ld[e] : 0.f;
+                    float dL = 0.f;
+                    {
+                        const float g = a16 * ((lmc - l_r) * (lmc - l_r) + (lmc - l_d) * (lmc - l_d));
+                        if (g <= p.ms_lambda) dL += a8 * ((lmc - l_r) + (lmc - l_d));
+                    }
+                    if (vl) {
+                        const float l_l = ll[e], l_ld = vd ? lld[e] : 0.f;
+                        const float g = a16 * ((l_l - lmc) * (l_l - lmc) + (l_l - l_ld) * (l_l - l_ld));
+                        if (g <= p.ms_lambda) dL -= a8 * (l_l - lmc);
+                    }
+                    if (vu) {
+                        const float l_u = lu[e], l_ur = vr ? lur[e] : 0.f;
+                        const float g = a16 * ((l_u - l_ur) * (l_u - l_ur) + (l_u - lmc) * (l_u - lmc));
+                        if (g <= p.ms_lambda) dL -= a8 * (l_u - lmc);
+                    }
+                    direct[c0 + e] += wmsl * dL;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const float lmc = lm[e];
+                float gg = 0.f;
+                if (vu) gg += lmc - lu[e];
+                if (vd) gg -= ld[e] - lmc;
+                if (vl) gg += lmc - ll[e];
+                if (vr) gg -= lr[e] - lmc;
+                direct[c0 + e] += wgmrf * gg;
+            }
+        }
+    }
+    float dot = 0.f, dot_r = 0.f;
+#pragma unroll
+    for (int c = 0; c < P; ++c) { dot += m[c] * gm[c]; dot_r += m[c] * gh[c]; }
+#pragma unroll
+    for (int c0 = 0; c0 < P; c0 += CH) {
+        float a[CH], b[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const int c = c0 + e;
+            a[e] = m[c] * (gm[c] - dot) + direct[c];
+            b[e] = m[c] * (gh[c] - dot_r);
+        }
+        stg_chunk<CH>(p.dl + o0 + c0, a);
+        stg_chunk<CH>(p.dl_rec + o0 + c0, b);
+    }
+}
+
 // Test hook: UPS_PRIOR_PX_BPI caps the blocks per image of the pixel-per-lane kernels, so that a three-image test walks the multi-tile
 // loops (ring slots, counted waits) the 64-image benchmark shape walks.  Read at every call (a getenv, microseconds).
 int px_bpi_cap() { const char* e = getenv("UPS_PRIOR_PX_BPI"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 30); }
@@ -1137,6 +1412,34 @@ extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
             }
         }
     }
+    {   // direct-from-global form (round 6): view 0, the part counts the rings cannot hold; one slab record per block
+        static int dr_on = -1;
+        if (dr_on < 0) { const char* e = getenv("UPS_PRIOR_DIRECT"); dr_on = (e && e[0] == '0') ? 0 : 1; }
+        const long long hw = (long long)d->h * d->w;
+        const uintptr_t all = ((uintptr_t)d->m) | ((uintptr_t)d->l_mean) | ((uintptr_t)d->l) | ((uintptr_t)d->hard);
+        if (dr_on && d->view == 0 && (d->P == 16 || d->P == 20 || d->P == 25) && (d->w == 128 || d->w == 256) &&
+            hw % 256 == 0 && (all & 15) == 0) {
+            // blocks per image: a power of two that divides the tiles and the NSLAB slab records, ~four blocks per CU
+            const int tiles_img = (int)(hw / 256);
+            int bpi = 1;
+            while (bpi < NSLAB && (long long)d->n * bpi < 1024 && tiles_img % (2 * bpi) == 0) bpi *= 2;
+            const dim3 grid(d->n * bpi);
+            const int tpb = tiles_img / bpi, spb = NSLAB / bpi;
+#define UPS_PRIOR_F0(PV, LWV, VARV) hipLaunchKernelGGL((prior_fwd_direct_kernel<PV, LWV, VARV>), grid, dim3(256), 0, s, k, tpb, bpi, spb)
+#define UPS_PRIOR_F0P(PV)                                                                                  \
+            do {                                                                                          \
+                if (d->w == 128) { if (d->variant == 0) UPS_PRIOR_F0(PV, 7, 0); else UPS_PRIOR_F0(PV, 7, 1); } \
+                else { if (d->variant == 0) UPS_PRIOR_F0(PV, 8, 0); else UPS_PRIOR_F0(PV, 8, 1); }         \
+            } while (0)
+            if (d->P == 16) UPS_PRIOR_F0P(16); else if (d->P == 20) UPS_PRIOR_F0P(20); else UPS_PRIOR_F0P(25);
+#undef UPS_PRIOR_F0P
+#undef UPS_PRIOR_F0
+            UPS_LAUNCH_CHECK();
+            hipLaunchKernelGGL(prior_finalize_px_kernel, dim3(1), dim3(256), 0, s, k, bpi, spb);
+            UPS_LAUNCH_CHECK();
+            return UPS_OK;
+        }
+    }
     const int rows = ups_cdiv(d->h, NSLAB);
     const int PP = d->P | 1, NS = 256 / d->P;
     auto lds_fl = [&](int t) {
@@ -1212,6 +1515,28 @@ extern "C" int ups_prior_bwd(const ups_prior_desc* d, void* stream) {
             if (d->w == 128) { if (d->variant == 0) UPS_PRIOR_B0(7, 0); else UPS_PRIOR_B0(7, 1); }
             else { if (d->variant == 0) UPS_PRIOR_B0(8, 0); else UPS_PRIOR_B0(8, 1); }
 #undef UPS_PRIOR_B0
+            UPS_LAUNCH_CHECK();
+            return UPS_OK;
+        }
+    }
+    {   // direct-from-global form (round 6): view 0, the part counts the rings cannot hold, both result maps asked for
+        static int dr_on = -1;
+        if (dr_on < 0) { const char* e = getenv("UPS_PRIOR_DIRECT"); dr_on = (e && e[0] == '0') ? 0 : 1; }
+        const long long hw = (long long)d->h * d->w;
+        const uintptr_t all = ((uintptr_t)d->m) | ((uintptr_t)d->l_mean) | ((uintptr_t)d->l) | ((uintptr_t)d->hard) | ((uintptr_t)d->g_hard) |
+                              ((uintptr_t)d->dl) | ((uintptr_t)d->dl_rec);
+        if (dr_on && d->view == 0 && (d->P == 16 || d->P == 20 || d->P == 25) && (d->w == 128 || d->w == 256) && hw % 256 == 0 &&
+            d->g_hard && d->dl_rec && d->l && d->l_mean && d->hard && (all & 15) == 0 && d->n * (hw / 256) < (1ll << 31)) {
+            const dim3 grid((unsigned)(d->n * (hw / 256)));
+#define UPS_PRIOR_D0(PV, LWV, VARV) hipLaunchKernelGGL((prior_bwd0_direct_kernel<PV, LWV, VARV>), grid, dim3(256), 0, s, k)
+#define UPS_PRIOR_D0P(PV)                                                                                  \
+            do {                                                                                          \
+                if (d->w == 128) { if (d->variant == 0) UPS_PRIOR_D0(PV, 7, 0); else UPS_PRIOR_D0(PV, 7, 1); } \
+                else { if (d->variant == 0) UPS_PRIOR_D0(PV, 8, 0); else UPS_PRIOR_D0(PV, 8, 1); }         \
+            } while (0)
+            if (d->P == 16) UPS_PRIOR_D0P(16); else if (d->P == 20) UPS_PRIOR_D0P(20); else UPS_PRIOR_D0P(25);
+#undef UPS_PRIOR_D0P
+#undef UPS_PRIOR_D0
             UPS_LAUNCH_CHECK();
             return UPS_OK;
         }
