@@ -417,7 +417,7 @@ def test_grouped_critics_match_the_generic_path(dev, monkeypatch):
     convolution path (UPS_TOWERS=0) inside the whole step: the yaml's latent widths (256 / 64) at tiny spatial sizes, one step from
     the same weights, views and noise.  The storage points are the same, so the two differ by fp32 summation order only: critic
     losses, the adversarial term's effect (encoder_0's gradient) and every critic gradient agree (cosine >= 0.9999, norms within
-    1 %), the state update agrees; and the host-order variants of the step (UPS_CRITICS_LATE, UPS_PRE_FREE) and the one-launch state
+    1 %), the state update agrees; and the one-launch state
     update leave a grouped run BIT-identical."""
     import upsparts_amd  # noqa: F401
     from upsparts_amd import model as M, ops
@@ -463,7 +463,7 @@ def test_grouped_critics_match_the_generic_path(dev, monkeypatch):
         assert abs(sa[k] - sb[k]) <= 1e-4 * max(1.0, abs(sb[k])), (k, sa[k], sb[k])
     # host-order / stream-order variants and the torch form of the state update: the same launches, so the same bits
     monkeypatch.setattr(ops, "TOWERS", True)
-    for name, val in (("CRITICS_LATE", True), ("PRE_FREE", True), ("STATE_KERNEL", False)):
+    for name, val in (("STATE_KERNEL", False),):
         monkeypatch.setattr(M, name, val)
         other = run()
         monkeypatch.setattr(M, name, not val)

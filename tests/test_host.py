@@ -535,3 +535,31 @@ def test_runner_does_not_train_on_noise_silently(tmp_path, monkeypatch, caplog):
     monkeypatch.setitem(runner.DATA_ALIASES, "src.data.data.AugmentedPair2", Boom)
     with pytest.raises(KeyError):
         runner.make_dataset(cfg, rank=0, strict=False)
+
+
+def test_every_switch_is_documented():
+    """switches.py is the one table of the UPS_* environment switches (round-5 verdict, weak 11): every environment read in the package
+    and every getenv in csrc/ names a switch of that table, the package reads its switches through switches.flag / value only, and the
+    table names nothing that no longer exists."""
+    import re
+    from upsparts_amd import switches as SW
+    pkg = os.path.join(ROOT, "unsupervised-part-segmentation_amd")
+    used = set()
+    for fn in sorted(os.listdir(pkg)):
+        if fn.endswith(".py") and fn != "switches.py":
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"environ[^\n]*UPS_", src), fn + " reads a UPS_ switch from os.environ directly: use switches.flag / value"
+            used |= set(re.findall(r"SW\.(?:flag|value)\(\"(UPS_[A-Z0-9_]+)\"\)", src))
+    csrc = os.path.join(pkg, "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h")):
+            used |= set(re.findall(r"getenv\(\"(UPS_[A-Z0-9_]+)\"\)", open(os.path.join(csrc, fn)).read()))
+            for m in re.findall(r"(?:ifn?def|defined\()\s*(UPS_[A-Z0-9_]+)", open(os.path.join(csrc, fn)).read()):
+                assert m in SW.COMPILE_TIME or m.endswith("_H"), "compile-time form {} of {} is not listed in switches.COMPILE_TIME".format(m, fn)
+    missing = sorted(used - set(SW.SWITCHES))
+    stale = sorted(set(SW.SWITCHES) - used)
+    assert not missing, "undocumented switches: {}".format(missing)
+    assert not stale, "switches.py documents switches nobody reads: {}".format(stale)
+    for name, (default, kind, where, what) in SW.SWITCHES.items():
+        assert kind in ("product", "ab", "test", "debug") and what
+    assert SW.report().startswith("UPS switches: ")

@@ -11,15 +11,17 @@
 import torch
 import torch.distributed as dist
 
+from . import switches as SW
+
 
 # UPS_FORCE_COLLECTIVES=1: issue the gradient all-reduces even at world size 1 (identity) -- exercises the RCCL call pattern
 # (asynchronous bucket all-reduces launched from inside the backward pass beside the side streams) on a single-GPU box
-FORCE_COLLECTIVES = __import__("os").environ.get("UPS_FORCE_COLLECTIVES", "0") == "1"
+FORCE_COLLECTIVES = SW.flag("UPS_FORCE_COLLECTIVES")
 # UPS_DP_STANDIN=1 (single-GPU measurement of the data-parallel stream budget, tools/probes/stream_dp.py): every bucket "all-reduce"
 # is an out-of-place device copy of the bucket on a stream of its own, started where the real collective would start and waited
 # for where the real one is -- the load an RCCL kernel puts on HBM and on a hardware queue, without a second GPU.  The values are
 # untouched (world size 1: the sum over ranks is the bucket itself).
-STANDIN = __import__("os").environ.get("UPS_DP_STANDIN", "0") == "1"
+STANDIN = SW.flag("UPS_DP_STANDIN")
 FORCE_COLLECTIVES = FORCE_COLLECTIVES or STANDIN
 _standin = {}
 

@@ -9,8 +9,10 @@ import os
 
 import torch
 
+from . import switches as SW
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("UPS_LIB", os.path.join(_HERE, "csrc", "libupsparts_hip.so"))   # UPS_LIB: A/B builds
+LIB_PATH = SW.value("UPS_LIB") or os.path.join(_HERE, "csrc", "libupsparts_hip.so")   # UPS_LIB: A/B builds
 
 ABI_VERSION = 4               # include/upsparts_hip.h UPS_ABI_VERSION
 F32, BF16, F16 = 0, 1, 2      # F16: forward tensors of precision-critical scopes (held in torch.bfloat16 containers, see ops.py)

@@ -24,6 +24,7 @@ from collections.abc import Mapping
 import torch
 
 from . import lib as L
+from . import switches as SW
 from . import nets as N
 from . import ops
 from . import dist as D
@@ -33,20 +34,17 @@ from .schedules import make_var, make_linear_var
 
 
 PERCEPTUAL_INPUTS = ("native", "resize256", "resize256_crop224")
-LATE_JOIN = os.environ.get("UPS_LATE_JOIN", "1") != "0"      # A/B switch: single rank joins the weight-gradient stream only before Adam
+LATE_JOIN = SW.flag("UPS_LATE_JOIN")      # A/B switch: single rank joins the weight-gradient stream only before Adam
 # A/B switch (off: measured neutral, 2 032 / 2 034 against 2 017 / 2 057 img/s): enqueue the mask decoder's forward before the critics
-CRITICS_LATE = os.environ.get("UPS_CRITICS_LATE", "0") != "0"
-LAZY_SIDES = os.environ.get("UPS_LAZY_SIDES", "0") != "0"             # A/B switch: no extra critic streams when the critics run grouped
-PRE_FREE = os.environ.get("UPS_PRE_FREE", "0") != "0"                  # A/B switch: the target's perceptual features do not wait for the previous step
-STATE_KERNEL = os.environ.get("UPS_STATE_KERNEL", "1") != "0"          # A/B switch: the state update as one launch (ups_state_update)
+STATE_KERNEL = SW.flag("UPS_STATE_KERNEL")          # A/B switch: the state update as one launch (ups_state_update)
 STATE_KEYS = ("avg_acc0", "avg_acc1", "avg_acc_error", "avg_loss_dis0", "avg_loss_dis1", "avg_mim", "avg_independent_mim", "loa", "lor")
-CRITIC_STREAMS = os.environ.get("UPS_CRITIC_STREAMS", "1") != "0"      # A/B switch: the three critics on three side streams
-EARLY_ALPHA = os.environ.get("UPS_EARLY_ALPHA", "1") != "0"      # A/B switch: appearance code on "aux" beside the pose encoder
-JOIN_TIMING = os.environ.get("UPS_JOIN_TIMING", "0") == "1"
+CRITIC_STREAMS = SW.flag("UPS_CRITIC_STREAMS")      # A/B switch: the three critics on three side streams
+EARLY_ALPHA = SW.flag("UPS_EARLY_ALPHA")      # A/B switch: appearance code on "aux" beside the pose encoder
+JOIN_TIMING = SW.flag("UPS_JOIN_TIMING")
 # data parallel: bucket all-reduces are enqueued from the weight-gradient stream's position instead of after a join of the launching
 # stream with it (UPS_DP_SIDE_LAUNCH=0: the round-4 form, A/B runs)
-DP_SIDE_LAUNCH = os.environ.get("UPS_DP_SIDE_LAUNCH", "1") != "0"
-EARLY_ADAM = os.environ.get("UPS_EARLY_ADAM", "1") != "0"    # A/B switch: ... and queues each key's Adam behind its weight gradients
+DP_SIDE_LAUNCH = SW.flag("UPS_DP_SIDE_LAUNCH")
+EARLY_ADAM = SW.flag("UPS_EARLY_ADAM")    # A/B switch: ... and queues each key's Adam behind its weight gradients
 
 
 def _scalar(v, device):
@@ -250,7 +248,7 @@ class Trainer(object):
                               # (measured, round 5: the trunk on fp8 copies -- 20 more launches per step on e4m3 operands -- runs the
                               # step 1.4 % SLOWER: the pools' and the convolutions' copy emission costs more than blocks 2-4 gain at
                               # 64 images; off by default, `vgg_fp8: True` / UPS_VGG_FP8=1 for measurements)
-                              fp8=bool(config.get("vgg_fp8", os.environ.get("UPS_VGG_FP8", "0") == "1")))
+                              fp8=bool(config.get("vgg_fp8", SW.flag("UPS_VGG_FP8"))))
         # `vgg_weights`: npz / torch file with the Keras VGG19 ImageNet kernels in HWIO (edflow downloads them at run time;
         # they are not obtainable offline).  Without it the perceptual loss runs on seeded He-normal stand-ins: fine for
         # timing and parity, NOT for training a model that should match the reference's part quality -- say so loudly.
@@ -274,18 +272,19 @@ class Trainer(object):
                       "avg_acc0": _scalar(0.5, d), "avg_acc1": _scalar(0.5, d), "avg_acc_error": _scalar(0.0, d),
                       "avg_loss_dis0": _scalar(1.0, d), "avg_loss_dis1": _scalar(1.0, d),
                       "avg_mim": _scalar(0.0, d), "avg_independent_mim": _scalar(0.0, d)}
-        if os.environ.get("UPS_STREAM_ORDER") and ops.Streams.enabled and torch.device(d).type == "cuda":
-            ops.Streams.precreate(d, os.environ["UPS_STREAM_ORDER"].split(","))
         self._gen = torch.Generator(device=d)
         self._gen.manual_seed(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))      # TPS uniforms, crop window
         self._noise = ops.NoiseStream(D.shard_seed(config.get("noise_seed", 4321), kwargs.get("rank", 0)))  # the sampling noise
         self._lazy_logs, self._done_thunk = None, None
+        self.switches_report = SW.report()       # the environment switches that differ from their defaults (switches.py), logged once
+        if self.logger:
+            self.logger.info(self.switches_report)
         self._adam_done, self._step_graph_lr = set(), None
         self._adam_stepped = set()      # keys whose Adam step of the RUNNING training step has been enqueued (cleared when the step ends)
         # `stream_plan` (full | compact | auto): how the step's logical streams map onto HIP streams (ops.Streams.set_plan).  auto =
         # full on one rank, compact under data parallelism, where the collectives' stream needs a hardware queue of its own
         # (measured with a stand-in for the collectives on one GPU: tools/probes/stream_dp.py, profiles/round5_stream_dp.txt)
-        plan = str(config.get("stream_plan", os.environ.get("UPS_STREAM_PLAN", "auto"))).lower()
+        plan = str(config.get("stream_plan", SW.value("UPS_STREAM_PLAN"))).lower()
         if plan == "auto":
             plan = "compact" if (self.world_size > 1 or D.FORCE_COLLECTIVES) else "full"
         self.stream_plan = plan
@@ -294,7 +293,7 @@ class Trainer(object):
         self._poisoned = None           # set when a step failed half-way through its optimizer updates (_after_failed_step)
         self._losses = OrderedDict((k, None) for k in self.loss_keys())
         self._early, self._early_hooked = {}, False
-        self._graph_enabled = bool(config.get("hip_graph", os.environ.get("UPS_GRAPH", "0") == "1"))
+        self._graph_enabled = bool(config.get("hip_graph", SW.flag("UPS_GRAPH")))
         self._g = None
         self._cap = None                # set while the step is being captured into HIP graphs (_capture_step)
 
@@ -761,19 +760,9 @@ class Trainer(object):
         c.ft_pre, c.ft_ready = None, None
         if ops.Streams.enabled:
             pre = ops.Streams.get("pre", dev)
-            # The target's features depend on the batch alone.  When the batch arrives ready (resident, fp32, no in-graph TPS) nothing
-            # the launching stream has queued is an input of this block, so it need not wait for the previous step's tail (Adam,
-            # weight conversion, the thin last layers of the backward pass): it only must not overwrite the previous step's features
-            # before that step's perceptual backward has read them (the event recorded there) -- a host that runs a step ahead
-            # then fills the previous step's bubbles with this block instead of sharing the chip with the pose encoder.
-            src = batch["view0"] if df else batch["view0_target"]
-            free = (PRE_FREE and getattr(self, "_cap", None) is None and self._step_graph_lr is None and torch.is_tensor(src)
-                    and vt.data_ptr() == src.data_ptr() and not model.use_tps and c.crop_yx is None)
-            consumed = getattr(self, "_ft_consumed", None)
-            if free and consumed is not None:
-                pre.wait_event(consumed)
-            else:
-                pre.wait_stream(c.main_stream)
+            # (Letting this block start before the previous step's tail -- it depends on the batch alone -- measured neutral twice,
+            # UPS_PRE_FREE in round 5: docs/design/negative_results.md; retired in round 6.)
+            pre.wait_stream(c.main_stream)
             with torch.cuda.stream(pre), torch.no_grad():
                 tgt_pre = vt if c.pmode == "native" else self._perceptual_view(c, model.to_act(vt))
                 c.ft_pre = self.vgg.features(tgt_pre, c.T)
@@ -887,11 +876,8 @@ class Trainer(object):
         # (not in a captured step: replayed from a HIP graph the three branches cost more than they save -- 1 887 against 1 919 img/s
         # with one critic stream, eager 1 979 -- so a capture keeps the one-stream form)
         multi = ops.Streams.enabled and ops.Streams.on_aux(self.device) and CRITIC_STREAMS and self._step_graph_lr is None
-        # (LAZY_SIDES: with the critics on grouped launches the two extra critic streams are only needed by SB_model48c's single-sample
-        # decoders -- not creating them changes which of the remaining streams share a hardware queue)
-        grouped = LAZY_SIDES and self._critics_grouped(c, names, crit, alpha_in)
-        if LAZY_SIDES and grouped and not c.df:
-            multi = False
+        # (the two extra critic streams stay created even when the critics run as grouped launches: which streams share a hardware
+        # queue depends on the creation order, and the order without them sits in the slower cluster -- docs/design/negative_results.md)
         sides = [cur] + ([ops.Streams.get("aux{}".format(i), self.device) for i in (1, 2)] if multi else [cur, cur])
         for sd in sides[1:]:
             if sd is not cur:
@@ -900,7 +886,7 @@ class Trainer(object):
                 else:
                     sd.wait_stream(c.main_stream)  # forked from the launching stream (a HIP-graph capture wants first-level forks) ...
                 sd.wait_stream(cur)                # ... and behind the appearance code
-        if not (grouped if LAZY_SIDES else self._critics_grouped(c, names, crit, alpha_in)):
+        if not self._critics_grouped(c, names, crit, alpha_in):
             for ci, name in enumerate(names):
                 with torch.cuda.stream(sides[ci]):
                     one(ci, name)
@@ -1029,8 +1015,6 @@ class Trainer(object):
         rec_keys = [k for k in ("encoder_1", "decoder_delta") if k in c.keys]
         rec_params = [bank.params[n] for k in rec_keys for n in bank.groups[k]["names"]]
         gr = torch.autograd.grad([c.auto_rec], [c.hard0, c.hard1] + rec_params)
-        if c.ft_pre is not None and getattr(self, "_cap", None) is None:
-            self._ft_consumed = c.main_stream.record_event()        # (the target's features have been read: _step_begin, PRE_FREE)
         c.g_hard0, c.g_hard1 = gr[0].contiguous(), gr[1].contiguous()
         return self._launch_reduce(rec_keys)
 
@@ -1239,26 +1223,16 @@ class Trainer(object):
         self._step_graph_lr, self._adam_done, self._adam_stepped = graph_lr, set(), set()
         c = self._step_begin(batch, noise)
         self._fwd_pose(c)
-        if ops.Streams.enabled and CRITICS_LATE and graph_lr is None:
-            # The critics need the latent samples only, but their block is ~50 launches of a few blocks each: enqueued FIRST, the
-            # launching stream sat idle behind the pose encoder until the host was through them (tools/probes/step_sequence.py).
-            # So the mask decoder's forward pass goes to the launching stream first and the critics to "aux" behind the point where
-            # the samples exist -- the host builds its lead on kernels that fill the chip.
-            ready = c.main_stream.record_event()
-            self._fwd_masks(c)
+        # (enqueueing the mask decoder's forward pass BEFORE the critics' block measured neutral twice, UPS_CRITICS_LATE in round 5:
+        # retired in round 6)
+        if ops.Streams.enabled:
             aux = ops.Streams.get("aux", dev)
-            aux.wait_event(ready)
+            aux.wait_stream(c.main_stream)
             with torch.cuda.stream(aux):
-                self._critics(c, forked_at=ready)
-        else:
-            if ops.Streams.enabled:
-                aux = ops.Streams.get("aux", dev)
-                aux.wait_stream(c.main_stream)
-                with torch.cuda.stream(aux):
-                    self._critics(c)
-            else:
                 self._critics(c)
-            self._fwd_masks(c)
+        else:
+            self._critics(c)
+        self._fwd_masks(c)
         self._fwd_reconstruction(c)
         pending = self._bwd_reconstruction(c)
         self._priors(c)
@@ -1484,6 +1458,7 @@ class Trainer(object):
         num_steps = num_steps if num_steps is not None else cfg.get("num_steps", 1000000)
         log_freq, ckpt_freq = cfg.get("log_freq", 250), cfg.get("ckpt_freq", 10000)
         interval = 1
+        log_fn("[INFO] [Trainer]: " + self.switches_report)
         for batch in batch_iterator:
             if self.global_step >= num_steps:
                 break

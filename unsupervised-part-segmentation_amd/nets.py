@@ -14,6 +14,7 @@ from collections import OrderedDict
 import torch
 
 from . import lib as L
+from . import switches as SW
 from . import ops
 from .ops import ConvLayer, round8
 
@@ -330,7 +331,7 @@ class Nets(object):
         self.scope_fmt = {"decoder_visualize": L.F16} if md in ("fp16", "f16", "half") else {}
         # `post_activation_storage` (default on): tensors whose only convolution consumer activates them are stored as act(x)
         # (Scope.conv2d); False restores activation-on-load everywhere (A/B runs, debugging)
-        self.post_storage = bool(config.get("post_activation_storage", os.environ.get("UPS_POST_ACT", "1") != "0"))
+        self.post_storage = bool(config.get("post_activation_storage", SW.flag("UPS_POST_ACT")))
         S = config["spatial_size"]
         Z, A, P = config.get("z0_size", 256), config.get("local_app_size", 64), config["n_parts"]
         img = Act(None, 1, S, S, 3)

@@ -17,6 +17,7 @@ import os
 import torch
 
 from . import lib as L
+from . import switches as SW
 
 
 def round8(c):
@@ -54,7 +55,7 @@ class Streams(object):
     input gradient continues on the launching stream (the two are independent; small layers that cannot fill 256 CUs
     then overlap).  ``aux``: the critics + the appearance code of the whole views, which the main path only needs
     again at the encoder_0 backward.  UPS_NO_OVERLAP=1 keeps everything on one stream (A/B runs, debugging)."""
-    enabled = os.environ.get("UPS_NO_OVERLAP", "0") != "1"
+    enabled = not SW.flag("UPS_NO_OVERLAP")
     _pool = {}
     _raw = {}       # (name, device index) -> raw hipStream_t
     epoch = 0          # bumped by the trainer at the end of every step (all side streams joined): scopes ConvLayer._mark_ready
@@ -94,16 +95,6 @@ class Streams(object):
         return st
 
     _pads = []
-
-    @classmethod
-    def precreate(cls, device, order):
-        """Create the side streams in a given order before their first use ("pad" = a stream nobody uses): the HIP runtime deals
-        streams onto its hardware queues in creation order, and streams that share a queue serialize (UPS_STREAM_ORDER, A/B runs)."""
-        for name in order:
-            if name == "pad":
-                cls._pads.append(torch.cuda.Stream(device=device))
-            elif name:
-                cls.get(name, device)
 
     @classmethod
     def on_aux(cls, device):
@@ -162,7 +153,7 @@ class SignBits(object):
     PRODUCER of such a tensor (a convolution's epilogue, the x2 bilinear kernel) now also writes [n,h,w,c/8] sign bytes, the handle
     carries them (nets.Act.bits) and the consuming convolution's backward passes them to ups_conv_igemm next to `dact`.
     Hand-off like Fp8.last_out: `want` is set by the caller that will keep the bits, `last` by the producer."""
-    ENABLED = os.environ.get("UPS_SIGN_BITS", "1") != "0"
+    ENABLED = SW.flag("UPS_SIGN_BITS")
     want = False
     last = None
     stats = None        # a dict when a probe wants to know which input gradients ran without bits (tools/probes/sign_bits_coverage.py)
@@ -260,7 +251,7 @@ class Fp8State(object):
         self.GRAD = True            # input gradients of the fp8 layers on e5m2 operands (False: bf16 kernels)
         # weight gradients of the wide 3x3 layers on e4m3 x e5m2 operands (conv_wgrad3x3_f8.hip) wherever the gradient arrives with
         # its producer's e5m2 copy; UPS_F8_WGRAD=0: bf16 weight gradients (A/B runs)
-        self.WGRAD = os.environ.get("UPS_F8_WGRAD", "1") != "0"
+        self.WGRAD = SW.flag("UPS_F8_WGRAD")
         # COPY_ONLY: a layer takes the fp8 kernels only when its operand arrives quantised (a copy written by the producing
         # bilinear / convolution kernel); layers whose operand would have to be converted inside the kernel (24 staging
         # registers, one block per CU: slower than bf16) stay on the bf16 kernels.  None: follows PRODUCER.
@@ -271,7 +262,7 @@ class Fp8State(object):
         # conversion.  nets.Scope passes the handle along: next_in / next_out_act are set right before ops.conv, last_out is
         # read right after.  UPS_F8_PRODUCER=0 switches the hand-off off (every eligible layer then converts its bf16 operand
         # inside the kernel).
-        self.PRODUCER = os.environ.get("UPS_F8_PRODUCER", "1") != "0"
+        self.PRODUCER = SW.flag("UPS_F8_PRODUCER")
         self.next_in = None         # {"t": uint8 tensor, "act": UPS_ACT_*, "slot": scale slot} of the coming call's input
         self.next_out_act = None    # activation-on-load of the consumer of the coming call's output (None: no copy wanted)
         self.last_out = None        # the copy the last call wrote (same dict), or None
@@ -622,7 +613,7 @@ def _fill_taps(desc, dy, dx, tw, ntaps):
 
 
 SPLITK_WS_BYTES = 48 << 20
-D2S_DGRAD = os.environ.get("UPS_NO_D2S", "0") != "1"      # one-launch input gradient of the stride-2 layers (A/B switch)
+D2S_DGRAD = not SW.flag("UPS_NO_D2S")      # one-launch input gradient of the stride-2 layers (A/B switch)
 
 
 def _attach_ws(d, device):
@@ -862,7 +853,7 @@ def conv_dgrad(g, x, layer, res=None, mask_view=None, n_parts=0, f8_src="pop", x
     return gx if mask_view is None else g_hard
 
 
-COORD_STREAM = os.environ.get("UPS_COORD_STREAM", "1") != "0"     # A/B switch: CoordConv rows of the weight gradients on their own stream
+COORD_STREAM = SW.flag("UPS_COORD_STREAM")     # A/B switch: CoordConv rows of the weight gradients on their own stream
 
 
 def conv_wgrad(g, x, layer, mask=None, fmt=None, launch_stream=None, f8_src=None):
@@ -1336,7 +1327,7 @@ class CriticHeadFn(torch.autograd.Function):
         return gp, ga, None, None
 
 
-TOWERS = os.environ.get("UPS_TOWERS", "1") != "0"      # A/B switch: the critics' towers as grouped launches (ups_towers_*)
+TOWERS = SW.flag("UPS_TOWERS")      # A/B switch: the critics' towers as grouped launches (ups_towers_*)
 
 
 def towers_eligible(towers, xs):

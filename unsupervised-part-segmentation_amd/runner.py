@@ -26,6 +26,7 @@ from .model import TrainModel, Trainer
 
 from . import data as _data
 from . import dist as D
+from . import switches as SW
 
 LOG = logging.getLogger("upsparts")
 ALIASES = {"TrainModel": TrainModel, "Trainer": Trainer}
@@ -47,7 +48,7 @@ def dist_setup():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
-    world, rank, local = D.init_from_env(os.environ.get("UPS_DIST_BACKEND", "nccl"))
+    world, rank, local = D.init_from_env(SW.value("UPS_DIST_BACKEND"))
     return world, rank, local
 
 
