@@ -743,14 +743,19 @@ def _prior_oracle(R, variant, lm0, eps0, lm1, eps1, px_order, gamma, patch, w, g
     return q, t0 + r0, t1 + r1, r0, r1
 
 
-@pytest.mark.parametrize("variant,P,S,entropy_func", [(0, 10, 32, "entropy"), (0, 25, 32, "cross_entropy"), (0, 10, 20, "entropy"),
-                                                      (1, 10, 32, "cross_entropy"), (1, 25, 32, "cross_entropy"), (0, 3, 48, "entropy"),
-                                                      # the pixel-per-lane forward of round 5 (P = 10 at 128- / 256-wide images)
-                                                      (0, 10, 128, "entropy"), (1, 10, 128, "cross_entropy"), (0, 10, 256, "cross_entropy"),
-                                                      # the direct-from-global forms of round 6 (P = 16 / 20 / 25 at 128- / 256-wide images)
-                                                      (0, 16, 128, "entropy"), (1, 20, 128, "cross_entropy"), (0, 25, 128, "cross_entropy"),
-                                                      (0, 20, 256, "entropy"), (1, 16, 256, "cross_entropy")])
-@pytest.mark.parametrize("px_bpi", [0, 4, 1])
+PRIOR_CASES = [(0, 10, 32, "entropy"), (0, 25, 32, "cross_entropy"), (0, 10, 20, "entropy"),
+               (1, 10, 32, "cross_entropy"), (1, 25, 32, "cross_entropy"), (0, 3, 48, "entropy"),
+               # the pixel-per-lane forward of round 5 (P = 10 at 128- / 256-wide images)
+               (0, 10, 128, "entropy"), (1, 10, 128, "cross_entropy"), (0, 10, 256, "cross_entropy"),
+               # the direct-from-global forms of round 6 (P = 16 / 20 / 25 at 128- / 256-wide images)
+               (0, 16, 128, "entropy"), (1, 20, 128, "cross_entropy"), (0, 25, 128, "cross_entropy"),
+               (0, 20, 256, "entropy"), (1, 16, 256, "cross_entropy")]
+# px_bpi (UPS_PRIOR_PX_BPI: blocks per image of the pixel-per-lane kernels) only exists for the shapes those kernels take: the
+# multi-tile variants are generated for exactly those cases (until round 6 they were generated for every case and skipped)
+PRIOR_PARAMS = [c + (0,) for c in PRIOR_CASES] + [c + (b,) for c in PRIOR_CASES if c[1] == 10 and c[2] in (128, 256) for b in (4, 1)]
+
+
+@pytest.mark.parametrize("variant,P,S,entropy_func,px_bpi", PRIOR_PARAMS)
 def test_mask_priors_forward_and_backward(variant, P, S, entropy_func, px_bpi, dev, monkeypatch):
     """ups_prior_fwd / ups_prior_bwd ALONE (8a-12; until round 4 only covered through the whole-step tests): every logged prior
     and the fused analytic d/d logits -- total (`dl`, the decoder_visualize key) and reconstruction-only (`dl_rec`, what
@@ -764,8 +769,6 @@ def test_mask_priors_forward_and_backward(variant, P, S, entropy_func, px_bpi, d
     # px_bpi (UPS_PRIOR_PX_BPI): blocks per image of the pixel-per-lane kernels -- 0: the launcher's choice (one tile per block for
     # three images), 4 / 1: 16 / 64 tiles per block at 128 x 128, the multi-tile loops of the 64-image benchmark shape
     if px_bpi:
-        if not (P == 10 and S in (128, 256)):
-            pytest.skip("the pixel-per-lane kernels take P = 10 at 128- / 256-wide images")
         monkeypatch.setenv("UPS_PRIOR_PX_BPI", str(px_bpi))
     g = torch.Generator().manual_seed(100 * variant + P + S)
     B, gamma, patch = 3, 10.0, 8
