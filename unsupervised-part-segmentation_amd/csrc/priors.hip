@@ -1086,6 +1086,76 @@ __device__ __forceinline__ void ldg_row(const float* __restrict__ src, float (&d
     }
 }
 
+// The view-1 backward (KL + variance terms through the soft-max Jacobian; m and g_hard in, dl and dl_rec out: no stencil at all) for
+// the same part counts: every thread streams its pixel's two rows in and its two result rows out.
+template <int P, int LW, int VAR>
+__global__ __launch_bounds__(256) void prior_bwd1_direct_kernel(const PriorK p) {
+    constexpr int W = 1 << LW, CH = PChunk<P>::N;
+    __shared__ float cst[P][10];       // rcy, rcx, kmax, wv, muy2, mux2, ca, cb, cc, s11
+    const int tid = threadIdx.x;
+    const int hw = p.h * W, tiles_img = hw >> 8;
+    const int lb = xcd_logical_block();
+    const int n = lb / tiles_img, t = lb - n * tiles_img;
+    const float inv_pix = 1.f / (float)((long long)p.n * hw), inv_n = 1.f / (float)p.n;
+    if (tid < P) {
+        const float* np = p.per_np + ((long long)n * P + tid) * 8;
+        const float Z = np[1], muy = np[3] / Z, mux = np[4] / Z, k6 = np[5] / Z, k7 = np[6] / Z;
+        float* k = cst[tid];
+        k[0] = p.px ? (float)p.px[((long long)n * P + tid) * 2] : 0.f;
+        k[1] = p.px ? (float)p.px[((long long)n * P + tid) * 2 + 1] : 0.f;
+        k[2] = np[0];
+        float wv = p.w_var * inv_n * p.gamma * __fdividef(1.f, Z);
+        k[4] = 2.f * muy; k[5] = 2.f * mux;
+        if (VAR == 1) {
+            const float Qyn = k7, Qxn = k6 - k7;
+            k[6] = Qyn - 2.f * muy * muy; k[7] = Qxn - 2.f * mux * mux; k[8] = Qyn - muy * muy;
+            k[9] = (k6 - k7) - mux * mux;
+            wv *= 2.f;
+        } else {
+            k[6] = k6 - 2.f * muy * muy - 2.f * mux * mux; k[7] = 0.f; k[8] = 0.f; k[9] = 0.f;
+        }
+        k[3] = wv;
+    }
+    __syncthreads();
+    const float sy = p.h > 1 ? 2.f / (float)(p.h - 1) : 0.f, sx = W > 1 ? 2.f / (float)(W - 1) : 0.f;
+    const float wkl = p.w_kl * inv_pix;
+    const int q = (t << 8) + tid;
+    const int yy = q >> LW, xx = q & (W - 1);
+    const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
+    const float gq = gy * gy + gx * gx;
+    const long long o0 = ((long long)n * hw + q) * P;
+    float m[P], gh[P], gmv[P];
+    ldg_row<P>(p.m + o0, m); ldg_row<P>(p.g_hard + o0, gh);
+    float dot = 0.f, dot_r = 0.f;
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        const float* k = cst[c];
+        const float mc = m[c];
+        const float pm = (float)P * mc;
+        float g = wkl * (ups_log_fast(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[c];
+        const float sq = __expf(p.gamma * mc - k[2]);
+        if (VAR == 1) {
+            const float ay = gy * gy - k[4] * gy - k[6];
+            const float ax = gx * gx - k[5] * gx - k[7];
+            g += k[3] * sq * (k[8] * ay + k[9] * ax);
+        } else {
+            const float kk = (abs(yy - (int)k[0]) <= p.half_h && abs(xx - (int)k[1]) <= p.half_w) ? 0.f : 1.f;
+            const float a = gq - k[4] * gy - k[5] * gx;
+            g += k[3] * sq * (a * kk - k[6]);
+        }
+        gmv[c] = g;
+        dot += mc * g; dot_r += mc * gh[c];
+    }
+#pragma unroll
+    for (int c0 = 0; c0 < P; c0 += CH) {
+        float a[CH], b[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { a[e] = m[c0 + e] * (gmv[c0 + e] - dot); b[e] = m[c0 + e] * (gh[c0 + e] - dot_r); }
+        stg_chunk<CH>(p.dl + o0 + c0, a);
+        stg_chunk<CH>(p.dl_rec + o0 + c0, b);
+    }
+}
+
 // The view-0 forward sums in the same form: a block walks `tiles_per_block` consecutive tiles of 256 pixels of one image, carries the
 // four pixel sums and the per-part sums (S, R, Rsmooth, Rcontour) in registers and writes ONE slab record (the workspace layout and the
 // finalize kernel of the pixel-per-lane form: blocks per image = NSLAB records, one each).
@@ -1525,6 +1595,22 @@ extern "C" int ups_prior_bwd(const ups_prior_desc* d, void* stream) {
         const long long hw = (long long)d->h * d->w;
         const uintptr_t all = ((uintptr_t)d->m) | ((uintptr_t)d->l_mean) | ((uintptr_t)d->l) | ((uintptr_t)d->hard) | ((uintptr_t)d->g_hard) |
                               ((uintptr_t)d->dl) | ((uintptr_t)d->dl_rec);
+        if (dr_on && d->view == 1 && (d->P == 16 || d->P == 20 || d->P == 25) && (d->w == 128 || d->w == 256) && hw % 256 == 0 &&
+            d->g_hard && d->dl_rec && (((uintptr_t)d->m | (uintptr_t)d->g_hard | (uintptr_t)d->dl | (uintptr_t)d->dl_rec) & 15) == 0 &&
+            d->n * (hw / 256) < (1ll << 31)) {
+            const dim3 grid((unsigned)(d->n * (hw / 256)));
+#define UPS_PRIOR_D1(PV, LWV, VARV) hipLaunchKernelGGL((prior_bwd1_direct_kernel<PV, LWV, VARV>), grid, dim3(256), 0, s, k)
+#define UPS_PRIOR_D1P(PV)                                                                                  \
+            do {                                                                                          \
+                if (d->w == 128) { if (d->variant == 0) UPS_PRIOR_D1(PV, 7, 0); else UPS_PRIOR_D1(PV, 7, 1); } \
+                else { if (d->variant == 0) UPS_PRIOR_D1(PV, 8, 0); else UPS_PRIOR_D1(PV, 8, 1); }         \
+            } while (0)
+            if (d->P == 16) UPS_PRIOR_D1P(16); else if (d->P == 20) UPS_PRIOR_D1P(20); else UPS_PRIOR_D1P(25);
+#undef UPS_PRIOR_D1P
+#undef UPS_PRIOR_D1
+            UPS_LAUNCH_CHECK();
+            return UPS_OK;
+        }
         if (dr_on && d->view == 0 && (d->P == 16 || d->P == 20 || d->P == 25) && (d->w == 128 || d->w == 256) && hw % 256 == 0 &&
             d->g_hard && d->dl_rec && d->l && d->l_mean && d->hard && (all & 15) == 0 && d->n * (hw / 256) < (1ll << 31)) {
             const dim3 grid((unsigned)(d->n * (hw / 256)));
