@@ -77,7 +77,14 @@ def test_residual_block_launches_repeat_bit_identically(case, dev, monkeypatch):
             nd = int((a.view(torch.int16) != b_.view(torch.int16)).sum())
             assert nd == 0, "{}: {} differs in {} elements between launch 0 and launch {}".format(name, what, nd, rep)
         del again
-    assert torch.equal(first[1], first[2]), "{}: the input gradient from sign bytes differs from the one from the forward input".format(name)
+    # The two input gradients are the same numbers up to fp32 summation order: with sign bytes the wide instances take the residual from
+    # the resident patch DURING the channel loop (res_patch == 2, round 6), without them it is added in the epilogue -- a bf16 rounding
+    # flips in a few elements per thousand, by one unit in the last place; anything else is a bug.
+    a, b_ = first[1].float(), first[2].float()
+    diff = (a - b_).abs()
+    ulp = b_.abs() * 2.0 ** -7 + 1e-5 * float(b_.pow(2).mean().sqrt())      # one bf16 unit, or (results near zero: cancellation) the fp32 noise of the terms
+    assert bool((diff <= ulp).all()), "{}: input gradient from sign bytes vs from the forward input: max {} of the bound".format(name, float((diff / ulp).max()))
+    assert float((diff > 0).float().mean()) < 0.02, "{}: {} of the elements differ".format(name, float((diff > 0).float().mean()))
     if alt:
         for k, v in alt.items():
             monkeypatch.setenv(k, v)

@@ -80,7 +80,12 @@ struct PatchK {
     // the halo patch of channel chunk c holds exactly the residual values of output channels 32c .. 32c+31, so each wave adds
     // its share into its accumulators straight from LDS while that chunk is resident -- the residual tensor is never read a
     // second time from global memory and the epilogue needs no residual tile (launcher sets it; 16-bit, SUB == TS)
+    // res_patch == 2 (round 6): the same for the INPUT GRADIENT of a residual block, gx = act'(x) * conv^T(g) + g with act' from the producer's
+    // sign bytes: the residual g is the launch's own operand, so it is added from the resident patch DIVIDED by act' (1 or 1 / slope:
+    // the epilogue's multiplication by act' restores it) and the launch reads nothing but its operand, 32 bytes of signs per pixel and
+    // the weights.  The tile's sign bytes sit in LDS from the prologue on (`sgn_off`: 256 pixels x BN / 8 bytes behind the buffers).
     int res_patch;
+    int sgn_off;
 };
 
 __device__ __forceinline__ int fast_div(int n, int d, unsigned m) {
@@ -656,10 +661,20 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         constexpr int CPW = TN16 / 2 > 0 ? TN16 / 2 : 1;
         const int rp_first = nt * (BN / 32) + wn * CPW;
         const int rp_lane = ((px_l16 + 1) * APX) + ((((q16 >> 1)) ^ a_swz16(px_l16 + 1)) << 4) + (q16 & 1) * 8;   // jj = 0; jj = 1: slot ^ 2
+        // (flipped-tap instances, res_patch == 2: the residual goes in divided by act' -- the lane's four sign bits of pixel (row, p16),
+        // channels 32 chunk + 16 jj + 4 q16 .. + 3, from the tile's resident sign bytes)
+        constexpr bool RP2 = DMAP && SUB == TS && TN16 >= 2 && TAPS == 2 && BN == 128 && F8 == 0 && __is_same(T, bf16);
+        const unsigned char* S1 = smem + p.sgn_off;
+        const float rp2_inv = (RP2 && p.res_patch == 2) ? 1.f / dact_ns : 1.f;
         auto add_res_patch = [&](const unsigned char* A, int cc) __attribute__((always_inline)) {
             if constexpr (DMAP && SUB == TS && TN16 >= 2) {     // (the conditions of res_patch are those of the DMA patch)
                 const int c2 = cc - rp_first;
                 if (p.res_patch && c2 >= 0 && c2 < CPW) {
+                    // (the lane part of the sign-byte address is re-derived here, once per channel chunk, from a copy of the lane id the
+                    // compiler cannot hoist: two more loop-invariant registers would push the 128-register instances into scratch)
+                    int ln = lane;
+                    if constexpr (RP2) asm volatile("" : "+v"(ln));
+                    const int sg_lane = (ln & 15) * (BN / 8) + (ln >> 5), sg_sh = (ln >> 2) & 4;
 #pragma unroll
                     for (int jh = 0; jh < CPW; ++jh) {
                         if (jh != c2) continue;
@@ -670,6 +685,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                                 const uint2 rv = *(const uint2*)(A + (wm * TM16 + i + 1) * (PWPS * APX) + (rp_lane ^ (jj << 5)));
                                 float r0, r1, r2, r3;
                                 ups_unpack2<T>(rv.x, r0, r1); ups_unpack2<T>(rv.y, r2, r3);
+                                if constexpr (RP2) {
+                                    if (p.res_patch == 2) {
+                                        const unsigned nib = (unsigned)S1[(wm * TM16 + i) * 16 * (BN / 8) + 4 * (wn * CPW + jh) + 2 * jj + sg_lane] >> sg_sh;
+                                        r0 = (nib & 1u) ? r0 : r0 * rp2_inv; r1 = (nib & 2u) ? r1 : r1 * rp2_inv;
+                                        r2 = (nib & 4u) ? r2 : r2 * rp2_inv; r3 = (nib & 8u) ? r3 : r3 * rp2_inv;
+                                    }
+                                } else
                                 if (p.res_act) {
                                     r0 = r0 > 0.f ? r0 : r0 * res_inv; r1 = r1 > 0.f ? r1 : r1 * res_inv;
                                     r2 = r2 > 0.f ? r2 : r2 * res_inv; r3 = r3 > 0.f ? r3 : r3 * res_inv;
@@ -754,6 +776,16 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         if constexpr (DMAP) dma_patch(0);
         else { load_patch(0); store_patch(Abuf); }
         dma_w(0);
+        if constexpr (RP2) {
+            if (p.res_patch == 2) {      // thread t: 8 of the 16 sign bytes of tile pixel t / 2 (zero outside a ragged image)
+                const int px = tid >> 1, hf = tid & 1;
+                const int yy = ty0 + (px >> 4), xx = tx0 + (px & 15);
+                uint2 sv = make_uint2(0u, 0u);
+                if (yy < p.h && xx < p.w)
+                    sv = *(const uint2*)(p.dact_bits + (((long long)img_pm * p.h + yy) * p.w + xx) * (p.ldd >> 3) + (nt * BN >> 3) + 8 * hf);
+                *(uint2*)(smem + p.sgn_off + px * (BN / 8) + 8 * hf) = sv;
+            }
+        }
         if (OCC != 2 && total > 1) dma_w(1);
         // a single channel chunk on the 3-stage ring: all nine taps' weights fit the ring at once -- everything is requested
         // up front, ONE wait + barrier, then the three tap-rows run back to back (the thin 128x128 layers of encoder_1 on the
@@ -905,7 +937,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !defined(UPS_ABLATE_BARRIER)          // (timing experiment of round 6: what the per-tap-row barrier costs; results are garbage without it)
             __builtin_amdgcn_s_barrier();
+#endif
         }
         }
         }       // (!F8S)
@@ -946,6 +980,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 
     UPS_PHASE(3);
     // ---- epilogue
+#if defined(UPS_EPI_PRIO)
+    __builtin_amdgcn_s_setprio(UPS_EPI_PRIO);      // (round-6 experiment: the epilogue's vector instructions ahead of the CU neighbour's MFMA bursts)
+#endif
 #if defined(UPS_ABLATE_EPI)
     {   // ablation build: keep the accumulators alive, write (almost) nothing
         float sacc = 0.f;
@@ -1028,9 +1065,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             constexpr int CPR = BN / 8;                      // 16-byte chunks per row
             constexpr int NIT = 256 * CPR / 512;             // chunks per thread
             unsigned char* R0 = smem;                        // residual tile, then the output tile (in place)
-            unsigned char* R1 = smem + 256 * ERS;            // activation-derivative tile as sign bits: [256 px][BN / 8 bytes]
+            // activation-derivative tile as sign bits: [256 px][BN / 8 bytes]; res_patch == 2: the copy the prologue left behind the buffers
+            const bool sgn_resident = DMAP && SUB == TS && TAPS == 2 && BN == 128 && F8 == 0 && __is_same(T, bf16) && p.res_patch == 2;
+            unsigned char* R1 = sgn_resident ? smem + p.sgn_off : smem + 256 * ERS;
             const int c_lim = p.co_fill - nt * BN;           // valid channels of this N-tile (multiple of 8)
-            if (res || dact) {
+            if ((res || dact) && !sgn_resident) {
 #pragma unroll
                 for (int i = 0; i < NIT; ++i) {
                     const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
@@ -1311,10 +1350,15 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     if (F8 >= 3) shmem = shmem_max = 2 * ABY + 2 * (2 * (size_t)BN * 64);      // block-scaled fp8: two patch images, two per-tap stages
     const size_t epi = sizeof(T) == 2 ? 256 * (size_t)(BN * 2 + 16) + 256 * (size_t)(BN / 8) : 0;   // staged bf16 epilogue
     if (epi > shmem) shmem = epi;
+    constexpr bool rp2_ok = __is_same(T, bf16) && BN == 128 && TAPS == 2 && DMAP && SUB == TS && F8 == 0;
+    constexpr size_t sgn_bytes = rp2_ok ? 256 * (size_t)(BN / 8) : 0;       // the resident sign tile of res_patch == 2
+    if (kk.res_patch == 2 && !rp2_ok) kk.res_patch = 0;                     // (this instance has no such path: residual and signs in the epilogue)
+    kk.sgn_off = (int)shmem;
+    if (kk.res_patch == 2) shmem += sgn_bytes;
     static UpsPerDevice attr_set;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE, TAPS, DMAP, CSTD>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(epi > shmem_max ? epi : shmem_max));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((epi > shmem_max ? epi : shmem_max) + sgn_bytes));
         if (e != hipSuccess) return UPS_E_LAUNCH;
         attr_set = true;
     }
@@ -1552,6 +1596,14 @@ int ups_conv3x3_patch_try(const ups_conv_desc* d, hipStream_t s) {
                       d->dtype != UPS_F32 && !small && !d->dact && !d->mask_bits && !d->mask_grad && !d->d2s && !d->f8_deq && !d->out_f32 &&
                       d->act_in == UPS_ACT_NONE &&    // (with activation-on-load the patch holds act(x), the residual wants x)
                       dma_patch_on() && static_taps_on() && (fwd || flip);       // ... and only the DMA-patch instances implement it
+        // round 6: the input gradient of a residual block whose act' arrives as sign bytes (leaky ReLU: 1 / slope exists)
+        static int rp2_on = -1;
+        if (rp2_on < 0) { const char* e = getenv("UPS_RES_PATCH_DGRAD"); rp2_on = (e && e[0] == '0') ? 0 : 1; }
+        if (rp_on && rp2_on && !k.res_patch && d->res && d->res == d->in && d->ldr == d->ldi && d->ci == d->co_fill && d->co == d->co_fill &&
+            d->ci % 32 == 0 && d->dtype == UPS_BF16 && !small && d->dact && k.dact_bits && d->dact_kind == UPS_ACT_LRELU && d->act_slope > 0.f &&
+            (d->ldd & 63) == 0 && (((uintptr_t)k.dact_bits) & 7) == 0 && !d->mask_bits && !d->mask_grad && !d->d2s && !d->f8_deq && !d->out_f32 &&
+            !d->res_act && d->act_in == UPS_ACT_NONE && dma_patch_on() && static_taps_on() && flip && !fwd)
+            k.res_patch = 2;
     }
     if ((d->out_act || d->res_act) && (d->mask_grad || d->d2s)) return 1;
     // an fp8 copy of a post-activation output is the quantisation of the stored value: no second activation

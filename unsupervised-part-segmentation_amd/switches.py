@@ -59,6 +59,7 @@ SWITCHES = OrderedDict([
     ("UPS_PATCH_THIN128", ("", "ab", "conv3x3_patch.hip", "patch kernel: thin 128-wide instance selection")),
     ("UPS_PATCH_THINOUT", ("", "ab", "conv3x3_patch.hip", "patch kernel: thin-output instance selection")),
     ("UPS_RES_PATCH", ("1", "ab", "conv3x3_patch.hip", "0: the forward's residual from global memory instead of the resident patch")),
+    ("UPS_RES_PATCH_DGRAD", ("1", "ab", "conv3x3_patch.hip", "0: the input gradient's residual and sign bytes fetched in the epilogue instead of from the resident patch (round 6)")),
     ("UPS_F8_SCALED", ("1", "ab", "conv3x3_patch.hip", "0: K = 32 fp8 MFMA instead of the block-scaled K = 128 form")),
     ("UPS_WGRAD_DIRECT", ("1", "ab", "conv_wgrad.hip", "0: single-split weight gradients through a slab + reduce launch")),
     ("UPS_WGRAD_SLIDE", ("1", "ab", "conv_wgrad3x3.hip", "0: the plain form of the 3x3 weight gradient (3 % slower step)")),
@@ -71,7 +72,7 @@ SWITCHES = OrderedDict([
     ("UPS_UNPOOL_MFMA", ("1", "test", "partpath.hip", "0: the VALU form of unpool_bwd (the unit test compares both)")),
 ])
 
-COMPILE_TIME = ("UPS_ABLATE_DMA", "UPS_ABLATE_EPI", "UPS_ABLATE_GLOAD", "UPS_ABLATE_LSTORE", "UPS_ABLATE_MFMA", "UPS_F8S_WN1", "UPS_OCC2_FRAG2",
+COMPILE_TIME = ("UPS_ABLATE_BARRIER", "UPS_EPI_PRIO", "UPS_ABLATE_DMA", "UPS_ABLATE_EPI", "UPS_ABLATE_GLOAD", "UPS_ABLATE_LSTORE", "UPS_ABLATE_MFMA", "UPS_F8S_WN1", "UPS_OCC2_FRAG2",
                 "UPS_PATCH_A2", "UPS_PHASE_TIMING", "UPS_W8_NO_DMA", "UPS_W8_NO_MFMA", "UPS_W8_NO_QUANT", "UPS_W8_NO_XLOAD", "UPS_WGRAD_NO_PIPE",
                 "UPS_ROWS_FWD_SIGN", "UPS_ROWS_NO_FENCE", "UPS_VMAX_BUILTIN")
 NOT_SWITCHES = ("UPS_ABI_VERSION", "UPS_ACT_", "UPS_OK", "UPS_E_", "UPS_BF16", "UPS_F16", "UPS_F32", "UPS_CHECK_ARG", "UPS_LAUNCH_CHECK")
