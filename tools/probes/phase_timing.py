@@ -32,7 +32,11 @@ out_f32 = case == "dv_out"
 fwd = lambda: ops.conv_forward(x, lay, res=x if res_self else None, fmt=fmt, res_post=lay.in_post, out_f32=out_f32)
 y = fwd()
 gy = torch.randn(y.shape, device=dev).to(torch.bfloat16)
-run = fwd if mode == "fwd" else (lambda: ops.conv_dgrad(gy, x, lay, res=gy if res_self else None))
+xb = None
+if "bits" in sys.argv[3:]:       # act' from the producer's sign bytes, as the step runs it (res_patch == 2 on the wide instances)
+    pos = (x.view(torch.int16) > 0).view(*x.shape[:-1], -1, 8).to(torch.uint8)
+    xb = (pos * (2 ** torch.arange(8, device=dev, dtype=torch.uint8))).sum(-1).to(torch.uint8).contiguous()
+run = fwd if mode == "fwd" else (lambda: ops.conv_dgrad(gy, x, lay, res=gy if res_self else None, x_bits=xb))
 for _ in range(3):
     run()
 torch.cuda.synchronize()

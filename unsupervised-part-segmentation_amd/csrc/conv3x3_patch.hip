@@ -1103,6 +1103,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             // channel, the y part is one multiply-add; only tiles that touch the image border look the class table up, and
             // only for their border pixels.
             // (multi-image tiles: every pixel takes the class-table path; the folded terms are then unused)
+            const bool all_valid = p.co == p.co_fill;
+            const bool has_affine = p.bias != nullptr || p.coord_tab != nullptr;
             const bool epi_vec = (p.co & 3) == 0 && ((((unsigned long long)p.bias) | ((unsigned long long)p.coord_tab)) & 15ull) == 0;
             const bool border_tile = p.coord_tab && (SUB < TS || ty0 == 0 || ty0 + TS >= p.h || tx0 == 0 || tx0 + TS >= p.w);
             const float xf = (float)(tx0 + p16);
@@ -1149,8 +1151,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                     const int yrow = wm * TM16 + i;
                     const int px = yrow * 16 + p16;
                     float v[4];
+                    if (has_affine) {          // (uniform: an input gradient has neither bias nor CoordConv term)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc16[i][j][e] + xs[e];
+                        for (int e = 0; e < 4; ++e) v[e] = acc16[i][j][e] + xs[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc16[i][j][e];
+                    }
                     if (p.coord_tab) {
                         const float yf = (float)(ty0 + yrow);
 #pragma unroll
@@ -1189,8 +1196,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = ups_vmax(v[e], oact_ns * v[e]);
                     }
+                    if (!all_valid) {          // (uniform: pad channels exist only when co < co_fill)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (!cv[e]) v[e] = 0.f;
+                        for (int e = 0; e < 4; ++e) if (!cv[e]) v[e] = 0.f;
+                    }
                     *slot = make_uint2(Chunk<T>::pk(v[0], v[1]), Chunk<T>::pk(v[2], v[3]));
                 }
             }
@@ -1209,12 +1218,22 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 }
                 return;
             }
+            // (round 6: the epilogue's vector instructions run on the issue port the CU neighbour's MFMAs need, DESIGN section 3.  A thread's
+            // NIT pieces are 512 / CPR pixels = whole tile rows apart: on plain full tiles their addresses are one base + a constant step
+            // instead of a 64-bit multiply-add chain per piece)
+            const bool lin = SUB == TS && !p.d2s && !ragged;
+            const unsigned px0 = (unsigned)tid / CPR, ch0 = (unsigned)tid - px0 * CPR;
+            const unsigned ga0 = lin ? gaddr((int)px0, nt * BN + (int)ch0 * 8, p.ldo) : 0u;
+            const unsigned ga_step = (unsigned)((512 / CPR / 16) * p.w) * (unsigned)p.ldo;       // 512 / CPR pixels = (512 / CPR) / 16 tile rows
+            const unsigned long long sg0 = lin && p.sign_out ? ((unsigned long long)img_pix + gpix((int)px0)) * (unsigned)(p.ldo >> 3) +
+                                                                (unsigned)((nt * BN + (int)ch0 * 8) >> 3) : 0ull;
+            const unsigned sg_step = (unsigned)((512 / CPR / 16) * p.w) * (unsigned)(p.ldo >> 3);
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
                 if (ch * 8 < c_lim && pix_ok(px)) {
                     const uint4 u = *(const uint4*)(R0 + px * ERS + ch * 16);
-                    const unsigned ga = gaddr(px, nt * BN + ch * 8, p.ldo);
+                    const unsigned ga = lin ? ga0 + (unsigned)i * ga_step : gaddr(px, nt * BN + ch * 8, p.ldo);
                     *(uint4*)(outT + ga) = u;
                     if (p.sign_out) {          // (uniform) bit e = stored element e > 0: positive and non-zero as a 16-bit integer
                         const unsigned wv[4] = {u.x, u.y, u.z, u.w};
@@ -1224,8 +1243,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                             sb |= ((short)(wv[k] & 0xffffu) > 0 ? 1u : 0u) << (2 * k);
                             sb |= (((int)wv[k] >> 16) > 0 ? 1u : 0u) << (2 * k + 1);
                         }
-                        p.sign_out[((unsigned long long)img_pix + gpix(px)) * (unsigned)(p.ldo >> 3) + (unsigned)((nt * BN + ch * 8) >> 3)] =
-                            (unsigned char)sb;
+                        const unsigned long long sgi = lin ? sg0 + (unsigned long long)((unsigned)i * sg_step)
+                                                           : ((unsigned long long)img_pix + gpix(px)) * (unsigned)(p.ldo >> 3) + (unsigned)((nt * BN + ch * 8) >> 3);
+                        p.sign_out[sgi] = (unsigned char)sb;
                     }
                     // fp8 copy for the consumer (uniform branch; not compiled into the 128-wide bf16 kernel at two blocks per CU, which
                     // has no register to spare -- the launcher keeps producers off it): act(out) -> max -> * scale -> 8 bytes
