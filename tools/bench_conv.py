@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--f16", action="store_true", help="fp16 forward tensors (the mask decoder's format): forward in fp16, gradients bf16")
     ap.add_argument("--post", action="store_true", help="post-activation storage: the input holds act(x), the output is stored as act(y) "
                     "(layers with an activation only)")
+    ap.add_argument("--bits", action="store_true", help="input gradient with act' from the producer's sign bytes, as the step runs it "
+                    "(res_patch == 2 on the wide residual blocks)")
     ap.add_argument("--fp8", action="store_true", help="forward / input gradient of the eligible layers on the fp8 path (ops.Fp8)")
     ap.add_argument("--fp8-copy", action="store_true", help="with --fp8: the forward input arrives as the fp8 copy a producing layer "
                     "would have written (no conversion in the kernel, two blocks per CU)")
@@ -111,7 +113,12 @@ def main():
             tf = timeit(_fwd, args.iters)
         if fmt == lib.F16:
             gy = torch.randn(y.shape, device=dev).to(T)
-        td = timeit(lambda: ops.conv_dgrad(gy, x, lay, res=gy if res_self else None), args.iters)
+        xb = None
+        if args.bits and lay.in_post and x.shape[-1] % 8 == 0:
+            pos = (x.view(torch.int16) > 0).view(*x.shape[:-1], -1, 8).to(torch.uint8)
+            xb = (pos * (2 ** torch.arange(8, device=dev, dtype=torch.uint8))).sum(-1).to(torch.uint8).contiguous()
+            del pos
+        td = timeit(lambda: ops.conv_dgrad(gy, x, lay, res=gy if res_self else None, x_bits=xb), args.iters)
         wsrc = None
         if args.fp8 and args.fp8_wgrad and ops.Fp8.eligible_wgrad(lay, gy, x, None):
             gslot = ops.Fp8.slot(dev)

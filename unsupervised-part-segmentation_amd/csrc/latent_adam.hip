@@ -249,18 +249,25 @@ namespace {
 __global__ void state_update_kernel(const float* __restrict__ stats, const float* __restrict__ old, float* __restrict__ out,
                                     float decay, float gain, int up_loa, float loa_lr, float loa_target, int up_lor, float lor_lr,
                                     float lor_target, float lor_min, float lor_max) {
+    // every product and sum below is rounded on its own, as the torch expressions it replaces round them (the test holds it to them bit for
+    // bit).  __fmul_rn / __fadd_rn do NOT stop hipcc's contraction (their bodies are compiled under the header's fp-contract=fast: the build
+    // without packed fp32 forms fused decay * o + gain * val into v_fmac_f32, round 6); plain operators under this pragma are not fused.
+#pragma clang fp contract(off)
     const int i = threadIdx.x;
     if (i >= 9) return;
     const float mim = stats[0], ind = stats[1], acc0 = stats[2], acc1 = stats[3], l0 = stats[4], l1 = stats[5];
     const float o = old[i];
     float v;
     if (i < 7) {
-        const float val = i == 0 ? acc0 : i == 1 ? acc1 : i == 2 ? __fsub_rn(acc1, acc0) : i == 3 ? l0 : i == 4 ? l1 : i == 5 ? mim : ind;
-        v = __fadd_rn(__fmul_rn(decay, o), __fmul_rn(gain, val));
+        const float val = i == 0 ? acc0 : i == 1 ? acc1 : i == 2 ? acc1 - acc0 : i == 3 ? l0 : i == 4 ? l1 : i == 5 ? mim : ind;
+        const float a = decay * o, b = gain * val;
+        v = a + b;
     } else if (i == 7) {
-        v = up_loa ? fmaxf(__fadd_rn(o, __fmul_rn(loa_lr, __fsub_rn(mim, loa_target))), 0.f) : o;
+        const float d = loa_lr * (mim - loa_target);
+        v = up_loa ? fmaxf(o + d, 0.f) : o;
     } else {
-        v = up_lor ? fminf(fmaxf(__fadd_rn(o, __fmul_rn(lor_lr, __fsub_rn(ind, lor_target))), lor_min), lor_max) : o;
+        const float d = lor_lr * (ind - lor_target);
+        v = up_lor ? fminf(fmaxf(o + d, lor_min), lor_max) : o;
     }
     out[i] = v;
 }
