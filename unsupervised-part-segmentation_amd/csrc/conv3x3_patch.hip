@@ -826,6 +826,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const int n1 = it + 1;
             if (n1 < total) {
                 if constexpr (!DMAP) { if (n1 % 3 == 0) load_patch(n1 / 3); }
+#if defined(UPS_ABLATE_PATCHWAIT)     // (timing experiment of round 6, results garbage: the next chunk's patch requested a whole chunk ahead INTO THE
+                if constexpr (DMAP) { if (g == 0 && cc + 1 < kchunks) dma_patch(cc + 1); }      // BUFFER BEING READ, no re-staging barrier: what a second patch buffer would buy)
+#endif
                 dma_w(n1);
             }
             const unsigned char* A = Abuf;
@@ -847,9 +850,12 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx1)) << 4),
                                     a_lane16 + ((q16 ^ a_swz16(px_l16 + dx2)) << 4), BN * 64, acc16);
             }
+#if !defined(UPS_ABLATE_PATCHWAIT)
             if (n1 < total && n1 % 3 == 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !defined(UPS_ABLATE_BARRIER)
                 __builtin_amdgcn_s_barrier();                 // every wave has read the last tap of this chunk's patch
+#endif
                 if constexpr (DMAP) dma_patch(n1 / 3);
                 else {
 #if !defined(UPS_ABLATE_LSTORE)
@@ -857,9 +863,12 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
 #endif
                 }
             }
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !defined(UPS_ABLATE_BARRIER)          // (timing experiment of round 6 on THIS loop -- the dominant instances run it; results garbage)
             __builtin_amdgcn_s_barrier();
+#endif
         }
         } else if constexpr (CHUNKST) {
         for (int cc = 0; cc < kchunks; ++cc) {
