@@ -1080,6 +1080,23 @@ def test_mask_parts_unpool(dtype, dev):
     assert_close(gf, fo.grad.float(), tol, "unpool d feat")
 
 
+@pytest.mark.parametrize("B,S,P", [(3, 16, 10), (2, 24, 25), (1, 10, 16), (2, 32, 20), (1, 7, 3)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mask_parts_forward_over_tiles(B, S, P, dtype, dev):
+    """mask_parts forward (model.py:176-187 + the part-major transpose, nn.py:97-103) over whole, partial and unaligned 256-pixel tiles
+    at the part counts of the BASELINE configs and the shipped yamls: since round 6 the hard tile is staged through LDS (tile.h)."""
+    lib, ops, R = _mods()
+    g = torch.Generator().manual_seed(B * 100 + S + P)
+    view = torch.rand(B, S, S, 3, generator=g) * 2 - 1
+    hard = torch.nn.functional.one_hot(torch.randint(0, P, (B, S, S), generator=g), P).float()
+    hard[0, 0, 0] = torch.randn(P, generator=g)               # an arbitrary fp32 row
+    parts = (view.unsqueeze(3) * hard.unsqueeze(4)).permute(3, 0, 1, 2, 4).reshape(P * B, S, S, 3)
+    out = ops.MaskPartsFn.apply(view.to(dev), hard.to(dev), dtype)
+    assert out.shape == (P * B, S, S, 8)
+    assert_close(out[..., :3].float(), parts.to(dtype).float(), 1e-6 if dtype == torch.float32 else 1e-2, "mask_parts fwd")
+    assert float(out[..., 3:].float().abs().max()) == 0.0
+
+
 def test_latent(dev):
     lib, ops, R = _mods()
     from oracle import np_ops
@@ -1692,15 +1709,17 @@ def test_weight_copies_per_layer_and_batched_are_bit_identical(k, stride, ci, co
         assert torch.equal(t.view(torch.uint8), ent[n].view(torch.uint8)), n
 
 
-@pytest.mark.parametrize("B,S", [(3, 128), (1, 32), (2, 64)])
-def test_unpool_backward_on_the_matrix_cores(B, S, dev, monkeypatch):
-    """ups_unpool_bwd at the benchmark shape class (bf16 gradient, 64 features + 10 parts in 80-channel rows): the MFMA form of
-    round 5 against torch-fp64 and against the VALU form it replaces (UPS_UNPOOL_MFMA=0).  hard: one-hot rows (what the model
-    passes), a tie, and a block of arbitrary fp32 values (the hi + lo bf16 pair of the mask operand must keep them to ~1e-5)."""
+@pytest.mark.parametrize("B,S,P", [(3, 128, 10), (1, 32, 10), (2, 64, 10), (2, 64, 16), (1, 32, 16), (2, 64, 20), (3, 32, 20), (2, 64, 25),
+                                   (1, 32, 25), (1, 128, 25)])
+def test_unpool_backward_on_the_matrix_cores(B, S, P, dev, monkeypatch):
+    """ups_unpool_bwd at the benchmark shape classes (bf16 gradient, 64 features + P parts in round8(64 + P)-channel rows; P = 10 since
+    round 5, 16 / 20 / 25 -- BASELINE configs #3 / #5, the shipped yamls -- since round 6: two 16-part blocks, a partial last DMA piece at
+    P = 25): the MFMA form against torch-fp64 and against the VALU form it replaces (UPS_UNPOOL_MFMA=0).  hard: one-hot rows (what the
+    model passes), a tie, and a block of arbitrary fp32 values (the hi + lo bf16 pair of the mask operand must keep them to ~1e-5)."""
     lib, ops, R = _mods()
     L = lib
-    P, F, ld = 10, 64, 80
-    g = torch.Generator().manual_seed(5 + B + S)
+    F, ld = 64, (64 + P + 7) // 8 * 8
+    g = torch.Generator().manual_seed(5 + B + S + P)
     hard = torch.nn.functional.one_hot(torch.randint(0, P, (B, S, S), generator=g), P).float()
     hard[0, 0, 0] = torch.tensor([1.0, 1.0] + [0.0] * (P - 2))
     hard[0, 1, :8] = torch.randn(8, P, generator=g)

@@ -535,16 +535,28 @@ __global__ void draw_rect_kernel(const int* __restrict__ px, int n, int h, int w
 }
 
 // ------------------------------------------------------------------ mask_parts (model.py:176-187) + part-major transpose (nn.py:97-103)
+// block = 256 consecutive pixels (of the batch): the hard tile comes in with 16-byte coalesced loads (tile.h; a thread-per-pixel read of P
+// floats at a 4 P byte stride touched 20-50 cache lines per wave instruction, P times over: 0.38-0.44 of the HBM roof at P = 16 / 20 / 25
+// with rotating operands), then thread = pixel writes P 16-byte pieces, each coalesced along the pixels of one part image
 template <typename T>
-__global__ void mask_parts_fwd_kernel(const float* __restrict__ view, const float* __restrict__ hard, T* __restrict__ out,
-                                      int B, long long hw, int P) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)B * hw) return;
+__global__ __launch_bounds__(256) void mask_parts_fwd_kernel(const float* __restrict__ view, const float* __restrict__ hard, T* __restrict__ out,
+                                                             int B, long long hw, int P) {
+    extern __shared__ __attribute__((aligned(16))) float ts[];          // [256][PP]
+    const int PP = tile_pitch(P);
+    const long long total = (long long)B * hw;
+    const long long pix0 = (long long)blockIdx.x * 256;
+    const int cnt = (int)min(256ll, total - pix0);
+    const long long idx = pix0 + threadIdx.x;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if (threadIdx.x < cnt) { v0 = view[idx * 3]; v1 = view[idx * 3 + 1]; v2 = view[idx * 3 + 2]; }
+    tile_load_f32(hard + pix0 * P, cnt, P, PP, ts);
+    __syncthreads();
+    if (threadIdx.x >= cnt) return;
     const int b = (int)(idx / hw);
     const long long px = idx - (long long)b * hw;
-    const float v0 = view[idx * 3], v1 = view[idx * 3 + 1], v2 = view[idx * 3 + 2];
+    const float* hrow = ts + threadIdx.x * PP;
     for (int p = 0; p < P; ++p) {
-        const float hm = hard[idx * P + p];
+        const float hm = hrow[p];
         float f[8] = {v0 * hm, v1 * hm, v2 * hm, 0.f, 0.f, 0.f, 0.f, 0.f};
         T* o = out + (((long long)p * B + b) * hw + px) * 8;
         if (sizeof(T) == 2) *(uint4*)o = Chunk<bf16>::pack(f);
@@ -780,150 +792,179 @@ __global__ __launch_bounds__(256) void unpool_bwd_kernel(const float* __restrict
 // ~100 wave instructions per 128-pixel tile instead of ~460.  Tiles (gradient rows + hard rows) arrive LINEARLY by LDS-DMA, three
 // slots (two tiles in flight), g_hard leaves through an LDS tile with 16-byte stores; waits are counted (loads, stores and LDS-DMA
 // retire in issue order).  80 KB of LDS: two blocks per CU.
-constexpr int UB_TP = 128, UB_P = 10, UB_F = 64, UB_LD = 80;
-constexpr int UB_GT = UB_TP * UB_LD * 2;            // 20480 B gradient tile
-constexpr int UB_HT = UB_TP * UB_P * 4;             // 5120 B hard tile (and g_hard tile)
-constexpr int UB_SLOT = UB_GT + UB_HT;
-constexpr int UB_PIECES = UB_SLOT / 1024;           // 25 LDS-DMA pieces per tile: wave 0 takes 7, the others 6
-constexpr size_t UB_SHMEM = 3 * (size_t)UB_SLOT + UB_HT;
+// Round 6: templated on the part count (P = 10 / 16 / 20 / 25 in rows of LD = 80 / 80 / 88 / 96 channels -- the BASELINE configs and
+// every shipped yaml); more than 16 parts take two 16-part blocks in both products.
+constexpr int UB_TP = 128, UB_F = 64;
+template <int P, int LD> struct UB {
+    static constexpr int GT = UB_TP * LD * 2;               // gradient tile (bf16): 20 / 22 / 24 KiB
+    static constexpr int HT = UB_TP * P * 4;                // hard tile (and g_hard tile), fp32
+    static constexpr int SLOT = GT + HT;
+    static constexpr int GP = GT / 1024, HP = (HT + 1023) / 1024, PIECES = GP + HP;       // LDS-DMA pieces of 1 KiB (the last hard piece may be partial)
+    static constexpr int NPB = (P + 15) / 16;               // 16-part blocks
+    static constexpr int NOUT = HT / 16;                    // 16-byte pieces of the g_hard tile
+    static constexpr size_t SHMEM = 3 * (size_t)SLOT + HT;
+    static_assert(GT % 1024 == 0 && HT % 16 == 0 && P <= 32 && LD >= UB_F + P && LD % 8 == 0, "tile geometry");
+};
 
 __device__ __forceinline__ void ub_wait_vm(int young) {
+#define UPS_UB_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
     switch (young) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        UPS_UB_W(0) UPS_UB_W(1) UPS_UB_W(2) UPS_UB_W(3) UPS_UB_W(4) UPS_UB_W(5) UPS_UB_W(6) UPS_UB_W(7) UPS_UB_W(8) UPS_UB_W(9)
+        UPS_UB_W(10) UPS_UB_W(11) UPS_UB_W(12) UPS_UB_W(13) UPS_UB_W(14) UPS_UB_W(15) UPS_UB_W(16) UPS_UB_W(17) UPS_UB_W(18) UPS_UB_W(19)
+        UPS_UB_W(20) UPS_UB_W(21) UPS_UB_W(22) UPS_UB_W(23) UPS_UB_W(24)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
+#undef UPS_UB_W
 }
 
-__global__ __launch_bounds__(256, 2) void unpool_bwd_mfma_kernel(const float* __restrict__ hard, const float* __restrict__ feat,
+template <int P, int LD>
+__global__ __launch_bounds__(256, P <= 10 ? 2 : 1) void unpool_bwd_mfma_kernel(const float* __restrict__ hard, const float* __restrict__ feat,
                                                                   const bf16* __restrict__ g, float* __restrict__ gh,
                                                                   float* __restrict__ gfeat_partial, const long long hw,
                                                                   const int tiles_per_block, const int slabs_per_block, const int nslab) {
+    typedef UB<P, LD> U;
+    constexpr int NPB = U::NPB;
     typedef __attribute__((ext_vector_type(4))) short v4s;
     typedef __attribute__((address_space(3))) v4s lds_v4s;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* OS = smem + 3 * UB_SLOT;          // g_hard tile [128][10] fp32, linear
+    unsigned char* OS = smem + 3 * U::SLOT;          // g_hard tile [128][P] fp32, linear
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int b = blockIdx.x, sb = blockIdx.y;       // image, block of the image
     const long long px0 = (long long)sb * tiles_per_block * UB_TP;       // first pixel of this block
     const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
-    const unsigned char* gsrc = (const unsigned char*)(g + ((long long)b * hw + px0) * UB_LD);
-    const unsigned char* hsrc = (const unsigned char*)(hard + ((long long)b * hw + px0) * UB_P);
+    const unsigned char* gsrc = (const unsigned char*)(g + ((long long)b * hw + px0) * LD);
+    const unsigned char* hsrc = (const unsigned char*)(hard + ((long long)b * hw + px0) * P);
     const unsigned voff = (unsigned)lane * 16u;
-    const int L = wid == 0 ? 7 : 6, S = wid == 0 ? 2 : 1;                 // LDS-DMA pieces / stores per wave and tile
+    // LDS-DMA pieces / 16-byte stores this wave issues per tile (wave-instructions: what vmcnt counts)
+    constexpr int KQ = (U::PIECES + 3) / 4, KS = (U::NOUT + 255) / 256;
+    const int L = (U::PIECES - wid + 3) / 4, S = (U::NOUT - 64 * wid + 255) / 256;
     auto issue = [&](int t) __attribute__((always_inline)) {
-        const unsigned base = smem_lds + (unsigned)((t % 3) * UB_SLOT);
+        const unsigned base = smem_lds + (unsigned)((t % 3) * U::SLOT);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
+        for (int k = 0; k < KQ; ++k) {
             const int q = wid + 4 * k;
-            if (q < UB_PIECES) {
-                const unsigned char* src = q < UB_GT / 1024 ? gsrc + (long long)t * UB_GT + q * 1024
-                                                            : hsrc + (long long)t * UB_HT + (q - UB_GT / 1024) * 1024;
+            if (q < U::PIECES) {
+                const unsigned char* src = q < U::GP ? gsrc + (long long)t * U::GT + q * 1024
+                                                     : hsrc + (long long)t * U::HT + (q - U::GP) * 1024;
                 const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)q * 1024u);
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
+                // (the last piece of a hard tile whose size is not a multiple of 1 KiB -- P = 25: 12.5 KiB -- moves its first lanes only)
+                const bool part = (U::HT & 1023) != 0 && q == U::PIECES - 1;
+                if (!part || voff < (unsigned)(U::HT & 1023))
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
             }
         }
     };
     issue(0);
     if (1 < tiles_per_block) issue(1);
-    // B operand of the first product: feat[b][part li][features 8 lg .. + 7] and [32 + 8 lg .. + 7] as bf16 (exact: in bf16 mode feat is
-    // the float view of a bf16 tensor)
-    bf16x8 fb[2];
-    {
-        const float* fr = feat + ((long long)b * UB_P + min(li, UB_P - 1)) * UB_F;
+    // B operand of the first product: feat[b][part 16 nb + li][features 8 lg .. + 7] and [32 + 8 lg .. + 7] as bf16 (exact: in bf16 mode
+    // feat is the float view of a bf16 tensor)
+    bf16x8 fb[NPB][2];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+        const int pi = 16 * pb + li;
+        const float* fr = feat + ((long long)b * P + min(pi, P - 1)) * UB_F;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fb[h][e] = (__bf16)(li < UB_P ? fr[32 * h + 8 * lg + e] : 0.f);
+            for (int e = 0; e < 8; ++e) fb[pb][h][e] = (__bf16)(pi < P ? fr[32 * h + 8 * lg + e] : 0.f);
     }
-    f32x4 acc[4];                                     // g_feat: parts 4 lg + i x features 16 nb + li, this wave's pixels
+    f32x4 acc[NPB][4];                                // g_feat: parts 16 pb + 4 lg + i x features 16 nb + li, this wave's pixels
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[pb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int t = 0; t < tiles_per_block; ++t) {
         // younger than tile t's pieces: the stores of up to two tiles and tile t + 1's pieces
         ub_wait_vm(min(t, 2) * S + (t + 1 < tiles_per_block ? L : 0));
         __builtin_amdgcn_s_barrier();                 // tile t is in; everyone is done with tile t - 1 (its slot, the g_hard tile)
         if (t + 2 < tiles_per_block) issue(t + 2);
-        const unsigned char* G = smem + (t % 3) * UB_SLOT;
-        const unsigned char* H = G + UB_GT;
+        const unsigned char* G = smem + (t % 3) * U::SLOT;
+        const unsigned char* H = G + U::GT;
         const int R0 = wid * 32;                      // this wave's 32 pixels of the tile
         // ---- g_hard: two 16-pixel blocks, K = 64 features in two steps
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const int row = R0 + 16 * mb + li;
-            const bf16x8 a0 = *(const bf16x8*)(G + row * (UB_LD * 2) + 16 * lg);
-            const bf16x8 a1 = *(const bf16x8*)(G + row * (UB_LD * 2) + 64 + 16 * lg);
-            f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, fb[0], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, fb[1], d, 0, 0, 0);
-            // lane: pixels R0 + 16 mb + 4 lg + i, part li; + the gradient's own part channel
-            if (li < UB_P) {
+            const bf16x8 a0 = *(const bf16x8*)(G + row * (LD * 2) + 16 * lg);
+            const bf16x8 a1 = *(const bf16x8*)(G + row * (LD * 2) + 64 + 16 * lg);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = R0 + 16 * mb + 4 * lg + i;
-                    const unsigned short u = *(const unsigned short*)(G + r * (UB_LD * 2) + 2 * (UB_F + li));
-                    *(float*)(OS + r * (UB_P * 4) + 4 * li) = d[i] + __uint_as_float((unsigned)u << 16);
+            for (int pb = 0; pb < NPB; ++pb) {
+                f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, fb[pb][0], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, fb[pb][1], d, 0, 0, 0);
+                // lane: pixels R0 + 16 mb + 4 lg + i, part 16 pb + li; + the gradient's own part channel
+                const int pi = 16 * pb + li;
+                if (pi < P) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = R0 + 16 * mb + 4 * lg + i;
+                        const unsigned short u = *(const unsigned short*)(G + r * (LD * 2) + 2 * (UB_F + pi));
+                        *(float*)(OS + r * (P * 4) + 4 * pi) = d[i] + __uint_as_float((unsigned)u << 16);
+                    }
                 }
             }
         }
         // ---- g_feat: K = this wave's 32 pixels; k-index j of lane group lg <-> rows R0 + 4 lg + j (j < 4), R0 + 16 + 4 lg + j - 4
         // (two 4-row blocks per 16-lane group that a 32-lane half reads from eight DIFFERENT rows: conflict-free at 160-byte rows)
-        bf16x8 ah, al;
+        bf16x8 ah[NPB], al[NPB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = R0 + (j < 4 ? 4 * lg + j : 16 + 4 * lg + j - 4);
-            const float v = *(const float*)(H + r * (UB_P * 4) + 4 * li);          // (li >= P: the next pixel's values, dropped)
-            const float hv = li < UB_P ? v : 0.f;
-            const __bf16 hi = (__bf16)hv;
-            ah[j] = hi;
-            al[j] = (__bf16)(hv - (float)hi);
+        for (int pb = 0; pb < NPB; ++pb) {
+            const int pi = 16 * pb + li;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = R0 + (j < 4 ? 4 * lg + j : 16 + 4 * lg + j - 4);
+                const float v = *(const float*)(H + r * (P * 4) + 4 * min(pi, P - 1));
+                const float hv = pi < P ? v : 0.f;
+                const __bf16 hi = (__bf16)hv;
+                ah[pb][j] = hi;
+                al[pb][j] = (__bf16)(hv - (float)hi);
+            }
         }
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             // lane 4 q + p of a group supplies row q, columns 4 p .. 4 p + 3 of the 4 x 16 block (guide T10); EXEC is all ones here
             const int q = li >> 2, pp = li & 3;
-            const v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(G + (R0 + 4 * lg + q) * (UB_LD * 2) + 2 * (16 * nb + 4 * pp)));
-            const v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(G + (R0 + 16 + 4 * lg + q) * (UB_LD * 2) + 2 * (16 * nb + 4 * pp)));
+            const v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(G + (R0 + 4 * lg + q) * (LD * 2) + 2 * (16 * nb + 4 * pp)));
+            const v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(G + (R0 + 16 + 4 * lg + q) * (LD * 2) + 2 * (16 * nb + 4 * pp)));
             bf16x8 bb;
             __builtin_memcpy(&bb, &b0, 8);
             __builtin_memcpy((char*)&bb + 8, &b1, 8);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bb, acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bb, acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+                acc[pb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[pb], bb, acc[pb][nb], 0, 0, 0);
+                acc[pb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[pb], bb, acc[pb][nb], 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // the g_hard tile is complete
         {
-            float4* dst = (float4*)(gh + ((long long)b * hw + px0 + (long long)t * UB_TP) * UB_P);
+            float4* dst = (float4*)(gh + ((long long)b * hw + px0 + (long long)t * UB_TP) * P);
             const float4* o4 = (const float4*)OS;
-            dst[tid] = o4[tid];                                        // 320 16-byte pieces: one per thread + one more for wave 0
-            if (wid == 0) dst[256 + tid] = o4[256 + tid];
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+                if (256 * k + tid < U::NOUT) dst[256 * k + tid] = o4[256 * k + tid];
         }
     }
     // ---- the four waves' g_feat blocks -> one record of the block's slab group (the other records of the group: zero)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    float* red = (float*)smem;                        // [4 waves][16 parts][64 features]
+    float* red = (float*)smem;                        // [4 waves][16 NPB parts][64 features]
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[(wid * 16 + 4 * lg + i) * 64 + 16 * nb + li] = acc[nb][i];
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(wid * 16 * NPB + 16 * pb + 4 * lg + i) * 64 + 16 * nb + li] = acc[pb][nb][i];
     __syncthreads();
-    float* out = gfeat_partial + (((long long)b * nslab + (long long)sb * slabs_per_block) * UB_P) * UB_F;
-    for (int i = tid; i < slabs_per_block * UB_P * UB_F; i += 256) {
+    float* out = gfeat_partial + (((long long)b * nslab + (long long)sb * slabs_per_block) * P) * UB_F;
+    for (int i = tid; i < slabs_per_block * P * UB_F; i += 256) {
         float v = 0.f;
-        if (i < UB_P * UB_F) {
+        if (i < P * UB_F) {
             const int pp = i >> 6, ff = i & 63;
-            v = (red[pp * 64 + ff] + red[(16 + pp) * 64 + ff]) + (red[(32 + pp) * 64 + ff] + red[(48 + pp) * 64 + ff]);
+            v = (red[pp * 64 + ff] + red[(16 * NPB + pp) * 64 + ff]) + (red[(32 * NPB + pp) * 64 + ff] + red[(48 * NPB + pp) * 64 + ff]);
         }
         out[i] = v;
     }
@@ -1124,10 +1165,13 @@ extern "C" int ups_draw_rect(const int32_t* px, int32_t n, int32_t h, int32_t w,
 
 extern "C" int ups_mask_parts_fwd(const float* view, const float* hard, void* out, int32_t dtype, int32_t B, int64_t hw,
                                   int32_t P, void* stream) {
-    UPS_CHECK_ARG(view && hard && out);
+    UPS_CHECK_ARG(view && hard && out && P >= 1 && P <= 64);
     const int grid = ups_cdiv((long long)B * hw, 256);
-    if (dtype == UPS_F32) hipLaunchKernelGGL(mask_parts_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, view, hard, (float*)out, B, (long long)hw, P);
-    else hipLaunchKernelGGL(mask_parts_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, view, hard, (bf16*)out, B, (long long)hw, P);
+    const size_t shm = (size_t)256 * (P | 1) * sizeof(float);
+    static UpsPerDevice a0, a1;
+    if (!allow_big_lds(mask_parts_fwd_kernel<float>, a0) || !allow_big_lds(mask_parts_fwd_kernel<bf16>, a1)) return UPS_E_LAUNCH;
+    if (dtype == UPS_F32) hipLaunchKernelGGL(mask_parts_fwd_kernel<float>, dim3(grid), dim3(256), shm, (hipStream_t)stream, view, hard, (float*)out, B, (long long)hw, P);
+    else hipLaunchKernelGGL(mask_parts_fwd_kernel<bf16>, dim3(grid), dim3(256), shm, (hipStream_t)stream, view, hard, (bf16*)out, B, (long long)hw, P);
     UPS_LAUNCH_CHECK();
     return UPS_OK;
 }
@@ -1165,24 +1209,32 @@ extern "C" int ups_unpool_bwd(const float* hard, const float* feat, const void* 
     hipStream_t s = (hipStream_t)stream;
     float* partial = g_feat + (long long)B * P * F;
     const size_t esz = dtype == UPS_F32 ? 4 : 2;
-    {   // matrix-core form (round 5): bf16 gradient, 64 features + 10 parts in 80-channel rows, whole 128-pixel tiles
+    {   // matrix-core form (round 5; round 6: P = 16 / 20 / 25 too): bf16 gradient, 64 features + P parts in round8(64 + P)-channel rows,
+        // whole 128-pixel tiles
         const char* e = getenv("UPS_UNPOOL_MFMA");          // (read at every call: the unit test compares both forms)
         const bool mf_on = !(e && e[0] == '0');
         const bool al16 = ((((uintptr_t)hard) | ((uintptr_t)g) | ((uintptr_t)g_hard)) & 15) == 0;
-        if (mf_on && dtype == UPS_BF16 && P == UB_P && F == UB_F && ldo == UB_LD && hw % UB_TP == 0 && al16) {
+        const bool shape = (P == 10 && ldo == 80) || (P == 16 && ldo == 80) || (P == 20 && ldo == 88) || (P == 25 && ldo == 96);
+        if (mf_on && dtype == UPS_BF16 && shape && F == UB_F && hw % UB_TP == 0 && al16) {
             const int tiles_img = (int)(hw / UB_TP);
             // blocks per image: two per CU over the batch, a power of two dividing the tiles and the slab records
             int bpi = 1;
             while (2 * bpi <= UNPOOL_SLABS && (long long)B * bpi < 512 && tiles_img % (2 * bpi) == 0) bpi *= 2;
-            static UpsPerDevice am;
-            if (!am) {
-                if (hipFuncSetAttribute((const void*)unpool_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)UB_SHMEM) != hipSuccess)
-                    return UPS_E_LAUNCH;
-                am = true;
-            }
             // (one record per block, `bpi` records per image: the reduction walks 8 records instead of UNPOOL_SLABS = 32)
-            hipLaunchKernelGGL(unpool_bwd_mfma_kernel, dim3(B, bpi), dim3(256), UB_SHMEM, s, hard, feat, (const bf16*)g, g_hard, partial,
-                               (long long)hw, tiles_img / bpi, 1, bpi);
+#define UPS_UB_LAUNCH(PV, LDV) do { \
+                static UpsPerDevice am; \
+                if (!am) { \
+                    if (hipFuncSetAttribute((const void*)unpool_bwd_mfma_kernel<PV, LDV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)UB<PV, LDV>::SHMEM) != hipSuccess) return UPS_E_LAUNCH; \
+                    am = true; \
+                } \
+                hipLaunchKernelGGL((unpool_bwd_mfma_kernel<PV, LDV>), dim3(B, bpi), dim3(256), (UB<PV, LDV>::SHMEM), s, hard, feat, (const bf16*)g, \
+                                   g_hard, partial, (long long)hw, tiles_img / bpi, 1, bpi); } while (0)
+            if (P == 10) UPS_UB_LAUNCH(10, 80);
+            else if (P == 16) UPS_UB_LAUNCH(16, 80);
+            else if (P == 20) UPS_UB_LAUNCH(20, 88);
+            else UPS_UB_LAUNCH(25, 96);
+#undef UPS_UB_LAUNCH
             UPS_LAUNCH_CHECK();
             const int total = B * P * F;
             hipLaunchKernelGGL(unpool_feat_reduce_kernel, dim3(ups_cdiv(total, 256)), dim3(256), 0, s, partial, B, bpi, P * F, g_feat);
