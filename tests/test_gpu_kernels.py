@@ -749,7 +749,9 @@ PRIOR_CASES = [(0, 10, 32, "entropy"), (0, 25, 32, "cross_entropy"), (0, 10, 20,
                (0, 10, 128, "entropy"), (1, 10, 128, "cross_entropy"), (0, 10, 256, "cross_entropy"),
                # the direct-from-global forms of round 6 (P = 16 / 20 / 25 at 128- / 256-wide images)
                (0, 16, 128, "entropy"), (1, 20, 128, "cross_entropy"), (0, 25, 128, "cross_entropy"),
-               (0, 20, 256, "entropy"), (1, 16, 256, "cross_entropy")]
+               (0, 20, 256, "entropy"), (1, 16, 256, "cross_entropy"),
+               # (round 6, late: those shapes run chunk-per-lane -- five chunks of five parts per pixel at P = 25, twelve pixels per wave)
+               (1, 25, 128, "entropy"), (0, 25, 256, "entropy")]
 # px_bpi (UPS_PRIOR_PX_BPI: blocks per image of the pixel-per-lane kernels) only exists for the shapes those kernels take: the
 # multi-tile variants are generated for exactly those cases (until round 6 they were generated for every case and skipped)
 PRIOR_PARAMS = [c + (0,) for c in PRIOR_CASES] + [c + (b,) for c in PRIOR_CASES if c[1] == 10 and c[2] in (128, 256) for b in (4, 1)]

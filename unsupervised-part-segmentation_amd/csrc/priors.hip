@@ -411,42 +411,64 @@ __global__ __launch_bounds__(256) void prior_finalize_img_kernel(const PriorK p)
 // Finalize of the pixel-per-lane forward: a block of prior_fwd_px_kernel leaves ONE record per slab group, so an image has only
 // `bpi` non-zero records and the whole reduction -- per_np[n][P][8], the four pixel sums and the four sums of squares over (n, part) --
 // is a few thousand floats: one block, one launch (the two-stage pair of the slab kernel costs 10 us behind a 38 us forward).
-__global__ __launch_bounds__(256) void prior_finalize_px_kernel(const PriorK p, const int bpi, const int spb) {
-    // (one block, latency-bound: 16-byte loads that do not depend on each other, ONE exchange through LDS for the eight sums)
+// (round 6, late: 1 024 threads = four record groups x 256 (image, part) items: a wave reads 64 CONSECUTIVE 16-byte pieces of one
+// record row -- eight cache lines per instruction -- with a group's eight loads independent of each other, and the four groups meet in
+// LDS.  One thread per item walking 32 records in a chain kept 16 KB in flight: 53 us behind a 95 us forward at P = 25, B = 64; four
+// adjacent lanes per item touched 64 lines per instruction: 27 us)
+__global__ __launch_bounds__(1024) void prior_finalize_px_kernel(const PriorK p, const int bpi, const int spb) {
+    constexpr int RS = 4;
+    __shared__ float4 part[RS][256];
     __shared__ float red[4][8];
     const float4* gpart = (const float4*)p.ws;
     const float4* npart = (const float4*)(p.ws + (long long)p.n * NSLAB * 4);
+    const int tid = threadIdx.x, rs = tid >> 8, ti = tid & 255;
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int n = threadIdx.x; n < p.n; n += 256)
-        for (int b = 0; b < bpi; ++b) {
-            const float4 g = gpart[(long long)n * NSLAB + (long long)b * spb];
-            a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
-        }
     const int items = p.n * p.P;
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int n = it / p.P, c = it - n * p.P;
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-        for (int b = 0; b < bpi; ++b) {
-            const float4 q = npart[((long long)n * NSLAB + (long long)b * spb) * p.P + c];
-            o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+    // pass 0: the four pixel sums (items = images, one piece per record); pass 1: the per-part sums (items = (image, part))
+    for (int pass = 0; pass < 2; ++pass) {
+        const int cnt = pass == 0 ? p.n : items;
+        for (int i0 = 0; i0 < cnt; i0 += 256) {
+            const int it = i0 + ti;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < cnt) {
+                const int n = pass == 0 ? it : it / p.P, c = pass == 0 ? 0 : it - n * p.P;
+                const float4* src = pass == 0 ? gpart + (long long)n * NSLAB : npart + (long long)n * NSLAB * p.P + c;
+                const long long step = pass == 0 ? (long long)spb : (long long)spb * p.P;
+#pragma unroll 8
+                for (int b = rs; b < bpi; b += RS) {
+                    const float4 q = src[b * step];
+                    o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+                }
+            }
+            __syncthreads();                       // (the previous chunk's partials have been read)
+            part[rs][ti] = o;
+            __syncthreads();
+            if (rs == 0 && it < cnt) {
+                const float4 q1 = part[1][ti], q2 = part[2][ti], q3 = part[3][ti];
+                o.x = (o.x + q1.x) + (q2.x + q3.x); o.y = (o.y + q1.y) + (q2.y + q3.y);
+                o.z = (o.z + q1.z) + (q2.z + q3.z); o.w = (o.w + q1.w) + (q2.w + q3.w);
+                if (pass == 0) { a[0] += o.x; a[1] += o.y; a[2] += o.z; a[3] += o.w; }
+                else {
+                    float4* d = (float4*)(p.per_np + (long long)it * 8);
+                    d[0] = o; d[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    a[4] += o.y * o.y; a[5] += o.x * o.x; a[6] += o.z * o.z; a[7] += o.w * o.w;
+                }
+            }
         }
-        float4* d = (float4*)(p.per_np + (long long)it * 8);
-        d[0] = o; d[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        a[4] += o.y * o.y; a[5] += o.x * o.x; a[6] += o.z * o.z; a[7] += o.w * o.w;
     }
+    if (rs == 0) {          // (waves 0 .. 3 hold the sums)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float v = a[k];
+        for (int k = 0; k < 8; ++k) {
+            float v = a[k];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        a[k] = v;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            a[k] = v;
+        }
+        if ((tid & 63) == 0)
+            for (int k = 0; k < 8; ++k) red[tid >> 6][k] = a[k];
     }
-    if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 8; ++k) red[threadIdx.x >> 6][k] = a[k];
     __syncthreads();
-    if (threadIdx.x < 16)
-        p.sums[threadIdx.x] = threadIdx.x < 8 ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.f;
+    if (tid < 16) p.sums[tid] = tid < 8 ? (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]) : 0.f;
 }
 
 __global__ __launch_bounds__(256) void prior_finalize_kernel(const PriorK p) {
@@ -1046,15 +1068,16 @@ __global__ __launch_bounds__(256, 1) void prior_bwd0_px_kernel(const PriorK p, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Round 6: the view-0 passes for the part counts the pixel-per-lane RINGS cannot hold (P = 16 / 20 / 25: BASELINE configs #3 / #5 and
+// Round 6: the prior passes for the part counts the pixel-per-lane RINGS cannot hold (P = 16 / 20 / 25: BASELINE configs #3 / #5 and
 // every shipped yaml).  A tile-row of the four maps is 16-25 KB per map at 256 columns; seven slot pairs of them do not fit 160 KB of
 // LDS, and the staged kernels above pay for that with a two-row halo around a one-row tile (3x the reads of m and l_mean, one HBM
 // round trip per block: prior_bwd at 256x256, P = 20 ran at 0.06 of the HBM roof, 1.27 ms of config #5's step --
-// profiles/round6_hbm_kernels.txt).  These forms keep NOTHING in LDS: one thread owns one pixel and takes every row it needs straight
-// from global memory with the widest aligned loads P allows (the neighbours' rows are the neighbouring lanes' / the next tile's own
-// rows: served by L1 / the XCD's L2, blocks of one image run on one XCD in row order), the stencil terms are evaluated in chunks of
-// four (five) parts so that the six neighbour rows never sit in registers at once.  Every wait is the compiler's own: no inline-asm
-// loads, no counted waits -- correct by construction; what it gives up against the DMA rings is the last third of the bandwidth.
+// profiles/round6_hbm_kernels.txt).  These forms keep NOTHING in LDS: every row comes straight from global memory (the neighbours' rows
+// are the neighbouring lanes' / the next rows' own loads: served by L1 / the XCD's L2, blocks of one image run on one XCD in row order),
+// every wait is the compiler's own: no inline-asm loads, no counted waits -- correct by construction.  The first form of the round
+// (one thread per pixel, rows in chunks of four or five parts) reached 0.24-0.58 of the roof: 4-6 rows of P floats per thread are
+// 224-350 registers -- one or two waves per SIMD -- and a 16-byte load per lane at a 4 P byte stride touches 20-50 cache lines per wave
+// instruction.  It is replaced by the chunk-per-lane form below.
 template <int P> struct PChunk { static constexpr int N = (P % 4 == 0) ? 4 : ((P % 5 == 0) ? 5 : (P % 2 == 0 ? 2 : 1)); };
 template <int N>
 __device__ __forceinline__ void ldg_chunk(const float* __restrict__ src, float (&dst)[N]) {
@@ -1074,28 +1097,38 @@ __device__ __forceinline__ void stg_chunk(float* __restrict__ dst, const float (
         for (int e = 0; e < N; ++e) dst[e] = v[e];
     }
 }
-template <int P>
-__device__ __forceinline__ void ldg_row(const float* __restrict__ src, float (&dst)[P]) {
-    constexpr int CH = PChunk<P>::N;
+// ---------------------------------------------------------------------------------------------------------------------------
+// Chunk-per-lane forms (round 6, late).  A lane owns ONE chunk of CH parts of one pixel (P / CH lanes per pixel, 12 or 16 pixels per wave): every wave
+// load is 1 KiB of consecutive bytes, a lane's state is a handful of CH-wide arrays, and the per-pixel sums over the parts (soft-max
+// normaliser, the two Jacobian dot products) are NCH-term shuffle sums taken in the same order by every lane of the pixel.
+template <int P> struct Cpl {
+    static constexpr int CH = PChunk<P>::N, NCH = P / CH;       // 4 x 4 (P = 16), 5 x 4 (P = 20), 5 x 5 (P = 25)
+    static constexpr int PXW = 64 / NCH, PXB = 4 * PXW;          // pixels per wave / block: 16 / 64, 12 / 48
+    static_assert(CH * NCH == P && CH >= 4, "chunks");
+};
+template <int NCH> __device__ __forceinline__ float cpl_sum(float v, int gb) {
+    float s = __shfl(v, gb, 64);
 #pragma unroll
-    for (int c = 0; c < P; c += CH) {
-        float t[CH];
-        ldg_chunk<CH>(src + c, t);
+    for (int k = 1; k < NCH; ++k) s += __shfl(v, gb + k, 64);
+    return s;
+}
+template <int NCH> __device__ __forceinline__ float cpl_max(float v, int gb) {
+    float s = __shfl(v, gb, 64);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) dst[c + e] = t[e];
-    }
+    for (int k = 1; k < NCH; ++k) s = fmaxf(s, __shfl(v, gb + k, 64));
+    return s;
 }
 
-// The view-1 backward (KL + variance terms through the soft-max Jacobian; m and g_hard in, dl and dl_rec out: no stencil at all) for
-// the same part counts: every thread streams its pixel's two rows in and its two result rows out.
+// The view-1 backward chunk-per-lane (no stencil: the two Jacobian dot products are the only cross-lane terms).
 template <int P, int LW, int VAR>
-__global__ __launch_bounds__(256) void prior_bwd1_direct_kernel(const PriorK p) {
-    constexpr int W = 1 << LW, CH = PChunk<P>::N;
+__global__ __launch_bounds__(256) void prior_bwd1_cpl_kernel(const PriorK p, const int bpi) {
+    typedef Cpl<P> C;
+    constexpr int W = 1 << LW, CH = C::CH, NCH = C::NCH;
     __shared__ float cst[P][10];       // rcy, rcx, kmax, wv, muy2, mux2, ca, cb, cc, s11
-    const int tid = threadIdx.x;
-    const int hw = p.h * W, tiles_img = hw >> 8;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int hw = p.h * W;
     const int lb = xcd_logical_block();
-    const int n = lb / tiles_img, t = lb - n * tiles_img;
+    const int n = lb / bpi, bi = lb - n * bpi;
     const float inv_pix = 1.f / (float)((long long)p.n * hw), inv_n = 1.f / (float)p.n;
     if (tid < P) {
         const float* np = p.per_np + ((long long)n * P + tid) * 8;
@@ -1119,20 +1152,25 @@ __global__ __launch_bounds__(256) void prior_bwd1_direct_kernel(const PriorK p) 
     __syncthreads();
     const float sy = p.h > 1 ? 2.f / (float)(p.h - 1) : 0.f, sx = W > 1 ? 2.f / (float)(W - 1) : 0.f;
     const float wkl = p.w_kl * inv_pix;
-    const int q = (t << 8) + tid;
+    const int pl_raw = lane / NCH, ci = lane - pl_raw * NCH;
+    const int pl = min(pl_raw, C::PXW - 1), gb = pl * NCH;
+    const int q_raw = bi * C::PXB + wid * C::PXW + pl;
+    const bool act = pl_raw < C::PXW && q_raw < hw;
+    const int q = min(q_raw, hw - 1);
+    const int c0 = ci * CH;
     const int yy = q >> LW, xx = q & (W - 1);
     const float gy = -1.f + sy * (float)yy, gx = -1.f + sx * (float)xx;
     const float gq = gy * gy + gx * gx;
-    const long long o0 = ((long long)n * hw + q) * P;
-    float m[P], gh[P], gmv[P];
-    ldg_row<P>(p.m + o0, m); ldg_row<P>(p.g_hard + o0, gh);
+    const long long o0 = ((long long)n * hw + q) * P + c0;
+    float m[CH], gh[CH], gmv[CH];
+    ldg_chunk<CH>(p.m + o0, m); ldg_chunk<CH>(p.g_hard + o0, gh);
     float dot = 0.f, dot_r = 0.f;
 #pragma unroll
-    for (int c = 0; c < P; ++c) {
-        const float* k = cst[c];
-        const float mc = m[c];
+    for (int e = 0; e < CH; ++e) {
+        const float* k = cst[c0 + e];
+        const float mc = m[e];
         const float pm = (float)P * mc;
-        float g = wkl * (ups_log_fast(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[c];
+        float g = wkl * (ups_log_fast(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[e];
         const float sq = __expf(p.gamma * mc - k[2]);
         if (VAR == 1) {
             const float ay = gy * gy - k[4] * gy - k[6];
@@ -1143,27 +1181,26 @@ __global__ __launch_bounds__(256) void prior_bwd1_direct_kernel(const PriorK p) 
             const float a = gq - k[4] * gy - k[5] * gx;
             g += k[3] * sq * (a * kk - k[6]);
         }
-        gmv[c] = g;
-        dot += mc * g; dot_r += mc * gh[c];
+        gmv[e] = g;
+        dot += mc * g; dot_r += mc * gh[e];
     }
+    dot = cpl_sum<NCH>(dot, gb); dot_r = cpl_sum<NCH>(dot_r, gb);
+    float a[CH], b[CH];
 #pragma unroll
-    for (int c0 = 0; c0 < P; c0 += CH) {
-        float a[CH], b[CH];
-#pragma unroll
-        for (int e = 0; e < CH; ++e) { a[e] = m[c0 + e] * (gmv[c0 + e] - dot); b[e] = m[c0 + e] * (gh[c0 + e] - dot_r); }
-        stg_chunk<CH>(p.dl + o0 + c0, a);
-        stg_chunk<CH>(p.dl_rec + o0 + c0, b);
-    }
+    for (int e = 0; e < CH; ++e) { a[e] = m[e] * (gmv[e] - dot); b[e] = m[e] * (gh[e] - dot_r); }
+    if (act) { stg_chunk<CH>(p.dl + o0, a); stg_chunk<CH>(p.dl_rec + o0, b); }
 }
 
-// The view-0 forward sums in the same form: a block walks `tiles_per_block` consecutive tiles of 256 pixels of one image, carries the
-// four pixel sums and the per-part sums (S, R, Rsmooth, Rcontour) in registers and writes ONE slab record (the workspace layout and the
-// finalize kernel of the pixel-per-lane form: blocks per image = NSLAB records, one each).
+// The view-0 forward sums chunk-per-lane: a block walks its pixel range 4 x PXW pixels at a time; a lane keeps the four per-part sums of
+// ITS chunk's parts (the chunk index of a lane never changes) and its share of the four pixel sums; one slab record per block, as the
+// per-pixel form writes it.
 template <int P, int LW, int VAR>
-__global__ __launch_bounds__(256) void prior_fwd_direct_kernel(const PriorK p, const int tiles_per_block, const int bpi, const int spb) {
-    constexpr int W = 1 << LW, CH = PChunk<P>::N;
+__global__ __launch_bounds__(256) void prior_fwd_cpl_kernel(const PriorK p, const int tiles_per_block, const int bpi, const int spb) {
+    typedef Cpl<P> C;
+    constexpr int W = 1 << LW, CH = C::CH, NCH = C::NCH;
     __shared__ float cst[P][2];
-    __shared__ float red[4][4 + 4 * P];
+    __shared__ float part[4][64][4 * CH];
+    __shared__ float red[4][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hw = p.h * W;
     const int lb = xcd_logical_block();
@@ -1173,83 +1210,106 @@ __global__ __launch_bounds__(256) void prior_fwd_direct_kernel(const PriorK p, c
         cst[tid][1] = (VAR == 0 && p.px) ? (float)p.px[((long long)n * P + tid) * 2 + 1] : 0.f;
     }
     __syncthreads();
+    const int pl_raw = lane / NCH, ci = lane - pl_raw * NCH;
+    const int pl = min(pl_raw, C::PXW - 1), gb = pl * NCH;
+    const int c0 = ci * CH;
+    int cy[CH], cx[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { cy[e] = (int)cst[c0 + e][0]; cx[e] = (int)cst[c0 + e][1]; }
     const long long img = (long long)n * hw;
+    const int start = bi * tiles_per_block * 256, end = start + tiles_per_block * 256;
     float kl = 0.f, ent = 0.f, patch = 0.f, gmrf = 0.f;
-    float S[P], R[P], Rs[P], Rc[P];
+    float S[CH], R[CH], Rs[CH], Rc[CH];
 #pragma unroll
-    for (int c = 0; c < P; ++c) S[c] = R[c] = Rs[c] = Rc[c] = 0.f;
-    for (int t = bi * tiles_per_block; t < (bi + 1) * tiles_per_block; ++t) {
-        const int q = (t << 8) + tid;
-        const int yy = q >> LW, xx = q & (W - 1);
-        const bool vr = xx + 1 < W, vd = yy + 1 < p.h;
-        const long long o0 = (img + q) * P, oR = (img + (vr ? q + 1 : q)) * P, oD = (img + (vd ? q + W : q)) * P;
-        float l[P];
-        ldg_row<P>(p.l + o0, l);
-        float mx = l[0];
+    for (int e = 0; e < CH; ++e) S[e] = R[e] = Rs[e] = Rc[e] = 0.f;
+    // two steps per trip: the second step's eight chunks are requested before the first step's arithmetic (and the next trip's first
+    // step before the second's), so that a round trip to HBM is always in flight under the shuffle / accumulate chains
+    struct Px { float l[CH], m[CH], lm[CH], hv[CH], mr[CH], lr[CH], md[CH], ld[CH]; int yy, xx; bool act; };
+    auto fetch = [&](int base, Px& r) __attribute__((always_inline)) {
+        const int q_raw = base + wid * C::PXW + pl;
+        r.act = pl_raw < C::PXW && q_raw < end;
+        const int q = min(q_raw, end - 1);
+        r.yy = q >> LW; r.xx = q & (W - 1);
+        const bool vr = r.xx + 1 < W, vd = r.yy + 1 < p.h;
+        const long long o0 = (img + q) * P + c0, oR = (img + (vr ? q + 1 : q)) * P + c0, oD = (img + (vd ? q + W : q)) * P + c0;
+        ldg_chunk<CH>(p.l + o0, r.l); ldg_chunk<CH>(p.m + o0, r.m); ldg_chunk<CH>(p.l_mean + o0, r.lm); ldg_chunk<CH>(p.hard + o0, r.hv);
+        ldg_chunk<CH>(p.m + oR, r.mr); ldg_chunk<CH>(p.l_mean + oR, r.lr);
+        ldg_chunk<CH>(p.m + oD, r.md); ldg_chunk<CH>(p.l_mean + oD, r.ld);
+    };
+    auto step = [&](const Px& r) __attribute__((always_inline)) {
+        const bool vr = r.xx + 1 < W, vd = r.yy + 1 < p.h;
+        float mx = r.l[0];
 #pragma unroll
-        for (int c = 1; c < P; ++c) mx = fmaxf(mx, l[c]);
+        for (int e = 1; e < CH; ++e) mx = fmaxf(mx, r.l[e]);
+        mx = cpl_max<NCH>(mx, gb);
         float se = 0.f;
 #pragma unroll
-        for (int c = 0; c < P; ++c) se += __expf(l[c] - mx);
+        for (int e = 0; e < CH; ++e) se += __expf(r.l[e] - mx);
+        se = cpl_sum<NCH>(se, gb);
         const float lse = mx + ups_log_fast(se);
-#pragma unroll
-        for (int c0 = 0; c0 < P; c0 += CH) {
-            float m[CH], lm[CH], hv[CH], mr[CH], lr[CH], md[CH], ld[CH];
-            ldg_chunk<CH>(p.m + o0 + c0, m); ldg_chunk<CH>(p.l_mean + o0 + c0, lm); ldg_chunk<CH>(p.hard + o0 + c0, hv);
-            ldg_chunk<CH>(p.m + oR + c0, mr); ldg_chunk<CH>(p.l_mean + oR + c0, lr);
-            ldg_chunk<CH>(p.m + oD + c0, md); ldg_chunk<CH>(p.l_mean + oD + c0, ld);
+        if (r.act) {
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
-                const int c = c0 + e;
-                const float mc = m[e];
+                const float mc = r.m[e];
                 kl += mc * ups_log_fast((float)P * mc + 1e-20f);
-                ent += -(p.entropy_ce ? hv[e] : mc) * (l[c] - lse);
-                const float lmc = lm[e];
-                const float lrc = vr ? lr[e] : 0.f, ldc = vd ? ld[e] : 0.f;
+                ent += -(p.entropy_ce ? r.hv[e] : mc) * (r.l[e] - lse);
+                const float lmc = r.lm[e];
+                const float lrc = vr ? r.lr[e] : 0.f, ldc = vd ? r.ld[e] : 0.f;
                 if (VAR == 0) {
-                    const bool in_rect = abs(yy - (int)cst[c][0]) <= p.half_h && abs(xx - (int)cst[c][1]) <= p.half_w;
-                    patch += in_rect ? 0.f : hv[e];
+                    const bool in_rect = abs(r.yy - cy[e]) <= p.half_h && abs(r.xx - cx[e]) <= p.half_w;
+                    patch += in_rect ? 0.f : r.hv[e];
                 } else {
                     const float gw = 0.25f * (lmc - lrc), gh = 0.25f * (lmc - ldc);
                     patch += fminf(p.ms_alpha * (gw * gw + gh * gh), p.ms_lambda);
                 }
                 if (vd) { const float d = ldc - lmc; gmrf += 0.5f * d * d; }
                 if (vr) { const float d = lrc - lmc; gmrf += 0.5f * d * d; }
-                const float mrc = vr ? mr[e] : 0.f, mdc = vd ? md[e] : 0.f;
+                const float mrc = vr ? r.mr[e] : 0.f, mdc = vd ? r.md[e] : 0.f;
                 const float gw = 0.25f * (mc - mrc), gh = 0.25f * (mc - mdc);
                 const float g = p.ms_alpha * (gw * gw + gh * gh);
-                const float r = fminf(g, p.ms_lambda);
-                S[c] += mc; R[c] += r;
-                if (g < p.ms_lambda) Rs[c] += r; else Rc[c] += r;
+                const float rr = fminf(g, p.ms_lambda);
+                S[e] += mc; R[e] += rr;
+                if (g < p.ms_lambda) Rs[e] += rr; else Rc[e] += rr;
             }
         }
+    };
+    Px pa, pb;
+    fetch(start, pa);
+    for (int base = start; base < end; base += 2 * C::PXB) {
+        fetch(base + C::PXB, pb);              // (past the range: shadows the last pixel, act = false)
+        step(pa);
+        fetch(base + 2 * C::PXB, pa);
+        step(pb);
     }
     kl = wave_sum_full(kl); ent = wave_sum_full(ent); patch = wave_sum_full(patch); gmrf = wave_sum_full(gmrf);
+    if (lane == 0) { red[wid][0] = kl; red[wid][1] = ent; red[wid][2] = patch; red[wid][3] = gmrf; }
 #pragma unroll
-    for (int c = 0; c < P; ++c) { S[c] = wave_sum_full(S[c]); R[c] = wave_sum_full(R[c]); Rs[c] = wave_sum_full(Rs[c]); Rc[c] = wave_sum_full(Rc[c]); }
-    if (lane == 0) {
-        float* d = red[wid];
-        d[0] = kl; d[1] = ent; d[2] = patch; d[3] = gmrf;
-#pragma unroll
-        for (int c = 0; c < P; ++c) { d[4 + 4 * c] = S[c]; d[5 + 4 * c] = R[c]; d[6 + 4 * c] = Rs[c]; d[7 + 4 * c] = Rc[c]; }
+    for (int e = 0; e < CH; ++e) {
+        part[wid][lane][e] = S[e]; part[wid][lane][CH + e] = R[e]; part[wid][lane][2 * CH + e] = Rs[e]; part[wid][lane][3 * CH + e] = Rc[e];
     }
     __syncthreads();
-    // workspace: glob_partial[n][NSLAB][4], np_partial[n][NSLAB][P][4]; this block owns record bi * spb of image n (the finalize
-    // kernel reads the records b * spb, b < bpi, only)
+    // workspace: glob_partial[n][NSLAB][4], np_partial[n][NSLAB][P][4]; this block owns record bi * spb of image n
     float* gpart = p.ws + ((long long)n * NSLAB + (long long)bi * spb) * 4;
     float* npart = p.ws + (long long)p.n * NSLAB * 4 + ((long long)n * NSLAB + (long long)bi * spb) * P * 4;
     if (tid < 4) gpart[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    for (int i = tid; i < 4 * P; i += 256) npart[i] = (red[0][4 + i] + red[1][4 + i]) + (red[2][4 + i] + red[3][4 + i]);
+    if (tid < 4 * P) {          // part c, sum k (S, R, Rsmooth, Rcontour): the lanes that own chunk c / CH, in a fixed order
+        const int c = tid >> 2, k = tid & 3, cc = c / CH, e = c - cc * CH;
+        float v = 0.f;
+        for (int w = 0; w < 4; ++w)
+            for (int q = 0; q < C::PXW; ++q) v += part[w][q * NCH + cc][k * CH + e];
+        npart[tid] = v;
+    }
 }
 
 template <int P, int LW, int VAR>
-__global__ __launch_bounds__(256) void prior_bwd0_direct_kernel(const PriorK p) {
-    constexpr int W = 1 << LW, CH = PChunk<P>::N;
+__global__ __launch_bounds__(256) void prior_bwd0_cpl_kernel(const PriorK p, const int bpi) {
+    typedef Cpl<P> C;
+    constexpr int W = 1 << LW, CH = C::CH, NCH = C::NCH;
     __shared__ float cst[P][4];                      // rectangle centre (y, x), S, R of the image's parts
-    const int tid = threadIdx.x;
-    const int hw = p.h * W, tiles_img = hw >> 8;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int hw = p.h * W;
     const int lb = xcd_logical_block();
-    const int n = lb / tiles_img, t = lb - n * tiles_img;
+    const int n = lb / bpi, bi = lb - n * bpi;
     if (tid < P) {
         cst[tid][0] = (VAR == 0 && p.px) ? (float)p.px[((long long)n * P + tid) * 2] : 0.f;
         cst[tid][1] = (VAR == 0 && p.px) ? (float)p.px[((long long)n * P + tid) * 2 + 1] : 0.f;
@@ -1257,137 +1317,125 @@ __global__ __launch_bounds__(256) void prior_bwd0_direct_kernel(const PriorK p) 
         cst[tid][3] = p.per_np[((long long)n * P + tid) * 8 + 1];
     }
     __syncthreads();
+    // lane -> (pixel of the wave, chunk); the spare lanes of a wave (60 .. 63 at five chunks per pixel) and the pixels past the image's
+    // end shadow a valid pixel: same loads, same shuffles, no store
+    const int pl_raw = lane / NCH, ci = lane - pl_raw * NCH;
+    const int pl = min(pl_raw, C::PXW - 1), gb = pl * NCH;
+    const int q_raw = bi * C::PXB + wid * C::PXW + pl;
+    const bool act = pl_raw < C::PXW && q_raw < hw;
+    const int q = min(q_raw, hw - 1);
+    const int c0 = ci * CH;
     const long long img = (long long)n * hw;
-    const int q = (t << 8) + tid;
     const int yy = q >> LW, xx = q & (W - 1);
     const bool vr = xx + 1 < W, vd = yy + 1 < p.h, vl = xx > 0, vu = yy > 0;
-    // neighbour pixels, clamped into the image (a clamped row is loaded and its values dropped by the validity flags)
-    const long long o0 = (img + q) * P;
-    const long long oR = (img + (vr ? q + 1 : q)) * P, oL = (img + (vl ? q - 1 : q)) * P;
-    const long long oD = (img + (vd ? q + W : q)) * P, oU = (img + (vu ? q - W : q)) * P;
-    const long long oLD = (img + ((vl && vd) ? q + W - 1 : q)) * P, oUR = (img + ((vu && vr) ? q - W + 1 : q)) * P;
+    const long long o0 = (img + q) * P + c0;
+    const long long oR = (img + (vr ? q + 1 : q)) * P + c0, oL = (img + (vl ? q - 1 : q)) * P + c0;
+    const long long oD = (img + (vd ? q + W : q)) * P + c0, oU = (img + (vu ? q - W : q)) * P + c0;
+    const long long oLD = (img + ((vl && vd) ? q + W - 1 : q)) * P + c0, oUR = (img + ((vu && vr) ? q - W + 1 : q)) * P + c0;
     const float inv_pix = 1.f / (float)((long long)p.n * hw), inv_n = 1.f / (float)p.n;
     const float a8 = p.ms_alpha * 0.125f, a16 = p.ms_alpha * 0.0625f;
     const float wkl = p.w_kl * inv_pix, went = p.w_entropy * inv_pix;
     const float wpatch = p.w_patch * inv_n, warea2 = p.w_area * inv_n * 2.f, wms2 = p.w_ms * inv_n * 2.f;
     const float wmsl = p.w_msl * inv_n, wgmrf = p.w_gmrf * inv_n;
 
-    float m[P], gh[P], gm[P], direct[P];
-    {
-        float l[P], hv[P];
-        ldg_row<P>(p.m + o0, m); ldg_row<P>(p.l + o0, l); ldg_row<P>(p.hard + o0, hv); ldg_row<P>(p.g_hard + o0, gh);
-        float mx = l[0];
+    float m[CH], l[CH], hv[CH], gh[CH];
+    ldg_chunk<CH>(p.m + o0, m); ldg_chunk<CH>(p.l + o0, l); ldg_chunk<CH>(p.hard + o0, hv); ldg_chunk<CH>(p.g_hard + o0, gh);
+    float mr[CH], md[CH], ml[CH], mld[CH], mu[CH], mur[CH];
+    ldg_chunk<CH>(p.m + oR, mr); ldg_chunk<CH>(p.m + oD, md); ldg_chunk<CH>(p.m + oL, ml);
+    ldg_chunk<CH>(p.m + oLD, mld); ldg_chunk<CH>(p.m + oU, mu); ldg_chunk<CH>(p.m + oUR, mur);
+    float lm[CH], lr[CH], ld[CH], ll[CH], lu[CH];
+    ldg_chunk<CH>(p.l_mean + o0, lm); ldg_chunk<CH>(p.l_mean + oR, lr); ldg_chunk<CH>(p.l_mean + oD, ld);
+    ldg_chunk<CH>(p.l_mean + oL, ll); ldg_chunk<CH>(p.l_mean + oU, lu);
+
+    float mx = l[0];
 #pragma unroll
-        for (int c = 1; c < P; ++c) mx = fmaxf(mx, l[c]);
-        float se = 0.f;
+    for (int e = 1; e < CH; ++e) mx = fmaxf(mx, l[e]);
+    mx = cpl_max<NCH>(mx, gb);
+    float se = 0.f;
 #pragma unroll
-        for (int c = 0; c < P; ++c) se += __expf(l[c] - mx);
-        const float lse = mx + ups_log_fast(se);
-        float qs = 0.f, labsum = 0.f;
+    for (int e = 0; e < CH; ++e) se += __expf(l[e] - mx);
+    se = cpl_sum<NCH>(se, gb);
+    const float lse = mx + ups_log_fast(se);
+    float qs = 0.f, labsum = 0.f;
 #pragma unroll
-        for (int c = 0; c < P; ++c) { qs += m[c] * (l[c] - lse); labsum += hv[c]; }
+    for (int e = 0; e < CH; ++e) { qs += m[e] * (l[e] - lse); labsum += hv[e]; }
+    qs = cpl_sum<NCH>(qs, gb); labsum = cpl_sum<NCH>(labsum, gb);
+
+    float gm[CH], direct[CH];
 #pragma unroll
-        for (int c = 0; c < P; ++c) {
-            const float mc = m[c];
-            const float pm = (float)P * mc;
-            float g = wkl * (ups_log_fast(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[c];
-            float dr = went * (-mc * ((l[c] - lse) - qs));
-            if (p.entropy_ce) dr += went * (-(hv[c] - mc * labsum));
-            if (VAR == 0) {
-                const bool in_rect = abs(yy - (int)cst[c][0]) <= p.half_h && abs(xx - (int)cst[c][1]) <= p.half_w;
-                g += in_rect ? 0.f : wpatch;
-            }
-            g += warea2 * cst[c][2];
-            gm[c] = g; direct[c] = dr;
+    for (int e = 0; e < CH; ++e) {
+        const int c = c0 + e;
+        const float mc = m[e];
+        const float pm = (float)P * mc;
+        float g = wkl * (ups_log_fast(pm + 1e-20f) + __fdividef(pm, pm + 1e-20f)) + gh[e];
+        float dr = went * (-mc * ((l[e] - lse) - qs));
+        if (p.entropy_ce) dr += went * (-(hv[e] - mc * labsum));
+        if (VAR == 0) {
+            const bool in_rect = abs(yy - (int)cst[c][0]) <= p.half_h && abs(xx - (int)cst[c][1]) <= p.half_w;
+            g += in_rect ? 0.f : wpatch;
         }
+        g += warea2 * cst[c][2];
+        // Mumford-Shah on the soft masks: own cell, the left neighbour's cell, the upper neighbour's
+        const float m_r = vr ? mr[e] : 0.f, m_d = vd ? md[e] : 0.f;
+        float dR = 0.f;
+        {
+            const float gg = a16 * ((mc - m_r) * (mc - m_r) + (mc - m_d) * (mc - m_d));
+            if (gg <= p.ms_lambda) dR += a8 * ((mc - m_r) + (mc - m_d));
+        }
+        if (vl) {
+            const float m_l = ml[e], m_ld = vd ? mld[e] : 0.f;
+            const float gg = a16 * ((m_l - mc) * (m_l - mc) + (m_l - m_ld) * (m_l - m_ld));
+            if (gg <= p.ms_lambda) dR -= a8 * (m_l - mc);
+        }
+        if (vu) {
+            const float m_u = mu[e], m_ur = vr ? mur[e] : 0.f;
+            const float gg = a16 * ((m_u - m_ur) * (m_u - m_ur) + (m_u - mc) * (m_u - mc));
+            if (gg <= p.ms_lambda) dR -= a8 * (m_u - mc);
+        }
+        g += wms2 * cst[c][3] * dR;
+        // the noise-free logits: GMRF term
+        const float lmc = lm[e];
+        float gg = 0.f;
+        if (vu) gg += lmc - lu[e];
+        if (vd) gg -= ld[e] - lmc;
+        if (vl) gg += lmc - ll[e];
+        if (vr) gg -= lr[e] - lmc;
+        dr += wgmrf * gg;
+        gm[e] = g; direct[e] = dr;
     }
-    // Mumford-Shah on the soft masks (own cell, the left neighbour's cell, the upper neighbour's) and, on the noise-free logits, the
-    // GMRF term and (SB_model48c) the same stencil: chunks of CH parts
+    if (VAR == 1) {         // (SB_model48c) the Mumford-Shah stencil on the logits too
+        float lld[CH], lur[CH];
+        ldg_chunk<CH>(p.l_mean + oLD, lld); ldg_chunk<CH>(p.l_mean + oUR, lur);
 #pragma unroll
-    for (int c0 = 0; c0 < P; c0 += CH) {
-        {
-            float mr[CH], md[CH], ml[CH], mld[CH], mu[CH], mur[CH];
-            ldg_chunk<CH>(p.m + oR + c0, mr); ldg_chunk<CH>(p.m + oD + c0, md); ldg_chunk<CH>(p.m + oL + c0, ml);
-            ldg_chunk<CH>(p.m + oLD + c0, mld); ldg_chunk<CH>(p.m + oU + c0, mu); ldg_chunk<CH>(p.m + oUR + c0, mur);
-#pragma unroll
-            for (int e = 0; e < CH; ++e) {
-                const int c = c0 + e;
-                const float mc = m[c];
-                const float m_r = vr ? mr[e] : 0.f, m_d = vd ? md[e] : 0.f;
-                float dR = 0.f;
-                {
-                    const float g = a16 * ((mc - m_r) * (mc - m_r) + (mc - m_d) * (mc - m_d));
-                    if (g <= p.ms_lambda) dR += a8 * ((mc - m_r) + (mc - m_d));
-                }
-                if (vl) {
-                    const float m_l = ml[e], m_ld = vd ? mld[e] : 0.f;
-                    const float g = a16 * ((m_l - mc) * (m_l - mc) + (m_l - m_ld) * (m_l - m_ld));
-                    if (g <= p.ms_lambda) dR -= a8 * (m_l - mc);
-                }
-                if (vu) {
-                    const float m_u = mu[e], m_ur = vr ? mur[e] : 0.f;
-                    const float g = a16 * ((m_u - m_ur) * (m_u - m_ur) + (m_u - mc) * (m_u - mc));
-                    if (g <= p.ms_lambda) dR -= a8 * (m_u - mc);
-                }
-                gm[c] += wms2 * cst[c][3] * dR;
+        for (int e = 0; e < CH; ++e) {
+            const float lmc = lm[e];
+            const float l_r = vr ? lr[e] : 0.f, l_d = vd ? ld[e] : 0.f;
+            float dL = 0.f;
+            {
+                const float gg = a16 * ((lmc - l_r) * (lmc - l_r) + (lmc - l_d) * (lmc - l_d));
+                if (gg <= p.ms_lambda) dL += a8 * ((lmc - l_r) + (lmc - l_d));
             }
-        }
-        {
-            float lm[CH], lr[CH], ld[CH], ll[CH], lu[CH];
-            ldg_chunk<CH>(p.l_mean + o0 + c0, lm); ldg_chunk<CH>(p.l_mean + oR + c0, lr); ldg_chunk<CH>(p.l_mean + oD + c0, ld);
-            ldg_chunk<CH>(p.l_mean + oL + c0, ll); ldg_chunk<CH>(p.l_mean + oU + c0, lu);
-            if (VAR == 1) {
-                float lld[CH], lur[CH];
-                ldg_chunk<CH>(p.l_mean + oLD + c0, lld); ldg_chunk<CH>(p.l_mean + oUR + c0, lur);
-#pragma unroll
-                for (int e = 0; e < CH; ++e) {
-                    const float lmc = lm[e];
-                    const float l_r = vr ? lr[e] : 0.f, l_d = vd ? ld[e] : 0.f;
-                    float dL = 0.f;
-                    {
-                        const float g = a16 * ((lmc - l_r) * (lmc - l_r) + (lmc - l_d) * (lmc - l_d));
-                        if (g <= p.ms_lambda) dL += a8 * ((lmc - l_r) + (lmc - l_d));
-                    }
-                    if (vl) {
-                        const float l_l = ll[e], l_ld = vd ? lld[e] : 0.f;
-                        const float g = a16 * ((l_l - lmc) * (l_l - lmc) + (l_l - l_ld) * (l_l - l_ld));
-                        if (g <= p.ms_lambda) dL -= a8 * (l_l - lmc);
-                    }
-                    if (vu) {
-                        const float l_u = lu[e], l_ur = vr ? lur[e] : 0.f;
-                        const float g = a16 * ((l_u - l_ur) * (l_u - l_ur) + (l_u - lmc) * (l_u - lmc));
-                        if (g <= p.ms_lambda) dL -= a8 * (l_u - lmc);
-                    }
-                    direct[c0 + e] += wmsl * dL;
-                }
+            if (vl) {
+                const float l_l = ll[e], l_ld = vd ? lld[e] : 0.f;
+                const float gg = a16 * ((l_l - lmc) * (l_l - lmc) + (l_l - l_ld) * (l_l - l_ld));
+                if (gg <= p.ms_lambda) dL -= a8 * (l_l - lmc);
             }
-#pragma unroll
-            for (int e = 0; e < CH; ++e) {
-                const float lmc = lm[e];
-                float gg = 0.f;
-                if (vu) gg += lmc - lu[e];
-                if (vd) gg -= ld[e] - lmc;
-                if (vl) gg += lmc - ll[e];
-                if (vr) gg -= lr[e] - lmc;
-                direct[c0 + e] += wgmrf * gg;
+            if (vu) {
+                const float l_u = lu[e], l_ur = vr ? lur[e] : 0.f;
+                const float gg = a16 * ((l_u - l_ur) * (l_u - l_ur) + (l_u - lmc) * (l_u - lmc));
+                if (gg <= p.ms_lambda) dL -= a8 * (l_u - lmc);
             }
+            direct[e] += wmsl * dL;
         }
     }
     float dot = 0.f, dot_r = 0.f;
 #pragma unroll
-    for (int c = 0; c < P; ++c) { dot += m[c] * gm[c]; dot_r += m[c] * gh[c]; }
+    for (int e = 0; e < CH; ++e) { dot += m[e] * gm[e]; dot_r += m[e] * gh[e]; }
+    dot = cpl_sum<NCH>(dot, gb); dot_r = cpl_sum<NCH>(dot_r, gb);
+    float a[CH], b[CH];
 #pragma unroll
-    for (int c0 = 0; c0 < P; c0 += CH) {
-        float a[CH], b[CH];
-#pragma unroll
-        for (int e = 0; e < CH; ++e) {
-            const int c = c0 + e;
-            a[e] = m[c] * (gm[c] - dot) + direct[c];
-            b[e] = m[c] * (gh[c] - dot_r);
-        }
-        stg_chunk<CH>(p.dl + o0 + c0, a);
-        stg_chunk<CH>(p.dl_rec + o0 + c0, b);
-    }
+    for (int e = 0; e < CH; ++e) { a[e] = m[e] * (gm[e] - dot) + direct[e]; b[e] = m[e] * (gh[e] - dot_r); }
+    if (act) { stg_chunk<CH>(p.dl + o0, a); stg_chunk<CH>(p.dl_rec + o0, b); }
 }
 
 // Test hook: UPS_PRIOR_PX_BPI caps the blocks per image of the pixel-per-lane kernels, so that a three-image test walks the multi-tile
@@ -1476,7 +1524,7 @@ extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
                 else { if (d->variant == 0) UPS_PRIOR_PX(8, 0); else UPS_PRIOR_PX(8, 1); }
 #undef UPS_PRIOR_PX
                 UPS_LAUNCH_CHECK();
-                hipLaunchKernelGGL(prior_finalize_px_kernel, dim3(1), dim3(256), 0, s, k, bpi, spb);
+                hipLaunchKernelGGL(prior_finalize_px_kernel, dim3(1), dim3(1024), 0, s, k, bpi, spb);
                 UPS_LAUNCH_CHECK();
                 return UPS_OK;
             }
@@ -1489,13 +1537,15 @@ extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
         const uintptr_t all = ((uintptr_t)d->m) | ((uintptr_t)d->l_mean) | ((uintptr_t)d->l) | ((uintptr_t)d->hard);
         if (dr_on && d->view == 0 && (d->P == 16 || d->P == 20 || d->P == 25) && (d->w == 128 || d->w == 256) &&
             hw % 256 == 0 && (all & 15) == 0) {
-            // blocks per image: a power of two that divides the tiles and the NSLAB slab records, ~four blocks per CU
+            // blocks per image: a power of two that divides the tiles and the NSLAB slab records, two blocks per CU: every record is one more
+            // row for the one-block finalize, whose round trips to the other XCDs' records are what a finer grid pays for (measured:
+            // 2 048 / 1 024 / 512 blocks = 0.43 / 0.46 / 0.51 of the HBM roof at P = 25, B = 64)
             const int tiles_img = (int)(hw / 256);
             int bpi = 1;
-            while (bpi < NSLAB && (long long)d->n * bpi < 1024 && tiles_img % (2 * bpi) == 0) bpi *= 2;
+            while (bpi < NSLAB && (long long)d->n * bpi < 512 && tiles_img % (2 * bpi) == 0) bpi *= 2;
             const dim3 grid(d->n * bpi);
             const int tpb = tiles_img / bpi, spb = NSLAB / bpi;
-#define UPS_PRIOR_F0(PV, LWV, VARV) hipLaunchKernelGGL((prior_fwd_direct_kernel<PV, LWV, VARV>), grid, dim3(256), 0, s, k, tpb, bpi, spb)
+#define UPS_PRIOR_F0(PV, LWV, VARV) hipLaunchKernelGGL((prior_fwd_cpl_kernel<PV, LWV, VARV>), grid, dim3(256), 0, s, k, tpb, bpi, spb)
 #define UPS_PRIOR_F0P(PV)                                                                                  \
             do {                                                                                          \
                 if (d->w == 128) { if (d->variant == 0) UPS_PRIOR_F0(PV, 7, 0); else UPS_PRIOR_F0(PV, 7, 1); } \
@@ -1505,7 +1555,7 @@ extern "C" int ups_prior_fwd(const ups_prior_desc* d, void* stream) {
 #undef UPS_PRIOR_F0P
 #undef UPS_PRIOR_F0
             UPS_LAUNCH_CHECK();
-            hipLaunchKernelGGL(prior_finalize_px_kernel, dim3(1), dim3(256), 0, s, k, bpi, spb);
+            hipLaunchKernelGGL(prior_finalize_px_kernel, dim3(1), dim3(1024), 0, s, k, bpi, spb);
             UPS_LAUNCH_CHECK();
             return UPS_OK;
         }
@@ -1598,8 +1648,9 @@ extern "C" int ups_prior_bwd(const ups_prior_desc* d, void* stream) {
         if (dr_on && d->view == 1 && (d->P == 16 || d->P == 20 || d->P == 25) && (d->w == 128 || d->w == 256) && hw % 256 == 0 &&
             d->g_hard && d->dl_rec && (((uintptr_t)d->m | (uintptr_t)d->g_hard | (uintptr_t)d->dl | (uintptr_t)d->dl_rec) & 15) == 0 &&
             d->n * (hw / 256) < (1ll << 31)) {
-            const dim3 grid((unsigned)(d->n * (hw / 256)));
-#define UPS_PRIOR_D1(PV, LWV, VARV) hipLaunchKernelGGL((prior_bwd1_direct_kernel<PV, LWV, VARV>), grid, dim3(256), 0, s, k)
+            const int bpi_c = (int)ups_cdiv(hw, d->P == 16 ? Cpl<16>::PXB : Cpl<20>::PXB);
+            const dim3 grid((unsigned)(d->n * (long long)bpi_c));
+#define UPS_PRIOR_D1(PV, LWV, VARV) hipLaunchKernelGGL((prior_bwd1_cpl_kernel<PV, LWV, VARV>), grid, dim3(256), 0, s, k, bpi_c)
 #define UPS_PRIOR_D1P(PV)                                                                                  \
             do {                                                                                          \
                 if (d->w == 128) { if (d->variant == 0) UPS_PRIOR_D1(PV, 7, 0); else UPS_PRIOR_D1(PV, 7, 1); } \
@@ -1613,8 +1664,10 @@ extern "C" int ups_prior_bwd(const ups_prior_desc* d, void* stream) {
         }
         if (dr_on && d->view == 0 && (d->P == 16 || d->P == 20 || d->P == 25) && (d->w == 128 || d->w == 256) && hw % 256 == 0 &&
             d->g_hard && d->dl_rec && d->l && d->l_mean && d->hard && (all & 15) == 0 && d->n * (hw / 256) < (1ll << 31)) {
-            const dim3 grid((unsigned)(d->n * (hw / 256)));
-#define UPS_PRIOR_D0(PV, LWV, VARV) hipLaunchKernelGGL((prior_bwd0_direct_kernel<PV, LWV, VARV>), grid, dim3(256), 0, s, k)
+            const int pxb = d->P == 16 ? Cpl<16>::PXB : Cpl<20>::PXB;
+            const int bpi_c = (int)ups_cdiv(hw, pxb);
+            const dim3 grid((unsigned)(d->n * (long long)bpi_c));
+#define UPS_PRIOR_D0(PV, LWV, VARV) hipLaunchKernelGGL((prior_bwd0_cpl_kernel<PV, LWV, VARV>), grid, dim3(256), 0, s, k, bpi_c)
 #define UPS_PRIOR_D0P(PV)                                                                                  \
             do {                                                                                          \
                 if (d->w == 128) { if (d->variant == 0) UPS_PRIOR_D0(PV, 7, 0); else UPS_PRIOR_D0(PV, 7, 1); } \

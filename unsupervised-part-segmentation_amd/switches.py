@@ -65,7 +65,7 @@ SWITCHES = OrderedDict([
     ("UPS_WGRAD_SLIDE", ("1", "ab", "conv_wgrad3x3.hip", "0: the plain form of the 3x3 weight gradient (3 % slower step)")),
     ("UPS_PRIOR_PX", ("1", "ab", "priors.hip", "0: the staged prior kernels at P = 10 instead of the pixel-per-lane rings")),
     ("UPS_PRIOR_PX_BPI", ("", "test", "priors.hip", "cap on blocks per image of the pixel-per-lane prior kernels (multi-tile loops at three images)")),
-    ("UPS_PRIOR_DIRECT", ("1", "ab", "priors.hip", "0: the staged prior kernels at P = 16 / 20 / 25 instead of the direct-from-global forms (round 6)")),
+    ("UPS_PRIOR_DIRECT", ("1", "ab", "priors.hip", "0: the staged prior kernels at P = 16 / 20 / 25 instead of the chunk-per-lane direct-from-global forms (round 6)")),
     ("UPS_SOFTMAX_PX", ("1", "ab", "partpath.hip", "0: the LDS-walking soft-max kernel at P = 10")),
     ("UPS_MOMENTS_PX", ("1", "ab", "partpath.hip", "0: the slab form of the spatial moments at P = 10")),
     ("UPS_MOMENTS_PX_BLOCKS", ("", "test", "partpath.hip", "blocks of the pixel-per-lane moments kernel")),
