@@ -864,7 +864,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                 }
             }
 #endif
+#if !defined(UPS_ABLATE_WWAIT)            // (timing experiment of round 6, results garbage: the wait for the next tap-row's weights)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if !defined(UPS_ABLATE_BARRIER)          // (timing experiment of round 6 on THIS loop -- the dominant instances run it; results garbage)
             __builtin_amdgcn_s_barrier();

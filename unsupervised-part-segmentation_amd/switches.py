@@ -72,7 +72,7 @@ SWITCHES = OrderedDict([
     ("UPS_UNPOOL_MFMA", ("1", "test", "partpath.hip", "0: the VALU form of unpool_bwd (the unit test compares both)")),
 ])
 
-COMPILE_TIME = ("UPS_ABLATE_BARRIER", "UPS_ABLATE_PATCHWAIT", "UPS_EPI_PRIO", "UPS_ABLATE_DMA", "UPS_ABLATE_EPI", "UPS_ABLATE_GLOAD", "UPS_ABLATE_LSTORE", "UPS_ABLATE_MFMA", "UPS_F8S_WN1", "UPS_OCC2_FRAG2",
+COMPILE_TIME = ("UPS_ABLATE_BARRIER", "UPS_ABLATE_PATCHWAIT", "UPS_ABLATE_WWAIT", "UPS_EPI_PRIO", "UPS_ABLATE_DMA", "UPS_ABLATE_EPI", "UPS_ABLATE_GLOAD", "UPS_ABLATE_LSTORE", "UPS_ABLATE_MFMA", "UPS_F8S_WN1", "UPS_OCC2_FRAG2",
                 "UPS_PATCH_A2", "UPS_PHASE_TIMING", "UPS_W8_NO_DMA", "UPS_W8_NO_MFMA", "UPS_W8_NO_QUANT", "UPS_W8_NO_XLOAD", "UPS_WGRAD_NO_PIPE",
                 "UPS_ROWS_FWD_SIGN", "UPS_ROWS_NO_FENCE", "UPS_VMAX_BUILTIN")
 NOT_SWITCHES = ("UPS_ABI_VERSION", "UPS_ACT_", "UPS_OK", "UPS_E_", "UPS_BF16", "UPS_F16", "UPS_F32", "UPS_CHECK_ARG", "UPS_LAUNCH_CHECK")
