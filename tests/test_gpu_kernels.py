@@ -1835,6 +1835,9 @@ def _pack_signs(t16):
 @pytest.mark.parametrize("n,h,cin,cout,k,stride,f16", [(4, 32, 64, 64, 3, 1, False), (2, 64, 256, 256, 3, 1, True), (3, 28, 64, 64, 3, 1, False),
                                                        (8, 8, 128, 128, 3, 1, False), (4, 32, 64, 128, 1, 1, False), (4, 32, 64, 64, 3, 2, False),
                                                        (2, 32, 16, 24, 3, 1, False),
+                                                       # (round 6: the tile's sign bytes are loaded by the prologue -- PatchK.sgn_res -- here with a
+                                                       # partial second N-tile, 192 = 128 + 64 channels, on the descriptor-tap instance)
+                                                       (2, 32, 192, 24, 3, 1, False), (2, 32, 192, 192, 3, 1, False),
                                                        # the row-stream kernels (UPS_ROWS_KERNEL=force takes them at small batches): the one-tile
                                                        # forms write / read the bytes (LDS-DMA ring), the two-tile form does neither
                                                        (4, 128, 32, 32, 3, 1, False), (4, 64, 64, 64, 3, 1, False), (2, 128, 64, 64, 3, 1, False),

@@ -14,6 +14,8 @@ dev = torch.device("cuda:0")
 case = sys.argv[1]
 mode = sys.argv[2] if len(sys.argv) > 2 else "fwd"
 name, n, h, cin, cout, k, stride, coords, act = [c for c in CASES if c[0] == case][0]
+if case == "dv_out" and mode == "dgrad":
+    act = "leaky_relu"      # as the model runs it: the logit convolution reads the stored post-activation tensor, its input gradient takes act' from sign bytes
 g = torch.Generator().manual_seed(1)
 cin_v = cin + (2 if coords else 0)
 V = (torch.randn(k, k, cin_v, cout, generator=g) / math.sqrt(k * k * cin_v)).to(dev)
@@ -31,7 +33,9 @@ res_self = act is not None and stride == 1 and cin == cout
 out_f32 = case == "dv_out"
 fwd = lambda: ops.conv_forward(x, lay, res=x if res_self else None, fmt=fmt, res_post=lay.in_post, out_f32=out_f32)
 y = fwd()
-gy = torch.randn(y.shape, device=dev).to(torch.bfloat16)
+gy = torch.zeros(y.shape[:-1] + (ops.round8(cout),), device=dev)
+gy[..., :cout] = torch.randn(y.shape[:-1] + (cout,), device=dev)
+gy = gy.to(torch.bfloat16)
 xb = None
 if "bits" in sys.argv[3:]:       # act' from the producer's sign bytes, as the step runs it (res_patch == 2 on the wide instances)
     pos = (x.view(torch.int16) > 0).view(*x.shape[:-1], -1, 8).to(torch.uint8)

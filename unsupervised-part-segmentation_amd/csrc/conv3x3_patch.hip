@@ -86,6 +86,11 @@ struct PatchK {
     // the weights.  The tile's sign bytes sit in LDS from the prologue on (`sgn_off`: 256 pixels x BN / 8 bytes behind the buffers).
     int res_patch;
     int sgn_off;
+    // sgn_res (round 6, late): EVERY one-tile-per-image 16-bit launch whose act' comes from sign bytes has the tile's bytes loaded by the
+    // prologue (8 bytes per thread, under the first patch / weight round trip) instead of by the epilogue (one BYTE per lane and item,
+    // a dependent round trip and a barrier in front of the accumulators: 6.9 of the 20.8 us of a block of the logit convolution's input
+    // gradient).  Launcher: dact_bits given, ldd a multiple of 64, not depth-to-space, LDS permitting.
+    int sgn_res;
 };
 
 __device__ __forceinline__ int fast_div(int n, int d, unsigned m) {
@@ -773,18 +778,28 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
         }
         } else {
         UPS_PHASE(1);
+        // the tile's sign bytes (PatchK.sgn_res): [256 px][BN / 8], zero outside a ragged image and past the tensor's channels.  REQUESTED
+        // first -- they come from HBM, the weights from L2 -- and committed to LDS behind the patch / weight requests, so that their round
+        // trip runs under the patch's (two registers for the length of the prologue)
+        constexpr int SG_BPP = BN / 8, SG_TPP = SG_BPP >= 8 ? SG_BPP / 8 : 1, SG_PCB = SG_BPP >= 8 ? 8 : 4;     // bytes / threads per pixel, bytes per thread
+        const bool sgn_on = SUB == TS && p.sgn_res;
+        uint2 sgn_v = make_uint2(0u, 0u);
+        const int sgn_px = tid / SG_TPP, sgn_hf = tid - sgn_px * SG_TPP;
+        if (sgn_on && sgn_px < 256) {
+            const int yy = ty0 + (sgn_px >> 4), xx = tx0 + (sgn_px & 15);
+            const int boff = (nt * BN >> 3) + SG_PCB * sgn_hf, rem = (p.ldd >> 3) - boff;       // bytes of the pixel's row from this thread's piece on
+            const unsigned char* row = p.dact_bits + (((long long)img_pm * p.h + yy) * p.w + xx) * (p.ldd >> 3) + boff;
+            if (yy < p.h && xx < p.w) {
+                if (RP2 || (SG_BPP >= 8 && rem >= 8)) sgn_v = *(const uint2*)row;     // (RP2: whole 128-channel N-tiles, launcher)
+                else if (rem >= 4) sgn_v.x = *(const unsigned*)row;
+            }
+        }
         if constexpr (DMAP) dma_patch(0);
         else { load_patch(0); store_patch(Abuf); }
         dma_w(0);
-        if constexpr (RP2) {
-            if (p.res_patch == 2) {      // thread t: 8 of the 16 sign bytes of tile pixel t / 2 (zero outside a ragged image)
-                const int px = tid >> 1, hf = tid & 1;
-                const int yy = ty0 + (px >> 4), xx = tx0 + (px & 15);
-                uint2 sv = make_uint2(0u, 0u);
-                if (yy < p.h && xx < p.w)
-                    sv = *(const uint2*)(p.dact_bits + (((long long)img_pm * p.h + yy) * p.w + xx) * (p.ldd >> 3) + (nt * BN >> 3) + 8 * hf);
-                *(uint2*)(smem + p.sgn_off + px * (BN / 8) + 8 * hf) = sv;
-            }
+        if (sgn_on && sgn_px < 256) {
+            if constexpr (SG_BPP >= 8) *(uint2*)(smem + p.sgn_off + sgn_px * SG_BPP + 8 * sgn_hf) = sgn_v;
+            else *(unsigned*)(smem + p.sgn_off + sgn_px * SG_BPP) = sgn_v.x;
         }
         if (OCC != 2 && total > 1) dma_w(1);
         // a single channel chunk on the 3-stage ring: all nine taps' weights fit the ring at once -- everything is requested
@@ -1077,16 +1092,17 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             constexpr int NIT = 256 * CPR / 512;             // chunks per thread
             unsigned char* R0 = smem;                        // residual tile, then the output tile (in place)
             // activation-derivative tile as sign bits: [256 px][BN / 8 bytes]; res_patch == 2: the copy the prologue left behind the buffers
-            const bool sgn_resident = DMAP && SUB == TS && TAPS == 2 && BN == 128 && F8 == 0 && __is_same(T, bf16) && p.res_patch == 2;
+            const bool sgn_resident = SUB == TS && F8 < 3 && p.sgn_res;
             unsigned char* R1 = sgn_resident ? smem + p.sgn_off : smem + 256 * ERS;
             const int c_lim = p.co_fill - nt * BN;           // valid channels of this N-tile (multiple of 8)
-            if ((res || dact) && !sgn_resident) {
+            if (res || (dact && !sgn_resident)) {
 #pragma unroll
                 for (int i = 0; i < NIT; ++i) {
                     const int idx = tid + 512 * i, px = idx / CPR, ch = idx - px * CPR;
                     if (ch * 8 < c_lim && pix_ok(px)) {
                         if (res) *(uint4*)(R0 + px * ERS + ch * 16) = *(const uint4*)(res + gaddr(px, nt * BN + ch * 8, p.ldr));
-                        if (dact && p.dact_bits) {
+                        if (sgn_resident) {
+                        } else if (dact && p.dact_bits) {
                             // round 5: the byte the loop below would derive from 16 bytes of the forward input arrives packed (one bit per
                             // element, written by the tensor's producer): 1.07 GB less per launch of the roofline layer, no compares
                             R1[px * CPR + ch] = p.dact_bits[((unsigned long long)img_pix + gpix(px)) * (unsigned)(p.ldd >> 3) +
@@ -1382,10 +1398,12 @@ int launch_bn(const PatchK& k, hipStream_t s) {
     const size_t epi = sizeof(T) == 2 ? 256 * (size_t)(BN * 2 + 16) + 256 * (size_t)(BN / 8) : 0;   // staged bf16 epilogue
     if (epi > shmem) shmem = epi;
     constexpr bool rp2_ok = __is_same(T, bf16) && BN == 128 && TAPS == 2 && DMAP && SUB == TS && F8 == 0;
-    constexpr size_t sgn_bytes = rp2_ok ? 256 * (size_t)(BN / 8) : 0;       // the resident sign tile of res_patch == 2
-    if (kk.res_patch == 2 && !rp2_ok) kk.res_patch = 0;                     // (this instance has no such path: residual and signs in the epilogue)
+    constexpr size_t sgn_bytes = (sizeof(T) == 2 && SUB == TS && F8 < 3) ? 256 * (size_t)(BN / 8) : 0;       // the resident sign tile (PatchK.sgn_res)
+    kk.sgn_res = (sgn_bytes && kk.dact && kk.dact_bits && kk.ldd % 64 == 0 && (((uintptr_t)kk.dact_bits) & 7) == 0 && !kk.d2s) ? 1 : 0;
+    if (rp2_ok && kk.co_fill % BN != 0) kk.sgn_res = 0;                    // (that instance's loader reads the 16 bytes of whole N-tiles)
+    if (kk.res_patch == 2 && !(rp2_ok && kk.sgn_res)) kk.res_patch = 0;    // (this instance has no such path: the residual in the epilogue)
     kk.sgn_off = (int)shmem;
-    if (kk.res_patch == 2) shmem += sgn_bytes;
+    if (kk.sgn_res) shmem += sgn_bytes;
     static UpsPerDevice attr_set;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, BN, OCC, SUB, F8, PRE, TAPS, DMAP, CSTD>,
