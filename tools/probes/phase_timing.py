@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 case = sys.argv[1]
 mode = sys.argv[2] if len(sys.argv) > 2 else "fwd"
 name, n, h, cin, cout, k, stride, coords, act = [c for c in CASES if c[0] == case][0]
-if case == "dv_out" and mode == "dgrad":
+if case == "dv_out" and mode == "dgrad" and "noact" not in sys.argv[3:]:
     act = "leaky_relu"      # as the model runs it: the logit convolution reads the stored post-activation tensor, its input gradient takes act' from sign bytes
 g = torch.Generator().manual_seed(1)
 cin_v = cin + (2 if coords else 0)
