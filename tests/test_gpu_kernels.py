@@ -1201,6 +1201,11 @@ def test_integration_stub_runs(dev):
     (5, 32, 64, 64, False, 0, False),        # VGG block1_conv1 form: 3 -> 64
     (3, 16, 16, 24, True, 0, False),         # all-border tile, ragged channel tail
     (1, 48, 32, 64, True, 32, True),         # the most parts a mask word holds, 64 output channels
+    # (round 6: strips of 16 columns x 64 / 32 rows, the fragments of the next four rows in flight; the CoordConv class of a first / last
+    # column is the lane's own, only the first and the last ROW take the table path)
+    (2, 128, 32, 32, True, 0, True),         # 16 rows per wave: encoder_0's first convolution form, both row borders in one strip's waves
+    (2, 64, 48, 64, False, 0, False),        # 16 rows per wave, 64 output channels (VGG block1_conv1 form)
+    (2, 64, 32, 32, True, 5, False),         # part-masked at 8 rows per wave, two strips per column
 ])
 def test_first_layer_kernel(case, dev, monkeypatch):
     """conv3x3_first.hip (im2col in the MFMA fragment addressing, every part image of a tile from one read of the view) against

@@ -1109,14 +1109,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                                                             (unsigned)((nt * BN + ch * 8) >> 3)];
                         } else if (dact) {
                             const uint4 dv = *(const uint4*)(dact + gaddr(px, nt * BN + ch * 8, p.ldd));
-                            const unsigned wv[4] = {dv.x, dv.y, dv.z, dv.w};
-                            unsigned sb = 0;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {      // bit e = (element e > 0), elements = bf16 halves of the words
-                                sb |= ((short)(wv[k] & 0xffffu) > 0 ? 1u : 0u) << (2 * k);
-                                sb |= (((int)wv[k] >> 16) > 0 ? 1u : 0u) << (2 * k + 1);
-                            }
-                            R1[px * CPR + ch] = (unsigned char)sb;
+                            R1[px * CPR + ch] = (unsigned char)ups_sign_byte(dv);      // bit e = (element e > 0), elements = the 16-bit halves of the words
                         }
                     }
                 }
@@ -1263,13 +1256,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                     const unsigned ga = lin ? ga0 + (unsigned)i * ga_step : gaddr(px, nt * BN + ch * 8, p.ldo);
                     *(uint4*)(outT + ga) = u;
                     if (p.sign_out) {          // (uniform) bit e = stored element e > 0: positive and non-zero as a 16-bit integer
-                        const unsigned wv[4] = {u.x, u.y, u.z, u.w};
-                        unsigned sb = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            sb |= ((short)(wv[k] & 0xffffu) > 0 ? 1u : 0u) << (2 * k);
-                            sb |= (((int)wv[k] >> 16) > 0 ? 1u : 0u) << (2 * k + 1);
-                        }
+                        const unsigned sb = ups_sign_byte(u);
                         const unsigned long long sgi = lin ? sg0 + (unsigned long long)((unsigned)i * sg_step)
                                                            : ((unsigned long long)img_pix + gpix(px)) * (unsigned)(p.ldo >> 3) + (unsigned)((nt * BN + ch * 8) >> 3);
                         p.sign_out[sgi] = (unsigned char)sb;

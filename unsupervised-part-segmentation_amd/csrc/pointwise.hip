@@ -128,14 +128,7 @@ __global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y
             *(uint4*)ptr = u;
             if (sbits) {
                 // (the sign of the STORED 16-bit value: a tiny positive fp32 that rounds to zero must not count as positive)
-                const unsigned wv[4] = {u.x, u.y, u.z, u.w};
-                unsigned sb = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    sb |= ((short)(wv[k] & 0xffffu) > 0 ? 1u : 0u) << (2 * k);
-                    sb |= (((int)wv[k] >> 16) > 0 ? 1u : 0u) << (2 * k + 1);
-                }
-                sbits[(ptr - y) >> 3] = (unsigned char)sb;
+                sbits[(ptr - y) >> 3] = (unsigned char)ups_sign_byte(u);
             }
         } else {
             V16<T>::st(ptr, t);
@@ -237,14 +230,7 @@ __global__ void act_mean_bwd_kernel(const T* __restrict__ x, const T* __restrict
 __global__ void sign_pack_kernel(const uint4* __restrict__ x, unsigned char* __restrict__ bits, long long chunks) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
         const uint4 u = x[i];
-        const unsigned wv[4] = {u.x, u.y, u.z, u.w};
-        unsigned sb = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            sb |= ((short)(wv[k] & 0xffffu) > 0 ? 1u : 0u) << (2 * k);
-            sb |= (((int)wv[k] >> 16) > 0 ? 1u : 0u) << (2 * k + 1);
-        }
-        bits[i] = (unsigned char)sb;
+        bits[i] = (unsigned char)ups_sign_byte(u);
     }
 }
 
