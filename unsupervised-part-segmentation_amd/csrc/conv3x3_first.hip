@@ -36,10 +36,8 @@ struct FirstK {
 // round trip: with 148-220 registers two or three blocks share a CU, and a 16 x 16 tile per block left ~1 TB/s of stores behind one
 // exposed round trip per tile.
 template <int NC, int RW>       // NC: groups of 16 output channels: 2 (co_fill 32) or 4 (co_fill 64)
-#if !defined(UPS_FIRST_OCC)
-#define UPS_FIRST_OCC 0
-#endif
-__global__ __launch_bounds__(256, UPS_FIRST_OCC ? (NC == 2 ? UPS_FIRST_OCC : UPS_FIRST_OCC - 1) : 1) void conv3x3_first_kernel(const FirstK p) {
+// (132-236 registers: two or three waves per SIMD.  Occupancy bounds of 4 / 5 waves spill 26-188 registers and run 1.5-4x slower.)
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(const FirstK p) {
     __shared__ __attribute__((aligned(16))) unsigned char stage[4][16 * NC * 32];     // per wave: 16 pixels x NC*16 channels x 2 B
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (uniform: the row bases below stay on the scalar unit)
