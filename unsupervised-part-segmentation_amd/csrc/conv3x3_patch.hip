@@ -1126,10 +1126,15 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
             const bool all_valid = p.co == p.co_fill;
             const bool has_affine = p.bias != nullptr || p.coord_tab != nullptr;
             const bool epi_vec = (p.co & 3) == 0 && ((((unsigned long long)p.bias) | ((unsigned long long)p.coord_tab)) & 15ull) == 0;
-            const bool border_tile = p.coord_tab && (SUB < TS || ty0 == 0 || ty0 + TS >= p.h || tx0 == 0 || tx0 + TS >= p.w);
+            // (round 6, late: the folded terms are those of the lane's own COLUMN class in an interior row -- class 7 * 8 + xm, 63 for an
+            // interior column -- so that only the first and the last ROW of the image take the per-pixel table path below.  Until then every
+            // pixel of a first / last column did, in every row of the 28 border tiles of 64: sixteen dependent dword loads per (i, j), and
+            // the forward's epilogue took 11.2 us on average, 21 us at p90, against the input gradient's 7.3)
+            const bool border_tile = p.coord_tab && (SUB < TS || ty0 == 0 || ty0 + TS >= p.h);
             const float xf = (float)(tx0 + p16);
             const int xq = xcoord(p16);
             const int xm = (xq > 0 ? 1 : 0) | 2 | (xq + 1 < p.w ? 4 : 0);
+            const int cls_col = SUB == TS ? 7 * 8 + xm : 63;          // (multi-image tiles: every pixel takes the table path anyway)
 #pragma unroll
             for (int j = 0; j < TN16; ++j) {
                 const int cl = (wn * TN16 + j) * 16 + 4 * q16;
@@ -1144,7 +1149,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), t04 = b4, t14 = b4, t24 = b4;
                     if (ok && p.bias) b4 = *(const float4*)(p.bias + col);
                     if (ok && p.coord_tab) {
-                        const float* tb = p.coord_tab + (long long)63 * 3 * p.co + col;
+                        const float* tb = p.coord_tab + (long long)cls_col * 3 * p.co + col;
                         t04 = *(const float4*)tb; t14 = *(const float4*)(tb + p.co); t24 = *(const float4*)(tb + 2 * p.co);
                     }
                     const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, a0[4] = {t04.x, t04.y, t04.z, t04.w};
@@ -1159,7 +1164,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                     float t0 = 0.f, t1 = 0.f;
                     t2v[e] = 0.f;
                     if (cv[e] && p.coord_tab) {
-                        const float* tb = p.coord_tab + (long long)63 * 3 * p.co + col + e;
+                        const float* tb = p.coord_tab + (long long)cls_col * 3 * p.co + col + e;
                         t0 = tb[0]; t1 = tb[p.co]; t2v[e] = tb[2 * p.co];
                     }
                     xs[e] = fmaf(xf, t1, bias + t0);
@@ -1185,7 +1190,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                         if (border_tile) {
                             const int y = ycoord(yrow);
                             const int ym = (y > 0 ? 1 : 0) | 2 | (y + 1 < p.h ? 4 : 0);
-                            if ((ym & xm) != 7 || SUB < TS) {
+                            if (ym != 7 || SUB < TS) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     if (!cv[e]) continue;
