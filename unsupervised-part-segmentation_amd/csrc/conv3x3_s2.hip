@@ -72,12 +72,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(const S2K p) {
                 const int ys = 2 * y + p.dy[0] + rr, xs = 2 * (x0 + p16) + p.dx[s];
                 const bool ok = (unsigned)ys < (unsigned)p.hi && (unsigned)xs < (unsigned)p.wi;
                 const long long off = ok ? ((long long)ys * p.wi + xs) * p.ldi * 2 + kc * 64 + q16 * 16 : 0;
-                uint4 v = *(const uint4*)(inb + off);
-                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
-                a[rr][s] = v;
+                const uint4 v = *(const uint4*)(inb + off);
+                const unsigned km = ok ? 0xffffffffu : 0u;      // (an AND, not a select: under the branch hipcc makes of it the load waits vmcnt(0))
+                a[rr][s] = make_uint4(v.x & km, v.y & km, v.z & km, v.w & km);
             }
     };
     const float oact_ns = ups_slope_eff(p.out_act, p.slope);
+    const float oact_e = p.out_act ? oact_ns : 1.f;        // max(f, 1 f) = f: no branch
+    // the per-channel terms as 16-byte loads: whole groups of four channels, 16-byte aligned vectors
+    const bool epi_vec = (p.co & 3) == 0 && ((((unsigned long long)p.bias) | ((unsigned long long)p.coord_tab)) & 15ull) == 0;
     const int x = x0 + p16;
     int xm = 0;
 #pragma unroll
@@ -132,6 +135,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(const S2K p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v[4];
+                const int col4 = co0 + 16 * j + 4 * q16;
+                if (epi_vec) {
+                    // (round 6, late: the lane's four channels with ONE unconditional 16-byte load per term -- clamped channel, the weight
+                    // tensor as a stand-in address for an absent bias / table -- instead of sixteen dword loads under branches per (row, j))
+                    const bool ok4 = col4 < p.co;
+                    const int colc = ok4 ? col4 : 0;
+                    const float* bp = (p.bias ? p.bias : (const float*)p.w) + colc;
+                    const float* tb = (p.coord_tab ? p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co : (const float*)p.w) + colc;
+                    const int tstr = p.coord_tab ? p.co : 0;
+                    const float4 b4 = *(const float4*)bp, t04 = *(const float4*)tb, t14 = *(const float4*)(tb + tstr), t24 = *(const float4*)(tb + 2 * tstr);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, a0[4] = {t04.x, t04.y, t04.z, t04.w};
+                    const float a1[4] = {t14.x, t14.y, t14.z, t14.w}, a2[4] = {t24.x, t24.y, t24.z, t24.w};
+                    const bool kb = ok4 && p.bias != nullptr, kt = ok4 && p.coord_tab != nullptr;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float f = acc[i][j][e] + (kb ? bb[e] : 0.f);
+                        if (kt) f += a0[e] + (float)x * a1[e] + (float)y * a2[e];
+                        f = ups_vmax(f, oact_e * f);
+                        v[e] = ok4 ? f : 0.f;
+                    }
+                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int col = co0 + 16 * j + 4 * q16 + e;
@@ -147,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(const S2K p) {
                         f = 0.f;
                     }
                     v[e] = f;
+                }
                 }
                 *(uint2*)(stage + p16 * 128 + j * 32 + q16 * 8) = make_uint2(Chunk<bf16>::pk(v[0], v[1]), Chunk<bf16>::pk(v[2], v[3]));
             }
