@@ -165,7 +165,7 @@ S2_CASES = [
 @pytest.mark.parametrize("case", S2_CASES)
 def test_conv_stride2_forward_kernel(case, dev, monkeypatch):
     """conv3x3_s2.hip: the forward of the large 3x3 / stride-2 `downsample` layers (N:816-817) with the taps read straight from
-    global memory.  The model only routes launches of >= 256 Ki output pixels to it; UPS_S2_KERNEL=force takes the size gate away so
+    global memory.  The model only routes launches of >= 128 Ki output pixels to it; UPS_S2_KERNEL=force takes the size gate away so
     that the parity shapes stay small.  Against the fp64 oracle on the bf16-rounded operands, and against the generic gather
     kernel (UPS_S2_KERNEL=0) on the same inputs."""
     lib, ops, R = _mods()
