@@ -20,14 +20,54 @@ __device__ inline float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 // out[0] = 0.5 * (mean softplus(-joint) + mean softplus(marg))     logit_loss(real=True) / (real=False), model.py:524-529
 // out[1] = (#joint > 0 + #marg < 0) / 2B                            model.py:821-826
 // out[2] = mean joint                                               logit_constraint(real=False), model.py:532-536, 855
+// (round 6, late: sixteen waves and 16-byte loads, four rows of a wave in flight at once.  Four waves walking 32 rows each with 2-byte
+// loads and a reduction per row were 2B dependent round trips in a row: 80 us for 128 rows, three times per step)
 template <typename T>
-__global__ __launch_bounds__(256) void critic_head_fwd_kernel(const T* __restrict__ hp, const T* __restrict__ ha, int B, int K, int ld,
-                                                              float* __restrict__ logits, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void critic_head_fwd_kernel(const T* __restrict__ hp, const T* __restrict__ ha, int B, int K, int ld,
+                                                               float* __restrict__ logits, float* __restrict__ out) {
     extern __shared__ float lg[];                         // [2B]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int r = wv; r < 2 * B; r += 4) {
-        const float d = row_dot(hp + (long long)r * ld, ha + (long long)r * ld, K, lane);
-        if (lane == 0) { lg[r] = d; logits[r] = d; }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const bool vec = sizeof(T) == 2 && (K & 7) == 0 && (ld & 7) == 0 && ((((unsigned long long)hp) | ((unsigned long long)ha)) & 15ull) == 0;
+    bool done = false;
+    if constexpr (sizeof(T) == 2) {
+    if (vec) {
+        done = true;
+        const int nv = K >> 3;                            // 16-byte pieces per row
+        for (int r0 = wv; r0 < 2 * B; r0 += 4 * nw) {     // rows r0, r0 + nw, r0 + 2 nw, r0 + 3 nw of this wave: their pieces requested together
+            float sum[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int v = lane; v < nv; v += 64) {
+                uint4 a[4], b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = min(r0 + q * nw, 2 * B - 1);          // (clamped: a row past the end is read and dropped)
+                    a[q] = *(const uint4*)(hp + (long long)r * ld + 8 * v);
+                    b[q] = *(const uint4*)(ha + (long long)r * ld + 8 * v);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned aw[4] = {a[q].x, a[q].y, a[q].z, a[q].w}, bw[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float a0, a1, b0, b1;
+                        ups_unpack2<T>(aw[k], a0, a1); ups_unpack2<T>(bw[k], b0, b1);
+                        sum[q] += a0 * b0; sum[q] += a1 * b1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float d = wave_sum(sum[q]);
+                const int r = r0 + q * nw;
+                if (lane == 0 && r < 2 * B) { lg[r] = d; logits[r] = d; }
+            }
+        }
+    }
+    }
+    if (!done) {
+        for (int r = wv; r < 2 * B; r += nw) {
+            const float d = row_dot(hp + (long long)r * ld, ha + (long long)r * ld, K, lane);
+            if (lane == 0) { lg[r] = d; logits[r] = d; }
+        }
     }
     __syncthreads();
     if (wv == 0) {                                        // one wave, rows in a fixed order per lane, then a fixed shuffle tree
@@ -243,8 +283,8 @@ extern "C" int ups_critic_head_fwd(const void* h_pi, const void* h_al, int32_t d
     UPS_CHECK_ARG(h_pi && h_al && logits && out4 && B > 0 && B <= 4096 && K > 0 && K <= ld);
     hipStream_t s = (hipStream_t)stream;
     const size_t shm = (size_t)2 * B * sizeof(float);
-    if (dtype == UPS_F32) hipLaunchKernelGGL(critic_head_fwd_kernel<float>, dim3(1), dim3(256), shm, s, (const float*)h_pi, (const float*)h_al, B, K, ld, logits, out4);
-    else if (dtype == UPS_BF16) hipLaunchKernelGGL(critic_head_fwd_kernel<bf16>, dim3(1), dim3(256), shm, s, (const bf16*)h_pi, (const bf16*)h_al, B, K, ld, logits, out4);
+    if (dtype == UPS_F32) hipLaunchKernelGGL(critic_head_fwd_kernel<float>, dim3(1), dim3(1024), shm, s, (const float*)h_pi, (const float*)h_al, B, K, ld, logits, out4);
+    else if (dtype == UPS_BF16) hipLaunchKernelGGL(critic_head_fwd_kernel<bf16>, dim3(1), dim3(1024), shm, s, (const bf16*)h_pi, (const bf16*)h_al, B, K, ld, logits, out4);
     else { ups_set_error("bad dtype %d", (int)dtype); return UPS_E_ARG; }
     UPS_LAUNCH_CHECK();
     return UPS_OK;
