@@ -1191,12 +1191,24 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv3x3_patch_kernel(const Patch
                             const int y = ycoord(yrow);
                             const int ym = (y > 0 ? 1 : 0) | 2 | (y + 1 < p.h ? 4 : 0);
                             if (ym != 7 || SUB < TS) {
+                                if (epi_vec && cv[0]) {      // (the lane's four channels with one 16-byte load per term: every pixel of the
+                                                             // multi-image tiles -- the 8 x 8 / 4 x 4 maps -- comes through here)
+                                    const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col;
+                                    const float4 t04 = *(const float4*)tb, t14 = *(const float4*)(tb + p.co), t24 = *(const float4*)(tb + 2 * p.co);
+                                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                                    if (p.bias) b4 = *(const float4*)(p.bias + col);
+                                    const float a0[4] = {t04.x, t04.y, t04.z, t04.w}, a1[4] = {t14.x, t14.y, t14.z, t14.w};
+                                    const float a2[4] = {t24.x, t24.y, t24.z, t24.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = acc16[i][j][e] + bb[e] + (a0[e] + (float)xq * a1[e] + (float)y * a2[e]);
+                                } else {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     if (!cv[e]) continue;
                                     const float* tb = p.coord_tab + (long long)(ym * 8 + xm) * 3 * p.co + col + e;
                                     const float bias = p.bias ? p.bias[col + e] : 0.f;
                                     v[e] = acc16[i][j][e] + bias + (tb[0] + (float)xq * tb[p.co] + (float)y * tb[2 * p.co]);
+                                }
                                 }
                             }
                         }
