@@ -920,56 +920,75 @@ __global__ __launch_bounds__(512, SW == 16 ? 4 : 2) void conv3x3_thinout_kernel(
 
     const int iters = y1 - y0;
     unsigned char* out_img = p.out + (long long)img * h_ * wd_ * ldo_ * (of32_ ? 4 : 2);
-    for (int it = 0; it < iters; ++it) {
-        // rows it .. it + 2 of this wave's plane must have landed (row it + 2 was requested by iteration it - L); younger: the NPC
-        // requests of each of the L - 1 rows behind it and the stores issued since (every iteration ends with one: counted once)
-        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * NPC) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * NPC + 1) : "memory");
-        UPS_THIN_ISSUE_ROW(it + L + 2);      // into the slot of row it - 1, whose last fragment reads fed the previous iteration's MFMAs
-        // four accumulator chains (column tiles x two tap groups)
-        f32x4v acc[NC2][2];
-#pragma unroll
-        for (int c2i = 0; c2i < NC2; ++c2i) { acc[c2i][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[c2i][1] = acc[c2i][0]; }
-#define UPS_THIN_TAP(TP, WB)                                                                                                     \
-        do {                                                                                                                     \
-            constexpr int dyi_ = (TP) / 3, dx_ = (TP) % 3;                                                                       \
-            const unsigned char* rowp_ = ring + ((it + dyi_) % NR) * RB + wid * PLW;                                             \
+    // (round 6, late) the fragments of a plane row are read from LDS ONCE, when the row enters as row it + 2, and stay in registers for the
+    // three output rows that use it (slot = row % 3: the loop is unrolled by three so that the slots are static): 6 fragment reads per
+    // output row instead of 18 -- the ring's LDS reads were 147 KB per output row and CU
+    frag_t fr[3][3][NC2];
+#define UPS_THIN_LOAD_ROW(ROWI, SL)                                                                                              \
+    do {                                                                                                                         \
+        const unsigned char* rowp_ = ring + ((ROWI) % NR) * RB + wid * PLW;                                                      \
+        _Pragma("unroll") for (int dx_ = 0; dx_ < 3; ++dx_)                                                                      \
             _Pragma("unroll") for (int c2i = 0; c2i < NC2; ++c2i) {                                                              \
                 const int P_ = 16 * c2i + p16 + dx_;                                                                             \
-                const frag_t a_ = *(const frag_t*)(rowp_ + P_ * 64 + ((q16 ^ r_swz(P_)) << 4));                                  \
-                if constexpr (__is_same(T, bf16)) acc[c2i][(TP) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB, a_, acc[c2i][(TP) & 1], 0, 0, 0); \
-                else acc[c2i][(TP) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WB, a_, acc[c2i][(TP) & 1], 0, 0, 0);         \
+                fr[SL][dx_][c2i] = *(const frag_t*)(rowp_ + P_ * 64 + ((q16 ^ r_swz(P_)) << 4));                                 \
             }                                                                                                                    \
-        } while (0)
-        UPS_THIN_TAP(0, wb0); UPS_THIN_TAP(1, wb1); UPS_THIN_TAP(2, wb2); UPS_THIN_TAP(3, wb3); UPS_THIN_TAP(4, wb4);
-        UPS_THIN_TAP(5, wb5); UPS_THIN_TAP(6, wb6); UPS_THIN_TAP(7, wb7); UPS_THIN_TAP(8, wb8);
-#undef UPS_THIN_TAP
-        float* mine = red + ((it & 1) * 8 + wid) * RED;
-#pragma unroll
-        for (int c2i = 0; c2i < NC2; ++c2i) *(f32x4v*)(mine + (16 * c2i + p16) * 20 + 4 * q16) = acc[c2i][0] + acc[c2i][1];
-        // (a raw barrier: __syncthreads() carries a fence that drains vmcnt -- every row request in flight -- each iteration)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // thread (px_t, co_t): the eight partials of this output row, in wave order
-        const float* all = red + (it & 1) * 8 * RED + px_t * 20 + co_t;
-        float v = all[0];
-#pragma unroll
-        for (int w8 = 1; w8 < 8; ++w8) v += all[w8 * RED];
-        const int y = y0 + it;
-        v = c_ok ? v + bias_t : 0.f;          // (channels co .. co_fill - 1 of a 16-bit output are stored as zeros)
-        if (has_ct && c_ok) {
-            const bool first = y == 0, last = y + 1 >= h_;
-            const float t0 = first ? ct0a : (last ? ct0c : ct0b);
-            const float t1 = first ? ct1a : (last ? ct1c : ct1b);
-            const float t2 = first ? ct2a : (last ? ct2c : ct2b);
-            v += t0 + (float)xg * t1 + (float)y * t2;
-        }
-        // (one store instruction per wave and iteration whatever the masks: the count of the wait above is static)
-        const long long o = ((long long)y * wd_ + xg) * ldo_ + co_t;
-        const bool on = t_on && co_t < cofill_;
-        if (of32_) { if (on) ((float*)out_img)[o] = v; }
-        else { if (on) st_from_float<T>((T*)out_img + o, v); }
+    } while (0)
+#define UPS_THIN_MMA(WB, SL, DX)                                                                                                 \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int c2i = 0; c2i < NC2; ++c2i) {                                                                  \
+            if constexpr (__is_same(T, bf16)) acc[c2i][tpar] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB, fr[SL][DX][c2i], acc[c2i][tpar], 0, 0, 0); \
+            else acc[c2i][tpar] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WB, fr[SL][DX][c2i], acc[c2i][tpar], 0, 0, 0);         \
+        }                                                                                                                        \
+        tpar ^= 1;                                                                                                               \
+    } while (0)
+#define UPS_THIN_BODY(IT, S0, S1, S2)                                                                                            \
+    do {                                                                                                                         \
+        const int it = (IT);                                                                                                     \
+        /* rows it .. it + 2 of this wave's plane must have landed (row it + 2 was requested by iteration it - L); younger: the NPC */ \
+        /* requests of each of the L - 1 rows behind it and the stores issued since (every iteration ends with one: counted once) */ \
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * NPC) : "memory");                                       \
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((L - 1) * NPC + 1) : "memory");                                           \
+        UPS_THIN_ISSUE_ROW(it + L + 2);      /* into the slot of row it - 1 (in registers since iteration it - 3) */             \
+        if (it == 0) { UPS_THIN_LOAD_ROW(0, S0); UPS_THIN_LOAD_ROW(1, S1); }                                                     \
+        UPS_THIN_LOAD_ROW(it + 2, S2);                                                                                           \
+        f32x4v acc[NC2][2];                                                                                                      \
+        _Pragma("unroll") for (int c2i = 0; c2i < NC2; ++c2i) { acc[c2i][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[c2i][1] = acc[c2i][0]; } \
+        int tpar = 0;                                                                                                            \
+        UPS_THIN_MMA(wb0, S0, 0); UPS_THIN_MMA(wb1, S0, 1); UPS_THIN_MMA(wb2, S0, 2);                                            \
+        UPS_THIN_MMA(wb3, S1, 0); UPS_THIN_MMA(wb4, S1, 1); UPS_THIN_MMA(wb5, S1, 2);                                            \
+        UPS_THIN_MMA(wb6, S2, 0); UPS_THIN_MMA(wb7, S2, 1); UPS_THIN_MMA(wb8, S2, 2);                                            \
+        float* mine = red + ((it & 1) * 8 + wid) * RED;                                                                          \
+        _Pragma("unroll") for (int c2i = 0; c2i < NC2; ++c2i) *(f32x4v*)(mine + (16 * c2i + p16) * 20 + 4 * q16) = acc[c2i][0] + acc[c2i][1]; \
+        /* (a raw barrier: __syncthreads() carries a fence that drains vmcnt -- every row request in flight -- each iteration) */ \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
+        __builtin_amdgcn_s_barrier();                                                                                            \
+        /* thread (px_t, co_t): the eight partials of this output row, in wave order */                                          \
+        const float* all = red + (it & 1) * 8 * RED + px_t * 20 + co_t;                                                          \
+        float v = all[0];                                                                                                        \
+        _Pragma("unroll") for (int w8 = 1; w8 < 8; ++w8) v += all[w8 * RED];                                                     \
+        const int y = y0 + it;                                                                                                   \
+        v = c_ok ? v + bias_t : 0.f;          /* (channels co .. co_fill - 1 of a 16-bit output are stored as zeros) */          \
+        if (has_ct && c_ok) {                                                                                                    \
+            const bool first = y == 0, last = y + 1 >= h_;                                                                       \
+            const float t0 = first ? ct0a : (last ? ct0c : ct0b);                                                                \
+            const float t1 = first ? ct1a : (last ? ct1c : ct1b);                                                                \
+            const float t2 = first ? ct2a : (last ? ct2c : ct2b);                                                                \
+            v += t0 + (float)xg * t1 + (float)y * t2;                                                                            \
+        }                                                                                                                        \
+        /* (one store instruction per wave and iteration whatever the masks: the count of the wait above is static) */           \
+        const long long o = ((long long)y * wd_ + xg) * ldo_ + co_t;                                                             \
+        const bool on = t_on && co_t < cofill_;                                                                                  \
+        if (of32_) { if (on) ((float*)out_img)[o] = v; }                                                                         \
+        else { if (on) st_from_float<T>((T*)out_img + o, v); }                                                                   \
+    } while (0)
+    for (int it3 = 0; it3 < iters; it3 += 3) {
+        UPS_THIN_BODY(it3, 0, 1, 2);
+        if (it3 + 1 < iters) UPS_THIN_BODY(it3 + 1, 1, 2, 0);
+        if (it3 + 2 < iters) UPS_THIN_BODY(it3 + 2, 2, 0, 1);
     }
+#undef UPS_THIN_BODY
+#undef UPS_THIN_MMA
+#undef UPS_THIN_LOAD_ROW
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 #undef UPS_THIN_ISSUE_ROW
