@@ -233,7 +233,9 @@ __global__ void batch_sum_kernel(const T* __restrict__ d, int n, long long pix, 
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] = 0.f;
         const T* base = d + px * ldo + k * E;
-#pragma unroll 4
+        // (sixteen images' pieces in flight per thread, was four: on the small maps -- two to sixteen blocks -- the launch is a chain of
+        // n / 16 round trips and nothing else; the order of the additions is unchanged)
+#pragma unroll 16
         for (int b = 0; b < n; ++b) {
             float f[E];
             const uint4 u = *(const uint4*)(base + (long long)b * pix * ldo);
